@@ -1,0 +1,95 @@
+"""ctypes binding of libeasyhybrid_hip.so (include/easyhybrid_hip.h).
+
+This is the same calling convention Julia's `@ccall` uses; the Julia stub in
+`julia/EasyHybridHIP/src/EasyHybridHIP.jl` binds the identical symbols.  There is no fallback: if the
+shared library is missing or a symbol cannot be resolved, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG = 4, 8, 4, 4
+EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE = 0, -1, -2, -3, -4, -5
+EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
+EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V = 0, 1, 2, 3
+
+ACTIVATIONS = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
+OPT_RULES = {"Adam": 0, "AdamW": 1, "RMSProp": 2, "Descent": 3}
+PAR_NEURAL, PAR_GLOBAL, PAR_FIXED = 0, 1, 2
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("n_predictors", C.c_int32), ("n_hidden", C.c_int32),
+        ("hidden", C.c_int32 * EH_MAX_HIDDEN), ("activation", C.c_int32), ("scale_nn_outputs", C.c_int32),
+        ("mech", C.c_int32), ("n_params", C.c_int32),
+        ("param_kind", C.c_int32 * EH_MAX_PARAMS), ("param_index", C.c_int32 * EH_MAX_PARAMS),
+        ("param_default", C.c_float * EH_MAX_PARAMS), ("param_lower", C.c_float * EH_MAX_PARAMS),
+        ("param_upper", C.c_float * EH_MAX_PARAMS),
+        ("n_forcings", C.c_int32), ("forcing_index", C.c_int32 * EH_MAX_FORC),
+        ("n_targets", C.c_int32), ("target_output", C.c_int32 * EH_MAX_TARG),
+    ]
+
+
+class TargetMetrics(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("n", "mse", "rmse", "mae", "r2", "nse", "pearson", "kge", "pbkge", "beta", "alpha", "sse")]
+
+
+LIB_NAME = "libeasyhybrid_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+_F = C.POINTER(C.c_float)
+_FP = C.POINTER(_F)
+_H = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/easyhybrid_hip.h declares
+SIGNATURES = {
+    "eh_version": (C.c_int32, []),
+    "eh_last_error": (C.c_char_p, [_H]),
+    "eh_create": (C.c_int32, [C.POINTER(ModelDesc), C.POINTER(_H)]),
+    "eh_destroy": (C.c_int32, [_H]),
+    "eh_n_theta": (C.c_int32, [_H, C.POINTER(C.c_int64)]),
+    "eh_set_stream": (C.c_int32, [_H, C.c_void_p]),
+    "eh_synchronize": (C.c_int32, [_H]),
+    "eh_set_data": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]),
+    "eh_set_params": (C.c_int32, [_H, _F, C.c_int64]),
+    "eh_get_params": (C.c_int32, [_H, _F, C.c_int64]),
+    "eh_forward": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, _FP, _FP]),
+    "eh_loss_and_grad": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64, _F, _F, C.POINTER(C.c_int64)]),
+    "eh_opt_init": (C.c_int32, [_H, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "eh_get_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
+    "eh_set_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
+    "eh_train_step": (C.c_int32, [_H, C.c_int64, C.c_int64, _F]),
+    "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
+    "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
+    "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),
+    "eh_dp_apply": (C.c_int32, [_H, _F]),
+    "eh_device_buffer": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "eh_profile_enable": (C.c_int32, [_H, C.c_int32]),
+    "eh_profile_read": (C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "eh_set_option": (C.c_int32, [_H, C.c_char_p, C.c_int64]),
+}
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP engine is not built.  Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C easyhybrid.jl_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib

@@ -1,0 +1,858 @@
+// C ABI of libeasyhybrid_hip.so (declared in include/easyhybrid_hip.h) and the small kernels around
+// the fused step kernel: partial-slab reduction + optimiser update, valid counts, epoch
+// permutation, record packing.  Everything here runs on one HIP stream per handle; there is no CPU
+// compute path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "eh_arch.hpp"
+
+// --------------------------------------------------------------------------------------------
+// small kernels
+// --------------------------------------------------------------------------------------------
+struct EhOpt {
+    int rule;
+    float lr, b1, b2, eps, wd;
+};
+
+// Optimisers.jl rules, fp32 op for op.  sc = {beta1^t, beta2^t} running products (Optimisers keeps
+// them in Float32: 1 - Float32(0.999) != 1e-3, which matters at 1e-5 in the first steps).
+__device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1, float bt2, float& th, float& m, float& v) {
+    if (o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW) {
+        m = o.b1 * m + (1.0f - o.b1) * g;
+        v = o.b2 * v + (1.0f - o.b2) * (g * g);
+        float upd = m / (1.0f - bt1) / (sqrtf(v / (1.0f - bt2)) + o.eps) * o.lr;
+        if (o.rule == EH_OPT_ADAMW) upd += o.lr * o.wd * th;     // AdamW(couple = true)
+        th -= upd;
+    } else if (o.rule == EH_OPT_RMSPROP) {                       // RMSProp(eta, rho = b1, eps)
+        v = o.b1 * v + (1.0f - o.b1) * (g * g);
+        th -= g * (o.lr / (sqrtf(v) + o.eps));
+    } else {                                                     // Descent(eta)
+        th -= o.lr * g;
+    }
+}
+
+// Sum the per-workgroup partials of the step kernel (fixed order: deterministic), normalise by the
+// valid count when the step ran with deferred normalisation, and (APPLY) update theta in place.
+// Block = 32 columns x 8 row groups.  gradbuf = [grad | loss | counts].
+template <bool APPLY>
+__global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
+                                                        float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
+                                                        float* sc_out, EhOpt o, float* loss_slot) {
+    __shared__ float part[8][33];
+    __shared__ float red[256];
+    __shared__ float cnts[EH_MAX_TARG];
+    const int tid = threadIdx.x, p = tid & 31, q = tid >> 5;
+    const int idx = blockIdx.x * 32 + p;
+    float s = 0.0f;
+    if (idx < n_acc)
+        for (int r = q; r < nblk; r += 8) s += slab[(size_t)r * n_acc + idx];
+    part[q][p] = s;
+    for (int t = 0; t < T; ++t) {
+        float cs = 0.0f;
+        for (int r = tid; r < nblk; r += 256) cs += slab[(size_t)r * n_acc + n_theta + 1 + t];
+        red[tid] = cs;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) cnts[t] = red[0];
+        __syncthreads();
+    }
+    __syncthreads();
+    float ntot = 0.0f;
+    for (int t = 0; t < T; ++t) ntot += cnts[t];
+    if (q == 0 && idx < n_acc) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += part[k][p];
+        const float scale = deferred ? (cnts[0] > 0.0f ? 1.0f / cnts[0] : 0.0f) : 1.0f;
+        if (idx < n_theta) {
+            const float g = tot * scale;
+            gradbuf[idx] = g;
+            if (APPLY && ntot > 0.0f) {
+                float th = theta[idx], mm = m[idx], vv = v[idx];
+                eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
+                theta[idx] = th; m[idx] = mm; v[idx] = vv;
+            }
+        } else if (idx == n_theta) {
+            const float loss = ntot > 0.0f ? tot * scale : __builtin_nanf("");
+            gradbuf[idx] = loss;
+            if (loss_slot) *loss_slot = loss;
+        } else {
+            gradbuf[idx] = tot;
+        }
+    }
+    if (APPLY && blockIdx.x == 0 && tid == 0) {
+        sc_out[0] = ntot > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
+        sc_out[1] = ntot > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
+    }
+}
+
+// data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
+__global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
+                                                       float* sc_out, EhOpt o, float* loss_slot) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const float cnt = gradbuf[n_theta + 1];
+    if (idx < n_theta && cnt > 0.0f) {
+        const float g = gradbuf[idx] / cnt;
+        float th = theta[idx], mm = m[idx], vv = v[idx];
+        eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
+        theta[idx] = th; m[idx] = mm; v[idx] = vv;
+    }
+    if (idx == 0) {
+        sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
+        sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
+        if (loss_slot) *loss_slot = cnt > 0.0f ? gradbuf[n_theta] / cnt : __builtin_nanf("");
+    }
+}
+
+// per-target 1/n_valid of one batch (only needed when T > 1: the normaliser differs per target)
+__global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
+                                                       float* inv_n) {
+    __shared__ float red[256];
+    const int t = blockIdx.x;
+    float c = 0.0f;
+    for (long long i = threadIdx.x; i < count; i += 256) {
+        const long long n = idx ? (long long)idx[first + i] : first + i;
+        c += __builtin_isnan(recs[n * C + toff + t]) ? 0.0f : 1.0f;
+    }
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) inv_n[t] = red[0] > 0.0f ? 1.0f / red[0] : 0.0f;
+}
+
+// keyed bijection of [0, n): 4-round Feistel network on 2*hb bits, cycle-walked into range.
+__host__ __device__ inline uint32_t eh_mix32(uint32_t x, uint32_t k) {
+    x ^= k; x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t eh_perm32(uint32_t i, uint32_t n, int hb, uint64_t seed) {
+    const uint32_t mask = (1u << hb) - 1u;
+    uint32_t x = i;
+    do {
+        uint32_t L = x >> hb, R = x & mask;
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t k = (uint32_t)(seed >> (16 * (r & 1))) + 0x632BE5ABu * (uint32_t)(r + 1) + (uint32_t)(seed >> 32);
+            const uint32_t t = L ^ (eh_mix32(R, k) & mask);
+            L = R; R = t;
+        }
+        x = (L << hb) | R;
+    } while (x >= n);
+    return x;
+}
+__global__ void eh_perm_kernel(int* idx, uint32_t n, int hb, uint64_t seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (int)eh_perm32(i, n, hb, seed);
+}
+
+// (P x N col-major predictors, F forcing arrays, T target arrays) -> N records of C floats
+struct EhPackArgs {
+    const float* x;
+    const float* forc[EH_MAX_FORC];
+    const float* targ[EH_MAX_TARG];
+};
+__global__ void eh_pack_kernel(EhPackArgs a, float* recs, long long n, int P, int F, int T) {
+    const int C = P + F + T;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * C) return;
+    const long long s = e / C;
+    const int j = (int)(e % C);
+    float v;
+    if (j < P) v = a.x[s * P + j];
+    else if (j < P + F) v = a.forc[j - P][s];
+    else v = a.targ[j - P - F][s];
+    recs[e] = v;
+}
+
+// --------------------------------------------------------------------------------------------
+// handle
+// --------------------------------------------------------------------------------------------
+struct EhSplit {
+    float* recs = nullptr;
+    long long n = 0;
+    float shift[EH_MAX_TARG] = {0, 0, 0, 0};
+};
+
+struct eh_handle_s {
+    eh_model_desc desc;
+    EhNet net;
+    const EhArchInfo* arch = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    int C = 0, n_acc = 0, n_par = 0;
+    float *theta = nullptr, *m = nullptr, *v = nullptr, *sc = nullptr;   // sc: [2][2] running beta products, ping-pong
+    int sc_sel = 0;
+    bool opt_ready = false;
+    EhOpt opt{};
+    EhSplit split[2];
+    float *slab = nullptr, *gradbuf = nullptr, *inv_n = nullptr, *loss_hist = nullptr;
+    long long loss_cap = 0;
+    int* perm = nullptr;
+    long long perm_cap = 0;
+    bool perm_valid = false;
+    int max_blocks = 256;
+    // scratch for forward / eval outputs
+    float* out_buf = nullptr;
+    long long out_cap = 0;
+    int* idx_buf = nullptr;
+    long long idx_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev;   // 3 per step: before step kernel, between, after reduce
+    size_t ev_used = 0;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static int fail(eh_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(h, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(h, e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct MechInfo { int n_par, n_forc, n_out; };
+static bool mech_info(int mech, MechInfo* mi) {
+    switch (mech) {
+        case EH_MECH_RBQ10: *mi = {2, 1, 1}; return true;
+        case EH_MECH_EXPO: *mi = {2, 1, 1}; return true;
+        case EH_MECH_LINEAR: *mi = {2, 1, 1}; return true;
+        case EH_MECH_EXPO2POOL: *mi = {4, 1, 1}; return true;
+        case EH_MECH_RS_COMPONENTS: *mi = {6, 1, 1}; return true;
+        default: return false;
+    }
+}
+
+static const EhArchInfo* find_arch(int nbi, int nbh, int nl) {
+#define EH_ARCH_TRY(a, b, c) if (nbi == a && nbh == b && nl == c) return eh_arch_##a##_##b##_##c();
+    EH_ARCH_LIST(EH_ARCH_TRY)
+#undef EH_ARCH_TRY
+    return nullptr;
+}
+
+extern "C" {
+
+int32_t eh_version(void) { return EH_ABI_VERSION; }
+
+const char* eh_last_error(const eh_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
+    if (!d || !out) return fail(nullptr, EH_EINVAL, "eh_create: null argument");
+    *out = nullptr;
+    if (d->struct_size != (int32_t)sizeof(eh_model_desc)) return fail(nullptr, EH_EINVAL, "eh_create: struct_size %d != %zu", d->struct_size, sizeof(eh_model_desc));
+    MechInfo mi;
+    if (!mech_info(d->mech, &mi)) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown mechanistic model id %d (no silent fallback)", d->mech);
+    if (d->activation < 0 || d->activation > EH_ACT_IDENTITY) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d", d->activation);
+    if (d->n_params != mi.n_par) return fail(nullptr, EH_EINVAL, "eh_create: model %d takes %d parameters, descriptor has %d", d->mech, mi.n_par, d->n_params);
+    if (d->n_predictors < 1) return fail(nullptr, EH_EINVAL, "eh_create: n_predictors must be >= 1");
+    if (d->n_hidden < 1 || d->n_hidden > EH_MAX_HIDDEN) return fail(nullptr, EH_EINVAL, "eh_create: n_hidden must be 1..%d", EH_MAX_HIDDEN);
+    if (d->n_forcings < mi.n_forc || d->n_forcings > EH_MAX_FORC) return fail(nullptr, EH_EINVAL, "eh_create: n_forcings %d (model needs %d, max %d)", d->n_forcings, mi.n_forc, EH_MAX_FORC);
+    if (d->n_targets < 1 || d->n_targets > EH_MAX_TARG) return fail(nullptr, EH_EINVAL, "eh_create: n_targets must be 1..%d", EH_MAX_TARG);
+    int K = 0, G = 0, maxw = 0;
+    bool seenK[EH_MAX_PARAMS] = {}, seenG[EH_MAX_PARAMS] = {};
+    for (int j = 0; j < d->n_params; ++j) {
+        const int k = d->param_kind[j], ix = d->param_index[j];
+        if (k == EH_PAR_NEURAL || k == EH_PAR_GLOBAL) {
+            if (ix < 0 || ix >= EH_MAX_PARAMS) return fail(nullptr, EH_EINVAL, "eh_create: param_index[%d] = %d out of range", j, ix);
+            bool* seen = k == EH_PAR_NEURAL ? seenK : seenG;
+            if (seen[ix]) return fail(nullptr, EH_EINVAL, "eh_create: duplicate param_index %d", ix);
+            seen[ix] = true;
+            (k == EH_PAR_NEURAL ? K : G)++;
+            if (!(d->param_upper[j] > d->param_lower[j]) && (k == EH_PAR_GLOBAL || d->scale_nn_outputs))
+                return fail(nullptr, EH_EINVAL, "eh_create: parameter %d needs upper > lower for sigmoid scaling", j);
+        } else if (k != EH_PAR_FIXED) {
+            return fail(nullptr, EH_EINVAL, "eh_create: param_kind[%d] = %d", j, k);
+        }
+    }
+    for (int i = 0; i < K; ++i) if (!seenK[i]) return fail(nullptr, EH_EINVAL, "eh_create: neural param_index values must be 0..K-1");
+    for (int i = 0; i < G; ++i) if (!seenG[i]) return fail(nullptr, EH_EINVAL, "eh_create: global param_index values must be 0..G-1");
+    if (K < 1) return fail(nullptr, EH_EINVAL, "eh_create: at least one neural parameter is required");
+    for (int l = 0; l < d->n_hidden; ++l) {
+        if (d->hidden[l] < 1) return fail(nullptr, EH_EINVAL, "eh_create: hidden[%d] = %d", l, d->hidden[l]);
+        maxw = std::max(maxw, d->hidden[l]);
+    }
+    for (int f = 0; f < mi.n_forc; ++f)
+        if (d->forcing_index[f] < 0 || d->forcing_index[f] >= d->n_forcings) return fail(nullptr, EH_EINVAL, "eh_create: forcing_index[%d] out of range", f);
+    for (int t = 0; t < d->n_targets; ++t)
+        if (d->target_output[t] < 0 || d->target_output[t] >= mi.n_out) return fail(nullptr, EH_EINVAL, "eh_create: target_output[%d] = %d (model has %d outputs)", t, d->target_output[t], mi.n_out);
+    const int nbi = (d->n_predictors + 15) / 16, nbh_raw = (maxw + 15) / 16;
+    const int nbh = nbh_raw <= 1 ? 1 : nbh_raw <= 2 ? 2 : nbh_raw <= 4 ? 4 : 0;
+    const EhArchInfo* arch = (nbh && K <= 16) ? find_arch(nbi, nbh, d->n_hidden) : nullptr;
+    if (!arch)
+        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no compiled kernel for P=%d, hidden max width %d, %d hidden layers, K=%d (built: P<=32, width<=64, <=3 layers, K<=16)",
+                    d->n_predictors, maxw, d->n_hidden, K);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, EH_EHIP, "eh_create: no HIP device (this library has no CPU path)");
+    if (d->device < 0 || d->device >= ndev) return fail(nullptr, EH_EINVAL, "eh_create: device %d of %d", d->device, ndev);
+
+    eh_handle* h = new eh_handle_s();
+    h->desc = *d;
+    h->device = d->device;
+    h->arch = arch;
+    EhNet& n = h->net;
+    memset(&n, 0, sizeof n);
+    n.P = d->n_predictors; n.K = K; n.NL = d->n_hidden; n.G = G;
+    int off = 0, in = n.P;
+    for (int l = 0; l <= n.NL; ++l) {
+        const int o = l < n.NL ? d->hidden[l] : K;
+        if (l < n.NL) n.width[l] = o;
+        n.w_off[l] = off; off += o * in;
+        n.b_off[l] = off; off += o;
+        in = o;
+    }
+    n.g_off = off;
+    n.n_theta = off + G;
+    n.act = d->activation; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
+    n.mech = d->mech; n.n_par = d->n_params;
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) {
+        n.par_kind[j] = j < d->n_params ? d->param_kind[j] : EH_PAR_FIXED;
+        n.par_idx[j] = j < d->n_params ? d->param_index[j] : 0;
+        n.par_lo[j] = d->param_lower[j]; n.par_hi[j] = d->param_upper[j]; n.par_def[j] = d->param_default[j];
+    }
+    n.F = d->n_forcings;
+    for (int f = 0; f < EH_MAX_FORC; ++f) n.forc_col[f] = f < mi.n_forc ? d->forcing_index[f] : -1;
+    n.T = d->n_targets;
+    for (int t = 0; t < EH_MAX_TARG; ++t) n.targ_out[t] = t < d->n_targets ? d->target_output[t] : 0;
+    h->C = n.P + n.F + n.T;
+    h->n_par = d->n_params;
+    h->n_acc = n.n_theta + 1 + n.T;
+    if (h->n_acc > arch->red_floats || EH_EVAL_STATS * n.T > arch->red_floats) {
+        delete h;
+        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: %d accumulators exceed the kernel's reduction space %d", n.n_theta + 1 + n.T, arch->red_floats);
+    }
+#define HIPCHK_C(expr)                                                            \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            fail(nullptr, e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "eh_create: %s: %s", #expr, hipGetErrorString(e_)); \
+            eh_destroy(h);                                                        \
+            return e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP;               \
+        }                                                                         \
+    } while (0)
+    HIPCHK_C(hipSetDevice(h->device));
+    HIPCHK_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIPCHK_C(arch->prepare());
+    const size_t nt = (size_t)n.n_theta;
+    HIPCHK_C(hipMalloc(&h->theta, nt * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->m, nt * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->v, nt * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->sc, 4 * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->slab, (size_t)h->max_blocks * std::max(h->n_acc, EH_EVAL_STATS * n.T) * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->inv_n, EH_MAX_TARG * sizeof(float)));
+    HIPCHK_C(hipMemset(h->theta, 0, nt * sizeof(float)));
+    HIPCHK_C(hipMemset(h->m, 0, nt * sizeof(float)));
+    HIPCHK_C(hipMemset(h->v, 0, nt * sizeof(float)));
+    HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
+#undef HIPCHK_C
+    *out = h;
+    return EH_OK;
+}
+
+int32_t eh_destroy(eh_handle* h) {
+    if (!h) return EH_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    (void)hipFree(h->theta); (void)hipFree(h->m); (void)hipFree(h->v); (void)hipFree(h->sc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return EH_OK;
+}
+
+int32_t eh_n_theta(const eh_handle* h, int64_t* n) {
+    if (!h || !n) return EH_EINVAL;
+    *n = h->net.n_theta;
+    return EH_OK;
+}
+
+int32_t eh_set_stream(eh_handle* h, void* s) {
+    if (!h) return EH_EINVAL;
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return EH_OK;
+}
+
+int32_t eh_synchronize(eh_handle* h) {
+    if (!h) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EH_OK;
+}
+
+int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return EH_EINVAL;
+    if (!strcmp(name, "max_blocks")) {
+        if (value < 1 || value > 256) return fail(h, EH_EINVAL, "max_blocks must be 1..256 (one workgroup per CU)");
+        h->max_blocks = (int)value;
+        return EH_OK;
+    }
+    return fail(h, EH_EINVAL, "unknown option %s", name);
+}
+
+int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, const float* const* forcings, const float* const* targets,
+                    int32_t on_device) {
+    if (!h) return EH_EINVAL;
+    if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_set_data: split %d", split);
+    if (n < 0 || n > 0x7fffffffLL) return fail(h, EH_EINVAL, "eh_set_data: n = %lld", (long long)n);
+    if (n > 0 && (!x || !forcings || !targets)) return fail(h, EH_EINVAL, "eh_set_data: null array");
+    const EhNet& net = h->net;
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[split];
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(sp.recs);
+    sp.recs = nullptr; sp.n = 0;
+    if (split == EH_SPLIT_TRAIN) h->perm_valid = false;
+    if (n == 0) return EH_OK;
+    const int C = h->C;
+    HIPCHK(h, hipMalloc(&sp.recs, (size_t)n * C * sizeof(float)));
+    if (on_device) {
+        EhPackArgs pa{};
+        pa.x = x;
+        for (int f = 0; f < net.F; ++f) pa.forc[f] = forcings[f];
+        for (int t = 0; t < net.T; ++t) pa.targ[t] = targets[t];
+        const long long tot = (long long)n * C;
+        hipLaunchKernelGGL(eh_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, pa, sp.recs, (long long)n, net.P, net.F, net.T);
+        HIPCHK(h, hipGetLastError());
+        // metric shift: mean of the first valid targets, computed from a small host copy
+        std::vector<float> tmp((size_t)std::min<int64_t>(n, 4096));
+        for (int t = 0; t < net.T; ++t) {
+            HIPCHK(h, hipMemcpy(tmp.data(), targets[t], tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+            double s = 0; long long c = 0;
+            for (float vv : tmp) if (!std::isnan(vv)) { s += vv; ++c; }
+            sp.shift[t] = c ? (float)(s / c) : 0.0f;
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        std::vector<float> host((size_t)n * C);
+        for (int64_t s = 0; s < n; ++s) {
+            float* r = &host[(size_t)s * C];
+            for (int j = 0; j < net.P; ++j) r[j] = x[(size_t)s * net.P + j];
+            for (int f = 0; f < net.F; ++f) r[net.P + f] = forcings[f][s];
+            for (int t = 0; t < net.T; ++t) r[net.P + net.F + t] = targets[t][s];
+        }
+        for (int t = 0; t < net.T; ++t) {
+            double sum = 0; long long c = 0;
+            for (int64_t s = 0; s < std::min<int64_t>(n, 4096); ++s) if (!std::isnan(targets[t][s])) { sum += targets[t][s]; ++c; }
+            sp.shift[t] = c ? (float)(sum / c) : 0.0f;
+        }
+        HIPCHK(h, hipMemcpy(sp.recs, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    sp.n = n;
+    return EH_OK;
+}
+
+int32_t eh_set_params(eh_handle* h, const float* theta, int64_t n) {
+    if (!h || !theta) return EH_EINVAL;
+    if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_set_params: n = %lld, model has %d", (long long)n, h->net.n_theta);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->theta, theta, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return EH_OK;
+}
+
+int32_t eh_get_params(eh_handle* h, float* theta, int64_t n) {
+    if (!h || !theta) return EH_EINVAL;
+    if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_get_params: n = %lld, model has %d", (long long)n, h->net.n_theta);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(theta, h->theta, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return EH_OK;
+}
+
+}   // extern "C"
+
+// ---- internal launch helpers ---------------------------------------------------------------------
+static int grid_for(const eh_handle* h, long long count) {
+    const long long mt = 16LL * h->arch->nt;
+    const long long ntiles = (count + mt - 1) / mt;
+    return (int)std::max<long long>(1, std::min<long long>((ntiles + 3) / 4, h->max_blocks));
+}
+
+static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* grid_out) {
+    const EhNet& net = h->net;
+    if (net.T > 1) {
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
+        HIPCHK(h, hipGetLastError());
+    }
+    EhStepArgs a{};
+    a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
+    a.theta = h->theta; a.slab = h->slab; a.n_acc = h->n_acc;
+    a.inv_n = net.T > 1 ? h->inv_n : nullptr;
+    const int grid = grid_for(h, count);
+    *grid_out = grid;
+    HIPCHK(h, h->arch->launch(EH_MODE_TRAIN, grid, h->stream, &h->net, &a));
+    return EH_OK;
+}
+
+static int ensure_events(eh_handle* h, size_t need) {
+    while (h->ev.size() < need) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    return EH_OK;
+}
+
+// fused step on the train split.  apply = update theta; loss_slot = device float for the loss.
+static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool apply, bool raw, float* loss_slot) {
+    const EhNet& net = h->net;
+    const bool prof = h->prof && apply && h->ev_used + 3 <= 3 * 8192;
+    if (prof) {
+        int rc = ensure_events(h, h->ev_used + 3);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    }
+    int grid = 1;
+    int rc = launch_train_kernel(h, sp, idx, first, count, &grid);
+    if (rc) return rc;
+    if (prof) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+    const int deferred = (net.T == 1 && !raw) ? 1 : 0;
+    const int rgrid = (h->n_acc + 31) / 32;
+    float* sc_in = h->sc + 2 * h->sc_sel;
+    float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
+    if (apply) {
+        hipLaunchKernelGGL(eh_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
+                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot);
+        h->sc_sel ^= 1;
+    } else {
+        hipLaunchKernelGGL(eh_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
+                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (prof) {
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
+        h->ev_used += 3;
+    }
+    return EH_OK;
+}
+
+static int ensure_loss_hist(eh_handle* h, long long need) {
+    if (h->loss_cap >= need) return EH_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->loss_hist);
+    h->loss_hist = nullptr; h->loss_cap = 0;
+    HIPCHK(h, hipMalloc(&h->loss_hist, (size_t)need * sizeof(float)));
+    h->loss_cap = need;
+    return EH_OK;
+}
+
+static int check_window(eh_handle* h, const EhSplit& sp, long long first, long long count, const char* who) {
+    if (!sp.recs || sp.n == 0) return fail(h, EH_ESTATE, "%s: no data set for this split (call eh_set_data)", who);
+    if (first < 0 || count < 0 || first + count > sp.n) return fail(h, EH_EINVAL, "%s: window [%lld, %lld) outside 0..%lld", who, first, first + count, sp.n);
+    return EH_OK;
+}
+
+// forward / eval on a window; stats (host, double) per target may be null
+static int do_eval(eh_handle* h, int split, long long first, long long count, double* stats, float* const* yhat, float* const* params) {
+    const EhNet& net = h->net;
+    EhSplit& sp = h->split[split];
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = check_window(h, sp, first, count, "eh_eval");
+    if (rc) return rc;
+    const long long need = (long long)(yhat ? net.T : 0) * count + (long long)(params ? h->n_par : 0) * count;
+    if (need > h->out_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->out_buf);
+        h->out_buf = nullptr; h->out_cap = 0;
+        HIPCHK(h, hipMalloc(&h->out_buf, (size_t)need * sizeof(float)));
+        h->out_cap = need;
+    }
+    EhStepArgs a{};
+    a.recs = sp.recs; a.C = h->C; a.idx = nullptr; a.first = first; a.count = count;
+    a.theta = h->theta; a.slab = h->slab; a.n_acc = EH_EVAL_STATS * net.T;
+    a.yhat = yhat ? h->out_buf : nullptr;
+    a.pout = params ? h->out_buf + (yhat ? (long long)net.T * count : 0) : nullptr;
+    a.yld = count;
+    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
+    const int grid = count > 0 ? grid_for(h, count) : 1;
+    HIPCHK(h, h->arch->launch(EH_MODE_EVAL, grid, h->stream, &h->net, &a));
+    std::vector<float> part((size_t)grid * a.n_acc);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (stats) {
+        for (int k = 0; k < a.n_acc; ++k) {
+            double s = 0;
+            for (int b = 0; b < grid; ++b) s += part[(size_t)b * a.n_acc + k];
+            stats[k] = s;
+        }
+    }
+    if (yhat)
+        for (int t = 0; t < net.T; ++t)
+            if (yhat[t]) HIPCHK(h, hipMemcpy(yhat[t], a.yhat + (long long)t * count, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    if (params)
+        for (int j = 0; j < h->n_par; ++j)
+            if (params[j]) HIPCHK(h, hipMemcpy(params[j], a.pout + (long long)j * count, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return EH_OK;
+}
+
+extern "C" {
+
+int32_t eh_forward(eh_handle* h, int32_t split, int64_t first, int64_t count, float* const* yhat, float* const* params) {
+    if (!h) return EH_EINVAL;
+    if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_forward: split %d", split);
+    return do_eval(h, split, first, count, nullptr, yhat, params);
+}
+
+int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_target_metrics* out, float* const* yhat, float* const* params) {
+    if (!h || !out) return EH_EINVAL;
+    if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_eval: split %d", split);
+    double st[EH_MAX_TARG * EH_EVAL_STATS] = {0};
+    int rc = do_eval(h, split, first, count, st, yhat, params);
+    if (rc) return rc;
+    const double nan = std::nan("");
+    for (int t = 0; t < h->net.T; ++t) {
+        const double* s = st + t * EH_EVAL_STATS;
+        const double c = h->split[split].shift[t];
+        const double S = s[0], Sy = s[1], Syy = s[2], n = s[3], Sh = s[4], Shh = s[5], Shy = s[6], A = s[7];
+        eh_target_metrics& o = out[t];
+        o.n = n; o.sse = S;
+        if (n <= 0) { o.mse = o.rmse = o.mae = o.r2 = o.nse = o.pearson = o.kge = o.pbkge = o.beta = o.alpha = nan; continue; }
+        const double ssy = Syy - Sy * Sy / n, ssh = Shh - Sh * Sh / n, shy = Shy - Sh * Sy / n;
+        o.mse = S / n; o.rmse = std::sqrt(o.mse); o.mae = A / n;
+        o.r2 = 1.0 - S / ssy;           // loss_fn(Val(:r2)), src/losses/loss_fn.jl:71-73
+        o.nse = o.r2;                   // :nse has the same closed form (:85-86)
+        o.pearson = shy / std::sqrt(ssh * ssy);
+        o.alpha = std::sqrt(ssh / ssy); // std ratio (the n-1 cancels)
+        o.beta = (c + Sh / n) / (c + Sy / n);
+        o.kge = 1.0 - std::sqrt((o.pearson - 1) * (o.pearson - 1) + (o.alpha - 1) * (o.alpha - 1) + (o.beta - 1) * (o.beta - 1));
+        o.pbkge = 1.0 - std::sqrt((o.pearson - 1) * (o.pearson - 1) + (o.beta - 1) * (o.beta - 1));
+    }
+    return EH_OK;
+}
+
+int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_t first, int64_t count, float* loss, float* grad, int64_t* n_valid) {
+    if (!h) return EH_EINVAL;
+    if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_loss_and_grad: split %d", split);
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[split];
+    int rc;
+    const int* didx = nullptr;
+    if (idx) {
+        if (!sp.recs) return fail(h, EH_ESTATE, "eh_loss_and_grad: no data set for this split");
+        if (count < 0) return fail(h, EH_EINVAL, "eh_loss_and_grad: count < 0");
+        for (int64_t i = 0; i < count; ++i)
+            if (idx[i] < 0 || idx[i] >= sp.n) return fail(h, EH_EINVAL, "eh_loss_and_grad: idx[%lld] = %d outside 0..%lld", (long long)i, idx[i], sp.n);
+        if (count > h->idx_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->idx_buf);
+            h->idx_buf = nullptr; h->idx_cap = 0;
+            HIPCHK(h, hipMalloc(&h->idx_buf, (size_t)std::max<int64_t>(count, 1) * sizeof(int)));
+            h->idx_cap = count;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->idx_buf, idx, (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        didx = h->idx_buf;
+        first = 0;
+    } else {
+        rc = check_window(h, sp, first, count, "eh_loss_and_grad");
+        if (rc) return rc;
+    }
+    rc = do_step(h, sp, didx, first, count, false, false, nullptr);
+    if (rc) return rc;
+    std::vector<float> host((size_t)h->n_acc);
+    HIPCHK(h, hipMemcpyAsync(host.data(), h->gradbuf, host.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int nt = h->net.n_theta;
+    if (grad) memcpy(grad, host.data(), (size_t)nt * sizeof(float));
+    if (loss) *loss = host[nt];
+    if (n_valid) {
+        double c = 0;
+        for (int t = 0; t < h->net.T; ++t) c += host[nt + 1 + t];
+        *n_valid = (int64_t)std::llround(c);
+    }
+    return EH_OK;
+}
+
+int32_t eh_opt_init(eh_handle* h, int32_t rule, float lr, float beta1, float beta2, float eps, float weight_decay) {
+    if (!h) return EH_EINVAL;
+    if (rule < EH_OPT_ADAM || rule > EH_OPT_DESCENT) return fail(h, EH_EUNSUPPORTED, "eh_opt_init: unknown rule %d", rule);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->opt = EhOpt{rule, lr, beta1, beta2, eps, weight_decay};
+    const size_t nt = (size_t)h->net.n_theta;
+    HIPCHK(h, hipMemset(h->m, 0, nt * sizeof(float)));
+    HIPCHK(h, hipMemset(h->v, 0, nt * sizeof(float)));
+    const float sc[4] = {beta1, beta2, beta1, beta2};   // Optimisers.jl starts the running product at beta (t = 1)
+    HIPCHK(h, hipMemcpy(h->sc, sc, sizeof sc, hipMemcpyHostToDevice));
+    h->sc_sel = 0;
+    h->opt_ready = true;
+    return EH_OK;
+}
+
+int32_t eh_get_opt_state(eh_handle* h, float* m, float* v, int64_t n, float* beta_t) {
+    if (!h) return EH_EINVAL;
+    if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_get_opt_state: n");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (m) HIPCHK(h, hipMemcpy(m, h->m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (v) HIPCHK(h, hipMemcpy(v, h->v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (beta_t) HIPCHK(h, hipMemcpy(beta_t, h->sc + 2 * h->sc_sel, 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return EH_OK;
+}
+
+int32_t eh_set_opt_state(eh_handle* h, const float* m, const float* v, int64_t n, const float* beta_t) {
+    if (!h) return EH_EINVAL;
+    if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_set_opt_state: call eh_opt_init first");
+    if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_set_opt_state: n");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (m) HIPCHK(h, hipMemcpy(h->m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (v) HIPCHK(h, hipMemcpy(h->v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (beta_t) HIPCHK(h, hipMemcpy(h->sc + 2 * h->sc_sel, beta_t, 2 * sizeof(float), hipMemcpyHostToDevice));
+    return EH_OK;
+}
+
+int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out) {
+    if (!h) return EH_EINVAL;
+    if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_train_step: call eh_opt_init first");
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    int rc = check_window(h, sp, first, count, "eh_train_step");
+    if (rc) return rc;
+    rc = ensure_loss_hist(h, 1);
+    if (rc) return rc;
+    rc = do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, true, false, loss_out ? h->loss_hist : nullptr);
+    if (rc) return rc;
+    if (loss_out) {
+        HIPCHK(h, hipMemcpyAsync(loss_out, h->loss_hist, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return EH_OK;
+}
+
+int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t shuffle, float* mean_loss, int64_t* n_steps) {
+    if (!h) return EH_EINVAL;
+    if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_train_epoch: call eh_opt_init first");
+    if (batchsize < 1) return fail(h, EH_EINVAL, "eh_train_epoch: batchsize %lld", (long long)batchsize);
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    if (!sp.recs || sp.n == 0) return fail(h, EH_ESTATE, "eh_train_epoch: no training data");
+    const long long N = sp.n;
+    if (shuffle) {
+        if (h->perm_cap < N) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->perm);
+            h->perm = nullptr; h->perm_cap = 0;
+            HIPCHK(h, hipMalloc(&h->perm, (size_t)N * sizeof(int)));
+            h->perm_cap = N;
+        }
+        int bits = 1;
+        while ((1LL << bits) < N) ++bits;
+        const int hb = std::max(1, (bits + 1) / 2);
+        hipLaunchKernelGGL(eh_perm_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->perm, (uint32_t)N, hb, seed);
+        HIPCHK(h, hipGetLastError());
+    }
+    const long long steps = (N + batchsize - 1) / batchsize;
+    int rc = ensure_loss_hist(h, steps);
+    if (rc) return rc;
+    for (long long s = 0; s < steps; ++s) {
+        const long long first = s * batchsize, count = std::min<long long>(batchsize, N - first);
+        rc = do_step(h, sp, shuffle ? h->perm : nullptr, first, count, true, false, h->loss_hist + s);
+        if (rc) return rc;
+    }
+    if (n_steps) *n_steps = steps;
+    if (mean_loss) {
+        std::vector<float> l((size_t)steps);
+        HIPCHK(h, hipMemcpyAsync(l.data(), h->loss_hist, l.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        double sum = 0; long long c = 0;
+        for (float x : l) if (!std::isnan(x)) { sum += x; ++c; }
+        *mean_loss = c ? (float)(sum / c) : std::nanf("");
+    }
+    return EH_OK;
+}
+
+int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
+    if (!h) return EH_EINVAL;
+    if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    int rc = check_window(h, sp, first, count, "eh_dp_grad");
+    if (rc) return rc;
+    return do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
+}
+
+int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
+    if (!h) return EH_EINVAL;
+    if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_dp_apply: call eh_opt_init first");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_loss_hist(h, 1);
+    if (rc) return rc;
+    float* sc_in = h->sc + 2 * h->sc_sel;
+    float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
+    const int nt = h->net.n_theta;
+    hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, h->theta, h->m, h->v, sc_in, sc_out, h->opt,
+                       h->loss_hist);
+    HIPCHK(h, hipGetLastError());
+    h->sc_sel ^= 1;
+    if (loss_out) {
+        HIPCHK(h, hipMemcpyAsync(loss_out, h->loss_hist, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return EH_OK;
+}
+
+int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {
+    if (!h || !dev_ptr || !n_floats) return EH_EINVAL;
+    switch (which) {
+        case EH_BUF_GRAD: *dev_ptr = h->gradbuf; *n_floats = h->n_acc; return EH_OK;
+        case EH_BUF_THETA: *dev_ptr = h->theta; *n_floats = h->net.n_theta; return EH_OK;
+        case EH_BUF_OPT_M: *dev_ptr = h->m; *n_floats = h->net.n_theta; return EH_OK;
+        case EH_BUF_OPT_V: *dev_ptr = h->v; *n_floats = h->net.n_theta; return EH_OK;
+        default: return fail(h, EH_EINVAL, "eh_device_buffer: which = %d", which);
+    }
+}
+
+int32_t eh_profile_enable(eh_handle* h, int32_t on) {
+    if (!h) return EH_EINVAL;
+    h->prof = on != 0;
+    h->ev_used = 0;
+    return EH_OK;
+}
+
+int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_kernel, double* mean_ms_reduce_kernel) {
+    if (!h) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double a = 0, b = 0;
+    const size_t n = h->ev_used / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[3 * i], h->ev[3 * i + 1]));
+        a += ms;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[3 * i + 1], h->ev[3 * i + 2]));
+        b += ms;
+    }
+    if (n_launches) *n_launches = (int64_t)n;
+    if (mean_ms_step_kernel) *mean_ms_step_kernel = n ? a / n : 0.0;
+    if (mean_ms_reduce_kernel) *mean_ms_reduce_kernel = n ? b / n : 0.0;
+    h->ev_used = 0;
+    return EH_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,71 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, `torch.distributed`
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no multi-GPU code at all; samples are independent through
+the NN, the mechanistic model and the per-sample loss terms, so the path shards over samples.  The
+only exchange per step is ONE sum all-reduce of
+
+    [ grad_unnormalised (n_theta) | sum_i m_i (yhat_i - y_i)^2 | n_valid ]        (n_theta + 2 floats)
+
+after which every rank divides by the GLOBAL valid count -- the mean the reference takes over the
+whole batch (src/losses/loss_fn.jl:61-63) -- and applies the same optimiser update to its replica.
+Shards never exchange per-shard means (they would weight shards with more NaN targets wrongly).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous sample range [lo, hi) of `rank`; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_partials(buf, group=None):
+    """SUM all-reduce of the raw partial vector (torch tensor, CPU or GPU), in place."""
+    import torch.distributed as dist
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def normalise(buf, n_theta: int):
+    """[grad | sse | n] raw sums -> (grad / n, mse, n); n == 0 -> (zeros, nan, 0): batch skipped."""
+    n = float(buf[n_theta + 1])
+    if n <= 0:
+        return buf[:n_theta] * 0, float("nan"), 0.0
+    return buf[:n_theta] / n, float(buf[n_theta]) / n, n
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of a library-owned device buffer (no copy, no torch types in the ABI)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class DataParallel:
+    """Drives one replica.  `engine` already holds this rank's shard as its train split."""
+
+    def __init__(self, engine, group=None):
+        import torch
+        from . import _lib as L
+        self.engine, self.group = engine, group
+        ptr, n = engine.device_buffer(L.EH_BUF_GRAD)
+        self.buf = torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", torch.cuda.current_device()))
+        # run the engine on torch's current stream so kernels and the collective are ordered
+        engine.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step(self, first: int, count: int, want_loss: bool = False):
+        self.engine.dp_grad(first, count)
+        allreduce_partials(self.buf, self.group)
+        return self.engine.dp_apply(want_loss)
+
+    def broadcast_params(self, src: int = 0):
+        import torch
+        import torch.distributed as dist
+        from . import _lib as L
+        ptr, n = self.engine.device_buffer(L.EH_BUF_THETA)
+        t = torch.as_tensor(_DevArray(ptr, n), device=self.buf.device)
+        dist.broadcast(t, src=src, group=self.group)

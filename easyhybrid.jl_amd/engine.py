@@ -1,0 +1,208 @@
+"""Thin object wrapper over the C ABI (one `HybridEngine` = one `eh_handle` = one GPU).
+
+All numerics run in the HIP library; this class only marshals NumPy arrays and converts status
+codes into the exception types the reference raises (ArgumentError -> ValueError, unknown model
+pieces -> NotImplementedError, call-order / device problems -> RuntimeError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+_F = C.POINTER(C.c_float)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _raise(status: int, msg: str):
+    if status == L.EH_EINVAL:
+        raise ValueError(msg)
+    if status == L.EH_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if status == L.EH_ENOMEM:
+        raise MemoryError(msg)
+    raise EngineError(msg)
+
+
+def _fptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(_F) if a is not None else None
+
+
+class HybridEngine:
+    """Device-resident hybrid model: parameters, optimiser state and datasets live in HBM."""
+
+    def __init__(self, desc: L.ModelDesc, n_par: int, target_names: Sequence[str], param_names: Sequence[str]):
+        self._lib = L.lib()
+        self._h = C.c_void_p()
+        self.desc = desc
+        st = self._lib.eh_create(C.byref(desc), C.byref(self._h))
+        if st != L.EH_OK:
+            self._h = C.c_void_p()
+            _raise(st, self._lib.eh_last_error(None).decode())
+        n = C.c_int64()
+        self._chk(self._lib.eh_n_theta(self._h, C.byref(n)))
+        self.n_theta = int(n.value)
+        self.n_par = n_par
+        self.target_names = list(target_names)
+        self.param_names = list(param_names)
+        self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _chk(self, st: int):
+        if st != L.EH_OK:
+            _raise(st, self._lib.eh_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.eh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        self._chk(self._lib.eh_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self._lib.eh_synchronize(self._h))
+
+    def set_option(self, name: str, value: int):
+        self._chk(self._lib.eh_set_option(self._h, name.encode(), int(value)))
+
+    # -- data ------------------------------------------------------------------------------------
+    def set_data(self, split: int, X: np.ndarray, forcings: Sequence[np.ndarray], targets: Sequence[np.ndarray]):
+        """X: (P, N) like the reference (features x samples); forcings / targets: lists of (N,)."""
+        X = np.asarray(X, np.float32)
+        P, N = X.shape
+        if P != self.desc.n_predictors:
+            raise ValueError(f"X has {P} predictor rows, model expects {self.desc.n_predictors}")
+        if len(forcings) != self.desc.n_forcings or len(targets) != self.desc.n_targets:
+            raise ValueError("number of forcing / target arrays does not match the model")
+        xf = np.asfortranarray(X)                       # (P x N) column-major == N records of P
+        fs = [np.ascontiguousarray(f, np.float32) for f in forcings]
+        ts = [np.ascontiguousarray(t, np.float32) for t in targets]
+        for a in fs + ts:
+            if a.shape != (N,):
+                raise ValueError("forcing / target arrays must have one value per sample")
+        fp = (C.c_void_p * max(1, len(fs)))(*[a.ctypes.data for a in fs])
+        tp = (C.c_void_p * max(1, len(ts)))(*[a.ctypes.data for a in ts])
+        self._chk(self._lib.eh_set_data(self._h, split, N, C.c_void_p(xf.ctypes.data), fp, tp, 0))
+        self.n_samples[split] = N
+
+    def set_data_device(self, split: int, n: int, x_ptr: int, forcing_ptrs: Sequence[int], target_ptrs: Sequence[int]):
+        """Same as set_data with pointers that already live on the handle's device."""
+        fp = (C.c_void_p * max(1, len(forcing_ptrs)))(*forcing_ptrs)
+        tp = (C.c_void_p * max(1, len(target_ptrs)))(*target_ptrs)
+        self._chk(self._lib.eh_set_data(self._h, split, n, C.c_void_p(x_ptr), fp, tp, 1))
+        self.n_samples[split] = n
+
+    # -- parameters ------------------------------------------------------------------------------
+    def set_params(self, theta: np.ndarray):
+        theta = np.ascontiguousarray(theta, np.float32)
+        self._chk(self._lib.eh_set_params(self._h, _fptr(theta), theta.size))
+
+    def get_params(self) -> np.ndarray:
+        out = np.empty(self.n_theta, np.float32)
+        self._chk(self._lib.eh_get_params(self._h, _fptr(out), out.size))
+        return out
+
+    # -- forward / eval --------------------------------------------------------------------------
+    def _outs(self, count, want_yhat, want_params):
+        ys = [np.empty(count, np.float32) for _ in self.target_names] if want_yhat else None
+        ps = [np.empty(count, np.float32) for _ in range(self.n_par)] if want_params else None
+        yp = (_F * len(ys))(*[_fptr(a) for a in ys]) if ys else None
+        pp = (_F * len(ps))(*[_fptr(a) for a in ps]) if ps else None
+        return ys, ps, yp, pp
+
+    def forward(self, split: int, first: int = 0, count: Optional[int] = None, params: bool = True):
+        count = self.n_samples[split] - first if count is None else count
+        ys, ps, yp, pp = self._outs(count, True, params)
+        self._chk(self._lib.eh_forward(self._h, split, first, count, yp, pp))
+        out = dict(zip(self.target_names, ys))
+        if params:
+            out["parameters"] = dict(zip(self.param_names, ps))
+        return out
+
+    def eval(self, split: int, first: int = 0, count: Optional[int] = None, predictions: bool = False):
+        count = self.n_samples[split] - first if count is None else count
+        m = (L.TargetMetrics * len(self.target_names))()
+        ys, _, yp, _ = self._outs(count, predictions, False)
+        self._chk(self._lib.eh_eval(self._h, split, first, count, m, yp, None))
+        metrics = [{f: getattr(m[t], f) for f, _ in L.TargetMetrics._fields_} for t in range(len(self.target_names))]
+        return metrics, (dict(zip(self.target_names, ys)) if predictions else None)
+
+    def loss_and_grad(self, split: int = L.EH_SPLIT_TRAIN, first: int = 0, count: Optional[int] = None, idx=None):
+        loss = C.c_float()
+        nv = C.c_int64()
+        grad = np.empty(self.n_theta, np.float32)
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, np.int32)
+            ip, first, count = idx.ctypes.data_as(C.POINTER(C.c_int32)), 0, idx.size
+        else:
+            ip = None
+            count = self.n_samples[split] - first if count is None else count
+        self._chk(self._lib.eh_loss_and_grad(self._h, split, ip, first, count, C.byref(loss), _fptr(grad), C.byref(nv)))
+        return float(loss.value), grad, int(nv.value)
+
+    # -- optimiser / training --------------------------------------------------------------------
+    def opt_init(self, rule: str = "Adam", lr: float = 0.01, beta1: float = 0.9, beta2: float = 0.999,
+                 eps: float = 1e-8, weight_decay: float = 0.0):
+        if rule not in L.OPT_RULES:
+            raise NotImplementedError(f"optimiser rule {rule} is not implemented on the device")
+        self._chk(self._lib.eh_opt_init(self._h, L.OPT_RULES[rule], lr, beta1, beta2, eps, weight_decay))
+
+    def get_opt_state(self):
+        m = np.empty(self.n_theta, np.float32)
+        v = np.empty(self.n_theta, np.float32)
+        bt = np.empty(2, np.float32)
+        self._chk(self._lib.eh_get_opt_state(self._h, _fptr(m), _fptr(v), m.size, _fptr(bt)))
+        return m, v, bt
+
+    def set_opt_state(self, m, v, bt):
+        m = np.ascontiguousarray(m, np.float32); v = np.ascontiguousarray(v, np.float32); bt = np.ascontiguousarray(bt, np.float32)
+        self._chk(self._lib.eh_set_opt_state(self._h, _fptr(m), _fptr(v), m.size, _fptr(bt)))
+
+    def train_step(self, first: int, count: int, want_loss: bool = True):
+        loss = C.c_float()
+        self._chk(self._lib.eh_train_step(self._h, first, count, C.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def train_epoch(self, batchsize: int, seed: int = 0, shuffle: bool = True, want_loss: bool = True):
+        loss = C.c_float()
+        ns = C.c_int64()
+        self._chk(self._lib.eh_train_epoch(self._h, batchsize, seed & (2**64 - 1), int(shuffle),
+                                           C.byref(loss) if want_loss else None, C.byref(ns)))
+        return (float(loss.value) if want_loss else None), int(ns.value)
+
+    # -- data-parallel seam ----------------------------------------------------------------------
+    def dp_grad(self, first: int, count: int):
+        self._chk(self._lib.eh_dp_grad(self._h, first, count))
+
+    def dp_apply(self, want_loss: bool = False):
+        loss = C.c_float()
+        self._chk(self._lib.eh_dp_apply(self._h, C.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def device_buffer(self, which: int):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._chk(self._lib.eh_device_buffer(self._h, which, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    # -- profiling -------------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self._chk(self._lib.eh_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        n = C.c_int64(); a = C.c_double(); b = C.c_double()
+        self._chk(self._lib.eh_profile_read(self._h, C.byref(n), C.byref(a), C.byref(b)))
+        return int(n.value), float(a.value), float(b.value)

@@ -1,0 +1,318 @@
+"""Host-side mirror of the reference's model constructor API.
+
+  constructHybridModel(predictors, forcing, targets, mechanistic_model, parameters,
+                       neural_param_names, global_param_names; hidden_layers=[32, 32], activation=tanh,
+                       scale_nn_outputs=false, input_batchnorm=false, start_from_default=true)
+                                                   -- src/models/GenericHybridModel.jl:89-140
+  SingleNNHybridModel (alias HybridModel)          -- src/models/GenericHybridModel.jl:44-63
+  build_parameters / ParameterContainer            -- src/models/helpers_for_HybridModel.jl:39-52,95-102
+  scale_single_param, inv_sigmoid, ...             -- src/models/GenericHybridModel.jl:348-365
+
+The reference accepts any Julia closure as `mechanistic_model`; a closure cannot run inside a HIP
+kernel, so this engine accepts the mechanistic models of its registry (the reference's own RbQ10,
+Expo, Linear, Rs_components formulas plus the build-defined two-pool Expo of BASELINE config 3),
+either by name or as the tagged Python callables below, and raises NotImplementedError for anything
+else -- never a silent CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib as L
+
+# ---------------------------------------------------------------------------------------------
+# mechanistic model registry (names = kwargs of the reference's Julia functions)
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class MechSpec:
+    id: int
+    name: str
+    params: Tuple[str, ...]
+    forcings: Tuple[str, ...]
+    outputs: Tuple[str, ...]
+
+
+MECH_REGISTRY: Dict[str, MechSpec] = {
+    "RbQ10": MechSpec(0, "RbQ10", ("rb", "Q10"), ("ta",), ("reco",)),
+    "Expo_resp_model": MechSpec(1, "Expo_resp_model", ("Resp0", "k"), ("T",), ("Resp_obs",)),
+    "LinearHM": MechSpec(2, "LinearHM", ("alpha", "beta"), ("x",), ("obs",)),
+    "Expo2Pool": MechSpec(3, "Expo2Pool", ("R0a", "ka", "R0b", "kb"), ("T",), ("Resp_obs",)),
+    "Rs_components": MechSpec(4, "Rs_components", ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
+                              ("ta",), ("R_soil",)),
+}
+
+
+def _tag(name):
+    def deco(fn):
+        fn.eh_mech = MECH_REGISTRY[name]
+        return fn
+    return deco
+
+
+@_tag("RbQ10")
+def RbQ10(*, ta, Q10, rb, tref=15.0):
+    """test/test_split_data_train.jl:36-39 (documentation of the formula; the device evaluates it)."""
+    raise NotImplementedError("mechanistic models are evaluated on the device; this callable is a registry tag")
+
+
+@_tag("Expo_resp_model")
+def Expo_resp_model(*, T, Resp0, k):
+    """projects/ExpoHybrid/ExpoHybridEstim.jl:69-85"""
+    raise NotImplementedError("registry tag")
+
+
+@_tag("LinearHM")
+def LinearHM(*, x, alpha, beta):
+    """src/models/LinearHM.jl:61-68"""
+    raise NotImplementedError("registry tag")
+
+
+@_tag("Expo2Pool")
+def Expo2Pool(*, T, R0a, ka, R0b, kb):
+    """build-defined: R0a*exp(ka*T) + R0b*exp(kb*T) (BASELINE.json config 3)"""
+    raise NotImplementedError("registry tag")
+
+
+@_tag("Rs_components")
+def Rs_components(*, ta, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc):
+    """src/models/Rs_components.jl:40-57"""
+    raise NotImplementedError("registry tag")
+
+
+def resolve_mech(m) -> MechSpec:
+    if isinstance(m, MechSpec):
+        return m
+    if isinstance(m, str):
+        if m in MECH_REGISTRY:
+            return MECH_REGISTRY[m]
+        raise NotImplementedError(f"mechanistic model {m!r} is not in the device registry {sorted(MECH_REGISTRY)}")
+    spec = getattr(m, "eh_mech", None)
+    if spec is None:
+        raise NotImplementedError(
+            "an arbitrary mechanistic closure cannot run inside the HIP kernel; use one of the registry models "
+            f"{sorted(MECH_REGISTRY)} (no CPU fallback is provided)")
+    return spec
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter table + scaling helpers
+# ---------------------------------------------------------------------------------------------
+
+
+class ParameterContainer:
+    """(default, lower, upper) table; helpers_for_HybridModel.jl:95-102, GenericHybridModel.jl:22-30."""
+
+    def __init__(self, values: Dict[str, Tuple[float, float, float]]):
+        for k, v in values.items():
+            if len(v) != 3:
+                raise ValueError(f"parameter {k} must be (default, lower, upper)")
+        self.values = {k: tuple(np.float32(x) for x in v) for k, v in values.items()}
+
+    def names(self):
+        return list(self.values)
+
+    def default(self, n): return self.values[n][0]
+    def lower(self, n): return self.values[n][1]
+    def upper(self, n): return self.values[n][2]
+
+
+def build_parameters(parameters, f=None) -> ParameterContainer:
+    return parameters if isinstance(parameters, ParameterContainer) else ParameterContainer(dict(parameters))
+
+
+def sigmoid(x):
+    x = np.asarray(x, np.float32)
+    return (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+
+
+def inv_sigmoid(y):
+    y = np.asarray(y, np.float32)
+    return np.log(y / (1 - y))                                   # GenericHybridModel.jl:354
+
+
+def scale_single_param(name, raw_val, hm: ParameterContainer):
+    lo, hi = hm.lower(name), hm.upper(name)
+    return lo + (hi - lo) * sigmoid(raw_val)                       # GenericHybridModel.jl:348-352
+
+
+def scale_single_param_minmax(name, hm: ParameterContainer):
+    lo, hi = hm.lower(name), hm.upper(name)
+    return inv_sigmoid((hm.default(name) - lo) / (hi - lo))       # GenericHybridModel.jl:361-365
+
+
+def hard_sigmoid(x):
+    return np.clip(0.2 * np.asarray(x) + 0.5, 0.0, 1.0)           # GenericHybridModel.jl:9-11
+
+
+def inv_hard_sigmoid(y):
+    return (np.asarray(y) - 0.5) / 0.2                            # GenericHybridModel.jl:16-18
+
+
+# ---------------------------------------------------------------------------------------------
+# model
+# ---------------------------------------------------------------------------------------------
+
+_ACT_ALIASES = {"tanh": "tanh", "sigmoid": "sigmoid", "relu": "relu", "swish": "swish", "identity": "identity",
+                "σ": "sigmoid", "sigmoid_fast": "sigmoid", "tanh_fast": "tanh"}
+_ACT_GAIN = {"tanh": 5.0 / 3.0, "relu": math.sqrt(2.0), "sigmoid": 1.0, "swish": 1.0, "identity": 1.0}
+
+
+def _act_name(a) -> str:
+    name = a if isinstance(a, str) else getattr(a, "__name__", str(a))
+    if name not in _ACT_ALIASES:
+        raise NotImplementedError(f"activation {name!r} has no device implementation (have {sorted(set(_ACT_ALIASES.values()))})")
+    return _ACT_ALIASES[name]
+
+
+@dataclass
+class SingleNNHybridModel:
+    """Field-for-field mirror of the reference struct (GenericHybridModel.jl:44-63); `NN` is the
+    list of Dense (out, in) shapes that prepare_hidden_chain (NNModels.jl:220-231) would build."""
+    NN: List[Tuple[int, int]]
+    predictors: List[str]
+    forcing: List[str]
+    targets: List[str]
+    mechanistic_model: MechSpec
+    parameters: ParameterContainer
+    neural_param_names: List[str]
+    global_param_names: List[str]
+    fixed_param_names: List[str]
+    scale_nn_outputs: bool
+    start_from_default: bool
+    config: dict = field(default_factory=dict)
+
+    # -- sizes ---------------------------------------------------------------------------------
+    @property
+    def hidden_layers(self) -> List[int]:
+        return [o for o, _ in self.NN[:-1]]
+
+    @property
+    def n_nn(self) -> int:
+        return sum(o * i + o for o, i in self.NN)
+
+    @property
+    def n_theta(self) -> int:
+        return self.n_nn + len(self.global_param_names)
+
+    @property
+    def activation(self) -> str:
+        return self.config["activation"]
+
+    # -- LuxCore.initialparameters analogue (GenericHybridModel.jl:236-256) ----------------------
+    def initialparameters(self, rng: Union[int, np.random.Generator] = 0) -> np.ndarray:
+        """Flat theta in the reference's ComponentArray order.  Lux >= 1.0 Dense defaults (third
+        party, from its docs): weight kaiming_uniform with the activation's gain, bias
+        U(+-1/sqrt(fan_in)).  NumPy's stream, not Julia's Xoshiro -- parity tests inject theta."""
+        rng = np.random.default_rng(rng) if not isinstance(rng, np.random.Generator) else rng
+        parts = []
+        for li, (o, i) in enumerate(self.NN):
+            gain = _ACT_GAIN[self.activation] if li < len(self.NN) - 1 else 1.0
+            bw = gain * math.sqrt(3.0 / i)
+            parts.append(rng.uniform(-bw, bw, (o, i)).astype(np.float32).flatten(order="F"))
+            parts.append(rng.uniform(-1 / math.sqrt(i), 1 / math.sqrt(i), o).astype(np.float32))
+        for g in self.global_param_names:
+            if self.start_from_default:
+                parts.append(np.asarray([scale_single_param_minmax(g, self.parameters)], np.float32))
+            else:
+                parts.append(rng.random(1).astype(np.float32))
+        return np.concatenate(parts).astype(np.float32)
+
+    def unpack(self, theta: np.ndarray):
+        """flat theta -> (ps = [(weight (out,in), bias)...], {global: raw})"""
+        off, layers = 0, []
+        for o, i in self.NN:
+            W = theta[off:off + o * i].reshape((o, i), order="F"); off += o * i
+            b = theta[off:off + o]; off += o
+            layers.append((W, b))
+        return layers, {g: theta[off + j:off + j + 1] for j, g in enumerate(self.global_param_names)}
+
+    # -- C descriptor ----------------------------------------------------------------------------
+    def to_desc(self, device: int = 0) -> L.ModelDesc:
+        ms = self.mechanistic_model
+        d = L.ModelDesc()
+        d.struct_size = __import__("ctypes").sizeof(L.ModelDesc)
+        d.device = device
+        d.n_predictors = len(self.predictors)
+        hl = self.hidden_layers
+        if not 1 <= len(hl) <= L.EH_MAX_HIDDEN:
+            raise NotImplementedError(f"{len(hl)} hidden layers (device kernels: 1..{L.EH_MAX_HIDDEN})")
+        d.n_hidden = len(hl)
+        for k, w in enumerate(hl):
+            d.hidden[k] = w
+        d.activation = L.ACTIVATIONS[self.activation]
+        d.scale_nn_outputs = int(self.scale_nn_outputs)
+        d.mech = ms.id
+        d.n_params = len(ms.params)
+        for j, p in enumerate(ms.params):
+            if p in self.neural_param_names:
+                d.param_kind[j], d.param_index[j] = L.PAR_NEURAL, self.neural_param_names.index(p)
+            elif p in self.global_param_names:
+                d.param_kind[j], d.param_index[j] = L.PAR_GLOBAL, self.global_param_names.index(p)
+            else:
+                d.param_kind[j], d.param_index[j] = L.PAR_FIXED, 0
+            d.param_default[j] = self.parameters.default(p)
+            d.param_lower[j] = self.parameters.lower(p)
+            d.param_upper[j] = self.parameters.upper(p)
+        d.n_forcings = len(self.forcing)
+        for f, name in enumerate(ms.forcings):
+            d.forcing_index[f] = self.forcing.index(name)
+        d.n_targets = len(self.targets)
+        for t, name in enumerate(self.targets):
+            d.target_output[t] = ms.outputs.index(name)
+        return d
+
+    def engine(self, device: int = 0):
+        from .engine import HybridEngine
+        return HybridEngine(self.to_desc(device), len(self.mechanistic_model.params), self.targets,
+                            list(self.mechanistic_model.params))
+
+
+HybridModel = SingleNNHybridModel     # spelling used by BASELINE.json's north_star
+
+
+def constructHybridModel(predictors: Sequence[str], forcing: Sequence[str], targets: Sequence[str], mechanistic_model,
+                         parameters, neural_param_names: Sequence[str], global_param_names: Sequence[str], *,
+                         hidden_layers: Sequence[int] = (32, 32), activation="tanh", scale_nn_outputs: bool = False,
+                         input_batchnorm: bool = False, start_from_default: bool = True, **kwargs) -> SingleNNHybridModel:
+    """GenericHybridModel.jl:89-140 (Vector{Symbol} predictors form)."""
+    if isinstance(predictors, dict):
+        raise NotImplementedError("MultiNNHybridModel (NamedTuple predictors) is not built yet (SURVEY.md section 8f rank 4)")
+    ms = resolve_mech(mechanistic_model)
+    parameters = build_parameters(parameters, mechanistic_model)
+    all_names = parameters.names()
+    if not all(n in all_names for n in neural_param_names):
+        raise AssertionError("neural_param_names ⊆ param_names")                      # GenericHybridModel.jl:110
+    if input_batchnorm:
+        raise NotImplementedError("input_batchnorm=true is not built yet (SURVEY.md section 8f rank 2)")
+    predictors, forcing, targets = list(predictors), list(forcing), list(targets)
+    neural_param_names, global_param_names = list(neural_param_names), list(global_param_names)
+    if len(predictors) == 0 or len(neural_param_names) == 0:
+        raise NotImplementedError("models without a neural network (empty predictors / neural_param_names) are not built")
+    for p in ms.params:
+        if p not in all_names:
+            raise ValueError(f"mechanistic model {ms.name} needs parameter {p!r}; the table has {all_names}")
+    extra = [n for n in all_names if n not in ms.params]
+    if extra:
+        raise ValueError(f"parameters {extra} are not arguments of {ms.name}{ms.params}")
+    for f in ms.forcings:
+        if f not in forcing:
+            raise ValueError(f"mechanistic model {ms.name} needs forcing {f!r}; got {forcing}")
+    for t in targets:
+        if t not in ms.outputs:
+            raise ValueError(f"target {t!r} is not an output of {ms.name} {ms.outputs}")
+    if not isinstance(hidden_layers, (list, tuple)):
+        raise NotImplementedError("hidden_layers given as a Lux Chain is not supported; pass the widths")
+    act = _act_name(activation)
+    dims = [len(predictors)] + [int(h) for h in hidden_layers] + [len(neural_param_names)]
+    NN = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+    fixed = [n for n in all_names if n not in neural_param_names and n not in global_param_names]    # :127
+    config = dict(hidden_layers=list(hidden_layers), activation=act, scale_nn_outputs=scale_nn_outputs,
+                  input_batchnorm=input_batchnorm, start_from_default=start_from_default, **kwargs)
+    return SingleNNHybridModel(NN, predictors, forcing, targets, ms, parameters, neural_param_names, global_param_names,
+                               fixed, bool(scale_nn_outputs), bool(start_from_default), config)

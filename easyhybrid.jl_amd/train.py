@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference's training front door.
+
+  train(model, data; nepochs, batchsize, opt, training_loss, loss_types, agg, random_seed, ...)
+                                             -- src/training/train.jl:95-136,211-219
+  TrainConfig (the fields the step consumes) -- src/config/TrainingConfig.jl:9-160, validate_config :162-185
+  DataConfig  (split fields)                 -- src/config/DataConfig.jl:7-59
+  prepare_data / split_data                  -- src/data/prepare_data.jl:31-63, src/data/split_data.jl:8-79
+  EarlyStopping / best_or_final / TrainResults -- src/training/early_stopping.jl, src/config/TrainingConfig.jl:190-223
+
+The per-minibatch work (`run_epoch!`, src/training/epoch.jl:13-33) and the per-epoch evaluation
+(`evaluate_epoch`, :53-66) are calls into the HIP engine; this file is bookkeeping only.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field, replace
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .models import SingleNNHybridModel
+
+# ---------------------------------------------------------------------------------------------
+# optimiser rule specs (Optimisers.jl constructors; reference re-exports them, EasyHybrid.jl:59)
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class Adam:
+    eta: float = 0.001
+    beta: tuple = (0.9, 0.999)
+    epsilon: float = 1e-8
+
+
+@dataclass(frozen=True)
+class AdamW:
+    eta: float = 0.001
+    beta: tuple = (0.9, 0.999)
+    lambda_: float = 0.0
+    epsilon: float = 1e-8
+
+
+@dataclass(frozen=True)
+class RMSProp:
+    eta: float = 0.001
+    rho: float = 0.9
+    epsilon: float = 1e-8
+
+
+@dataclass(frozen=True)
+class Descent:
+    eta: float = 0.1
+
+
+def _opt_args(opt):
+    if isinstance(opt, Adam):
+        return dict(rule="Adam", lr=opt.eta, beta1=opt.beta[0], beta2=opt.beta[1], eps=opt.epsilon)
+    if isinstance(opt, AdamW):
+        return dict(rule="AdamW", lr=opt.eta, beta1=opt.beta[0], beta2=opt.beta[1], eps=opt.epsilon, weight_decay=opt.lambda_)
+    if isinstance(opt, RMSProp):
+        return dict(rule="RMSProp", lr=opt.eta, beta1=opt.rho, eps=opt.epsilon)
+    if isinstance(opt, Descent):
+        return dict(rule="Descent", lr=opt.eta)
+    raise NotImplementedError(f"optimiser {opt!r}: only Optimisers.jl-style Adam/AdamW/RMSProp/Descent run on the device "
+                              "(the Optimization.jl path, src/training/train_optimization.jl, is out of scope)")
+
+
+# ---------------------------------------------------------------------------------------------
+# configs
+# ---------------------------------------------------------------------------------------------
+
+_MAXIMIZE = {"pearson", "r2", "nse", "kge"}                      # loss_fn.jl:181-187
+_DEVICE_METRICS = {"mse", "rmse", "mae", "r2", "nse", "pearson", "kge", "pbkge"}
+
+
+def isbetter(new, best, loss_type) -> bool:                      # loss_fn.jl:189-194
+    return new > best if loss_type in _MAXIMIZE else new < best
+
+
+def check_training_loss(loss_type):                              # loss_fn.jl:196-205
+    if loss_type in _MAXIMIZE:
+        raise ValueError(f"Got a metric that is defined as `to be maximized` as a training loss: {loss_type}. "
+                         "For training you must use a true loss (to be minimized), e.g. :mse.")
+
+
+@dataclass
+class TrainConfig:
+    nepochs: int = 200
+    batchsize: int = 64
+    opt: Any = field(default_factory=lambda: Adam(0.01))
+    patience: int = 2**62
+    training_loss: str = "mse"
+    loss_types: List[str] = field(default_factory=lambda: ["mse", "r2"])
+    agg: str = "sum"
+    train_from: Any = None
+    random_seed: Optional[int] = 161803
+    return_model: str = "best"
+    keep_history: bool = True
+    show_progress: bool = False
+    device: int = 0
+
+
+@dataclass
+class DataConfig:
+    shuffleobs: bool = False
+    split_by_id: Any = None
+    split_data_at: float = 0.8
+    folds: Any = None
+    val_fold: Optional[int] = None
+
+
+def validate_config(cfg: TrainConfig):                           # TrainingConfig.jl:162-185
+    if cfg.nepochs < 0:
+        raise ValueError("nepochs must be >= 0")
+    if cfg.batchsize < 1:
+        raise ValueError("batchsize must be >= 1")
+    if cfg.return_model not in ("best", "final"):
+        raise ValueError("return_model must be :best or :final")
+    if not cfg.loss_types:
+        raise ValueError("loss_types must not be empty")
+    check_training_loss(cfg.training_loss)
+    if cfg.training_loss != "mse":
+        raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements :mse (others: SURVEY.md section 8f rank 3)")
+    if cfg.agg != "sum":
+        raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
+    for lt in cfg.loss_types:
+        if lt not in _DEVICE_METRICS:
+            raise NotImplementedError(f"loss type {lt!r} is not computed by the eval kernel (have {sorted(_DEVICE_METRICS)})")
+
+
+# ---------------------------------------------------------------------------------------------
+# data preparation (host; runs once)
+# ---------------------------------------------------------------------------------------------
+
+
+def _columns(data) -> Dict[str, np.ndarray]:
+    if hasattr(data, "columns") and hasattr(data, "__getitem__") and not isinstance(data, dict):   # pandas DataFrame
+        return {str(c): np.asarray(data[c]) for c in data.columns}
+    if isinstance(data, dict):
+        return {k: np.asarray(v) for k, v in data.items()}
+    raise TypeError("data must be a dict of columns, a pandas DataFrame or a prepared ((X, forcings), targets) tuple")
+
+
+def prepare_data(model: SingleNNHybridModel, data, drop_missing_rows: bool = True):
+    """-> ((X (P,N) float32, {forcing: (N,)}), {target: (N,)}); prepare_data.jl:31-63."""
+    if isinstance(data, tuple):
+        return data
+    cols = _columns(data)
+    need = list(dict.fromkeys(list(model.predictors) + list(model.forcing) + list(model.targets)))
+    for c in need:
+        if c not in cols:
+            raise KeyError(f"column {c!r} missing from data")
+    arr = {c: np.asarray(cols[c], np.float64) for c in need}
+    n = len(next(iter(arr.values())))
+    if drop_missing_rows:
+        predforce = [c for c in need if c not in model.targets]
+        miss = np.zeros(n, bool)
+        for c in predforce:
+            miss |= np.isnan(arr[c])
+        some_target = np.zeros(n, bool)
+        for c in model.targets:
+            some_target |= ~np.isnan(arr[c])
+        keep = ~miss & some_target
+        arr = {c: v[keep] for c, v in arr.items()}
+    X = np.stack([arr[p] for p in model.predictors]).astype(np.float32)
+    return (X, {f: arr[f].astype(np.float32) for f in model.forcing}), {t: arr[t].astype(np.float32) for t in model.targets}
+
+
+def split_data(data, model, cfg: DataConfig = DataConfig(), rng: Optional[np.random.Generator] = None):
+    """split_data.jl:8-79 -> (train, val) each ((X, forcings), targets)."""
+    raw_cols = _columns(data) if not isinstance(data, tuple) else None
+    (X, forc), targ = prepare_data(model, data)
+    n = X.shape[1]
+    if cfg.split_by_id is not None and cfg.folds is not None:
+        raise ValueError("split_by_id and folds are not supported together; do the split when constructing folds")
+    if cfg.split_by_id is not None:
+        ids = np.asarray(raw_cols[cfg.split_by_id] if isinstance(cfg.split_by_id, str) else cfg.split_by_id)
+        if len(ids) != n:
+            raise ValueError("split_by_id needs one id per retained sample (drop NaN rows first)")
+        uniq = np.array(list(dict.fromkeys(ids.tolist())))
+        if cfg.shuffleobs:
+            uniq = (rng or np.random.default_rng()).permutation(uniq)
+        k = int(np.clip(round(cfg.split_data_at * len(uniq)), 0, len(uniq)))
+        tr = np.flatnonzero(np.isin(ids, uniq[:k])); va = np.flatnonzero(np.isin(ids, uniq[k:]))
+    elif cfg.folds is not None or cfg.val_fold is not None:
+        if cfg.folds is None or cfg.val_fold is None:
+            raise AssertionError("Provide folds together with val_fold.")
+        f = np.asarray(raw_cols[cfg.folds] if isinstance(cfg.folds, str) else cfg.folds)
+        if len(f) != n:
+            raise AssertionError(f"length(folds) ({len(f)}) must equal number of samples ({n}).")
+        va = np.flatnonzero(f == cfg.val_fold)
+        if va.size == 0:
+            raise AssertionError(f"No samples assigned to validation fold {cfg.val_fold}.")
+        tr = np.setdiff1d(np.arange(n), va)
+    else:
+        idx = (rng or np.random.default_rng()).permutation(n) if cfg.shuffleobs else np.arange(n)
+        k = int(np.clip(round(cfg.split_data_at * n), 0, n))           # MLUtils.splitobs(at = ...)
+        tr, va = idx[:k], idx[k:]
+
+    def take(ix):
+        return (np.ascontiguousarray(X[:, ix]), {k: v[ix] for k, v in forc.items()}), {k: v[ix] for k, v in targ.items()}
+    return take(tr), take(va)
+
+
+# ---------------------------------------------------------------------------------------------
+# results
+# ---------------------------------------------------------------------------------------------
+
+
+@dataclass
+class EpochSnapshot:                                               # initialization.jl:53-58
+    l_train: dict
+    l_val: dict
+    y_train: Optional[dict] = None
+    y_val: Optional[dict] = None
+
+
+@dataclass
+class TrainResults:                                                # TrainingConfig.jl:190-223
+    train_history: list
+    val_history: list
+    epoch_history: list
+    train_obs_pred: dict
+    val_obs_pred: dict
+    train_diffs: Optional[dict]
+    val_diffs: Optional[dict]
+    ps: np.ndarray
+    st: dict
+    best_epoch: int
+    best_loss: float
+
+
+def _losses(engine, split, targets, loss_types):
+    """(mse = (reco = .., sum = ..), r2 = (...)) as nested dicts; compute_loss.jl:55-66."""
+    if engine.n_samples[split] == 0:
+        return {lt: {**{t: float("nan") for t in targets}, "sum": float("nan")} for lt in loss_types}
+    metrics, _ = engine.eval(split)
+    out = {}
+    for lt in loss_types:
+        per = {t: metrics[i][lt] for i, t in enumerate(targets)}
+        per["sum"] = float(sum(per[t] for t in targets))
+        out[lt] = per
+    return out
+
+
+def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[TrainConfig] = None,
+          data_cfg: Optional[DataConfig] = None, engine=None, **kwargs) -> Optional[TrainResults]:
+    """train(model, data; kwargs...) -> TrainResults (train.jl:211-219 -> _train :95-136).
+    Flat kwargs override config fields exactly like override_configs (train.jl:300-314)."""
+    tc = copy.copy(train_cfg) if train_cfg else TrainConfig()
+    dc = copy.copy(data_cfg) if data_cfg else DataConfig()
+    for k, v in kwargs.items():
+        if hasattr(tc, k):
+            setattr(tc, k, v)
+        elif hasattr(dc, k):
+            setattr(dc, k, v)
+        else:
+            raise TypeError(f"train: unknown keyword {k!r}")
+    validate_config(tc)
+    rng = np.random.default_rng(tc.random_seed)
+    (xtr, ftr, ytr), (xva, fva, yva) = [(a[0][0], a[0][1], a[1]) for a in split_data(data, model, dc, rng)]
+    if xtr.shape[1] == 0:
+        return None                                                # train.jl:186 ("returns nothing on empty splits")
+    own = engine is None
+    eng = engine if engine is not None else model.engine(tc.device)
+    try:
+        eng.set_data(L.EH_SPLIT_TRAIN, xtr, [ftr[f] for f in model.forcing], [ytr[t] for t in model.targets])
+        eng.set_data(L.EH_SPLIT_VAL, xva, [fva[f] for f in model.forcing], [yva[t] for t in model.targets])
+        if tc.train_from is None:
+            theta = model.initialparameters(rng)
+        else:
+            theta = np.asarray(tc.train_from.ps if isinstance(tc.train_from, TrainResults) else tc.train_from[0], np.float32)
+        eng.set_params(theta)
+        eng.opt_init(**_opt_args(tc.opt))
+        first_lt = tc.loss_types[0]
+
+        def snapshot():
+            return EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
+                                 _losses(eng, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
+        init = snapshot()
+        history = [init]
+        best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0
+        seed0 = tc.random_seed if tc.random_seed is not None else int(rng.integers(2**31))
+        for epoch in range(1, tc.nepochs + 1):
+            eng.train_epoch(tc.batchsize, seed=seed0 + epoch, shuffle=True, want_loss=False)      # run_epoch!
+            snap = snapshot()                                                                  # evaluate_epoch
+            if tc.keep_history:
+                history.append(snap)
+            cur = snap.l_val[first_lt]["sum"]
+            if isbetter(cur, best_loss, first_lt):                                             # early_stopping.jl:16-42
+                best_loss, best_ps, best_epoch, counter = cur, eng.get_params(), epoch, 0
+                if not tc.keep_history:
+                    history[0] = snap
+            else:
+                counter += 1
+            if counter >= tc.patience:
+                break
+        ps = best_ps if tc.return_model == "best" else eng.get_params()                        # best_or_final
+        eng.set_params(ps)
+
+        def obs_pred(split, y):
+            if eng.n_samples[split] == 0:
+                return {}, None
+            out = eng.forward(split)
+            d = {t: y[t] for t in model.targets}
+            d.update({t + "_pred": out[t] for t in model.targets})
+            return d, out["parameters"]
+        tr_op, tr_diff = obs_pred(L.EH_SPLIT_TRAIN, ytr)
+        va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
+        fixed = {f: np.float32(model.parameters.default(f)) for f in model.fixed_param_names}
+        return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
+                            ps, {"fixed": fixed}, best_epoch, best_loss)
+    finally:
+        if own:
+            eng.close()

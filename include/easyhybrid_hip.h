@@ -1,0 +1,187 @@
+/* easyhybrid_hip.h -- C ABI of libeasyhybrid_hip.so: the MI355X (gfx950) engine for the
+ * EasyHybrid.jl training-step hot path.
+ *
+ * The reference (EarthyScience/EasyHybrid.jl, pure Julia) has no FFI; the seam this ABI replaces is
+ * the per-minibatch call
+ *     Lux.Training.single_train_step!(cfg.autodiff_backend, loss_fn, (x, y), train_state)
+ *                                                           src/training/epoch.jl:20-26 (run_epoch!, :13-33)
+ * together with the forward/eval calls around it (evaluate_acc, src/training/train.jl:347-355;
+ * evaluate_epoch, src/training/epoch.jl:53-66).  A Julia host binds these symbols with @ccall
+ * (INTEGRATION.md shows the stub); the test/bench harness binds the same symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns an eh_status (0 = ok, < 0 = error); nothing throws across the ABI;
+ *     eh_last_error(h) (or eh_last_error(NULL) for eh_create failures) gives the message.
+ *   - the caller owns every pointer it passes; the library copies during the call and never
+ *     retains it.  The library owns all device memory behind the opaque handle.
+ *   - a handle is not thread-safe (one driver thread per handle); distinct handles are independent.
+ *   - flat parameter vector theta (length eh_n_theta) has the reference's ComponentArray order
+ *     (src/models/GenericHybridModel.jl:236-256, src/training/initialization.jl:42-44):
+ *       for each Dense layer in chain order: weight, column-major (out,in), then bias (out);
+ *       then one raw (pre-sigmoid) value per global parameter, in global_param_names order.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     EH_EHIP.
+ */
+#ifndef EASYHYBRID_HIP_H
+#define EASYHYBRID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EH_ABI_VERSION 1
+#define EH_MAX_HIDDEN 4
+#define EH_MAX_PARAMS 8
+#define EH_MAX_FORC 4
+#define EH_MAX_TARG 4
+
+typedef enum eh_status {
+    EH_OK = 0,
+    EH_EINVAL = -1,        /* bad argument / inconsistent descriptor (reference: ArgumentError / AssertionError) */
+    EH_EHIP = -2,          /* HIP runtime error or no device */
+    EH_ENOMEM = -3,
+    EH_EUNSUPPORTED = -4,  /* unknown mechanistic model / activation / shape outside the compiled kernels */
+    EH_ESTATE = -5         /* call order (e.g. train step before eh_opt_init / eh_set_data) */
+} eh_status;
+
+/* activation of the hidden Dense layers (src/models/NNModels.jl:225-230; last layer is linear) */
+typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 2, EH_ACT_SWISH = 3, EH_ACT_IDENTITY = 4 } eh_activation;
+
+/* registry of mechanistic models (the reference takes an arbitrary Julia closure,
+ * src/models/GenericHybridModel.jl:425; a closure cannot run in a kernel, so the engine ships
+ * hand-derived forward+VJP pairs for the reference's own models).  Canonical parameter /
+ * forcing / output order per model:
+ *   RBQ10          params (rb, Q10)               forcing (ta)  output (reco)      reco = rb*Q10^(0.1(ta-15))
+ *                                                  test/test_split_data_train.jl:36-39, src/models/Respiration_Rb_Q10.jl:39-41
+ *   EXPO           params (Resp0, k)              forcing (T)   output (Resp_obs)  Resp0*exp(k*T)
+ *                                                  projects/ExpoHybrid/ExpoHybridEstim.jl:69-85
+ *   LINEAR         params (alpha, beta)           forcing (x)   output (obs)       alpha*x+beta        src/models/LinearHM.jl:61-68
+ *   EXPO2POOL      params (R0a, ka, R0b, kb)      forcing (T)   output (Resp_obs)  R0a*exp(ka*T)+R0b*exp(kb*T)
+ *                                                  (build-defined 4-parameter model of BASELINE.json config 3)
+ *   RS_COMPONENTS  params (Rb_het,Rb_root,Rb_myc,Q10_het,Q10_root,Q10_myc) forcing (ta) output (R_soil)
+ *                                                  src/models/Rs_components.jl:40-57
+ */
+typedef enum eh_mech { EH_MECH_RBQ10 = 0, EH_MECH_EXPO = 1, EH_MECH_LINEAR = 2, EH_MECH_EXPO2POOL = 3, EH_MECH_RS_COMPONENTS = 4 } eh_mech;
+
+/* where a mechanistic parameter comes from (neural_param_names / global_param_names / the rest,
+ * src/models/GenericHybridModel.jl:96-97,127) */
+typedef enum eh_param_kind { EH_PAR_NEURAL = 0, EH_PAR_GLOBAL = 1, EH_PAR_FIXED = 2 } eh_param_kind;
+
+typedef enum eh_split { EH_SPLIT_TRAIN = 0, EH_SPLIT_VAL = 1 } eh_split;
+
+/* optimiser rules (Optimisers.jl; reference default Adam(0.01), src/config/TrainingConfig.jl:43) */
+typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2, EH_OPT_DESCENT = 3 } eh_opt_rule;
+
+/* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
+typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3 } eh_buffer;
+
+typedef struct eh_model_desc {
+    int32_t struct_size;                     /* = sizeof(eh_model_desc) */
+    int32_t device;                          /* HIP device ordinal */
+    int32_t n_predictors;                    /* P  = length(predictors) */
+    int32_t n_hidden;                        /* length(hidden_layers), 1..EH_MAX_HIDDEN */
+    int32_t hidden[EH_MAX_HIDDEN];           /* hidden_layers */
+    int32_t activation;                      /* eh_activation */
+    int32_t scale_nn_outputs;                /* constructHybridModel kwarg */
+    int32_t mech;                            /* eh_mech */
+    int32_t n_params;                        /* must equal the registry's parameter count */
+    int32_t param_kind[EH_MAX_PARAMS];       /* per canonical parameter: eh_param_kind */
+    int32_t param_index[EH_MAX_PARAMS];      /* NEURAL: row of the NN output; GLOBAL: position in global_param_names */
+    float param_default[EH_MAX_PARAMS];      /* the (default, lower, upper) table, helpers_for_HybridModel.jl:95-102 */
+    float param_lower[EH_MAX_PARAMS];
+    float param_upper[EH_MAX_PARAMS];
+    int32_t n_forcings;                      /* F = number of forcing arrays handed to eh_set_data */
+    int32_t forcing_index[EH_MAX_FORC];      /* per canonical forcing of the mech model: which of the F arrays feeds it */
+    int32_t n_targets;                       /* T */
+    int32_t target_output[EH_MAX_TARG];      /* per target: which output of the mech model it is compared with */
+} eh_model_desc;
+
+typedef struct eh_target_metrics {           /* src/losses/loss_fn.jl:58-179 on the valid samples of one target */
+    double n;                                /* number of valid (non-NaN) targets */
+    double mse, rmse, mae, r2, nse, pearson, kge, pbkge, beta, alpha;
+    double sse;                              /* sum of squared residuals */
+} eh_target_metrics;
+
+typedef struct eh_handle_s eh_handle;
+
+int32_t eh_version(void);
+const char* eh_last_error(const eh_handle* h);
+
+/* constructHybridModel(...) -> device-side model + workspace (src/models/GenericHybridModel.jl:89-140) */
+int32_t eh_create(const eh_model_desc* desc, eh_handle** out);
+int32_t eh_destroy(eh_handle* h);
+int32_t eh_n_theta(const eh_handle* h, int64_t* n);
+
+/* run every later call on this hipStream_t (NULL = the handle's own stream) */
+int32_t eh_set_stream(eh_handle* h, void* hip_stream);
+int32_t eh_synchronize(eh_handle* h);
+
+/* dataset of one split, made resident in HBM once (replaces the per-batch host->device copies of
+ * collect_dim_data, src/training/epoch.jl:1-11).  x: (P x N) column-major exactly as the reference
+ * holds it (src/data/prepare_data.jl:6); forcings: F arrays of N; targets: T arrays of N with NaN =
+ * missing (valid_mask, src/training/train.jl:221-232).  on_device != 0: the pointers are device
+ * pointers on the handle's device. */
+int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, const float* const* forcings,
+                    const float* const* targets, int32_t on_device);
+
+int32_t eh_set_params(eh_handle* h, const float* theta, int64_t n);
+int32_t eh_get_params(eh_handle* h, float* theta, int64_t n);
+
+/* model forward on samples [first, first+count) of a split (GenericHybridModel.jl:370-431, test mode).
+ * yhat: T host arrays of count floats (or NULL); params: n_params host arrays of count floats (or NULL). */
+int32_t eh_forward(eh_handle* h, int32_t split, int64_t first, int64_t count, float* const* yhat, float* const* params);
+
+/* compute_loss(train_mode) value and its gradient wrt flat theta on one minibatch, no update
+ * (the objective Zygote differentiates, src/training/epoch.jl:40-51; also the seam
+ * train_optimization.jl:121-133 would use).  idx: optional count sample indices (host, int32) into the
+ * split, NULL = the contiguous window.  An all-masked batch gives loss = NaN, grad = 0, n_valid = 0. */
+int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_t first, int64_t count,
+                         float* loss, float* grad, int64_t* n_valid);
+
+/* Optimisers.setup(rule, ps): zero moments, t = 0 (src/training/initialization.jl:42-44) */
+int32_t eh_opt_init(eh_handle* h, int32_t rule, float lr, float beta1, float beta2, float eps, float weight_decay);
+int32_t eh_get_opt_state(eh_handle* h, float* m, float* v, int64_t n, float* beta_t /* [2] */);
+int32_t eh_set_opt_state(eh_handle* h, const float* m, const float* v, int64_t n, const float* beta_t);
+
+/* one single_train_step! on train samples [first, first+count) (or idx_dev gather if
+ * eh_shuffle_epoch was called): fused forward + mechanistic model + masked MSE + VJP, then reduce +
+ * optimiser update.  loss_out == NULL: fully asynchronous on the stream.  An all-masked batch is
+ * skipped without touching theta or the optimiser state (src/training/epoch.jl:17-19). */
+int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out);
+
+/* one run_epoch! over the train split (src/training/epoch.jl:13-33): ceil(N/batchsize) steps, the
+ * last one partial (MLUtils.DataLoader default), shuffled on the device when shuffle != 0
+ * (src/data/loaders.jl:6; the permutation is the engine's own keyed bijection, not Julia's RNG
+ * stream).  mean_loss: mean of the per-step losses (nullable); n_steps: steps run (nullable). */
+int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t shuffle, float* mean_loss, int64_t* n_steps);
+
+/* evaluate_acc on samples [first, first+count) of a split: metrics per target, optionally the
+ * predictions and physical parameters (host arrays as in eh_forward). */
+int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_target_metrics* out,
+                float* const* yhat, float* const* params);
+
+/* ---- data-parallel seam: one process per GPU, the host all-reduces EH_BUF_GRAD over RCCL ----------
+ * eh_dp_grad   : local partial sums of the UN-normalised gradient, loss and valid counts into
+ *                EH_BUF_GRAD  = [ grad (n_theta) | sum m (yhat-y)^2 | n_valid per target (T) ]
+ * (host: all_reduce(SUM) over that buffer)
+ * eh_dp_apply  : normalise by the global counts and apply the optimiser update (replicated).
+ * The mean over the GLOBAL valid count is what the reference computes (src/losses/loss_fn.jl:61-63),
+ * so shards exchange sums and counts, never per-shard means.  Single-target models only (T == 1). */
+int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count);
+int32_t eh_dp_apply(eh_handle* h, float* loss_out);
+int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats);
+
+/* timing aid for bench.py: when enabled, eh_train_step brackets the fused step kernel with HIP
+ * events on its stream; eh_profile_read returns the number of launches and their mean duration. */
+int32_t eh_profile_enable(eh_handle* h, int32_t on);
+int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_kernel, double* mean_ms_reduce_kernel);
+
+/* tuning knobs (name/value), e.g. "max_blocks" */
+int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,546 @@
+"""CPU oracle for the EasyHybrid training-step hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain NumPy restatement of what the reference computes on its
+hot path.  It exists to CHECK the HIP kernels; nothing in the
+product path (`easyhybrid.jl_amd/`) may import it.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` use it.
+
+Pinning status
+--------------
+The reference is pure Julia (Lux + Zygote + Optimisers) and cannot run in the
+build container (no `julia`, no network).  The oracle is therefore pinned on
+the numeric known-answers the reference's own tests hold for this path
+(tests/test_oracle_pins.py):
+  * `scale_single_param` = 1.0 / 2.0 at raw 0      (test/test_generic_hybrid_model.jl:109-117)
+  * `scale_single_param_minmax` = 0 at mid-range    (test/test_generic_hybrid_model.jl:119-126)
+  * MSE [1,2,3,4] vs [1.1,1.9,3.2,3.8] = 0.025; masked [T,T,F,T] = 0.02
+                                                    (test/test_loss_fn.jl:6-8,20,90-96)
+  * every other metric vs its closed form           (test/test_loss_fn.jl:17-74)
+  * multi-target loss = sum_t mean-square           (test/test_compute_loss.jl:69-79)
+GRADIENT VALUES, DENSE NUMERICS AND THE ADAM TRAJECTORY ARE *PARITY UNPINNED*
+by the reference's own tests (they are smoke tests only,
+test/test_autodiff_backend.jl:21-37).  For those the oracle is cross-checked
+three ways instead (tests/test_oracle_selfcheck.py): hand VJP (this file) vs
+PyTorch-CPU autograd of the same forward (oracle/torch_twin.py) vs central
+finite differences in fp64.
+
+What each function follows in the reference (paths relative to /root/reference)
+-------------------------------------------------------------------------------
+  sigmoid scaling / inverse      src/models/GenericHybridModel.jl:348-365
+  flat theta order               src/models/GenericHybridModel.jl:236-256,
+                                 src/training/initialization.jl:42-44 (ComponentArray, one leaf)
+  MLP chain shape                src/models/NNModels.jl:220-231 (Dense+act ..., last Dense linear)
+  forward                        src/models/GenericHybridModel.jl:370-431
+  RbQ10 formula                  test/test_split_data_train.jl:36-39, src/models/Respiration_Rb_Q10.jl:39-41
+  Expo formula                   projects/ExpoHybrid/ExpoHybridEstim.jl:69-85
+  Linear formula                 src/models/LinearHM.jl:61-68
+  Rs_components formula          src/models/Rs_components.jl:40-57
+  loss                           src/losses/loss_fn.jl:58-179, src/losses/compute_loss.jl:50-66,115-126
+  valid mask / empty batch       src/training/train.jl:221-232, src/training/epoch.jl:17-19,35-37
+  Adam                           Optimisers.jl `Adam` (third-party, un-vendored; reference default
+                                 `Adam(0.01)` at src/config/TrainingConfig.jl:43, beta=(0.9,0.999), eps=1e-8):
+                                 m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+                                 theta -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps), t = 1,2,...
+  AdamW / RMSProp                Optimisers.jl rules of the same names (EasyHybrid.jl:59 re-exports them)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# activations (Lux Dense applies `act.(W*x .+ b)`; NNModels.jl:225-230)
+# ----------------------------------------------------------------------------------------------
+
+
+def _sigmoid(x):
+    # numerically stable logistic; same value as Lux.sigmoid to rounding
+    out = np.empty_like(x)
+    pos = x >= 0
+    out[pos] = 1.0 / (1.0 + np.exp(-x[pos]))
+    ex = np.exp(x[~pos])
+    out[~pos] = ex / (1.0 + ex)
+    return out
+
+
+def act_fwd(name: str, z):
+    if name == "tanh":
+        return np.tanh(z)
+    if name == "sigmoid":
+        return _sigmoid(z)
+    if name == "relu":
+        return np.maximum(z, 0)
+    if name == "swish":
+        return z * _sigmoid(z)
+    if name == "identity":
+        return z.copy()
+    raise ValueError(f"unknown activation {name}")
+
+
+def act_bwd(name: str, z, h):
+    """d act / d z given pre-activation z and output h."""
+    one = z.dtype.type(1)
+    if name == "tanh":
+        return one - h * h
+    if name == "sigmoid":
+        return h * (one - h)
+    if name == "relu":
+        return (z > 0).astype(z.dtype)
+    if name == "swish":
+        s = _sigmoid(z)
+        return s * (one + z * (one - s))
+    if name == "identity":
+        return np.ones_like(z)
+    raise ValueError(f"unknown activation {name}")
+
+
+# ----------------------------------------------------------------------------------------------
+# mechanistic model registry: forward + hand VJP.  par/frc are dicts name -> array (B,) or scalar.
+# ----------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class MechModel:
+    name: str
+    params: Tuple[str, ...]      # canonical parameter names (kwargs of the Julia function)
+    forcings: Tuple[str, ...]    # canonical forcing names
+    outputs: Tuple[str, ...]     # outputs that can be used as targets
+
+
+def _rbq10_fwd(par, frc, dt):
+    # reco = rb .* Q10 .^ (0.1f0 .* (ta .- tref)), tref = 15f0   (test_split_data_train.jl:36-39)
+    e = dt.type(0.1) * (frc["ta"] - dt.type(15.0))
+    p = np.power(par["Q10"], e)
+    return {"reco": par["rb"] * p}, {"e": e, "p": p}
+
+
+def _rbq10_vjp(par, frc, out, aux, dout, dt):
+    d = dout["reco"]
+    return {"rb": d * aux["p"], "Q10": d * out["reco"] * aux["e"] / par["Q10"]}
+
+
+def _expo_fwd(par, frc, dt):
+    # Resp_obs = Resp0 .* exp.(k .* T)   (ExpoHybridEstim.jl:83)
+    ex = np.exp(par["k"] * frc["T"])
+    return {"Resp_obs": par["Resp0"] * ex}, {"ex": ex}
+
+
+def _expo_vjp(par, frc, out, aux, dout, dt):
+    d = dout["Resp_obs"]
+    return {"Resp0": d * aux["ex"], "k": d * out["Resp_obs"] * frc["T"]}
+
+
+def _linear_fwd(par, frc, dt):
+    # y = alpha .* x .+ beta   (LinearHM.jl:65)
+    return {"obs": par["alpha"] * frc["x"] + par["beta"]}, {}
+
+
+def _linear_vjp(par, frc, out, aux, dout, dt):
+    d = dout["obs"]
+    return {"alpha": d * frc["x"], "beta": d}
+
+
+def _expo2pool_fwd(par, frc, dt):
+    # build-defined 4-parameter variant of the Expo model (BASELINE.json config 3; not in the
+    # reference): two pools, each Resp0_i * exp(k_i * T)
+    ea = np.exp(par["ka"] * frc["T"])
+    eb = np.exp(par["kb"] * frc["T"])
+    return {"Resp_obs": par["R0a"] * ea + par["R0b"] * eb}, {"ea": ea, "eb": eb}
+
+
+def _expo2pool_vjp(par, frc, out, aux, dout, dt):
+    d = dout["Resp_obs"]
+    T = frc["T"]
+    return {
+        "R0a": d * aux["ea"], "ka": d * par["R0a"] * aux["ea"] * T,
+        "R0b": d * aux["eb"], "kb": d * par["R0b"] * aux["eb"] * T,
+    }
+
+
+def _rs_fwd(par, frc, dt):
+    # R_soil = sum_c Rb_c * Q10_c^(0.1 (T - 15))   (Rs_components.jl:45-55)
+    e = dt.type(0.1) * (frc["ta"] - dt.type(15.0))
+    aux = {"e": e}
+    tot = 0
+    for c in ("het", "root", "myc"):
+        p = np.power(par[f"Q10_{c}"], e)
+        aux[f"p_{c}"] = p
+        aux[f"R_{c}"] = par[f"Rb_{c}"] * p
+        tot = tot + aux[f"R_{c}"]
+    return {"R_soil": tot}, aux
+
+
+def _rs_vjp(par, frc, out, aux, dout, dt):
+    d = dout["R_soil"]
+    g = {}
+    for c in ("het", "root", "myc"):
+        g[f"Rb_{c}"] = d * aux[f"p_{c}"]
+        g[f"Q10_{c}"] = d * aux[f"R_{c}"] * aux["e"] / par[f"Q10_{c}"]
+    return g
+
+
+MECH: Dict[str, Tuple[MechModel, callable, callable]] = {
+    "rbq10": (MechModel("rbq10", ("rb", "Q10"), ("ta",), ("reco",)), _rbq10_fwd, _rbq10_vjp),
+    "expo": (MechModel("expo", ("Resp0", "k"), ("T",), ("Resp_obs",)), _expo_fwd, _expo_vjp),
+    "linear": (MechModel("linear", ("alpha", "beta"), ("x",), ("obs",)), _linear_fwd, _linear_vjp),
+    "expo2pool": (MechModel("expo2pool", ("R0a", "ka", "R0b", "kb"), ("T",), ("Resp_obs",)),
+                  _expo2pool_fwd, _expo2pool_vjp),
+    "rs_components": (MechModel("rs_components",
+                                ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
+                                ("ta",), ("R_soil",)), _rs_fwd, _rs_vjp),
+}
+
+
+# ----------------------------------------------------------------------------------------------
+# model spec  (mirror of constructHybridModel's arguments, GenericHybridModel.jl:89-140)
+# ----------------------------------------------------------------------------------------------
+
+
+@dataclass
+class HybridSpec:
+    n_pred: int
+    hidden: List[int]
+    mech: str
+    parameters: Dict[str, Tuple[float, float, float]]   # name -> (default, lower, upper)
+    neural: List[str]
+    glob: List[str]
+    targets: List[str] = field(default_factory=list)
+    activation: str = "tanh"
+    scale_nn_outputs: bool = False
+
+    def __post_init__(self):
+        mm = MECH[self.mech][0]
+        for n in mm.params:
+            if n not in self.parameters:
+                raise ValueError(f"parameter table lacks {n}")
+        for n in self.neural + self.glob:
+            if n not in self.parameters:
+                raise AssertionError("neural_param_names ⊆ param_names")   # GenericHybridModel.jl:110
+        if not self.targets:
+            self.targets = [mm.outputs[0]]
+        self.fixed = [n for n in self.parameters if n not in self.neural and n not in self.glob]
+
+    # -- sizes / flat layout (a11 in SURVEY section 8a) ---------------------------------------
+    @property
+    def layer_dims(self) -> List[Tuple[int, int]]:
+        dims = [self.n_pred] + list(self.hidden) + [len(self.neural)]
+        return [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]   # (out, in)
+
+    @property
+    def n_nn(self) -> int:
+        return sum(o * i + o for o, i in self.layer_dims)
+
+    @property
+    def n_theta(self) -> int:
+        return self.n_nn + len(self.glob)
+
+    def lo(self, n): return self.parameters[n][1]
+    def hi(self, n): return self.parameters[n][2]
+    def default(self, n): return self.parameters[n][0]
+
+
+def inv_sigmoid(y):
+    return np.log(y / (1 - y))                       # GenericHybridModel.jl:354
+
+
+def scale_single_param(raw, lo, hi):
+    return lo + (hi - lo) * _sigmoid(np.asarray(raw))  # GenericHybridModel.jl:348-352
+
+
+def scale_single_param_minmax(default, lo, hi):
+    return inv_sigmoid((default - lo) / (hi - lo))   # GenericHybridModel.jl:361-365
+
+
+def unpack(spec: HybridSpec, theta):
+    """flat theta -> ([(W (out,in), b (out,)), ...], raw globals).  Weights are Julia
+    column-major (out,in) inside the flat vector (ComponentArray of Lux Dense params)."""
+    Ws, off = [], 0
+    for o, i in spec.layer_dims:
+        W = theta[off:off + o * i].reshape((o, i), order="F"); off += o * i
+        b = theta[off:off + o]; off += o
+        Ws.append((W, b))
+    raw = theta[off:off + len(spec.glob)]
+    return Ws, raw
+
+
+def pack(spec: HybridSpec, Ws, raw, dtype=np.float64):
+    parts = []
+    for W, b in Ws:
+        parts += [np.asarray(W, dtype).flatten(order="F"), np.asarray(b, dtype)]
+    parts.append(np.asarray(raw, dtype).reshape(-1))
+    return np.concatenate(parts)
+
+
+def init_theta(spec: HybridSpec, seed: int, dtype=np.float32):
+    """Explicit theta0 for tests/bench: W, b ~ U(+-1/sqrt(fan_in)); global raws start from the
+    table default (start_from_default=true, GenericHybridModel.jl:244-249).  Lux's own initialiser
+    and Julia's RNG stream are not reproducible here, so parity tests always inject theta."""
+    rng = np.random.default_rng(seed)
+    Ws = []
+    for o, i in spec.layer_dims:
+        s = 1.0 / np.sqrt(i)
+        Ws.append((rng.uniform(-s, s, (o, i)), rng.uniform(-s, s, (o,))))
+    raw = [scale_single_param_minmax(np.float32(spec.default(g)), np.float32(spec.lo(g)), np.float32(spec.hi(g)))
+           for g in spec.glob]
+    return pack(spec, Ws, raw, dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# forward / loss / VJP
+# ----------------------------------------------------------------------------------------------
+
+
+def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=np.float64, keep=False):
+    """X is (P, B) like the reference (features x batch).  Returns dict with the mech outputs,
+    'parameters' (all physical params) and, if keep, the tape for the VJP."""
+    dt = np.dtype(dtype)
+    theta = np.asarray(theta, dt)
+    X = np.asarray(X, dt)
+    Ws, raw = unpack(spec, theta)
+    # k1: global params
+    glob = {}
+    for g, r in zip(spec.glob, raw):
+        glob[g] = dt.type(spec.lo(g)) + dt.type(spec.hi(g) - spec.lo(g)) * _sigmoid(r.reshape(1))
+    # k2: MLP
+    h, zs, hs = X, [], [X]
+    for li, (W, b) in enumerate(Ws):
+        z = (W @ h + b[:, None]).astype(dt)
+        last = li == len(Ws) - 1
+        h = z if last else act_fwd(spec.activation, z).astype(dt)
+        zs.append(z); hs.append(h)
+    o = h                                                              # (K, B)
+    # k3: optional sigmoid scaling of NN outputs
+    nn = {}
+    for k, n in enumerate(spec.neural):
+        nn[n] = (dt.type(spec.lo(n)) + dt.type(spec.hi(n) - spec.lo(n)) * _sigmoid(o[k])) if spec.scale_nn_outputs else o[k]
+    # k4: fixed
+    fixed = {f: np.full(1, spec.default(f), dt) for f in spec.fixed}
+    par = {**nn, **glob, **fixed}
+    frc = {k: np.asarray(v, dt) for k, v in forcings.items()}
+    mm, fwd, _ = MECH[spec.mech]
+    out, aux = fwd(par, frc, dt)
+    out = {k: v.astype(dt) for k, v in out.items()}
+    res = dict(out)
+    res["parameters"] = par
+    if keep:
+        res["_tape"] = dict(Ws=Ws, raw=raw, zs=zs, hs=hs, o=o, par=par, frc=frc, aux=aux, out=out)
+    return res
+
+
+def valid_mask(y):
+    return ~np.isnan(y)                                               # train.jl:221-232
+
+
+def loss_fn(yhat, y, mask, kind: str):
+    """src/losses/loss_fn.jl:58-179 on yhat[mask], y[mask]."""
+    a, b = yhat[mask], y[mask]
+    if kind == "mse":
+        return np.mean((a - b) ** 2)
+    if kind == "rmse":
+        return np.sqrt(np.mean((a - b) ** 2))
+    if kind == "mae":
+        return np.mean(np.abs(a - b))
+    if kind == "pearson":
+        return np.corrcoef(a, b)[0, 1]
+    if kind == "r2":
+        return 1 - np.sum((b - a) ** 2) / np.sum((b - np.mean(b)) ** 2)
+    if kind == "pearsonLoss":
+        return 1 - np.corrcoef(a, b)[0, 1]
+    if kind == "nseLoss":
+        return np.sum((a - b) ** 2) / np.sum((b - np.mean(b)) ** 2)
+    if kind == "nse":
+        return 1 - np.sum((a - b) ** 2) / np.sum((b - np.mean(b)) ** 2)
+    if kind in ("kgeLoss", "kge"):
+        r = np.corrcoef(a, b)[0, 1]
+        al = np.std(a, ddof=1) / np.std(b, ddof=1)
+        be = np.mean(a) / np.mean(b)
+        l = np.sqrt((r - 1) ** 2 + (al - 1) ** 2 + (be - 1) ** 2)
+        return l if kind == "kgeLoss" else 1 - l
+    if kind in ("pbkgeLoss", "pbkge"):
+        r = np.corrcoef(a, b)[0, 1]
+        be = np.mean(a) / np.mean(b)
+        l = np.sqrt((r - 1) ** 2 + (be - 1) ** 2)
+        return l if kind == "pbkgeLoss" else 1 - l
+    if kind == "β":
+        return np.mean(a) / np.mean(b)
+    if kind == "α":
+        return np.std(a, ddof=1) / np.std(b, ddof=1)
+    raise ValueError(kind)
+
+
+def compute_loss(spec, theta, X, forcings, targets: Dict[str, np.ndarray], dtype=np.float64, kind="mse"):
+    """train-mode compute_loss (compute_loss.jl:20-35): agg = sum over targets."""
+    res = forward(spec, theta, X, forcings, dtype)
+    tot = np.dtype(dtype).type(0)
+    for t in spec.targets:
+        y = np.asarray(targets[t], dtype)
+        tot = tot + loss_fn(res[t], y, valid_mask(y), kind)
+    return tot
+
+
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64):
+    """MSE loss (agg=sum over targets) and its gradient wrt flat theta: the hand-derived VJP of
+    SURVEY.md section 8(a).  Returns (loss, grad, n_valid per target).  A target with no valid
+    sample contributes 0 (the reference skips all-masked batches, epoch.jl:17-19)."""
+    dt = np.dtype(dtype)
+    res = forward(spec, theta, X, forcings, dtype, keep=True)
+    tp = res["_tape"]
+    B = X.shape[1]
+    loss = dt.type(0)
+    dout = {}
+    nvalid = []
+    for t in spec.targets:
+        y = np.asarray(targets[t], dt)
+        m = valid_mask(y)
+        n = int(m.sum())
+        nvalid.append(n)
+        d = np.zeros(B, dt)
+        if n > 0:
+            r = np.where(m, res[t] - np.where(m, y, 0), 0).astype(dt)
+            loss = loss + np.sum(r * r) / dt.type(n)
+            d = dt.type(2) * r / dt.type(n)
+        dout[t] = d
+    mm, _, vjp = MECH[spec.mech]
+    for oname in mm.outputs:
+        dout.setdefault(oname, np.zeros(B, dt))
+    dpar = vjp(tp["par"], tp["frc"], tp["out"], tp["aux"], dout, dt)
+    # globals: sum over samples, chain through the sigmoid scaling
+    graw = []
+    for g, r in zip(spec.glob, tp["raw"]):
+        s = _sigmoid(r.reshape(1))[0]
+        graw.append(np.sum(dpar[g]) * dt.type(spec.hi(g) - spec.lo(g)) * s * (1 - s))
+    # NN outputs
+    do = np.zeros_like(tp["o"])
+    for k, n in enumerate(spec.neural):
+        d = np.broadcast_to(dpar[n], (B,)).astype(dt)
+        if spec.scale_nn_outputs:
+            s = _sigmoid(tp["o"][k])
+            d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
+        do[k] = d
+    # MLP backward
+    gWs = []
+    delta = do
+    for li in reversed(range(len(tp["Ws"]))):
+        W, b = tp["Ws"][li]
+        hin = tp["hs"][li]
+        gW = delta @ hin.T
+        gb = delta.sum(axis=1)
+        gWs.append((gW, gb))
+        if li > 0:
+            dh = W.T @ delta
+            delta = dh * act_bwd(spec.activation, tp["zs"][li - 1], tp["hs"][li])
+    gWs.reverse()
+    grad = pack(spec, gWs, graw, dt)
+    return loss, grad, nvalid
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser rules (Optimisers.jl restated; state is a dict)
+# ----------------------------------------------------------------------------------------------
+
+
+def adam_init(n, dtype=np.float32):
+    return dict(m=np.zeros(n, dtype), v=np.zeros(n, dtype), t=0)
+
+
+def adam_step(theta, grad, st, lr=0.01, b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0):
+    """One Optimisers.Adam update in the dtype of theta (fp32 op order as Optimisers.jl:
+    mt/(1-bt1) / (sqrt(vt/(1-bt2)) + eps) * eta).  weight_decay != 0 gives Optimisers.AdamW
+    with couple=true: theta -= eta*(adam_dir + lambda*theta)."""
+    T = theta.dtype.type
+    st["t"] += 1
+    t = st["t"]
+    st["m"] = T(b1) * st["m"] + (T(1) - T(b1)) * grad
+    st["v"] = T(b2) * st["v"] + (T(1) - T(b2)) * grad * grad
+    bt1 = T(b1) ** t
+    bt2 = T(b2) ** t
+    upd = st["m"] / (T(1) - bt1) / (np.sqrt(st["v"] / (T(1) - bt2)) + T(eps)) * T(lr)
+    if weight_decay:
+        upd = upd + T(lr) * T(weight_decay) * theta
+    return (theta - upd).astype(theta.dtype)
+
+
+def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32):
+    """Run Adam over contiguous batches [(first, count), ...]; all-masked batches are skipped
+    (epoch.jl:17-19).  Returns (theta, [loss per batch])."""
+    theta = np.asarray(theta0, dtype).copy()
+    st = adam_init(theta.size, dtype)
+    losses = []
+    for first, count in batches:
+        sl = slice(first, first + count)
+        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()},
+                                 {k: v[sl] for k, v in targets.items()}, dtype)
+        if sum(nv) == 0:
+            losses.append(float("nan"))
+            continue
+        theta = adam_step(theta, g.astype(dtype), st, lr)
+        losses.append(float(l))
+    return theta, losses
+
+
+# ----------------------------------------------------------------------------------------------
+# evaluation metrics (evaluate_acc -> compute_loss eval branch, compute_loss.jl:36-66)
+# ----------------------------------------------------------------------------------------------
+
+
+def evaluate(spec, theta, X, forcings, targets, loss_types=("mse", "r2"), dtype=np.float64):
+    res = forward(spec, theta, X, forcings, dtype)
+    out = {}
+    for lt in loss_types:
+        per = {}
+        for t in spec.targets:
+            y = np.asarray(targets[t], dtype)
+            per[t] = loss_fn(res[t], y, valid_mask(y), lt)
+        per["sum"] = sum(per[t] for t in spec.targets)
+        out[lt] = per
+    return out, {t: res[t] for t in spec.targets}
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic workloads (distributions of the reference fixtures; NumPy PCG64, not Julia's RNG)
+# ----------------------------------------------------------------------------------------------
+
+RBQ10_PARAMS = {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}      # test_split_data_train.jl:42-45
+EXPO_PARAMS = {"k": (0.01, 0.0, 0.2), "Resp0": (2.0, 0.0, 8.0)}       # ExpoHybridEstim.jl:26-30
+EXPO2POOL_PARAMS = {"R0a": (1.0, 0.0, 8.0), "ka": (0.05, 0.0, 0.2), "R0b": (0.5, 0.0, 8.0), "kb": (0.02, 0.0, 0.2)}
+
+
+def rbq10_spec(hidden=(16, 16), activation="tanh", scale_nn_outputs=False):
+    return HybridSpec(2, list(hidden), "rbq10", dict(RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], activation, scale_nn_outputs)
+
+
+def make_synth_rbq10(n: int, seed: int = 42, nan_frac: float = 0.0):
+    """test/test_split_data_train.jl:15-31 (make_synth_df) with NumPy's generator."""
+    rng = np.random.default_rng(seed)
+    ta = 10 + 10 * rng.standard_normal(n)
+    sw_pot = np.abs(50 + 20 * rng.standard_normal(n))
+    dsw_pot = np.concatenate([[0.0], np.diff(sw_pot)])
+    rb_true = 3.0 + 0.02 * (sw_pot - sw_pot.mean())
+    reco = rb_true * 2.0 ** (0.1 * (ta - 15.0)) + 0.1 * rng.standard_normal(n)
+    if nan_frac > 0:
+        reco[rng.random(n) < nan_frac] = np.nan
+    X = np.stack([sw_pot, dsw_pot]).astype(np.float32)               # (P, N)
+    return X, {"ta": ta.astype(np.float32)}, {"reco": reco.astype(np.float32)}
+
+
+def expo2pool_spec(hidden=(64, 64), activation="tanh", scale_nn_outputs=True):
+    return HybridSpec(8, list(hidden), "expo2pool", dict(EXPO2POOL_PARAMS), ["R0a", "ka", "R0b", "kb"], [],
+                      ["Resp_obs"], activation, scale_nn_outputs)
+
+
+def make_synth_expo2pool(n: int, seed: int = 42, nan_frac: float = 0.0):
+    """BASELINE.json config 3 inputs: 8 predictors U(0,1), T = U(-10,30) as in
+    ExpoHybridEstim.jl:39-46, target from the two-pool formula + 5 % noise."""
+    rng = np.random.default_rng(seed)
+    X = rng.random((8, n))
+    T = rng.random(n) * 40 - 10
+    sm = X[0] * 0.8 + 0.1
+    R0a = 1.1 * np.exp(-8.0 * (sm - 0.6) ** 2)
+    R0b = 0.3 + 0.4 * X[1]
+    resp = R0a * np.exp(0.07 * T) + R0b * np.exp(0.02 * T)
+    resp = resp + 0.05 * resp.mean() * rng.standard_normal(n)
+    if nan_frac > 0:
+        resp[rng.random(n) < nan_frac] = np.nan
+    return X.astype(np.float32), {"T": T.astype(np.float32)}, {"Resp_obs": resp.astype(np.float32)}

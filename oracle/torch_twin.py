@@ -1,0 +1,107 @@
+"""PyTorch-CPU autograd twin of oracle/hybrid_oracle.py  --  TEST INFRASTRUCTURE ONLY.
+
+Second, independent derivation of the gradients: the same forward
+written op-by-op with torch tensors, differentiated by autograd's tape.  It is the closest
+structural analogue of the reference's Lux + Zygote path that can run in the build container
+(BLAS GEMMs, un-fused broadcasts, boolean-mask gather exactly as loss_fn.jl:61-63 does
+`mean(abs2, yhat[mask] .- y[mask])`).  Used (a) to validate the hand VJP in tests and (b) as the
+"eager autograd" CPU baseline figure quoted in DESIGN.md.  Never imported by the product path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import hybrid_oracle as ho
+
+
+def _act(name, z):
+    if name == "tanh":
+        return torch.tanh(z)
+    if name == "sigmoid":
+        return torch.sigmoid(z)
+    if name == "relu":
+        return torch.relu(z)
+    if name == "swish":
+        return z * torch.sigmoid(z)
+    if name == "identity":
+        return z
+    raise ValueError(name)
+
+
+def _mech(spec, par, frc):
+    m = spec.mech
+    if m == "rbq10":
+        return {"reco": par["rb"] * par["Q10"] ** (0.1 * (frc["ta"] - 15.0))}
+    if m == "expo":
+        return {"Resp_obs": par["Resp0"] * torch.exp(par["k"] * frc["T"])}
+    if m == "linear":
+        return {"obs": par["alpha"] * frc["x"] + par["beta"]}
+    if m == "expo2pool":
+        return {"Resp_obs": par["R0a"] * torch.exp(par["ka"] * frc["T"]) + par["R0b"] * torch.exp(par["kb"] * frc["T"])}
+    if m == "rs_components":
+        e = 0.1 * (frc["ta"] - 15.0)
+        return {"R_soil": sum(par[f"Rb_{c}"] * par[f"Q10_{c}"] ** e for c in ("het", "root", "myc"))}
+    raise ValueError(m)
+
+
+def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
+    dt = theta.dtype
+    off = 0
+    h = torch.as_tensor(X, dtype=dt)
+    nl = len(spec.layer_dims)
+    for li, (o, i) in enumerate(spec.layer_dims):
+        W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)
+        off += o * i
+        b = theta[off:off + o]
+        off += o
+        z = W @ h + b[:, None]
+        h = z if li == nl - 1 else _act(spec.activation, z)
+    par = {}
+    for k, n in enumerate(spec.neural):
+        par[n] = (spec.lo(n) + (spec.hi(n) - spec.lo(n)) * torch.sigmoid(h[k])) if spec.scale_nn_outputs else h[k]
+    for j, g in enumerate(spec.glob):
+        par[g] = spec.lo(g) + (spec.hi(g) - spec.lo(g)) * torch.sigmoid(theta[off + j:off + j + 1])
+    for f in spec.fixed:
+        par[f] = torch.full((1,), spec.default(f), dtype=dt)
+    frc = {k: torch.as_tensor(v, dtype=dt) for k, v in forcings.items()}
+    return _mech(spec, par, frc)
+
+
+def loss(spec, theta, X, forcings, targets):
+    out = forward(spec, theta, X, forcings)
+    tot = 0
+    for t in spec.targets:
+        y = torch.as_tensor(targets[t], dtype=theta.dtype)
+        m = ~torch.isnan(y)
+        if int(m.sum()) == 0:
+            continue
+        tot = tot + torch.mean((out[t][m] - y[m]) ** 2)
+    return tot
+
+
+def loss_and_grad(spec, theta_np, X, forcings, targets, dtype=torch.float64):
+    theta = torch.tensor(np.asarray(theta_np), dtype=dtype, requires_grad=True)
+    l = loss(spec, theta, X, forcings, targets)
+    if not torch.is_tensor(l):
+        return 0.0, np.zeros(theta.numel())
+    l.backward()
+    return float(l), theta.grad.numpy().copy()
+
+
+def train_step_timed(spec, theta_np, X, forcings, targets, n_steps, lr=0.01, threads=None):
+    """Eager autograd + torch.optim.Adam steps on one batch; returns seconds per step."""
+    import time
+    if threads:
+        torch.set_num_threads(threads)
+    theta = torch.tensor(np.asarray(theta_np, np.float32), requires_grad=True)
+    opt = torch.optim.Adam([theta], lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    Xt = torch.as_tensor(X)
+    ft = {k: torch.as_tensor(v) for k, v in forcings.items()}
+    tt = {k: torch.as_tensor(v) for k, v in targets.items()}
+    for _ in range(3):
+        opt.zero_grad(); loss(spec, theta, Xt, ft, tt).backward(); opt.step()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        opt.zero_grad(); loss(spec, theta, Xt, ft, tt).backward(); opt.step()
+    return (time.perf_counter() - t0) / n_steps

@@ -1,0 +1,37 @@
+"""Shared helpers for the tests: oracle spec <-> package model, standard cases."""
+import numpy as np
+
+import easyhybrid_jl_amd as eh
+from oracle import hybrid_oracle as ho
+
+MECH_NAME = {"rbq10": "RbQ10", "expo": "Expo_resp_model", "linear": "LinearHM", "expo2pool": "Expo2Pool",
+             "rs_components": "Rs_components"}
+
+
+def model_from_spec(spec: ho.HybridSpec):
+    mm = ho.MECH[spec.mech][0]
+    return eh.constructHybridModel([f"x{i}" for i in range(spec.n_pred)], list(mm.forcings), list(spec.targets),
+                                   MECH_NAME[spec.mech], dict(spec.parameters), list(spec.neural), list(spec.glob),
+                                   hidden_layers=list(spec.hidden), activation=spec.activation,
+                                   scale_nn_outputs=spec.scale_nn_outputs)
+
+
+def load_engine(spec, theta, X, forcings, targets, split=0, engine=None):
+    mm = ho.MECH[spec.mech][0]
+    eng = engine or model_from_spec(spec).engine()
+    eng.set_data(split, X, [forcings[f] for f in mm.forcings], [targets[t] for t in spec.targets])
+    eng.set_params(np.asarray(theta, np.float32))
+    return eng
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def rbq10_case(B, act="tanh", scale=False, nan_frac=0.0, seed=42, hidden=(16, 16), theta_seed=1):
+    spec = ho.rbq10_spec(hidden, act, scale)
+    X, f, y = ho.make_synth_rbq10(B, seed, nan_frac)
+    X = (X / np.float32(50.0)).astype(np.float32)      # keep activations out of saturation for a sharp test
+    theta = ho.init_theta(spec, theta_seed, np.float32)
+    return spec, theta, X, f, y
