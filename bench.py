@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: training samples/s + ms/step, RbQ10 hybrid
+([2,16,16,1] MLP -> rb, Q10 global), batch 65 536 per GPU, fp32, synthetic data resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: fused forward + mechanistic model + masked
+MSE + VJP kernel, partial reduction + Adam update (and, for N > 1, one RCCL all-reduce of the
+n_theta+2 raw sums in between).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+BATCH = 65536
+NBATCHES = 64                 # distinct resident batches per GPU (67 MB of 16-byte records)
+FLOP_PER_SAMPLE = 1824        # 3 x 2 x (2*16 + 16*16 + 16*1)    SURVEY.md section 8(d)
+BYTES_PER_SAMPLE = 16         # 4 x (P + F + T) floats; the mask is the NaN in the target, so no +T byte
+PEAK_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def cpu_baseline(batch, seconds=12.0):
+    """The CPU oracle (plain-C port, OpenMP over samples) timed on this box's host cores, on a
+    bounded sample of the same workload: steps of `batch` samples for ~`seconds` of CPU work."""
+    from oracle import c_oracle as co
+    from oracle import hybrid_oracle as ho
+    cores = os.cpu_count() or 1
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    X, f, y = ho.make_synth_rbq10(4 * batch, 42)
+    theta = ho.init_theta(spec, 1, np.float32)
+    co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=cores)          # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    co.train_steps(spec, theta, X, f, y, batch, 2, nthreads=cores)
+    per = (time.perf_counter() - t0) / 2
+    n = max(4, int(seconds / max(per, 1e-6)))
+    t0 = time.perf_counter()
+    co.train_steps(spec, theta, X, f, y, batch, n, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": batch * n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the plain-C oracle port, "
+                      f"OpenMP over samples on {cores} host threads",
+            "ms_per_step": 1e3 * dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import easyhybrid_jl_amd as eh
+    from easyhybrid_jl_amd.synthetic import RBQ10_PARAMS, make_synth_rbq10
+
+    B = args.batch
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    cols = make_synth_rbq10(NBATCHES * B, seed=42 + rank)           # each rank: its own shard (weak scaling)
+    X = np.stack([cols["sw_pot"], cols["dsw_pot"]]).astype(np.float32)
+    eng = model.engine(local)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_data(eh.EH_SPLIT_TRAIN, X, [cols["ta"]], [cols["reco"]])
+    eng.set_params(model.initialparameters(161803))                 # same seed on every rank: replicas start equal
+    eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
+    dp = eh.dp.DataParallel(eng) if world > 1 else None
+
+    def run(nsteps, base):
+        for s in range(nsteps):
+            first = ((base + s) % NBATCHES) * B
+            if dp is None:
+                eng.train_step(first, B, want_loss=False)
+            else:
+                dp.step(first, B)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # live kernel timing: the same K steps again with HIP events bracketing the fused step kernel
+    roof = None
+    if rank == 0:
+        eng.profile_enable(True)
+        nprof = min(args.steps, 2048)
+        if dp is None:
+            run(nprof, args.warmup + args.steps)
+        else:
+            for s in range(nprof):
+                eng.dp_grad(((s) % NBATCHES) * B, B)               # local part only: no collective inside the bracket
+        n, ms_step, ms_red = eng.profile_read()
+        eng.profile_enable(False)
+        if n and ms_step > 0:
+            tf = FLOP_PER_SAMPLE * B / (ms_step * 1e-3) / 1e12
+            gbs = BYTES_PER_SAMPLE * B / (ms_step * 1e-3) / 1e9
+            roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
+                    "traffic": None, "kernel": "eh_step_kernel<1,1,2,4,train>", "kernel_ms": ms_step, "launches_timed": n,
+                    "reduce_adam_kernel_ms": ms_red,
+                    "algorithmic": {"flop_per_launch": FLOP_PER_SAMPLE * B, "bytes_per_launch": BYTES_PER_SAMPLE * B},
+                    "hbm_achieved_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBPS}
+    loss = None
+    if dp is None:
+        loss = eng.train_step(0, B, want_loss=True)
+    fence()
+
+    if rank == 0:
+        out = {
+            "metric": "training samples/sec", "value": world * B * args.steps / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RbQ10 hybrid, MLP [2,16,16,1] tanh -> rb (sigmoid-scaled), Q10 global, MSE + Adam(0.01), "
+                                   f"batch={B} per GPU, fp32 (BASELINE.json configs[1])",
+                       "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if loss is not None:
+            out["final_loss"] = loss
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,49 +39,82 @@ __device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1
     }
 }
 
+// Where the optimiser mirrors theta into the padded parameter image the step kernel stages.
+struct EhImg {
+    float* image;
+    const int* imap;     // canonical index -> image offset (-1 for the raw globals)
+    int g_off, phi_off;
+    int glob_par[EH_MAX_PARAMS];   // global g -> canonical mech parameter j
+    float glo[EH_MAX_PARAMS], ghi[EH_MAX_PARAMS];
+};
+
+__device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float th) {
+    if (idx < im.g_off) {
+        im.image[im.imap[idx]] = th;
+    } else {   // raw global -> physical value and sigmoid slope (GenericHybridModel.jl:348-352)
+        const int g = idx - im.g_off, j = im.glob_par[g];
+        const float s = 1.0f / (1.0f + expf(-th));
+        im.image[im.phi_off + j] = im.glo[g] + (im.ghi[g] - im.glo[g]) * s;
+        im.image[im.phi_off + 8 + j] = (im.ghi[g] - im.glo[g]) * s * (1.0f - s);
+    }
+}
+
+__global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_theta) eh_image_store(im, idx, theta[idx]);
+}
+
 // Sum the per-workgroup partials of the step kernel (fixed order: deterministic), normalise by the
-// valid count when the step ran with deferred normalisation, and (APPLY) update theta in place.
-// Block = 32 columns x 8 row groups.  gradbuf = [grad | loss | counts].
+// valid count when the step ran with deferred normalisation, and (APPLY) update theta and its
+// image in place.  Block = 16 columns x 16 row groups; every load of a thread is independent, so
+// the whole slab read costs about one L2 round trip.  gradbuf = [grad | loss | counts].
 template <bool APPLY>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
-                                                        float* sc_out, EhOpt o, float* loss_slot) {
-    __shared__ float part[8][33];
-    __shared__ float red[256];
-    __shared__ float cnts[EH_MAX_TARG];
-    const int tid = threadIdx.x, p = tid & 31, q = tid >> 5;
-    const int idx = blockIdx.x * 32 + p;
+                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im) {
+    __shared__ float part[16][17];
+    __shared__ float wsum[4][EH_MAX_TARG];
+    const int tid = threadIdx.x, p = tid & 15, q = tid >> 4;
+    const int idx = blockIdx.x * 16 + p;
+    // optimiser inputs are independent of the slab: request them first so they arrive together
+    float th = 0.0f, mm = 0.0f, vv = 0.0f, bt1 = 0.0f, bt2 = 0.0f;
+    if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; }
     float s = 0.0f;
-    if (idx < n_acc)
-        for (int r = q; r < nblk; r += 8) s += slab[(size_t)r * n_acc + idx];
+    if (idx < n_acc) {
+#pragma unroll 16
+        for (int r = q; r < nblk; r += 16) s += slab[(size_t)r * n_acc + idx];
+    }
     part[q][p] = s;
-    for (int t = 0; t < T; ++t) {
-        float cs = 0.0f;
-        for (int r = tid; r < nblk; r += 256) cs += slab[(size_t)r * n_acc + n_theta + 1 + t];
-        red[tid] = cs;
-        __syncthreads();
-        for (int w = 128; w >= 1; w >>= 1) {
-            if (tid < w) red[tid] += red[tid + w];
-            __syncthreads();
-        }
-        if (tid == 0) cnts[t] = red[0];
-        __syncthreads();
+    // valid counts: every block needs them (nblk <= 256: one row per thread)
+    float cs[EH_MAX_TARG];
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) {
+        cs[t] = 0.0f;
+        if (t < T)
+            for (int r = tid; r < nblk; r += 256) cs[t] += slab[(size_t)r * n_acc + n_theta + 1 + t];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cs[t] += __shfl_xor(cs[t], off, 64);
+        if ((tid & 63) == 0) wsum[tid >> 6][t] = cs[t];
     }
     __syncthreads();
-    float ntot = 0.0f;
-    for (int t = 0; t < T; ++t) ntot += cnts[t];
+    float cnts[EH_MAX_TARG], ntot = 0.0f;
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) {
+        cnts[t] = t < T ? (wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]) : 0.0f;
+        ntot += cnts[t];
+    }
     if (q == 0 && idx < n_acc) {
         float tot = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot += part[k][p];
+        for (int k = 0; k < 16; ++k) tot += part[k][p];
         const float scale = deferred ? (cnts[0] > 0.0f ? 1.0f / cnts[0] : 0.0f) : 1.0f;
         if (idx < n_theta) {
             const float g = tot * scale;
             gradbuf[idx] = g;
             if (APPLY && ntot > 0.0f) {
-                float th = theta[idx], mm = m[idx], vv = v[idx];
-                eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
+                eh_opt_update(o, g, bt1, bt2, th, mm, vv);
                 theta[idx] = th; m[idx] = mm; v[idx] = vv;
+                eh_image_store(im, idx, th);
             }
         } else if (idx == n_theta) {
             const float loss = ntot > 0.0f ? tot * scale : __builtin_nanf("");
@@ -99,7 +132,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
 
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
 __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
-                                                       float* sc_out, EhOpt o, float* loss_slot) {
+                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const float cnt = gradbuf[n_theta + 1];
     if (idx < n_theta && cnt > 0.0f) {
@@ -107,6 +140,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
         float th = theta[idx], mm = m[idx], vv = v[idx];
         eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;
+        eh_image_store(im, idx, th);
     }
     if (idx == 0) {
         sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
@@ -190,6 +224,10 @@ struct eh_handle_s {
     eh_model_desc desc;
     EhNet net;
     const EhArchInfo* arch = nullptr;
+    int variant = 0, act = 0;
+    float* image = nullptr;
+    int* imap = nullptr;
+    EhImg img{};
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
     int C = 0, n_acc = 0, n_par = 0;
@@ -213,6 +251,7 @@ struct eh_handle_s {
     bool prof = false;
     std::vector<hipEvent_t> ev;   // 3 per step: before step kernel, between, after reduce
     size_t ev_used = 0;
+    unsigned long long* stamps = nullptr;   // diagnostic builds only
     std::string err;
 };
 
@@ -325,7 +364,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     n.g_off = off;
     n.n_theta = off + G;
-    n.act = d->activation; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
+    h->act = d->activation; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
     n.mech = d->mech; n.n_par = d->n_params;
     for (int j = 0; j < EH_MAX_PARAMS; ++j) {
         n.par_kind[j] = j < d->n_params ? d->param_kind[j] : EH_PAR_FIXED;
@@ -335,14 +374,14 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     n.F = d->n_forcings;
     for (int f = 0; f < EH_MAX_FORC; ++f) n.forc_col[f] = f < mi.n_forc ? d->forcing_index[f] : -1;
     n.T = d->n_targets;
-    for (int t = 0; t < EH_MAX_TARG; ++t) n.targ_out[t] = t < d->n_targets ? d->target_output[t] : 0;
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T;
-    if (h->n_acc > arch->red_floats || EH_EVAL_STATS * n.T > arch->red_floats) {
-        delete h;
-        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: %d accumulators exceed the kernel's reduction space %d", n.n_theta + 1 + n.T, arch->red_floats);
-    }
+    for (int vi = 0; vi < arch->nvar; ++vi)
+        if (arch->var[vi].nw * std::max(h->n_acc, EH_EVAL_STATS * n.T) > arch->var[vi].red_floats) {
+            delete h;
+            return fail(nullptr, EH_EUNSUPPORTED, "eh_create: %d accumulators exceed the kernel's reduction space", n.n_theta + 1 + n.T);
+        }
 #define HIPCHK_C(expr)                                                            \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \
@@ -355,7 +394,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipSetDevice(h->device));
     HIPCHK_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    HIPCHK_C(arch->prepare());
+    for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
     const size_t nt = (size_t)n.n_theta;
     HIPCHK_C(hipMalloc(&h->theta, nt * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->m, nt * sizeof(float)));
@@ -368,6 +407,40 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipMemset(h->m, 0, nt * sizeof(float)));
     HIPCHK_C(hipMemset(h->v, 0, nt * sizeof(float)));
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
+    {   // parameter image: canonical index -> padded LDS-layout offset
+        std::vector<int> imap(nt, -1);
+        int inl = n.P;
+        for (int l = 0; l <= n.NL; ++l) {
+            const int o = l < n.NL ? d->hidden[l] : K;
+            for (int col = 0; col < inl; ++col)
+                for (int row = 0; row < o; ++row) {
+                    int off;
+                    if (l == 0) off = arch->w0_off + row * arch->s0 + col;
+                    else if (l < n.NL) off = arch->wh_off + (l - 1) * arch->hp * arch->sh + row * arch->sh + col;
+                    else off = arch->wo_off + row * arch->sh + col;
+                    imap[n.w_off[l] + row + o * col] = off;
+                }
+            for (int row = 0; row < o; ++row) imap[n.b_off[l] + row] = arch->b_off + l * arch->hp + row;
+            inl = o;
+        }
+        std::vector<float> img0((size_t)arch->img_floats, 0.0f);
+        for (int j = 0; j < d->n_params; ++j)
+            if (d->param_kind[j] == EH_PAR_FIXED) img0[arch->phi_off + j] = d->param_default[j];   // st.fixed, GenericHybridModel.jl:289-303
+        HIPCHK_C(hipMalloc(&h->image, img0.size() * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->imap, nt * sizeof(int)));
+        HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK_C(hipMemcpy(h->imap, imap.data(), nt * sizeof(int), hipMemcpyHostToDevice));
+        EhImg& im = h->img;
+        im.image = h->image; im.imap = h->imap; im.g_off = n.g_off; im.phi_off = arch->phi_off;
+        for (int j = 0; j < d->n_params; ++j)
+            if (d->param_kind[j] == EH_PAR_GLOBAL) {
+                const int g = d->param_index[j];
+                im.glob_par[g] = j; im.glo[g] = d->param_lower[j]; im.ghi[g] = d->param_upper[j];
+            }
+        hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, h->theta, (int)nt, h->img);
+        HIPCHK_C(hipGetLastError());
+        HIPCHK_C(hipStreamSynchronize(h->stream));
+    }
 #undef HIPCHK_C
     *out = h;
     return EH_OK;
@@ -380,6 +453,7 @@ int32_t eh_destroy(eh_handle* h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->theta); (void)hipFree(h->m); (void)hipFree(h->v); (void)hipFree(h->sc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -410,6 +484,11 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "max_blocks")) {
         if (value < 1 || value > 256) return fail(h, EH_EINVAL, "max_blocks must be 1..256 (one workgroup per CU)");
         h->max_blocks = (int)value;
+        return EH_OK;
+    }
+    if (!strcmp(name, "variant")) {
+        if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
+        h->variant = (int)value;
         return EH_OK;
     }
     return fail(h, EH_EINVAL, "unknown option %s", name);
@@ -473,6 +552,9 @@ int32_t eh_set_params(eh_handle* h, const float* theta, int64_t n) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->theta, theta, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->theta, (int)n, h->img);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return EH_OK;
 }
 
@@ -489,9 +571,10 @@ int32_t eh_get_params(eh_handle* h, float* theta, int64_t n) {
 
 // ---- internal launch helpers ---------------------------------------------------------------------
 static int grid_for(const eh_handle* h, long long count) {
-    const long long mt = 16LL * h->arch->nt;
+    const EhVariant& v = h->arch->var[h->variant];
+    const long long mt = 16LL * v.nt;
     const long long ntiles = (count + mt - 1) / mt;
-    return (int)std::max<long long>(1, std::min<long long>((ntiles + 3) / 4, h->max_blocks));
+    return (int)std::max<long long>(1, std::min<long long>((ntiles + v.nw - 1) / v.nw, h->max_blocks));
 }
 
 static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* grid_out) {
@@ -502,11 +585,12 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     }
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
-    a.theta = h->theta; a.slab = h->slab; a.n_acc = h->n_acc;
+    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
     a.inv_n = net.T > 1 ? h->inv_n : nullptr;
+    a.stamps = h->stamps;
     const int grid = grid_for(h, count);
     *grid_out = grid;
-    HIPCHK(h, h->arch->launch(EH_MODE_TRAIN, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, grid, h->stream, &h->net, &a));
     return EH_OK;
 }
 
@@ -522,7 +606,7 @@ static int ensure_events(eh_handle* h, size_t need) {
 // fused step on the train split.  apply = update theta; loss_slot = device float for the loss.
 static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool apply, bool raw, float* loss_slot) {
     const EhNet& net = h->net;
-    const bool prof = h->prof && apply && h->ev_used + 3 <= 3 * 8192;
+    const bool prof = h->prof && h->ev_used + 3 <= 3 * 8192;
     if (prof) {
         int rc = ensure_events(h, h->ev_used + 3);
         if (rc) return rc;
@@ -533,16 +617,16 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (rc) return rc;
     if (prof) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
-    const int rgrid = (h->n_acc + 31) / 32;
+    const int rgrid = (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     if (apply) {
         hipLaunchKernelGGL(eh_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot);
+                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot, h->img);
         h->sc_sel ^= 1;
     } else {
         hipLaunchKernelGGL(eh_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot);
+                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot, h->img);
     }
     HIPCHK(h, hipGetLastError());
     if (prof) {
@@ -585,13 +669,13 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     }
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = nullptr; a.first = first; a.count = count;
-    a.theta = h->theta; a.slab = h->slab; a.n_acc = EH_EVAL_STATS * net.T;
+    a.image = h->image; a.slab = h->slab; a.n_acc = EH_EVAL_STATS * net.T;
     a.yhat = yhat ? h->out_buf : nullptr;
     a.pout = params ? h->out_buf + (yhat ? (long long)net.T * count : 0) : nullptr;
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     const int grid = count > 0 ? grid_for(h, count) : 1;
-    HIPCHK(h, h->arch->launch(EH_MODE_EVAL, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, grid, h->stream, &h->net, &a));
     std::vector<float> part((size_t)grid * a.n_acc);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -807,7 +891,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     const int nt = h->net.n_theta;
     hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, h->theta, h->m, h->v, sc_in, sc_out, h->opt,
-                       h->loss_hist);
+                       h->loss_hist, h->img);
     HIPCHK(h, hipGetLastError());
     h->sc_sel ^= 1;
     if (loss_out) {
@@ -826,6 +910,20 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
         case EH_BUF_OPT_V: *dev_ptr = h->v; *n_floats = h->net.n_theta; return EH_OK;
         default: return fail(h, EH_EINVAL, "eh_device_buffer: which = %d", which);
     }
+}
+
+int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n) {
+    if (!h || !out || n < 0 || n > 32) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->stamps) {   // first call arms the buffer; later calls read it
+        HIPCHK(h, hipMalloc(&h->stamps, 32 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->stamps, 0, 32 * sizeof(unsigned long long)));
+        memset(out, 0, (size_t)n * sizeof(uint64_t));
+        return EH_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->stamps, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return EH_OK;
 }
 
 int32_t eh_profile_enable(eh_handle* h, int32_t on) {

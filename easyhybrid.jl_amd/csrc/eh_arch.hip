@@ -1,4 +1,5 @@
 // One compiled kernel shape; built with -DEH_NBI=.. -DEH_NBH=.. -DEH_NL=.. (see Makefile).
+// -DEH_EXTRA_VARIANTS adds the (NT, NW) variants used for tuning the small shapes.
 #include "eh_arch.hpp"
 
 #ifndef EH_NBI
@@ -6,28 +7,63 @@
 #endif
 
 namespace {
-constexpr int NT = eh_pick_nt<EH_NBI, EH_NBH, EH_NL>();
-using Geom = EhGeom<EH_NBI, EH_NBH, EH_NL, NT>;
-static_assert(sizeof(float) * Geom::TOTAL_FLOATS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+constexpr int NT0 = eh_pick_nt<EH_NBI, EH_NBH, EH_NL>();
 
-hipError_t prepare() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, EH_MODE_TRAIN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * Geom::TOTAL_FLOATS));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, EH_MODE_EVAL>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * Geom::TOTAL_FLOATS));
-}
+template <int NT, int NW>
+struct Var {
+    using Geom = EhGeom<EH_NBI, EH_NBH, EH_NL, NT, NW>;
+    static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
+    static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
 
-hipError_t launch(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
-    const size_t lds = sizeof(float) * Geom::TOTAL_FLOATS;
-    if (mode == EH_MODE_TRAIN)
-        hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, EH_MODE_TRAIN>), dim3(grid), dim3(256), lds, stream, *net, *args);
-    else
-        hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, EH_MODE_EVAL>), dim3(grid), dim3(256), lds, stream, *net, *args);
-    return hipGetLastError();
-}
+    template <int ACT, int MODE>
+    static hipError_t prep1() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    }
+    template <int ACT>
+    static hipError_t prep2() {
+        hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
+        return e != hipSuccess ? e : prep1<ACT, EH_MODE_EVAL>();
+    }
+    static hipError_t prepare() {
+        hipError_t e;
+        if ((e = prep2<EH_ACT_TANH>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_SIGMOID>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_RELU>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
+        return prep2<EH_ACT_IDENTITY>();
+    }
+    template <int ACT>
+    static void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode == EH_MODE_TRAIN)
+            hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, EH_MODE_TRAIN>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
+        else
+            hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, EH_MODE_EVAL>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
+    }
+    static hipError_t launch(int mode, int act, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        switch (act) {
+            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
+            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
+            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
+            case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, grid, stream, net, args); break;
+            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    static constexpr EhVariant info() { return EhVariant{NT, NW, LDS, NW * Geom::WAVE_WS, &prepare, &launch}; }
+};
 
-const EhArchInfo info = {EH_NBI, EH_NBH, EH_NL, NT, sizeof(float) * Geom::TOTAL_FLOATS, 4 * Geom::WAVE_WS, &prepare, &launch};
+using G0 = EhGeom<EH_NBI, EH_NBH, EH_NL, NT0, 4>;
+const EhArchInfo info = {
+    EH_NBI, EH_NBH, EH_NL,
+    G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
+#ifdef EH_EXTRA_VARIANTS
+    4, {Var<NT0, 4>::info(), Var<2, 8>::info(), Var<1, 16>::info(), Var<1, 8>::info()}
+#else
+    1, {Var<NT0, 4>::info(), {}, {}, {}}
+#endif
+};
 }   // namespace
 
 #define EH_CAT_(a, b, c) eh_arch_##a##_##b##_##c

@@ -3,25 +3,34 @@
 //   NBI  input  blocks of 16  (P <= 16*NBI)
 //   NBH  hidden blocks of 16  (every hidden width <= 16*NBH)
 //   NL   hidden layers
-// and the macro-tile size NT (x16 samples per wave) is the largest of {4,2,1} whose LDS image fits
-// the 160 KiB of a gfx950 CU with one 4-wave workgroup per CU.
+// for every activation and both modes.  A shape has one or more (NT, NW) variants: NT x16 samples per
+// wave macro-tile, NW waves per workgroup; variant 0 is the default (largest NT in {4,2,1} whose LDS
+// image fits the 160 KiB of a gfx950 CU with a 4-wave workgroup).
 #pragma once
 #include "eh_device.hpp"
 
-struct EhArchInfo {
-    int nbi, nbh, nl, nt;
+struct EhVariant {
+    int nt, nw;
     size_t lds_bytes;        // dynamic LDS per workgroup
-    int red_floats;          // floats available to the end-of-kernel reduction (must be >= n_acc)
-    hipError_t (*prepare)(void);   // raises the dynamic-LDS limit of both kernels
-    hipError_t (*launch)(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
+    int red_floats;          // floats available to the end-of-kernel reduction (needs nw * n_acc)
+    hipError_t (*prepare)(void);   // raises the dynamic-LDS limit of every kernel of the variant
+    hipError_t (*launch)(int mode, int act, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
+};
+
+struct EhArchInfo {
+    int nbi, nbh, nl;
+    // parameter-image geometry (EhGeom; independent of the variant)
+    int ip, hp, s0, sh, w0_off, wh_off, wo_off, b_off, phi_off, img_floats;
+    int nvar;
+    EhVariant var[4];
 };
 
 constexpr size_t EH_LDS_LIMIT = 160 * 1024;
 
 template <int NBI, int NBH, int NL>
 constexpr int eh_pick_nt() {
-    if (sizeof(float) * EhGeom<NBI, NBH, NL, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
-    if (sizeof(float) * EhGeom<NBI, NBH, NL, 2>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 2;
+    if (sizeof(float) * EhGeom<NBI, NBH, NL, 4, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
+    if (sizeof(float) * EhGeom<NBI, NBH, NL, 2, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 2;
     return 1;
 }
 

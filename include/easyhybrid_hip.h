@@ -178,6 +178,10 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
 int32_t eh_profile_enable(eh_handle* h, int32_t on);
 int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_kernel, double* mean_ms_reduce_kernel);
 
+/* diagnostic builds (make STAMPS=1) only: in-kernel phase stamps of workgroup 0 as (shader clock, 100 MHz clock)
+ * pairs; the first call arms the buffer.  A normal build leaves the buffer zero. */
+int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
+
 /* tuning knobs (name/value), e.g. "max_blocks" */
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
 
