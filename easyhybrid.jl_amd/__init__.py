@@ -11,6 +11,6 @@ from .models import (Expo2Pool, Expo_resp_model, HybridModel, LinearHM, MECH_REG
                      inv_hard_sigmoid, inv_sigmoid, scale_single_param, scale_single_param_minmax, sigmoid)
 from .train import (Adam, AdamW, DataConfig, Descent, EpochSnapshot, RMSProp, TrainConfig, TrainResults,
                     check_training_loss, isbetter, prepare_data, split_data, train, validate_config)
-from . import dp
+from . import dp, synthetic
 
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = _lib.EH_SPLIT_TRAIN, _lib.EH_SPLIT_VAL

@@ -86,7 +86,7 @@ def loss_and_grad(spec, theta_np, X, forcings, targets, dtype=torch.float64):
     if not torch.is_tensor(l):
         return 0.0, np.zeros(theta.numel())
     l.backward()
-    return float(l), theta.grad.numpy().copy()
+    return float(l.detach()), theta.grad.numpy().copy()
 
 
 def train_step_timed(spec, theta_np, X, forcings, targets, n_steps, lr=0.01, threads=None):

@@ -1,0 +1,90 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/easyhybrid_hip.h declares, its structs match the ctypes mirror, and -- with no GPU in the
+container -- every compute entry point fails loudly instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import easyhybrid_jl_amd as eh
+from easyhybrid_jl_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "easyhybrid_hip.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(eh_[a-z_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(L.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
+    assert lib.eh_version() == 1
+
+
+def test_struct_layout_matches_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "easyhybrid_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu\\n", sizeof(eh_model_desc), sizeof(eh_target_metrics),'
+                   ' offsetof(eh_model_desc, param_default), offsetof(eh_model_desc, n_targets));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    a, b, c, d = map(int, subprocess.check_output([str(exe)]).split())
+    assert a == C.sizeof(L.ModelDesc) and b == C.sizeof(L.TargetMetrics)
+    assert c == L.ModelDesc.param_default.offset and d == L.ModelDesc.n_targets.offset
+
+
+def _model(**kw):
+    args = dict(hidden_layers=[16, 16])
+    args.update(kw)
+    return eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, {"rb": (3, 0, 13), "Q10": (2, 1, 4)}, ["rb"], ["Q10"], **args)
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly_no_cpu_fallback():
+    with pytest.raises(eh.EngineError, match="no HIP device"):
+        _model().engine()
+
+
+def test_create_rejects_bad_descriptors_before_touching_a_device():
+    lib = L.lib()
+    h = C.c_void_p()
+    d = _model().to_desc()
+    d.mech = 99
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EUNSUPPORTED and b"unknown mechanistic model" in lib.eh_last_error(None)
+    d = _model().to_desc()
+    d.struct_size = 4
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL
+    d = _model().to_desc()
+    d.hidden[0] = 512                                     # wider than the compiled kernels
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EUNSUPPORTED and b"no compiled kernel" in lib.eh_last_error(None)
+    d = _model().to_desc()
+    d.param_kind[0] = L.PAR_FIXED                         # no neural parameter left
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL
+    assert lib.eh_create(None, C.byref(h)) == L.EH_EINVAL
+    assert lib.eh_destroy(None) == L.EH_OK
+
+
+def test_descriptor_from_model():
+    m = _model(activation="swish", scale_nn_outputs=True, hidden_layers=[32, 24, 8])
+    d = m.to_desc(3)
+    assert (d.device, d.n_predictors, d.n_hidden, list(d.hidden)[:3]) == (3, 2, 3, [32, 24, 8])
+    assert d.activation == L.ACTIVATIONS["swish"] and d.scale_nn_outputs == 1 and d.mech == 0 and d.n_params == 2
+    assert list(d.param_kind)[:2] == [L.PAR_NEURAL, L.PAR_GLOBAL] and list(d.param_index)[:2] == [0, 0]
+    assert (d.param_default[0], d.param_lower[0], d.param_upper[0]) == (3.0, 0.0, 13.0)
+    assert (d.n_forcings, d.forcing_index[0], d.n_targets, d.target_output[0]) == (1, 0, 1, 0)
+    assert m.n_theta == (2 * 32 + 32) + (32 * 24 + 24) + (24 * 8 + 8) + (8 * 1 + 1) + 1

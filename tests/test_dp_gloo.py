@@ -1,0 +1,75 @@
+"""Data-parallel protocol on CPU: world_size 2, gloo.  Each rank makes the raw partial vector
+[grad_unnormalised | sse | n_valid] of ITS shard (here with the oracle standing in for the HIP
+kernel: tests may use it as the checker), runs the package's all-reduce + normalisation, and must
+land on the full-batch gradient -- including when the shards hold different numbers of NaN targets,
+which is exactly where averaging per-shard means would be wrong."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from easyhybrid_jl_amd import dp
+from oracle import hybrid_oracle as ho
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _raw_partials(spec, theta, X, f, y):
+    """unnormalised sums of one shard: grad*n, sse, n  (what eh_dp_grad leaves in EH_BUF_GRAD)"""
+    l, g, nv = ho.loss_and_grad(spec, theta, X, f, y)
+    n = float(sum(nv))
+    return np.concatenate([g * n, [l * n if n else 0.0, n]])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    N = 257                                                       # odd: shards differ in size
+    X, f, y = ho.make_synth_rbq10(N, 3, 0.0)
+    X = X / 50
+    y["reco"][:100][::2] = np.nan                                 # all the NaNs land in rank 0's shard
+    theta = ho.init_theta(spec, 4, np.float64)
+    lo, hi = dp.shard_range(N, rank, world)
+    buf = torch.from_numpy(_raw_partials(spec, theta, X[:, lo:hi], {k: v[lo:hi] for k, v in f.items()}, {k: v[lo:hi] for k, v in y.items()}))
+    dp.allreduce_partials(buf)
+    g, loss, n = dp.normalise(buf, spec.n_theta)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta, X, f, y)
+    ok = abs(loss - l0) <= 1e-12 * abs(l0) and n == sum(nv0) and float(np.max(np.abs(g.numpy() - g0))) <= 1e-12 * np.max(np.abs(g0))
+    # the wrong protocol (mean of per-shard means) must NOT agree here
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_dp_allreduce_of_raw_sums_matches_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_mean_of_shard_means_would_be_wrong():
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    X, f, y = ho.make_synth_rbq10(200, 3, 0.0)
+    X = X / 50
+    y["reco"][:100][::2] = np.nan
+    th = ho.init_theta(spec, 4, np.float64)
+    l0, g0, _ = ho.loss_and_grad(spec, th, X, f, y)
+    halves = [ho.loss_and_grad(spec, th, X[:, a:b], {k: v[a:b] for k, v in f.items()}, {k: v[a:b] for k, v in y.items()}) for a, b in ((0, 100), (100, 200))]
+    naive = 0.5 * (halves[0][1] + halves[1][1])
+    assert np.max(np.abs(naive - g0)) > 1e-3 * np.max(np.abs(g0))
+    buf = torch.from_numpy(sum(np.concatenate([g * sum(nv), [l * sum(nv), sum(nv)]]) for l, g, nv in halves))
+    g, loss, n = dp.normalise(buf, spec.n_theta)
+    assert np.max(np.abs(g.numpy() - g0)) <= 1e-12 * np.max(np.abs(g0)) and loss == pytest.approx(l0, rel=1e-12)

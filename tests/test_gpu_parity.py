@@ -1,9 +1,15 @@
 """-m gpu parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
-seeded inputs.  Tolerance: BASELINE.json north_star = 1e-5 relative (fp32); the oracle is
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Tolerance: north_star = 1e-5 relative (fp32); the oracle is
 evaluated in fp64 so its own rounding does not eat the budget."""
+import glob
+import json
+import os
+
 import numpy as np
 import pytest
 
+import easyhybrid_jl_amd as eh
 from oracle import hybrid_oracle as ho
 from tests import util
 
@@ -11,20 +17,124 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.mark.parametrize("act", ["tanh", "sigmoid", "relu", "swish"])
-@pytest.mark.parametrize("scale", [False, True])
-@pytest.mark.parametrize("B,nan_frac", [(12, 0.0), (64, 0.2), (1024, 0.2), (1000, 0.05)])
-def test_rbq10_loss_and_grad(act, scale, B, nan_frac):
-    spec, theta, X, f, y = util.rbq10_case(B, act, scale, nan_frac)
-    eng = util.load_engine(spec, theta, X, f, y)
-    loss, grad, nv = eng.loss_and_grad()
-    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+def _check_grad(spec, theta, X, f, y, eng=None, **kw):
+    own = eng is None
+    eng = eng or util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad(**kw)
+    if "idx" in kw:
+        ix = kw["idx"]
+        X, f, y = X[:, ix], {k: v[ix] for k, v in f.items()}, {k: v[ix] for k, v in y.items()}
+    elif "first" in kw:
+        sl = slice(kw["first"], kw["first"] + kw["count"])
+        X, f, y = X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}
+    l0, g0, nv0 = ho.loss_and_grad(spec, np.asarray(theta, np.float64), X, f, y)
     assert nv == sum(nv0)
     assert abs(loss - l0) <= TOL * abs(l0)
     assert util.relerr(grad, g0) <= TOL
+    if own:
+        eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# loss + gradient: activations x scaling x mask patterns x ragged sizes (RbQ10 = BASELINE configs 0/1)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "relu", "swish"])
+@pytest.mark.parametrize("scale", [False, True])
+@pytest.mark.parametrize("B,nan_frac", [(12, 0.0), (64, 0.2), (1024, 0.2), (1000, 0.05), (1, 0.0), (65, 0.5)])
+def test_rbq10_loss_and_grad(act, scale, B, nan_frac):
+    _check_grad(*util.rbq10_case(B, act, scale, nan_frac))
+
+
+@pytest.mark.parametrize("hidden", [(16,), (32, 32), (16, 16, 16), (24, 8), (64, 64), (48, 33, 16), (64,), (40, 64, 24)])
+def test_other_mlp_shapes(hidden):
+    _check_grad(*util.rbq10_case(300, "tanh", True, 0.1, hidden=hidden))
+
+
+def test_identity_activation():
+    spec, theta, X, f, y = util.rbq10_case(200, "tanh", False, 0.1)
+    spec.activation = "identity"
+    _check_grad(spec, theta, X, f, y)
+
+
+def test_expo2pool_config3_shape():
+    # BASELINE.json configs[2]: MLP [8,64,64,4], four neural parameters, build-defined two-pool Expo model
+    spec = ho.expo2pool_spec((64, 64), "tanh", True)
+    X, f, y = ho.make_synth_expo2pool(1000, 5, 0.1)
+    _check_grad(spec, ho.init_theta(spec, 2, np.float32), X, f, y)
+
+
+def test_reference_expo_model_one_predictor():
+    # projects/ExpoHybrid/ExpoHybridEstim.jl: Resp0 neural, k global, sigmoid activation (without its BatchNorm)
+    spec = ho.HybridSpec(1, [16, 16], "expo", dict(ho.EXPO_PARAMS), ["Resp0"], ["k"], ["Resp_obs"], "sigmoid", False)
+    rng = np.random.default_rng(0)
+    T = (rng.random(500) * 40 - 10).astype(np.float32)
+    SM = (rng.random(500) * 0.8 + 0.1).astype(np.float32)
+    resp = (1.1 * np.exp(-8.0 * (SM - 0.6) ** 2) * np.exp(0.07 * T)).astype(np.float32)
+    _check_grad(spec, ho.init_theta(spec, 3, np.float32), SM[None], {"T": T}, {"Resp_obs": resp})
+
+
+@pytest.mark.parametrize("mech,neural,glob", [
+    ("linear", ["alpha"], ["beta"]),
+    ("linear", ["alpha", "beta"], []),
+    ("rs_components", ["Rb_het", "Rb_root", "Rb_myc"], ["Q10_het", "Q10_root", "Q10_myc"]),
+    ("rs_components", ["Rb_het", "Rb_root", "Rb_myc"], ["Q10_het"]),          # two Q10s fixed at their defaults
+    ("rbq10", ["rb", "Q10"], []),                                             # Q10 predicted by the network too
+    ("expo2pool", ["R0a", "R0b"], ["ka", "kb"]),
+])
+def test_parameter_sources_neural_global_fixed(mech, neural, glob):
+    mm = ho.MECH[mech][0]
+    tabs = {"linear": {"alpha": (1.0, -2.0, 3.0), "beta": (0.5, -1.0, 2.0)}, "rbq10": dict(ho.RBQ10_PARAMS), "expo2pool": dict(ho.EXPO2POOL_PARAMS),
+            "rs_components": {**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in ("het", "root", "myc")}, **{f"Q10_{c}": (2.0 + i * 0.3, 1.0, 4.0) for i, c in enumerate(("het", "root", "myc"))}}}
+    spec = ho.HybridSpec(5, [32, 16], mech, tabs[mech], neural, glob, [mm.outputs[0]], "tanh", True)
+    rng = np.random.default_rng(1)
+    B = 400
+    X = rng.standard_normal((5, B)).astype(np.float32)
+    frc = {mm.forcings[0]: rng.uniform(-5, 25, B).astype(np.float32)}
+    yv = rng.uniform(0.5, 4, B).astype(np.float32)
+    yv[rng.random(B) < 0.1] = np.nan
+    _check_grad(spec, ho.init_theta(spec, 4, np.float32), X, frc, {mm.outputs[0]: yv})
+
+
+def test_wide_input_two_blocks():
+    # P = 20 > 16 exercises the second input block and the scalar (C % 4 != 0) record path: C = 20 + 1 + 1
+    spec = ho.HybridSpec(20, [32, 32], "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "tanh", True)
+    rng = np.random.default_rng(2)
+    B = 333
+    X = rng.standard_normal((20, B)).astype(np.float32) * 0.3
+    _check_grad(spec, ho.init_theta(spec, 5, np.float32), X, {"ta": rng.uniform(0, 30, B).astype(np.float32)},
+                {"reco": rng.uniform(1, 9, B).astype(np.float32)})
+
+
+def test_window_and_gather_indices():
+    spec, theta, X, f, y = util.rbq10_case(2000, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    _check_grad(spec, theta, X, f, y, eng, first=137, count=701)
+    idx = np.random.default_rng(3).permutation(2000)[:555].astype(np.int32)
+    _check_grad(spec, theta, X, f, y, eng, idx=idx)
+    with pytest.raises(ValueError):
+        eng.loss_and_grad(first=1900, count=200)
+    with pytest.raises(ValueError):
+        eng.loss_and_grad(idx=np.array([0, 2000], np.int32))
     eng.close()
 
 
+def test_all_masked_batch():
+    spec, theta, X, f, y = util.rbq10_case(128, "tanh", True)
+    y = {"reco": np.full(128, np.nan, np.float32)}
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad()
+    assert np.isnan(loss) and nv == 0 and not grad.any()
+    eng.opt_init("Adam", 0.01)
+    l = eng.train_step(0, 128)
+    assert np.isnan(l) and np.array_equal(eng.get_params(), theta)            # skipped: src/training/epoch.jl:17-19
+    m, v, bt = eng.get_opt_state()
+    assert not m.any() and not v.any() and bt.tolist() == [np.float32(0.9), np.float32(0.999)]
+    eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# forward / eval
+# ----------------------------------------------------------------------------------------------
 def test_forward_matches_oracle():
     spec, theta, X, f, y = util.rbq10_case(300, "tanh", True, 0.1)
     eng = util.load_engine(spec, theta, X, f, y)
@@ -33,4 +143,254 @@ def test_forward_matches_oracle():
     assert util.relerr(out["reco"], ref["reco"]) <= TOL
     assert util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= TOL
     assert util.relerr(out["parameters"]["Q10"], np.broadcast_to(ref["parameters"]["Q10"], (300,))) <= TOL
+    part = eng.forward(0, 100, 50, params=False)
+    assert np.array_equal(part["reco"], out["reco"][100:150])
     eng.close()
+
+
+def test_eval_metrics_match_loss_fn():
+    spec, theta, X, f, y = util.rbq10_case(5000, "tanh", True, 0.15)
+    eng = util.load_engine(spec, theta, X, f, y, split=1)
+    metrics, pred = eng.eval(1, predictions=True)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)["reco"]
+    yy = y["reco"].astype(np.float64)
+    mask = ~np.isnan(yy)
+    assert metrics[0]["n"] == mask.sum()
+    for k in ("mse", "rmse", "mae", "r2", "nse", "pearson", "kge", "pbkge"):
+        assert metrics[0][k] == pytest.approx(ho.loss_fn(ref, yy, mask, k), rel=2e-5, abs=2e-6), k
+    assert metrics[0]["beta"] == pytest.approx(ho.loss_fn(ref, yy, mask, "β"), rel=2e-5)
+    assert metrics[0]["alpha"] == pytest.approx(ho.loss_fn(ref, yy, mask, "α"), rel=2e-5)
+    assert util.relerr(pred["reco"], ref) <= TOL
+    eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser trajectory
+# ----------------------------------------------------------------------------------------------
+def test_adam_trajectory_matches_oracle():
+    spec, theta, X, f, y = util.rbq10_case(1024, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 128, 128) for i in range(8)]
+    losses = [eng.train_step(a, b) for a, b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    # Adam's first steps are sign-like (m/sqrt(v) ~ +-1): rounding in g flips nothing but shows up at ~1e-6 absolute
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    m, v, bt = eng.get_opt_state()
+    assert bt[0] == pytest.approx(np.float32(0.9) ** 9, rel=1e-6) and bt[1] == pytest.approx(np.float32(0.999) ** 9, rel=1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("rule,kw", [("Descent", dict(lr=0.05)), ("RMSProp", dict(lr=0.003, beta1=0.9)), ("AdamW", dict(lr=0.01, weight_decay=0.1))])
+def test_other_optimiser_rules(rule, kw):
+    spec, theta, X, f, y = util.rbq10_case(512, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init(rule, **kw)
+    th = theta.astype(np.float32).copy()
+    st = ho.adam_init(th.size)
+    vq = np.zeros_like(th)
+    for a in range(0, 512, 128):
+        eng.train_step(a, 128)
+        sl = slice(a, a + 128)
+        _, g, _ = ho.loss_and_grad(spec, th, X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}, np.float32)
+        g = g.astype(np.float32)
+        if rule == "Descent":
+            th = th - np.float32(kw["lr"]) * g
+        elif rule == "RMSProp":
+            vq = np.float32(0.9) * vq + np.float32(0.1) * g * g
+            th = th - g * (np.float32(kw["lr"]) / (np.sqrt(vq) + np.float32(1e-8)))
+        else:
+            th = ho.adam_step(th, g, st, lr=kw["lr"], weight_decay=kw["weight_decay"])
+    assert np.max(np.abs(eng.get_params() - th)) <= 3e-5 * max(1.0, float(np.max(np.abs(th))))
+    eng.close()
+
+
+def test_set_get_opt_state_round_trip_resumes_identically():
+    spec, theta, X, f, y = util.rbq10_case(512, "tanh", True)
+    a = util.load_engine(spec, theta, X, f, y); a.opt_init("Adam", 0.01)
+    for i in range(3):
+        a.train_step(i * 128, 128)
+    b = util.load_engine(spec, a.get_params(), X, f, y); b.opt_init("Adam", 0.01)
+    b.set_opt_state(*a.get_opt_state())
+    a.train_step(384, 128); b.train_step(384, 128)
+    assert np.array_equal(a.get_params(), b.get_params())
+    a.close(); b.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# epoch driver
+# ----------------------------------------------------------------------------------------------
+def test_epoch_unshuffled_equals_manual_steps_with_partial_last_batch():
+    spec, theta, X, f, y = util.rbq10_case(1000, "tanh", True, 0.1)
+    a = util.load_engine(spec, theta, X, f, y); a.opt_init("Adam", 0.01)
+    b = util.load_engine(spec, theta, X, f, y); b.opt_init("Adam", 0.01)
+    mean_loss, ns = a.train_epoch(300, shuffle=False)
+    losses = [b.train_step(s, min(300, 1000 - s)) for s in range(0, 1000, 300)]
+    assert ns == 4 and np.array_equal(a.get_params(), b.get_params())
+    assert mean_loss == pytest.approx(np.mean(losses), rel=1e-6)
+    a.close(); b.close()
+
+
+def test_epoch_shuffle_is_a_permutation_and_trains():
+    # with Descent(lr=0) nothing moves, so the mean over the shuffled full-batch epoch must equal the
+    # unshuffled one: every sample is visited exactly once whatever the permutation
+    spec, theta, X, f, y = util.rbq10_case(4096, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Descent", 0.0)
+    l_plain, _ = eng.train_epoch(4096, shuffle=False)
+    l_shuf, _ = eng.train_epoch(4096, seed=7, shuffle=True)
+    assert l_shuf == pytest.approx(l_plain, rel=1e-5)
+    eng.opt_init("Adam", 0.01)
+    first, _ = eng.train_epoch(256, seed=1, shuffle=True)
+    for e in range(2, 12):
+        last, _ = eng.train_epoch(256, seed=e, shuffle=True)
+    assert last < 0.7 * first
+    eng.close()
+
+
+def test_train_front_door_runs_and_improves():
+    cols = eh.synthetic.make_synth_rbq10(4000, seed=3, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=6, batchsize=256, opt=eh.Adam(0.01), random_seed=1)
+    assert len(out.train_history) == 7 and len(out.val_history) == 7          # initial snapshot + one per epoch (history.jl)
+    assert set(out.val_history[0]) == {"mse", "r2"} and set(out.val_history[0]["mse"]) == {"reco", "sum"}
+    assert out.val_history[-1]["mse"]["sum"] < out.val_history[0]["mse"]["sum"]
+    assert out.best_epoch >= 1 and out.ps.size == 338 and "reco_pred" in out.val_obs_pred
+    out2 = eh.train(model, cols, nepochs=2, batchsize=256, keep_history=False, random_seed=1)
+    assert len(out2.train_history) == 1                                        # test_split_data_train.jl:165-166
+
+
+# ----------------------------------------------------------------------------------------------
+# committed golden fixtures
+# ----------------------------------------------------------------------------------------------
+def _load_spec(d):
+    s = json.loads(str(d["spec"]))
+    return ho.HybridSpec(s["n_pred"], s["hidden"], s["mech"], {k: tuple(v) for k, v in s["parameters"].items()}, s["neural"],
+                         s["glob"], s["targets"], s["activation"], s["scale_nn_outputs"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_fixture(path):
+    d = np.load(path)
+    spec = _load_spec(d)
+    f = {k[8:]: d[k] for k in d.files if k.startswith("forcing_")}
+    y = {k[7:]: d[k] for k in d.files if k.startswith("target_")}
+    eng = util.load_engine(spec, d["theta"], d["X"], f, y)
+    loss, grad, nv = eng.loss_and_grad()
+    assert nv == int(d["n_valid"].sum())
+    assert abs(loss - float(d["loss"])) <= TOL * abs(float(d["loss"]))
+    assert util.relerr(grad, d["grad"]) <= TOL
+    for t in spec.targets:
+        assert util.relerr(eng.forward(0, params=False)[t], d["yhat_" + t]) <= TOL
+    n, batch = d["X"].shape[1], int(d["batch"])
+    batches = [(i, min(batch, n - i)) for i in range(0, n, batch)]
+    eng.opt_init("Adam", 0.01)
+    eng.train_step(*batches[0])
+    scale = max(1.0, float(np.max(np.abs(d["theta_after_1"]))))
+    assert np.max(np.abs(eng.get_params() - d["theta_after_1"])) <= 2e-5 * scale
+    for b in ((batches * 10)[1:10]):
+        eng.train_step(*b)
+    assert np.max(np.abs(eng.get_params() - d["theta_after_10"])) <= 2e-4 * scale     # 10 sign-like Adam steps of 1e-2
+    eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties
+# ----------------------------------------------------------------------------------------------
+def test_full_size_gradient_is_count_weighted_sum_of_shards():
+    # B = 65 536 (configs[1]): grad(full) * n = sum_k grad(shard_k) * n_k   (linearity of the sums; the DP protocol)
+    B = 65536
+    spec, theta, X, f, y = util.rbq10_case(B, "tanh", True, 0.05)
+    eng = util.load_engine(spec, theta, X, f, y)
+    l, g, n = eng.loss_and_grad()
+    acc_g, acc_l, acc_n = np.zeros_like(g, dtype=np.float64), 0.0, 0
+    for k in range(8):
+        lk, gk, nk = eng.loss_and_grad(first=k * B // 8, count=B // 8)
+        acc_g += gk.astype(np.float64) * nk; acc_l += lk * nk; acc_n += nk
+    assert acc_n == n and acc_l / n == pytest.approx(l, rel=1e-5)
+    assert util.relerr(acc_g / n, g) <= 2e-5
+    # and against the CPU oracle on a 4096-sample slice of the same resident data
+    _check_grad(spec, theta, X, f, y, eng, first=12345, count=4096)
+    eng.close()
+
+
+def test_full_size_variants_and_grids_agree():
+    B = 65536
+    spec, theta, X, f, y = util.rbq10_case(B, "tanh", True, 0.05)
+    eng = util.load_engine(spec, theta, X, f, y)
+    l0, g0, n0 = eng.loss_and_grad()
+    for var, mb in ((1, 256), (2, 256), (3, 256), (0, 64), (1, 100)):
+        eng.set_option("variant", var); eng.set_option("max_blocks", mb)
+        l, g, n = eng.loss_and_grad()
+        assert n == n0 and l == pytest.approx(l0, rel=2e-6) and util.relerr(g, g0) <= 5e-6
+    eng.set_option("variant", 0); eng.set_option("max_blocks", 256)
+    l, g, n = eng.loss_and_grad()
+    assert l == l0 and np.array_equal(g, g0)                                   # same launch -> bitwise (deterministic reduction)
+    eng.close()
+
+
+def test_config3_full_batch_262144_runs_and_matches_slice():
+    spec = ho.expo2pool_spec((64, 64), "tanh", True)
+    X, f, y = ho.make_synth_expo2pool(262144, 11, 0.05)
+    theta = ho.init_theta(spec, 2, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    l, g, n = eng.loss_and_grad()
+    assert n == int((~np.isnan(y["Resp_obs"])).sum()) and np.isfinite(l) and np.isfinite(g).all()
+    _check_grad(spec, theta, X, f, y, eng, first=100000, count=2048)
+    eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# data-parallel seam on one GPU ("virtual shards") and device-resident inputs
+# ----------------------------------------------------------------------------------------------
+def test_dp_seam_virtual_shards_equal_single_step():
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    l_ref = ref.train_step(0, 2048)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    ptr, n = eng.device_buffer(eh._lib.EH_BUF_GRAD)
+    buf = torch.as_tensor(eh.dp._DevArray(ptr, n), device="cuda")
+    acc = torch.zeros_like(buf)
+    for k in range(4):                                    # 4 "ranks", each its quarter; the sum stands in for the all-reduce
+        eng.dp_grad(k * 512, 512)
+        eng.synchronize()
+        acc += buf
+    buf.copy_(acc)
+    torch.cuda.synchronize()
+    l = eng.dp_apply(want_loss=True)
+    assert l == pytest.approx(l_ref, rel=1e-5)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-6
+    ref.close(); eng.close()
+
+
+def test_set_data_from_device_pointers():
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(777, "tanh", True, 0.1)
+    eng = util.model_from_spec(spec).engine()
+    xd = torch.from_numpy(np.asfortranarray(X).T.copy()).cuda()          # (N, P) row-major == (P x N) column-major
+    fd = torch.from_numpy(f["ta"]).cuda(); yd = torch.from_numpy(y["reco"]).cuda()
+    eng.set_data_device(0, 777, xd.data_ptr(), [fd.data_ptr()], [yd.data_ptr()])
+    eng.set_params(theta)
+    _check_grad(spec, theta, X, f, y, eng)
+    eng.close()
+
+
+def test_error_paths_on_device():
+    spec, theta, X, f, y = util.rbq10_case(64)
+    eng = util.model_from_spec(spec).engine()
+    with pytest.raises(eh.EngineError):
+        eng.loss_and_grad(count=10)                       # no data yet
+    with pytest.raises(eh.EngineError):
+        eng.train_step(0, 10)                             # no optimiser yet
+    with pytest.raises(ValueError):
+        eng.set_params(np.zeros(5, np.float32))
+    with pytest.raises(NotImplementedError):
+        eng.opt_init("Lion")
+    eng.close()
+    wide = ho.rbq10_spec((256, 16))
+    with pytest.raises(NotImplementedError, match="no compiled kernel"):
+        util.model_from_spec(wide).engine()

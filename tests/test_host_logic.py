@@ -1,0 +1,92 @@
+"""Host-side mirror of the reference interface: constructor checks, parameter helpers, data
+preparation / splitting and the bookkeeping of `train` (no GPU needed)."""
+import numpy as np
+import pytest
+
+import easyhybrid_jl_amd as eh
+from easyhybrid_jl_amd import dp
+
+PARAMS = {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}
+
+
+def model(**kw):
+    return eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, PARAMS, ["rb"], ["Q10"], **kw)
+
+
+def test_constructor_mirrors_reference_struct():
+    m = model()
+    assert isinstance(m, eh.SingleNNHybridModel) and eh.HybridModel is eh.SingleNNHybridModel
+    assert m.hidden_layers == [32, 32] and m.activation == "tanh" and not m.scale_nn_outputs and m.start_from_default
+    assert m.neural_param_names == ["rb"] and m.global_param_names == ["Q10"] and m.fixed_param_names == []
+    m2 = eh.constructHybridModel(["sw_pot"], ["ta"], ["reco"], "RbQ10", PARAMS, ["rb"], [])     # Q10 neither neural nor global -> fixed
+    assert m2.fixed_param_names == ["Q10"]
+
+
+def test_constructor_errors_match_reference():
+    with pytest.raises(AssertionError, match="neural_param_names"):           # GenericHybridModel.jl:110 / test_generic_hybrid_model.jl:569-586
+        eh.constructHybridModel(["a"], ["ta"], ["reco"], eh.RbQ10, PARAMS, ["nope"], ["Q10"])
+    with pytest.raises(NotImplementedError, match="closure"):
+        eh.constructHybridModel(["a"], ["ta"], ["reco"], lambda **kw: None, PARAMS, ["rb"], ["Q10"])
+    with pytest.raises(NotImplementedError):
+        model(input_batchnorm=True)
+    with pytest.raises(ValueError, match="forcing"):
+        eh.constructHybridModel(["a"], ["temp"], ["reco"], eh.RbQ10, PARAMS, ["rb"], ["Q10"])
+
+
+def test_scaling_helpers_known_answers():
+    hp = eh.build_parameters({"a": (1.0, 0.0, 2.0), "b": (2.0, 1.0, 3.0)})
+    assert eh.scale_single_param("a", np.float32([0.0]), hp)[0] == pytest.approx(1.0)      # test_generic_hybrid_model.jl:109-117
+    assert eh.scale_single_param("b", np.float32([0.0]), hp)[0] == pytest.approx(2.0)
+    assert eh.scale_single_param_minmax("a", hp) == pytest.approx(0.0)                     # :119-126
+    assert eh.hard_sigmoid(np.array([-10.0, 0.0, 10.0])).tolist() == [0.0, 0.5, 1.0]       # :23-35
+    assert eh.inv_hard_sigmoid(0.7) == pytest.approx(1.0)
+
+
+def test_initialparameters_layout_and_defaults():
+    m = model(hidden_layers=[16, 16])
+    th = m.initialparameters(0)
+    assert th.dtype == np.float32 and th.size == 338
+    assert th[-1] == pytest.approx(np.log(0.5), rel=1e-6)          # start_from_default: inv_sigmoid((2-1)/(4-1))
+    layers, glob = m.unpack(th)
+    assert [w.shape for w, _ in layers] == [(16, 2), (16, 16), (1, 16)] and list(glob) == ["Q10"]
+
+
+def test_prepare_data_drops_rows_like_reference():
+    n = 10
+    cols = {"sw_pot": np.arange(n, dtype=float), "dsw_pot": np.ones(n), "ta": np.linspace(0, 9, n), "reco": np.arange(n, dtype=float), "id": np.arange(n)}
+    cols["sw_pot"][2] = np.nan            # predictor missing -> row dropped (prepare_data.jl:45-55)
+    cols["reco"][5] = np.nan              # only target missing and it is the only target -> dropped
+    (X, f), y = eh.prepare_data(model(), cols)
+    assert X.shape == (2, 8) and X.dtype == np.float32 and f["ta"].shape == (8,) and not np.isnan(y["reco"]).any()
+
+
+def test_split_data_ratio_and_folds():
+    n = 100
+    cols = {"sw_pot": np.arange(n, dtype=float), "dsw_pot": np.ones(n), "ta": np.zeros(n), "reco": np.ones(n)}
+    (tr, _), (va, _) = [(a[0][0], a[1]) for a in eh.split_data(cols, model())]
+    assert tr.shape[1] == 80 and va.shape[1] == 20 and tr[0, 0] == 0 and va[0, 0] == 80        # chronological, at = 0.8
+    folds = np.arange(n) % 5 + 1
+    (tr, _), (va, _) = [(a[0][0], a[1]) for a in eh.split_data(cols, model(), eh.DataConfig(folds=folds, val_fold=2))]
+    assert va.shape[1] == 20 and tr.shape[1] == 80 and set(va[0].astype(int) % 5) == {1}
+    with pytest.raises(ValueError):
+        eh.split_data(cols, model(), eh.DataConfig(folds=folds, val_fold=1, split_by_id=folds))
+
+
+def test_config_validation_and_directions():
+    assert eh.isbetter(0.1, 0.2, "mse") and eh.isbetter(0.9, 0.8, "r2") and not eh.isbetter(0.9, 0.8, "rmse")   # loss_fn.jl:181-194
+    with pytest.raises(ValueError, match="to be maximized"):
+        eh.check_training_loss("nse")                                                                         # loss_fn.jl:196-205
+    eh.validate_config(eh.TrainConfig())
+    with pytest.raises(ValueError):
+        eh.validate_config(eh.TrainConfig(batchsize=0))
+    with pytest.raises(NotImplementedError):
+        eh.validate_config(eh.TrainConfig(training_loss="nseLoss"))
+    with pytest.raises(TypeError):
+        eh.train(model(), {}, bogus_keyword=1)
+
+
+def test_shard_ranges_cover_exactly():
+    for n, w in [(10, 3), (65536 * 8, 8), (7, 8)]:
+        r = [dp.shard_range(n, k, w) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1

@@ -1,0 +1,109 @@
+"""The oracle's hand VJP against two independent derivations (torch autograd, central finite
+differences), the plain-C port against the NumPy oracle, and the committed golden fixtures
+against a fresh oracle run.  Gradients / Adam are PARITY UNPINNED by the reference's own tests
+(SURVEY.md section 8c); this three-way agreement is what stands in for them."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import hybrid_oracle as ho
+from oracle import torch_twin as tt
+
+CASES = [(a, s) for a in ("tanh", "sigmoid", "relu", "swish") for s in (False, True)]
+
+
+def _case(act, scale, B=96, nan=0.2):
+    spec = ho.rbq10_spec((16, 16), act, scale)
+    X, f, y = ho.make_synth_rbq10(B, 5, nan)
+    X = X / 50
+    return spec, ho.init_theta(spec, 6, np.float64), X, f, y
+
+
+@pytest.mark.parametrize("act,scale", CASES)
+def test_hand_vjp_matches_autograd(act, scale):
+    spec, th, X, f, y = _case(act, scale)
+    l, g, _ = ho.loss_and_grad(spec, th, X, f, y)
+    l2, g2 = tt.loss_and_grad(spec, th, X, f, y)
+    assert l == pytest.approx(l2, rel=1e-12)
+    assert np.max(np.abs(g - g2)) <= 1e-11 * np.max(np.abs(g2))
+
+
+@pytest.mark.parametrize("act,scale", [("tanh", True), ("sigmoid", False), ("swish", True)])
+def test_hand_vjp_matches_finite_differences(act, scale):
+    spec, th, X, f, y = _case(act, scale, B=40)
+    _, g, _ = ho.loss_and_grad(spec, th, X, f, y)
+    rng = np.random.default_rng(0)
+    for k in rng.choice(th.size, 25, replace=False):
+        e = np.zeros_like(th); e[k] = 1e-6
+        fd = (ho.compute_loss(spec, th + e, X, f, y) - ho.compute_loss(spec, th - e, X, f, y)) / 2e-6
+        assert fd == pytest.approx(g[k], rel=2e-5, abs=1e-8)
+
+
+@pytest.mark.parametrize("mech", ["expo", "linear", "expo2pool", "rs_components"])
+def test_other_mech_models_vjp(mech):
+    rng = np.random.default_rng(3)
+    mm = ho.MECH[mech][0]
+    tabs = {"expo": dict(ho.EXPO_PARAMS), "linear": {"alpha": (1.0, -2.0, 3.0), "beta": (0.5, -1.0, 2.0)},
+            "expo2pool": dict(ho.EXPO2POOL_PARAMS),
+            "rs_components": {**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in ("het", "root", "myc")},
+                              **{f"Q10_{c}": (2.0, 1.0, 4.0) for c in ("het", "root", "myc")}}}
+    names = list(mm.params)
+    neural, glob = names[: max(1, len(names) // 2)], names[max(1, len(names) // 2):-1] if len(names) > 2 else names[1:]
+    spec = ho.HybridSpec(3, [8, 8], mech, tabs[mech], neural, glob, [mm.outputs[0]], "tanh", True)
+    B = 50
+    X = rng.standard_normal((3, B))
+    frc = {mm.forcings[0]: rng.uniform(-5, 25, B)}
+    y = {mm.outputs[0]: rng.uniform(0.5, 4, B)}
+    th = ho.init_theta(spec, 1, np.float64)
+    l, g, _ = ho.loss_and_grad(spec, th, X, frc, y)
+    l2, g2 = tt.loss_and_grad(spec, th, X, frc, y)
+    assert l == pytest.approx(l2, rel=1e-12)
+    assert np.max(np.abs(g - g2)) <= 1e-10 * max(np.max(np.abs(g2)), 1e-12)
+
+
+@pytest.mark.parametrize("act,scale", [("tanh", True), ("swish", False)])
+def test_c_port_matches_numpy_oracle(act, scale):
+    spec, th, X, f, y = _case(act, scale, B=500)
+    l, g, nv = co.loss_and_grad(spec, th.astype(np.float32), X, f, y, nthreads=3)
+    l0, g0, nv0 = ho.loss_and_grad(spec, th, X, f, y)
+    assert nv == nv0 and l == pytest.approx(l0, rel=2e-6)
+    assert np.max(np.abs(g - g0)) <= 2e-6 * np.max(np.abs(g0))
+
+
+def test_c_port_adam_trajectory():
+    spec, th, X, f, y = _case("tanh", True, B=512, nan=0.1)
+    th32 = th.astype(np.float32)
+    a, _ = ho.train_steps(spec, th32, X, f, y, [(i * 128, 128) for i in range(4)], dtype=np.float32)
+    b, _ = co.train_steps(spec, th32, X, f, y, 128, 4)
+    assert np.max(np.abs(a - b)) <= 5e-5      # Adam's sign-like first steps amplify rounding; both are fp32
+
+
+def test_all_masked_batch_is_skipped():
+    spec, th, X, f, y = _case("tanh", False, B=64)
+    y = {"reco": np.full(64, np.nan, np.float32)}
+    th32 = th.astype(np.float32)
+    out, losses = ho.train_steps(spec, th32, X, f, y, [(0, 64)], dtype=np.float32)
+    assert np.array_equal(out, th32) and np.isnan(losses[0])          # epoch.jl:17-19
+
+
+def _load_spec(d):
+    s = json.loads(str(d["spec"]))
+    return ho.HybridSpec(s["n_pred"], s["hidden"], s["mech"], {k: tuple(v) for k, v in s["parameters"].items()}, s["neural"],
+                         s["glob"], s["targets"], s["activation"], s["scale_nn_outputs"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_fixtures_reproduce(path):
+    d = np.load(path)
+    spec = _load_spec(d)
+    f = {k[8:]: d[k] for k in d.files if k.startswith("forcing_")}
+    y = {k[7:]: d[k] for k in d.files if k.startswith("target_")}
+    l, g, nv = ho.loss_and_grad(spec, d["theta"].astype(np.float64), d["X"], f, y)
+    assert l == pytest.approx(float(d["loss"]), rel=1e-12)
+    assert np.allclose(g, d["grad"], rtol=1e-10, atol=1e-14)
+    assert list(nv) == list(d["n_valid"])
