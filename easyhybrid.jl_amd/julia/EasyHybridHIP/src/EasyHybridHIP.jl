@@ -1,0 +1,254 @@
+# EasyHybridHIP.jl -- thin Julia host over libeasyhybrid_hip.so (include/easyhybrid_hip.h).
+#
+# Keeps the reference's front door -- `constructHybridModel(...)` and `train(model, data; ...)`
+# (EasyHybrid.jl src/models/GenericHybridModel.jl:89-140, src/training/train.jl:211-219) -- and
+# replaces what `run_epoch!` / `evaluate_epoch` do per minibatch / per epoch
+# (src/training/epoch.jl:13-33, 53-66) by `@ccall`s into the HIP engine.  No CUDA.jl, no AMDGPU.jl:
+# the only thing that crosses the boundary is plain pointers and sizes.
+#
+# NOTE: the build container has no `julia`, so this file is written against the C header and
+# mirrored call-for-call by the ctypes harness (easyhybrid.jl_amd/_lib.py, engine.py), which IS
+# exercised by the test-suite.  INTEGRATION.md shows the same binding inside EasyHybrid itself.
+module EasyHybridHIP
+
+using Libdl
+
+export constructHybridModel, SingleNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model
+
+const LIB = Ref{String}(get(ENV, "EASYHYBRID_HIP_LIB", joinpath(@__DIR__, "..", "..", "..", "libeasyhybrid_hip.so")))
+
+const EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG = 4, 8, 4, 4
+const EH_SPLIT_TRAIN, EH_SPLIT_VAL = Int32(0), Int32(1)
+
+# mirror of `eh_model_desc` (field order and widths exactly as in the header)
+struct EhModelDesc
+    struct_size::Int32
+    device::Int32
+    n_predictors::Int32
+    n_hidden::Int32
+    hidden::NTuple{4, Int32}
+    activation::Int32
+    scale_nn_outputs::Int32
+    mech::Int32
+    n_params::Int32
+    param_kind::NTuple{8, Int32}
+    param_index::NTuple{8, Int32}
+    param_default::NTuple{8, Float32}
+    param_lower::NTuple{8, Float32}
+    param_upper::NTuple{8, Float32}
+    n_forcings::Int32
+    forcing_index::NTuple{4, Int32}
+    n_targets::Int32
+    target_output::NTuple{4, Int32}
+end
+
+struct EhTargetMetrics
+    n::Float64; mse::Float64; rmse::Float64; mae::Float64; r2::Float64; nse::Float64
+    pearson::Float64; kge::Float64; pbkge::Float64; beta::Float64; alpha::Float64; sse::Float64
+end
+
+# ------------------------------------------------------------------------------------------------
+# mechanistic registry: the Julia functions of the reference, tagged with the device model id
+# ------------------------------------------------------------------------------------------------
+struct MechSpec
+    id::Int32
+    params::Vector{Symbol}
+    forcings::Vector{Symbol}
+    outputs::Vector{Symbol}
+end
+
+RbQ10(; ta, Q10, rb, tref = 15.0f0) = (; reco = rb .* Q10 .^ (0.1f0 .* (ta .- tref)), Q10, rb)       # test/test_split_data_train.jl:36-39
+Expo_resp_model(; T, Resp0, k) = (; Resp_obs = Resp0 .* exp.(k .* T), Resp0, k)                      # projects/ExpoHybrid/ExpoHybridEstim.jl:69-85
+const MECH = IdDict{Any, MechSpec}(
+    RbQ10 => MechSpec(0, [:rb, :Q10], [:ta], [:reco]),
+    Expo_resp_model => MechSpec(1, [:Resp0, :k], [:T], [:Resp_obs]),
+)
+"Register another Julia function under one of the device model ids (see include/easyhybrid_hip.h)."
+register_mechanistic!(f, spec::MechSpec) = (MECH[f] = spec)
+
+const ACT = Dict(:tanh => 0, :sigmoid => 1, :relu => 2, :swish => 3, :identity => 4)
+
+# ------------------------------------------------------------------------------------------------
+# model (field-for-field the reference's SingleNNHybridModel, GenericHybridModel.jl:44-63, minus Lux)
+# ------------------------------------------------------------------------------------------------
+struct SingleNNHybridModel
+    NN::Vector{Tuple{Int, Int}}          # Dense (out, in) shapes that prepare_hidden_chain would build
+    predictors::Vector{Symbol}
+    forcing::Vector{Symbol}
+    targets::Vector{Symbol}
+    mechanistic_model::Function
+    parameters::NamedTuple               # name => (default, lower, upper)
+    neural_param_names::Vector{Symbol}
+    global_param_names::Vector{Symbol}
+    fixed_param_names::Vector{Symbol}
+    scale_nn_outputs::Bool
+    start_from_default::Bool
+    config::NamedTuple
+end
+const HybridModel = SingleNNHybridModel
+
+function constructHybridModel(predictors::Vector{Symbol}, forcing, targets, mechanistic_model, parameters,
+        neural_param_names, global_param_names; hidden_layers::Vector{Int} = [32, 32], activation = tanh,
+        scale_nn_outputs = false, input_batchnorm = false, start_from_default = true, kwargs...)
+    haskey(MECH, mechanistic_model) || throw(ArgumentError("mechanistic_model is not in the device registry; " *
+        "an arbitrary closure cannot run inside the HIP kernel (no CPU fallback)"))
+    all_names = collect(keys(parameters))
+    @assert all(n in all_names for n in neural_param_names) "neural_param_names ⊆ param_names"
+    input_batchnorm && throw(ArgumentError("input_batchnorm = true is not built yet"))
+    dims = [length(predictors); hidden_layers; length(neural_param_names)]
+    NN = [(dims[i + 1], dims[i]) for i in 1:(length(dims) - 1)]
+    fixed = [n for n in all_names if !(n in [neural_param_names..., global_param_names...])]
+    config = (; hidden_layers, activation = Symbol(nameof(activation)), scale_nn_outputs, input_batchnorm, start_from_default, kwargs...)
+    return SingleNNHybridModel(NN, predictors, collect(forcing), collect(targets), mechanistic_model, parameters,
+        collect(neural_param_names), collect(global_param_names), fixed, scale_nn_outputs, start_from_default, config)
+end
+
+n_theta(m::SingleNNHybridModel) = sum(o * i + o for (o, i) in m.NN) + length(m.global_param_names)
+
+pad(v, n, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), n)
+
+function descriptor(m::SingleNNHybridModel; device::Integer = 0)
+    ms = MECH[m.mechanistic_model]
+    kind = Int32[]; index = Int32[]; def = Float32[]; lo = Float32[]; hi = Float32[]
+    for p in ms.params
+        if p in m.neural_param_names
+            push!(kind, 0); push!(index, findfirst(==(p), m.neural_param_names) - 1)
+        elseif p in m.global_param_names
+            push!(kind, 1); push!(index, findfirst(==(p), m.global_param_names) - 1)
+        else
+            push!(kind, 2); push!(index, 0)
+        end
+        d, l, u = m.parameters[p]
+        push!(def, d); push!(lo, l); push!(hi, u)
+    end
+    hidden = [o for (o, _) in m.NN[1:(end - 1)]]
+    return EhModelDesc(sizeof(EhModelDesc), device, length(m.predictors), length(hidden), pad(hidden, 4, Int32),
+        ACT[m.config.activation], m.scale_nn_outputs, ms.id, length(ms.params),
+        pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
+        length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
+        length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32))
+end
+
+# ------------------------------------------------------------------------------------------------
+# engine = one eh_handle
+# ------------------------------------------------------------------------------------------------
+mutable struct HybridEngine
+    h::Ptr{Cvoid}
+    model::SingleNNHybridModel
+    n_theta::Int
+end
+
+function check(e::HybridEngine, st::Integer)
+    st == 0 && return
+    msg = unsafe_string(@ccall LIB[].eh_last_error(e.h::Ptr{Cvoid})::Cstring)
+    st == -1 && throw(ArgumentError(msg))                   # EH_EINVAL      (reference: ArgumentError / AssertionError)
+    st == -4 && throw(ArgumentError("unsupported: " * msg)) # EH_EUNSUPPORTED
+    st == -3 && throw(OutOfMemoryError())
+    error(msg)                                              # EH_EHIP / EH_ESTATE
+end
+
+function HybridEngine(m::SingleNNHybridModel; device::Integer = 0)
+    d = Ref(descriptor(m; device))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = @ccall LIB[].eh_create(d::Ref{EhModelDesc}, h::Ref{Ptr{Cvoid}})::Int32
+    st == 0 || error(unsafe_string(@ccall LIB[].eh_last_error(C_NULL::Ptr{Cvoid})::Cstring))
+    e = HybridEngine(h[], m, n_theta(m))
+    finalizer(x -> (@ccall LIB[].eh_destroy(x.h::Ptr{Cvoid})::Int32), e)
+    return e
+end
+
+"X is (P × N) exactly as prepare_data returns it (src/data/prepare_data.jl:6); forcings / targets NamedTuples of Vector{Float32}."
+function set_data!(e::HybridEngine, split::Integer, X::Matrix{Float32}, forcings::NamedTuple, targets::NamedTuple)
+    f = [forcings[k] for k in e.model.forcing]; t = [targets[k] for k in e.model.targets]
+    GC.@preserve X f t begin
+        fp = [pointer(v) for v in f]; tp = [pointer(v) for v in t]
+        check(e, @ccall LIB[].eh_set_data(e.h::Ptr{Cvoid}, split::Int32, size(X, 2)::Int64, X::Ptr{Float32},
+            fp::Ptr{Ptr{Float32}}, tp::Ptr{Ptr{Float32}}, 0::Int32)::Int32)
+    end
+end
+set_params!(e::HybridEngine, θ::Vector{Float32}) = check(e, @ccall LIB[].eh_set_params(e.h::Ptr{Cvoid}, θ::Ptr{Float32}, length(θ)::Int64)::Int32)
+function get_params(e::HybridEngine)
+    θ = Vector{Float32}(undef, e.n_theta)
+    check(e, @ccall LIB[].eh_get_params(e.h::Ptr{Cvoid}, θ::Ptr{Float32}, length(θ)::Int64)::Int32)
+    return θ
+end
+opt_init!(e::HybridEngine; rule = 0, eta = 0.01f0, beta = (0.9f0, 0.999f0), epsilon = 1.0f-8, lambda = 0.0f0) =
+    check(e, @ccall LIB[].eh_opt_init(e.h::Ptr{Cvoid}, rule::Int32, eta::Float32, beta[1]::Float32, beta[2]::Float32, epsilon::Float32, lambda::Float32)::Int32)
+
+"one Lux.Training.single_train_step! (src/training/epoch.jl:20-26) on train samples first+1 : first+count"
+function train_step!(e::HybridEngine, first::Integer, count::Integer)
+    loss = Ref{Float32}(NaN32)
+    check(e, @ccall LIB[].eh_train_step(e.h::Ptr{Cvoid}, first::Int64, count::Int64, loss::Ref{Float32})::Int32)
+    return loss[]
+end
+"one run_epoch! (src/training/epoch.jl:13-33)"
+function train_epoch!(e::HybridEngine, batchsize::Integer; seed::Integer = 0, shuffle::Bool = true)
+    loss = Ref{Float32}(NaN32); n = Ref{Int64}(0)
+    check(e, @ccall LIB[].eh_train_epoch(e.h::Ptr{Cvoid}, batchsize::Int64, seed::UInt64, shuffle::Int32, loss::Ref{Float32}, n::Ref{Int64})::Int32)
+    return loss[], n[]
+end
+function loss_and_grad(e::HybridEngine, split::Integer, first::Integer, count::Integer)
+    loss = Ref{Float32}(NaN32); nv = Ref{Int64}(0); g = Vector{Float32}(undef, e.n_theta)
+    check(e, @ccall LIB[].eh_loss_and_grad(e.h::Ptr{Cvoid}, split::Int32, C_NULL::Ptr{Int32}, first::Int64, count::Int64,
+        loss::Ref{Float32}, g::Ptr{Float32}, nv::Ref{Int64})::Int32)
+    return loss[], g, nv[]
+end
+"evaluate_acc (src/training/train.jl:347-355): nested (mse = (reco = .., sum = ..), r2 = ...) like compute_loss.jl:55-66"
+function evaluate(e::HybridEngine, split::Integer, n::Integer; loss_types = [:mse, :r2])
+    T = length(e.model.targets)
+    m = Vector{EhTargetMetrics}(undef, T)
+    check(e, @ccall LIB[].eh_eval(e.h::Ptr{Cvoid}, split::Int32, 0::Int64, n::Int64, m::Ptr{EhTargetMetrics}, C_NULL::Ptr{Ptr{Float32}}, C_NULL::Ptr{Ptr{Float32}})::Int32)
+    return NamedTuple{Tuple(loss_types)}(map(loss_types) do lt
+        per = [getfield(m[t], lt) for t in 1:T]
+        NamedTuple{(e.model.targets..., :sum)}((per..., sum(per)))
+    end)
+end
+function forward(e::HybridEngine, split::Integer, n::Integer)
+    ŷ = [Vector{Float32}(undef, n) for _ in e.model.targets]
+    GC.@preserve ŷ begin
+        p = [pointer(v) for v in ŷ]
+        check(e, @ccall LIB[].eh_forward(e.h::Ptr{Cvoid}, split::Int32, 0::Int64, n::Int64, p::Ptr{Ptr{Float32}}, C_NULL::Ptr{Ptr{Float32}})::Int32)
+    end
+    return NamedTuple{Tuple(e.model.targets)}(Tuple(ŷ))
+end
+
+# ------------------------------------------------------------------------------------------------
+# train: the epoch loop of _train (src/training/train.jl:95-136) with the hot path on the device
+# ------------------------------------------------------------------------------------------------
+"""
+    train!(engine, ((x_train, forcings_train), y_train), ((x_val, forcings_val), y_val); nepochs, batchsize, ...)
+
+In-place variant: updates the parameters held by `engine`.  `train(model, data...; kwargs...)`
+builds an engine, calls this and returns `(; ps, train_history, val_history, best_epoch, best_loss)`.
+"""
+function train!(e::HybridEngine, train_data, val_data; nepochs = 200, batchsize = 64, eta = 0.01f0, patience = typemax(Int),
+        loss_types = [:mse, :r2], random_seed = 161803, return_model = :best)
+    ((xt, ft), yt), ((xv, fv), yv) = train_data, val_data
+    set_data!(e, EH_SPLIT_TRAIN, xt, ft, yt); set_data!(e, EH_SPLIT_VAL, xv, fv, yv)
+    opt_init!(e; eta)
+    nt, nv = size(xt, 2), size(xv, 2)
+    hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types)]
+    best_loss = hist_v[1][1].sum; best_ps = get_params(e); best_epoch = 0; counter = 0
+    better = first(loss_types) in (:pearson, :r2, :nse, :kge) ? (>) : (<)        # loss_fn.jl:181-194
+    for epoch in 1:nepochs
+        train_epoch!(e, batchsize; seed = random_seed + epoch, shuffle = true)   # run_epoch!
+        push!(hist_t, evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)); push!(hist_v, evaluate(e, EH_SPLIT_VAL, nv; loss_types))   # evaluate_epoch
+        cur = hist_v[end][1].sum
+        if better(cur, best_loss)
+            best_loss, best_ps, best_epoch, counter = cur, get_params(e), epoch, 0
+        else
+            counter += 1
+        end
+        counter >= patience && break
+    end
+    return_model == :best && set_params!(e, best_ps)
+    return (; ps = get_params(e), train_history = hist_t, val_history = hist_v, best_epoch, best_loss)
+end
+
+function train(m::SingleNNHybridModel, train_data, val_data; θ0::Vector{Float32}, device = 0, kwargs...)
+    e = HybridEngine(m; device)
+    set_params!(e, θ0)
+    return train!(e, train_data, val_data; kwargs...)
+end
+
+end # module
