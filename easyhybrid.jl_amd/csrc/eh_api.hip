@@ -54,8 +54,8 @@ __device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float t
     } else {   // raw global -> physical value and sigmoid slope (GenericHybridModel.jl:348-352)
         const int g = idx - im.g_off, j = im.glob_par[g];
         const float s = 1.0f / (1.0f + expf(-th));
-        im.image[im.phi_off + j] = im.glo[g] + (im.ghi[g] - im.glo[g]) * s;
-        im.image[im.phi_off + 8 + j] = (im.ghi[g] - im.glo[g]) * s * (1.0f - s);
+        im.image[im.phi_off + EH_IMG_PHI + j] = im.glo[g] + (im.ghi[g] - im.glo[g]) * s;
+        im.image[im.phi_off + EH_IMG_DPHI + j] = (im.ghi[g] - im.glo[g]) * s * (1.0f - s);
     }
 }
 
@@ -224,7 +224,7 @@ struct eh_handle_s {
     eh_model_desc desc;
     EhNet net;
     const EhArchInfo* arch = nullptr;
-    int variant = 0, act = 0;
+    int variant = 0, act = 0, fast = 0;
     float* image = nullptr;
     int* imap = nullptr;
     EhImg img{};
@@ -353,27 +353,27 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->arch = arch;
     EhNet& n = h->net;
     memset(&n, 0, sizeof n);
-    n.P = d->n_predictors; n.K = K; n.NL = d->n_hidden; n.G = G;
+    n.P = d->n_predictors; n.K = K; n.G = G; n.T = d->n_targets; n.F = d->n_forcings;
+    int lw_off[EH_MAX_HIDDEN + 1], lb_off[EH_MAX_HIDDEN + 1];
     int off = 0, in = n.P;
-    for (int l = 0; l <= n.NL; ++l) {
-        const int o = l < n.NL ? d->hidden[l] : K;
-        if (l < n.NL) n.width[l] = o;
-        n.w_off[l] = off; off += o * in;
-        n.b_off[l] = off; off += o;
+    for (int l = 0; l <= d->n_hidden; ++l) {
+        const int o = l < d->n_hidden ? d->hidden[l] : K;
+        lw_off[l] = off; off += o * in;
+        lb_off[l] = off; off += o;
         in = o;
     }
     n.g_off = off;
     n.n_theta = off + G;
     h->act = d->activation; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
     n.mech = d->mech; n.n_par = d->n_params;
-    for (int j = 0; j < EH_MAX_PARAMS; ++j) {
-        n.par_kind[j] = j < d->n_params ? d->param_kind[j] : EH_PAR_FIXED;
-        n.par_idx[j] = j < d->n_params ? d->param_index[j] : 0;
-        n.par_lo[j] = d->param_lower[j]; n.par_hi[j] = d->param_upper[j]; n.par_def[j] = d->param_default[j];
+    for (int j = 0; j < d->n_params; ++j) {
+        n.par_kind |= (unsigned)d->param_kind[j] << (2 * j);
+        n.par_idx |= (unsigned)(d->param_kind[j] == EH_PAR_FIXED ? 0 : d->param_index[j]) << (4 * j);
     }
-    n.F = d->n_forcings;
-    for (int f = 0; f < EH_MAX_FORC; ++f) n.forc_col[f] = f < mi.n_forc ? d->forcing_index[f] : -1;
-    n.T = d->n_targets;
+    for (int j = d->n_params; j < EH_MAX_PARAMS; ++j) n.par_kind |= (unsigned)EH_PAR_FIXED << (2 * j);
+    n.forc_col = 0xFFFFFFFFu;
+    for (int f = 0; f < mi.n_forc; ++f) n.forc_col = (n.forc_col & ~(0xFFu << (8 * f))) | ((unsigned)d->forcing_index[f] << (8 * f));
+    h->fast = (arch->has_fast ? ((K == 1 ? 1 : 0) | ((K == 1 && n.P <= 4) ? 2 : 0)) : 0);
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T;
@@ -410,22 +410,28 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     {   // parameter image: canonical index -> padded LDS-layout offset
         std::vector<int> imap(nt, -1);
         int inl = n.P;
-        for (int l = 0; l <= n.NL; ++l) {
-            const int o = l < n.NL ? d->hidden[l] : K;
+        for (int l = 0; l <= d->n_hidden; ++l) {
+            const int o = l < d->n_hidden ? d->hidden[l] : K;
             for (int col = 0; col < inl; ++col)
                 for (int row = 0; row < o; ++row) {
                     int off;
                     if (l == 0) off = arch->w0_off + row * arch->s0 + col;
-                    else if (l < n.NL) off = arch->wh_off + (l - 1) * arch->hp * arch->sh + row * arch->sh + col;
+                    else if (l < d->n_hidden) off = arch->wh_off + (l - 1) * arch->hp * arch->sh + row * arch->sh + col;
                     else off = arch->wo_off + row * arch->sh + col;
-                    imap[n.w_off[l] + row + o * col] = off;
+                    imap[lw_off[l] + row + o * col] = off;
                 }
-            for (int row = 0; row < o; ++row) imap[n.b_off[l] + row] = arch->b_off + l * arch->hp + row;
+            for (int row = 0; row < o; ++row) imap[lb_off[l] + row] = arch->b_off + l * arch->hp + row;
             inl = o;
         }
         std::vector<float> img0((size_t)arch->img_floats, 0.0f);
-        for (int j = 0; j < d->n_params; ++j)
-            if (d->param_kind[j] == EH_PAR_FIXED) img0[arch->phi_off + j] = d->param_default[j];   // st.fixed, GenericHybridModel.jl:289-303
+        for (int j = 0; j < d->n_params; ++j) {
+            if (d->param_kind[j] == EH_PAR_FIXED) img0[arch->phi_off + EH_IMG_PHI + j] = d->param_default[j];   // st.fixed, GenericHybridModel.jl:289-303
+            img0[arch->phi_off + EH_IMG_LO + j] = d->param_lower[j];
+            img0[arch->phi_off + EH_IMG_SC + j] = d->param_upper[j] - d->param_lower[j];
+        }
+        auto put_int = [&](int slot, int v) { memcpy(&img0[arch->phi_off + slot], &v, sizeof(int)); };
+        for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
+        for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, d->hidden[l]);
         HIPCHK_C(hipMalloc(&h->image, img0.size() * sizeof(float)));
         HIPCHK_C(hipMalloc(&h->imap, nt * sizeof(int)));
         HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -484,6 +490,11 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "max_blocks")) {
         if (value < 1 || value > 256) return fail(h, EH_EINVAL, "max_blocks must be 1..256 (one workgroup per CU)");
         h->max_blocks = (int)value;
+        return EH_OK;
+    }
+    if (!strcmp(name, "fast_paths")) {       // 0 forces the generic MFMA kernels (A/B testing)
+        const int want = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
+        h->fast = value ? (want & (int)value) : 0;
         return EH_OK;
     }
     if (!strcmp(name, "variant")) {
@@ -590,7 +601,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.stamps = h->stamps;
     const int grid = grid_for(h, count);
     *grid_out = grid;
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
     return EH_OK;
 }
 
@@ -675,7 +686,7 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     const int grid = count > 0 ? grid_for(h, count) : 1;
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, grid, h->stream, &h->net, &a));
     std::vector<float> part((size_t)grid * a.n_acc);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

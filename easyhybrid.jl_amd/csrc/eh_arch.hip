@@ -15,15 +15,21 @@ struct Var {
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
 
-    template <int ACT, int MODE>
+    template <int ACT, int MODE, int FAST>
     static hipError_t prep1() {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     template <int ACT>
     static hipError_t prep2() {
-        hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
-        return e != hipSuccess ? e : prep1<ACT, EH_MODE_EVAL>();
+        hipError_t e = prep1<ACT, EH_MODE_TRAIN, 0>();
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 0>();
+#ifdef EH_FAST_PATHS
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 1>();
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 3>();
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 1>();
+#endif
+        return e;
     }
     static hipError_t prepare() {
         hipError_t e;
@@ -33,20 +39,24 @@ struct Var {
         if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
         return prep2<EH_ACT_IDENTITY>();
     }
+#define EH_GO(MODE, FAST) hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args)
     template <int ACT>
-    static void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
-        if (mode == EH_MODE_TRAIN)
-            hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, EH_MODE_TRAIN>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
-        else
-            hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, EH_MODE_EVAL>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
+    static void go(int mode, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+#ifdef EH_FAST_PATHS
+        if (mode == EH_MODE_TRAIN && fast == 3) { EH_GO(EH_MODE_TRAIN, 3); return; }
+        if (mode == EH_MODE_TRAIN && (fast & 1)) { EH_GO(EH_MODE_TRAIN, 1); return; }
+        if (mode == EH_MODE_EVAL && (fast & 1)) { EH_GO(EH_MODE_EVAL, 1); return; }
+#endif
+        if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN, 0); else EH_GO(EH_MODE_EVAL, 0);
     }
-    static hipError_t launch(int mode, int act, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+#undef EH_GO
+    static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
         switch (act) {
-            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
-            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
-            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
-            case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, grid, stream, net, args); break;
-            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
+            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, fast, grid, stream, net, args); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -58,6 +68,11 @@ using G0 = EhGeom<EH_NBI, EH_NBH, EH_NL, NT0, 4>;
 const EhArchInfo info = {
     EH_NBI, EH_NBH, EH_NL,
     G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
+#ifdef EH_FAST_PATHS
+    1,
+#else
+    0,
+#endif
 #ifdef EH_EXTRA_VARIANTS
     4, {Var<NT0, 4>::info(), Var<2, 8>::info(), Var<1, 16>::info(), Var<1, 8>::info()}
 #else

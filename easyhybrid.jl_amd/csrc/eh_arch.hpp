@@ -14,13 +14,15 @@ struct EhVariant {
     size_t lds_bytes;        // dynamic LDS per workgroup
     int red_floats;          // floats available to the end-of-kernel reduction (needs nw * n_acc)
     hipError_t (*prepare)(void);   // raises the dynamic-LDS limit of every kernel of the variant
-    hipError_t (*launch)(int mode, int act, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
+    // fast: bit 0 = single NN output (K == 1), bit 1 = P <= 4; only honoured by shapes built with EH_FAST_PATHS
+    hipError_t (*launch)(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
 };
 
 struct EhArchInfo {
     int nbi, nbh, nl;
     // parameter-image geometry (EhGeom; independent of the variant)
     int ip, hp, s0, sh, w0_off, wh_off, wo_off, b_off, phi_off, img_floats;
+    int has_fast;            // K1 / small-P kernels compiled for this shape
     int nvar;
     EhVariant var[4];
 };

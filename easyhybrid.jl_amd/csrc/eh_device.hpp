@@ -35,19 +35,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { EH_MODE_TRAIN = 0, EH_MODE_EVAL = 1 };
 
 struct EhNet {
-    int P, K, NL, G;                 // predictors, NN outputs (neural params), hidden layers, global params
-    int width[EH_MAX_HIDDEN];        // hidden widths
-    int w_off[EH_MAX_HIDDEN + 1];    // canonical flat-theta offset of layer l's weight (column-major (out,in))
-    int b_off[EH_MAX_HIDDEN + 1];    // ... and bias
-    int g_off;                       // offset of the raw global parameters
-    int n_theta;                     // n_nn + G
-    int scale_nn;
-    int mech, n_par;
-    int par_kind[EH_MAX_PARAMS], par_idx[EH_MAX_PARAMS];
-    float par_lo[EH_MAX_PARAMS], par_hi[EH_MAX_PARAMS], par_def[EH_MAX_PARAMS];
-    int F, forc_col[EH_MAX_FORC];    // number of forcing columns; column (0..F) feeding the mech model's f-th forcing (-1 unused)
-    int T;                           // number of targets (each compared with the model's output)
+    int P, K, G, T, F;               // predictors, NN outputs (neural params), global params, targets, forcing columns
+    int n_theta, g_off;              // n_nn + G ; offset of the raw global parameters in flat theta
+    int scale_nn, mech, n_par;
+    unsigned par_kind;               // 2 bits per canonical mech parameter: eh_param_kind
+    unsigned par_idx;                // 4 bits per canonical mech parameter: NN output row / global index
+    unsigned forc_col;               // 8 bits per canonical forcing: column among the F forcing columns (0xFF unused)
 };
+// Per-layer offsets / widths and the (lower, upper-lower) table travel in the parameter image
+// (EhGeom::PHI_OFF block) instead of the kernarg: they are read from LDS where they are used,
+// which keeps them out of the scalar register file during the tile loop.
+enum { EH_IMG_PHI = 0, EH_IMG_DPHI = 8, EH_IMG_LO = 16, EH_IMG_SC = 24, EH_IMG_WOFF = 32, EH_IMG_BOFF = 37, EH_IMG_WIDTH = 42, EH_IMG_META = 48 };
 
 struct EhStepArgs {
     const float* recs;    // dataset, one record of C = P+F+T floats per sample: [predictors | forcings | targets (NaN = missing)]
@@ -176,8 +174,8 @@ struct EhGeom {
     static constexpr int WH_OFF = W0_OFF + HP * S0;                  // NL-1 hidden->hidden matrices
     static constexpr int WO_OFF = WH_OFF + (NL - 1) * HP * SH;       // output layer, 16 padded rows
     static constexpr int B_OFF = WO_OFF + 16 * SH;                   // biases: NL * HP + 16
-    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;             // phi[8] (physical value of global / fixed params), dphi[8]
-    static constexpr int IMG_FLOATS = PHI_OFF + 16;                  // multiple of 4
+    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;             // EH_IMG_* block: phi[8], dphi[8], lo[8], hi-lo[8], int w_off[5], b_off[5], width[4]
+    static constexpr int IMG_FLOATS = PHI_OFF + EH_IMG_META;         // multiple of 4
     // per-wave workspace
     static constexpr int XS_OFF = 0;
     static constexpr int HS_OFF = XS_OFF + IP * SR;                  // NL images of HP rows
@@ -214,12 +212,19 @@ struct EhGeom {
 
 // ------------------------------------------------------------------------------------------
 // the fused kernel
+//   FAST bit 0 (K1): exactly one NN output -> output layer, its weight gradient and the first
+//                    backward step run on the vector ALU and the hand-over to the one-sample-per-lane
+//                    mechanistic stage needs no LDS round trip
+//   FAST bit 1 (PS): P <= 4 predictors -> the first layer's weight gradient runs on the vector ALU
 // ------------------------------------------------------------------------------------------
-template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE>
+template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
     using G = EhGeom<NBI, NBH, NL, NT, NW>;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, NTHR = 64 * NW;
     constexpr bool TRAIN = MODE == EH_MODE_TRAIN;
+    constexpr bool K1 = (FAST & 1) != 0, PS = (FAST & 2) != 0;
+    constexpr bool KEEPH = TRAIN && ACT != EH_ACT_SWISH && NL * NBH * NT * 4 <= 64;   // activations stay in registers for act'
+    constexpr int NHS = KEEPH ? NL : 1, NHM = KEEPH ? NBH : 1, NHT = KEEPH ? NT : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -228,14 +233,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     float* const HS = ws + G::HS_OFF;
     float* const DZ = ws + G::DZ_OFF;
     float* const OS = ws + G::OS_OFF;
+    const float* const meta = wl + G::PHI_OFF;
+    auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
+    auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
 
     // one sample record per lane, fetched one macro-tile ahead of its use
     constexpr int NX4 = (G::IP + 3) / 4;
     struct { f32x4 x[NX4]; float frc[EH_MAX_FORC]; float y[EH_MAX_TARG]; } nx;
-    const long long ntiles_ = (a.count + MT - 1) / MT;
+    const long long ntiles = (a.count + MT - 1) / MT;
     auto fetch = [&](long long tile) {
         const long long n_loc = tile * MT + lane;
-        const bool live = (tile < ntiles_) && (lane < MT) && (n_loc < a.count);
+        const bool live = (tile < ntiles) && (lane < MT) && (n_loc < a.count);
         const long long n_glb = live ? (a.idx ? (long long)a.idx[a.first + n_loc] : a.first + n_loc) : 0;
         const float* const rec = a.recs + n_glb * a.C;
         if ((a.C & 3) == 0) {          // 16-byte-multiple records (RbQ10: exactly one dwordx4 per sample)
@@ -248,7 +256,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 for (int e = 0; e < 4; ++e) nx.x[q][e] = (live && 4 * q + e < net.P) ? rec[4 * q + e] : 0.0f;
         }
 #pragma unroll
-        for (int f = 0; f < EH_MAX_FORC; ++f) nx.frc[f] = (net.forc_col[f] >= 0 && live) ? rec[net.P + net.forc_col[f]] : 0.0f;
+        for (int f = 0; f < EH_MAX_FORC; ++f) {
+            const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
+            nx.frc[f] = (col != 0xFFu && live) ? rec[net.P + col] : 0.0f;
+        }
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t) nx.y[t] = (t < net.T && live) ? rec[net.P + net.F + t] : __builtin_nanf("");
     };
@@ -262,22 +273,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     EH_STAMP(1);
 
     // ---- accumulators (registers, live across the tile loop) ------------------------------------
-    f32x4 aW0[NBH][NBI], aWh[NL > 1 ? NL - 1 : 1][NBH][NBH], aWo[NBH];
+    f32x4 aW0[PS ? 1 : NBH][PS ? 1 : NBI], aWh[NL > 1 ? NL - 1 : 1][NBH][NBH], aWo[K1 ? 1 : NBH];
+    f32x4 aW0V[PS ? NBH : 1][4];      // PS: [m][p][r]  (p = predictor)
+    f32x4 aWoV[K1 ? NBH : 1];         // K1: d/dWo[16m + 4g + r]
     f32x4 aB[NL][NBH], aBo;
+    float aBoS = 0.0f;
     float gacc[EH_MAX_PARAMS];
     float lacc = 0.0f;
     float cacc[EH_MAX_TARG];
     float est[EH_MAX_TARG][EH_EVAL_STATS];
-    if (TRAIN) {
+    if constexpr (TRAIN) {
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
+            if constexpr (!PS) {
 #pragma unroll
-            for (int n = 0; n < NBI; ++n) aW0[m][n] = f32x4{0, 0, 0, 0};
+                for (int n = 0; n < NBI; ++n) aW0[m][n] = f32x4{0, 0, 0, 0};
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) aW0V[m][pp] = f32x4{0, 0, 0, 0};
+            }
 #pragma unroll
             for (int l = 0; l < NL - 1; ++l)
 #pragma unroll
                 for (int n = 0; n < NBH; ++n) aWh[l][m][n] = f32x4{0, 0, 0, 0};
-            aWo[m] = f32x4{0, 0, 0, 0};
+            if constexpr (K1) aWoV[m] = f32x4{0, 0, 0, 0}; else aWo[m] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int l = 0; l < NL; ++l) aB[l][m] = f32x4{0, 0, 0, 0};
         }
@@ -291,8 +310,6 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
         for (int k = 0; k < EH_EVAL_STATS; ++k) est[t][k] = 0.0f;
     }
-
-    const long long ntiles = (a.count + MT - 1) / MT;
     const int ksteps0 = (net.P + 3) / 4;   // k-steps of layer 0 that hold real features (natural k order 4s+g)
 
     for (long long tile = (long long)blockIdx.x * NW + wave; tile < ntiles; tile += (long long)gridDim.x * NW) {
@@ -317,6 +334,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         EH_STAMP_FINE(3);
         // ---- 2. forward, layer 0 : z = W0 x + b0 ------------------------------------------------
         f32x4 h[NBH][NT];
+        f32x4 hs[NHS][NHM][NHT];       // KEEPH: every layer's activations for the backward pass
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
             const f32x4 bias = *(const f32x4*)&wl[G::B_OFF + 16 * m + 4 * g];
@@ -331,14 +349,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 }
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z = h[m][t][r];
                     const float hv = eh_act<ACT>(z);
                     h[m][t][r] = hv;
-                    if (TRAIN) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z : hv;
+                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z : hv;
                 }
+                if constexpr (KEEPH) hs[0][m][t] = h[m][t];
+            }
         }
         EH_STAMP_FINE(4);
         // ---- 3. hidden layers -------------------------------------------------------------------
@@ -365,18 +385,41 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
             for (int m = 0; m < NBH; ++m)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float z = hn[m][t][r];
                         const float hv = eh_act<ACT>(z);
                         h[m][t][r] = hv;
-                        if (TRAIN) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z : hv;
+                        // the last layer's image is only read back for act' / dWo when those do not have it in registers
+                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z : hv;
                     }
+                    if constexpr (KEEPH) hs[l < NHS ? l : 0][m < NHM ? m : 0][t < NHT ? t : 0] = h[m][t];
+                }
         }
         EH_STAMP_FINE(5);
         // ---- 4. output layer (K <= 16 rows, zero padded) ----------------------------------------
-        {
+        float om = 0.0f;               // K1: this lane's sample's single NN output
+        if constexpr (K1) {
+            float part[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) part[t] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NBH; ++q) {
+                const f32x4 w4 = *(const f32x4*)&wl[G::WO_OFF + 16 * q + 4 * g];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[t] = fmaf(w4[r], h[q][t][r], part[t]);
+            }
+            const float bo = wl[G::B_OFF + NL * HP];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {           // sum over the four feature quads g (lanes c, c+16, c+32, c+48)
+                part[t] += __shfl_xor(part[t], 16, 64);
+                part[t] += __shfl_xor(part[t], 32, 64);
+                if (g == t) om = part[t] + bo;       // lane 16t + c owns sample 16t + c
+            }
+        } else {
             const float* W = wl + G::WO_OFF;
             f32x4 o[NT];
             const f32x4 bias = *(const f32x4*)&wl[G::B_OFF + NL * HP + 4 * g];
@@ -395,22 +438,23 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) OS[(4 * g + r) * SR + 16 * t + c] = o[t][r];
+            EH_WAVE_SYNC();
         }
-        EH_WAVE_SYNC();
 
         EH_STAMP_FINE(6);
         // ---- 5. mechanistic model + masked loss, one sample per lane -----------------------------
+        float dOm = 0.0f;              // K1: d loss / d (this lane's NN output)
         {
             float par[EH_MAX_PARAMS], sg[EH_MAX_PARAMS], dydp[EH_MAX_PARAMS];
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
-                par[j] = wl[G::PHI_OFF + j]; sg[j] = 1.0f; dydp[j] = 0.0f;
-                if (j < net.n_par && net.par_kind[j] == EH_PAR_NEURAL) {
-                    const float ov = (lane < MT) ? OS[net.par_idx[j] * SR + lane] : 0.0f;
+                par[j] = meta[EH_IMG_PHI + j]; sg[j] = 1.0f; dydp[j] = 0.0f;
+                if (j < net.n_par && pkind(j) == EH_PAR_NEURAL) {
+                    const float ov = K1 ? om : ((lane < MT) ? OS[pidx(j) * SR + lane] : 0.0f);
                     if (net.scale_nn) {
-                        const float s = eh_sigmoid(ov);
-                        par[j] = net.par_lo[j] + (net.par_hi[j] - net.par_lo[j]) * s;
-                        sg[j] = (net.par_hi[j] - net.par_lo[j]) * s * (1.0f - s);
+                        const float s = eh_sigmoid(ov), sc = meta[EH_IMG_SC + j];
+                        par[j] = fmaf(sc, s, meta[EH_IMG_LO + j]);
+                        sg[j] = sc * s * (1.0f - s);
                     } else {
                         par[j] = ov;
                     }
@@ -423,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 if (t < net.T) {
                     const bool valid = live && !__builtin_isnan(yobs[t]);
                     const float r = valid ? y - yobs[t] : 0.0f;
-                    if (TRAIN) {
+                    if constexpr (TRAIN) {
                         const float w = a.inv_n ? a.inv_n[t] : 1.0f;
                         lacc += w * r * r;
                         cacc[t] += valid ? 1.0f : 0.0f;
@@ -435,7 +479,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                     }
                 }
             }
-            if (!TRAIN) {
+            if constexpr (!TRAIN) {
                 if (live) {
                     if (a.yhat)
                         for (int t = 0; t < net.T; ++t) a.yhat[(long long)t * a.yld + n_loc] = y;
@@ -448,20 +492,47 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
                 if (j < net.n_par) {
                     const float dp = live ? dy * dydp[j] : 0.0f;
-                    if (net.par_kind[j] == EH_PAR_NEURAL) {
-                        if (lane < MT) OS[net.par_idx[j] * SR + lane] = dp * sg[j];
-                    } else if (net.par_kind[j] == EH_PAR_GLOBAL) {
+                    const int kd = pkind(j);
+                    if (kd == EH_PAR_NEURAL) {
+                        if constexpr (K1) dOm = dp * sg[j];
+                        else if (lane < MT) OS[pidx(j) * SR + lane] = dp * sg[j];
+                    } else if (kd == EH_PAR_GLOBAL) {
                         gacc[j] += dp;
                     }
                 }
             }
         }
-        EH_WAVE_SYNC();
+        if constexpr (!K1) EH_WAVE_SYNC();
 
         EH_STAMP_FINE(7);
         // ---- 6. backward ------------------------------------------------------------------------
         f32x4 dz[NBH][NT];
-        {
+        constexpr bool DZ_LAST = NL > 1 || !PS;       // does the last hidden layer's delta feed an MFMA weight gradient?
+        if constexpr (K1) {
+            float dOt[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dOt[t] = __shfl(dOm, 16 * t + c, 64);   // sample 16t + c lives in lane 16t + c
+            aBoS += dOm;
+            const float* Hl = HS + (NL - 1) * HP * SR;
+#pragma unroll
+            for (int m = 0; m < NBH; ++m) {
+                const f32x4 w4 = *(const f32x4*)&wl[G::WO_OFF + 16 * m + 4 * g];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ad = (16 * m + 4 * g + r) * SR + 16 * t + c;
+                        const float sv = KEEPH ? hs[NL - 1 < NHS ? NL - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hl[ad];
+                        const float hv = (ACT == EH_ACT_SWISH) ? sv * eh_sigmoid(sv) : sv;
+                        aWoV[m][r] = fmaf(dOt[t], hv, aWoV[m][r]);
+                        const float d = w4[r] * dOt[t] * eh_dact<ACT>(sv);
+                        dz[m][t][r] = d;
+                        if constexpr (DZ_LAST) DZ[ad] = d;
+                    }
+                    aB[NL - 1][m] += dz[m][t];
+                }
+            }
+        } else {
             // output layer: dWo += dO * H_last^T ; dbo += dO ; dH = Wo^T dO
             f32x4 dO[NT], aT[NT];
 #pragma unroll
@@ -504,9 +575,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ad = (16 * m + 4 * g + r) * SR + 16 * t + c;
-                        const float d = dh[t][r] * eh_dact<ACT>(Hl[ad]);
+                        const float sv = KEEPH ? hs[NL - 1 < NHS ? NL - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hl[ad];
+                        const float d = dh[t][r] * eh_dact<ACT>(sv);
                         dz[m][t][r] = d;
-                        DZ[ad] = d;
+                        if constexpr (DZ_LAST) DZ[ad] = d;
                     }
                     aB[NL - 1][m] += dz[m][t];
                 }
@@ -554,6 +626,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                     }
             }
             EH_WAVE_SYNC();
+            const bool need_dz = l > 1 || !PS;
 #pragma unroll
             for (int m = 0; m < NBH; ++m)
 #pragma unroll
@@ -561,28 +634,45 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ad = (16 * m + 4 * g + r) * SR + 16 * t + c;
-                        const float d = dn[m][t][r] * eh_dact<ACT>(Hp[ad]);
+                        const float sv = KEEPH ? hs[l - 1 < NHS ? l - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hp[ad];
+                        const float d = dn[m][t][r] * eh_dact<ACT>(sv);
                         dz[m][t][r] = d;
-                        DZ[ad] = d;
+                        if (need_dz) DZ[ad] = d;
                     }
                     aB[l - 1][m] += dz[m][t];
                 }
         }
-        EH_WAVE_SYNC();
         // layer 0: dW0 += dZ_0 * X^T
+        if constexpr (PS) {
+            float xv[4][NT];
 #pragma unroll
-        for (int m = 0; m < NBH; ++m) {
-            f32x4 aT[NT];
+            for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * m + c) * SR + 16 * t + 4 * g];
+                for (int t = 0; t < NT; ++t) xv[pp][t] = XS[pp * SR + 16 * t + c];     // rows >= P are zero
 #pragma unroll
-            for (int n = 0; n < NBI; ++n)
+            for (int m = 0; m < NBH; ++m)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 b4 = *(const f32x4*)&XS[(16 * n + c) * SR + 16 * t + 4 * g];
+                for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) aW0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aW0[m][n], 0, 0, 0);
-                }
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) aW0V[m][pp][r] = fmaf(dz[m][t][r], xv[pp][t], aW0V[m][pp][r]);
+        } else {
+            EH_WAVE_SYNC();
+#pragma unroll
+            for (int m = 0; m < NBH; ++m) {
+                f32x4 aT[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * m + c) * SR + 16 * t + 4 * g];
+#pragma unroll
+                for (int n = 0; n < NBI; ++n)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const f32x4 b4 = *(const f32x4*)&XS[(16 * n + c) * SR + 16 * t + 4 * g];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) aW0[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aW0[m][n], 0, 0, 0);
+                    }
+            }
         }
         EH_WAVE_SYNC();
     }
@@ -591,12 +681,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     // ---- 7. workgroup reduction -> one partial per workgroup -------------------------------------
     // every wave drops its partial (canonical theta order) into a private LDS region, then the
     // workgroup sums the NW regions in wave order: deterministic, one barrier, no read-modify-write.
-    __syncthreads();                               // the wave workspaces are dead from here on
-    float* const RED = smem + G::IMG_FLOATS + wave * a.n_acc;
     float gscale[EH_MAX_PARAMS];
 #pragma unroll
-    for (int j = 0; j < EH_MAX_PARAMS; ++j) gscale[j] = wl[G::PHI_OFF + 8 + j];
-    if (!TRAIN) {
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) gscale[j] = meta[EH_IMG_DPHI + j];
+    int w_off[NL + 1], b_off[NL + 1], width[NL];
+#pragma unroll
+    for (int l = 0; l <= NL; ++l) { w_off[l] = __float_as_int(meta[EH_IMG_WOFF + l]); b_off[l] = __float_as_int(meta[EH_IMG_BOFF + l]); }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) width[l] = __float_as_int(meta[EH_IMG_WIDTH + l]);
+    __syncthreads();                               // the wave workspaces are dead from here on
+    float* const RED = smem + G::IMG_FLOATS + wave * a.n_acc;
+    if constexpr (!TRAIN) {
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t)
 #pragma unroll
@@ -606,43 +701,81 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             }
     } else {
 #pragma unroll
-        for (int m = 0; m < NBH; ++m)
+        for (int m = 0; m < NBH; ++m) {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) aB[l][m][r] = eh_row16_sum(aB[l][m][r]);
+            if constexpr (K1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
+                for (int r = 0; r < 4; ++r) aWoV[m][r] = eh_row16_sum(aWoV[m][r]);
+            }
+            if constexpr (PS) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aW0V[m][pp][r] = eh_row16_sum(aW0V[m][pp][r]);
+            }
+        }
+        if constexpr (K1) aBoS = eh_wave_sum(aBoS);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
+        }
         lacc = eh_wave_sum(lacc);
 #pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) cacc[t] = eh_wave_sum(cacc[t]);
+        for (int t = 0; t < EH_MAX_TARG; ++t)
+            if (t < net.T) cacc[t] = eh_wave_sum(cacc[t]);
 #pragma unroll
-        for (int j = 0; j < EH_MAX_PARAMS; ++j) gacc[j] = eh_wave_sum(gacc[j]) * gscale[j];
-        const int out0 = net.width[0];
+        for (int j = 0; j < EH_MAX_PARAMS; ++j)
+            if (j < net.n_par) gacc[j] = eh_wave_sum(gacc[j]) * gscale[j];
+        const int out0 = width[0];
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
+            if constexpr (PS) {
+                if (c == 0) {
 #pragma unroll
-            for (int n = 0; n < NBI; ++n)
+                    for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * m + 4 * g + r, col = 16 * n + c;
-                    if (row < out0 && col < net.P) RED[net.w_off[0] + row + out0 * col] = aW0[m][n][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * m + 4 * g + r;
+                            if (row < out0 && pp < net.P) RED[w_off[0] + row + out0 * pp] = aW0V[m][pp][r];
+                        }
                 }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NBI; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * m + 4 * g + r, col = 16 * n + c;
+                        if (row < out0 && col < net.P) RED[w_off[0] + row + out0 * col] = aW0[m][n][r];
+                    }
+            }
 #pragma unroll
             for (int l = 1; l < NL; ++l) {
-                const int outl = net.width[l], inl = net.width[l - 1];
+                const int outl = width[l], inl = width[l - 1];
 #pragma unroll
                 for (int n = 0; n < NBH; ++n)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * m + 4 * g + r, col = 16 * n + c;
-                        if (row < outl && col < inl) RED[net.w_off[l] + row + outl * col] = aWh[l - 1][m][n][r];
+                        if (row < outl && col < inl) RED[w_off[l] + row + outl * col] = aWh[l - 1][m][n][r];
                     }
             }
+            if constexpr (K1) {
+                if (c == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * g + r, col = 16 * m + c;
-                if (row < net.K && col < net.width[NL - 1]) RED[net.w_off[NL] + row + net.K * col] = aWo[m][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = 16 * m + 4 * g + r;
+                        if (col < width[NL - 1]) RED[w_off[NL] + col] = aWoV[m][r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * g + r, col = 16 * m + c;
+                    if (row < net.K && col < width[NL - 1]) RED[w_off[NL] + row + net.K * col] = aWo[m][r];
+                }
             }
             if (c == 0) {
 #pragma unroll
@@ -650,19 +783,21 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * m + 4 * g + r;
-                        if (row < net.width[l]) RED[net.b_off[l] + row] = aB[l][m][r];
+                        if (row < width[l]) RED[b_off[l] + row] = aB[l][m][r];
                     }
             }
         }
-        if (c == 0) {
+        if constexpr (K1) {
+            if (lane == 0) RED[b_off[NL]] = aBoS;
+        } else if (c == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * g + r < net.K) RED[net.b_off[NL] + 4 * g + r] = aBo[r];
+                if (4 * g + r < net.K) RED[b_off[NL] + 4 * g + r] = aBo[r];
         }
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j)
-                if (j < net.n_par && net.par_kind[j] == EH_PAR_GLOBAL) RED[net.g_off + net.par_idx[j]] = gacc[j];
+                if (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) RED[net.g_off + pidx(j)] = gacc[j];
             RED[net.n_theta] = lacc;
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t)
