@@ -5,9 +5,11 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: fused forward + mechanistic model + masked
-MSE + VJP kernel, partial reduction + Adam update (and, for N > 1, one RCCL all-reduce of the
-n_theta+2 raw sums in between).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch: forward + mechanistic model + masked MSE + VJP
++ Adam update.  On one GPU that is ONE kernel per step (fused-update mode: the update of step s is
+applied in the prologue of step s+1's kernel and flushed at the end of the timed region); for N > 1
+it is the step kernel, the partial reduction, one RCCL all-reduce of n_theta+2 raw sums and the
+Adam kernel.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -89,7 +91,17 @@ def main():
     eng.set_data(eh.EH_SPLIT_TRAIN, X, [cols["ta"]], [cols["reco"]])
     eng.set_params(model.initialparameters(161803))                 # same seed on every rank: replicas start equal
     eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
-    dp = eh.dp.DataParallel(eng) if world > 1 else None
+    force_dp = os.environ.get("EH_FORCE_DP", "0") == "1"          # exercise the data-parallel seam on one GPU
+    if world > 1 or force_dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        dp = eh.dp.DataParallel(eng)
+    else:
+        dp = None
+        # one kernel per step: the optimiser update of step s runs in the prologue of step s+1 and the
+        # partial sums are accumulated with float atomics (opt-in mode)
+        eng.set_option("fused_update", int(os.environ.get("EH_FUSED", "1")))
 
     def run(nsteps, base):
         for s in range(nsteps):
@@ -100,6 +112,7 @@ def main():
                 dp.step(first, B)
 
     def fence():
+        eng.synchronize()              # also applies the last step's pending update (fused-update mode)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -132,8 +145,9 @@ def main():
             tf = FLOP_PER_SAMPLE * B / (ms_step * 1e-3) / 1e12
             gbs = BYTES_PER_SAMPLE * B / (ms_step * 1e-3) / 1e9
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                    "traffic": None, "kernel": "eh_step_kernel<1,1,2,4,train>", "kernel_ms": ms_step, "launches_timed": n,
-                    "reduce_adam_kernel_ms": ms_red,
+                    "traffic": None, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if dp is None else
+                    "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS>", "kernel_ms": ms_step, "launches_timed": n,
+                    "reduce_adam_kernel_ms": ms_red if dp is not None else 0.0,
                     "algorithmic": {"flop_per_launch": FLOP_PER_SAMPLE * B, "bytes_per_launch": BYTES_PER_SAMPLE * B},
                     "hbm_achieved_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBPS}
     loss = None
@@ -157,7 +171,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -17,28 +17,6 @@
 // --------------------------------------------------------------------------------------------
 // small kernels
 // --------------------------------------------------------------------------------------------
-struct EhOpt {
-    int rule;
-    float lr, b1, b2, eps, wd;
-};
-
-// Optimisers.jl rules, fp32 op for op.  sc = {beta1^t, beta2^t} running products (Optimisers keeps
-// them in Float32: 1 - Float32(0.999) != 1e-3, which matters at 1e-5 in the first steps).
-__device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1, float bt2, float& th, float& m, float& v) {
-    if (o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW) {
-        m = o.b1 * m + (1.0f - o.b1) * g;
-        v = o.b2 * v + (1.0f - o.b2) * (g * g);
-        float upd = m / (1.0f - bt1) / (sqrtf(v / (1.0f - bt2)) + o.eps) * o.lr;
-        if (o.rule == EH_OPT_ADAMW) upd += o.lr * o.wd * th;     // AdamW(couple = true)
-        th -= upd;
-    } else if (o.rule == EH_OPT_RMSPROP) {                       // RMSProp(eta, rho = b1, eps)
-        v = o.b1 * v + (1.0f - o.b1) * (g * g);
-        th -= g * (o.lr / (sqrtf(v) + o.eps));
-    } else {                                                     // Descent(eta)
-        th -= o.lr * g;
-    }
-}
-
 // Where the optimiser mirrors theta into the padded parameter image the step kernel stages.
 struct EhImg {
     float* image;
@@ -127,6 +105,30 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     if (APPLY && blockIdx.x == 0 && tid == 0) {
         sc_out[0] = ntot > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
         sc_out[1] = ntot > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
+    }
+}
+
+// fused-update mode: apply the still-pending gradient (sharded accumulator g_prev) in place
+__global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev, int n_acc, int n_theta, float* theta, float* m, float* v,
+                                                             const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float cnt = 0.0f, sse = 0.0f;
+#pragma unroll
+    for (int sh = 0; sh < EH_GSHARDS; ++sh) { cnt += g_prev[sh * n_acc + n_theta + 1]; sse += g_prev[sh * n_acc + n_theta]; }
+    const float inv = cnt > 0.0f ? 1.0f / cnt : 0.0f;
+    if (idx < n_theta && cnt > 0.0f) {
+        float gs = 0.0f;
+#pragma unroll
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * n_acc + idx];
+        float th = theta[idx], mm = m[idx], vv = v[idx];
+        eh_opt_update(o, gs * inv, sc_in[0], sc_in[1], th, mm, vv);
+        theta[idx] = th; m[idx] = mm; v[idx] = vv;
+    }
+    if (idx < n_theta) eh_image_store(im, idx, theta[idx]);
+    if (idx == 0) {
+        sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
+        sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
+        if (loss_slot) *loss_slot = cnt > 0.0f ? sse * inv : __builtin_nanf("");
     }
 }
 
@@ -220,6 +222,10 @@ struct EhSplit {
     float shift[EH_MAX_TARG] = {0, 0, 0, 0};
 };
 
+#define TH(h) ((h)->thb[(h)->cur])
+#define MM(h) ((h)->mb[(h)->cur])
+#define VV(h) ((h)->vb[(h)->cur])
+
 struct eh_handle_s {
     eh_model_desc desc;
     EhNet net;
@@ -227,12 +233,20 @@ struct eh_handle_s {
     int variant = 0, act = 0, fast = 0;
     float* image = nullptr;
     int* imap = nullptr;
+    int* rmap = nullptr;            // v2 reduction map for the current fast-path flags
+    int hidden[EH_MAX_HIDDEN + 1] = {0};
     EhImg img{};
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
     int C = 0, n_acc = 0, n_par = 0;
-    float *theta = nullptr, *m = nullptr, *v = nullptr, *sc = nullptr;   // sc: [2][2] running beta products, ping-pong
-    int sc_sel = 0;
+    float *thb[2] = {nullptr, nullptr}, *mb[2] = {nullptr, nullptr}, *vb[2] = {nullptr, nullptr};   // parameter sets (fused mode ping-pongs them)
+    float* sc = nullptr;            // [2][2] running beta products, ping-pong
+    int cur = 0, sc_sel = 0;
+    // fused-update mode
+    bool fused = false, pending = false;
+    float* gacc = nullptr;          // [3][EH_GSHARDS][n_acc] rotating gradient accumulators
+    long long gstep = 0;
+    float* pending_loss = nullptr;
     bool opt_ready = false;
     EhOpt opt{};
     EhSplit split[2];
@@ -271,6 +285,79 @@ static int fail(eh_handle* h, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) return fail(h, e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// ---- fused-update mode: apply the pending gradient so theta / m / v / image are current -----------
+static int flush_pending(eh_handle* h) {
+    if (!h->pending) return EH_OK;
+    const int nt = h->net.n_theta;
+    const float* g_prev = h->gacc + (size_t)((h->gstep + 2) % 3) * EH_GSHARDS * h->n_acc;
+    float* sc_in = h->sc + 2 * h->sc_sel;
+    float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
+    hipLaunchKernelGGL(eh_fused_flush_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, g_prev, h->n_acc, nt, TH(h), MM(h), VV(h), sc_in, sc_out,
+                       h->opt, h->pending_loss, h->img);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemsetAsync(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
+    h->sc_sel ^= 1;
+    h->pending = false;
+    h->pending_loss = nullptr;
+    return EH_OK;
+}
+#define FLUSH(h)                          \
+    do {                                  \
+        int rc_ = flush_pending(h);       \
+        if (rc_) return rc_;              \
+    } while (0)
+
+// canonical index -> position in the step kernel's v2 reduction region (see eh_acc_layout)
+static int build_rmap(eh_handle* h) {
+    const eh_model_desc& d = h->desc;
+    const EhNet& n = h->net;
+    const int nbi = h->arch->nbi, nbh = h->arch->nbh, nl = h->arch->nl, fast = h->fast;
+    const EhAccLayout L = eh_acc_layout(nbi, nbh, nl, fast);
+    std::vector<int> rmap((size_t)h->n_acc, 0);
+    auto at = [](int k, int lane, int r) { return k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15); };   // region[k][g][r][c]
+    int off = 0, in = n.P;
+    for (int l = 0; l <= nl; ++l) {
+        const int o = l < nl ? d.hidden[l] : n.K;
+        for (int col = 0; col < in; ++col)
+            for (int row = 0; row < o; ++row) {
+                const int e = off + row + o * col;
+                int code;
+                if (l == 0) {
+                    const int m = row / 16, g = (row % 16) / 4, r = row % 4;
+                    if (fast & 2) code = at(L.kw0 + m * 4 + col, 16 * g, r) | (16 << 24);
+                    else code = at(L.kw0 + m * nbi + col / 16, 16 * g + col % 16, r) | (1 << 24);
+                } else if (l < nl) {
+                    const int m = row / 16, g = (row % 16) / 4, r = row % 4;
+                    code = at(L.kwh + ((l - 1) * nbh + m) * nbh + col / 16, 16 * g + col % 16, r) | (1 << 24);
+                } else if (fast & 1) {
+                    const int m = col / 16, g = (col % 16) / 4, r = col % 4;
+                    code = at(L.kwo + m, 16 * g, r) | (16 << 24);
+                } else {
+                    code = at(L.kwo + col / 16, 16 * (row / 4) + col % 16, row % 4) | (1 << 24);
+                }
+                rmap[e] = code;
+            }
+        off += o * in;
+        for (int row = 0; row < o; ++row) {
+            int code;
+            if (l < nl) code = at(L.kb + l * nbh + row / 16, 16 * ((row % 16) / 4), row % 4) | (16 << 24);
+            else if (fast & 1) code = (L.na * 256 + 13) | (1 << 24);
+            else code = at(L.kbo, 16 * (row / 4), row % 4) | (16 << 24);
+            rmap[off + row] = code;
+        }
+        off += o;
+        in = o;
+    }
+    for (int j = 0; j < d.n_params; ++j)
+        if (d.param_kind[j] == EH_PAR_GLOBAL) rmap[n.g_off + d.param_index[j]] = (L.na * 256 + j) | (1 << 24);
+    rmap[n.n_theta] = (L.na * 256 + 8) | (1 << 24);
+    for (int t = 0; t < n.T; ++t) rmap[n.n_theta + 1 + t] = (L.na * 256 + 9 + t) | (1 << 24);
+    if (!h->rmap) HIPCHK(h, hipMalloc(&h->rmap, rmap.size() * sizeof(int)));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->rmap, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice));
+    return EH_OK;
+}
 
 struct MechInfo { int n_par, n_forc, n_out; };
 static bool mech_info(int mech, MechInfo* mi) {
@@ -351,6 +438,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->desc = *d;
     h->device = d->device;
     h->arch = arch;
+    h->variant = arch->nvar > 1 ? 1 : 0;   // narrow nets: two waves per SIMD hide the latency of the short tile
     EhNet& n = h->net;
     memset(&n, 0, sizeof n);
     n.P = d->n_predictors; n.K = K; n.G = G; n.T = d->n_targets; n.F = d->n_forcings;
@@ -396,16 +484,20 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->stream = h->own_stream;
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
     const size_t nt = (size_t)n.n_theta;
-    HIPCHK_C(hipMalloc(&h->theta, nt * sizeof(float)));
-    HIPCHK_C(hipMalloc(&h->m, nt * sizeof(float)));
-    HIPCHK_C(hipMalloc(&h->v, nt * sizeof(float)));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK_C(hipMalloc(&h->thb[k], nt * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->mb[k], nt * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->vb[k], nt * sizeof(float)));
+        HIPCHK_C(hipMemset(h->thb[k], 0, nt * sizeof(float)));
+        HIPCHK_C(hipMemset(h->mb[k], 0, nt * sizeof(float)));
+        HIPCHK_C(hipMemset(h->vb[k], 0, nt * sizeof(float)));
+    }
+    HIPCHK_C(hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->sc, 4 * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->slab, (size_t)h->max_blocks * std::max(h->n_acc, EH_EVAL_STATS * n.T) * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, EH_MAX_TARG * sizeof(float)));
-    HIPCHK_C(hipMemset(h->theta, 0, nt * sizeof(float)));
-    HIPCHK_C(hipMemset(h->m, 0, nt * sizeof(float)));
-    HIPCHK_C(hipMemset(h->v, 0, nt * sizeof(float)));
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
     {   // parameter image: canonical index -> padded LDS-layout offset
         std::vector<int> imap(nt, -1);
@@ -432,6 +524,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         auto put_int = [&](int slot, int v) { memcpy(&img0[arch->phi_off + slot], &v, sizeof(int)); };
         for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
         for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, d->hidden[l]);
+        for (int j = 0; j < d->n_params; ++j)
+            if (d->param_kind[j] == EH_PAR_GLOBAL) put_int(EH_IMG_GPAR + d->param_index[j], j);
         HIPCHK_C(hipMalloc(&h->image, img0.size() * sizeof(float)));
         HIPCHK_C(hipMalloc(&h->imap, nt * sizeof(int)));
         HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -443,11 +537,12 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
                 const int g = d->param_index[j];
                 im.glob_par[g] = j; im.glo[g] = d->param_lower[j]; im.ghi[g] = d->param_upper[j];
             }
-        hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, h->theta, (int)nt, h->img);
+        hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, TH(h), (int)nt, h->img);
         HIPCHK_C(hipGetLastError());
         HIPCHK_C(hipStreamSynchronize(h->stream));
     }
 #undef HIPCHK_C
+    if (int rc = build_rmap(h)) { g_create_err = h->err; eh_destroy(h); return rc; }
     *out = h;
     return EH_OK;
 }
@@ -457,9 +552,10 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
-    (void)hipFree(h->theta); (void)hipFree(h->m); (void)hipFree(h->v); (void)hipFree(h->sc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    for (int k = 0; k < 2; ++k) { (void)hipFree(h->thb[k]); (void)hipFree(h->mb[k]); (void)hipFree(h->vb[k]); }
+    (void)hipFree(h->gacc); (void)hipFree(h->sc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap);
+    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -481,6 +577,7 @@ int32_t eh_set_stream(eh_handle* h, void* s) {
 int32_t eh_synchronize(eh_handle* h) {
     if (!h) return EH_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return EH_OK;
 }
@@ -495,6 +592,15 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "fast_paths")) {       // 0 forces the generic MFMA kernels (A/B testing)
         const int want = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
         h->fast = value ? (want & (int)value) : 0;
+        HIPCHK(h, hipSetDevice(h->device));
+        FLUSH(h);
+        return build_rmap(h);
+    }
+    if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
+        if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
+        HIPCHK(h, hipSetDevice(h->device));
+        FLUSH(h);
+        h->fused = value != 0;
         return EH_OK;
     }
     if (!strcmp(name, "variant")) {
@@ -561,9 +667,10 @@ int32_t eh_set_params(eh_handle* h, const float* theta, int64_t n) {
     if (!h || !theta) return EH_EINVAL;
     if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_set_params: n = %lld, model has %d", (long long)n, h->net.n_theta);
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(h->theta, theta, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->theta, (int)n, h->img);
+    HIPCHK(h, hipMemcpy(TH(h), theta, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, TH(h), (int)n, h->img);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return EH_OK;
@@ -573,14 +680,16 @@ int32_t eh_get_params(eh_handle* h, float* theta, int64_t n) {
     if (!h || !theta) return EH_EINVAL;
     if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_get_params: n = %lld, model has %d", (long long)n, h->net.n_theta);
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(theta, h->theta, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(theta, TH(h), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return EH_OK;
 }
 
 }   // extern "C"
 
 // ---- internal launch helpers ---------------------------------------------------------------------
+static int ensure_events(eh_handle* h, size_t need);
 static int grid_for(const eh_handle* h, long long count) {
     const EhVariant& v = h->arch->var[h->variant];
     const long long mt = 16LL * v.nt;
@@ -598,10 +707,45 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
     a.inv_n = net.T > 1 ? h->inv_n : nullptr;
+    a.rmap = h->rmap;
     a.stamps = h->stamps;
+    a.fz.g_cur = nullptr;
     const int grid = grid_for(h, count);
     *grid_out = grid;
     HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
+    return EH_OK;
+}
+
+// one fused kernel: prologue applies the previous step's update, epilogue accumulates this step's sums
+static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, float* loss_slot_for_this_step) {
+    const bool prof = h->prof && h->ev_used + 3 <= 3 * 8192;
+    if (prof) {
+        int rc = ensure_events(h, h->ev_used + 3);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    }
+    const size_t gsz = (size_t)EH_GSHARDS * h->n_acc;
+    EhStepArgs a{};
+    a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
+    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;
+    EhFused& z = a.fz;
+    z.g_cur = h->gacc + (size_t)(h->gstep % 3) * gsz;
+    z.g_prev = h->gacc + (size_t)((h->gstep + 2) % 3) * gsz;
+    z.g_zero = h->gacc + (size_t)((h->gstep + 1) % 3) * gsz;
+    const int in = h->cur, out = h->cur ^ 1;
+    z.th_in = h->thb[in]; z.m_in = h->mb[in]; z.v_in = h->vb[in]; z.sc_in = h->sc + 2 * h->sc_sel;
+    z.th_out = h->thb[out]; z.m_out = h->mb[out]; z.v_out = h->vb[out]; z.sc_out = h->sc + 2 * (h->sc_sel ^ 1);
+    z.imap = h->imap; z.loss_slot = h->pending_loss; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
+    const int grid = grid_for(h, count);
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
+    h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;
+    h->pending = true;
+    h->pending_loss = loss_slot_for_this_step;
+    if (prof) {
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
+        h->ev_used += 3;
+    }
     return EH_OK;
 }
 
@@ -633,11 +777,11 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     if (apply) {
         hipLaunchKernelGGL(eh_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot, h->img);
+                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img);
         h->sc_sel ^= 1;
     } else {
         hipLaunchKernelGGL(eh_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           h->theta, h->m, h->v, sc_in, sc_out, h->opt, loss_slot, h->img);
+                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img);
     }
     HIPCHK(h, hipGetLastError());
     if (prof) {
@@ -649,6 +793,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
 
 static int ensure_loss_hist(eh_handle* h, long long need) {
     if (h->loss_cap >= need) return EH_OK;
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(h->loss_hist);
     h->loss_hist = nullptr; h->loss_cap = 0;
@@ -670,6 +815,7 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     HIPCHK(h, hipSetDevice(h->device));
     int rc = check_window(h, sp, first, count, "eh_eval");
     if (rc) return rc;
+    FLUSH(h);
     const long long need = (long long)(yhat ? net.T : 0) * count + (long long)(params ? h->n_par : 0) * count;
     if (need > h->out_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -745,6 +891,7 @@ int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_
     if (!h) return EH_EINVAL;
     if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_loss_and_grad: split %d", split);
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     EhSplit& sp = h->split[split];
     int rc;
     const int* didx = nullptr;
@@ -787,11 +934,12 @@ int32_t eh_opt_init(eh_handle* h, int32_t rule, float lr, float beta1, float bet
     if (!h) return EH_EINVAL;
     if (rule < EH_OPT_ADAM || rule > EH_OPT_DESCENT) return fail(h, EH_EUNSUPPORTED, "eh_opt_init: unknown rule %d", rule);
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->opt = EhOpt{rule, lr, beta1, beta2, eps, weight_decay};
     const size_t nt = (size_t)h->net.n_theta;
-    HIPCHK(h, hipMemset(h->m, 0, nt * sizeof(float)));
-    HIPCHK(h, hipMemset(h->v, 0, nt * sizeof(float)));
+    HIPCHK(h, hipMemset(MM(h), 0, nt * sizeof(float)));
+    HIPCHK(h, hipMemset(VV(h), 0, nt * sizeof(float)));
     const float sc[4] = {beta1, beta2, beta1, beta2};   // Optimisers.jl starts the running product at beta (t = 1)
     HIPCHK(h, hipMemcpy(h->sc, sc, sizeof sc, hipMemcpyHostToDevice));
     h->sc_sel = 0;
@@ -803,9 +951,10 @@ int32_t eh_get_opt_state(eh_handle* h, float* m, float* v, int64_t n, float* bet
     if (!h) return EH_EINVAL;
     if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_get_opt_state: n");
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (m) HIPCHK(h, hipMemcpy(m, h->m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    if (v) HIPCHK(h, hipMemcpy(v, h->v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (m) HIPCHK(h, hipMemcpy(m, MM(h), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (v) HIPCHK(h, hipMemcpy(v, VV(h), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     if (beta_t) HIPCHK(h, hipMemcpy(beta_t, h->sc + 2 * h->sc_sel, 2 * sizeof(float), hipMemcpyDeviceToHost));
     return EH_OK;
 }
@@ -815,9 +964,10 @@ int32_t eh_set_opt_state(eh_handle* h, const float* m, const float* v, int64_t n
     if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_set_opt_state: call eh_opt_init first");
     if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_set_opt_state: n");
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (m) HIPCHK(h, hipMemcpy(h->m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    if (v) HIPCHK(h, hipMemcpy(h->v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (m) HIPCHK(h, hipMemcpy(MM(h), m, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (v) HIPCHK(h, hipMemcpy(VV(h), v, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     if (beta_t) HIPCHK(h, hipMemcpy(h->sc + 2 * h->sc_sel, beta_t, 2 * sizeof(float), hipMemcpyHostToDevice));
     return EH_OK;
 }
@@ -831,8 +981,14 @@ int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_ou
     if (rc) return rc;
     rc = ensure_loss_hist(h, 1);
     if (rc) return rc;
-    rc = do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, true, false, loss_out ? h->loss_hist : nullptr);
-    if (rc) return rc;
+    if (h->fused) {
+        rc = do_fused_step(h, sp, nullptr, first, count, loss_out ? h->loss_hist : nullptr);
+        if (rc) return rc;
+        if (loss_out) FLUSH(h);
+    } else {
+        rc = do_step(h, sp, nullptr, first, count, true, false, loss_out ? h->loss_hist : nullptr);
+        if (rc) return rc;
+    }
     if (loss_out) {
         HIPCHK(h, hipMemcpyAsync(loss_out, h->loss_hist, sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -867,9 +1023,11 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
     if (rc) return rc;
     for (long long s = 0; s < steps; ++s) {
         const long long first = s * batchsize, count = std::min<long long>(batchsize, N - first);
-        rc = do_step(h, sp, shuffle ? h->perm : nullptr, first, count, true, false, h->loss_hist + s);
+        rc = h->fused ? do_fused_step(h, sp, shuffle ? h->perm : nullptr, first, count, h->loss_hist + s)
+                      : do_step(h, sp, shuffle ? h->perm : nullptr, first, count, true, false, h->loss_hist + s);
         if (rc) return rc;
     }
+    if (mean_loss) FLUSH(h);
     if (n_steps) *n_steps = steps;
     if (mean_loss) {
         std::vector<float> l((size_t)steps);
@@ -886,10 +1044,23 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
     HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
     int rc = check_window(h, sp, first, count, "eh_dp_grad");
     if (rc) return rc;
     return do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
+}
+
+int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index) {
+    if (!h || !buffer_index) return EH_EINVAL;
+    if (!h->fused) return fail(h, EH_ESTATE, "eh_dp_fused_step: set the fused_update option first");
+    if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_dp_fused_step: call eh_opt_init first");
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    int rc = check_window(h, sp, first, count, "eh_dp_fused_step");
+    if (rc) return rc;
+    *buffer_index = (int32_t)(h->gstep % 3);
+    return do_fused_step(h, sp, nullptr, first, count, nullptr);
 }
 
 int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
@@ -901,7 +1072,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     const int nt = h->net.n_theta;
-    hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, h->theta, h->m, h->v, sc_in, sc_out, h->opt,
+    hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, TH(h), MM(h), VV(h), sc_in, sc_out, h->opt,
                        h->loss_hist, h->img);
     HIPCHK(h, hipGetLastError());
     h->sc_sel ^= 1;
@@ -914,11 +1085,13 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
 
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {
     if (!h || !dev_ptr || !n_floats) return EH_EINVAL;
+    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
     switch (which) {
         case EH_BUF_GRAD: *dev_ptr = h->gradbuf; *n_floats = h->n_acc; return EH_OK;
-        case EH_BUF_THETA: *dev_ptr = h->theta; *n_floats = h->net.n_theta; return EH_OK;
-        case EH_BUF_OPT_M: *dev_ptr = h->m; *n_floats = h->net.n_theta; return EH_OK;
-        case EH_BUF_OPT_V: *dev_ptr = h->v; *n_floats = h->net.n_theta; return EH_OK;
+        case EH_BUF_THETA: *dev_ptr = TH(h); *n_floats = h->net.n_theta; return EH_OK;
+        case EH_BUF_OPT_M: *dev_ptr = MM(h); *n_floats = h->net.n_theta; return EH_OK;
+        case EH_BUF_OPT_V: *dev_ptr = VV(h); *n_floats = h->net.n_theta; return EH_OK;
+        case EH_BUF_GACC: *dev_ptr = h->gacc; *n_floats = (int64_t)3 * EH_GSHARDS * h->n_acc; return EH_OK;
         default: return fail(h, EH_EINVAL, "eh_device_buffer: which = %d", which);
     }
 }

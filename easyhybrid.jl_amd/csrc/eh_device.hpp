@@ -45,7 +45,49 @@ struct EhNet {
 // Per-layer offsets / widths and the (lower, upper-lower) table travel in the parameter image
 // (EhGeom::PHI_OFF block) instead of the kernarg: they are read from LDS where they are used,
 // which keeps them out of the scalar register file during the tile loop.
-enum { EH_IMG_PHI = 0, EH_IMG_DPHI = 8, EH_IMG_LO = 16, EH_IMG_SC = 24, EH_IMG_WOFF = 32, EH_IMG_BOFF = 37, EH_IMG_WIDTH = 42, EH_IMG_META = 48 };
+enum { EH_IMG_PHI = 0, EH_IMG_DPHI = 8, EH_IMG_LO = 16, EH_IMG_SC = 24, EH_IMG_WOFF = 32, EH_IMG_BOFF = 37, EH_IMG_WIDTH = 42, EH_IMG_GPAR = 48, EH_IMG_META = 56 };
+
+struct EhOpt {
+    int rule;
+    float lr, b1, b2, eps, wd;
+};
+
+// Optimisers.jl rules, fp32 op for op.  bt = {beta1^t, beta2^t} running products (Optimisers keeps
+// them in Float32: 1 - Float32(0.999) != 1e-3, which matters at 1e-5 in the first steps).
+__device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1, float bt2, float& th, float& m, float& v) {
+    if (o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW) {
+        m = o.b1 * m + (1.0f - o.b1) * g;
+        v = o.b2 * v + (1.0f - o.b2) * (g * g);
+        float upd = m / (1.0f - bt1) / (sqrtf(v / (1.0f - bt2)) + o.eps) * o.lr;
+        if (o.rule == EH_OPT_ADAMW) upd += o.lr * o.wd * th;     // AdamW(couple = true)
+        th -= upd;
+    } else if (o.rule == EH_OPT_RMSPROP) {                       // RMSProp(eta, rho = b1, eps)
+        v = o.b1 * v + (1.0f - o.b1) * (g * g);
+        th -= g * (o.lr / (sqrtf(v) + o.eps));
+    } else {                                                     // Descent(eta)
+        th -= o.lr * g;
+    }
+}
+
+#define EH_GSHARDS 8   // gradient accumulators are sharded 8 ways (blockIdx & 7) to spread the float atomics
+
+// "fused update" mode: ONE kernel per training step.  The step kernel's prologue applies the
+// optimiser update of the PREVIOUS step (every workgroup recomputes the new theta into its LDS
+// image from theta/m/v and the accumulated gradient; workgroup 0 also stores it), and its epilogue
+// adds this step's partial sums into the sharded accumulator with float atomics instead of
+// writing a slab row.  Saves the reduce kernel and its launch boundary; the sums are no longer
+// bitwise reproducible (atomic arrival order), so it is opt-in.
+struct EhFused {
+    float* g_cur;          // nullptr = two-kernel (deterministic) mode; else [EH_GSHARDS][n_acc] accumulator of this step
+    const float* g_prev;   // accumulator of the previous step (applied in the prologue when pending)
+    float* g_zero;         // accumulator the NEXT step will use: cleared by workgroup 0
+    const float *th_in, *m_in, *v_in, *sc_in;
+    float *th_out, *m_out, *v_out, *sc_out;
+    const int* imap;       // canonical index -> image offset
+    float* loss_slot;      // where the previous step's loss goes (nullable)
+    int pending;
+    EhOpt opt;
+};
 
 struct EhStepArgs {
     const float* recs;    // dataset, one record of C = P+F+T floats per sample: [predictors | forcings | targets (NaN = missing)]
@@ -57,10 +99,12 @@ struct EhStepArgs {
     int n_acc;            // train: n_theta + 1 + T ; eval: EH_EVAL_STATS*T
     const float* inv_n;   // train: per-target 1/n_t (device) or nullptr = deferred normalisation (weight 1)
     float* yhat;          // eval (optional): [T][yld] predictions for samples first..first+count
+    const int* rmap;      // train: canonical index -> (position | lanes<<24) in the v2 reduction region
     float* pout;          // eval (optional): [n_par][yld] physical parameters per sample
     long long yld;
     float shift[EH_MAX_TARG];   // eval: metric shift c_t
     unsigned long long* stamps;   // diagnostic builds (-DEH_STAMPS) only: [16][2] (shader clock, 100 MHz wall clock)
+    EhFused fz;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -174,7 +218,7 @@ struct EhGeom {
     static constexpr int WH_OFF = W0_OFF + HP * S0;                  // NL-1 hidden->hidden matrices
     static constexpr int WO_OFF = WH_OFF + (NL - 1) * HP * SH;       // output layer, 16 padded rows
     static constexpr int B_OFF = WO_OFF + 16 * SH;                   // biases: NL * HP + 16
-    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;             // EH_IMG_* block: phi[8], dphi[8], lo[8], hi-lo[8], int w_off[5], b_off[5], width[4]
+    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;             // EH_IMG_* block: phi[8], dphi[8], lo[8], hi-lo[8], int w_off[5], b_off[5], width[4], gpar[8]
     static constexpr int IMG_FLOATS = PHI_OFF + EH_IMG_META;         // multiple of 4
     // per-wave workspace
     static constexpr int XS_OFF = 0;
@@ -184,6 +228,22 @@ struct EhGeom {
     static constexpr int WAVE_WS = OS_OFF + 16 * SR;
     static constexpr int TOTAL_FLOATS = IMG_FLOATS + NW * WAVE_WS;
 };
+
+// Order of the per-lane f32x4 gradient accumulators as the step kernel parks them in LDS for the
+// end-of-kernel reduction ("v2" layout: region[k][lane][r], then 16 scalars).  Shared with the host,
+// which builds the canonical-index -> region-position map (rmap) from it.
+struct EhAccLayout { int kw0, nw0, kwh, nwh, kwo, kb, kbo, na, rw; };
+__host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl, int fast) {
+    EhAccLayout L{};
+    L.kw0 = 0; L.nw0 = (fast & 2) ? nbh * 4 : nbh * nbi;
+    L.kwh = L.kw0 + L.nw0; L.nwh = (nl - 1) * nbh * nbh;
+    L.kwo = L.kwh + L.nwh;
+    L.kb = L.kwo + nbh;
+    L.kbo = L.kb + nl * nbh;
+    L.na = L.kbo + ((fast & 1) ? 0 : 1);
+    L.rw = L.na * 256 + 16;      // tail scalars: [0..7] global-param sums, [8] loss, [9..12] counts, [13] output bias (K1)
+    return L;
+}
 
 #ifdef EH_STAMPS
 #define EH_STAMP(i)                                                                      \
@@ -267,9 +327,66 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 
     EH_STAMP(0);
     // ---- stage the parameter image into LDS (straight copy) ------------------------------------
+    // (fused update) the first chunk of optimiser inputs is requested together with the image so
+    // that everything arrives in one memory round trip
+    const bool fusedm = TRAIN && a.fz.g_cur != nullptr;
+    float f_th = 0.0f, f_m = 0.0f, f_v = 0.0f, f_g = 0.0f, f_cnt = 0.0f, f_sse = 0.0f, f_bt1 = 0.0f, f_bt2 = 0.0f;
+    int f_map = 0;
+    if (fusedm) {
+        const EhFused& z = a.fz;
+        if (z.pending) {
+#pragma unroll
+            for (int sh = 0; sh < EH_GSHARDS; ++sh) { f_cnt += z.g_prev[sh * a.n_acc + net.n_theta + 1]; f_sse += z.g_prev[sh * a.n_acc + net.n_theta]; }
+        }
+        f_bt1 = z.sc_in[0]; f_bt2 = z.sc_in[1];
+        if (tid < net.n_theta) {
+            f_th = z.th_in[tid]; f_m = z.m_in[tid]; f_v = z.v_in[tid];
+            f_map = tid < net.g_off ? z.imap[tid] : 0;
+            if (z.pending) {
+#pragma unroll
+                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += z.g_prev[sh * a.n_acc + tid];
+            }
+        }
+    }
     for (int e = 4 * tid; e < G::IMG_FLOATS; e += 4 * NTHR) *(f32x4*)&wl[e] = *(const f32x4*)&a.image[e];
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
     __syncthreads();
+    if (fusedm) {
+        // fused update: apply the previous step's optimiser update straight into the LDS image
+        const EhFused& z = a.fz;
+        const bool upd = z.pending && f_cnt > 0.0f;
+        const float inv = upd ? 1.0f / f_cnt : 0.0f;
+        for (int idx = tid; idx < net.n_theta; idx += NTHR) {
+            float th, mm, vv, gs = 0.0f;
+            int mp;
+            if (idx == tid) { th = f_th; mm = f_m; vv = f_v; gs = f_g; mp = f_map; }
+            else {
+                th = z.th_in[idx]; mm = z.m_in[idx]; vv = z.v_in[idx];
+                mp = idx < net.g_off ? z.imap[idx] : 0;
+                if (upd) {
+#pragma unroll
+                    for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += z.g_prev[sh * a.n_acc + idx];
+                }
+            }
+            if (upd) eh_opt_update(z.opt, gs * inv, f_bt1, f_bt2, th, mm, vv);
+            if ((unsigned)idx % gridDim.x == blockIdx.x) { z.th_out[idx] = th; z.m_out[idx] = mm; z.v_out[idx] = vv; }   // every workgroup holds the same values: spread the stores
+            if (idx < net.g_off) {
+                wl[mp] = th;
+            } else {
+                const int j = __float_as_int(meta[EH_IMG_GPAR + idx - net.g_off]);
+                const float sg = 1.0f / (1.0f + expf(-th)), sc = meta[EH_IMG_SC + j];
+                wl[G::PHI_OFF + EH_IMG_PHI + j] = meta[EH_IMG_LO + j] + sc * sg;
+                wl[G::PHI_OFF + EH_IMG_DPHI + j] = sc * sg * (1.0f - sg);
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            z.sc_out[0] = upd ? f_bt1 * z.opt.b1 : f_bt1;
+            z.sc_out[1] = upd ? f_bt2 * z.opt.b2 : f_bt2;
+            if (z.loss_slot && z.pending) *z.loss_slot = upd ? f_sse * inv : __builtin_nanf("");
+        }
+        for (int e = blockIdx.x * NTHR + tid; e < EH_GSHARDS * a.n_acc; e += gridDim.x * NTHR) z.g_zero[e] = 0.0f;
+        __syncthreads();
+    }
     EH_STAMP(1);
 
     // ---- accumulators (registers, live across the tile loop) ------------------------------------
@@ -679,8 +796,87 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 
     EH_STAMP(8);
     // ---- 7. workgroup reduction -> one partial per workgroup -------------------------------------
-    // every wave drops its partial (canonical theta order) into a private LDS region, then the
-    // workgroup sums the NW regions in wave order: deterministic, one barrier, no read-modify-write.
+    constexpr EhAccLayout AL = eh_acc_layout(NBI, NBH, NL, FAST);
+    constexpr bool REDV2 = TRAIN && AL.rw <= G::WAVE_WS;
+    if constexpr (REDV2) {
+        // v2: every lane parks its raw accumulators with unconditional 16-byte stores; the sums over
+        // the 16 samples of a row, over the waves and the padding removal all happen in the final
+        // gather loop through the host-built rmap (fixed order: deterministic).
+        float tailv[16];
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) tailv[j] = (j < net.n_par) ? eh_wave_sum(gacc[j]) * meta[EH_IMG_DPHI + j] : 0.0f;
+        tailv[8] = eh_wave_sum(lacc);
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) tailv[9 + t] = (t < net.T) ? eh_wave_sum(cacc[t]) : 0.0f;
+        tailv[13] = K1 ? eh_wave_sum(aBoS) : 0.0f;
+        tailv[14] = 0.0f; tailv[15] = 0.0f;
+        EH_STAMP(13);
+        __syncthreads();                           // the wave workspaces are dead from here on
+        EH_STAMP(14);
+        float* const R = smem + G::IMG_FLOATS + wave * AL.rw;
+        // region[k][g][r][c]: the 16 samples (c) of a row are contiguous, so row sums are four 16-byte reads
+        auto put = [&](int k, const f32x4& v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[k * 256 + g * 64 + r * 16 + c] = v[r];
+        };
+#pragma unroll
+        for (int m = 0; m < NBH; ++m) {
+            if constexpr (PS) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) put(AL.kw0 + m * 4 + pp, aW0V[m][pp]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NBI; ++n) put(AL.kw0 + m * NBI + n, aW0[m][n]);
+            }
+#pragma unroll
+            for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+                for (int n = 0; n < NBH; ++n) put(AL.kwh + (l * NBH + m) * NBH + n, aWh[l][m][n]);
+            if constexpr (K1) put(AL.kwo + m, aWoV[m]); else put(AL.kwo + m, aWo[m]);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) put(AL.kb + l * NBH + m, aB[l][m]);
+        }
+        if constexpr (!K1) put(AL.kbo, aBo);
+        if (lane < 16) {
+            float tv = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tv = (lane == k) ? tailv[k] : tv;
+            R[AL.na * 256 + lane] = tv;
+        }
+        EH_STAMP(12);
+        __syncthreads();
+        EH_STAMP(9);
+        const float* const R0 = smem + G::IMG_FLOATS;
+        float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
+        float* const gsh = a.fz.g_cur ? a.fz.g_cur + (blockIdx.x & (EH_GSHARDS - 1)) * a.n_acc : nullptr;
+        for (int e = tid; e < a.n_acc; e += NTHR) {
+            const int code = a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
+            float sum = 0.0f;
+            if (nlan == 16) {
+                f32x4 v[NW][4];
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[w][i] = *(const f32x4*)&R0[w * AL.rw + pos + 4 * i];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const f32x4 q = (v[w][0] + v[w][1]) + (v[w][2] + v[w][3]);
+                    sum += (q[0] + q[1]) + (q[2] + q[3]);
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += R0[w * AL.rw + pos];
+            }
+#ifdef EH_EXP_NOATOMIC
+            out[e] = sum;
+#else
+            if (gsh) atomicAdd(&gsh[e], sum);
+            else out[e] = sum;
+#endif
+        }
+        EH_STAMP(10);
+        return;
+    }
     float gscale[EH_MAX_PARAMS];
 #pragma unroll
     for (int j = 0; j < EH_MAX_PARAMS; ++j) gscale[j] = meta[EH_IMG_DPHI + j];
@@ -689,7 +885,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     for (int l = 0; l <= NL; ++l) { w_off[l] = __float_as_int(meta[EH_IMG_WOFF + l]); b_off[l] = __float_as_int(meta[EH_IMG_BOFF + l]); }
 #pragma unroll
     for (int l = 0; l < NL; ++l) width[l] = __float_as_int(meta[EH_IMG_WIDTH + l]);
+    EH_STAMP(13);
     __syncthreads();                               // the wave workspaces are dead from here on
+    EH_STAMP(14);
     float* const RED = smem + G::IMG_FLOATS + wave * a.n_acc;
     if constexpr (!TRAIN) {
 #pragma unroll
@@ -729,6 +927,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
         for (int j = 0; j < EH_MAX_PARAMS; ++j)
             if (j < net.n_par) gacc[j] = eh_wave_sum(gacc[j]) * gscale[j];
+        EH_STAMP(11);
         const int out0 = width[0];
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
@@ -804,16 +1003,19 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 if (t < net.T) RED[net.n_theta + 1 + t] = cacc[t];
         }
     }
+    EH_STAMP(12);
     __syncthreads();
     EH_STAMP(9);
     {
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
+        float* const gsh = (TRAIN && a.fz.g_cur) ? a.fz.g_cur + (blockIdx.x & (EH_GSHARDS - 1)) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             float s = R0[e];
 #pragma unroll
             for (int w = 1; w < NW; ++w) s += R0[w * a.n_acc + e];
-            out[e] = s;
+            if (gsh) atomicAdd(&gsh[e], s);
+            else out[e] = s;
         }
     }
     EH_STAMP(10);

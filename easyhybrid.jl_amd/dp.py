@@ -48,16 +48,28 @@ class _DevArray:
 class DataParallel:
     """Drives one replica.  `engine` already holds this rank's shard as its train split."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, fused: bool = True):
+        """fused=True: one kernel + one all-reduce per step (the update of step s is applied in the
+        prologue of step s+1; `engine.synchronize()` applies the last one).  fused=False: step kernel,
+        deterministic reduction, all-reduce, optimiser kernel."""
         import torch
         from . import _lib as L
-        self.engine, self.group = engine, group
+        self.engine, self.group, self.fused = engine, group, fused
+        dev = torch.device("cuda", torch.cuda.current_device())
         ptr, n = engine.device_buffer(L.EH_BUF_GRAD)
-        self.buf = torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", torch.cuda.current_device()))
+        self.buf = torch.as_tensor(_DevArray(ptr, n), device=dev)
+        if fused:
+            engine.set_option("fused_update", 1)
+            gptr, gn = engine.device_buffer(L.EH_BUF_GACC)
+            self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=dev) for k in range(3)]
         # run the engine on torch's current stream so kernels and the collective are ordered
         engine.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step(self, first: int, count: int, want_loss: bool = False):
+        if self.fused and not want_loss:
+            k = self.engine.dp_fused_step(first, count)
+            allreduce_partials(self.gacc[k], self.group)      # 8 shards x (n_theta + 2) raw sums
+            return None
         self.engine.dp_grad(first, count)
         allreduce_partials(self.buf, self.group)
         return self.engine.dp_apply(want_loss)

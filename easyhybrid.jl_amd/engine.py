@@ -192,6 +192,11 @@ class HybridEngine:
         self._chk(self._lib.eh_dp_apply(self._h, C.byref(loss) if want_loss else None))
         return float(loss.value) if want_loss else None
 
+    def dp_fused_step(self, first: int, count: int) -> int:
+        k = C.c_int32()
+        self._chk(self._lib.eh_dp_fused_step(self._h, first, count, C.byref(k)))
+        return int(k.value)
+
     def device_buffer(self, which: int):
         p = C.c_void_p()
         n = C.c_int64()

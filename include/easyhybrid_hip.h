@@ -75,7 +75,7 @@ typedef enum eh_split { EH_SPLIT_TRAIN = 0, EH_SPLIT_VAL = 1 } eh_split;
 typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2, EH_OPT_DESCENT = 3 } eh_opt_rule;
 
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
-typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3 } eh_buffer;
+typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4 } eh_buffer;
 
 typedef struct eh_model_desc {
     int32_t struct_size;                     /* = sizeof(eh_model_desc) */
@@ -173,6 +173,14 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count);
 int32_t eh_dp_apply(eh_handle* h, float* loss_out);
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats);
 
+/* One-kernel-per-step variant of the data-parallel seam (needs eh_set_option("fused_update", 1)):
+ * eh_dp_fused_step launches the fused step kernel, whose prologue applies the (already all-reduced)
+ * accumulator of the previous step and whose epilogue adds this step's raw partial sums into one
+ * of three rotating accumulators inside EH_BUF_GACC ([3][8 shards][n_theta+1+T] floats);
+ * *buffer_index says which third the host must all_reduce(SUM) next.  eh_synchronize applies the
+ * last pending update. */
+int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index);
+
 /* timing aid for bench.py: when enabled, eh_train_step brackets the fused step kernel with HIP
  * events on its stream; eh_profile_read returns the number of launches and their mean duration. */
 int32_t eh_profile_enable(eh_handle* h, int32_t on);
@@ -182,7 +190,8 @@ int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_
  * pairs; the first call arms the buffer.  A normal build leaves the buffer zero. */
 int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
 
-/* tuning knobs (name/value), e.g. "max_blocks" */
+/* tuning knobs (name/value): "max_blocks" (1..256), "variant" (tile shape), "fast_paths" (0 = generic MFMA kernels),
+ * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible) */
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -321,6 +321,7 @@ def test_full_size_variants_and_grids_agree():
     B = 65536
     spec, theta, X, f, y = util.rbq10_case(B, "tanh", True, 0.05)
     eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_option("variant", 0)
     l0, g0, n0 = eng.loss_and_grad()
     for var, mb in ((1, 256), (2, 256), (3, 256), (0, 64), (1, 100)):
         eng.set_option("variant", var); eng.set_option("max_blocks", mb)
@@ -394,3 +395,78 @@ def test_error_paths_on_device():
     wide = ho.rbq10_spec((256, 16))
     with pytest.raises(NotImplementedError, match="no compiled kernel"):
         util.model_from_spec(wide).engine()
+
+
+# ----------------------------------------------------------------------------------------------
+# fused-update mode (one kernel per step; float-atomic accumulation -> tolerance, not bitwise)
+# ----------------------------------------------------------------------------------------------
+def test_fused_update_mode_matches_two_kernel_mode():
+    spec, theta, X, f, y = util.rbq10_case(4096, "tanh", True, 0.1)
+    a = util.load_engine(spec, theta, X, f, y); a.opt_init("Adam", 0.01)
+    b = util.load_engine(spec, theta, X, f, y); b.opt_init("Adam", 0.01); b.set_option("fused_update", 1)
+    la, na = a.train_epoch(512, shuffle=False)
+    lb, nb = b.train_epoch(512, shuffle=False)
+    assert na == nb == 8 and lb == pytest.approx(la, rel=1e-5)
+    assert np.max(np.abs(a.get_params() - b.get_params())) <= 2e-5
+    assert a.train_step(0, 1000) == pytest.approx(b.train_step(0, 1000), rel=1e-5)      # loss of the step itself
+    for i in range(5):
+        a.train_step(i * 512, 512, want_loss=False); b.train_step(i * 512, 512, want_loss=False)
+    assert np.max(np.abs(a.get_params() - b.get_params())) <= 3e-5
+    ma, va, bta = a.get_opt_state(); mb, vb, btb = b.get_opt_state()
+    assert np.array_equal(bta, btb) and util.relerr(mb, ma) <= 1e-4 and util.relerr(vb, va) <= 1e-4
+    # and against the oracle's trajectory from the start
+    c = util.load_engine(spec, theta, X, f, y); c.opt_init("Adam", 0.01); c.set_option("fused_update", 1)
+    batches = [(i * 256, 256) for i in range(6)]
+    for bb in batches:
+        c.train_step(*bb, want_loss=False)
+    th_ref, _ = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.max(np.abs(c.get_params() - th_ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    lg = c.loss_and_grad()                                     # a non-fused call in between flushes and stays consistent
+    l0, g0, _ = ho.loss_and_grad(spec, c.get_params().astype(np.float64), X, f, y)
+    assert lg[0] == pytest.approx(l0, rel=1e-5) and util.relerr(lg[1], g0) <= 1e-5
+    a.close(); b.close(); c.close()
+
+
+def test_fused_update_skips_all_masked_batch_and_reports_losses():
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "rbq10_allmasked_batch.npz"))
+    spec = _load_spec(d)
+    f = {"ta": d["forcing_ta"]}; y = {"reco": d["target_reco"]}
+    eng = util.load_engine(spec, d["theta"], d["X"], f, y); eng.opt_init("Adam", 0.01); eng.set_option("fused_update", 1)
+    ref = util.load_engine(spec, d["theta"], d["X"], f, y); ref.opt_init("Adam", 0.01)
+    le, _ = eng.train_epoch(64, shuffle=False)                 # batches: valid, ALL MASKED, valid
+    lr, _ = ref.train_epoch(64, shuffle=False)
+    assert le == pytest.approx(lr, rel=1e-5)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-5
+    _, _, bt = eng.get_opt_state()
+    assert bt[0] == pytest.approx(np.float32(0.9) ** 3, rel=1e-6)           # two updates only: beta^(2+1)
+    eng.set_option("fused_update", 0)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-5
+    eng.close(); ref.close()
+
+
+def test_data_parallel_driver_world_size_one_nccl():
+    # the real DataParallel driver (RCCL through torch.distributed) with a single rank: both the
+    # fused one-kernel path and the deterministic three-kernel path must reproduce plain training
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec, theta, X, f, y = util.rbq10_case(4096, "tanh", True, 0.1)
+        ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+        for i in range(8):
+            ref.train_step(i * 512, 512, want_loss=False)
+        for fused in (True, False):
+            eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+            drv = eh.dp.DataParallel(eng, fused=fused)
+            for i in range(8):
+                drv.step(i * 512, 512)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-5, fused
+            eng.close()
+        ref.close()
+    finally:
+        dist.destroy_process_group()

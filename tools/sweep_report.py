@@ -10,7 +10,7 @@ red = [r for r in rows if "eh_reduce_kernel" in r["Kernel_Name"]]
 i = 0
 for p in plan:
     n = p["steps"]
-    s = step[i:i + n]; r = red[i:i + n]; i += n
+    s = step[i:i + n]; r = red[i:i + n] if len(red) >= i + n else s; i += n
     ds = sorted(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in s)
     dr = sorted(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in r)
     wall = (int(r[-1]["End_Timestamp"]) - int(s[10]["Start_Timestamp"])) / (n - 10)

@@ -11,8 +11,9 @@ import easyhybrid_jl_amd as eh
 from easyhybrid_jl_amd.synthetic import RBQ10_PARAMS, make_synth_rbq10
 
 STEPS = 300
+FUSED = int(os.environ.get("EH_FUSED", "0"))
 configs = [(b, 256, v) for v in (0, 1, 2, 3) for b in (64, 65536, 131072, 1048576)] + \
-          [(65536, mb, v) for v in (0, 1, 2) for mb in (64, 128)]
+          [(65536, mb, v) for v in (0, 1) for mb in (128,)]
 model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"],
                                 hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
 cols = make_synth_rbq10(1 << 21, seed=1)
@@ -21,6 +22,7 @@ eng = model.engine(0)
 eng.set_data(0, X, [cols["ta"]], [cols["reco"]])
 eng.set_params(model.initialparameters(1))
 eng.opt_init("Adam", 0.01)
+eng.set_option("fused_update", FUSED)
 plan = []
 for b, mb, var in configs:
     eng.set_option("max_blocks", mb)
