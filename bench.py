@@ -88,7 +88,10 @@ def main():
     X = np.stack([cols["sw_pot"], cols["dsw_pot"]]).astype(np.float32)
     eng = model.engine(local)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    t_up = time.perf_counter()
     eng.set_data(eh.EH_SPLIT_TRAIN, X, [cols["ta"]], [cols["reco"]])
+    eng.synchronize()
+    t_up = time.perf_counter() - t_up      # one-time host -> HBM upload (interleave on the host + PCIe); never part of `value`
     eng.set_params(model.initialparameters(161803))                 # same seed on every rank: replicas start equal
     eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
     force_dp = os.environ.get("EH_FORCE_DP", "0") == "1"          # exercise the data-parallel seam on one GPU
@@ -144,8 +147,15 @@ def main():
         if n and ms_step > 0:
             tf = FLOP_PER_SAMPLE * B / (ms_step * 1e-3) / 1e12
             gbs = BYTES_PER_SAMPLE * B / (ms_step * 1e-3) / 1e9
+            traffic, traffic_src = None, None
+            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                if tj.get("batch") == B and tj.get("fused") == (dp is None):
+                    traffic, traffic_src = (2.0 * tj["FETCH_SIZE_KiB"] + tj["WRITE_SIZE_KiB"]) * 1024.0, tj["source"]
+            except Exception:
+                pass
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                    "traffic": None, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if dp is None else
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if dp is None else
                     "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS>", "kernel_ms": ms_step, "launches_timed": n,
                     "reduce_adam_kernel_ms": ms_red if dp is not None else 0.0,
                     "algorithmic": {"flop_per_launch": FLOP_PER_SAMPLE * B, "bytes_per_launch": BYTES_PER_SAMPLE * B},
@@ -165,6 +175,7 @@ def main():
                        "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}"},
             "roofline": roof,
         }
+        out["dataset_upload_ms_once"] = 1e3 * t_up
         if loss is not None:
             out["final_loss"] = loss
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats of the bench command plus separate
+# PMC passes for HBM traffic.  Writes under gpurun_out/prof_$1/ ; copy the summaries into profiles/.
+set -u
+export TMPDIR=/tmp
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
+timeout 300 python3 bench.py --steps 3000 --warmup 300 > $OUT/bench.json 2> $OUT/bench.err
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    print(open(f).read())
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "eh_" in k:
+                acc[k.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in acc.items():
+        print(name, k, {c: (round(sum(v) / len(v), 2), len(v)) for c, v in sorted(d.items())})
+PY
+# keep only small summaries for merging back
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +2M -delete
