@@ -240,6 +240,7 @@ struct eh_handle_s {
     hipStream_t stream = nullptr, own_stream = nullptr;
     int C = 0, n_acc = 0, n_par = 0;
     float *thb[2] = {nullptr, nullptr}, *mb[2] = {nullptr, nullptr}, *vb[2] = {nullptr, nullptr};   // parameter sets (fused mode ping-pongs them)
+    float* pset = nullptr;          // backing allocation of thb/mb/vb/sc
     float* sc = nullptr;            // [2][2] running beta products, ping-pong
     int cur = 0, sc_sel = 0;
     // fused-update mode
@@ -484,17 +485,13 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->stream = h->own_stream;
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
     const size_t nt = (size_t)n.n_theta;
-    for (int k = 0; k < 2; ++k) {
-        HIPCHK_C(hipMalloc(&h->thb[k], nt * sizeof(float)));
-        HIPCHK_C(hipMalloc(&h->mb[k], nt * sizeof(float)));
-        HIPCHK_C(hipMalloc(&h->vb[k], nt * sizeof(float)));
-        HIPCHK_C(hipMemset(h->thb[k], 0, nt * sizeof(float)));
-        HIPCHK_C(hipMemset(h->mb[k], 0, nt * sizeof(float)));
-        HIPCHK_C(hipMemset(h->vb[k], 0, nt * sizeof(float)));
-    }
+    // one allocation: [2][3][n_theta] parameter sets {theta, m, v}, then the [2][2] running beta products
+    HIPCHK_C(hipMalloc(&h->pset, (6 * nt + 4) * sizeof(float)));
+    HIPCHK_C(hipMemset(h->pset, 0, (6 * nt + 4) * sizeof(float)));
+    for (int k = 0; k < 2; ++k) { h->thb[k] = h->pset + (size_t)k * 3 * nt; h->mb[k] = h->thb[k] + nt; h->vb[k] = h->thb[k] + 2 * nt; }
+    h->sc = h->pset + 6 * nt;
     HIPCHK_C(hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK_C(hipMalloc(&h->sc, 4 * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->slab, (size_t)h->max_blocks * std::max(h->n_acc, EH_EVAL_STATS * n.T) * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, EH_MAX_TARG * sizeof(float)));
@@ -552,8 +549,8 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
-    for (int k = 0; k < 2; ++k) { (void)hipFree(h->thb[k]); (void)hipFree(h->mb[k]); (void)hipFree(h->vb[k]); }
-    (void)hipFree(h->gacc); (void)hipFree(h->sc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    (void)hipFree(h->pset);
+    (void)hipFree(h->gacc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
@@ -709,7 +706,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.inv_n = net.T > 1 ? h->inv_n : nullptr;
     a.rmap = h->rmap;
     a.stamps = h->stamps;
-    a.fz.g_cur = nullptr;
+    a.fz.gacc = nullptr;
     const int grid = grid_for(h, count);
     *grid_out = grid;
     HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
@@ -724,18 +721,12 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
         if (rc) return rc;
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
     }
-    const size_t gsz = (size_t)EH_GSHARDS * h->n_acc;
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;
     EhFused& z = a.fz;
-    z.g_cur = h->gacc + (size_t)(h->gstep % 3) * gsz;
-    z.g_prev = h->gacc + (size_t)((h->gstep + 2) % 3) * gsz;
-    z.g_zero = h->gacc + (size_t)((h->gstep + 1) % 3) * gsz;
-    const int in = h->cur, out = h->cur ^ 1;
-    z.th_in = h->thb[in]; z.m_in = h->mb[in]; z.v_in = h->vb[in]; z.sc_in = h->sc + 2 * h->sc_sel;
-    z.th_out = h->thb[out]; z.m_out = h->mb[out]; z.v_out = h->vb[out]; z.sc_out = h->sc + 2 * (h->sc_sel ^ 1);
-    z.imap = h->imap; z.loss_slot = h->pending_loss; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
+    z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
+    z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
     const int grid = grid_for(h, count);
     HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
     h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;

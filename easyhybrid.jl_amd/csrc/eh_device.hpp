@@ -78,13 +78,13 @@ __device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1
 // writing a slab row.  Saves the reduce kernel and its launch boundary; the sums are no longer
 // bitwise reproducible (atomic arrival order), so it is opt-in.
 struct EhFused {
-    float* g_cur;          // nullptr = two-kernel (deterministic) mode; else [EH_GSHARDS][n_acc] accumulator of this step
-    const float* g_prev;   // accumulator of the previous step (applied in the prologue when pending)
-    float* g_zero;         // accumulator the NEXT step will use: cleared by workgroup 0
-    const float *th_in, *m_in, *v_in, *sc_in;
-    float *th_out, *m_out, *v_out, *sc_out;
+    float* gacc;           // nullptr = two-kernel (deterministic) mode; else [3][EH_GSHARDS][n_acc] rotating accumulators
+    float* pset;           // [2][3][n_theta] parameter sets {theta, m, v}, then [2][2] running beta products
     const int* imap;       // canonical index -> image offset
     float* loss_slot;      // where the previous step's loss goes (nullable)
+    int gslot;             // this step accumulates into gacc[gslot], applies gacc[(gslot+2)%3] when pending, clears gacc[(gslot+1)%3]
+    int cur;               // reads parameter set `cur`, writes set `cur ^ 1`
+    int sc_sel;            // same for the beta products
     int pending;
     EhOpt opt;
 };
@@ -296,16 +296,39 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     const float* const meta = wl + G::PHI_OFF;
     auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
     auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
+    // Per-parameter / per-target switches as per-lane values pinned in VGPRs: as wave-uniform
+    // conditions the compiler would hoist ~30 of them out of the tile loop into SGPR masks and then
+    // spill them (measured: 117 SGPR spills); as VGPRs they cost one compare where they are used.
+    float kN[EH_MAX_PARAMS], kG[EH_MAX_PARAMS], tOn[EH_MAX_TARG], sclOn = net.scale_nn ? 1.0f : 0.0f;
+    int oOff[EH_MAX_PARAMS], fCol[EH_MAX_FORC];
+#pragma unroll
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) {
+        kN[j] = (j < net.n_par && pkind(j) == EH_PAR_NEURAL) ? 1.0f : 0.0f;
+        kG[j] = (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) ? 1.0f : 0.0f;
+        oOff[j] = pidx(j) * SR;
+        asm volatile("" : "+v"(kN[j]), "+v"(kG[j]), "+v"(oOff[j]));
+    }
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) { tOn[t] = t < net.T ? 1.0f : 0.0f; asm volatile("" : "+v"(tOn[t])); }
+#pragma unroll
+    for (int f = 0; f < EH_MAX_FORC; ++f) {
+        const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
+        fCol[f] = col == 0xFFu ? -1 : (int)(net.P + col);
+        asm volatile("" : "+v"(fCol[f]));
+    }
+    asm volatile("" : "+v"(sclOn));
+    const int tcol0 = net.P + net.F;
 
     // one sample record per lane, fetched one macro-tile ahead of its use
     constexpr int NX4 = (G::IP + 3) / 4;
     struct { f32x4 x[NX4]; float frc[EH_MAX_FORC]; float y[EH_MAX_TARG]; } nx;
-    const long long ntiles = (a.count + MT - 1) / MT;
-    auto fetch = [&](long long tile) {
-        const long long n_loc = tile * MT + lane;
-        const bool live = (tile < ntiles) && (lane < MT) && (n_loc < a.count);
-        const long long n_glb = live ? (a.idx ? (long long)a.idx[a.first + n_loc] : a.first + n_loc) : 0;
-        const float* const rec = a.recs + n_glb * a.C;
+    const int count = (int)a.count, first = (int)a.first;     // N <= 2^31 - 1 (checked by eh_set_data)
+    const int ntiles = (count + MT - 1) / MT;
+    auto fetch = [&](int tile) {
+        const int n_loc = tile * MT + lane;
+        const bool live = (tile < ntiles) && (lane < MT) && (n_loc < count);
+        const int n_glb = live ? (a.idx ? a.idx[first + n_loc] : first + n_loc) : 0;
+        const float* const rec = a.recs + (long long)n_glb * a.C;
         if ((a.C & 3) == 0) {          // 16-byte-multiple records (RbQ10: exactly one dwordx4 per sample)
 #pragma unroll
             for (int q = 0; q < NX4; ++q) nx.x[q] = (live && 4 * q < net.P) ? *(const f32x4*)(rec + 4 * q) : f32x4{0, 0, 0, 0};
@@ -316,35 +339,35 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 for (int e = 0; e < 4; ++e) nx.x[q][e] = (live && 4 * q + e < net.P) ? rec[4 * q + e] : 0.0f;
         }
 #pragma unroll
-        for (int f = 0; f < EH_MAX_FORC; ++f) {
-            const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
-            nx.frc[f] = (col != 0xFFu && live) ? rec[net.P + col] : 0.0f;
-        }
+        for (int f = 0; f < EH_MAX_FORC; ++f) nx.frc[f] = (fCol[f] >= 0 && live) ? rec[fCol[f]] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) nx.y[t] = (t < net.T && live) ? rec[net.P + net.F + t] : __builtin_nanf("");
+        for (int t = 0; t < EH_MAX_TARG; ++t) nx.y[t] = (tOn[t] != 0.0f && live) ? rec[tcol0 + t] : __builtin_nanf("");
     };
-    fetch((long long)blockIdx.x * NW + wave);
+    fetch((int)blockIdx.x * NW + wave);
 
     EH_STAMP(0);
     // ---- stage the parameter image into LDS (straight copy) ------------------------------------
     // (fused update) the first chunk of optimiser inputs is requested together with the image so
     // that everything arrives in one memory round trip
-    const bool fusedm = TRAIN && a.fz.g_cur != nullptr;
+    const bool fusedm = TRAIN && a.fz.gacc != nullptr;
     float f_th = 0.0f, f_m = 0.0f, f_v = 0.0f, f_g = 0.0f, f_cnt = 0.0f, f_sse = 0.0f, f_bt1 = 0.0f, f_bt2 = 0.0f;
     int f_map = 0;
     if (fusedm) {
         const EhFused& z = a.fz;
+        const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
+        const float* const pin = z.pset + z.cur * 3 * net.n_theta;
         if (z.pending) {
 #pragma unroll
-            for (int sh = 0; sh < EH_GSHARDS; ++sh) { f_cnt += z.g_prev[sh * a.n_acc + net.n_theta + 1]; f_sse += z.g_prev[sh * a.n_acc + net.n_theta]; }
+            for (int sh = 0; sh < EH_GSHARDS; ++sh) { f_cnt += g_prev[sh * a.n_acc + net.n_theta + 1]; f_sse += g_prev[sh * a.n_acc + net.n_theta]; }
         }
-        f_bt1 = z.sc_in[0]; f_bt2 = z.sc_in[1];
+        const float* const sc_in = z.pset + 6 * net.n_theta + 2 * z.sc_sel;
+        f_bt1 = sc_in[0]; f_bt2 = sc_in[1];
         if (tid < net.n_theta) {
-            f_th = z.th_in[tid]; f_m = z.m_in[tid]; f_v = z.v_in[tid];
+            f_th = pin[tid]; f_m = pin[net.n_theta + tid]; f_v = pin[2 * net.n_theta + tid];
             f_map = tid < net.g_off ? z.imap[tid] : 0;
             if (z.pending) {
 #pragma unroll
-                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += z.g_prev[sh * a.n_acc + tid];
+                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += g_prev[sh * a.n_acc + tid];
             }
         }
     }
@@ -354,22 +377,27 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     if (fusedm) {
         // fused update: apply the previous step's optimiser update straight into the LDS image
         const EhFused& z = a.fz;
+        const int nth = net.n_theta;
+        const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
+        float* const g_zero = z.gacc + ((z.gslot + 1) % 3) * (EH_GSHARDS * a.n_acc);
+        const float* const pin = z.pset + z.cur * 3 * nth;
+        float* const pout = z.pset + (z.cur ^ 1) * 3 * nth;
         const bool upd = z.pending && f_cnt > 0.0f;
         const float inv = upd ? 1.0f / f_cnt : 0.0f;
-        for (int idx = tid; idx < net.n_theta; idx += NTHR) {
+        for (int idx = tid; idx < nth; idx += NTHR) {
             float th, mm, vv, gs = 0.0f;
             int mp;
             if (idx == tid) { th = f_th; mm = f_m; vv = f_v; gs = f_g; mp = f_map; }
             else {
-                th = z.th_in[idx]; mm = z.m_in[idx]; vv = z.v_in[idx];
+                th = pin[idx]; mm = pin[nth + idx]; vv = pin[2 * nth + idx];
                 mp = idx < net.g_off ? z.imap[idx] : 0;
                 if (upd) {
 #pragma unroll
-                    for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += z.g_prev[sh * a.n_acc + idx];
+                    for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * a.n_acc + idx];
                 }
             }
             if (upd) eh_opt_update(z.opt, gs * inv, f_bt1, f_bt2, th, mm, vv);
-            if ((unsigned)idx % gridDim.x == blockIdx.x) { z.th_out[idx] = th; z.m_out[idx] = mm; z.v_out[idx] = vv; }   // every workgroup holds the same values: spread the stores
+            if ((unsigned)idx % gridDim.x == blockIdx.x) { pout[idx] = th; pout[nth + idx] = mm; pout[2 * nth + idx] = vv; }   // every workgroup holds the same values: spread the stores
             if (idx < net.g_off) {
                 wl[mp] = th;
             } else {
@@ -380,11 +408,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             }
         }
         if (blockIdx.x == 0 && tid == 0) {
-            z.sc_out[0] = upd ? f_bt1 * z.opt.b1 : f_bt1;
-            z.sc_out[1] = upd ? f_bt2 * z.opt.b2 : f_bt2;
+            float* const sc_out = z.pset + 6 * nth + 2 * (z.sc_sel ^ 1);
+            sc_out[0] = upd ? f_bt1 * z.opt.b1 : f_bt1;
+            sc_out[1] = upd ? f_bt2 * z.opt.b2 : f_bt2;
             if (z.loss_slot && z.pending) *z.loss_slot = upd ? f_sse * inv : __builtin_nanf("");
         }
-        for (int e = blockIdx.x * NTHR + tid; e < EH_GSHARDS * a.n_acc; e += gridDim.x * NTHR) z.g_zero[e] = 0.0f;
+        for (int e = blockIdx.x * NTHR + tid; e < EH_GSHARDS * a.n_acc; e += gridDim.x * NTHR) g_zero[e] = 0.0f;
         __syncthreads();
     }
     EH_STAMP(1);
@@ -429,9 +458,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     }
     const int ksteps0 = (net.P + 3) / 4;   // k-steps of layer 0 that hold real features (natural k order 4s+g)
 
-    for (long long tile = (long long)blockIdx.x * NW + wave; tile < ntiles; tile += (long long)gridDim.x * NW) {
-        const long long n_loc = tile * MT + lane;                  // sample of this lane in the mech stage
-        const bool live = (lane < MT) && (n_loc < a.count);
+    for (int tile = (int)blockIdx.x * NW + wave; tile < ntiles; tile += (int)gridDim.x * NW) {
+        const int n_loc = tile * MT + lane;                        // sample of this lane in the mech stage
+        const bool live = (lane < MT) && (n_loc < count);
 
         EH_STAMP_FINE(2);
         // ---- 1. the record was fetched one iteration ahead: predictors -> [feature][sample] image
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * q + e < net.P && lane < MT) XS[(4 * q + e) * SR + lane] = nx.x[q][e];
-        fetch(tile + (long long)gridDim.x * NW);   // next tile's record: in flight behind this tile's compute
+        fetch(tile + (int)gridDim.x * NW);   // next tile's record: in flight behind this tile's compute
         EH_WAVE_SYNC();
 
         EH_STAMP_FINE(3);
@@ -566,9 +595,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
                 par[j] = meta[EH_IMG_PHI + j]; sg[j] = 1.0f; dydp[j] = 0.0f;
-                if (j < net.n_par && pkind(j) == EH_PAR_NEURAL) {
-                    const float ov = K1 ? om : ((lane < MT) ? OS[pidx(j) * SR + lane] : 0.0f);
-                    if (net.scale_nn) {
+                if (kN[j] != 0.0f) {
+                    const float ov = K1 ? om : ((lane < MT) ? OS[oOff[j] + lane] : 0.0f);
+                    if (sclOn != 0.0f) {
                         const float s = eh_sigmoid(ov), sc = meta[EH_IMG_SC + j];
                         par[j] = fmaf(sc, s, meta[EH_IMG_LO + j]);
                         sg[j] = sc * s * (1.0f - s);
@@ -581,7 +610,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             float dy = 0.0f;
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t) {
-                if (t < net.T) {
+                if (tOn[t] != 0.0f) {
                     const bool valid = live && !__builtin_isnan(yobs[t]);
                     const float r = valid ? y - yobs[t] : 0.0f;
                     if constexpr (TRAIN) {
@@ -607,16 +636,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             }
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
-                if (j < net.n_par) {
-                    const float dp = live ? dy * dydp[j] : 0.0f;
-                    const int kd = pkind(j);
-                    if (kd == EH_PAR_NEURAL) {
-                        if constexpr (K1) dOm = dp * sg[j];
-                        else if (lane < MT) OS[pidx(j) * SR + lane] = dp * sg[j];
-                    } else if (kd == EH_PAR_GLOBAL) {
-                        gacc[j] += dp;
-                    }
+                const float dp = live ? dy * dydp[j] : 0.0f;
+                if (kN[j] != 0.0f) {
+                    if constexpr (K1) dOm = dp * sg[j];
+                    else if (lane < MT) OS[oOff[j] + lane] = dp * sg[j];
                 }
+                gacc[j] = fmaf(kG[j], dp, gacc[j]);
             }
         }
         if constexpr (!K1) EH_WAVE_SYNC();
@@ -848,7 +873,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         EH_STAMP(9);
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = a.fz.g_cur ? a.fz.g_cur + (blockIdx.x & (EH_GSHARDS - 1)) * a.n_acc : nullptr;
+        float* const gsh = a.fz.gacc ? a.fz.gacc + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             const int code = a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
             float sum = 0.0f;
@@ -1009,7 +1034,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     {
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = (TRAIN && a.fz.g_cur) ? a.fz.g_cur + (blockIdx.x & (EH_GSHARDS - 1)) * a.n_acc : nullptr;
+        float* const gsh = (TRAIN && a.fz.gacc) ? a.fz.gacc + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             float s = R0[e];
 #pragma unroll
