@@ -49,9 +49,9 @@ __global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
 template <bool APPLY>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
-                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im) {
+                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
     __shared__ float part[16][17];
-    __shared__ float wsum[4][EH_MAX_TARG];
+    __shared__ float wsum[4][EH_MAX_TARG + 3];
     const int tid = threadIdx.x, p = tid & 15, q = tid >> 4;
     const int idx = blockIdx.x * 16 + p;
     // optimiser inputs are independent of the slab: request them first so they arrive together
@@ -64,28 +64,32 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     }
     part[q][p] = s;
     // valid counts: every block needs them (nblk <= 256: one row per thread)
-    float cs[EH_MAX_TARG];
+    // wsum columns: [0..3] n_valid per target, [4] S, [5] Sy, [6] Syy
+    float cs[EH_MAX_TARG + 3];
 #pragma unroll
-    for (int t = 0; t < EH_MAX_TARG; ++t) {
+    for (int t = 0; t < EH_MAX_TARG + 3; ++t) {
         cs[t] = 0.0f;
-        if (t < T)
-            for (int r = tid; r < nblk; r += 256) cs[t] += slab[(size_t)r * n_acc + n_theta + 1 + t];
+        const int col = t < EH_MAX_TARG ? (t < T ? n_theta + 1 + t : -1) : (t == EH_MAX_TARG ? n_theta : n_theta + T + (t - EH_MAX_TARG));
+        if (col >= 0)
+            for (int r = tid; r < nblk; r += 256) cs[t] += slab[(size_t)r * n_acc + col];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cs[t] += __shfl_xor(cs[t], off, 64);
         if ((tid & 63) == 0) wsum[tid >> 6][t] = cs[t];
     }
     __syncthreads();
-    float cnts[EH_MAX_TARG], ntot = 0.0f;
+    float cnts[EH_MAX_TARG + 3], ntot = 0.0f;
 #pragma unroll
-    for (int t = 0; t < EH_MAX_TARG; ++t) {
-        cnts[t] = t < T ? (wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]) : 0.0f;
-        ntot += cnts[t];
+    for (int t = 0; t < EH_MAX_TARG + 3; ++t) {
+        cnts[t] = (wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]);
+        if (t < EH_MAX_TARG) ntot += cnts[t];
     }
+    float dscale = 1.0f, dloss = 0.0f;
+    if (deferred) eh_loss_finish(loss_kind, cnts[EH_MAX_TARG], cnts[0], cnts[EH_MAX_TARG + 1], cnts[EH_MAX_TARG + 2], dscale, dloss);
     if (q == 0 && idx < n_acc) {
         float tot = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += part[k][p];
-        const float scale = deferred ? (cnts[0] > 0.0f ? 1.0f / cnts[0] : 0.0f) : 1.0f;
+        const float scale = deferred ? dscale : 1.0f;
         if (idx < n_theta) {
             const float g = tot * scale;
             gradbuf[idx] = g;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
                 eh_image_store(im, idx, th);
             }
         } else if (idx == n_theta) {
-            const float loss = ntot > 0.0f ? tot * scale : __builtin_nanf("");
+            const float loss = ntot > 0.0f ? (deferred ? dloss : tot) : __builtin_nanf("");
             gradbuf[idx] = loss;
             if (loss_slot) *loss_slot = loss;
         } else {
@@ -110,12 +114,16 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
 
 // fused-update mode: apply the still-pending gradient (sharded accumulator g_prev) in place
 __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev, int n_acc, int n_theta, float* theta, float* m, float* v,
-                                                             const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im) {
+                                                             const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    float cnt = 0.0f, sse = 0.0f;
+    float cnt = 0.0f, sse = 0.0f, sy = 0.0f, syy = 0.0f;
 #pragma unroll
-    for (int sh = 0; sh < EH_GSHARDS; ++sh) { cnt += g_prev[sh * n_acc + n_theta + 1]; sse += g_prev[sh * n_acc + n_theta]; }
-    const float inv = cnt > 0.0f ? 1.0f / cnt : 0.0f;
+    for (int sh = 0; sh < EH_GSHARDS; ++sh) {
+        const float* gp = g_prev + sh * n_acc + n_theta;
+        sse += gp[0]; cnt += gp[1]; sy += gp[2]; syy += gp[3];
+    }
+    float inv = 0.0f, lossv = 0.0f;
+    eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
     if (idx < n_theta && cnt > 0.0f) {
         float gs = 0.0f;
 #pragma unroll
@@ -128,17 +136,19 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
     if (idx == 0) {
         sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
         sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
-        if (loss_slot) *loss_slot = cnt > 0.0f ? sse * inv : __builtin_nanf("");
+        if (loss_slot) *loss_slot = lossv;
     }
 }
 
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
 __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
-                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im) {
+                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const float cnt = gradbuf[n_theta + 1];
+    float scale = 0.0f, lossv = 0.0f;
+    eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv);
     if (idx < n_theta && cnt > 0.0f) {
-        const float g = gradbuf[idx] / cnt;
+        const float g = gradbuf[idx] * scale;
         float th = theta[idx], mm = m[idx], vv = v[idx];
         eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
     if (idx == 0) {
         sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
         sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
-        if (loss_slot) *loss_slot = cnt > 0.0f ? gradbuf[n_theta] / cnt : __builtin_nanf("");
+        if (loss_slot) *loss_slot = lossv;
     }
 }
 
@@ -295,7 +305,7 @@ static int flush_pending(eh_handle* h) {
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     hipLaunchKernelGGL(eh_fused_flush_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, g_prev, h->n_acc, nt, TH(h), MM(h), VV(h), sc_in, sc_out,
-                       h->opt, h->pending_loss, h->img);
+                       h->opt, h->pending_loss, h->img, h->net.loss);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemsetAsync(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
     h->sc_sel ^= 1;
@@ -354,6 +364,8 @@ static int build_rmap(eh_handle* h) {
         if (d.param_kind[j] == EH_PAR_GLOBAL) rmap[n.g_off + d.param_index[j]] = (L.na * 256 + j) | (1 << 24);
     rmap[n.n_theta] = (L.na * 256 + 8) | (1 << 24);
     for (int t = 0; t < n.T; ++t) rmap[n.n_theta + 1 + t] = (L.na * 256 + 9 + t) | (1 << 24);
+    rmap[n.n_theta + 1 + n.T] = (L.na * 256 + 14) | (1 << 24);
+    rmap[n.n_theta + 2 + n.T] = (L.na * 256 + 15) | (1 << 24);
     if (!h->rmap) HIPCHK(h, hipMalloc(&h->rmap, rmap.size() * sizeof(int)));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(h->rmap, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -465,7 +477,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->fast = (arch->has_fast ? ((K == 1 ? 1 : 0) | ((K == 1 && n.P <= 4) ? 2 : 0)) : 0);
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
-    h->n_acc = n.n_theta + 1 + n.T;
+    h->n_acc = n.n_theta + 1 + n.T + 2;      // [grad | S | n_valid per target | Sy | Syy]
     for (int vi = 0; vi < arch->nvar; ++vi)
         if (arch->var[vi].nw * std::max(h->n_acc, EH_EVAL_STATS * n.T) > arch->var[vi].red_floats) {
             delete h;
@@ -600,6 +612,14 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->fused = value != 0;
         return EH_OK;
     }
+    if (!strcmp(name, "training_loss")) {
+        if (value < EH_LOSS_MSE || value > EH_LOSS_NSELOSS) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
+        if (value != EH_LOSS_MSE && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "training losses other than MSE need a single-target model");
+        HIPCHK(h, hipSetDevice(h->device));
+        FLUSH(h);
+        h->net.loss = (int)value;
+        return EH_OK;
+    }
     if (!strcmp(name, "variant")) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
         h->variant = (int)value;
@@ -704,6 +724,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
     a.inv_n = net.T > 1 ? h->inv_n : nullptr;
+    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     a.rmap = h->rmap;
     a.stamps = h->stamps;
     a.fz.gacc = nullptr;
@@ -724,6 +745,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;
+    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
     z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
@@ -768,11 +790,11 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     if (apply) {
         hipLaunchKernelGGL(eh_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img);
+                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss);
         h->sc_sel ^= 1;
     } else {
         hipLaunchKernelGGL(eh_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img);
+                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss);
     }
     HIPCHK(h, hipGetLastError());
     if (prof) {
@@ -1064,7 +1086,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     const int nt = h->net.n_theta;
     hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, TH(h), MM(h), VV(h), sc_in, sc_out, h->opt,
-                       h->loss_hist, h->img);
+                       h->loss_hist, h->img, h->net.loss);
     HIPCHK(h, hipGetLastError());
     h->sc_sel ^= 1;
     if (loss_out) {

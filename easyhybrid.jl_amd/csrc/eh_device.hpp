@@ -38,6 +38,7 @@ struct EhNet {
     int P, K, G, T, F;               // predictors, NN outputs (neural params), global params, targets, forcing columns
     int n_theta, g_off;              // n_nn + G ; offset of the raw global parameters in flat theta
     int scale_nn, mech, n_par;
+    int loss;                        // eh_loss (training loss)
     unsigned par_kind;               // 2 bits per canonical mech parameter: eh_param_kind
     unsigned par_idx;                // 4 bits per canonical mech parameter: NN output row / global index
     unsigned forc_col;               // 8 bits per canonical forcing: column among the F forcing columns (0xFF unused)
@@ -66,6 +67,25 @@ __device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1
         th -= g * (o.lr / (sqrtf(v) + o.eps));
     } else {                                                     // Descent(eta)
         th -= o.lr * g;
+    }
+}
+
+// From the batch sums to the loss value and the factor that turns the accumulated un-normalised
+// gradient (sum of 2 r dyhat, or of sign(r) dyhat for MAE) into the gradient of the loss
+// (src/losses/loss_fn.jl:58-86).  S = sum r^2 (sum |r| for MAE), n = valid count, Sy / Syy = shifted
+// target sums.  n == 0 -> scale 0, loss NaN: the batch is skipped (src/training/epoch.jl:17-19).
+__device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float Sy, float Syy, float& scale, float& loss) {
+    if (!(n > 0.0f)) { scale = 0.0f; loss = __builtin_nanf(""); return; }
+    if (kind == EH_LOSS_RMSE) {
+        loss = sqrtf(S / n);
+        scale = 1.0f / (2.0f * n * loss);
+    } else if (kind == EH_LOSS_NSELOSS) {
+        const float D = Syy - Sy * Sy / n;       // sum (y - mean y)^2
+        loss = S / D;
+        scale = 1.0f / D;
+    } else {                                     // MSE, MAE
+        scale = 1.0f / n;
+        loss = S * scale;
     }
 }
 
@@ -316,7 +336,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         fCol[f] = col == 0xFFu ? -1 : (int)(net.P + col);
         asm volatile("" : "+v"(fCol[f]));
     }
-    asm volatile("" : "+v"(sclOn));
+    float maeOn = net.loss == EH_LOSS_MAE ? 1.0f : 0.0f;
+    asm volatile("" : "+v"(sclOn), "+v"(maeOn));
     const int tcol0 = net.P + net.F;
 
     // one sample record per lane, fetched one macro-tile ahead of its use
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     // (fused update) the first chunk of optimiser inputs is requested together with the image so
     // that everything arrives in one memory round trip
     const bool fusedm = TRAIN && a.fz.gacc != nullptr;
-    float f_th = 0.0f, f_m = 0.0f, f_v = 0.0f, f_g = 0.0f, f_cnt = 0.0f, f_sse = 0.0f, f_bt1 = 0.0f, f_bt2 = 0.0f;
+    float f_th = 0.0f, f_m = 0.0f, f_v = 0.0f, f_g = 0.0f, f_cnt = 0.0f, f_sse = 0.0f, f_sy = 0.0f, f_syy = 0.0f, f_bt1 = 0.0f, f_bt2 = 0.0f;
     int f_map = 0;
     if (fusedm) {
         const EhFused& z = a.fz;
@@ -358,7 +379,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         const float* const pin = z.pset + z.cur * 3 * net.n_theta;
         if (z.pending) {
 #pragma unroll
-            for (int sh = 0; sh < EH_GSHARDS; ++sh) { f_cnt += g_prev[sh * a.n_acc + net.n_theta + 1]; f_sse += g_prev[sh * a.n_acc + net.n_theta]; }
+            for (int sh = 0; sh < EH_GSHARDS; ++sh) {
+                const float* gp = g_prev + sh * a.n_acc + net.n_theta;
+                f_sse += gp[0]; f_cnt += gp[1]; f_sy += gp[2]; f_syy += gp[3];      // single target: [S | n | Sy | Syy]
+            }
         }
         const float* const sc_in = z.pset + 6 * net.n_theta + 2 * z.sc_sel;
         f_bt1 = sc_in[0]; f_bt2 = sc_in[1];
@@ -383,7 +407,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         const float* const pin = z.pset + z.cur * 3 * nth;
         float* const pout = z.pset + (z.cur ^ 1) * 3 * nth;
         const bool upd = z.pending && f_cnt > 0.0f;
-        const float inv = upd ? 1.0f / f_cnt : 0.0f;
+        float inv = 0.0f, lossv = __builtin_nanf("");
+        if (upd) eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv);
         for (int idx = tid; idx < nth; idx += NTHR) {
             float th, mm, vv, gs = 0.0f;
             int mp;
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             float* const sc_out = z.pset + 6 * nth + 2 * (z.sc_sel ^ 1);
             sc_out[0] = upd ? f_bt1 * z.opt.b1 : f_bt1;
             sc_out[1] = upd ? f_bt2 * z.opt.b2 : f_bt2;
-            if (z.loss_slot && z.pending) *z.loss_slot = upd ? f_sse * inv : __builtin_nanf("");
+            if (z.loss_slot && z.pending) *z.loss_slot = lossv;
         }
         for (int e = blockIdx.x * NTHR + tid; e < EH_GSHARDS * a.n_acc; e += gridDim.x * NTHR) g_zero[e] = 0.0f;
         __syncthreads();
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     f32x4 aB[NL][NBH], aBo;
     float aBoS = 0.0f;
     float gacc[EH_MAX_PARAMS];
-    float lacc = 0.0f;
+    float lacc = 0.0f, syacc = 0.0f, syyacc = 0.0f;
     float cacc[EH_MAX_TARG];
     float est[EH_MAX_TARG][EH_EVAL_STATS];
     if constexpr (TRAIN) {
@@ -615,9 +640,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                     const float r = valid ? y - yobs[t] : 0.0f;
                     if constexpr (TRAIN) {
                         const float w = a.inv_n ? a.inv_n[t] : 1.0f;
-                        lacc += w * r * r;
+                        const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
+                        if (maeOn != 0.0f) { lacc += w * fabsf(r); dy += r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                        else { lacc += w * r * r; dy += 2.0f * w * r; }
                         cacc[t] += valid ? 1.0f : 0.0f;
-                        dy += 2.0f * w * r;
+                        syacc += cy; syyacc += cy * cy;
                     } else if (valid) {
                         const float cy = yobs[t] - a.shift[t], ch = y - a.shift[t];
                         est[t][0] += r * r; est[t][1] += cy; est[t][2] += cy * cy; est[t][3] += 1.0f;
@@ -834,7 +861,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t) tailv[9 + t] = (t < net.T) ? eh_wave_sum(cacc[t]) : 0.0f;
         tailv[13] = K1 ? eh_wave_sum(aBoS) : 0.0f;
-        tailv[14] = 0.0f; tailv[15] = 0.0f;
+        tailv[14] = eh_wave_sum(syacc); tailv[15] = eh_wave_sum(syyacc);
         EH_STAMP(13);
         __syncthreads();                           // the wave workspaces are dead from here on
         EH_STAMP(14);
@@ -945,7 +972,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
             for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
         }
-        lacc = eh_wave_sum(lacc);
+        lacc = eh_wave_sum(lacc); syacc = eh_wave_sum(syacc); syyacc = eh_wave_sum(syyacc);
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t)
             if (t < net.T) cacc[t] = eh_wave_sum(cacc[t]);
@@ -1026,6 +1053,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t)
                 if (t < net.T) RED[net.n_theta + 1 + t] = cacc[t];
+            RED[net.n_theta + 1 + net.T] = syacc;
+            RED[net.n_theta + 2 + net.T] = syyacc;
         }
     }
     EH_STAMP(12);

@@ -30,12 +30,20 @@ def allreduce_partials(buf, group=None):
     return buf
 
 
-def normalise(buf, n_theta: int):
-    """[grad | sse | n] raw sums -> (grad / n, mse, n); n == 0 -> (zeros, nan, 0): batch skipped."""
+def normalise(buf, n_theta: int, kind: str = "mse"):
+    """[grad | S | n | Sy | Syy] raw sums -> (gradient of the loss, loss, n); n == 0 -> (zeros, nan, 0):
+    batch skipped.  Same arithmetic as eh_loss_finish in csrc/eh_device.hpp."""
     n = float(buf[n_theta + 1])
     if n <= 0:
         return buf[:n_theta] * 0, float("nan"), 0.0
-    return buf[:n_theta] / n, float(buf[n_theta]) / n, n
+    S = float(buf[n_theta])
+    if kind == "rmse":
+        loss = (S / n) ** 0.5
+        return buf[:n_theta] / (2 * n * loss), loss, n
+    if kind == "nseLoss":
+        D = float(buf[n_theta + 3]) - float(buf[n_theta + 2]) ** 2 / n
+        return buf[:n_theta] / D, S / D, n
+    return buf[:n_theta] / n, S / n, n
 
 
 class _DevArray:

@@ -160,6 +160,12 @@ class HybridEngine:
             raise NotImplementedError(f"optimiser rule {rule} is not implemented on the device")
         self._chk(self._lib.eh_opt_init(self._h, L.OPT_RULES[rule], lr, beta1, beta2, eps, weight_decay))
 
+    def set_training_loss(self, name: str):
+        """TrainConfig.training_loss (src/config/TrainingConfig.jl:64): mse | rmse | mae | nseLoss."""
+        if name not in L.TRAINING_LOSSES:
+            raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
+        self.set_option("training_loss", L.TRAINING_LOSSES[name])
+
     def get_opt_state(self):
         m = np.empty(self.n_theta, np.float32)
         v = np.empty(self.n_theta, np.float32)

@@ -120,8 +120,9 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
     if not cfg.loss_types:
         raise ValueError("loss_types must not be empty")
     check_training_loss(cfg.training_loss)
-    if cfg.training_loss != "mse":
-        raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements :mse (others: SURVEY.md section 8f rank 3)")
+    if cfg.training_loss not in L.TRAINING_LOSSES:
+        raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements {sorted(L.TRAINING_LOSSES)} "
+                                  "(correlation-based losses need a second pass: SURVEY.md section 8f rank 3)")
     if cfg.agg != "sum":
         raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
     for lt in cfg.loss_types:
@@ -273,6 +274,7 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
             theta = np.asarray(tc.train_from.ps if isinstance(tc.train_from, TrainResults) else tc.train_from[0], np.float32)
         eng.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
+        eng.set_training_loss(tc.training_loss)
         first_lt = tc.loss_types[0]
 
         def snapshot():

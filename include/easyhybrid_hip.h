@@ -74,6 +74,11 @@ typedef enum eh_split { EH_SPLIT_TRAIN = 0, EH_SPLIT_VAL = 1 } eh_split;
 /* optimiser rules (Optimisers.jl; reference default Adam(0.01), src/config/TrainingConfig.jl:43) */
 typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2, EH_OPT_DESCENT = 3 } eh_opt_rule;
 
+/* training losses of src/losses/loss_fn.jl:58-86 that the fused kernel can minimise (per target on the valid samples):
+ *   MSE mean(r^2) | RMSE sqrt(mean(r^2)) | MAE mean(|r|) | NSELOSS sum(r^2) / sum((y - mean(y))^2);  selected with
+ *   eh_set_option(h, "training_loss", k) (TrainConfig.training_loss, src/config/TrainingConfig.jl:64; default MSE) */
+typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LOSS_NSELOSS = 3 } eh_loss;
+
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
 typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4 } eh_buffer;
 
@@ -164,7 +169,7 @@ int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_ta
 
 /* ---- data-parallel seam: one process per GPU, the host all-reduces EH_BUF_GRAD over RCCL ----------
  * eh_dp_grad   : local partial sums of the UN-normalised gradient, loss and valid counts into
- *                EH_BUF_GRAD  = [ grad (n_theta) | sum m (yhat-y)^2 | n_valid per target (T) ]
+ *                EH_BUF_GRAD  = [ grad (n_theta) | sum m (yhat-y)^2 | n_valid per target (T) | sum (y-c) | sum (y-c)^2 ]
  * (host: all_reduce(SUM) over that buffer)
  * eh_dp_apply  : normalise by the global counts and apply the optimiser update (replicated).
  * The mean over the GLOBAL valid count is what the reference computes (src/losses/loss_fn.jl:61-63),
@@ -190,7 +195,7 @@ int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_
  * pairs; the first call arms the buffer.  A normal build leaves the buffer zero. */
 int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
 
-/* tuning knobs (name/value): "max_blocks" (1..256), "variant" (tile shape), "fast_paths" (0 = generic MFMA kernels),
+/* tuning knobs (name/value): "max_blocks" (1..256), "variant" (tile shape), "fast_paths" (0 = generic MFMA kernels), "training_loss" (eh_loss),
  * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible) */
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
 

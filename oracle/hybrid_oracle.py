@@ -380,10 +380,11 @@ def compute_loss(spec, theta, X, forcings, targets: Dict[str, np.ndarray], dtype
     return tot
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64):
-    """MSE loss (agg=sum over targets) and its gradient wrt flat theta: the hand-derived VJP of
-    SURVEY.md section 8(a).  Returns (loss, grad, n_valid per target).  A target with no valid
-    sample contributes 0 (the reference skips all-masked batches, epoch.jl:17-19)."""
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse"):
+    """Training loss (`kind` in mse / rmse / mae / nseLoss, loss_fn.jl:58-86; agg=sum over targets)
+    and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
+    (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
+    skips all-masked batches, epoch.jl:17-19)."""
     dt = np.dtype(dtype)
     res = forward(spec, theta, X, forcings, dtype, keep=True)
     tp = res["_tape"]
@@ -399,8 +400,23 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64):
         d = np.zeros(B, dt)
         if n > 0:
             r = np.where(m, res[t] - np.where(m, y, 0), 0).astype(dt)
-            loss = loss + np.sum(r * r) / dt.type(n)
-            d = dt.type(2) * r / dt.type(n)
+            if kind == "mse":
+                loss = loss + np.sum(r * r) / dt.type(n)
+                d = dt.type(2) * r / dt.type(n)
+            elif kind == "rmse":
+                rm = np.sqrt(np.sum(r * r) / dt.type(n))
+                loss = loss + rm
+                d = r / (dt.type(n) * rm)
+            elif kind == "mae":
+                loss = loss + np.sum(np.abs(r)) / dt.type(n)
+                d = np.sign(r) / dt.type(n)
+            elif kind == "nseLoss":
+                yv = y[m]
+                D = np.sum((yv - np.mean(yv)) ** 2)
+                loss = loss + np.sum(r * r) / D
+                d = dt.type(2) * r / D
+            else:
+                raise ValueError(f"training loss {kind}")
         dout[t] = d
     mm, _, vjp = MECH[spec.mech]
     for oname in mm.outputs:
@@ -462,7 +478,7 @@ def adam_step(theta, grad, st, lr=0.01, b1=0.9, b2=0.999, eps=1e-8, weight_decay
     return (theta - upd).astype(theta.dtype)
 
 
-def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32):
+def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32, kind="mse"):
     """Run Adam over contiguous batches [(first, count), ...]; all-masked batches are skipped
     (epoch.jl:17-19).  Returns (theta, [loss per batch])."""
     theta = np.asarray(theta0, dtype).copy()
@@ -471,7 +487,7 @@ def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int,
     for first, count in batches:
         sl = slice(first, first + count)
         l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()},
-                                 {k: v[sl] for k, v in targets.items()}, dtype)
+                                 {k: v[sl] for k, v in targets.items()}, dtype, kind)
         if sum(nv) == 0:
             losses.append(float("nan"))
             continue

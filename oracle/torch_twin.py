@@ -68,7 +68,7 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
     return _mech(spec, par, frc)
 
 
-def loss(spec, theta, X, forcings, targets):
+def loss(spec, theta, X, forcings, targets, kind="mse"):
     out = forward(spec, theta, X, forcings)
     tot = 0
     for t in spec.targets:
@@ -76,13 +76,23 @@ def loss(spec, theta, X, forcings, targets):
         m = ~torch.isnan(y)
         if int(m.sum()) == 0:
             continue
-        tot = tot + torch.mean((out[t][m] - y[m]) ** 2)
+        a, b = out[t][m], y[m]
+        if kind == "mse":
+            tot = tot + torch.mean((a - b) ** 2)                       # loss_fn.jl:61-63
+        elif kind == "rmse":
+            tot = tot + torch.sqrt(torch.mean((a - b) ** 2))           # :58-60
+        elif kind == "mae":
+            tot = tot + torch.mean(torch.abs(a - b))                   # :64-66
+        elif kind == "nseLoss":
+            tot = tot + torch.sum((a - b) ** 2) / torch.sum((b - torch.mean(b)) ** 2)   # :79-81
+        else:
+            raise ValueError(kind)
     return tot
 
 
-def loss_and_grad(spec, theta_np, X, forcings, targets, dtype=torch.float64):
+def loss_and_grad(spec, theta_np, X, forcings, targets, dtype=torch.float64, kind="mse"):
     theta = torch.tensor(np.asarray(theta_np), dtype=dtype, requires_grad=True)
-    l = loss(spec, theta, X, forcings, targets)
+    l = loss(spec, theta, X, forcings, targets, kind)
     if not torch.is_tensor(l):
         return 0.0, np.zeros(theta.numel())
     l.backward()

@@ -73,3 +73,23 @@ def test_mean_of_shard_means_would_be_wrong():
     buf = torch.from_numpy(sum(np.concatenate([g * sum(nv), [l * sum(nv), sum(nv)]]) for l, g, nv in halves))
     g, loss, n = dp.normalise(buf, spec.n_theta)
     assert np.max(np.abs(g.numpy() - g0)) <= 1e-12 * np.max(np.abs(g0)) and loss == pytest.approx(l0, rel=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["rmse", "nseLoss"])
+def test_normalise_other_losses_from_raw_sums(kind):
+    # the raw vector a shard produces is [sum_i 2 r_i dyhat_i/dtheta | sum r^2 | n | sum (y-c) | sum (y-c)^2]; summed over
+    # shards and finished with the GLOBAL statistics it must give the full-batch loss and gradient
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    X, f, y = ho.make_synth_rbq10(300, 3, 0.1)
+    X = X / 50
+    th = ho.init_theta(spec, 4, np.float64)
+    l0, g0, _ = ho.loss_and_grad(spec, th, X, f, y, kind=kind)
+    c = 2.0
+    parts = []
+    for a, b in ((0, 100), (100, 300)):
+        sl = slice(a, b)
+        lm, gm, nv = ho.loss_and_grad(spec, th, X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()})
+        yv = y["reco"][sl].astype(np.float64); yv = yv[~np.isnan(yv)] - c
+        parts.append(np.concatenate([gm * sum(nv), [lm * sum(nv), sum(nv), yv.sum(), (yv ** 2).sum()]]))
+    g, loss, n = dp.normalise(torch.from_numpy(sum(parts)), spec.n_theta, kind)
+    assert loss == pytest.approx(l0, rel=1e-10) and np.max(np.abs(g.numpy() - g0)) <= 1e-10 * np.max(np.abs(g0))

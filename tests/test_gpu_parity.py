@@ -470,3 +470,33 @@ def test_data_parallel_driver_world_size_one_nccl():
         ref.close()
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# other training losses (loss_fn.jl:58-86)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["rmse", "mae", "nseLoss"])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_other_training_losses(kind, fused):
+    spec, theta, X, f, y = util.rbq10_case(1500, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.opt_init("Adam", 0.01)
+    eng.set_option("fused_update", fused)
+    batches = [(i * 300, 300) for i in range(5)]
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32, kind=kind)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    eng.close()
+
+
+def test_train_with_nse_loss_front_door():
+    cols = eh.synthetic.make_synth_rbq10(3000, seed=5, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=5, batchsize=200, training_loss="nseLoss", loss_types=["nse", "mse"], random_seed=2)
+    assert out.val_history[-1]["nse"]["sum"] > out.val_history[0]["nse"]["sum"]         # maximised metric (loss_fn.jl:181-187)

@@ -79,8 +79,9 @@ def test_config_validation_and_directions():
     eh.validate_config(eh.TrainConfig())
     with pytest.raises(ValueError):
         eh.validate_config(eh.TrainConfig(batchsize=0))
+    eh.validate_config(eh.TrainConfig(training_loss="nseLoss"))
     with pytest.raises(NotImplementedError):
-        eh.validate_config(eh.TrainConfig(training_loss="nseLoss"))
+        eh.validate_config(eh.TrainConfig(training_loss="kgeLoss"))
     with pytest.raises(TypeError):
         eh.train(model(), {}, bogus_keyword=1)
 

@@ -32,6 +32,17 @@ def test_hand_vjp_matches_autograd(act, scale):
     assert np.max(np.abs(g - g2)) <= 1e-11 * np.max(np.abs(g2))
 
 
+@pytest.mark.parametrize("kind", ["rmse", "mae", "nseLoss"])
+def test_other_training_losses_vjp(kind):
+    # loss_fn.jl:58-86: the hand VJP of each supported training loss against autograd and its closed form
+    spec, th, X, f, y = _case("tanh", True, B=150)
+    l, g, _ = ho.loss_and_grad(spec, th, X, f, y, kind=kind)
+    l2, g2 = tt.loss_and_grad(spec, th, X, f, y, kind=kind)
+    yh = ho.forward(spec, th, X, f)["reco"]
+    assert l == pytest.approx(ho.loss_fn(yh, y["reco"].astype(np.float64), ho.valid_mask(y["reco"]), kind), rel=1e-12)
+    assert l == pytest.approx(l2, rel=1e-12) and np.max(np.abs(g - g2)) <= 1e-11 * np.max(np.abs(g2))
+
+
 @pytest.mark.parametrize("act,scale", [("tanh", True), ("sigmoid", False), ("swish", True)])
 def test_hand_vjp_matches_finite_differences(act, scale):
     spec, th, X, f, y = _case(act, scale, B=40)
