@@ -23,7 +23,7 @@ PAR_NEURAL, PAR_GLOBAL, PAR_FIXED = 0, 1, 2
 class ModelDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("device", C.c_int32), ("n_predictors", C.c_int32), ("n_hidden", C.c_int32),
-        ("hidden", C.c_int32 * EH_MAX_HIDDEN), ("activation", C.c_int32), ("scale_nn_outputs", C.c_int32),
+        ("hidden", C.c_int32 * EH_MAX_HIDDEN), ("activation", C.c_int32), ("scale_nn_outputs", C.c_int32), ("input_batchnorm", C.c_int32),
         ("mech", C.c_int32), ("n_params", C.c_int32),
         ("param_kind", C.c_int32 * EH_MAX_PARAMS), ("param_index", C.c_int32 * EH_MAX_PARAMS),
         ("param_default", C.c_float * EH_MAX_PARAMS), ("param_lower", C.c_float * EH_MAX_PARAMS),
@@ -59,6 +59,8 @@ SIGNATURES = {
     "eh_get_params": (C.c_int32, [_H, _F, C.c_int64]),
     "eh_forward": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, _FP, _FP]),
     "eh_loss_and_grad": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64, _F, _F, C.POINTER(C.c_int64)]),
+    "eh_get_bn_state": (C.c_int32, [_H, _F, _F, C.c_int64]),
+    "eh_set_bn_state": (C.c_int32, [_H, _F, _F, C.c_int64]),
     "eh_opt_init": (C.c_int32, [_H, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "eh_get_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
     "eh_set_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),

@@ -180,6 +180,42 @@ __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C,
     if (threadIdx.x == 0) inv_n[t] = red[0] > 0.0f ? 1.0f / red[0] : 0.0f;
 }
 
+// input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample
+// against cancellation.  part = [gridDim][64] (sum (x-c) | sum (x-c)^2 per predictor) then c[32].
+__global__ __launch_bounds__(1024) void eh_bn_stats_kernel(const float* recs, int C, int P, const int* idx, int first, int count, float* part) {
+    __shared__ float red[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = idx ? idx[first] : first;
+    float s1[32], s2[32];
+#pragma unroll
+    for (int p = 0; p < 32; ++p) { s1[p] = 0.0f; s2[p] = 0.0f; }
+    for (int i = blockIdx.x * 1024 + tid; i < count; i += gridDim.x * 1024) {
+        const int n = idx ? idx[first + i] : first + i;
+        const float* r = recs + (long long)n * C;
+        const float* r0 = recs + (long long)n0 * C;
+#pragma unroll
+        for (int p = 0; p < 32; ++p)
+            if (p < P) { const float d = r[p] - r0[p]; s1[p] += d; s2[p] += d * d; }
+    }
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        if (p < P) {
+            float a = s1[p], b = s2[p];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (lane == 0) { red[wave][p] = a; red[wave][32 + p] = b; }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.0f;
+        if ((tid & 31) < P)
+            for (int w = 0; w < 16; ++w) a += red[w][tid];
+        part[blockIdx.x * 64 + tid] = a;
+        if (blockIdx.x == 0 && tid < 32) part[gridDim.x * 64 + tid] = tid < P ? recs[(long long)n0 * C + tid] : 0.0f;
+    }
+}
+
 // keyed bijection of [0, n): 4-round Feistel network on 2*hb bits, cycle-walked into range.
 __host__ __device__ inline uint32_t eh_mix32(uint32_t x, uint32_t k) {
     x ^= k; x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
@@ -258,6 +294,10 @@ struct eh_handle_s {
     float* gacc = nullptr;          // [3][EH_GSHARDS][n_acc] rotating gradient accumulators
     long long gstep = 0;
     float* pending_loss = nullptr;
+    // input BatchNorm
+    bool bn_on = false;
+    float* bn_part = nullptr;       // [32][64] partials + c[32]
+    float* bn_run = nullptr;        // [2][32] running mean / var
     bool opt_ready = false;
     EhOpt opt{};
     EhSplit split[2];
@@ -502,6 +542,14 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipMemset(h->pset, 0, (6 * nt + 4) * sizeof(float)));
     for (int k = 0; k < 2; ++k) { h->thb[k] = h->pset + (size_t)k * 3 * nt; h->mb[k] = h->thb[k] + nt; h->vb[k] = h->thb[k] + 2 * nt; }
     h->sc = h->pset + 6 * nt;
+    h->bn_on = d->input_batchnorm != 0;
+    if (h->bn_on) {
+        HIPCHK_C(hipMalloc(&h->bn_part, (32 * 64 + 32) * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->bn_run, 64 * sizeof(float)));
+        float run0[64];
+        for (int p = 0; p < 32; ++p) { run0[p] = 0.0f; run0[32 + p] = 1.0f; }     // LuxCore.initialstates(BatchNorm)
+        HIPCHK_C(hipMemcpy(h->bn_run, run0, sizeof run0, hipMemcpyHostToDevice));
+    }
     HIPCHK_C(hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->slab, (size_t)h->max_blocks * std::max(h->n_acc, EH_EVAL_STATS * n.T) * sizeof(float)));
@@ -530,6 +578,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
             img0[arch->phi_off + EH_IMG_LO + j] = d->param_lower[j];
             img0[arch->phi_off + EH_IMG_SC + j] = d->param_upper[j] - d->param_lower[j];
         }
+        for (int p = 0; p < 32; ++p) { img0[arch->phi_off + EH_IMG_BNM + p] = 0.0f; img0[arch->phi_off + EH_IMG_BNR + p] = d->input_batchnorm ? 1.0f / std::sqrt(1.0f + EH_BN_EPS) : 1.0f; }
         auto put_int = [&](int slot, int v) { memcpy(&img0[arch->phi_off + slot], &v, sizeof(int)); };
         for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
         for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, d->hidden[l]);
@@ -562,7 +611,7 @@ int32_t eh_destroy(eh_handle* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->pset);
-    (void)hipFree(h->gacc); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
@@ -714,7 +763,18 @@ static int grid_for(const eh_handle* h, long long count) {
     return (int)std::max<long long>(1, std::min<long long>((ntiles + v.nw - 1) / v.nw, h->max_blocks));
 }
 
-static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* grid_out) {
+// input BatchNorm: statistics of the minibatch [first, first+count) -> a.bn_* (train-mode kernels only)
+static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool update, EhStepArgs* a) {
+    a->bn_part = nullptr; a->bn_nblk = 0; a->bn_update = 0; a->bn_run = h->bn_run; a->image_out = h->image;
+    if (!h->bn_on || count <= 0) return EH_OK;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(32, (count + 1023) / 1024));
+    hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part);
+    HIPCHK(h, hipGetLastError());
+    a->bn_part = h->bn_part; a->bn_nblk = nblk; a->bn_update = update ? 1 : 0;
+    return EH_OK;
+}
+
+static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* grid_out, bool bn_update) {
     const EhNet& net = h->net;
     if (net.T > 1) {
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
@@ -728,6 +788,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.rmap = h->rmap;
     a.stamps = h->stamps;
     a.fz.gacc = nullptr;
+    if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &a)) return rc;
     const int grid = grid_for(h, count);
     *grid_out = grid;
     HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
@@ -749,6 +810,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
     z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
+    if (int rc = bn_prepare(h, sp, idx, first, count, true, &a)) return rc;
     const int grid = grid_for(h, count);
     HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
     h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;
@@ -781,7 +843,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
     }
     int grid = 1;
-    int rc = launch_train_kernel(h, sp, idx, first, count, &grid);
+    int rc = launch_train_kernel(h, sp, idx, first, count, &grid, apply);
     if (rc) return rc;
     if (prof) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
@@ -943,6 +1005,34 @@ int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_
     return EH_OK;
 }
 
+int32_t eh_get_bn_state(eh_handle* h, float* running_mean, float* running_var, int64_t n) {
+    if (!h || !running_mean || !running_var) return EH_EINVAL;
+    if (!h->bn_on) return fail(h, EH_ESTATE, "eh_get_bn_state: the model has no input BatchNorm");
+    if (n != h->net.P) return fail(h, EH_EINVAL, "eh_get_bn_state: n = %lld, model has %d predictors", (long long)n, h->net.P);
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(running_mean, h->bn_run, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(running_var, h->bn_run + 32, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return EH_OK;
+}
+
+int32_t eh_set_bn_state(eh_handle* h, const float* running_mean, const float* running_var, int64_t n) {
+    if (!h || !running_mean || !running_var) return EH_EINVAL;
+    if (!h->bn_on) return fail(h, EH_ESTATE, "eh_set_bn_state: the model has no input BatchNorm");
+    if (n != h->net.P) return fail(h, EH_EINVAL, "eh_set_bn_state: n = %lld, model has %d predictors", (long long)n, h->net.P);
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<float> rstd((size_t)n);
+    for (int64_t p = 0; p < n; ++p) rstd[p] = 1.0f / std::sqrt(running_var[p] + EH_BN_EPS);
+    HIPCHK(h, hipMemcpy(h->bn_run, running_mean, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->bn_run + 32, running_var, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->image + h->arch->phi_off + EH_IMG_BNM, running_mean, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->image + h->arch->phi_off + EH_IMG_BNR, rstd.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return EH_OK;
+}
+
 int32_t eh_opt_init(eh_handle* h, int32_t rule, float lr, float beta1, float beta2, float eps, float weight_decay) {
     if (!h) return EH_EINVAL;
     if (rule < EH_OPT_ADAM || rule > EH_OPT_DESCENT) return fail(h, EH_EUNSUPPORTED, "eh_opt_init: unknown rule %d", rule);
@@ -1056,6 +1146,7 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
+    if (h->bn_on) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: input BatchNorm needs cross-GPU batch statistics (not built)");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
@@ -1067,6 +1158,7 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index) {
     if (!h || !buffer_index) return EH_EINVAL;
     if (!h->fused) return fail(h, EH_ESTATE, "eh_dp_fused_step: set the fused_update option first");
+    if (h->bn_on) return fail(h, EH_EUNSUPPORTED, "eh_dp_fused_step: input BatchNorm needs cross-GPU batch statistics (not built)");
     if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_dp_fused_step: call eh_opt_init first");
     HIPCHK(h, hipSetDevice(h->device));
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];

@@ -46,7 +46,7 @@ struct EhNet {
 // Per-layer offsets / widths and the (lower, upper-lower) table travel in the parameter image
 // (EhGeom::PHI_OFF block) instead of the kernarg: they are read from LDS where they are used,
 // which keeps them out of the scalar register file during the tile loop.
-enum { EH_IMG_PHI = 0, EH_IMG_DPHI = 8, EH_IMG_LO = 16, EH_IMG_SC = 24, EH_IMG_WOFF = 32, EH_IMG_BOFF = 37, EH_IMG_WIDTH = 42, EH_IMG_GPAR = 48, EH_IMG_META = 56 };
+enum { EH_IMG_PHI = 0, EH_IMG_DPHI = 8, EH_IMG_LO = 16, EH_IMG_SC = 24, EH_IMG_WOFF = 32, EH_IMG_BOFF = 37, EH_IMG_WIDTH = 42, EH_IMG_GPAR = 48, EH_IMG_BNM = 56, EH_IMG_BNR = 88, EH_IMG_META = 120 };
 
 struct EhOpt {
     int rule;
@@ -125,7 +125,16 @@ struct EhStepArgs {
     float shift[EH_MAX_TARG];   // eval: metric shift c_t
     unsigned long long* stamps;   // diagnostic builds (-DEH_STAMPS) only: [16][2] (shader clock, 100 MHz wall clock)
     EhFused fz;
+    // input BatchNorm, train mode: per-workgroup partial sums of the batch from eh_bn_stats_kernel
+    const float* bn_part;   // [bn_nblk][64] (sum (x-c), sum (x-c)^2 per predictor), then c[32]; nullptr = use the image's statistics
+    int bn_nblk;
+    int bn_update;          // workgroup 0 also updates the running statistics (a real training step)
+    float* bn_run;          // [2][32] running mean, running var
+    float* image_out;       // global parameter image: its normalisation block follows the running statistics
 };
+
+#define EH_BN_EPS 1e-5f
+#define EH_BN_MOMENTUM 0.1f
 
 // ------------------------------------------------------------------------------------------
 // scalar math (hardware transcendental units; every path stays well inside the 1e-5 budget)
@@ -238,7 +247,7 @@ struct EhGeom {
     static constexpr int WH_OFF = W0_OFF + HP * S0;                  // NL-1 hidden->hidden matrices
     static constexpr int WO_OFF = WH_OFF + (NL - 1) * HP * SH;       // output layer, 16 padded rows
     static constexpr int B_OFF = WO_OFF + 16 * SH;                   // biases: NL * HP + 16
-    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;             // EH_IMG_* block: phi[8], dphi[8], lo[8], hi-lo[8], int w_off[5], b_off[5], width[4], gpar[8]
+    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;             // EH_IMG_* block: phi[8], dphi[8], lo[8], hi-lo[8], int w_off[5], b_off[5], width[4], gpar[8], input-normalisation mean[32], 1/std[32]
     static constexpr int IMG_FLOATS = PHI_OFF + EH_IMG_META;         // multiple of 4
     // per-wave workspace
     static constexpr int XS_OFF = 0;
@@ -398,6 +407,25 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     for (int e = 4 * tid; e < G::IMG_FLOATS; e += 4 * NTHR) *(f32x4*)&wl[e] = *(const f32x4*)&a.image[e];
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
     __syncthreads();
+    if (a.bn_part) {
+        // input BatchNorm, train mode (Lux BatchNorm, affine = false): statistics of THIS minibatch
+        if (tid < net.P) {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
+            const float m = (float)count, c0 = a.bn_part[a.bn_nblk * 64 + tid];
+            const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
+            wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
+            wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);
+            if (a.bn_update && blockIdx.x == 0) {
+                const float rm = (1.0f - EH_BN_MOMENTUM) * a.bn_run[tid] + EH_BN_MOMENTUM * mu;
+                const float rv = (1.0f - EH_BN_MOMENTUM) * a.bn_run[32 + tid] + EH_BN_MOMENTUM * (m > 1.0f ? m / (m - 1.0f) : 1.0f) * var;
+                a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
+                a.image_out[G::PHI_OFF + EH_IMG_BNM + tid] = rm;                       // what forward / eval (test mode) will use
+                a.image_out[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
+            }
+        }
+        __syncthreads();
+    }
     if (fusedm) {
         // fused update: apply the previous step's optimiser update straight into the LDS image
         const EhFused& z = a.fz;
@@ -498,7 +526,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         for (int q = 0; q < NX4; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (4 * q + e < net.P && lane < MT) XS[(4 * q + e) * SR + lane] = nx.x[q][e];
+                if (4 * q + e < net.P && lane < MT)      // (x - mean) / std of the input BatchNorm; mean 0, 1/std 1 without it
+                    XS[(4 * q + e) * SR + lane] = (nx.x[q][e] - meta[EH_IMG_BNM + 4 * q + e]) * meta[EH_IMG_BNR + 4 * q + e];
         fetch(tile + (int)gridDim.x * NW);   // next tile's record: in flight behind this tile's compute
         EH_WAVE_SYNC();
 

@@ -160,6 +160,17 @@ class HybridEngine:
             raise NotImplementedError(f"optimiser rule {rule} is not implemented on the device")
         self._chk(self._lib.eh_opt_init(self._h, L.OPT_RULES[rule], lr, beta1, beta2, eps, weight_decay))
 
+    def get_bn_state(self):
+        """running (mean, var) of the input BatchNorm layer -- the `st.st_nn` part of the model state"""
+        P = self.desc.n_predictors
+        m = np.empty(P, np.float32); v = np.empty(P, np.float32)
+        self._chk(self._lib.eh_get_bn_state(self._h, _fptr(m), _fptr(v), P))
+        return m, v
+
+    def set_bn_state(self, mean, var):
+        m = np.ascontiguousarray(mean, np.float32); v = np.ascontiguousarray(var, np.float32)
+        self._chk(self._lib.eh_set_bn_state(self._h, _fptr(m), _fptr(v), m.size))
+
     def set_training_loss(self, name: str):
         """TrainConfig.training_loss (src/config/TrainingConfig.jl:64): mse | rmse | mae | nseLoss."""
         if name not in L.TRAINING_LOSSES:

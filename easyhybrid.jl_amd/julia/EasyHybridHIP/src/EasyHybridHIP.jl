@@ -29,6 +29,7 @@ struct EhModelDesc
     hidden::NTuple{4, Int32}
     activation::Int32
     scale_nn_outputs::Int32
+    input_batchnorm::Int32
     mech::Int32
     n_params::Int32
     param_kind::NTuple{8, Int32}
@@ -94,7 +95,6 @@ function constructHybridModel(predictors::Vector{Symbol}, forcing, targets, mech
         "an arbitrary closure cannot run inside the HIP kernel (no CPU fallback)"))
     all_names = collect(keys(parameters))
     @assert all(n in all_names for n in neural_param_names) "neural_param_names ⊆ param_names"
-    input_batchnorm && throw(ArgumentError("input_batchnorm = true is not built yet"))
     dims = [length(predictors); hidden_layers; length(neural_param_names)]
     NN = [(dims[i + 1], dims[i]) for i in 1:(length(dims) - 1)]
     fixed = [n for n in all_names if !(n in [neural_param_names..., global_param_names...])]
@@ -123,7 +123,7 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
     end
     hidden = [o for (o, _) in m.NN[1:(end - 1)]]
     return EhModelDesc(sizeof(EhModelDesc), device, length(m.predictors), length(hidden), pad(hidden, 4, Int32),
-        ACT[m.config.activation], m.scale_nn_outputs, ms.id, length(ms.params),
+        ACT[m.config.activation], m.scale_nn_outputs, m.config.input_batchnorm, ms.id, length(ms.params),
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
         length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32))

@@ -247,6 +247,7 @@ class SingleNNHybridModel:
             d.hidden[k] = w
         d.activation = L.ACTIVATIONS[self.activation]
         d.scale_nn_outputs = int(self.scale_nn_outputs)
+        d.input_batchnorm = int(bool(self.config.get("input_batchnorm", False)))
         d.mech = ms.id
         d.n_params = len(ms.params)
         for j, p in enumerate(ms.params):
@@ -288,8 +289,6 @@ def constructHybridModel(predictors: Sequence[str], forcing: Sequence[str], targ
     all_names = parameters.names()
     if not all(n in all_names for n in neural_param_names):
         raise AssertionError("neural_param_names ⊆ param_names")                      # GenericHybridModel.jl:110
-    if input_batchnorm:
-        raise NotImplementedError("input_batchnorm=true is not built yet (SURVEY.md section 8f rank 2)")
     predictors, forcing, targets = list(predictors), list(forcing), list(targets)
     neural_param_names, global_param_names = list(neural_param_names), list(global_param_names)
     if len(predictors) == 0 or len(neural_param_names) == 0:

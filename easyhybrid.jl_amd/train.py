@@ -311,8 +311,12 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         tr_op, tr_diff = obs_pred(L.EH_SPLIT_TRAIN, ytr)
         va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
         fixed = {f: np.float32(model.parameters.default(f)) for f in model.fixed_param_names}
+        st = {"fixed": fixed}
+        if model.config.get("input_batchnorm"):
+            rm, rv = eng.get_bn_state()
+            st["st_nn"] = {"running_mean": rm, "running_var": rv}          # Lux BatchNorm state (final, not best-epoch)
         return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
-                            ps, {"fixed": fixed}, best_epoch, best_loss)
+                            ps, st, best_epoch, best_loss)
     finally:
         if own:
             eng.close()

@@ -90,6 +90,7 @@ typedef struct eh_model_desc {
     int32_t hidden[EH_MAX_HIDDEN];           /* hidden_layers */
     int32_t activation;                      /* eh_activation */
     int32_t scale_nn_outputs;                /* constructHybridModel kwarg */
+    int32_t input_batchnorm;                 /* constructHybridModel kwarg: InputBatchNorm(P, affine = false) in front of the chain (src/models/NNModels.jl:89-105,226) */
     int32_t mech;                            /* eh_mech */
     int32_t n_params;                        /* must equal the registry's parameter count */
     int32_t param_kind[EH_MAX_PARAMS];       /* per canonical parameter: eh_param_kind */
@@ -144,6 +145,11 @@ int32_t eh_forward(eh_handle* h, int32_t split, int64_t first, int64_t count, fl
  * split, NULL = the contiguous window.  An all-masked batch gives loss = NaN, grad = 0, n_valid = 0. */
 int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_t first, int64_t count,
                          float* loss, float* grad, int64_t* n_valid);
+
+/* running statistics of the input BatchNorm layer (the model state `st.st_nn`; Lux starts them at mean 0, var 1).
+ * Training steps use the statistics of their own minibatch and update these with momentum 0.1; forward / eval use them. */
+int32_t eh_get_bn_state(eh_handle* h, float* running_mean, float* running_var, int64_t n_predictors);
+int32_t eh_set_bn_state(eh_handle* h, const float* running_mean, const float* running_var, int64_t n_predictors);
 
 /* Optimisers.setup(rule, ps): zero moments, t = 0 (src/training/initialization.jl:42-44) */
 int32_t eh_opt_init(eh_handle* h, int32_t rule, float lr, float beta1, float beta2, float eps, float weight_decay);

@@ -209,6 +209,7 @@ class HybridSpec:
     targets: List[str] = field(default_factory=list)
     activation: str = "tanh"
     scale_nn_outputs: bool = False
+    input_batchnorm: bool = False        # InputBatchNorm(in_dim, affine=false) in front of the chain (NNModels.jl:226)
 
     def __post_init__(self):
         mm = MECH[self.mech][0]
@@ -292,12 +293,44 @@ def init_theta(spec: HybridSpec, seed: int, dtype=np.float32):
 # ----------------------------------------------------------------------------------------------
 
 
-def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=np.float64, keep=False):
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # Lux.BatchNorm defaults (epsilon = 1f-5, momentum = 0.1f0)
+
+
+def bn_init(spec):
+    """LuxCore.initialstates of BatchNorm: running_mean = 0, running_var = 1."""
+    return {"mean": np.zeros(spec.n_pred), "var": np.ones(spec.n_pred)}
+
+
+def batchnorm_input(X, bn_state, train_mode: bool, dt):
+    """Lux BatchNorm(affine = false) on (features x batch) input.  Train mode: batch statistics
+    (biased variance) and the running-statistics update with the unbiased correction m/(m-1);
+    test mode: running statistics.  No parameters, and X is data: nothing to back-propagate."""
+    if train_mode:
+        m = X.shape[1]
+        mu = X.mean(axis=1)
+        var = X.var(axis=1)
+        new = None
+        if bn_state is not None:
+            corr = m / (m - 1.0) if m > 1 else 1.0
+            new = {"mean": (1 - BN_MOMENTUM) * bn_state["mean"] + BN_MOMENTUM * mu,
+                   "var": (1 - BN_MOMENTUM) * bn_state["var"] + BN_MOMENTUM * corr * var}
+    else:
+        mu, var, new = np.asarray(bn_state["mean"]), np.asarray(bn_state["var"]), bn_state
+    Xn = ((X - mu[:, None].astype(dt)) / np.sqrt(var[:, None].astype(dt) + dt.type(BN_EPS))).astype(dt)
+    return Xn, new
+
+
+def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=np.float64, keep=False, bn_state=None, train_mode=True):
     """X is (P, B) like the reference (features x batch).  Returns dict with the mech outputs,
-    'parameters' (all physical params) and, if keep, the tape for the VJP."""
+    'parameters' (all physical params) and, if keep, the tape for the VJP.  With
+    spec.input_batchnorm the predictors are normalised first (batch statistics in train mode,
+    `bn_state` running statistics otherwise); the updated running statistics come back as '_bn'."""
     dt = np.dtype(dtype)
     theta = np.asarray(theta, dt)
     X = np.asarray(X, dt)
+    bn_new = None
+    if spec.input_batchnorm:
+        X, bn_new = batchnorm_input(X, bn_state, train_mode, dt)
     Ws, raw = unpack(spec, theta)
     # k1: global params
     glob = {}
@@ -324,6 +357,7 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
     out = {k: v.astype(dt) for k, v in out.items()}
     res = dict(out)
     res["parameters"] = par
+    res["_bn"] = bn_new
     if keep:
         res["_tape"] = dict(Ws=Ws, raw=raw, zs=zs, hs=hs, o=o, par=par, frc=frc, aux=aux, out=out)
     return res
@@ -380,13 +414,13 @@ def compute_loss(spec, theta, X, forcings, targets: Dict[str, np.ndarray], dtype
     return tot
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse"):
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None):
     """Training loss (`kind` in mse / rmse / mae / nseLoss, loss_fn.jl:58-86; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
     (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
     skips all-masked batches, epoch.jl:17-19)."""
     dt = np.dtype(dtype)
-    res = forward(spec, theta, X, forcings, dtype, keep=True)
+    res = forward(spec, theta, X, forcings, dtype, keep=True, bn_state=bn_state, train_mode=True)
     tp = res["_tape"]
     B = X.shape[1]
     loss = dt.type(0)
@@ -478,19 +512,24 @@ def adam_step(theta, grad, st, lr=0.01, b1=0.9, b2=0.999, eps=1e-8, weight_decay
     return (theta - upd).astype(theta.dtype)
 
 
-def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32, kind="mse"):
+def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32, kind="mse",
+                bn_state=None):
     """Run Adam over contiguous batches [(first, count), ...]; all-masked batches are skipped
-    (epoch.jl:17-19).  Returns (theta, [loss per batch])."""
+    (epoch.jl:17-19).  Returns (theta, [loss per batch]); with input_batchnorm `bn_state` (a dict
+    from bn_init) is updated in place with the running statistics of every batch that ran."""
     theta = np.asarray(theta0, dtype).copy()
     st = adam_init(theta.size, dtype)
     losses = []
     for first, count in batches:
         sl = slice(first, first + count)
-        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()},
-                                 {k: v[sl] for k, v in targets.items()}, dtype, kind)
-        if sum(nv) == 0:
-            losses.append(float("nan"))
+        yb = {k: v[sl] for k, v in targets.items()}
+        if not any((~np.isnan(v)).any() for v in yb.values()):
+            losses.append(float("nan"))          # isemptybatch: the step (and its state update) never runs
             continue
+        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()}, yb, dtype, kind, bn_state)
+        if spec.input_batchnorm and bn_state is not None:
+            _, new = batchnorm_input(np.asarray(X[:, sl], np.float64), bn_state, True, np.dtype(np.float64))
+            bn_state.update(new)
         theta = adam_step(theta, g.astype(dtype), st, lr)
         losses.append(float(l))
     return theta, losses
@@ -501,8 +540,8 @@ def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int,
 # ----------------------------------------------------------------------------------------------
 
 
-def evaluate(spec, theta, X, forcings, targets, loss_types=("mse", "r2"), dtype=np.float64):
-    res = forward(spec, theta, X, forcings, dtype)
+def evaluate(spec, theta, X, forcings, targets, loss_types=("mse", "r2"), dtype=np.float64, bn_state=None):
+    res = forward(spec, theta, X, forcings, dtype, bn_state=bn_state, train_mode=False)
     out = {}
     for lt in loss_types:
         per = {}

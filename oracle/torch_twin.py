@@ -49,6 +49,8 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
     dt = theta.dtype
     off = 0
     h = torch.as_tensor(X, dtype=dt)
+    if getattr(spec, "input_batchnorm", False):            # train-mode batch statistics, biased variance, eps = 1e-5
+        h = (h - h.mean(dim=1, keepdim=True)) / torch.sqrt(h.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
     nl = len(spec.layer_dims)
     for li, (o, i) in enumerate(spec.layer_dims):
         W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)

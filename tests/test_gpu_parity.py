@@ -500,3 +500,62 @@ def test_train_with_nse_loss_front_door():
                                     hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
     out = eh.train(model, cols, nepochs=5, batchsize=200, training_loss="nseLoss", loss_types=["nse", "mse"], random_seed=2)
     assert out.val_history[-1]["nse"]["sum"] > out.val_history[0]["nse"]["sum"]         # maximised metric (loss_fn.jl:181-187)
+
+
+# ----------------------------------------------------------------------------------------------
+# input BatchNorm (constructHybridModel(...; input_batchnorm = true), NNModels.jl:89-105,226)
+# ----------------------------------------------------------------------------------------------
+def _bn_case(B, P_raw=True, seed=11):
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    spec.input_batchnorm = True
+    X, f, y = ho.make_synth_rbq10(B, seed, 0.1)          # raw predictors (sw_pot ~ 50 +- 20): exactly why the README turns BN on
+    return spec, ho.init_theta(spec, 3, np.float32), X, f, y
+
+
+def test_input_batchnorm_train_mode_gradient_and_test_mode_forward():
+    spec, theta, X, f, y = _bn_case(1500)
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad()                                    # train mode: statistics of this batch
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, bn_state=ho.bn_init(spec))
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    _check = eng.loss_and_grad(first=200, count=333)                        # other window -> other statistics
+    sl = slice(200, 533)
+    l1, g1, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {"ta": f["ta"][sl]}, {"reco": y["reco"][sl]})
+    assert _check[0] == pytest.approx(l1, rel=TOL) and util.relerr(_check[1], g1) <= TOL
+    st = ho.bn_init(spec)                                                   # test mode before any step: running mean 0, var 1
+    ref = ho.forward(spec, theta.astype(np.float64), X, f, bn_state=st, train_mode=False)
+    assert util.relerr(eng.forward(0, params=False)["reco"], ref["reco"]) <= TOL
+    rm, rv = eng.get_bn_state()
+    assert not rm.any() and np.all(rv == 1)                                 # loss_and_grad does not touch the state
+    eng.close()
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_input_batchnorm_training_trajectory_and_running_statistics(fused):
+    spec, theta, X, f, y = _bn_case(2048)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_option("fused_update", fused)
+    batches = [(i * 256, 256) for i in range(8)]
+    losses = [eng.train_step(*b) for b in batches]
+    st = ho.bn_init(spec)
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32, bn_state=st)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    rm, rv = eng.get_bn_state()
+    assert util.relerr(rm, st["mean"]) <= 1e-5 and util.relerr(rv, st["var"]) <= 1e-5
+    m, _ = eng.eval(0)                                                      # eval = test mode with the running statistics
+    ref = ho.evaluate(spec, eng.get_params().astype(np.float64), X, f, y, bn_state=st)[0]
+    assert m[0]["mse"] == pytest.approx(ref["mse"]["reco"], rel=3e-5)
+    eng.set_bn_state(np.array([50.0, 0.0], np.float32), np.array([400.0, 700.0], np.float32))
+    ref2 = ho.forward(spec, eng.get_params().astype(np.float64), X, f, bn_state={"mean": np.array([50.0, 0.0]), "var": np.array([400.0, 700.0])}, train_mode=False)
+    assert util.relerr(eng.forward(0, params=False)["reco"], ref2["reco"]) <= TOL
+    eng.close()
+
+
+def test_readme_quickstart_configuration_trains():
+    # README.md:185-201: hidden [16,16], sigmoid/tanh, scale_nn_outputs = true, input_batchnorm = true on RAW predictors
+    cols = eh.synthetic.make_synth_rbq10(4000, seed=8, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="sigmoid", scale_nn_outputs=True, input_batchnorm=True)
+    out = eh.train(model, cols, nepochs=8, batchsize=128, opt=eh.AdamW(0.01, (0.9, 0.999), 0.01), random_seed=3)
+    assert out.val_history[-1]["mse"]["sum"] < 0.5 * out.val_history[0]["mse"]["sum"]
+    assert out.st["st_nn"]["running_mean"][0] == pytest.approx(50.0, rel=0.1)

@@ -27,8 +27,7 @@ def test_constructor_errors_match_reference():
         eh.constructHybridModel(["a"], ["ta"], ["reco"], eh.RbQ10, PARAMS, ["nope"], ["Q10"])
     with pytest.raises(NotImplementedError, match="closure"):
         eh.constructHybridModel(["a"], ["ta"], ["reco"], lambda **kw: None, PARAMS, ["rb"], ["Q10"])
-    with pytest.raises(NotImplementedError):
-        model(input_batchnorm=True)
+    assert model(input_batchnorm=True).to_desc().input_batchnorm == 1
     with pytest.raises(ValueError, match="forcing"):
         eh.constructHybridModel(["a"], ["temp"], ["reco"], eh.RbQ10, PARAMS, ["rb"], ["Q10"])
 

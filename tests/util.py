@@ -13,7 +13,7 @@ def model_from_spec(spec: ho.HybridSpec):
     return eh.constructHybridModel([f"x{i}" for i in range(spec.n_pred)], list(mm.forcings), list(spec.targets),
                                    MECH_NAME[spec.mech], dict(spec.parameters), list(spec.neural), list(spec.glob),
                                    hidden_layers=list(spec.hidden), activation=spec.activation,
-                                   scale_nn_outputs=spec.scale_nn_outputs)
+                                   scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False))
 
 
 def load_engine(spec, theta, X, forcings, targets, split=0, engine=None):
