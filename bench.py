@@ -32,24 +32,30 @@ PEAK_HBM_GBPS = 8000.0
 
 def cpu_baseline(batch, seconds=12.0):
     """The CPU oracle (plain-C port, OpenMP over samples) timed on this box's host cores, on a
-    bounded sample of the same workload: steps of `batch` samples for ~`seconds` of CPU work."""
+    bounded sample of the same workload: steps of `batch` samples for ~`seconds` of CPU work.  The
+    thread count is the best of a short sweep (all cores is not the fastest on a 256-thread host)."""
     from oracle import c_oracle as co
     from oracle import hybrid_oracle as ho
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     spec = ho.rbq10_spec((16, 16), "tanh", True)
     X, f, y = ho.make_synth_rbq10(4 * batch, 42)
     theta = ho.init_theta(spec, 1, np.float32)
-    co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=cores)          # warm-up (page-in, thread pool)
-    t0 = time.perf_counter()
-    co.train_steps(spec, theta, X, f, y, batch, 2, nthreads=cores)
-    per = (time.perf_counter() - t0) / 2
-    n = max(4, int(seconds / max(per, 1e-6)))
-    t0 = time.perf_counter()
-    co.train_steps(spec, theta, X, f, y, batch, n, nthreads=cores)
+    best, per = None, None
+    for nt in sorted({min(avail, k) for k in (8, 16, 32, 64, 128, 256, avail)}):
+        co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt)          # warm-up (page-in, thread pool)
+        t0 = time.perf_counter()
+        co.train_steps(spec, theta, X, f, y, batch, 2, nthreads=nt)
+        t = (time.perf_counter() - t0) / 2
+        if per is None or t < per:
+            best, per = nt, t
+    n, chunk, t0 = 0, max(2, min(64, int(1.0 / max(per, 1e-4)))), time.perf_counter()
+    while time.perf_counter() - t0 < seconds:              # bounded by wall time, whatever the sweep estimated
+        co.train_steps(spec, theta, X, f, y, batch, chunk, nthreads=best)
+        n += chunk
     dt = time.perf_counter() - t0
-    return {"value": batch * n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": batch * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
             "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the plain-C oracle port, "
-                      f"OpenMP over samples on {cores} host threads",
+                      f"OpenMP over samples on {best} of {avail} host threads (fastest of a short sweep)",
             "ms_per_step": 1e3 * dt / n}
 
 
