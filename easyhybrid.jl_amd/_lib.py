@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG = 4, 8, 4, 4
+EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 4, 8, 4, 4, 8
 EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE = 0, -1, -2, -3, -4, -5
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
 EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC = 0, 1, 2, 3, 4
@@ -30,6 +30,7 @@ class ModelDesc(C.Structure):
         ("param_upper", C.c_float * EH_MAX_PARAMS),
         ("n_forcings", C.c_int32), ("forcing_index", C.c_int32 * EH_MAX_FORC),
         ("n_targets", C.c_int32), ("target_output", C.c_int32 * EH_MAX_TARG),
+        ("n_nets", C.c_int32), ("net_n_predictors", C.c_int32 * EH_MAX_NETS), ("net_hidden", (C.c_int32 * EH_MAX_HIDDEN) * EH_MAX_NETS),
     ]
 
 

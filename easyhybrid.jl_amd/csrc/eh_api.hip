@@ -280,7 +280,14 @@ struct eh_handle_s {
     float* image = nullptr;
     int* imap = nullptr;
     int* rmap = nullptr;            // v2 reduction map for the current fast-path flags
-    int hidden[EH_MAX_HIDDEN + 1] = {0};
+    int* cmap = nullptr;            // accumulator element -> canonical index (reduction of the wide shapes)
+    // block placement of every net inside the padded (block-diagonal) MLP
+    int n_nets = 1;                                     // 1 for SingleNN
+    int net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0};
+    int net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}};      // hidden widths of net k
+    int net_c0[EH_MAX_NETS] = {0};                      // first predictor row of net k
+    int net_r0[EH_MAX_NETS][EH_MAX_HIDDEN + 1] = {{0}}; // first row of net k in layer l (l == n_hidden: output row)
+    int tot_w[EH_MAX_HIDDEN] = {0};                     // total (summed) hidden widths
     EhImg img{};
     int device = 0;
     hipStream_t stream = nullptr, own_stream = nullptr;
@@ -359,46 +366,64 @@ static int flush_pending(eh_handle* h) {
         if (rc_) return rc_;              \
     } while (0)
 
-// canonical index -> position in the step kernel's v2 reduction region (see eh_acc_layout)
-static int build_rmap(eh_handle* h) {
+// Every trainable scalar of the model as (canonical flat index, layer, row, col) in the padded
+// block-diagonal MLP.  col < 0 marks a bias.  SingleNN = one net covering everything.
+struct EhEntry { int canon, l, row, col; };
+static std::vector<EhEntry> enumerate_entries(const eh_handle* h) {
+    std::vector<EhEntry> v;
+    const int nl = h->desc.n_hidden;
+    int off = 0;
+    for (int k = 0; k < h->n_nets; ++k) {
+        int in = h->net_P[k];
+        for (int l = 0; l <= nl; ++l) {
+            const int o = l < nl ? h->net_w[k][l] : h->net_K[k];
+            const int r0 = h->net_r0[k][l], c0 = l == 0 ? h->net_c0[k] : h->net_r0[k][l - 1];
+            for (int col = 0; col < in; ++col)
+                for (int row = 0; row < o; ++row) v.push_back({off + row + o * col, l, r0 + row, c0 + col});
+            off += o * in;
+            for (int row = 0; row < o; ++row) v.push_back({off + row, l, r0 + row, -1});
+            off += o;
+            in = o;
+        }
+    }
+    return v;
+}
+
+// canonical index -> parameter-image offset; canonical index <-> accumulator element of the step
+// kernel (rmap for the v2 reduction region, cmap for the canonical-order region; see eh_acc_layout)
+static int build_maps(eh_handle* h, bool with_imap) {
     const eh_model_desc& d = h->desc;
     const EhNet& n = h->net;
-    const int nbi = h->arch->nbi, nbh = h->arch->nbh, nl = h->arch->nl, fast = h->fast;
+    const EhArchInfo* A = h->arch;
+    const int nbi = A->nbi, nbh = A->nbh, nl = A->nl, fast = h->fast;
     const EhAccLayout L = eh_acc_layout(nbi, nbh, nl, fast);
-    std::vector<int> rmap((size_t)h->n_acc, 0);
-    auto at = [](int k, int lane, int r) { return k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15); };   // region[k][g][r][c]
-    int off = 0, in = n.P;
-    for (int l = 0; l <= nl; ++l) {
-        const int o = l < nl ? d.hidden[l] : n.K;
-        for (int col = 0; col < in; ++col)
-            for (int row = 0; row < o; ++row) {
-                const int e = off + row + o * col;
-                int code;
-                if (l == 0) {
-                    const int m = row / 16, g = (row % 16) / 4, r = row % 4;
-                    if (fast & 2) code = at(L.kw0 + m * 4 + col, 16 * g, r) | (16 << 24);
-                    else code = at(L.kw0 + m * nbi + col / 16, 16 * g + col % 16, r) | (1 << 24);
-                } else if (l < nl) {
-                    const int m = row / 16, g = (row % 16) / 4, r = row % 4;
-                    code = at(L.kwh + ((l - 1) * nbh + m) * nbh + col / 16, 16 * g + col % 16, r) | (1 << 24);
-                } else if (fast & 1) {
-                    const int m = col / 16, g = (col % 16) / 4, r = col % 4;
-                    code = at(L.kwo + m, 16 * g, r) | (16 << 24);
-                } else {
-                    code = at(L.kwo + col / 16, 16 * (row / 4) + col % 16, row % 4) | (1 << 24);
-                }
-                rmap[e] = code;
-            }
-        off += o * in;
-        for (int row = 0; row < o; ++row) {
-            int code;
-            if (l < nl) code = at(L.kb + l * nbh + row / 16, 16 * ((row % 16) / 4), row % 4) | (16 << 24);
-            else if (fast & 1) code = (L.na * 256 + 13) | (1 << 24);
-            else code = at(L.kbo, 16 * (row / 4), row % 4) | (16 << 24);
-            rmap[off + row] = code;
+    const std::vector<EhEntry> ent = enumerate_entries(h);
+    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0), cmap((size_t)L.na * 256, -1);
+    auto at = [](int k, int lane, int r) { return k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15); };   // v2 region[k][g][r][c]
+    auto cm = [](int k, int lane, int r) { return k * 256 + lane * 4 + r; };                              // cmap[k][lane][r]
+    for (const EhEntry& e : ent) {
+        const int m = e.row / 16, g = (e.row % 16) / 4, r = e.row % 4;
+        int img, k, lane, rr, nlan;
+        if (e.col < 0) {                                   // bias of layer l
+            img = A->b_off + e.l * A->hp + e.row;
+            if (e.l < nl) { k = L.kb + e.l * nbh + m; lane = 16 * g; rr = r; nlan = 16; }
+            else if (fast & 1) { k = -1; lane = 0; rr = 0; nlan = 1; }          // K1: scalar in the tail
+            else { k = L.kbo; lane = 16 * (e.row / 4); rr = e.row % 4; nlan = 16; }
+        } else if (e.l == 0) {
+            img = A->w0_off + e.row * A->s0 + e.col;
+            if (fast & 2) { k = L.kw0 + m * 4 + e.col; lane = 16 * g; rr = r; nlan = 16; }
+            else { k = L.kw0 + m * nbi + e.col / 16; lane = 16 * g + e.col % 16; rr = r; nlan = 1; }
+        } else if (e.l < nl) {
+            img = A->wh_off + (e.l - 1) * A->hp * A->sh + e.row * A->sh + e.col;
+            k = L.kwh + ((e.l - 1) * nbh + m) * nbh + e.col / 16; lane = 16 * g + e.col % 16; rr = r; nlan = 1;
+        } else {
+            img = A->wo_off + e.row * A->sh + e.col;
+            if (fast & 1) { k = L.kwo + e.col / 16; lane = 16 * ((e.col % 16) / 4); rr = e.col % 4; nlan = 16; }
+            else { k = L.kwo + e.col / 16; lane = 16 * (e.row / 4) + e.col % 16; rr = e.row % 4; nlan = 1; }
         }
-        off += o;
-        in = o;
+        imap[e.canon] = img;
+        if (k < 0) { rmap[e.canon] = (L.na * 256 + 13) | (1 << 24); }
+        else { rmap[e.canon] = at(k, lane, rr) | (nlan << 24); cmap[cm(k, lane, rr)] = e.canon; }
     }
     for (int j = 0; j < d.n_params; ++j)
         if (d.param_kind[j] == EH_PAR_GLOBAL) rmap[n.g_off + d.param_index[j]] = (L.na * 256 + j) | (1 << 24);
@@ -406,9 +431,17 @@ static int build_rmap(eh_handle* h) {
     for (int t = 0; t < n.T; ++t) rmap[n.n_theta + 1 + t] = (L.na * 256 + 9 + t) | (1 << 24);
     rmap[n.n_theta + 1 + n.T] = (L.na * 256 + 14) | (1 << 24);
     rmap[n.n_theta + 2 + n.T] = (L.na * 256 + 15) | (1 << 24);
-    if (!h->rmap) HIPCHK(h, hipMalloc(&h->rmap, rmap.size() * sizeof(int)));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (with_imap) {
+        if (!h->imap) HIPCHK(h, hipMalloc(&h->imap, imap.size() * sizeof(int)));
+        HIPCHK(h, hipMemcpy(h->imap, imap.data(), imap.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (!h->rmap) HIPCHK(h, hipMalloc(&h->rmap, rmap.size() * sizeof(int)));
     HIPCHK(h, hipMemcpy(h->rmap, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice));
+    (void)hipFree(h->cmap);
+    h->cmap = nullptr;
+    HIPCHK(h, hipMalloc(&h->cmap, cmap.size() * sizeof(int)));
+    HIPCHK(h, hipMemcpy(h->cmap, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice));
     return EH_OK;
 }
 
@@ -468,10 +501,31 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     for (int i = 0; i < K; ++i) if (!seenK[i]) return fail(nullptr, EH_EINVAL, "eh_create: neural param_index values must be 0..K-1");
     for (int i = 0; i < G; ++i) if (!seenG[i]) return fail(nullptr, EH_EINVAL, "eh_create: global param_index values must be 0..G-1");
     if (K < 1) return fail(nullptr, EH_EINVAL, "eh_create: at least one neural parameter is required");
-    for (int l = 0; l < d->n_hidden; ++l) {
-        if (d->hidden[l] < 1) return fail(nullptr, EH_EINVAL, "eh_create: hidden[%d] = %d", l, d->hidden[l]);
-        maxw = std::max(maxw, d->hidden[l]);
+    // nets and their block placement (SingleNN = one net with K outputs)
+    const int nl = d->n_hidden;
+    int n_nets = 1, net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0}, net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}}, tot_w[EH_MAX_HIDDEN] = {0};
+    if (d->n_nets < 0 || d->n_nets > EH_MAX_NETS) return fail(nullptr, EH_EINVAL, "eh_create: n_nets = %d (0..%d)", d->n_nets, EH_MAX_NETS);
+    if (d->n_nets > 0) {
+        if (d->n_nets != K) return fail(nullptr, EH_EINVAL, "eh_create: MultiNN needs one net per neural parameter (%d nets, %d neural parameters)", d->n_nets, K);
+        n_nets = d->n_nets;
+        int ptot = 0;
+        for (int k = 0; k < n_nets; ++k) {
+            if (d->net_n_predictors[k] < 1) return fail(nullptr, EH_EINVAL, "eh_create: net %d has no predictors", k);
+            net_P[k] = d->net_n_predictors[k]; net_K[k] = 1; ptot += net_P[k];
+            for (int l = 0; l < nl; ++l) {
+                if (d->net_hidden[k][l] < 1) return fail(nullptr, EH_EINVAL, "eh_create: net_hidden[%d][%d] = %d", k, l, d->net_hidden[k][l]);
+                net_w[k][l] = d->net_hidden[k][l]; tot_w[l] += net_w[k][l];
+            }
+        }
+        if (ptot != d->n_predictors) return fail(nullptr, EH_EINVAL, "eh_create: net_n_predictors sum to %d, n_predictors = %d", ptot, d->n_predictors);
+    } else {
+        net_P[0] = d->n_predictors; net_K[0] = K;
+        for (int l = 0; l < nl; ++l) {
+            if (d->hidden[l] < 1) return fail(nullptr, EH_EINVAL, "eh_create: hidden[%d] = %d", l, d->hidden[l]);
+            net_w[0][l] = d->hidden[l]; tot_w[l] = d->hidden[l];
+        }
     }
+    for (int l = 0; l < nl; ++l) maxw = std::max(maxw, tot_w[l]);
     for (int f = 0; f < mi.n_forc; ++f)
         if (d->forcing_index[f] < 0 || d->forcing_index[f] >= d->n_forcings) return fail(nullptr, EH_EINVAL, "eh_create: forcing_index[%d] out of range", f);
     for (int t = 0; t < d->n_targets; ++t)
@@ -480,8 +534,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     const int nbh = nbh_raw <= 1 ? 1 : nbh_raw <= 2 ? 2 : nbh_raw <= 4 ? 4 : 0;
     const EhArchInfo* arch = (nbh && K <= 16) ? find_arch(nbi, nbh, d->n_hidden) : nullptr;
     if (!arch)
-        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no compiled kernel for P=%d, hidden max width %d, %d hidden layers, K=%d (built: P<=32, width<=64, <=3 layers, K<=16)",
-                    d->n_predictors, maxw, d->n_hidden, K);
+        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no compiled kernel for P=%d, hidden max width %d%s, %d hidden layers, K=%d (built: P<=32, width<=64, <=3 layers, K<=16)",
+                    d->n_predictors, maxw, d->n_nets > 0 ? " (nets side by side)" : "", d->n_hidden, K);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, EH_EHIP, "eh_create: no HIP device (this library has no CPU path)");
@@ -495,13 +549,28 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     EhNet& n = h->net;
     memset(&n, 0, sizeof n);
     n.P = d->n_predictors; n.K = K; n.G = G; n.T = d->n_targets; n.F = d->n_forcings;
-    int lw_off[EH_MAX_HIDDEN + 1], lb_off[EH_MAX_HIDDEN + 1];
-    int off = 0, in = n.P;
-    for (int l = 0; l <= d->n_hidden; ++l) {
-        const int o = l < d->n_hidden ? d->hidden[l] : K;
-        lw_off[l] = off; off += o * in;
-        lb_off[l] = off; off += o;
-        in = o;
+    h->n_nets = n_nets;
+    {
+        int c0 = 0, r0[EH_MAX_HIDDEN] = {0};
+        for (int k = 0; k < n_nets; ++k) {
+            h->net_P[k] = net_P[k]; h->net_K[k] = net_K[k]; h->net_c0[k] = c0; c0 += net_P[k];
+            for (int l = 0; l < nl; ++l) { h->net_w[k][l] = net_w[k][l]; h->net_r0[k][l] = r0[l]; r0[l] += net_w[k][l]; }
+            h->net_r0[k][nl] = d->n_nets > 0 ? k : 0;            // output row
+        }
+        for (int l = 0; l < nl; ++l) h->tot_w[l] = tot_w[l];
+    }
+    int lw_off[EH_MAX_HIDDEN + 1], lb_off[EH_MAX_HIDDEN + 1];     // canonical offsets of net 0 (all there is for SingleNN)
+    int off = 0;
+    for (int k = 0; k < n_nets; ++k) {
+        int in = net_P[k];
+        for (int l = 0; l <= nl; ++l) {
+            const int o = l < nl ? net_w[k][l] : net_K[k];
+            if (k == 0) lw_off[l] = off;
+            off += o * in;
+            if (k == 0) lb_off[l] = off;
+            off += o;
+            in = o;
+        }
     }
     n.g_off = off;
     n.n_theta = off + G;
@@ -556,22 +625,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
-    {   // parameter image: canonical index -> padded LDS-layout offset
-        std::vector<int> imap(nt, -1);
-        int inl = n.P;
-        for (int l = 0; l <= d->n_hidden; ++l) {
-            const int o = l < d->n_hidden ? d->hidden[l] : K;
-            for (int col = 0; col < inl; ++col)
-                for (int row = 0; row < o; ++row) {
-                    int off;
-                    if (l == 0) off = arch->w0_off + row * arch->s0 + col;
-                    else if (l < d->n_hidden) off = arch->wh_off + (l - 1) * arch->hp * arch->sh + row * arch->sh + col;
-                    else off = arch->wo_off + row * arch->sh + col;
-                    imap[lw_off[l] + row + o * col] = off;
-                }
-            for (int row = 0; row < o; ++row) imap[lb_off[l] + row] = arch->b_off + l * arch->hp + row;
-            inl = o;
-        }
+    if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; }
+    {   // parameter image (constant parts; theta is mirrored into it by eh_image_kernel / the optimiser)
         std::vector<float> img0((size_t)arch->img_floats, 0.0f);
         for (int j = 0; j < d->n_params; ++j) {
             if (d->param_kind[j] == EH_PAR_FIXED) img0[arch->phi_off + EH_IMG_PHI + j] = d->param_default[j];   // st.fixed, GenericHybridModel.jl:289-303
@@ -581,13 +636,11 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         for (int p = 0; p < 32; ++p) { img0[arch->phi_off + EH_IMG_BNM + p] = 0.0f; img0[arch->phi_off + EH_IMG_BNR + p] = d->input_batchnorm ? 1.0f / std::sqrt(1.0f + EH_BN_EPS) : 1.0f; }
         auto put_int = [&](int slot, int v) { memcpy(&img0[arch->phi_off + slot], &v, sizeof(int)); };
         for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
-        for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, d->hidden[l]);
+        for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, tot_w[l]);
         for (int j = 0; j < d->n_params; ++j)
             if (d->param_kind[j] == EH_PAR_GLOBAL) put_int(EH_IMG_GPAR + d->param_index[j], j);
         HIPCHK_C(hipMalloc(&h->image, img0.size() * sizeof(float)));
-        HIPCHK_C(hipMalloc(&h->imap, nt * sizeof(int)));
         HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
-        HIPCHK_C(hipMemcpy(h->imap, imap.data(), nt * sizeof(int), hipMemcpyHostToDevice));
         EhImg& im = h->img;
         im.image = h->image; im.imap = h->imap; im.g_off = n.g_off; im.phi_off = arch->phi_off;
         for (int j = 0; j < d->n_params; ++j)
@@ -600,7 +653,6 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipStreamSynchronize(h->stream));
     }
 #undef HIPCHK_C
-    if (int rc = build_rmap(h)) { g_create_err = h->err; eh_destroy(h); return rc; }
     *out = h;
     return EH_OK;
 }
@@ -613,7 +665,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
+    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -652,7 +704,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->fast = value ? (want & (int)value) : 0;
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
-        return build_rmap(h);
+        return build_maps(h, false);
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
@@ -785,7 +837,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
     a.inv_n = net.T > 1 ? h->inv_n : nullptr;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
-    a.rmap = h->rmap;
+    a.rmap = h->rmap; a.cmap = h->cmap;
     a.stamps = h->stamps;
     a.fz.gacc = nullptr;
     if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &a)) return rc;
@@ -805,7 +857,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     }
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
-    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;
+    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.cmap = h->cmap; a.stamps = h->stamps;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;

@@ -120,6 +120,7 @@ struct EhStepArgs {
     const float* inv_n;   // train: per-target 1/n_t (device) or nullptr = deferred normalisation (weight 1)
     float* yhat;          // eval (optional): [T][yld] predictions for samples first..first+count
     const int* rmap;      // train: canonical index -> (position | lanes<<24) in the v2 reduction region
+    const int* cmap;      // train: [accumulator k][lane][r] -> canonical index or -1 (reduction of the wide shapes)
     float* pout;          // eval (optional): [n_par][yld] physical parameters per sample
     long long yld;
     float shift[EH_MAX_TARG];   // eval: metric shift c_t
@@ -1009,70 +1010,38 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         for (int j = 0; j < EH_MAX_PARAMS; ++j)
             if (j < net.n_par) gacc[j] = eh_wave_sum(gacc[j]) * gscale[j];
         EH_STAMP(11);
-        const int out0 = width[0];
+        // scatter the accumulators into the wave's canonical-order region through the host-built map
+        // (handles padding, bias rows and the block-diagonal MultiNN placement alike)
+        struct I4 { int x, y, z, w; };
+        const I4* const cm = reinterpret_cast<const I4*>(a.cmap);
+        auto putc = [&](int k, const f32x4& v) {
+            const I4 ix = cm[k * 64 + lane];
+            if (ix.x >= 0) RED[ix.x] = v[0];
+            if (ix.y >= 0) RED[ix.y] = v[1];
+            if (ix.z >= 0) RED[ix.z] = v[2];
+            if (ix.w >= 0) RED[ix.w] = v[3];
+        };
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
             if constexpr (PS) {
-                if (c == 0) {
 #pragma unroll
-                    for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * m + 4 * g + r;
-                            if (row < out0 && pp < net.P) RED[w_off[0] + row + out0 * pp] = aW0V[m][pp][r];
-                        }
-                }
+                for (int pp = 0; pp < 4; ++pp) putc(AL.kw0 + m * 4 + pp, aW0V[m][pp]);
             } else {
 #pragma unroll
-                for (int n = 0; n < NBI; ++n)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * m + 4 * g + r, col = 16 * n + c;
-                        if (row < out0 && col < net.P) RED[w_off[0] + row + out0 * col] = aW0[m][n][r];
-                    }
+                for (int n = 0; n < NBI; ++n) putc(AL.kw0 + m * NBI + n, aW0[m][n]);
             }
 #pragma unroll
-            for (int l = 1; l < NL; ++l) {
-                const int outl = width[l], inl = width[l - 1];
+            for (int l = 0; l < NL - 1; ++l)
 #pragma unroll
-                for (int n = 0; n < NBH; ++n)
+                for (int n = 0; n < NBH; ++n) putc(AL.kwh + (l * NBH + m) * NBH + n, aWh[l][m][n]);
+            if constexpr (K1) putc(AL.kwo + m, aWoV[m]); else putc(AL.kwo + m, aWo[m]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * m + 4 * g + r, col = 16 * n + c;
-                        if (row < outl && col < inl) RED[w_off[l] + row + outl * col] = aWh[l - 1][m][n][r];
-                    }
-            }
-            if constexpr (K1) {
-                if (c == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = 16 * m + 4 * g + r;
-                        if (col < width[NL - 1]) RED[w_off[NL] + col] = aWoV[m][r];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * g + r, col = 16 * m + c;
-                    if (row < net.K && col < width[NL - 1]) RED[w_off[NL] + row + net.K * col] = aWo[m][r];
-                }
-            }
-            if (c == 0) {
-#pragma unroll
-                for (int l = 0; l < NL; ++l)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * m + 4 * g + r;
-                        if (row < width[l]) RED[b_off[l] + row] = aB[l][m][r];
-                    }
-            }
+            for (int l = 0; l < NL; ++l) putc(AL.kb + l * NBH + m, aB[l][m]);
         }
         if constexpr (K1) {
             if (lane == 0) RED[b_off[NL]] = aBoS;
-        } else if (c == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * g + r < net.K) RED[b_off[NL] + 4 * g + r] = aBo[r];
+        } else {
+            putc(AL.kbo, aBo);
         }
         if (lane == 0) {
 #pragma unroll

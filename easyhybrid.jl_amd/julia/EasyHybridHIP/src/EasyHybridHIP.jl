@@ -41,6 +41,9 @@ struct EhModelDesc
     forcing_index::NTuple{4, Int32}
     n_targets::Int32
     target_output::NTuple{4, Int32}
+    n_nets::Int32                                   # 0 = SingleNNHybridModel
+    net_n_predictors::NTuple{8, Int32}
+    net_hidden::NTuple{32, Int32}                   # [8 nets][4 layers], row-major like the C array
 end
 
 struct EhTargetMetrics
@@ -126,7 +129,8 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         ACT[m.config.activation], m.scale_nn_outputs, m.config.input_batchnorm, ms.id, length(ms.params),
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
-        length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32))
+        length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32),
+        Int32(0), pad(Int32[], 8, Int32), pad(Int32[], 32, Int32))       # MultiNN form: fill n_nets / net_* (see include/easyhybrid_hip.h)
 end
 
 # ------------------------------------------------------------------------------------------------

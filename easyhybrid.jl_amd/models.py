@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Sequence, Tuple, Union
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -186,6 +186,9 @@ class SingleNNHybridModel:
     scale_nn_outputs: bool
     start_from_default: bool
     config: dict = field(default_factory=dict)
+    # MultiNNHybridModel: NNs[name] = Dense shapes of the single-output net predicting `name`, predictor_sets[name] = its columns
+    NNs: Optional[Dict[str, List[Tuple[int, int]]]] = None
+    predictor_sets: Optional[Dict[str, List[str]]] = None
 
     # -- sizes ---------------------------------------------------------------------------------
     @property
@@ -193,8 +196,12 @@ class SingleNNHybridModel:
         return [o for o, _ in self.NN[:-1]]
 
     @property
+    def nets(self) -> List[List[Tuple[int, int]]]:
+        return [self.NN] if self.NNs is None else [self.NNs[k] for k in self.neural_param_names]
+
+    @property
     def n_nn(self) -> int:
-        return sum(o * i + o for o, i in self.NN)
+        return sum(o * i + o for net in self.nets for o, i in net)
 
     @property
     def n_theta(self) -> int:
@@ -211,11 +218,12 @@ class SingleNNHybridModel:
         U(+-1/sqrt(fan_in)).  NumPy's stream, not Julia's Xoshiro -- parity tests inject theta."""
         rng = np.random.default_rng(rng) if not isinstance(rng, np.random.Generator) else rng
         parts = []
-        for li, (o, i) in enumerate(self.NN):
-            gain = _ACT_GAIN[self.activation] if li < len(self.NN) - 1 else 1.0
-            bw = gain * math.sqrt(3.0 / i)
-            parts.append(rng.uniform(-bw, bw, (o, i)).astype(np.float32).flatten(order="F"))
-            parts.append(rng.uniform(-1 / math.sqrt(i), 1 / math.sqrt(i), o).astype(np.float32))
+        for net in self.nets:
+            for li, (o, i) in enumerate(net):
+                gain = _ACT_GAIN[self.activation] if li < len(net) - 1 else 1.0
+                bw = gain * math.sqrt(3.0 / i)
+                parts.append(rng.uniform(-bw, bw, (o, i)).astype(np.float32).flatten(order="F"))
+                parts.append(rng.uniform(-1 / math.sqrt(i), 1 / math.sqrt(i), o).astype(np.float32))
         for g in self.global_param_names:
             if self.start_from_default:
                 parts.append(np.asarray([scale_single_param_minmax(g, self.parameters)], np.float32))
@@ -225,12 +233,16 @@ class SingleNNHybridModel:
 
     def unpack(self, theta: np.ndarray):
         """flat theta -> (ps = [(weight (out,in), bias)...], {global: raw})"""
-        off, layers = 0, []
-        for o, i in self.NN:
-            W = theta[off:off + o * i].reshape((o, i), order="F"); off += o * i
-            b = theta[off:off + o]; off += o
-            layers.append((W, b))
-        return layers, {g: theta[off + j:off + j + 1] for j, g in enumerate(self.global_param_names)}
+        off, nets = 0, []
+        for net in self.nets:
+            layers = []
+            for o, i in net:
+                W = theta[off:off + o * i].reshape((o, i), order="F"); off += o * i
+                b = theta[off:off + o]; off += o
+                layers.append((W, b))
+            nets.append(layers)
+        glob = {g: theta[off + j:off + j + 1] for j, g in enumerate(self.global_param_names)}
+        return (nets[0] if self.NNs is None else dict(zip(self.neural_param_names, nets))), glob
 
     # -- C descriptor ----------------------------------------------------------------------------
     def to_desc(self, device: int = 0) -> L.ModelDesc:
@@ -245,6 +257,15 @@ class SingleNNHybridModel:
         d.n_hidden = len(hl)
         for k, w in enumerate(hl):
             d.hidden[k] = w
+        if self.NNs is not None:
+            if len(self.NNs) > L.EH_MAX_NETS:
+                raise NotImplementedError(f"{len(self.NNs)} neural networks (device limit {L.EH_MAX_NETS})")
+            d.n_nets = len(self.NNs)
+            for k, name in enumerate(self.neural_param_names):
+                net = self.NNs[name]
+                d.net_n_predictors[k] = net[0][1]
+                for l, (o, _) in enumerate(net[:-1]):
+                    d.net_hidden[k][l] = o
         d.activation = L.ACTIVATIONS[self.activation]
         d.scale_nn_outputs = int(self.scale_nn_outputs)
         d.input_batchnorm = int(bool(self.config.get("input_batchnorm", False)))
@@ -277,13 +298,69 @@ class SingleNNHybridModel:
 HybridModel = SingleNNHybridModel     # spelling used by BASELINE.json's north_star
 
 
-def constructHybridModel(predictors: Sequence[str], forcing: Sequence[str], targets: Sequence[str], mechanistic_model,
-                         parameters, neural_param_names: Sequence[str], global_param_names: Sequence[str], *,
+def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mechanistic_model, parameters, global_param_names, *,
+                     hidden_layers, activation, scale_nn_outputs, input_batchnorm, start_from_default, **kwargs):
+    """MultiNNHybridModel: one single-output MLP per key of `predictors` (= neural parameter) on its own predictor set."""
+    ms = resolve_mech(mechanistic_model)
+    parameters = build_parameters(parameters, mechanistic_model)
+    all_names = parameters.names()
+    neural = list(predictors)
+    glob = list(global_param_names or [])
+    if not all(n in all_names for n in neural):
+        raise AssertionError("neural_param_names ⊆ param_names")
+    if isinstance(activation, dict):
+        acts = {_act_name(a) for a in activation.values()}
+        if len(acts) != 1:
+            raise NotImplementedError("per-network activations are not built: the fused kernel has one activation")
+        act = acts.pop()
+    else:
+        act = _act_name(activation)
+    hl = {k: list(hidden_layers[k]) for k in neural} if isinstance(hidden_layers, dict) else {k: list(hidden_layers) for k in neural}
+    if len({len(v) for v in hl.values()}) != 1:
+        raise NotImplementedError("networks with different numbers of hidden layers are not built")
+    for p in ms.params:
+        if p not in all_names:
+            raise ValueError(f"mechanistic model {ms.name} needs parameter {p!r}; the table has {all_names}")
+    forcing, targets = list(forcing), list(targets)
+    for f in ms.forcings:
+        if f not in forcing:
+            raise ValueError(f"mechanistic model {ms.name} needs forcing {f!r}; got {forcing}")
+    for t in targets:
+        if t not in ms.outputs:
+            raise ValueError(f"target {t!r} is not an output of {ms.name} {ms.outputs}")
+    NNs, flat_pred = {}, []
+    for k in neural:
+        preds = list(predictors[k])
+        if not preds:
+            raise NotImplementedError("a network without predictors")
+        dims = [len(preds)] + [int(w) for w in hl[k]] + [1]
+        NNs[k] = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+        flat_pred += preds                                   # the per-net predictor matrices stacked row-wise
+    nl = len(next(iter(hl.values())))
+    tot = [sum(hl[k][l] for k in neural) for l in range(nl)]
+    NN = [(a, b) for a, b in zip(tot + [len(neural)], [len(flat_pred)] + tot)]     # the block-diagonal envelope
+    fixed = [n for n in all_names if n not in neural and n not in glob]
+    config = dict(hidden_layers=hidden_layers, activation=act, scale_nn_outputs=scale_nn_outputs, input_batchnorm=input_batchnorm,
+                  start_from_default=start_from_default, **kwargs)
+    return SingleNNHybridModel(NN, flat_pred, forcing, targets, ms, parameters, neural, glob, fixed, bool(scale_nn_outputs),
+                               bool(start_from_default), config, NNs=NNs, predictor_sets={k: list(v) for k, v in predictors.items()})
+
+
+MultiNNHybridModel = SingleNNHybridModel      # one class serves both; `.NNs is not None` marks the multi-network form
+
+
+def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[str], mechanistic_model,
+                         parameters, neural_param_names: Sequence[str] = None, global_param_names: Sequence[str] = None, *,
                          hidden_layers: Sequence[int] = (32, 32), activation="tanh", scale_nn_outputs: bool = False,
                          input_batchnorm: bool = False, start_from_default: bool = True, **kwargs) -> SingleNNHybridModel:
     """GenericHybridModel.jl:89-140 (Vector{Symbol} predictors form)."""
     if isinstance(predictors, dict):
-        raise NotImplementedError("MultiNNHybridModel (NamedTuple predictors) is not built yet (SURVEY.md section 8f rank 4)")
+        # NamedTuple-predictors form (GenericHybridModel.jl:142-206): here `neural_param_names` is the reference's
+        # `global_param_names` argument position; accept both call shapes
+        return _construct_multi(predictors, forcing, targets, mechanistic_model, parameters,
+                                global_param_names if global_param_names is not None else neural_param_names,
+                                hidden_layers=hidden_layers, activation=activation, scale_nn_outputs=scale_nn_outputs,
+                                input_batchnorm=input_batchnorm, start_from_default=start_from_default, **kwargs)
     ms = resolve_mech(mechanistic_model)
     parameters = build_parameters(parameters, mechanistic_model)
     all_names = parameters.names()

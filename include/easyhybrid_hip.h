@@ -36,6 +36,7 @@ extern "C" {
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
 #define EH_MAX_TARG 4
+#define EH_MAX_NETS 8
 
 typedef enum eh_status {
     EH_OK = 0,
@@ -102,6 +103,14 @@ typedef struct eh_model_desc {
     int32_t forcing_index[EH_MAX_FORC];      /* per canonical forcing of the mech model: which of the F arrays feeds it */
     int32_t n_targets;                       /* T */
     int32_t target_output[EH_MAX_TARG];      /* per target: which output of the mech model it is compared with */
+    /* MultiNNHybridModel (src/models/GenericHybridModel.jl:142-206,458-530): n_nets >= 1 single-output MLPs, net k predicting
+     * the neural parameter with param_index k from its own predictors.  x passed to eh_set_data is then the per-net predictor
+     * matrices stacked row-wise (n_predictors = sum of net_n_predictors); every net has n_hidden hidden layers of
+     * net_hidden[k][.] units and the common activation; theta holds the nets one after the other.  The engine runs them as one
+     * block-diagonal MLP (the off-diagonal weights are structural zeros).  n_nets = 0: SingleNNHybridModel (hidden[] above). */
+    int32_t n_nets;
+    int32_t net_n_predictors[EH_MAX_NETS];
+    int32_t net_hidden[EH_MAX_NETS][EH_MAX_HIDDEN];
 } eh_model_desc;
 
 typedef struct eh_target_metrics {           /* src/losses/loss_fn.jl:58-179 on the valid samples of one target */

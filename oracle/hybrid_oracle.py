@@ -46,7 +46,7 @@ What each function follows in the reference (paths relative to /root/reference)
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -210,6 +210,9 @@ class HybridSpec:
     activation: str = "tanh"
     scale_nn_outputs: bool = False
     input_batchnorm: bool = False        # InputBatchNorm(in_dim, affine=false) in front of the chain (NNModels.jl:226)
+    # MultiNNHybridModel (GenericHybridModel.jl:142-206,458-530): one MLP with ONE output per neural parameter, each on
+    # its own predictor rows.  nets[k] = (rows of X feeding net k, hidden widths of net k); None = SingleNN.
+    nets: Optional[List[Tuple[List[int], List[int]]]] = None
 
     def __post_init__(self):
         mm = MECH[self.mech][0]
@@ -230,8 +233,19 @@ class HybridSpec:
         return [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]   # (out, in)
 
     @property
+    def net_list(self) -> List[Tuple[List[int], List[Tuple[int, int]]]]:
+        """[(predictor rows, [(out, in) per Dense layer])] -- one entry for SingleNN, one per neural parameter for MultiNN"""
+        if self.nets is None:
+            return [(list(range(self.n_pred)), self.layer_dims)]
+        out = []
+        for rows, hidden in self.nets:
+            dims = [len(rows)] + list(hidden) + [1]
+            out.append((list(rows), [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]))
+        return out
+
+    @property
     def n_nn(self) -> int:
-        return sum(o * i + o for o, i in self.layer_dims)
+        return sum(o * i + o for _, dims in self.net_list for o, i in dims)
 
     @property
     def n_theta(self) -> int:
@@ -255,21 +269,26 @@ def scale_single_param_minmax(default, lo, hi):
 
 
 def unpack(spec: HybridSpec, theta):
-    """flat theta -> ([(W (out,in), b (out,)), ...], raw globals).  Weights are Julia
-    column-major (out,in) inside the flat vector (ComponentArray of Lux Dense params)."""
-    Ws, off = [], 0
-    for o, i in spec.layer_dims:
-        W = theta[off:off + o * i].reshape((o, i), order="F"); off += o * i
-        b = theta[off:off + o]; off += o
-        Ws.append((W, b))
+    """flat theta -> ([[(W (out,in), b (out,)), ...] per net], raw globals).  Weights are Julia
+    column-major (out,in) inside the flat vector (ComponentArray of Lux Dense params); for a
+    MultiNN model the nets follow each other in neural_param_names order (GenericHybridModel.jl:259-287)."""
+    nets, off = [], 0
+    for _, dims in spec.net_list:
+        Ws = []
+        for o, i in dims:
+            W = theta[off:off + o * i].reshape((o, i), order="F"); off += o * i
+            b = theta[off:off + o]; off += o
+            Ws.append((W, b))
+        nets.append(Ws)
     raw = theta[off:off + len(spec.glob)]
-    return Ws, raw
+    return nets, raw
 
 
-def pack(spec: HybridSpec, Ws, raw, dtype=np.float64):
+def pack(spec: HybridSpec, nets, raw, dtype=np.float64):
     parts = []
-    for W, b in Ws:
-        parts += [np.asarray(W, dtype).flatten(order="F"), np.asarray(b, dtype)]
+    for Ws in nets:
+        for W, b in Ws:
+            parts += [np.asarray(W, dtype).flatten(order="F"), np.asarray(b, dtype)]
     parts.append(np.asarray(raw, dtype).reshape(-1))
     return np.concatenate(parts)
 
@@ -279,13 +298,16 @@ def init_theta(spec: HybridSpec, seed: int, dtype=np.float32):
     table default (start_from_default=true, GenericHybridModel.jl:244-249).  Lux's own initialiser
     and Julia's RNG stream are not reproducible here, so parity tests always inject theta."""
     rng = np.random.default_rng(seed)
-    Ws = []
-    for o, i in spec.layer_dims:
-        s = 1.0 / np.sqrt(i)
-        Ws.append((rng.uniform(-s, s, (o, i)), rng.uniform(-s, s, (o,))))
+    nets = []
+    for _, dims in spec.net_list:
+        Ws = []
+        for o, i in dims:
+            s = 1.0 / np.sqrt(i)
+            Ws.append((rng.uniform(-s, s, (o, i)), rng.uniform(-s, s, (o,))))
+        nets.append(Ws)
     raw = [scale_single_param_minmax(np.float32(spec.default(g)), np.float32(spec.lo(g)), np.float32(spec.hi(g)))
            for g in spec.glob]
-    return pack(spec, Ws, raw, dtype)
+    return pack(spec, nets, raw, dtype)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -331,19 +353,24 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
     bn_new = None
     if spec.input_batchnorm:
         X, bn_new = batchnorm_input(X, bn_state, train_mode, dt)
-    Ws, raw = unpack(spec, theta)
+    nets, raw = unpack(spec, theta)
     # k1: global params
     glob = {}
     for g, r in zip(spec.glob, raw):
         glob[g] = dt.type(spec.lo(g)) + dt.type(spec.hi(g) - spec.lo(g)) * _sigmoid(r.reshape(1))
-    # k2: MLP
-    h, zs, hs = X, [], [X]
-    for li, (W, b) in enumerate(Ws):
-        z = (W @ h + b[:, None]).astype(dt)
-        last = li == len(Ws) - 1
-        h = z if last else act_fwd(spec.activation, z).astype(dt)
-        zs.append(z); hs.append(h)
-    o = h                                                              # (K, B)
+    # k2: MLP(s): one chain for SingleNN, one single-output chain per neural parameter for MultiNN
+    tapes, outs = [], []
+    for (rows, _), Ws in zip(spec.net_list, nets):
+        h = X[rows]
+        zs, hs = [], [h]
+        for li, (W, b) in enumerate(Ws):
+            z = (W @ h + b[:, None]).astype(dt)
+            last = li == len(Ws) - 1
+            h = z if last else act_fwd(spec.activation, z).astype(dt)
+            zs.append(z); hs.append(h)
+        tapes.append((Ws, zs, hs))
+        outs.append(h)
+    o = np.concatenate(outs, axis=0)                                   # (K, B)
     # k3: optional sigmoid scaling of NN outputs
     nn = {}
     for k, n in enumerate(spec.neural):
@@ -359,7 +386,7 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
     res["parameters"] = par
     res["_bn"] = bn_new
     if keep:
-        res["_tape"] = dict(Ws=Ws, raw=raw, zs=zs, hs=hs, o=o, par=par, frc=frc, aux=aux, out=out)
+        res["_tape"] = dict(nets=tapes, raw=raw, o=o, par=par, frc=frc, aux=aux, out=out)
     return res
 
 
@@ -469,20 +496,21 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
             s = _sigmoid(tp["o"][k])
             d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
         do[k] = d
-    # MLP backward
-    gWs = []
-    delta = do
-    for li in reversed(range(len(tp["Ws"]))):
-        W, b = tp["Ws"][li]
-        hin = tp["hs"][li]
-        gW = delta @ hin.T
-        gb = delta.sum(axis=1)
-        gWs.append((gW, gb))
-        if li > 0:
-            dh = W.T @ delta
-            delta = dh * act_bwd(spec.activation, tp["zs"][li - 1], tp["hs"][li])
-    gWs.reverse()
-    grad = pack(spec, gWs, graw, dt)
+    # MLP backward (each net sees the rows of dO that belong to its outputs)
+    gnets, k0 = [], 0
+    for Ws, zs, hs in tp["nets"]:
+        kout = Ws[-1][0].shape[0]
+        delta = do[k0:k0 + kout]
+        k0 += kout
+        gWs = []
+        for li in reversed(range(len(Ws))):
+            W, b = Ws[li]
+            gWs.append((delta @ hs[li].T, delta.sum(axis=1)))
+            if li > 0:
+                delta = (W.T @ delta) * act_bwd(spec.activation, zs[li - 1], hs[li])
+        gWs.reverse()
+        gnets.append(gWs)
+    grad = pack(spec, gnets, graw, dt)
     return loss, grad, nvalid
 
 

@@ -51,14 +51,18 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
     h = torch.as_tensor(X, dtype=dt)
     if getattr(spec, "input_batchnorm", False):            # train-mode batch statistics, biased variance, eps = 1e-5
         h = (h - h.mean(dim=1, keepdim=True)) / torch.sqrt(h.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
-    nl = len(spec.layer_dims)
-    for li, (o, i) in enumerate(spec.layer_dims):
-        W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)
-        off += o * i
-        b = theta[off:off + o]
-        off += o
-        z = W @ h + b[:, None]
-        h = z if li == nl - 1 else _act(spec.activation, z)
+    X0, outs = h, []
+    for rows, dims in spec.net_list:
+        h = X0[rows]
+        for li, (o, i) in enumerate(dims):
+            W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)
+            off += o * i
+            b = theta[off:off + o]
+            off += o
+            z = W @ h + b[:, None]
+            h = z if li == len(dims) - 1 else _act(spec.activation, z)
+        outs.append(h)
+    h = torch.cat(outs, dim=0)
     par = {}
     for k, n in enumerate(spec.neural):
         par[n] = (spec.lo(n) + (spec.hi(n) - spec.lo(n)) * torch.sigmoid(h[k])) if spec.scale_nn_outputs else h[k]

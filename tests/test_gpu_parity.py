@@ -559,3 +559,37 @@ def test_readme_quickstart_configuration_trains():
     out = eh.train(model, cols, nepochs=8, batchsize=128, opt=eh.AdamW(0.01, (0.9, 0.999), 0.01), random_seed=3)
     assert out.val_history[-1]["mse"]["sum"] < 0.5 * out.val_history[0]["mse"]["sum"]
     assert out.st["st_nn"]["running_mean"][0] == pytest.approx(50.0, rel=0.1)
+
+
+# ----------------------------------------------------------------------------------------------
+# MultiNNHybridModel: one single-output MLP per neural parameter (GenericHybridModel.jl:142-206,458-530)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nets,glob", [
+    ([([0, 1], [16, 16]), ([1, 2], [8, 8])], []),                       # rb and Q10 both neural, overlapping predictor sets
+    ([([0, 1, 2], [16, 16])], ["Q10"]),                                 # a single network (ExpoHybridEstim.jl:34 style) + a global
+    ([([0], [24, 12]), ([1, 2, 3], [30, 20])], []),                     # unequal widths, 54 units side by side -> the 64-wide kernel
+])
+def test_multinn_hybrid_model(nets, glob):
+    neural = ["rb", "Q10"][: len(nets)]
+    spec = ho.HybridSpec(4, [1], "rbq10", dict(ho.RBQ10_PARAMS), neural, glob, ["reco"], "tanh", True, nets=nets)
+    rng = np.random.default_rng(5)
+    B = 700
+    X = rng.standard_normal((4, B)).astype(np.float32)
+    f = {"ta": rng.uniform(0, 30, B).astype(np.float32)}
+    yv = rng.uniform(1, 9, B).astype(np.float32); yv[rng.random(B) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 6, np.float32)
+    eng = util.load_engine(spec, theta, X, f, {"reco": yv})
+    assert eng.n_theta == spec.n_theta
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, {"reco": yv})
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 100, 100) for i in range(6)]
+    for b in batches:
+        eng.train_step(*b, want_loss=False)
+    th_ref, _ = ho.train_steps(spec, theta, X, f, {"reco": yv}, batches, dtype=np.float32)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    ref = ho.forward(spec, eng.get_params().astype(np.float64), X, f)
+    out = eng.forward(0)
+    assert util.relerr(out["reco"], ref["reco"]) <= TOL and util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= TOL
+    eng.close()

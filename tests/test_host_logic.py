@@ -90,3 +90,19 @@ def test_shard_ranges_cover_exactly():
         r = [dp.shard_range(n, k, w) for k in range(w)]
         assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
         assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_multinn_constructor_mirrors_reference():
+    # constructHybridModel(predictors::NamedTuple, forcing, targets, f, parameters, global_param_names; ...)  GenericHybridModel.jl:142-206
+    m = eh.constructHybridModel({"rb": ["sw_pot", "dsw_pot"], "Q10": ["dsw_pot"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [],
+                                hidden_layers={"rb": [16, 16], "Q10": [8, 4]}, activation="tanh")
+    assert m.neural_param_names == ["rb", "Q10"] and m.global_param_names == [] and m.predictors == ["sw_pot", "dsw_pot", "dsw_pot"]
+    assert m.NNs["rb"] == [(16, 2), (16, 16), (1, 16)] and m.NNs["Q10"] == [(8, 1), (4, 8), (1, 4)]
+    assert m.n_theta == (32 + 16 + 256 + 16 + 16 + 1) + (8 + 8 + 32 + 4 + 4 + 1)
+    d = m.to_desc()
+    assert d.n_nets == 2 and list(d.net_n_predictors)[:2] == [2, 1] and list(d.net_hidden[1])[:2] == [8, 4] and d.n_predictors == 3
+    th = m.initialparameters(0)
+    nets, glob = m.unpack(th)
+    assert th.size == m.n_theta and nets["Q10"][0][0].shape == (8, 1) and glob == {}
+    with pytest.raises(NotImplementedError):
+        eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [], hidden_layers={"rb": [16], "Q10": [8, 4]})

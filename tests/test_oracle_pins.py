@@ -73,7 +73,7 @@ def test_analytic_forward_theta_zero():
     y = {"reco": np.array([10.0, 7.0])}
     loss, grad, nv = ho.loss_and_grad(spec, theta, X, {"ta": np.array([25.0, 15.0])}, y)
     assert loss == pytest.approx(((13 - 10) ** 2 + (6.5 - 7) ** 2) / 2)
-    Ws, graw = ho.unpack(spec, grad)
+    (Ws,), graw = ho.unpack(spec, grad)
     assert np.all(Ws[2][0] == 0)                                       # dW3 = 0 (h2 = tanh(0) = 0)
     dy = 2 * np.array([3.0, -0.5]) / 2
     p = np.array([2.0, 1.0])
@@ -85,7 +85,7 @@ def test_flat_theta_layout():
     spec = ho.rbq10_spec((16, 16))
     assert spec.n_theta == 338 and spec.layer_dims == [(16, 2), (16, 16), (1, 16)]
     theta = np.arange(338, dtype=np.float64)
-    Ws, raw = ho.unpack(spec, theta)
+    (Ws,), raw = ho.unpack(spec, theta)
     assert Ws[0][0][3, 1] == 3 + 16 * 1 and Ws[0][1][0] == 32 and Ws[1][0][0, 0] == 48 and raw[0] == 337
 
 

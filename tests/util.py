@@ -10,6 +10,12 @@ MECH_NAME = {"rbq10": "RbQ10", "expo": "Expo_resp_model", "linear": "LinearHM", 
 
 def model_from_spec(spec: ho.HybridSpec):
     mm = ho.MECH[spec.mech][0]
+    if spec.nets is not None:
+        preds = {n: [f"x{i}" for i in rows] for n, (rows, _) in zip(spec.neural, spec.nets)}
+        hl = {n: list(h) for n, (_, h) in zip(spec.neural, spec.nets)}
+        return eh.constructHybridModel(preds, list(mm.forcings), list(spec.targets), MECH_NAME[spec.mech], dict(spec.parameters),
+                                       list(spec.glob), hidden_layers=hl, activation=spec.activation,
+                                       scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False))
     return eh.constructHybridModel([f"x{i}" for i in range(spec.n_pred)], list(mm.forcings), list(spec.targets),
                                    MECH_NAME[spec.mech], dict(spec.parameters), list(spec.neural), list(spec.glob),
                                    hidden_layers=list(spec.hidden), activation=spec.activation,
@@ -19,6 +25,8 @@ def model_from_spec(spec: ho.HybridSpec):
 def load_engine(spec, theta, X, forcings, targets, split=0, engine=None):
     mm = ho.MECH[spec.mech][0]
     eng = engine or model_from_spec(spec).engine()
+    if spec.nets is not None:                         # the per-net predictor matrices stacked row-wise
+        X = np.concatenate([X[rows] for rows, _ in spec.nets], axis=0)
     eng.set_data(split, X, [forcings[f] for f in mm.forcings], [targets[t] for t in spec.targets])
     eng.set_params(np.asarray(theta, np.float32))
     return eng
