@@ -453,6 +453,7 @@ static bool mech_info(int mech, MechInfo* mi) {
         case EH_MECH_LINEAR: *mi = {2, 1, 1}; return true;
         case EH_MECH_EXPO2POOL: *mi = {4, 1, 1}; return true;
         case EH_MECH_RS_COMPONENTS: *mi = {6, 1, 1}; return true;
+        case EH_MECH_FLUXPART: *mi = {3, 2, 3}; return true;
         default: return false;
     }
 }
@@ -583,6 +584,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     for (int j = d->n_params; j < EH_MAX_PARAMS; ++j) n.par_kind |= (unsigned)EH_PAR_FIXED << (2 * j);
     n.forc_col = 0xFFFFFFFFu;
     for (int f = 0; f < mi.n_forc; ++f) n.forc_col = (n.forc_col & ~(0xFFu << (8 * f))) | ((unsigned)d->forcing_index[f] << (8 * f));
+    n.n_out = mi.n_out;
+    for (int t = 0; t < d->n_targets; ++t) n.targ_out |= (unsigned)d->target_output[t] << (2 * t);
     h->fast = (arch->has_fast ? ((K == 1 ? 1 : 0) | ((K == 1 && n.P <= 4) ? 2 : 0)) : 0);
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;

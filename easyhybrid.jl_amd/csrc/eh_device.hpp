@@ -39,6 +39,8 @@ struct EhNet {
     int n_theta, g_off;              // n_nn + G ; offset of the raw global parameters in flat theta
     int scale_nn, mech, n_par;
     int loss;                        // eh_loss (training loss)
+    int n_out;                       // outputs of the mechanistic model
+    unsigned targ_out;               // 2 bits per target: which output it is compared with
     unsigned par_kind;               // 2 bits per canonical mech parameter: eh_param_kind
     unsigned par_idx;                // 4 bits per canonical mech parameter: NN output row / global index
     unsigned forc_col;               // 8 bits per canonical forcing: column among the F forcing columns (0xFF unused)
@@ -228,9 +230,30 @@ __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const 
                 dydp[c] = p; dydp[3 + c] = r * e * __builtin_amdgcn_rcpf(par[3 + c]);
             }
         } break;
+        case EH_MECH_FLUXPART: {    // output 0: NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:66-74
+            const float e = 0.1f * (frc[1] - 15.0f);
+            const float p = eh_pow(par[2], e);
+            const float gq = frc[0] * (1.0f / 12.011f);
+            const float reco = par[1] * p;
+            y = reco - gq * par[0];
+            dydp[0] = -gq; dydp[1] = p; dydp[2] = reco * e * __builtin_amdgcn_rcpf(par[2]);
+        } break;
         default: break;
     }
     return y;
+}
+
+// outputs 1.. of the multi-output models and their Jacobian rows (only FLUXPART: GPP, RECO)
+__device__ __forceinline__ void eh_mech_extra(int mech, const float* par, const float* frc, float* yx, float (*Jx)[3]) {
+    if (mech == EH_MECH_FLUXPART) {
+        const float e = 0.1f * (frc[1] - 15.0f);
+        const float p = eh_pow(par[2], e);
+        const float gq = frc[0] * (1.0f / 12.011f);
+        yx[0] = gq * par[0];                 // GPP
+        Jx[0][0] = gq; Jx[0][1] = 0.0f; Jx[0][2] = 0.0f;
+        yx[1] = par[1] * p;                  // RECO
+        Jx[1][0] = 0.0f; Jx[1][1] = p; Jx[1][2] = yx[1] * e * __builtin_amdgcn_rcpf(par[2]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,8 +361,14 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         oOff[j] = pidx(j) * SR;
         asm volatile("" : "+v"(kN[j]), "+v"(kG[j]), "+v"(oOff[j]));
     }
+    int tOut[EH_MAX_TARG];
 #pragma unroll
-    for (int t = 0; t < EH_MAX_TARG; ++t) { tOn[t] = t < net.T ? 1.0f : 0.0f; asm volatile("" : "+v"(tOn[t])); }
+    for (int t = 0; t < EH_MAX_TARG; ++t) {
+        tOn[t] = t < net.T ? 1.0f : 0.0f; tOut[t] = (int)((net.targ_out >> (2 * t)) & 3u);
+        asm volatile("" : "+v"(tOn[t]), "+v"(tOut[t]));
+    }
+    float multiOn = net.n_out > 1 ? 1.0f : 0.0f;
+    asm volatile("" : "+v"(multiOn));
 #pragma unroll
     for (int f = 0; f < EH_MAX_FORC; ++f) {
         const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
@@ -661,18 +690,23 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                     }
                 }
             }
-            const float y = eh_mech_eval(net.mech, par, frc, dydp);
-            float dy = 0.0f;
+            const float y0 = eh_mech_eval(net.mech, par, frc, dydp);
+            float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            if (multiOn != 0.0f) eh_mech_extra(net.mech, par, frc, yx, Jx);
+            float dy = 0.0f, dyx[2] = {0.0f, 0.0f};          // d loss / d output 0, outputs 1..2
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t) {
                 if (tOn[t] != 0.0f) {
+                    const float y = tOut[t] == 0 ? y0 : (tOut[t] == 1 ? yx[0] : yx[1]);
                     const bool valid = live && !__builtin_isnan(yobs[t]);
                     const float r = valid ? y - yobs[t] : 0.0f;
                     if constexpr (TRAIN) {
                         const float w = a.inv_n ? a.inv_n[t] : 1.0f;
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
-                        if (maeOn != 0.0f) { lacc += w * fabsf(r); dy += r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
-                        else { lacc += w * r * r; dy += 2.0f * w * r; }
+                        float d;
+                        if (maeOn != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                        else { lacc += w * r * r; d = 2.0f * w * r; }
+                        dy += tOut[t] == 0 ? d : 0.0f; dyx[0] += tOut[t] == 1 ? d : 0.0f; dyx[1] += tOut[t] == 2 ? d : 0.0f;
                         cacc[t] += valid ? 1.0f : 0.0f;
                         syacc += cy; syyacc += cy * cy;
                     } else if (valid) {
@@ -685,7 +719,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             if constexpr (!TRAIN) {
                 if (live) {
                     if (a.yhat)
-                        for (int t = 0; t < net.T; ++t) a.yhat[(long long)t * a.yld + n_loc] = y;
+                        for (int t = 0; t < net.T; ++t) {
+                            const int o = (int)((net.targ_out >> (2 * t)) & 3u);
+                            a.yhat[(long long)t * a.yld + n_loc] = o == 0 ? y0 : (o == 1 ? yx[0] : yx[1]);
+                        }
                     if (a.pout)
                         for (int j = 0; j < net.n_par; ++j) a.pout[(long long)j * a.yld + n_loc] = par[j];
                 }
@@ -693,7 +730,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             }
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
-                const float dp = live ? dy * dydp[j] : 0.0f;
+                float dp = dy * dydp[j];
+                if (j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];     // zero for the single-output models
+                dp = live ? dp : 0.0f;
                 if (kN[j] != 0.0f) {
                     if constexpr (K1) dOm = dp * sg[j];
                     else if (lane < MT) OS[oOff[j] + lane] = dp * sg[j];

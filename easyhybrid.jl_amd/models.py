@@ -45,6 +45,7 @@ MECH_REGISTRY: Dict[str, MechSpec] = {
     "Expo2Pool": MechSpec(3, "Expo2Pool", ("R0a", "ka", "R0b", "kb"), ("T",), ("Resp_obs",)),
     "Rs_components": MechSpec(4, "Rs_components", ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
                               ("ta",), ("R_soil",)),
+    "FluxPartModelQ10": MechSpec(5, "FluxPartModelQ10", ("RUE", "Rb", "Q10"), ("SW_IN", "TA"), ("NEE", "GPP", "RECO")),
 }
 
 
@@ -82,6 +83,12 @@ def Expo2Pool(*, T, R0a, ka, R0b, kb):
 @_tag("Rs_components")
 def Rs_components(*, ta, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc):
     """src/models/Rs_components.jl:40-57"""
+    raise NotImplementedError("registry tag")
+
+
+@_tag("FluxPartModelQ10")
+def FluxPartModelQ10(*, SW_IN, TA, RUE, Rb, Q10):
+    """src/models/FluxPartModel_Q10_Lux.jl:50-79: GPP = SW_IN*RUE/12.011, RECO = Rb*Q10^(0.1(TA-15)), NEE = RECO - GPP"""
     raise NotImplementedError("registry tag")
 
 

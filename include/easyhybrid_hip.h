@@ -63,8 +63,10 @@ typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 
  *                                                  (build-defined 4-parameter model of BASELINE.json config 3)
  *   RS_COMPONENTS  params (Rb_het,Rb_root,Rb_myc,Q10_het,Q10_root,Q10_myc) forcing (ta) output (R_soil)
  *                                                  src/models/Rs_components.jl:40-57
+ *   FLUXPART       params (RUE, Rb, Q10)          forcings (SW_IN, TA)  outputs (NEE, GPP, RECO)
+ *                  GPP = SW_IN*RUE/12.011, RECO = Rb*Q10^(0.1(TA-15)), NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:50-79
  */
-typedef enum eh_mech { EH_MECH_RBQ10 = 0, EH_MECH_EXPO = 1, EH_MECH_LINEAR = 2, EH_MECH_EXPO2POOL = 3, EH_MECH_RS_COMPONENTS = 4 } eh_mech;
+typedef enum eh_mech { EH_MECH_RBQ10 = 0, EH_MECH_EXPO = 1, EH_MECH_LINEAR = 2, EH_MECH_EXPO2POOL = 3, EH_MECH_RS_COMPONENTS = 4, EH_MECH_FLUXPART = 5 } eh_mech;
 
 /* where a mechanistic parameter comes from (neural_param_names / global_param_names / the rest,
  * src/models/GenericHybridModel.jl:96-97,127) */

@@ -15,7 +15,7 @@ SO = os.path.join(HERE, "libeh_oracle.so")
 SRC = os.path.join(HERE, "eh_oracle.c")
 
 ACT = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
-MECH = {"rbq10": 0, "expo": 1, "linear": 2, "expo2pool": 3, "rs_components": 4}
+MECH = {"rbq10": 0, "expo": 1, "linear": 2, "expo2pool": 3, "rs_components": 4}     # single-output models only
 
 
 class Spec(C.Structure):

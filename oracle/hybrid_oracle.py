@@ -181,6 +181,21 @@ def _rs_vjp(par, frc, out, aux, dout, dt):
     return g
 
 
+def _fluxpart_fwd(par, frc, dt):
+    # GPP = sw_in .* RUE ./ 12.011f0 ; RECO = Rb .* Q10 .^ (0.1f0 .* (ta .- 15f0)) ; NEE = RECO .- GPP   (FluxPartModel_Q10_Lux.jl:66-74)
+    e = dt.type(0.1) * (frc["TA"] - dt.type(15.0))
+    p = np.power(par["Q10"], e)
+    gpp = frc["SW_IN"] * par["RUE"] / dt.type(12.011)
+    reco = par["Rb"] * p
+    return {"NEE": reco - gpp, "GPP": gpp, "RECO": reco}, {"e": e, "p": p}
+
+
+def _fluxpart_vjp(par, frc, out, aux, dout, dt):
+    dr = dout["RECO"] + dout["NEE"]
+    dg = dout["GPP"] - dout["NEE"]
+    return {"RUE": dg * frc["SW_IN"] / dt.type(12.011), "Rb": dr * aux["p"], "Q10": dr * out["RECO"] * aux["e"] / par["Q10"]}
+
+
 MECH: Dict[str, Tuple[MechModel, callable, callable]] = {
     "rbq10": (MechModel("rbq10", ("rb", "Q10"), ("ta",), ("reco",)), _rbq10_fwd, _rbq10_vjp),
     "expo": (MechModel("expo", ("Resp0", "k"), ("T",), ("Resp_obs",)), _expo_fwd, _expo_vjp),
@@ -190,6 +205,7 @@ MECH: Dict[str, Tuple[MechModel, callable, callable]] = {
     "rs_components": (MechModel("rs_components",
                                 ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
                                 ("ta",), ("R_soil",)), _rs_fwd, _rs_vjp),
+    "fluxpart": (MechModel("fluxpart", ("RUE", "Rb", "Q10"), ("SW_IN", "TA"), ("NEE", "GPP", "RECO")), _fluxpart_fwd, _fluxpart_vjp),
 }
 
 

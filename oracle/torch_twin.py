@@ -42,6 +42,10 @@ def _mech(spec, par, frc):
     if m == "rs_components":
         e = 0.1 * (frc["ta"] - 15.0)
         return {"R_soil": sum(par[f"Rb_{c}"] * par[f"Q10_{c}"] ** e for c in ("het", "root", "myc"))}
+    if m == "fluxpart":
+        gpp = frc["SW_IN"] * par["RUE"] / 12.011
+        reco = par["Rb"] * par["Q10"] ** (0.1 * (frc["TA"] - 15.0))
+        return {"NEE": reco - gpp, "GPP": gpp, "RECO": reco}
     raise ValueError(m)
 
 

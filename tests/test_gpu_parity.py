@@ -593,3 +593,59 @@ def test_multinn_hybrid_model(nets, glob):
     out = eng.forward(0)
     assert util.relerr(out["reco"], ref["reco"]) <= TOL and util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= TOL
     eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-target losses through the multi-output FluxPart model (compute_loss.jl:50-53,115-126: L = sum_t mean_t)
+# ----------------------------------------------------------------------------------------------
+FLUX_PARAMS = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+
+
+def _flux_data(B, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((4, B)).astype(np.float32)
+    f = {"SW_IN": rng.uniform(0, 800, B).astype(np.float32), "TA": rng.uniform(0, 30, B).astype(np.float32)}
+    nee = rng.normal(-3, 4, B).astype(np.float32); reco = rng.uniform(1, 8, B).astype(np.float32); gpp = rng.uniform(0, 12, B).astype(np.float32)
+    nee[rng.random(B) < 0.2] = np.nan; reco[rng.random(B) < 0.35] = np.nan          # every target has its own mask and n_t
+    return X, f, {"NEE": nee, "RECO": reco, "GPP": gpp}
+
+
+@pytest.mark.parametrize("targets,nets", [
+    (["NEE"], None),
+    (["NEE", "RECO"], [([0, 1], [16, 16]), ([2, 3], [16, 16])]),      # the reference's layout: an RUE net and an Rb net (FluxPartModel_Q10_Lux.jl)
+    (["RECO", "GPP", "NEE"], None),
+])
+def test_fluxpart_multi_target(targets, nets):
+    B = 900
+    X, f, y = _flux_data(B)
+    spec = ho.HybridSpec(4, [16, 16], "fluxpart", dict(FLUX_PARAMS), ["RUE", "Rb"], ["Q10"], targets, "tanh", True, nets=nets)
+    theta = ho.init_theta(spec, 2, np.float32)
+    yt = {t: y[t] for t in targets}
+    eng = util.load_engine(spec, theta, X, f, yt)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, yt)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    out = eng.forward(0, params=False)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    for t in targets:
+        assert util.relerr(out[t], ref[t]) <= TOL
+    m, _ = eng.eval(0)
+    for i, t in enumerate(targets):
+        yy = yt[t].astype(np.float64)
+        assert m[i]["mse"] == pytest.approx(ho.loss_fn(ref[t], yy, ~np.isnan(yy), "mse"), rel=3e-5)
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 150, 150) for i in range(6)]
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, yt, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    if len(targets) > 1:
+        with pytest.raises(NotImplementedError):
+            eng.set_option("fused_update", 1)
+        yt2 = dict(yt); yt2[targets[0]] = np.full(B, np.nan, np.float32)          # one target entirely missing: it contributes 0
+        eng2 = util.load_engine(spec, theta, X, f, yt2)
+        l2, g2, n2 = eng2.loss_and_grad()
+        l20, g20, n20 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, yt2)
+        assert n2 == sum(n20) and l2 == pytest.approx(l20, rel=TOL) and util.relerr(g2, g20) <= TOL
+        eng2.close()
+    eng.close()

@@ -5,7 +5,7 @@ import easyhybrid_jl_amd as eh
 from oracle import hybrid_oracle as ho
 
 MECH_NAME = {"rbq10": "RbQ10", "expo": "Expo_resp_model", "linear": "LinearHM", "expo2pool": "Expo2Pool",
-             "rs_components": "Rs_components"}
+             "rs_components": "Rs_components", "fluxpart": "FluxPartModelQ10"}
 
 
 def model_from_spec(spec: ho.HybridSpec):
