@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "eh_arch.hpp"
+#include "eh_wide.hpp"
 
 // --------------------------------------------------------------------------------------------
 // small kernels
@@ -276,6 +277,7 @@ struct eh_handle_s {
     eh_model_desc desc;
     EhNet net;
     const EhArchInfo* arch = nullptr;
+    const EhArchInfo* arch_alt = nullptr;   // the other kernel family built for this shape ("row_split" option), if any
     int variant = 0, act = 0, fast = 0;
     float* image = nullptr;
     int* imap = nullptr;
@@ -398,7 +400,8 @@ static int build_maps(eh_handle* h, bool with_imap) {
     const int nbi = A->nbi, nbh = A->nbh, nl = A->nl, fast = h->fast;
     const EhAccLayout L = eh_acc_layout(nbi, nbh, nl, fast);
     const std::vector<EhEntry> ent = enumerate_entries(h);
-    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0), cmap((size_t)L.na * 256, -1);
+    const EhWideLayout WL = eh_wide_layout(nbi, nbh, nl);
+    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0), cmap(A->wide ? (size_t)4 * WL.na * 256 : (size_t)L.na * 256, -1);
     auto at = [](int k, int lane, int r) { return k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15); };   // v2 region[k][g][r][c]
     auto cm = [](int k, int lane, int r) { return k * 256 + lane * 4 + r; };                              // cmap[k][lane][r]
     for (const EhEntry& e : ent) {
@@ -422,6 +425,26 @@ static int build_maps(eh_handle* h, bool with_imap) {
             else { k = L.kwo + e.col / 16; lane = 16 * (e.row / 4) + e.col % 16; rr = e.row % 4; nlan = 1; }
         }
         imap[e.canon] = img;
+        if (A->wide) {
+            // row-split kernel: wave w owns feature blocks [w*mb, (w+1)*mb) of every layer; cmap[wave][k][lane][r]
+            int w = 0, kk;
+            const int mb = WL.mb;
+            if (e.l < nl) {
+                w = m / mb;
+                const int mm = m % mb;
+                if (e.col < 0) { kk = WL.kb + e.l * mb + mm; lane = 16 * g; rr = r; }
+                else if (e.l == 0) { kk = WL.kw0 + mm * nbi + e.col / 16; lane = 16 * g + e.col % 16; rr = r; }
+                else { kk = WL.kwh + ((e.l - 1) * mb + mm) * nbh + e.col / 16; lane = 16 * g + e.col % 16; rr = r; }
+            } else if (e.col < 0) {
+                kk = WL.kbo; lane = 16 * (e.row / 4); rr = e.row % 4;
+            } else {
+                const int q = e.col / 16;
+                w = q / mb;
+                kk = WL.kwo + q % mb; lane = 16 * (e.row / 4) + e.col % 16; rr = e.row % 4;
+            }
+            cmap[((size_t)w * WL.na + kk) * 256 + lane * 4 + rr] = e.canon;
+            continue;
+        }
         if (k < 0) { rmap[e.canon] = (L.na * 256 + 13) | (1 << 24); }
         else { rmap[e.canon] = at(k, lane, rr) | (nlan << 24); cmap[cm(k, lane, rr)] = e.canon; }
     }
@@ -463,6 +486,17 @@ static const EhArchInfo* find_arch(int nbi, int nbh, int nl) {
     EH_ARCH_LIST(EH_ARCH_TRY)
 #undef EH_ARCH_TRY
     return nullptr;
+}
+static const EhArchInfo* find_wide(int nbi, int nbh, int nl) {
+#define EH_ARCH_TRY(a, b, c) if (nbi == a && nbh == b && nl == c) return eh_wide_##a##_##b##_##c();
+    EH_WIDE_LIST(EH_ARCH_TRY)
+#undef EH_ARCH_TRY
+    return nullptr;
+}
+static bool arch_fits(const EhArchInfo* A, int need) {
+    for (int vi = 0; vi < A->nvar; ++vi)
+        if ((long long)A->var[vi].nw * need > A->var[vi].red_floats) return false;
+    return true;
 }
 
 extern "C" {
@@ -532,10 +566,12 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     for (int t = 0; t < d->n_targets; ++t)
         if (d->target_output[t] < 0 || d->target_output[t] >= mi.n_out) return fail(nullptr, EH_EINVAL, "eh_create: target_output[%d] = %d (model has %d outputs)", t, d->target_output[t], mi.n_out);
     const int nbi = (d->n_predictors + 15) / 16, nbh_raw = (maxw + 15) / 16;
-    const int nbh = nbh_raw <= 1 ? 1 : nbh_raw <= 2 ? 2 : nbh_raw <= 4 ? 4 : 0;
+    const int nbh = nbh_raw <= 1 ? 1 : nbh_raw <= 2 ? 2 : nbh_raw <= 4 ? 4 : nbh_raw <= 8 ? 8 : 0;
     const EhArchInfo* arch = (nbh && K <= 16) ? find_arch(nbi, nbh, d->n_hidden) : nullptr;
+    const EhArchInfo* const wide_arch = (nbh && K <= 16) ? find_wide(nbi, nbh, d->n_hidden) : nullptr;
+    if (!arch) arch = wide_arch;
     if (!arch)
-        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no compiled kernel for P=%d, hidden max width %d%s, %d hidden layers, K=%d (built: P<=32, width<=64, <=3 layers, K<=16)",
+        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no compiled kernel for P=%d, hidden max width %d%s, %d hidden layers, K=%d (built: P<=32, K<=16, width<=64 with <=3 layers or width<=128 with <=2)",
                     d->n_predictors, maxw, d->n_nets > 0 ? " (nets side by side)" : "", d->n_hidden, K);
 
     int ndev = 0;
@@ -590,11 +626,17 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T + 2;      // [grad | S | n_valid per target | Sy | Syy]
-    for (int vi = 0; vi < arch->nvar; ++vi)
-        if (arch->var[vi].nw * std::max(h->n_acc, EH_EVAL_STATS * n.T) > arch->var[vi].red_floats) {
+    if (!arch_fits(arch, std::max(h->n_acc, EH_EVAL_STATS * n.T))) {
+        // the per-wave kernel parks one gradient copy per wave in LDS; the row-split kernel needs none
+        if (!wide_arch) {
             delete h;
             return fail(nullptr, EH_EUNSUPPORTED, "eh_create: %d accumulators exceed the kernel's reduction space", n.n_theta + 1 + n.T);
         }
+        h->arch = arch = wide_arch;
+        h->variant = 0;
+        h->fast = 0;
+    }
+    h->arch_alt = arch == wide_arch ? nullptr : wide_arch;
 #define HIPCHK_C(expr)                                                            \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \
@@ -711,6 +753,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
+        if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->fused = value != 0;
@@ -723,6 +766,19 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         FLUSH(h);
         h->net.loss = (int)value;
         return EH_OK;
+    }
+    if (!strcmp(name, "row_split")) {        // A/B: the row-split kernel family (eh_wide.hpp) where both are built
+        const bool now = h->arch->wide != 0;
+        if ((value != 0) == now) return EH_OK;
+        if (!h->arch_alt) return fail(h, EH_EUNSUPPORTED, "row_split: this model has only the %s kernel", now ? "row-split" : "per-wave");
+        if (value && h->fused) return fail(h, EH_EUNSUPPORTED, "row_split: switch fused_update off first");
+        HIPCHK(h, hipSetDevice(h->device));
+        FLUSH(h);
+        std::swap(h->arch, h->arch_alt);
+        h->variant = h->arch->nvar > 1 ? 1 : 0;
+        h->fast = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
+        for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
+        return build_maps(h, false);
     }
     if (!strcmp(name, "variant")) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
@@ -815,7 +871,7 @@ static int grid_for(const eh_handle* h, long long count) {
     const EhVariant& v = h->arch->var[h->variant];
     const long long mt = 16LL * v.nt;
     const long long ntiles = (count + mt - 1) / mt;
-    return (int)std::max<long long>(1, std::min<long long>((ntiles + v.nw - 1) / v.nw, h->max_blocks));
+    return (int)std::max<long long>(1, std::min<long long>((ntiles + (v.tiles ? v.tiles : v.nw) - 1) / (v.tiles ? v.tiles : v.nw), h->max_blocks));
 }
 
 // input BatchNorm: statistics of the minibatch [first, first+count) -> a.bn_* (train-mode kernels only)

@@ -16,6 +16,7 @@ struct EhVariant {
     hipError_t (*prepare)(void);   // raises the dynamic-LDS limit of every kernel of the variant
     // fast: bit 0 = single NN output (K == 1), bit 1 = P <= 4; only honoured by shapes built with EH_FAST_PATHS
     hipError_t (*launch)(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
+    int tiles;               // macro-tiles a workgroup works on at a time; 0 = nw (one per wave)
 };
 
 struct EhArchInfo {
@@ -25,6 +26,7 @@ struct EhArchInfo {
     int has_fast;            // K1 / small-P kernels compiled for this shape
     int nvar;
     EhVariant var[4];
+    int wide;                // eh_wide_kernel (eh_wide.hpp): the four waves of a workgroup share one tile and split the layers by rows
 };
 
 constexpr size_t EH_LDS_LIMIT = 160 * 1024;
@@ -44,6 +46,17 @@ constexpr int eh_pick_nt() {
     X(2, 2, 1) X(2, 2, 2) X(2, 2, 3) \
     X(2, 4, 1) X(2, 4, 2) X(2, 4, 3)
 
+// Row-split kernel (eh_wide.hpp).  Hidden widths 65..128: the only kernel, at most two hidden layers
+// fit the LDS.  Widths 33..64: the fallback when the per-wave reduction space of the kernel above is
+// too small for the model's gradient (P > 16 with full-width layers), selectable with the
+// "row_split" option otherwise.
+#define EH_WIDE_LIST(X) \
+    X(1, 4, 1) X(1, 4, 2) X(1, 4, 3) X(2, 4, 1) X(2, 4, 2) X(2, 4, 3) \
+    X(1, 8, 1) X(1, 8, 2) X(2, 8, 1) X(2, 8, 2)
+
 #define EH_ARCH_DECL(a, b, c) extern "C" const EhArchInfo* eh_arch_##a##_##b##_##c(void);
 EH_ARCH_LIST(EH_ARCH_DECL)
+#undef EH_ARCH_DECL
+#define EH_ARCH_DECL(a, b, c) extern "C" const EhArchInfo* eh_wide_##a##_##b##_##c(void);
+EH_WIDE_LIST(EH_ARCH_DECL)
 #undef EH_ARCH_DECL

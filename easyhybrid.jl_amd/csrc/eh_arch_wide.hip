@@ -1,0 +1,72 @@
+// One compiled shape of the row-split wide kernel; built with -DEH_NBI=.. -DEH_NBH=8 -DEH_NL=.. (see Makefile).
+#include "eh_arch.hpp"
+#include "eh_wide.hpp"
+
+#ifndef EH_NBI
+#error "build with -DEH_NBI -DEH_NBH -DEH_NL"
+#endif
+
+namespace {
+constexpr int pick_nt() {
+    if (sizeof(float) * EhWideGeom<EH_NBI, EH_NBH, EH_NL, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
+    if (sizeof(float) * EhWideGeom<EH_NBI, EH_NBH, EH_NL, 2>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 2;
+    return 1;
+}
+#ifdef EH_WIDE_NT
+constexpr int NT = EH_WIDE_NT;
+#else
+constexpr int NT = pick_nt();
+#endif
+using Geom = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT>;
+constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
+static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+
+template <int ACT, int MODE>
+hipError_t prep1() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, ACT, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+}
+template <int ACT>
+hipError_t prep2() {
+    hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
+    return e == hipSuccess ? prep1<ACT, EH_MODE_EVAL>() : e;
+}
+hipError_t prepare() {
+    hipError_t e;
+    if ((e = prep2<EH_ACT_TANH>()) != hipSuccess) return e;
+    if ((e = prep2<EH_ACT_SIGMOID>()) != hipSuccess) return e;
+    if ((e = prep2<EH_ACT_RELU>()) != hipSuccess) return e;
+    if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
+    return prep2<EH_ACT_IDENTITY>();
+}
+template <int ACT>
+void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+    if (mode == EH_MODE_TRAIN)
+        hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, ACT, EH_MODE_TRAIN>), dim3(grid), dim3(256), LDS, stream, *net, *args);
+    else
+        hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, ACT, EH_MODE_EVAL>), dim3(grid), dim3(256), LDS, stream, *net, *args);
+}
+hipError_t launch(int mode, int act, int /*fast*/, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+    switch (act) {
+        case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
+        case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
+        case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
+        case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, grid, stream, net, args); break;
+        case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+const EhArchInfo info = {
+    EH_NBI, EH_NBH, EH_NL,
+    Geom::IP, Geom::HP, Geom::S0, Geom::SH, Geom::W0_OFF, Geom::WH_OFF, Geom::WO_OFF, Geom::B_OFF, Geom::PHI_OFF, Geom::IMG_FLOATS,
+    0,
+    1, {EhVariant{NT, 4, LDS, 1 << 30, &prepare, &launch, 1}, {}, {}, {}},
+    1,
+};
+}   // namespace
+
+#define EH_CAT_(a, b, c) eh_wide_##a##_##b##_##c
+#define EH_CAT(a, b, c) EH_CAT_(a, b, c)
+extern "C" const EhArchInfo* EH_CAT(EH_NBI, EH_NBH, EH_NL)(void) { return &info; }

@@ -649,3 +649,116 @@ def test_fluxpart_multi_target(targets, nets):
         assert n2 == sum(n20) and l2 == pytest.approx(l20, rel=TOL) and util.relerr(g2, g20) <= TOL
         eng2.close()
     eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# hidden widths 65..128: the row-split kernel (eh_wide.hpp); BASELINE.json configs[4] = [32,128,128,6]
+# ----------------------------------------------------------------------------------------------
+def _rs6_case(P, hidden, B, act="tanh", seed=11, nan_frac=0.1):
+    comps = ("het", "root", "myc")
+    tab = {**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in comps}, **{f"Q10_{c}": (2.0 + 0.3 * i, 1.0, 4.0) for i, c in enumerate(comps)}}
+    mm = ho.MECH["rs_components"][0]
+    spec = ho.HybridSpec(P, list(hidden), "rs_components", tab, list(tab), [], [mm.outputs[0]], act, True)
+    rng = np.random.default_rng(seed)
+    X = (rng.standard_normal((P, B)) * 0.5).astype(np.float32)
+    frc = {mm.forcings[0]: rng.uniform(-5, 25, B).astype(np.float32)}
+    yv = rng.uniform(0.5, 6, B).astype(np.float32)
+    yv[rng.random(B) < nan_frac] = np.nan
+    return spec, ho.init_theta(spec, seed, np.float32), X, frc, {mm.outputs[0]: yv}
+
+
+@pytest.mark.parametrize("hidden", [(128,), (128, 128), (100, 72), (65, 128), (16, 80)])
+@pytest.mark.parametrize("act", ["tanh", "swish", "relu"])
+def test_width_128_shapes(hidden, act):
+    _check_grad(*util.rbq10_case(300, act, True, 0.1, hidden=hidden))
+
+
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 1000])
+def test_config5_shape_32_128_128_6(B):
+    _check_grad(*_rs6_case(32, (128, 128), B))
+
+
+def test_width_128_twenty_predictors_unscaled_sigmoid():
+    # raw (unscaled) network outputs feed the mechanistic model: LinearHM tolerates any sign
+    mm = ho.MECH["linear"][0]
+    spec = ho.HybridSpec(20, [96, 128], "linear", {"alpha": (1.0, -2.0, 3.0), "beta": (0.5, -1.0, 2.0)}, ["alpha", "beta"], [], [mm.outputs[0]], "sigmoid", False)
+    rng = np.random.default_rng(8)
+    B = 500
+    X = (rng.standard_normal((20, B)) * 0.5).astype(np.float32)
+    yv = rng.uniform(-2, 4, B).astype(np.float32)
+    yv[rng.random(B) < 0.1] = np.nan
+    _check_grad(spec, ho.init_theta(spec, 8, np.float32), X, {mm.forcings[0]: rng.uniform(-1, 2, B).astype(np.float32)}, {mm.outputs[0]: yv})
+
+
+def test_width_128_forward_eval_and_adam_trajectory():
+    spec, theta, X, f, y = _rs6_case(32, (128, 128), 2000)
+    eng = util.load_engine(spec, theta, X, f, y)
+    out = eng.forward(0)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    assert util.relerr(out["R_soil"], ref["R_soil"]) <= TOL
+    for name in spec.parameters:
+        assert util.relerr(out["parameters"][name], np.broadcast_to(ref["parameters"][name], (2000,))) <= TOL
+    metrics, _ = eng.eval(0)
+    yy = y["R_soil"].astype(np.float64)
+    mask = ~np.isnan(yy)
+    assert metrics[0]["n"] == mask.sum()
+    for k in ("mse", "mae", "r2", "nse"):
+        assert metrics[0][k] == pytest.approx(ho.loss_fn(ref["R_soil"], yy, mask, k), rel=2e-5, abs=2e-6), k
+    eng.opt_init("Adam", 0.001)
+    batches = [(i * 250, 250) for i in range(8)]
+    losses = [eng.train_step(a, b) for a, b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, lr=0.001, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    with pytest.raises(NotImplementedError, match="fused_update"):
+        eng.set_option("fused_update", 1)
+    eng.close()
+
+
+def test_width_128_three_layers_is_refused_loudly():
+    with pytest.raises(NotImplementedError, match="no compiled kernel"):
+        util.model_from_spec(ho.rbq10_spec((128, 128, 128))).engine()
+
+
+def test_width_128_grid_independence_full_batch():
+    # 65 536 samples: 2048 tiles over 256 workgroups vs. a single workgroup walking all of them
+    spec, theta, X, f, y = _rs6_case(32, (128, 128), 65536, seed=5)
+    eng = util.load_engine(spec, theta, X, f, y)
+    l1, g1, n1 = eng.loss_and_grad()
+    eng.set_option("max_blocks", 7)
+    l2, g2, n2 = eng.loss_and_grad()
+    assert n1 == n2 and abs(l1 - l2) <= 1e-5 * abs(l1) and util.relerr(g1, g2) <= 1e-5
+    sl = slice(0, 4096)
+    l0, g0, _ = ho.loss_and_grad(spec, np.asarray(theta, np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()})
+    l3, g3, _ = eng.loss_and_grad(first=0, count=4096)
+    assert abs(l3 - l0) <= TOL * abs(l0) and util.relerr(g3, g0) <= TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden", [(64, 64), (64,), (64, 48, 64)])
+def test_width_64_with_32_predictors_falls_back_to_row_split_kernel(hidden):
+    # P > 16 with full 64-wide layers: the per-wave kernel has no LDS room to park one gradient per wave
+    _check_grad(*_rs6_case(32, hidden, 700))
+
+
+@pytest.mark.parametrize("hidden", [(64, 64), (40,), (64, 33, 64)])
+def test_row_split_option_agrees_with_per_wave_kernel(hidden):
+    spec = ho.expo2pool_spec(hidden, "tanh", True)
+    X, f, y = ho.make_synth_expo2pool(3000, 5, 0.1)
+    theta = ho.init_theta(spec, 2, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    l1, g1, n1 = eng.loss_and_grad()
+    eng.set_option("row_split", 1)
+    _check_grad(spec, theta, X, f, y, eng=eng)
+    l2, g2, n2 = eng.loss_and_grad()
+    assert n1 == n2 and abs(l1 - l2) <= 2e-6 * abs(l1) and util.relerr(g1, g2) <= 2e-6
+    ya = eng.forward(0)["Resp_obs"]
+    eng.set_option("row_split", 0)
+    assert util.relerr(eng.forward(0)["Resp_obs"], ya) <= 2e-6
+    l3, g3, _ = eng.loss_and_grad()
+    assert l3 == l1 and np.array_equal(g3, g1)
+    eng.close()
+    narrow = util.load_engine(*util.rbq10_case(64))
+    with pytest.raises(NotImplementedError, match="row_split"):
+        narrow.set_option("row_split", 1)
+    narrow.close()
