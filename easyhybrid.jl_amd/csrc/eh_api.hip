@@ -45,23 +45,25 @@ __global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
 
 // Sum the per-workgroup partials of the step kernel (fixed order: deterministic), normalise by the
 // valid count when the step ran with deferred normalisation, and (APPLY) update theta and its
-// image in place.  Block = 16 columns x 16 row groups; every load of a thread is independent, so
+// image in place.  Block = CW columns x 256/CW row groups (CW = 16 for small models: many blocks; CW = 64 for
+// big gradients: 256-byte runs per slab row); every load of a thread is independent, so
 // the whole slab read costs about one L2 round trip.  gradbuf = [grad | loss | counts].
-template <bool APPLY>
+template <bool APPLY, int CW>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
                                                         float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
-    __shared__ float part[16][17];
+    constexpr int NQ = 256 / CW;
+    __shared__ float part[NQ][CW + 1];
     __shared__ float wsum[4][EH_MAX_TARG + 3];
-    const int tid = threadIdx.x, p = tid & 15, q = tid >> 4;
-    const int idx = blockIdx.x * 16 + p;
+    const int tid = threadIdx.x, p = tid % CW, q = tid / CW;
+    const int idx = blockIdx.x * CW + p;
     // optimiser inputs are independent of the slab: request them first so they arrive together
     float th = 0.0f, mm = 0.0f, vv = 0.0f, bt1 = 0.0f, bt2 = 0.0f;
     if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; }
     float s = 0.0f;
     if (idx < n_acc) {
 #pragma unroll 16
-        for (int r = q; r < nblk; r += 16) s += slab[(size_t)r * n_acc + idx];
+        for (int r = q; r < nblk; r += NQ) s += slab[(size_t)r * n_acc + idx];
     }
     part[q][p] = s;
     // valid counts: every block needs them (nblk <= 256: one row per thread)
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     if (q == 0 && idx < n_acc) {
         float tot = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += part[k][p];
+        for (int k = 0; k < NQ; ++k) tot += part[k][p];
         const float scale = deferred ? dscale : 1.0f;
         if (idx < n_theta) {
             const float g = tot * scale;
@@ -400,8 +402,9 @@ static int build_maps(eh_handle* h, bool with_imap) {
     const int nbi = A->nbi, nbh = A->nbh, nl = A->nl, fast = h->fast;
     const EhAccLayout L = eh_acc_layout(nbi, nbh, nl, fast);
     const std::vector<EhEntry> ent = enumerate_entries(h);
-    const EhWideLayout WL = eh_wide_layout(nbi, nbh, nl);
-    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0), cmap(A->wide ? (size_t)4 * WL.na * 256 : (size_t)L.na * 256, -1);
+    const int nwv = A->wide ? A->var[h->variant].nw : 4;
+    const EhWideLayout WL = eh_wide_layout(nbi, nbh, nl, nwv);
+    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0), cmap((size_t)L.na * 256, -1);
     auto at = [](int k, int lane, int r) { return k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15); };   // v2 region[k][g][r][c]
     auto cm = [](int k, int lane, int r) { return k * 256 + lane * 4 + r; };                              // cmap[k][lane][r]
     for (const EhEntry& e : ent) {
@@ -426,7 +429,7 @@ static int build_maps(eh_handle* h, bool with_imap) {
         }
         imap[e.canon] = img;
         if (A->wide) {
-            // row-split kernel: wave w owns feature blocks [w*mb, (w+1)*mb) of every layer; cmap[wave][k][lane][r]
+            // row-split kernel: wave w owns feature blocks [w*mb, (w+1)*mb) of every layer
             int w = 0, kk;
             const int mb = WL.mb;
             if (e.l < nl) {
@@ -442,7 +445,7 @@ static int build_maps(eh_handle* h, bool with_imap) {
                 w = q / mb;
                 kk = WL.kwo + q % mb; lane = 16 * (e.row / 4) + e.col % 16; rr = e.row % 4;
             }
-            cmap[((size_t)w * WL.na + kk) * 256 + lane * 4 + rr] = e.canon;
+            rmap[e.canon] = (w * WL.na + kk) * 256 + lane * 4 + rr;      // position in the kernel's LDS staging
             continue;
         }
         if (k < 0) { rmap[e.canon] = (L.na * 256 + 13) | (1 << 24); }
@@ -582,7 +585,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->desc = *d;
     h->device = d->device;
     h->arch = arch;
-    h->variant = arch->nvar > 1 ? 1 : 0;   // narrow nets: two waves per SIMD hide the latency of the short tile
+    h->variant = (arch->nvar > 1 && !arch->wide) ? 1 : 0;   // narrow nets: two waves per SIMD hide the latency of the short tile
     EhNet& n = h->net;
     memset(&n, 0, sizeof n);
     n.P = d->n_predictors; n.K = K; n.G = G; n.T = d->n_targets; n.F = d->n_forcings;
@@ -775,7 +778,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         std::swap(h->arch, h->arch_alt);
-        h->variant = h->arch->nvar > 1 ? 1 : 0;
+        h->variant = (h->arch->nvar > 1 && !h->arch->wide) ? 1 : 0;
         h->fast = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
         for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
         return build_maps(h, false);
@@ -783,6 +786,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "variant")) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
         h->variant = (int)value;
+        if (h->arch->wide) {                 // the scatter map depends on the number of waves
+            HIPCHK(h, hipSetDevice(h->device));
+            return build_maps(h, false);
+        }
         return EH_OK;
     }
     return fail(h, EH_EINVAL, "unknown option %s", name);
@@ -958,17 +965,20 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (rc) return rc;
     if (prof) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
-    const int rgrid = (h->n_acc + 15) / 16;
+    const bool big = h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
+    const int rgrid = big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
+#define EH_REDUCE_GO(AP, CW_)                                                                                                                       \
+    hipLaunchKernelGGL((eh_reduce_kernel<AP, CW_>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
+                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss)
     if (apply) {
-        hipLaunchKernelGGL(eh_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss);
+        if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
     } else {
-        hipLaunchKernelGGL(eh_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf,
-                           TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss);
+        if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
     }
+#undef EH_REDUCE_GO
     HIPCHK(h, hipGetLastError());
     if (prof) {
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));

@@ -1,4 +1,6 @@
-// One compiled shape of the row-split wide kernel; built with -DEH_NBI=.. -DEH_NBH=8 -DEH_NL=.. (see Makefile).
+// One compiled shape of the row-split wide kernel; built with -DEH_NBI=.. -DEH_NBH=.. -DEH_NL=.. (see Makefile).
+// NBH = 8 gets two variants: 8 waves per workgroup (one feature block each, two waves per SIMD so that
+// one wave's LDS round trips hide behind the other's MFMAs) and 4 waves (two blocks each).
 #include "eh_arch.hpp"
 #include "eh_wide.hpp"
 
@@ -8,8 +10,8 @@
 
 namespace {
 constexpr int pick_nt() {
-    if (sizeof(float) * EhWideGeom<EH_NBI, EH_NBH, EH_NL, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
-    if (sizeof(float) * EhWideGeom<EH_NBI, EH_NBH, EH_NL, 2>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 2;
+    if (sizeof(float) * EhWideGeom<EH_NBI, EH_NBH, EH_NL, 4, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
+    if (sizeof(float) * EhWideGeom<EH_NBI, EH_NBH, EH_NL, 2, 4>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 2;
     return 1;
 }
 #ifdef EH_WIDE_NT
@@ -17,52 +19,62 @@ constexpr int NT = EH_WIDE_NT;
 #else
 constexpr int NT = pick_nt();
 #endif
-using Geom = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT>;
-constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
-static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
 
-template <int ACT, int MODE>
-hipError_t prep1() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, ACT, MODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-}
-template <int ACT>
-hipError_t prep2() {
-    hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
-    return e == hipSuccess ? prep1<ACT, EH_MODE_EVAL>() : e;
-}
-hipError_t prepare() {
-    hipError_t e;
-    if ((e = prep2<EH_ACT_TANH>()) != hipSuccess) return e;
-    if ((e = prep2<EH_ACT_SIGMOID>()) != hipSuccess) return e;
-    if ((e = prep2<EH_ACT_RELU>()) != hipSuccess) return e;
-    if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
-    return prep2<EH_ACT_IDENTITY>();
-}
-template <int ACT>
-void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
-    if (mode == EH_MODE_TRAIN)
-        hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, ACT, EH_MODE_TRAIN>), dim3(grid), dim3(256), LDS, stream, *net, *args);
-    else
-        hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, ACT, EH_MODE_EVAL>), dim3(grid), dim3(256), LDS, stream, *net, *args);
-}
-hipError_t launch(int mode, int act, int /*fast*/, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
-    switch (act) {
-        case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
-        case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
-        case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
-        case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, grid, stream, net, args); break;
-        case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
-        default: return hipErrorInvalidValue;
+template <int NWV>
+struct Var {
+    using Geom = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT, NWV>;
+    static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
+    static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+
+    template <int ACT, int MODE>
+    static hipError_t prep1() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, MODE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
-    return hipGetLastError();
-}
+    template <int ACT>
+    static hipError_t prep2() {
+        hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
+        return e == hipSuccess ? prep1<ACT, EH_MODE_EVAL>() : e;
+    }
+    static hipError_t prepare() {
+        hipError_t e;
+        if ((e = prep2<EH_ACT_TANH>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_SIGMOID>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_RELU>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
+        return prep2<EH_ACT_IDENTITY>();
+    }
+    template <int ACT>
+    static void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode == EH_MODE_TRAIN)
+            hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, EH_MODE_TRAIN>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args);
+        else
+            hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, EH_MODE_EVAL>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args);
+    }
+    static hipError_t launch(int mode, int act, int /*fast*/, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        switch (act) {
+            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
+            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
+            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
+            case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, grid, stream, net, args); break;
+            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    static constexpr EhVariant info() { return EhVariant{NT, NWV, LDS, 1 << 30, &prepare, &launch, 1}; }
+};
 
+using G0 = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT, 4>;
 const EhArchInfo info = {
     EH_NBI, EH_NBH, EH_NL,
-    Geom::IP, Geom::HP, Geom::S0, Geom::SH, Geom::W0_OFF, Geom::WH_OFF, Geom::WO_OFF, Geom::B_OFF, Geom::PHI_OFF, Geom::IMG_FLOATS,
+    G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
     0,
-    1, {EhVariant{NT, 4, LDS, 1 << 30, &prepare, &launch, 1}, {}, {}, {}},
+#if EH_NBH == 8
+    2, {Var<8>::info(), Var<4>::info(), {}, {}},
+#else
+    1, {Var<4>::info(), {}, {}, {}},
+#endif
     1,
 };
 }   // namespace

@@ -197,49 +197,52 @@ __device__ __forceinline__ float eh_pow(float b, float e) { return __builtin_amd
 // lane.  par[] in the registry's canonical order (see include/easyhybrid_hip.h).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const float* frc, float* dydp) {
-    float y = 0.0f;
+    // the partials live in named scalars inside the switch: writing dydp[] from its arms makes the
+    // compiler keep the array in scratch memory (and every scratch read drains vmcnt, i.e. waits for
+    // the record prefetch)
+    float y = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, d4 = 0.0f, d5 = 0.0f;
+    const float p0 = par[0], p1 = par[1], p2 = par[2], p3 = par[3], p4 = par[4], p5 = par[5], f0 = frc[0], f1 = frc[1];
     switch (mech) {
         case EH_MECH_RBQ10: {   // reco = rb * Q10^(0.1 (ta - 15))    test/test_split_data_train.jl:36-39
-            const float e = 0.1f * (frc[0] - 15.0f);
-            const float p = eh_pow(par[1], e);
-            y = par[0] * p;
-            dydp[0] = p; dydp[1] = y * e * __builtin_amdgcn_rcpf(par[1]);
+            const float e = 0.1f * (f0 - 15.0f);
+            const float p = eh_pow(p1, e);
+            y = p0 * p;
+            d0 = p; d1 = y * e * __builtin_amdgcn_rcpf(p1);
         } break;
         case EH_MECH_EXPO: {    // Resp_obs = Resp0 * exp(k T)        projects/ExpoHybrid/ExpoHybridEstim.jl:83
-            const float ex = __expf(par[1] * frc[0]);
-            y = par[0] * ex;
-            dydp[0] = ex; dydp[1] = y * frc[0];
+            const float ex = __expf(p1 * f0);
+            y = p0 * ex;
+            d0 = ex; d1 = y * f0;
         } break;
         case EH_MECH_LINEAR: {  // obs = alpha x + beta               src/models/LinearHM.jl:65
-            y = par[0] * frc[0] + par[1];
-            dydp[0] = frc[0]; dydp[1] = 1.0f;
+            y = p0 * f0 + p1;
+            d0 = f0; d1 = 1.0f;
         } break;
         case EH_MECH_EXPO2POOL: {   // build-defined: R0a exp(ka T) + R0b exp(kb T)   (BASELINE.json config 3)
-            const float ea = __expf(par[1] * frc[0]), eb = __expf(par[3] * frc[0]);
-            y = par[0] * ea + par[2] * eb;
-            dydp[0] = ea; dydp[1] = par[0] * ea * frc[0];
-            dydp[2] = eb; dydp[3] = par[2] * eb * frc[0];
+            const float ea = __expf(p1 * f0), eb = __expf(p3 * f0);
+            y = p0 * ea + p2 * eb;
+            d0 = ea; d1 = p0 * ea * f0;
+            d2 = eb; d3 = p2 * eb * f0;
         } break;
         case EH_MECH_RS_COMPONENTS: {   // R_soil = sum_c Rb_c Q10_c^(0.1 (ta-15))   src/models/Rs_components.jl:45-55
-            const float e = 0.1f * (frc[0] - 15.0f);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float p = eh_pow(par[3 + c], e);
-                const float r = par[c] * p;
-                y += r;
-                dydp[c] = p; dydp[3 + c] = r * e * __builtin_amdgcn_rcpf(par[3 + c]);
-            }
+            const float e = 0.1f * (f0 - 15.0f);
+            const float q0 = eh_pow(p3, e), q1 = eh_pow(p4, e), q2 = eh_pow(p5, e);
+            const float r0 = p0 * q0, r1 = p1 * q1, r2 = p2 * q2;
+            y = (r0 + r1) + r2;
+            d0 = q0; d1 = q1; d2 = q2;
+            d3 = r0 * e * __builtin_amdgcn_rcpf(p3); d4 = r1 * e * __builtin_amdgcn_rcpf(p4); d5 = r2 * e * __builtin_amdgcn_rcpf(p5);
         } break;
         case EH_MECH_FLUXPART: {    // output 0: NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:66-74
-            const float e = 0.1f * (frc[1] - 15.0f);
-            const float p = eh_pow(par[2], e);
-            const float gq = frc[0] * (1.0f / 12.011f);
-            const float reco = par[1] * p;
-            y = reco - gq * par[0];
-            dydp[0] = -gq; dydp[1] = p; dydp[2] = reco * e * __builtin_amdgcn_rcpf(par[2]);
+            const float e = 0.1f * (f1 - 15.0f);
+            const float p = eh_pow(p2, e);
+            const float gq = f0 * (1.0f / 12.011f);
+            const float reco = p1 * p;
+            y = reco - gq * p0;
+            d0 = -gq; d1 = p; d2 = reco * e * __builtin_amdgcn_rcpf(p2);
         } break;
         default: break;
     }
+    dydp[0] = d0; dydp[1] = d1; dydp[2] = d2; dydp[3] = d3; dydp[4] = d4; dydp[5] = d5;
     return y;
 }
 
@@ -434,7 +437,22 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             }
         }
     }
-    for (int e = 4 * tid; e < G::IMG_FLOATS; e += 4 * NTHR) *(f32x4*)&wl[e] = *(const f32x4*)&a.image[e];
+    {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
+        constexpr int NI = (G::IMG_FLOATS / 4 + NTHR - 1) / NTHR, NIB = NI < 16 ? NI : 16;
+        for (int e0 = 4 * tid; e0 < G::IMG_FLOATS; e0 += 4 * NTHR * NIB) {
+            f32x4 tmp[NIB];
+#pragma unroll
+            for (int u = 0; u < NIB; ++u) {
+                const int e = e0 + 4 * NTHR * u;
+                tmp[u] = e < G::IMG_FLOATS ? *(const f32x4*)&a.image[e] : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < NIB; ++u) {
+                const int e = e0 + 4 * NTHR * u;
+                if (e < G::IMG_FLOATS) *(f32x4*)&wl[e] = tmp[u];
+            }
+        }
+    }
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
     __syncthreads();
     if (a.bn_part) {

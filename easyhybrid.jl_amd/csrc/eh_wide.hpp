@@ -2,22 +2,22 @@
 //
 // Same math, data layout, parameter image and slab contract as eh_step_kernel (eh_device.hpp), but a
 // different decomposition: with 128-wide layers neither the weight-gradient accumulators
-// (128x128 floats = 256 registers per lane) nor a per-wave activation workspace fit, so the four
-// waves of a workgroup share ONE macro-tile of 16*NT samples and split every layer by OUTPUT ROWS:
-// wave w owns feature blocks [w*MB, (w+1)*MB), MB = NBH/4.  Each wave computes its slice of every
+// (128x128 floats = 256 registers per lane) nor a per-wave activation workspace fit, so the NWV
+// (4 or 8) waves of a workgroup share ONE macro-tile of 16*NT samples and split every layer by OUTPUT
+// ROWS: wave w owns feature blocks [w*MB, (w+1)*MB), MB = NBH/NWV.  Each wave computes its slice of every
 // layer's outputs (B operands = the previous layer's activations, read from the shared LDS image in
 // MFMA operand order), of every dH, and owns the matching slice of every weight gradient, so no
 // gradient ever has to be summed across waves; the price is a workgroup barrier per layer.  The
-// output layer is split over K (each wave contracts its own feature blocks, the four partial
+// output layer is split over K (each wave contracts its own feature blocks, the NWV partial
 // outputs meet in the one-sample-per-lane mechanistic stage, which wave 0 runs).
 #pragma once
 #include "eh_device.hpp"
 
-// per-wave accumulator order for the host-built scatter map (cmap[wave][k][lane][r])
+// per-wave accumulator order; the host maps canonical index -> staging position ((wave*na + k)*64 + lane)*4 + r (rmap)
 struct EhWideLayout { int mb, kw0, kwh, kwo, kb, kbo, na; };
-__host__ __device__ constexpr EhWideLayout eh_wide_layout(int nbi, int nbh, int nl) {
+__host__ __device__ constexpr EhWideLayout eh_wide_layout(int nbi, int nbh, int nl, int nwv) {
     EhWideLayout L{};
-    L.mb = nbh / 4;
+    L.mb = nbh / nwv;
     L.kw0 = 0;
     L.kwh = L.kw0 + L.mb * nbi;
     L.kwo = L.kwh + (nl - 1) * L.mb * nbh;
@@ -27,20 +27,28 @@ __host__ __device__ constexpr EhWideLayout eh_wide_layout(int nbi, int nbh, int 
     return L;
 }
 
-template <int NBI, int NBH, int NL, int NT>
+template <int NBI, int NBH, int NL, int NT, int NWV>
 struct EhWideGeom : EhGeom<NBI, NBH, NL, NT, 1> {
     using B = EhGeom<NBI, NBH, NL, NT, 1>;
-    static_assert(NBH % 4 == 0, "four waves split the feature blocks");
-    static_assert(4 * 16 * B::SR <= B::HP * B::SR, "the split-K output partials alias the delta image");
-    static constexpr int TOTAL_FLOATS = B::IMG_FLOATS + B::WAVE_WS;     // one shared workspace per workgroup
+    static_assert(NBH % NWV == 0, "the waves split the feature blocks evenly");
+    static_assert(NWV * 16 <= B::HP, "the split-K output partials alias the delta image");
+    static constexpr int RS_OFF = B::WAVE_WS;                           // forcings (rows 0..3) and targets (rows 4..7) of the tile
+    static constexpr int SG_OFF = RS_OFF + (EH_MAX_FORC + EH_MAX_TARG) * B::SR;   // d(parameter)/d(network output), 16 rows
+    static constexpr int WS_FLOATS = SG_OFF + 16 * B::SR;
+    static constexpr int TOTAL_FLOATS = B::IMG_FLOATS + WS_FLOATS;      // one shared workspace per workgroup
+    static_assert(NWV * eh_wide_layout(NBI, NBH, NL, NWV).na * 256 <= TOTAL_FLOATS, "the end-of-kernel staging of the accumulators overlays image + workspace");
 };
 
-template <int NBI, int NBH, int NL, int NT, int ACT, int MODE>
-__global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const EhStepArgs a) {
-    using G = EhWideGeom<NBI, NBH, NL, NT>;
-    constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, MB = NBH / 4;
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
+// make every barrier wait for the next tile's records (global loads issued a tile ahead on purpose).
+__device__ __forceinline__ void eh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE>
+__global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, const EhStepArgs a) {
+    using G = EhWideGeom<NBI, NBH, NL, NT, NWV>;
+    constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, MB = NBH / NWV, NTH = 64 * NWV;
     constexpr bool TRAIN = MODE == EH_MODE_TRAIN;
-    constexpr EhWideLayout WL = eh_wide_layout(NBI, NBH, NL);
+    constexpr EhWideLayout WL = eh_wide_layout(NBI, NBH, NL, NWV);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -49,45 +57,73 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
     float* const HS = ws + G::HS_OFF;
     float* const DZ = ws + G::DZ_OFF;
     float* const OS = ws + G::OS_OFF;
-    float* const OSP = DZ;                      // [4 waves][16][SR] partial outputs of the split-K output layer
+    float* const OSP = DZ;                      // [NWV waves][16][SR] partial outputs of the split-K output layer
     const float* const meta = wl + G::PHI_OFF;
     const int m0 = wave * MB;
     auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
     auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
     const bool mechw = wave == 0 && lane < MT;   // the lanes that own one sample each in the mechanistic stage
 
-    // one sample record per mechanistic lane, fetched one tile ahead
-    constexpr int NX4 = (G::IP + 3) / 4;
-    struct { f32x4 x[NX4]; float frc[EH_MAX_FORC]; float y[EH_MAX_TARG]; } nx;
-    const int count = (int)a.count, first = (int)a.first;
+    // The tile's MT records are MT*C consecutive floats (or MT gathered runs of C): every thread owns
+    // the elements e = tid + k*NTH, loads them coalesced one tile ahead and drops them transposed into
+    // the [feature][sample] image (predictors) or the forcing / target rows.
+    float* const RS = ws + G::RS_OFF;
+    constexpr int NEL = (MT * (G::IP + EH_MAX_FORC + EH_MAX_TARG) + NTH - 1) / NTH;
+    const int count = (int)a.count, first = (int)a.first, C = a.C;
     const int ntiles = (count + MT - 1) / MT;
-    auto fetch = [&](int tile) {
-        const int n_loc = tile * MT + lane;
-        const bool live = mechw && (tile < ntiles) && (n_loc < count);
-        const int n_glb = live ? (a.idx ? a.idx[first + n_loc] : first + n_loc) : 0;
-        const float* const rec = a.recs + (long long)n_glb * a.C;
-        if ((a.C & 3) == 0) {
+    int epk[NEL], nidx[NEL];          // element k: LDS offset | column << 16 | sample << 24 ; -1 = none
+    float nx[NEL];
 #pragma unroll
-            for (int q = 0; q < NX4; ++q) nx.x[q] = (live && 4 * q < net.P) ? *(const f32x4*)(rec + 4 * q) : f32x4{0, 0, 0, 0};
-        } else {
-#pragma unroll
-            for (int q = 0; q < NX4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) nx.x[q][e] = (live && 4 * q + e < net.P) ? rec[4 * q + e] : 0.0f;
+    for (int k = 0; k < NEL; ++k) {
+        const int e = tid + k * NTH;
+        epk[k] = -1; nidx[k] = 0; nx[k] = 0.0f;
+        if (e < MT * C) {
+            const int smp = e / C, col = e - smp * C;
+            const int row = col < net.P ? -1 : (col - net.P < net.F ? col - net.P : EH_MAX_FORC + (col - net.P - net.F));
+            const int dst = row < 0 ? G::XS_OFF + col * SR + smp : G::RS_OFF + row * SR + smp;
+            epk[k] = dst | (col << 16) | (smp << 24);
         }
+    }
+    auto fetch_idx = [&](int tile) {
+        if (!a.idx) return;
 #pragma unroll
-        for (int f = 0; f < EH_MAX_FORC; ++f) {
-            const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
-            nx.frc[f] = (col != 0xFFu && live) ? rec[net.P + col] : 0.0f;
+        for (int k = 0; k < NEL; ++k) {
+            const int s_loc = tile * MT + (epk[k] >> 24);
+            nidx[k] = (epk[k] >= 0 && tile < ntiles && s_loc < count) ? a.idx[first + s_loc] : 0;
         }
-#pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) nx.y[t] = (t < net.T && live) ? rec[net.P + net.F + t] : __builtin_nanf("");
     };
+    auto fetch = [&](int tile) {      // data of `tile` (its gather indices are already in nidx), then the indices one tile further
+#pragma unroll
+        for (int k = 0; k < NEL; ++k) {
+            const int col = (epk[k] >> 16) & 0xFF, s_loc = tile * MT + (epk[k] >> 24);
+            const bool live = epk[k] >= 0 && tile < ntiles && s_loc < count;
+            const long long src = a.idx ? (long long)nidx[k] * C + col : (long long)(first + tile * MT) * C + (tid + k * NTH);
+            nx[k] = live ? a.recs[src] : (col >= net.P + net.F ? __builtin_nanf("") : 0.0f);
+        }
+        fetch_idx(tile + (int)gridDim.x);
+    };
+    EH_STAMP(13);
+    fetch_idx((int)blockIdx.x);
     fetch((int)blockIdx.x);
 
-    for (int e = 4 * tid; e < G::IMG_FLOATS; e += 4 * 256) *(f32x4*)&wl[e] = *(const f32x4*)&a.image[e];
-    for (int e = tid; e < G::IP * SR; e += 256) XS[e] = 0.0f;
-    for (int e = tid; e < 16 * SR; e += 256) OS[e] = 0.0f;          // rows >= K of the output / dO image stay 0
+    {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
+        constexpr int NI = (G::IMG_FLOATS / 4 + NTH - 1) / NTH, NIB = NI < 16 ? NI : 16;
+        for (int e0 = 4 * tid; e0 < G::IMG_FLOATS; e0 += 4 * NTH * NIB) {
+            f32x4 tmp[NIB];
+#pragma unroll
+            for (int u = 0; u < NIB; ++u) {
+                const int e = e0 + 4 * NTH * u;
+                tmp[u] = e < G::IMG_FLOATS ? *(const f32x4*)&a.image[e] : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < NIB; ++u) {
+                const int e = e0 + 4 * NTH * u;
+                if (e < G::IMG_FLOATS) *(f32x4*)&wl[e] = tmp[u];
+            }
+        }
+    }
+    for (int e = tid; e < G::IP * SR; e += NTH) XS[e] = 0.0f;
+    for (int e = tid; e < 16 * SR; e += NTH) OS[e] = 0.0f;          // rows >= K of the output / dO image stay 0
     __syncthreads();
     if (a.bn_part) {       // input BatchNorm, train mode: statistics of this minibatch (see eh_step_kernel)
         if (tid < net.P) {
@@ -106,6 +142,19 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
             }
         }
         __syncthreads();
+    }
+
+    // split-K partials -> physical parameters: element (k, sample) = tid + u*NTH, its bounds fixed for the whole launch
+    float* const SG = ws + G::SG_OFF;
+    constexpr int NEO = (16 * MT + NTH - 1) / NTH;
+    float klo[NEO], ksc[NEO];
+#pragma unroll
+    for (int u = 0; u < NEO; ++u) {
+        const int k = (tid + u * NTH) / MT;
+        klo[u] = 0.0f; ksc[u] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j)
+            if (j < net.n_par && pkind(j) == EH_PAR_NEURAL && pidx(j) == k) { klo[u] = meta[EH_IMG_LO + j]; ksc[u] = meta[EH_IMG_SC + j]; }
     }
 
     // accumulators: this wave's row slice of every weight gradient
@@ -146,24 +195,23 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
             }
     };
 
+    EH_STAMP(14);
     for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        EH_STAMP(0);
         const int n_loc = tile * MT + lane;
         const bool live = mechw && (n_loc < count);
-        // ---- 1. records -> normalised [feature][sample] image (wave 0), next tile's record in flight
-        float frc[EH_MAX_FORC], yobs[EH_MAX_TARG];
+        // ---- 1. records -> normalised [feature][sample] image + forcing / target rows; next tile's records in flight
 #pragma unroll
-        for (int f = 0; f < EH_MAX_FORC; ++f) frc[f] = nx.frc[f];
-#pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) yobs[t] = nx.y[t];
-        if (mechw) {
-#pragma unroll
-            for (int q = 0; q < NX4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < net.P) XS[(4 * q + e) * SR + lane] = (nx.x[q][e] - meta[EH_IMG_BNM + 4 * q + e]) * meta[EH_IMG_BNR + 4 * q + e];
-        }
+        for (int k = 0; k < NEL; ++k)
+            if (epk[k] >= 0) {
+                const int col = (epk[k] >> 16) & 0xFF;
+                float v = nx[k];
+                if (col < net.P) v = (v - meta[EH_IMG_BNM + col]) * meta[EH_IMG_BNR + col];
+                ws[epk[k] & 0xFFFF] = v;
+            }
         fetch(tile + (int)gridDim.x);
-        __syncthreads();
+        eh_lds_barrier();
+        EH_STAMP(1);
 
         // ---- 2. layer 0, this wave's output blocks ----------------------------------------------
         {
@@ -196,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
                         HS[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH && TRAIN) ? z : eh_act<ACT>(z);
                     }
         }
-        __syncthreads();
+        eh_lds_barrier();
+        EH_STAMP(2);
         // ---- 3. hidden layers -------------------------------------------------------------------
 #pragma unroll
         for (int l = 1; l < NL; ++l) {
@@ -233,8 +282,9 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
                         const float z = acc[mm][t][r];
                         Hl[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH && TRAIN) ? z : eh_act<ACT>(z);
                     }
-            __syncthreads();
+            eh_lds_barrier();
         }
+        EH_STAMP(3);
         // ---- 4. output layer, split over K: this wave contracts its own feature blocks -------------
         {
             const float* W = wl + G::WO_OFF;
@@ -259,23 +309,43 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) OSP[(wave * 16 + 4 * g + r) * SR + 16 * t + c] = o[t][r];
         }
-        __syncthreads();
+        eh_lds_barrier();
+        // ---- 4b. all threads: sum the partials, sigmoid-scale into the parameter range (GenericHybridModel.jl:348-352)
+#pragma unroll
+        for (int u = 0; u < NEO; ++u) {
+            const int e = tid + u * NTH, k = e / MT, smp = e % MT;
+            if (k < net.K && (NEO * NTH == 16 * MT || e < 16 * MT)) {
+                float ov = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) ov += OSP[(16 * w + k) * SR + smp];
+                float pv = ov, sv = 1.0f;
+                if (net.scale_nn) {
+                    const float sgm = eh_sigmoid(ov);
+                    pv = fmaf(ksc[u], sgm, klo[u]);
+                    sv = ksc[u] * sgm * (1.0f - sgm);
+                }
+                OS[k * SR + smp] = pv;
+                SG[k * SR + smp] = sv;
+            }
+        }
+        eh_lds_barrier();
+        EH_STAMP(4);
         // ---- 5. mechanistic model + masked loss: wave 0, one sample per lane -----------------------
         if (mechw) {
-            float par[EH_MAX_PARAMS], sg[EH_MAX_PARAMS], dydp[EH_MAX_PARAMS];
+            float par[EH_MAX_PARAMS], sg[EH_MAX_PARAMS], dydp[EH_MAX_PARAMS], frc[EH_MAX_FORC], yobs[EH_MAX_TARG];
+#pragma unroll
+            for (int f = 0; f < EH_MAX_FORC; ++f) {
+                const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
+                frc[f] = col != 0xFFu ? RS[col * SR + lane] : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < EH_MAX_TARG; ++t) yobs[t] = t < net.T ? RS[(EH_MAX_FORC + t) * SR + lane] : __builtin_nanf("");
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
                 par[j] = meta[EH_IMG_PHI + j]; sg[j] = 1.0f; dydp[j] = 0.0f;
                 if (j < net.n_par && pkind(j) == EH_PAR_NEURAL) {
-                    const int k = pidx(j);
-                    const float ov = (OSP[k * SR + lane] + OSP[(16 + k) * SR + lane]) + (OSP[(32 + k) * SR + lane] + OSP[(48 + k) * SR + lane]);
-                    if (net.scale_nn) {
-                        const float s = eh_sigmoid(ov), sc = meta[EH_IMG_SC + j];
-                        par[j] = fmaf(sc, s, meta[EH_IMG_LO + j]);
-                        sg[j] = sc * s * (1.0f - s);
-                    } else {
-                        par[j] = ov;
-                    }
+                    par[j] = OS[pidx(j) * SR + lane];
+                    sg[j] = SG[pidx(j) * SR + lane];
                 }
             }
             const float y0 = eh_mech_eval(net.mech, par, frc, dydp);
@@ -329,7 +399,8 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
                 }
             }
         }
-        __syncthreads();
+        eh_lds_barrier();
+        EH_STAMP(5);
         if constexpr (!TRAIN) continue;
 
         // ---- 6. backward through the output layer ------------------------------------------------
@@ -384,7 +455,8 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) DZ[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = dzr[mm][t][r];
-        __syncthreads();
+        eh_lds_barrier();
+        EH_STAMP(6);
         // ---- 7. hidden layers backward -------------------------------------------------------------
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
@@ -429,7 +501,9 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
                         for (int t = 0; t < NT; ++t) dn[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[t][s], dn[mm][t], 0, 0, 0);
                     }
             }
-            __syncthreads();                         // every wave is done reading dZ_l
+            EH_STAMP(7);
+            eh_lds_barrier();                         // every wave is done reading dZ_l
+            EH_STAMP(8);
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
@@ -443,8 +517,9 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
                     }
                     aB[l - 1][mm] += dzr[mm][t];
                 }
-            __syncthreads();
+            eh_lds_barrier();
         }
+        EH_STAMP(9);
         // ---- 8. layer 0: dW0[own rows] += dZ_0 * X^T -------------------------------------------------
 #pragma unroll
         for (int mm = 0; mm < MB; ++mm) {
@@ -460,9 +535,11 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
                     for (int s = 0; s < 4; ++s) aW0[mm][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aW0[mm][n], 0, 0, 0);
                 }
         }
-        __syncthreads();                             // XS / OS / images are rewritten by the next tile
+        eh_lds_barrier();                             // XS / OS / images are rewritten by the next tile
+        EH_STAMP(10);
     }
 
+    EH_STAMP(11);
     // ---- 9. one partial per workgroup: the waves own disjoint entries, so they go straight to the slab
     float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
     if constexpr (!TRAIN) {
@@ -485,15 +562,15 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
             for (int r = 0; r < 4; ++r) aB[l][mm][r] = eh_row16_sum(aB[l][mm][r]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
-    struct I4 { int x, y, z, w; };
-    const I4* const cm = reinterpret_cast<const I4*>(a.cmap) + (long long)wave * WL.na * 64;
-    auto putc = [&](int k, const f32x4& v) {
-        const I4 ix = cm[k * 64 + lane];
-        if (ix.x >= 0) out[ix.x] = v[0];
-        if (ix.y >= 0) out[ix.y] = v[1];
-        if (ix.z >= 0) out[ix.z] = v[2];
-        if (ix.w >= 0) out[ix.w] = v[3];
-    };
+    // Stage the accumulators in LDS (image and workspace are dead now) as [wave][k][lane][4], then all
+    // threads write the canonical-order partial coalesced through the host-built position map (rmap);
+    // scattering them to the slab directly costs one 64-byte line per float.
+    float gs[EH_MAX_PARAMS];
+#pragma unroll
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) gs[j] = meta[EH_IMG_DPHI + j];
+    __syncthreads();
+    float* const st = smem + (long long)wave * WL.na * 256 + lane * 4;
+    auto putc = [&](int k, const f32x4& v) { *(f32x4*)&st[k * 256] = v; };
 #pragma unroll
     for (int mm = 0; mm < MB; ++mm) {
 #pragma unroll
@@ -506,7 +583,17 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
 #pragma unroll
         for (int l = 0; l < NL; ++l) putc(WL.kb + l * MB + mm, aB[l][mm]);
     }
-    putc(WL.kbo, aBo);                                // only wave 0's map has entries here
+    putc(WL.kbo, aBo);                                // only wave 0's copy is referenced
+    __syncthreads();
+    constexpr int GU = 16;                                    // independent map loads in flight per thread (each is an L2 round trip)
+    for (int i0 = tid; i0 < net.g_off; i0 += GU * NTH) {
+        int pos[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) pos[u] = (i0 + u * NTH < net.g_off) ? a.rmap[i0 + u * NTH] : 0;
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+            if (i0 + u * NTH < net.g_off) out[i0 + u * NTH] = smem[pos[u]];
+    }
     if (wave == 0) {
         lacc = eh_wave_sum(lacc); syacc = eh_wave_sum(syacc); syyacc = eh_wave_sum(syyacc);
 #pragma unroll
@@ -514,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
             if (t < net.T) cacc[t] = eh_wave_sum(cacc[t]);
 #pragma unroll
         for (int j = 0; j < EH_MAX_PARAMS; ++j)
-            if (j < net.n_par) gacc[j] = eh_wave_sum(gacc[j]) * meta[EH_IMG_DPHI + j];
+            if (j < net.n_par) gacc[j] = eh_wave_sum(gacc[j]) * gs[j];
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j)
@@ -527,4 +614,5 @@ __global__ __launch_bounds__(256, 1) void eh_wide_kernel(const EhNet net, const 
             out[net.n_theta + 2 + net.T] = syyacc;
         }
     }
+    EH_STAMP(12);
 }

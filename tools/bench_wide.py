@@ -14,6 +14,8 @@ import os
 P = int(os.environ.get("EH_P", "32"))
 spec, theta, X, f, y = tg._rs6_case(P, hidden, B)
 eng = util.load_engine(spec, theta, X, f, y)
+if "EH_VARIANT" in os.environ:
+    eng.set_option("variant", int(os.environ["EH_VARIANT"]))
 if "EH_ROW_SPLIT" in os.environ:
     eng.set_option("row_split", int(os.environ["EH_ROW_SPLIT"]))
 eng.opt_init("Adam", 1e-3)
@@ -27,4 +29,4 @@ eng.synchronize()
 dt = (time.perf_counter() - t0) / steps
 dims = [P, *hidden, 6]
 flops = 6 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
-print(f"P={P} row_split={os.environ.get('EH_ROW_SPLIT', 'default')} hidden={hidden} B={B}: {dt*1e6:.1f} us/step, {B/dt/1e9:.3f} G samples/s, {flops/dt/1e12:.1f} TFLOP/s (fwd+bwd, 6*B*sum(in*out))")
+print(f"P={P} variant={os.environ.get('EH_VARIANT', 'default')} row_split={os.environ.get('EH_ROW_SPLIT', 'default')} hidden={hidden} B={B}: {dt*1e6:.1f} us/step, {B/dt/1e9:.3f} G samples/s, {flops/dt/1e12:.1f} TFLOP/s (fwd+bwd, 6*B*sum(in*out))")
