@@ -201,7 +201,7 @@ __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const 
     // compiler keep the array in scratch memory (and every scratch read drains vmcnt, i.e. waits for
     // the record prefetch)
     float y = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, d4 = 0.0f, d5 = 0.0f;
-    const float p0 = par[0], p1 = par[1], p2 = par[2], p3 = par[3], p4 = par[4], p5 = par[5], f0 = frc[0], f1 = frc[1];
+    const float p0 = par[0], p1 = par[1], f0 = frc[0];
     switch (mech) {
         case EH_MECH_RBQ10: {   // reco = rb * Q10^(0.1 (ta - 15))    test/test_split_data_train.jl:36-39
             const float e = 0.1f * (f0 - 15.0f);
@@ -219,12 +219,14 @@ __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const 
             d0 = f0; d1 = 1.0f;
         } break;
         case EH_MECH_EXPO2POOL: {   // build-defined: R0a exp(ka T) + R0b exp(kb T)   (BASELINE.json config 3)
+            const float p2 = par[2], p3 = par[3];
             const float ea = __expf(p1 * f0), eb = __expf(p3 * f0);
             y = p0 * ea + p2 * eb;
             d0 = ea; d1 = p0 * ea * f0;
             d2 = eb; d3 = p2 * eb * f0;
         } break;
         case EH_MECH_RS_COMPONENTS: {   // R_soil = sum_c Rb_c Q10_c^(0.1 (ta-15))   src/models/Rs_components.jl:45-55
+            const float p2 = par[2], p3 = par[3], p4 = par[4], p5 = par[5];
             const float e = 0.1f * (f0 - 15.0f);
             const float q0 = eh_pow(p3, e), q1 = eh_pow(p4, e), q2 = eh_pow(p5, e);
             const float r0 = p0 * q0, r1 = p1 * q1, r2 = p2 * q2;
@@ -233,6 +235,7 @@ __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const 
             d3 = r0 * e * __builtin_amdgcn_rcpf(p3); d4 = r1 * e * __builtin_amdgcn_rcpf(p4); d5 = r2 * e * __builtin_amdgcn_rcpf(p5);
         } break;
         case EH_MECH_FLUXPART: {    // output 0: NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:66-74
+            const float p2 = par[2], f1 = frc[1];
             const float e = 0.1f * (f1 - 15.0f);
             const float p = eh_pow(p2, e);
             const float gq = f0 * (1.0f / 12.011f);
