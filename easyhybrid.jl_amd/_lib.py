@@ -74,6 +74,7 @@ SIGNATURES = {
     "eh_device_buffer": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "eh_profile_enable": (C.c_int32, [_H, C.c_int32]),
     "eh_profile_read": (C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "eh_profile_samples": (C.c_int32, [_H, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
     "eh_debug_stamps": (C.c_int32, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "eh_set_option": (C.c_int32, [_H, C.c_char_p, C.c_int64]),
 }

@@ -325,6 +325,8 @@ struct eh_handle_s {
     long long idx_cap = 0;
     // profiling
     bool prof = false;
+    int prof_stride = 1;            // events bracket bursts of this many steps (1 = every kernel of every step)
+    long long prof_k = 0;
     std::vector<hipEvent_t> ev;   // 3 per step: before step kernel, between, after reduce
     size_t ev_used = 0;
     unsigned long long* stamps = nullptr;   // diagnostic builds only
@@ -916,10 +918,12 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
 // one fused kernel: prologue applies the previous step's update, epilogue accumulates this step's sums
 static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, float* loss_slot_for_this_step) {
     const bool prof = h->prof && h->ev_used + 3 <= 3 * 8192;
+    const bool burst_first = h->prof_k % h->prof_stride == 0, burst_last = h->prof_k % h->prof_stride == h->prof_stride - 1;
     if (prof) {
         int rc = ensure_events(h, h->ev_used + 3);
         if (rc) return rc;
-        HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+        if (burst_first) HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+        h->prof_k++;
     }
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
@@ -934,7 +938,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;
     h->pending = true;
     h->pending_loss = loss_slot_for_this_step;
-    if (prof) {
+    if (prof && burst_last) {
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
         h->ev_used += 3;
@@ -955,15 +959,17 @@ static int ensure_events(eh_handle* h, size_t need) {
 static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool apply, bool raw, float* loss_slot) {
     const EhNet& net = h->net;
     const bool prof = h->prof && h->ev_used + 3 <= 3 * 8192;
+    const bool burst = h->prof_stride > 1, burst_first = h->prof_k % h->prof_stride == 0, burst_last = h->prof_k % h->prof_stride == h->prof_stride - 1;
     if (prof) {
         int rc = ensure_events(h, h->ev_used + 3);
         if (rc) return rc;
-        HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+        if (burst_first) HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+        h->prof_k++;
     }
     int grid = 1;
     int rc = launch_train_kernel(h, sp, idx, first, count, &grid, apply);
     if (rc) return rc;
-    if (prof) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+    if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
     const bool big = h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
     const int rgrid = big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
@@ -980,7 +986,8 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     }
 #undef EH_REDUCE_GO
     HIPCHK(h, hipGetLastError());
-    if (prof) {
+    if (prof && burst_last) {
+        if (burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
         HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
         h->ev_used += 3;
     }
@@ -1339,7 +1346,23 @@ int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n) {
 int32_t eh_profile_enable(eh_handle* h, int32_t on) {
     if (!h) return EH_EINVAL;
     h->prof = on != 0;
+    h->prof_stride = on > 1 ? on : 1;        // on = S > 1: one event pair around every burst of S consecutive steps
+    h->prof_k = 0;
     h->ev_used = 0;
+    return EH_OK;
+}
+
+int32_t eh_profile_samples(eh_handle* h, double* ms, int64_t cap, int64_t* n_out) {
+    if (!h || !n_out || (cap > 0 && !ms)) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int64_t n = std::min<int64_t>((int64_t)(h->ev_used / 3), cap);
+    for (int64_t i = 0; i < n; ++i) {
+        float t = 0;
+        HIPCHK(h, hipEventElapsedTime(&t, h->ev[3 * i], h->ev[3 * i + 2]));
+        ms[i] = t;
+    }
+    *n_out = n;
     return EH_OK;
 }
 

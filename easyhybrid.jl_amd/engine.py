@@ -221,8 +221,16 @@ class HybridEngine:
         return int(p.value), int(n.value)
 
     # -- profiling -------------------------------------------------------------------------------
-    def profile_enable(self, on: bool):
+    def profile_enable(self, on):
+        """False/0 off, True/1 = events around every kernel, S > 1 = one event pair per burst of S steps."""
         self._chk(self._lib.eh_profile_enable(self._h, int(on)))
+
+    def profile_samples(self, cap: int = 8192) -> np.ndarray:
+        """ms of every recorded step (or burst); call before profile_read, which consumes them."""
+        buf = np.empty(cap, np.float64)
+        n = C.c_int64()
+        self._chk(self._lib.eh_profile_samples(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n)))
+        return buf[:int(n.value)].copy()
 
     def profile_read(self):
         n = C.c_int64(); a = C.c_double(); b = C.c_double()

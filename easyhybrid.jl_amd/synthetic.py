@@ -41,3 +41,26 @@ def make_synth_expo2pool(n: int, seed: int = 42, nan_frac: float = 0.0):
     cols["T"] = T.astype(np.float32)
     cols["Resp_obs"] = resp.astype(np.float32)
     return cols
+
+
+RS6_PARAMS = {**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in ("het", "root", "myc")},
+              **{f"Q10_{c}": (2.0 + 0.3 * i, 1.0, 4.0) for i, c in enumerate(("het", "root", "myc"))}}
+
+
+def make_synth_fluxnet32(n: int, seed: int = 42, nan_frac: float = 0.0):
+    """BASELINE.json configs[4] stand-in: 32 covariates x0..x31, air temperature ta (the forcing the
+    Rs_components model reads), and a three-component soil-respiration target R_soil whose base rates
+    depend on the covariates.  -> dict of float32 columns."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((32, n)).astype(np.float32) * 0.5
+    ta = (10 + 10 * rng.standard_normal(n)).astype(np.float32)
+    e = 0.1 * (ta - 15.0)
+    rb = [1.0 + 0.8 * np.tanh(X[3 * c] + 0.5 * X[3 * c + 1]) for c in range(3)]
+    y = sum(rb[c] * np.power(1.6 + 0.4 * c, e) for c in range(3)).astype(np.float32)
+    y *= (1 + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    if nan_frac > 0:
+        y[rng.random(n) < nan_frac] = np.nan
+    cols = {f"x{i}": X[i] for i in range(32)}
+    cols["ta"] = ta
+    cols["R_soil"] = y
+    return cols

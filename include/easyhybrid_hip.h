@@ -207,6 +207,11 @@ int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* bu
  * events on its stream; eh_profile_read returns the number of launches and their mean duration. */
 int32_t eh_profile_enable(eh_handle* h, int32_t on);
 int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_kernel, double* mean_ms_reduce_kernel);
+/* on = S > 1 brackets bursts of S consecutive steps with ONE event pair (an event between two
+ * back-to-back kernels costs about as much as a small kernel; a burst measures the steady-state rate).
+ * eh_profile_samples copies out the duration in ms of every recorded step (S = 1) or burst (S > 1)
+ * without consuming them; call it before eh_profile_read. */
+int32_t eh_profile_samples(eh_handle* h, double* ms, int64_t cap, int64_t* n_out);
 
 /* diagnostic builds (make STAMPS=1) only: in-kernel phase stamps of workgroup 0 as (shader clock, 100 MHz clock)
  * pairs; the first call arms the buffer.  A normal build leaves the buffer zero. */

@@ -4,10 +4,10 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import easyhybrid_jl_amd as eh
-from easyhybrid_jl_amd.synthetic import EXPO2POOL_PARAMS, RBQ10_PARAMS, make_synth_expo2pool, make_synth_rbq10
+from easyhybrid_jl_amd.synthetic import EXPO2POOL_PARAMS, RBQ10_PARAMS, RS6_PARAMS, make_synth_expo2pool, make_synth_fluxnet32, make_synth_rbq10
 
 ap = argparse.ArgumentParser()
-ap.add_argument("config", choices=["c1", "c2", "c3"])
+ap.add_argument("config", choices=["c1", "c2", "c3", "c5"])
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--fused", type=int, default=1)
@@ -21,6 +21,14 @@ if a.config == "c3":
     cols = make_synth_expo2pool(a.nbatches * B, 1)
     X = np.stack([cols[f"x{i}"] for i in range(8)]); F = [cols["T"]]; Y = [cols["Resp_obs"]]
     flop, byts = 29184, 40
+elif a.config == "c5":          # configs[4]: MLP [32,128,128,6] + Rs_components (RbQ10 family, three pools), fp32 here
+    B = a.batch or 65536
+    model = eh.constructHybridModel([f"x{i}" for i in range(32)], ["ta"], ["R_soil"], eh.Rs_components, dict(RS6_PARAMS),
+                                    list(RS6_PARAMS), [], hidden_layers=[128, 128], activation="tanh", scale_nn_outputs=True)
+    cols = make_synth_fluxnet32(a.nbatches * B, 1)
+    X = np.stack([cols[f"x{i}"] for i in range(32)]); F = [cols["ta"]]; Y = [cols["R_soil"]]
+    flop, byts = 6 * (32 * 128 + 128 * 128 + 128 * 6), 4 * 34
+    a.fused = 0                   # the row-split kernel has no fused-update mode
 else:
     B = a.batch or (1024 if a.config == "c1" else 65536)
     model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"],
