@@ -12,7 +12,7 @@ import os
 EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 4, 8, 4, 4, 8
 EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE = 0, -1, -2, -3, -4, -5
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
-EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC = 0, 1, 2, 3, 4
+EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT = 0, 1, 2, 3, 4, 5
 
 ACTIVATIONS = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
 OPT_RULES = {"Adam": 0, "AdamW": 1, "RMSProp": 2, "Descent": 3}
@@ -70,6 +70,8 @@ SIGNATURES = {
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
     "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),
     "eh_dp_apply": (C.c_int32, [_H, _F]),
+    "eh_set_bn_shift": (C.c_int32, [_H, _F, C.c_int64]),
+    "eh_dp_bn_stats": (C.c_int32, [_H, C.c_int64, C.c_int64]),
     "eh_dp_fused_step": (C.c_int32, [_H, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "eh_device_buffer": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "eh_profile_enable": (C.c_int32, [_H, C.c_int32]),

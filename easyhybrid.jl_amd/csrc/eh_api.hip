@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C,
 
 // input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample
 // against cancellation.  part = [gridDim][64] (sum (x-c) | sum (x-c)^2 per predictor) then c[32].
-__global__ __launch_bounds__(1024) void eh_bn_stats_kernel(const float* recs, int C, int P, const int* idx, int first, int count, float* part) {
+// cshift != nullptr: shift by that common vector instead (sums of different GPUs must share their shift).
+__global__ __launch_bounds__(1024) void eh_bn_stats_kernel(const float* recs, int C, int P, const int* idx, int first, int count, float* part,
+                                                            const float* cshift) {
     __shared__ float red[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = idx ? idx[first] : first;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(1024) void eh_bn_stats_kernel(const float* recs, in
     for (int i = blockIdx.x * 1024 + tid; i < count; i += gridDim.x * 1024) {
         const int n = idx ? idx[first + i] : first + i;
         const float* r = recs + (long long)n * C;
-        const float* r0 = recs + (long long)n0 * C;
+        const float* r0 = cshift ? cshift : recs + (long long)n0 * C;
 #pragma unroll
         for (int p = 0; p < 32; ++p)
             if (p < P) { const float d = r[p] - r0[p]; s1[p] += d; s2[p] += d * d; }
@@ -215,8 +217,17 @@ __global__ __launch_bounds__(1024) void eh_bn_stats_kernel(const float* recs, in
         if ((tid & 31) < P)
             for (int w = 0; w < 16; ++w) a += red[w][tid];
         part[blockIdx.x * 64 + tid] = a;
-        if (blockIdx.x == 0 && tid < 32) part[gridDim.x * 64 + tid] = tid < P ? recs[(long long)n0 * C + tid] : 0.0f;
+        if (blockIdx.x == 0 && tid < 32) part[gridDim.x * 64 + tid] = tid < P ? (cshift ? cshift[tid] : recs[(long long)n0 * C + tid]) : 0.0f;
     }
+}
+
+// cross-GPU statistics: fold the workgroup partials of this GPU's shard into stat = [sum d (32) | sum d^2 (32) | n]
+__global__ __launch_bounds__(64) void eh_bn_fold_kernel(const float* part, int nblk, int count, float* stat) {
+    const int tid = threadIdx.x;
+    float a = 0.0f;
+    for (int b = 0; b < nblk; ++b) a += part[b * 64 + tid];
+    stat[tid] = a;
+    if (tid == 0) stat[64] = (float)count;
 }
 
 // keyed bijection of [0, n): 4-round Feistel network on 2*hb bits, cycle-walked into range.
@@ -309,6 +320,10 @@ struct eh_handle_s {
     bool bn_on = false;
     float* bn_part = nullptr;       // [32][64] partials + c[32]
     float* bn_run = nullptr;        // [2][32] running mean / var
+    float* bn_shift = nullptr;      // [32] common shift of the cross-GPU statistics (eh_set_bn_shift)
+    float* bn_stat = nullptr;       // [65] sum d | sum d^2 | n of the current step, all-reduced by the host (EH_BUF_BNSTAT)
+    bool bn_ext = false;            // bn_stat holds the statistics of the step about to run
+    bool bn_dp_update = false;
     bool opt_ready = false;
     EhOpt opt{};
     EhSplit split[2];
@@ -665,6 +680,10 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     if (h->bn_on) {
         HIPCHK_C(hipMalloc(&h->bn_part, (32 * 64 + 32) * sizeof(float)));
         HIPCHK_C(hipMalloc(&h->bn_run, 64 * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->bn_shift, 32 * sizeof(float)));
+        HIPCHK_C(hipMemset(h->bn_shift, 0, 32 * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->bn_stat, 68 * sizeof(float)));
+        HIPCHK_C(hipMemset(h->bn_stat, 0, 68 * sizeof(float)));
         float run0[64];
         for (int p = 0; p < 32; ++p) { run0[p] = 0.0f; run0[32 + p] = 1.0f; }     // LuxCore.initialstates(BatchNorm)
         HIPCHK_C(hipMemcpy(h->bn_run, run0, sizeof run0, hipMemcpyHostToDevice));
@@ -713,7 +732,7 @@ int32_t eh_destroy(eh_handle* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->pset);
-    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
@@ -886,11 +905,18 @@ static int grid_for(const eh_handle* h, long long count) {
 // input BatchNorm: statistics of the minibatch [first, first+count) -> a.bn_* (train-mode kernels only)
 static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool update, EhStepArgs* a) {
     a->bn_part = nullptr; a->bn_nblk = 0; a->bn_update = 0; a->bn_run = h->bn_run; a->image_out = h->image;
+    a->bn_c = nullptr; a->bn_n = nullptr;
     if (!h->bn_on || count <= 0) return EH_OK;
+    if (h->bn_ext) {          // statistics of the GLOBAL batch, summed over the GPUs by the host since eh_dp_bn_stats
+        a->bn_part = h->bn_stat; a->bn_nblk = 1; a->bn_c = h->bn_shift; a->bn_n = h->bn_stat + 64;
+        a->bn_update = (update || h->bn_dp_update) ? 1 : 0;
+        h->bn_ext = false; h->bn_dp_update = false;
+        return EH_OK;
+    }
     const int nblk = (int)std::max<long long>(1, std::min<long long>(32, (count + 1023) / 1024));
-    hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part);
+    hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part, nullptr);
     HIPCHK(h, hipGetLastError());
-    a->bn_part = h->bn_part; a->bn_nblk = nblk; a->bn_update = update ? 1 : 0;
+    a->bn_part = h->bn_part; a->bn_nblk = nblk; a->bn_c = h->bn_part + nblk * 64; a->bn_update = update ? 1 : 0;
     return EH_OK;
 }
 
@@ -1274,19 +1300,20 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
-    if (h->bn_on) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: input BatchNorm needs cross-GPU batch statistics (not built)");
+    if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
+    h->bn_dp_update = h->bn_on;
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
     int rc = check_window(h, sp, first, count, "eh_dp_grad");
     if (rc) return rc;
-    return do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
+    return do_step(h, sp, (!h->fused && h->perm_valid) ? h->perm : nullptr, first, count, false, true, nullptr);
 }
 
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index) {
     if (!h || !buffer_index) return EH_EINVAL;
     if (!h->fused) return fail(h, EH_ESTATE, "eh_dp_fused_step: set the fused_update option first");
-    if (h->bn_on) return fail(h, EH_EUNSUPPORTED, "eh_dp_fused_step: input BatchNorm needs cross-GPU batch statistics (not built)");
+    if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_fused_step: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_dp_fused_step: call eh_opt_init first");
     HIPCHK(h, hipSetDevice(h->device));
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
@@ -1294,6 +1321,33 @@ int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* bu
     if (rc) return rc;
     *buffer_index = (int32_t)(h->gstep % 3);
     return do_fused_step(h, sp, nullptr, first, count, nullptr);
+}
+
+int32_t eh_set_bn_shift(eh_handle* h, const float* shift, int64_t n) {
+    if (!h || !shift) return EH_EINVAL;
+    if (!h->bn_on) return fail(h, EH_ESTATE, "eh_set_bn_shift: the model has no input BatchNorm");
+    if (n != h->net.P) return fail(h, EH_EINVAL, "eh_set_bn_shift: n = %lld, model has %d predictors", (long long)n, h->net.P);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->bn_shift, shift, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return EH_OK;
+}
+
+int32_t eh_dp_bn_stats(eh_handle* h, int64_t first, int64_t count) {
+    if (!h) return EH_EINVAL;
+    if (!h->bn_on) return fail(h, EH_ESTATE, "eh_dp_bn_stats: the model has no input BatchNorm");
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    int rc = check_window(h, sp, first, count, "eh_dp_bn_stats");
+    if (rc) return rc;
+    const int* idx = (!h->fused && h->perm_valid) ? h->perm : nullptr;      // the same samples eh_dp_grad / eh_dp_fused_step will read
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(32, (count + 1023) / 1024));
+    hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part, h->bn_shift);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(eh_bn_fold_kernel, dim3(1), dim3(64), 0, h->stream, h->bn_part, nblk, (int)count, h->bn_stat);
+    HIPCHK(h, hipGetLastError());
+    h->bn_ext = true;
+    return EH_OK;
 }
 
 int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
@@ -1318,13 +1372,16 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
 
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {
     if (!h || !dev_ptr || !n_floats) return EH_EINVAL;
-    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
+    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC && which != EH_BUF_BNSTAT) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
     switch (which) {
         case EH_BUF_GRAD: *dev_ptr = h->gradbuf; *n_floats = h->n_acc; return EH_OK;
         case EH_BUF_THETA: *dev_ptr = TH(h); *n_floats = h->net.n_theta; return EH_OK;
         case EH_BUF_OPT_M: *dev_ptr = MM(h); *n_floats = h->net.n_theta; return EH_OK;
         case EH_BUF_OPT_V: *dev_ptr = VV(h); *n_floats = h->net.n_theta; return EH_OK;
         case EH_BUF_GACC: *dev_ptr = h->gacc; *n_floats = (int64_t)3 * EH_GSHARDS * h->n_acc; return EH_OK;
+        case EH_BUF_BNSTAT:
+            if (!h->bn_on) return fail(h, EH_ESTATE, "eh_device_buffer: the model has no input BatchNorm");
+            *dev_ptr = h->bn_stat; *n_floats = 65; return EH_OK;
         default: return fail(h, EH_EINVAL, "eh_device_buffer: which = %d", which);
     }
 }

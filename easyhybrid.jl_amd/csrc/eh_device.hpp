@@ -129,8 +129,10 @@ struct EhStepArgs {
     unsigned long long* stamps;   // diagnostic builds (-DEH_STAMPS) only: [16][2] (shader clock, 100 MHz wall clock)
     EhFused fz;
     // input BatchNorm, train mode: per-workgroup partial sums of the batch from eh_bn_stats_kernel
-    const float* bn_part;   // [bn_nblk][64] (sum (x-c), sum (x-c)^2 per predictor), then c[32]; nullptr = use the image's statistics
+    const float* bn_part;   // [bn_nblk][64] (sum (x-c), sum (x-c)^2 per predictor); nullptr = use the image's statistics
     int bn_nblk;
+    const float* bn_c;      // [32] the shift c the partial sums were taken around
+    const float* bn_n;      // number of samples behind the sums when it is not `count` (cross-GPU statistics), else nullptr
     int bn_update;          // workgroup 0 also updates the running statistics (a real training step)
     float* bn_run;          // [2][32] running mean, running var
     float* image_out;       // global parameter image: its normalisation block follows the running statistics
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         if (tid < net.P) {
             float s1 = 0.0f, s2 = 0.0f;
             for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
-            const float m = (float)count, c0 = a.bn_part[a.bn_nblk * 64 + tid];
+            const float m = a.bn_n ? *a.bn_n : (float)count, c0 = a.bn_c[tid];
             const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
             wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
             wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
         if (tid < net.P) {
             float s1 = 0.0f, s2 = 0.0f;
             for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
-            const float m = (float)count, c0 = a.bn_part[a.bn_nblk * 64 + tid];
+            const float m = a.bn_n ? *a.bn_n : (float)count, c0 = a.bn_c[tid];
             const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
             wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
             wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);

@@ -72,8 +72,24 @@ class DataParallel:
             self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=dev) for k in range(3)]
         # run the engine on torch's current stream so kernels and the collective are ordered
         engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.bn = bool(engine.desc.input_batchnorm)
+        if self.bn:
+            # input BatchNorm normalises with the statistics of the GLOBAL minibatch: a second, 65-float
+            # all-reduce per step ahead of the step kernel.  Every rank shifts its sums by the same
+            # vector (the mean of the whole training set) so they can be added.
+            bptr, bn_n = engine.device_buffer(L.EH_BUF_BNSTAT)
+            self.bnbuf = torch.as_tensor(_DevArray(bptr, bn_n), device=dev)
+            sx, n = engine.x_sum.get(L.EH_SPLIT_TRAIN, (None, 0))
+            if sx is None:
+                raise RuntimeError("DataParallel with input BatchNorm needs the train split uploaded through set_data first")
+            tot = torch.tensor(list(sx) + [float(n)], dtype=torch.float64, device=dev)
+            allreduce_partials(tot, group)
+            engine.set_bn_shift((tot[:-1] / tot[-1]).cpu().numpy())
 
     def step(self, first: int, count: int, want_loss: bool = False):
+        if self.bn:
+            self.engine.dp_bn_stats(first, count)
+            allreduce_partials(self.bnbuf, self.group)
         if self.fused and not want_loss:
             k = self.engine.dp_fused_step(first, count)
             allreduce_partials(self.gacc[k], self.group)      # 8 shards x (n_theta + 2) raw sums

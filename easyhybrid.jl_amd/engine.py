@@ -52,6 +52,7 @@ class HybridEngine:
         self.target_names = list(target_names)
         self.param_names = list(param_names)
         self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
+        self.x_sum = {}
 
     # -- plumbing --------------------------------------------------------------------------------
     def _chk(self, st: int):
@@ -87,6 +88,7 @@ class HybridEngine:
             raise ValueError(f"X has {P} predictor rows, model expects {self.desc.n_predictors}")
         if len(forcings) != self.desc.n_forcings or len(targets) != self.desc.n_targets:
             raise ValueError("number of forcing / target arrays does not match the model")
+        self.x_sum[split] = (X.sum(axis=1, dtype=np.float64), N)      # for the common BatchNorm shift under data parallelism
         xf = np.asfortranarray(X)                       # (P x N) column-major == N records of P
         fs = [np.ascontiguousarray(f, np.float32) for f in forcings]
         ts = [np.ascontiguousarray(t, np.float32) for t in targets]
@@ -203,6 +205,14 @@ class HybridEngine:
     # -- data-parallel seam ----------------------------------------------------------------------
     def dp_grad(self, first: int, count: int):
         self._chk(self._lib.eh_dp_grad(self._h, first, count))
+
+    def set_bn_shift(self, shift):
+        """common per-predictor shift of the cross-GPU BatchNorm sums (every rank must pass the same vector)"""
+        c = np.ascontiguousarray(shift, np.float32)
+        self._chk(self._lib.eh_set_bn_shift(self._h, _fptr(c), c.size))
+
+    def dp_bn_stats(self, first: int, count: int):
+        self._chk(self._lib.eh_dp_bn_stats(self._h, first, count))
 
     def dp_apply(self, want_loss: bool = False):
         loss = C.c_float()

@@ -83,7 +83,7 @@ typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2
 typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LOSS_NSELOSS = 3 } eh_loss;
 
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
-typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4 } eh_buffer;
+typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4, EH_BUF_BNSTAT = 5 } eh_buffer;
 
 typedef struct eh_model_desc {
     int32_t struct_size;                     /* = sizeof(eh_model_desc) */
@@ -193,6 +193,16 @@ int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_ta
  * so shards exchange sums and counts, never per-shard means.  Single-target models only (T == 1). */
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count);
 int32_t eh_dp_apply(eh_handle* h, float* loss_out);
+
+/* Input BatchNorm under data parallelism (Lux BatchNorm normalises with the statistics of the WHOLE
+ * minibatch, src/models/NNModels.jl:97-105): before eh_dp_grad / eh_dp_fused_step of a step,
+ *   eh_dp_bn_stats : this shard's sums into EH_BUF_BNSTAT = [ sum (x-c) (32) | sum (x-c)^2 (32) | n ]  (65 floats)
+ *   (host: all_reduce(SUM) over that buffer)
+ * and the step kernel normalises with the global mean / variance and updates the (replicated)
+ * running statistics.  c is a per-predictor shift every rank must share (eh_set_bn_shift, e.g. the
+ * mean of the whole training set); it only guards the variance against cancellation. */
+int32_t eh_set_bn_shift(eh_handle* h, const float* shift, int64_t n);
+int32_t eh_dp_bn_stats(eh_handle* h, int64_t first, int64_t count);
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats);
 
 /* One-kernel-per-step variant of the data-parallel seam (needs eh_set_option("fused_update", 1)):

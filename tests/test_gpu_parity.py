@@ -762,3 +762,66 @@ def test_row_split_option_agrees_with_per_wave_kernel(hidden):
     with pytest.raises(NotImplementedError, match="row_split"):
         narrow.set_option("row_split", 1)
     narrow.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# input BatchNorm under data parallelism: global batch statistics through a second all-reduce
+# ----------------------------------------------------------------------------------------------
+def test_sync_batchnorm_virtual_shards_equal_single_step():
+    import torch
+    spec, theta, X, f, y = _bn_case(2048)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    l_ref = ref.train_step(0, 2048)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    with pytest.raises(eh.EngineError, match="eh_dp_bn_stats"):
+        eng.dp_grad(0, 512)                                   # BatchNorm without the global statistics is refused
+    eng.set_bn_shift(X.mean(axis=1))
+    gptr, gn = eng.device_buffer(eh._lib.EH_BUF_GRAD)
+    bptr, bn = eng.device_buffer(eh._lib.EH_BUF_BNSTAT)
+    gbuf = torch.as_tensor(eh.dp._DevArray(gptr, gn), device="cuda")
+    bbuf = torch.as_tensor(eh.dp._DevArray(bptr, bn), device="cuda")
+    stat = torch.zeros_like(bbuf)
+    for k in range(4):                                        # first all-reduce: [sum (x-c) | sum (x-c)^2 | n] of every shard
+        eng.dp_bn_stats(k * 512, 512); eng.synchronize()
+        stat += bbuf
+    assert float(stat[64]) == 2048
+    acc = torch.zeros_like(gbuf)
+    for k in range(4):                                        # every "rank" runs its shard with the GLOBAL statistics
+        eng.dp_bn_stats(k * 512, 512); eng.synchronize()
+        bbuf.copy_(stat); torch.cuda.synchronize()
+        eng.dp_grad(k * 512, 512); eng.synchronize()
+        acc += gbuf
+    gbuf.copy_(acc); torch.cuda.synchronize()
+    l = eng.dp_apply(want_loss=True)
+    assert l == pytest.approx(l_ref, rel=1e-5)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-6
+    ref.close(); eng.close()
+
+
+def test_sync_batchnorm_data_parallel_driver_world_size_one_nccl():
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec, theta, X, f, y = _bn_case(4096)
+        ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+        for i in range(8):
+            ref.train_step(i * 512, 512, want_loss=False)
+        rm0, rv0 = ref.get_bn_state()
+        for fused in (True, False):
+            eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+            drv = eh.dp.DataParallel(eng, fused=fused)
+            for i in range(8):
+                drv.step(i * 512, 512)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-5, fused
+            rm, rv = eng.get_bn_state()
+            assert util.relerr(rm, rm0) <= 1e-5 and util.relerr(rv, rv0) <= 1e-5, fused
+            eng.close()
+        ref.close()
+    finally:
+        dist.destroy_process_group()
