@@ -46,6 +46,16 @@ def normalise(buf, n_theta: int, kind: str = "mse"):
     return buf[:n_theta] / n, S / n, n
 
 
+def bn_moments(stat, shift):
+    """[sum (x-c) (32) | sum (x-c)^2 (32) | n] summed over the ranks -> (mean, biased variance) per predictor.
+    Same arithmetic as the BatchNorm prologue of the step kernel (csrc/eh_device.hpp)."""
+    P = len(shift)
+    n = float(stat[64])
+    d = stat[:P] / n
+    var = (stat[32:32 + P] / n - d * d).clip(0)
+    return shift + d, var
+
+
 class _DevArray:
     """__cuda_array_interface__ view of a library-owned device buffer (no copy, no torch types in the ABI)."""
 

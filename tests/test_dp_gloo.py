@@ -93,3 +93,38 @@ def test_normalise_other_losses_from_raw_sums(kind):
         parts.append(np.concatenate([gm * sum(nv), [lm * sum(nv), sum(nv), yv.sum(), (yv ** 2).sum()]]))
     g, loss, n = dp.normalise(torch.from_numpy(sum(parts)), spec.n_theta, kind)
     assert loss == pytest.approx(l0, rel=1e-10) and np.max(np.abs(g.numpy() - g0)) <= 1e-10 * np.max(np.abs(g0))
+
+
+def _bn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    N, P = 301, 5
+    X = rng.standard_normal((P, N)) * np.array([20.0, 1.0, 0.1, 5.0, 300.0])[:, None] + np.array([50.0, 0.0, 3.0, -7.0, 290.0])[:, None]
+    lo, hi = dp.shard_range(N, rank, world)
+    # the common shift: global mean through an all-reduce of (sum, n), as DataParallel.__init__ does
+    tot = torch.from_numpy(np.concatenate([X[:, lo:hi].sum(axis=1), [hi - lo]]))
+    dp.allreduce_partials(tot)
+    shift = (tot[:-1] / tot[-1]).numpy()
+    stat = np.zeros(65)
+    d = X[:, lo:hi] - shift[:, None]
+    stat[:P] = d.sum(axis=1); stat[32:32 + P] = (d * d).sum(axis=1); stat[64] = hi - lo      # what eh_dp_bn_stats leaves in EH_BUF_BNSTAT
+    buf = torch.from_numpy(stat)
+    dp.allreduce_partials(buf)
+    mean, var = dp.bn_moments(buf.numpy(), shift)
+    ok = np.allclose(mean, X.mean(axis=1), rtol=1e-12) and np.allclose(var, X.var(axis=1), rtol=1e-10) and float(buf[64]) == N
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_dp_batchnorm_statistics_are_those_of_the_global_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
