@@ -149,8 +149,11 @@ def main():
         if dp is None:
             run(nprof, args.warmup + args.steps)
         else:
-            for s in range(nprof):
-                eng.dp_grad(((s) % NBATCHES) * B, B)               # local part only: no collective inside the bracket
+            for s in range(nprof):                                 # local part only: no collective inside the bracket
+                if dp.fused:
+                    eng.dp_fused_step((s % NBATCHES) * B, B)
+                else:
+                    eng.dp_grad((s % NBATCHES) * B, B)
         per_launch = eng.profile_samples() / BURST                 # ms per launch, one value per burst
         n, _, _ = eng.profile_read()
         eng.profile_enable(False)
@@ -163,15 +166,15 @@ def main():
             traffic, traffic_src = None, None
             try:      # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-                if tj.get("batch") == B and tj.get("fused") == (dp is None):
+                if tj.get("batch") == B and tj.get("fused") == (dp is None or dp.fused):
                     traffic, traffic_src = (2.0 * tj["FETCH_SIZE_KiB"] + tj["WRITE_SIZE_KiB"]) * 1024.0, tj["source"]
             except Exception:
                 pass
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if dp is None else
-                    "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS>", "kernel_ms": ms_step, "launches_timed": n,
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if (dp is None or dp.fused) else
+                    "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> + eh_reduce_kernel", "kernel_ms": ms_step, "launches_timed": n,
                     "kernel_ms_p10_p50_p90": [float(np.percentile(per_launch, q)) for q in (10, 50, 90)],
-                    "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce/Adam kernel per launch)" if dp is not None else ""),
+                    "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce kernel per launch)" if (dp is not None and not dp.fused) else ""),
                     "algorithmic": {"flop_per_launch": FLOP_PER_SAMPLE * B, "bytes_per_launch": BYTES_PER_SAMPLE * B},
                     "hbm_achieved_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBPS}
     loss = None

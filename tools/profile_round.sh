@@ -11,11 +11,20 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq.err
 timeout 300 python3 bench.py --steps 3000 --warmup 300 > $OUT/bench.json 2> $OUT/bench.err
+# the other BASELINE shapes: kernel trace of the front-door step loop (tools/bench_config.py)
+for cfg in c3 c5; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$cfg -- python3 tools/bench_config.py $cfg --steps 200 --fused 0 > $OUT/bench_config_$cfg.json 2> $OUT/trace_$cfg.err
+done
+timeout 120 python3 tools/bench_config.py c5 --steps 100 --batch 262144 > $OUT/bench_config_c5_b262144.json 2>/dev/null
+timeout 120 python3 tools/bench_config.py c5 --steps 30 --batch 1048576 --nbatches 2 > $OUT/bench_config_c5_b1048576.json 2>/dev/null
+timeout 120 python3 tools/bench_config.py c3 --steps 100 --batch 1048576 --nbatches 2 --fused 0 > $OUT/bench_config_c3_b1048576.json 2>/dev/null
+timeout 120 python3 tools/bench_config.py c2 --steps 300 --batch 1048576 --nbatches 4 > $OUT/bench_config_c2_b1048576.json 2>/dev/null
+timeout 120 python3 tools/bench_config.py c1 --steps 1000 > $OUT/bench_config_c1.json 2>/dev/null
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
-    print(open(f).read())
+for f in sorted(glob.glob(out + "/trace*/**/*kernel_stats.csv", recursive=True)):
+    print(f); print(open(f).read())
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
