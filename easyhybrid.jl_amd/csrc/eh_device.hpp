@@ -713,6 +713,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                     }
                 }
             }
+            // Settle the next tile's record prefetch here, mid-tile, rather than at the loop top where its
+            // registers are consumed: measured 2 % faster at 16 tiles per wave (the wait is almost always
+            // free at this point and the next prefetch then issues without a stall).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float y0 = eh_mech_eval(net.mech, par, frc, dydp);
             float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
             if (multiOn != 0.0f) eh_mech_extra(net.mech, par, frc, yx, Jx);
