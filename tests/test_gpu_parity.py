@@ -825,3 +825,96 @@ def test_sync_batchnorm_data_parallel_driver_world_size_one_nccl():
         ref.close()
     finally:
         dist.destroy_process_group()
+
+
+# the row-split kernel has its own record staging, mechanistic stage and epilogue: run the feature matrix through it too
+def test_width_128_gather_indices_and_windows():
+    spec, theta, X, f, y = _rs6_case(32, (128, 128), 3000)
+    eng = util.load_engine(spec, theta, X, f, y)
+    _check_grad(spec, theta, X, f, y, eng, first=137, count=701)
+    idx = np.random.default_rng(3).permutation(3000)[:1111].astype(np.int32)
+    _check_grad(spec, theta, X, f, y, eng, idx=idx)
+    _check_grad(spec, theta, X, f, y, eng, idx=idx[:7])
+    eng.close()
+
+
+def test_width_128_all_masked_batch_and_epoch_driver():
+    spec, theta, X, f, y = _rs6_case(20, (80, 128), 1000)
+    name = list(y)[0]
+    eng = util.load_engine(spec, theta, X, f, {name: np.full(1000, np.nan, np.float32)})
+    loss, grad, nv = eng.loss_and_grad()
+    assert np.isnan(loss) and nv == 0 and not grad.any()
+    eng.close()
+    a = util.load_engine(spec, theta, X, f, y); a.opt_init("Adam", 0.002)
+    b = util.load_engine(spec, theta, X, f, y); b.opt_init("Adam", 0.002)
+    mean_loss, ns = a.train_epoch(300, shuffle=False)
+    losses = [b.train_step(s, min(300, 1000 - s)) for s in range(0, 1000, 300)]
+    assert ns == 4 and np.array_equal(a.get_params(), b.get_params())
+    assert mean_loss == pytest.approx(np.mean(losses), rel=1e-6)
+    a.opt_init("Descent", 0.0)                              # nothing moves: a shuffled full-batch epoch visits every sample once
+    l_plain, _ = a.train_epoch(1000, shuffle=False)
+    l_shuf, _ = a.train_epoch(1000, seed=7, shuffle=True)
+    assert l_shuf == pytest.approx(l_plain, rel=1e-5)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind", ["rmse", "mae", "nseLoss"])
+def test_width_128_other_training_losses(kind):
+    spec, theta, X, f, y = _rs6_case(32, (128, 96), 1200)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.close()
+
+
+def test_width_128_input_batchnorm():
+    spec, theta, X, f, y = _rs6_case(32, (128, 128), 1500)
+    spec.input_batchnorm = True
+    X = (X * np.linspace(1, 40, 32)[:, None] + np.linspace(-100, 300, 32)[:, None]).astype(np.float32)      # raw-looking predictors
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, bn_state=ho.bn_init(spec))
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.opt_init("Adam", 0.002)
+    batches = [(i * 250, 250) for i in range(6)]
+    losses = [eng.train_step(*b) for b in batches]
+    st = ho.bn_init(spec)
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, lr=0.002, dtype=np.float32, bn_state=st)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    rm, rv = eng.get_bn_state()
+    assert util.relerr(rm, st["mean"]) <= 1e-5 and util.relerr(rv, st["var"]) <= 1e-5
+    out = eng.forward(0, params=False)                      # test mode: running statistics
+    ref = ho.forward(spec, eng.get_params().astype(np.float64), X, f, bn_state=st, train_mode=False)
+    assert util.relerr(out[list(y)[0]], ref[list(y)[0]]) <= 2e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("targets,nets", [
+    (["RECO", "GPP", "NEE"], None),
+    (["NEE", "RECO"], [([0, 1], [64, 48]), ([2, 3], [64, 80])]),        # two nets side by side: block-diagonal layers of width 128
+])
+def test_width_128_fluxpart_multi_target_and_multinn(targets, nets):
+    B = 900
+    X, f, y = _flux_data(B)
+    spec = ho.HybridSpec(4, [96, 128], "fluxpart", dict(FLUX_PARAMS), ["RUE", "Rb"], ["Q10"], targets, "tanh", True, nets=nets)
+    theta = ho.init_theta(spec, 2, np.float32)
+    yt = {t: y[t] for t in targets}
+    eng = util.load_engine(spec, theta, X, f, yt)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, yt)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    m, _ = eng.eval(0)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    for i, t in enumerate(targets):
+        yy = yt[t].astype(np.float64)
+        assert m[i]["mse"] == pytest.approx(ho.loss_fn(ref[t], yy, ~np.isnan(yy), "mse"), rel=3e-5)
+    eng.opt_init("Adam", 0.003)
+    batches = [(i * 150, 150) for i in range(6)]
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, yt, batches, lr=0.003, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    eng.close()
