@@ -13,7 +13,8 @@ module EasyHybridHIP
 
 using Libdl
 
-export constructHybridModel, SingleNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model
+export constructHybridModel, SingleNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model,
+    LinearHM, Expo2Pool, Rs_components, FluxPartModelQ10
 
 const LIB = Ref{String}(get(ENV, "EASYHYBRID_HIP_LIB", joinpath(@__DIR__, "..", "..", "..", "libeasyhybrid_hip.so")))
 
@@ -63,9 +64,25 @@ end
 
 RbQ10(; ta, Q10, rb, tref = 15.0f0) = (; reco = rb .* Q10 .^ (0.1f0 .* (ta .- tref)), Q10, rb)       # test/test_split_data_train.jl:36-39
 Expo_resp_model(; T, Resp0, k) = (; Resp_obs = Resp0 .* exp.(k .* T), Resp0, k)                      # projects/ExpoHybrid/ExpoHybridEstim.jl:69-85
+LinearHM(; x, alpha, beta) = (; obs = alpha .* x .+ beta, alpha, beta)                                   # src/models/LinearHM.jl:61-68
+Expo2Pool(; T, R0a, ka, R0b, kb) = (; Resp_obs = R0a .* exp.(ka .* T) .+ R0b .* exp.(kb .* T), R0a, ka, R0b, kb)   # build-defined (BASELINE config 3)
+function Rs_components(; ta, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc, tref = 15.0f0)       # src/models/Rs_components.jl:40-57
+    e = 0.1f0 .* (ta .- tref)
+    R_het = Rb_het .* Q10_het .^ e; R_root = Rb_root .* Q10_root .^ e; R_myc = Rb_myc .* Q10_myc .^ e
+    return (; R_soil = R_het .+ R_root .+ R_myc, R_het, R_root, R_myc)
+end
+function FluxPartModelQ10(; SW_IN, TA, RUE, Rb, Q10, tref = 15.0f0)                                     # src/models/FluxPartModel_Q10_Lux.jl:66-74
+    GPP = SW_IN .* RUE ./ 12.011f0
+    RECO = Rb .* Q10 .^ (0.1f0 .* (TA .- tref))
+    return (; NEE = RECO .- GPP, GPP, RECO)
+end
 const MECH = IdDict{Any, MechSpec}(
     RbQ10 => MechSpec(0, [:rb, :Q10], [:ta], [:reco]),
     Expo_resp_model => MechSpec(1, [:Resp0, :k], [:T], [:Resp_obs]),
+    LinearHM => MechSpec(2, [:alpha, :beta], [:x], [:obs]),
+    Expo2Pool => MechSpec(3, [:R0a, :ka, :R0b, :kb], [:T], [:Resp_obs]),
+    Rs_components => MechSpec(4, [:Rb_het, :Rb_root, :Rb_myc, :Q10_het, :Q10_root, :Q10_myc], [:ta], [:R_soil]),
+    FluxPartModelQ10 => MechSpec(5, [:RUE, :Rb, :Q10], [:SW_IN, :TA], [:NEE, :GPP, :RECO]),
 )
 "Register another Julia function under one of the device model ids (see include/easyhybrid_hip.h)."
 register_mechanistic!(f, spec::MechSpec) = (MECH[f] = spec)
@@ -178,6 +195,33 @@ function get_params(e::HybridEngine)
 end
 opt_init!(e::HybridEngine; rule = 0, eta = 0.01f0, beta = (0.9f0, 0.999f0), epsilon = 1.0f-8, lambda = 0.0f0) =
     check(e, @ccall LIB[].eh_opt_init(e.h::Ptr{Cvoid}, rule::Int32, eta::Float32, beta[1]::Float32, beta[2]::Float32, epsilon::Float32, lambda::Float32)::Int32)
+
+"engine options: :max_blocks, :variant, :fast_paths, :row_split, :fused_update, :training_loss (0 mse, 1 rmse, 2 mae, 3 nseLoss)"
+set_option!(e::HybridEngine, name::Symbol, value::Integer) =
+    check(e, @ccall LIB[].eh_set_option(e.h::Ptr{Cvoid}, String(name)::Cstring, value::Int64)::Int32)
+synchronize(e::HybridEngine) = check(e, @ccall LIB[].eh_synchronize(e.h::Ptr{Cvoid})::Int32)
+
+# data-parallel seam (one process per GPU; the caller all-reduces the device buffers with RCCL / ROCm-aware MPI)
+const EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT = Int32(0), Int32(4), Int32(5)
+function device_buffer(e::HybridEngine, which::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL); n = Ref{Int64}(0)
+    check(e, @ccall LIB[].eh_device_buffer(e.h::Ptr{Cvoid}, which::Int32, p::Ref{Ptr{Cvoid}}, n::Ref{Int64})::Int32)
+    return Ptr{Float32}(p[]), n[]
+end
+dp_grad!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_grad(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)
+function dp_apply!(e::HybridEngine)
+    loss = Ref{Float32}(NaN32)
+    check(e, @ccall LIB[].eh_dp_apply(e.h::Ptr{Cvoid}, loss::Ref{Float32})::Int32)
+    return loss[]
+end
+function dp_fused_step!(e::HybridEngine, first::Integer, count::Integer)
+    k = Ref{Int32}(0)
+    check(e, @ccall LIB[].eh_dp_fused_step(e.h::Ptr{Cvoid}, first::Int64, count::Int64, k::Ref{Int32})::Int32)
+    return k[]          # which third of EH_BUF_GACC to all-reduce
+end
+"input BatchNorm under DP: shard sums into EH_BUF_BNSTAT (all-reduce it before dp_grad! / dp_fused_step!)"
+set_bn_shift!(e::HybridEngine, c::Vector{Float32}) = check(e, @ccall LIB[].eh_set_bn_shift(e.h::Ptr{Cvoid}, c::Ptr{Float32}, length(c)::Int64)::Int32)
+dp_bn_stats!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_bn_stats(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)
 
 "one Lux.Training.single_train_step! (src/training/epoch.jl:20-26) on train samples first+1 : first+count"
 function train_step!(e::HybridEngine, first::Integer, count::Integer)

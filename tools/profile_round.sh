@@ -15,6 +15,12 @@ timeout 300 python3 bench.py --steps 3000 --warmup 300 > $OUT/bench.json 2> $OUT
 for cfg in c3 c5; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$cfg -- python3 tools/bench_config.py $cfg --steps 200 --fused 0 > $OUT/bench_config_$cfg.json 2> $OUT/trace_$cfg.err
 done
+# MFMA utilisation and HBM traffic of the MFMA-bound shapes (separate PMC passes)
+for cfg in c3 c5; do
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_$cfg -- python3 tools/bench_config.py $cfg --steps 20 --fused 0 > /dev/null 2> $OUT/pmc_mfma_$cfg.err
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$cfg -- python3 tools/bench_config.py $cfg --steps 20 --fused 0 > /dev/null 2> $OUT/pmc_fetch_$cfg.err
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$cfg -- python3 tools/bench_config.py $cfg --steps 20 --fused 0 > /dev/null 2> $OUT/pmc_write_$cfg.err
+done
 timeout 120 python3 tools/bench_config.py c5 --steps 100 --batch 262144 > $OUT/bench_config_c5_b262144.json 2>/dev/null
 timeout 120 python3 tools/bench_config.py c5 --steps 30 --batch 1048576 --nbatches 2 > $OUT/bench_config_c5_b1048576.json 2>/dev/null
 timeout 120 python3 tools/bench_config.py c3 --steps 100 --batch 1048576 --nbatches 2 --fused 0 > $OUT/bench_config_c3_b1048576.json 2>/dev/null
@@ -25,7 +31,7 @@ import csv, glob, sys, collections
 out = sys.argv[1]
 for f in sorted(glob.glob(out + "/trace*/**/*kernel_stats.csv", recursive=True)):
     print(f); print(open(f).read())
-for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mfma_c3", "pmc_fetch_c3", "pmc_write_c3", "pmc_mfma_c5", "pmc_fetch_c5", "pmc_write_c5"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
