@@ -127,6 +127,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if dp is not None and dp.p2p:
+        # burn-in of the peer-to-peer exchange: a deadline hit on any rank drops every rank back to the RCCL all-reduce
+        run(64, 0)
+        dp.check()
     run(args.warmup, 0)
     fence()
     t0 = time.perf_counter()
@@ -140,14 +144,19 @@ def main():
 
     # live kernel timing: the same K steps again with HIP events bracketing the fused step kernel
     roof = None
-    if rank == 0:
+    if rank == 0 or dp is not None:
         # one HIP event pair (on the engine's stream) around every burst of BURST consecutive launches: an event
-        # between two back-to-back 13 us kernels would add ~2 us to each, a burst measures the steady-state rate
+        # between two back-to-back 13 us kernels would add ~2 us to each, a burst measures the steady-state rate.
+        # Under data parallelism every rank runs the loop (the step kernels of the peer-to-peer mode wait for each
+        # other), with the exchange inside the bracket when it is part of the kernel.
         BURST = 50
         nprof = max(BURST, min(args.steps, 4000) // BURST * BURST)
         eng.profile_enable(BURST)
         if dp is None:
             run(nprof, args.warmup + args.steps)
+        elif dp.p2p:
+            for s in range(nprof):
+                dp.step((s % NBATCHES) * B, B)
         else:
             for s in range(nprof):                                 # local part only: no collective inside the bracket
                 if dp.fused:
@@ -160,6 +169,9 @@ def main():
         n *= BURST
         ms_step = float(per_launch.mean()) if per_launch.size else 0.0
         ms_red = 0.0
+        if dp is not None and dp.p2p:
+            fence()
+    if rank == 0:
         if n and ms_step > 0:
             tf = FLOP_PER_SAMPLE * B / (ms_step * 1e-3) / 1e12
             gbs = BYTES_PER_SAMPLE * B / (ms_step * 1e-3) / 1e9
@@ -174,7 +186,8 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if (dp is None or dp.fused) else
                     "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> + eh_reduce_kernel", "kernel_ms": ms_step, "launches_timed": n,
                     "kernel_ms_p10_p50_p90": [float(np.percentile(per_launch, q)) for q in (10, 50, 90)],
-                    "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce kernel per launch)" if (dp is not None and not dp.fused) else ""),
+                    "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce kernel per launch)" if (dp is not None and not dp.fused) else "")
+                              + (" (includes the wait for the peer GPUs' sums: the exchange is part of the kernel)" if (dp is not None and dp.p2p) else ""),
                     "algorithmic": {"flop_per_launch": FLOP_PER_SAMPLE * B, "bytes_per_launch": BYTES_PER_SAMPLE * B},
                     "hbm_achieved_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBPS}
     loss = None
@@ -189,7 +202,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RbQ10 hybrid, MLP [2,16,16,1] tanh -> rb (sigmoid-scaled), Q10 global, MSE + Adam(0.01), "
                                    f"batch={B} per GPU, fp32 (BASELINE.json configs[1])",
-                       "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}",
+                       "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
+                                             else "one RCCL all-reduce per step")},
             "roofline": roof,
         }
         out["dataset_upload_ms_once"] = 1e3 * t_up

@@ -117,20 +117,23 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
 
 // fused-update mode: apply the still-pending gradient (sharded accumulator g_prev) in place
 __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev, int n_acc, int n_theta, float* theta, float* m, float* v,
-                                                             const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
+                                                             const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind,
+                                                             const EhP2P* p2p, int slot, unsigned seq) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (p2p) eh_p2p_wait(p2p, p2p->peer_flag[p2p->rank] + slot * EH_GSHARDS, seq, (int)threadIdx.x);     // every rank's sums of the last step
+    auto ldg = [&](const float* q) { return p2p ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q; };
     float cnt = 0.0f, sse = 0.0f, sy = 0.0f, syy = 0.0f;
 #pragma unroll
     for (int sh = 0; sh < EH_GSHARDS; ++sh) {
         const float* gp = g_prev + sh * n_acc + n_theta;
-        sse += gp[0]; cnt += gp[1]; sy += gp[2]; syy += gp[3];
+        sse += ldg(gp); cnt += ldg(gp + 1); sy += ldg(gp + 2); syy += ldg(gp + 3);
     }
     float inv = 0.0f, lossv = 0.0f;
     eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
     if (idx < n_theta && cnt > 0.0f) {
         float gs = 0.0f;
 #pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * n_acc + idx];
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += ldg(&g_prev[sh * n_acc + idx]);
         float th = theta[idx], mm = m[idx], vv = v[idx];
         eh_opt_update(o, gs * inv, sc_in[0], sc_in[1], th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;
@@ -140,6 +143,31 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
         sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
         sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
         if (loss_slot) *loss_slot = lossv;
+    }
+}
+
+// eh_p2p_selftest: one exchange round of the EhP2P protocol with a known vector per rank
+__device__ __forceinline__ float eh_p2p_test_value(int rank, int i, unsigned seq) { return (float)((rank + 1) * 1000 + (i % 97) + (int)(seq & 255u)); }
+__global__ __launch_bounds__(256) void eh_p2p_test_kernel(const EhP2P* P, int slot, unsigned seq, int n_acc, int* bad) {
+    const int tid = threadIdx.x;
+    if (__hip_atomic_load(P->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // an earlier round timed out (on every rank at once): do not wait again
+    for (int i = tid; i < n_acc; i += 256) {
+        const float v = eh_p2p_test_value(P->rank, i, seq);
+        for (int r = 0; r < P->world; ++r)
+            __hip_atomic_store(&P->peer_gacc[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    eh_p2p_wait(P, P->peer_flag[P->rank] + slot * EH_GSHARDS, seq, tid, 5ull * EH_P2P_DEADLINE_TICKS / 2);     // 5 s: at start-up the ranks may be a while apart
+    const float* mine = P->peer_gacc[P->rank] + (long long)slot * EH_GSHARDS * n_acc;
+    for (int i = tid; i < n_acc; i += 256) {
+        float got = 0.0f, want = 0.0f;
+        for (int r = 0; r < P->world; ++r) {
+            got += __hip_atomic_load(&mine[r * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            want += eh_p2p_test_value(r, i, seq);
+        }
+        if (got != want) atomicAdd(bad, 1);
     }
 }
 
@@ -314,6 +342,14 @@ struct eh_handle_s {
     // fused-update mode
     bool fused = false, pending = false;
     float* gacc = nullptr;          // [3][EH_GSHARDS][n_acc] rotating gradient accumulators
+    // cross-GPU exchange (EhP2P): gacc is then an uncached, IPC-exported receive buffer with the arrival flags behind it
+    bool p2p_on = false, p2p_alloc = false;
+    int p2p_world = 0, p2p_rank = 0;
+    unsigned p2p_seq = 0;
+    float* p2p_stage = nullptr;
+    unsigned* p2p_ctr = nullptr;    // [0] workgroup counter, [1] error flag, [2] self-test mismatches
+    EhP2P* p2p_dev = nullptr;
+    void* p2p_peer[EH_GSHARDS] = {nullptr};
     long long gstep = 0;
     float* pending_loss = nullptr;
     // input BatchNorm
@@ -373,9 +409,10 @@ static int flush_pending(eh_handle* h) {
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     hipLaunchKernelGGL(eh_fused_flush_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, g_prev, h->n_acc, nt, TH(h), MM(h), VV(h), sc_in, sc_out,
-                       h->opt, h->pending_loss, h->img, h->net.loss);
+                       h->opt, h->pending_loss, h->img, h->net.loss, h->p2p_on ? h->p2p_dev : nullptr, (int)((h->gstep + 2) % 3), h->p2p_seq);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemsetAsync(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
+    // clear what the next steps add into (under EhP2P that is the staging copy; the receive shards are always overwritten whole)
+    HIPCHK(h, hipMemsetAsync(h->p2p_on ? h->p2p_stage : h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
     h->sc_sel ^= 1;
     h->pending = false;
     h->pending_loss = nullptr;
@@ -731,6 +768,9 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (int r = 0; r < EH_GSHARDS; ++r)
+        if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
+    (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
@@ -758,6 +798,11 @@ int32_t eh_synchronize(eh_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->p2p_on) {
+        unsigned c[3] = {0, 0, 0};
+        HIPCHK(h, hipMemcpy(c, h->p2p_ctr, sizeof c, hipMemcpyDeviceToHost));
+        if (c[1]) return fail(h, EH_EHIP, "eh_synchronize: a cross-GPU exchange ran into its 2 s deadline (a rank is missing or out of step); results are invalid");
+    }
     return EH_OK;
 }
 
@@ -778,6 +823,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
+        if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->fused = value != 0;
@@ -958,9 +1004,11 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
     z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
+    a.p2p = h->p2p_on ? h->p2p_dev : nullptr;
+    a.p2p_seq = h->p2p_on ? ++h->p2p_seq : 0u;
     if (int rc = bn_prepare(h, sp, idx, first, count, true, &a)) return rc;
     const int grid = grid_for(h, count);
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(h->p2p_on ? EH_MODE_TRAIN_P2P : EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
     h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;
     h->pending = true;
     h->pending_loss = loss_slot_for_this_step;
@@ -1319,8 +1367,110 @@ int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* bu
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
     int rc = check_window(h, sp, first, count, "eh_dp_fused_step");
     if (rc) return rc;
-    *buffer_index = (int32_t)(h->gstep % 3);
+    *buffer_index = h->p2p_on ? -1 : (int32_t)(h->gstep % 3);        // -1: the kernels exchange the sums themselves (eh_p2p_attach)
     return do_fused_step(h, sp, nullptr, first, count, nullptr);
+}
+
+// ---- cross-GPU exchange without a collective call (EhP2P, csrc/eh_device.hpp) ----------------------
+static size_t p2p_recv_floats(const eh_handle* h) { return ((size_t)3 * EH_GSHARDS * h->n_acc + 63) / 64 * 64; }
+
+int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out, int64_t handle_bytes) {
+    if (!h || !handle_out) return EH_EINVAL;
+    if (handle_bytes < (int64_t)sizeof(hipIpcMemHandle_t)) return fail(h, EH_EINVAL, "eh_p2p_init: handle buffer of %lld bytes, need %zu", (long long)handle_bytes, sizeof(hipIpcMemHandle_t));
+    if (world < 2 || world > EH_GSHARDS || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_p2p_init: world %d (2..%d), rank %d", world, EH_GSHARDS, rank);
+    if (!h->fused) return fail(h, EH_ESTATE, "eh_p2p_init: set the fused_update option first");
+    if (h->p2p_on || h->p2p_alloc) return fail(h, EH_ESTATE, "eh_p2p_init: already initialised");
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // receive buffer + flags in ONE uncached allocation (other GPUs store into it; nothing of it may linger in a cache)
+    const size_t nf = p2p_recv_floats(h), bytes = (nf + 3 * EH_GSHARDS + 64) * sizeof(float);
+    float* buf = nullptr;
+    hipError_t e = hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: no uncached / fine-grained device memory (%s)", hipGetErrorString(e)); }
+    HIPCHK(h, hipMemset(buf, 0, bytes));
+    hipIpcMemHandle_t hd;
+    e = hipIpcGetMemHandle(&hd, buf);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
+    (void)hipFree(h->gacc);
+    h->gacc = buf;
+    HIPCHK(h, hipMalloc(&h->p2p_stage, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    HIPCHK(h, hipMemset(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->p2p_ctr, 4 * sizeof(unsigned)));
+    HIPCHK(h, hipMemset(h->p2p_ctr, 0, 4 * sizeof(unsigned)));
+    HIPCHK(h, hipMalloc(&h->p2p_dev, sizeof(EhP2P)));
+    HIPCHK(h, hipDeviceSynchronize());        // the memsets ran on the null stream, which the engine's non-blocking stream does not wait for
+    memcpy(handle_out, &hd, sizeof hd);
+    h->p2p_world = world; h->p2p_rank = rank; h->p2p_alloc = true; h->p2p_seq = 0;
+    return EH_OK;
+}
+
+int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride) {
+    if (!h || !handles) return EH_EINVAL;
+    if (!h->p2p_alloc || h->p2p_on) return fail(h, EH_ESTATE, "eh_p2p_attach: call eh_p2p_init first (once)");
+    if (handle_stride < (int64_t)sizeof(hipIpcMemHandle_t)) return fail(h, EH_EINVAL, "eh_p2p_attach: handle stride %lld", (long long)handle_stride);
+    HIPCHK(h, hipSetDevice(h->device));
+    EhP2P P;
+    memset(&P, 0, sizeof P);
+    const size_t nf = p2p_recv_floats(h);
+    for (int r = 0; r < h->p2p_world; ++r) {
+        void* ptr = h->gacc;
+        if (r != h->p2p_rank) {
+            hipIpcMemHandle_t hd;
+            memcpy(&hd, (const char*)handles + (size_t)r * handle_stride, sizeof hd);
+            hipError_t e = hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, EH_EUNSUPPORTED, "eh_p2p_attach: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e)); }
+        }
+        h->p2p_peer[r] = ptr;
+        P.peer_gacc[r] = (float*)ptr;
+        P.peer_flag[r] = (unsigned*)((float*)ptr + nf);
+    }
+    P.stage = h->p2p_stage; P.counter = h->p2p_ctr; P.err = (int*)(h->p2p_ctr + 1);
+    P.world = h->p2p_world; P.rank = h->p2p_rank;
+    HIPCHK(h, hipMemcpy(h->p2p_dev, &P, sizeof P, hipMemcpyHostToDevice));
+    h->p2p_on = true;
+    return EH_OK;
+}
+
+// `rounds` exchanges of a known vector per rank through the real buffers; EVERY rank must call it at the same point.
+int32_t eh_p2p_selftest(eh_handle* h, int32_t rounds, int32_t* ok) {
+    if (!h || !ok) return EH_EINVAL;
+    *ok = 0;
+    if (!h->p2p_on) return fail(h, EH_ESTATE, "eh_p2p_selftest: call eh_p2p_attach first");
+    if (h->pending) return fail(h, EH_ESTATE, "eh_p2p_selftest: a training step is pending");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int k = 0; k < rounds; ++k) {
+        hipLaunchKernelGGL(eh_p2p_test_kernel, dim3(1), dim3(256), 0, h->stream, h->p2p_dev, k % 3, ++h->p2p_seq, h->n_acc, (int*)(h->p2p_ctr + 2));
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned c[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpy(c, h->p2p_ctr, sizeof c, hipMemcpyDeviceToHost));
+    *ok = (c[1] == 0 && c[2] == 0) ? 1 : 0;
+    return EH_OK;
+}
+
+// back to the host-side all-reduce (RCCL): ordinary memory for the accumulators again
+int32_t eh_p2p_disable(eh_handle* h) {
+    if (!h) return EH_EINVAL;
+    if (!h->p2p_alloc) return EH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < EH_GSHARDS; ++r) {
+        if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
+        h->p2p_peer[r] = nullptr;
+    }
+    h->p2p_on = false; h->p2p_alloc = false;
+    (void)hipFree(h->gacc); h->gacc = nullptr;
+    (void)hipFree(h->p2p_stage); h->p2p_stage = nullptr;
+    (void)hipFree(h->p2p_ctr); h->p2p_ctr = nullptr;
+    (void)hipFree(h->p2p_dev); h->p2p_dev = nullptr;
+    HIPCHK(h, hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    HIPCHK(h, hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    HIPCHK(h, hipDeviceSynchronize());        // (null-stream memset, see eh_p2p_init)
+    return EH_OK;
 }
 
 int32_t eh_set_bn_shift(eh_handle* h, const float* shift, int64_t n) {

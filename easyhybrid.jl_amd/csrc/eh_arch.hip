@@ -14,6 +14,12 @@ struct Var {
     using Geom = EhGeom<EH_NBI, EH_NBH, EH_NL, NT, NW>;
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+    // the cross-GPU (EH_MODE_TRAIN_P2P) kernels are built for the default variant of a shape only
+#ifdef EH_EXTRA_VARIANTS
+    static constexpr bool HASP2P = NT == 2 && NW == 8;
+#else
+    static constexpr bool HASP2P = true;
+#endif
 
     template <int ACT, int MODE, int FAST>
     static hipError_t prep1() {
@@ -24,10 +30,15 @@ struct Var {
     static hipError_t prep2() {
         hipError_t e = prep1<ACT, EH_MODE_TRAIN, 0>();
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 0>();
+        if constexpr (HASP2P) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 0>(); }
 #ifdef EH_FAST_PATHS
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 1>();
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 3>();
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 1>();
+        if constexpr (HASP2P) {
+            if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 1>();
+            if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 3>();
+        }
 #endif
         return e;
     }
@@ -42,6 +53,16 @@ struct Var {
 #define EH_GO(MODE, FAST) hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args)
     template <int ACT>
     static void go(int mode, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode == EH_MODE_TRAIN_P2P) {
+            if constexpr (HASP2P) {
+#ifdef EH_FAST_PATHS
+                if (fast == 3) { EH_GO(EH_MODE_TRAIN_P2P, 3); return; }
+                if (fast & 1) { EH_GO(EH_MODE_TRAIN_P2P, 1); return; }
+#endif
+                EH_GO(EH_MODE_TRAIN_P2P, 0);
+            }
+            return;
+        }
 #ifdef EH_FAST_PATHS
         if (mode == EH_MODE_TRAIN && fast == 3) { EH_GO(EH_MODE_TRAIN, 3); return; }
         if (mode == EH_MODE_TRAIN && (fast & 1)) { EH_GO(EH_MODE_TRAIN, 1); return; }
@@ -51,6 +72,7 @@ struct Var {
     }
 #undef EH_GO
     static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode == EH_MODE_TRAIN_P2P && !HASP2P) return hipErrorNotSupported;
         switch (act) {
             case EH_ACT_TANH: go<EH_ACT_TANH>(mode, fast, grid, stream, net, args); break;
             case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, fast, grid, stream, net, args); break;

@@ -32,7 +32,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EH_MODE_TRAIN = 0, EH_MODE_EVAL = 1 };
+enum { EH_MODE_TRAIN = 0, EH_MODE_EVAL = 1, EH_MODE_TRAIN_P2P = 2 };   // TRAIN_P2P: fused-update step that exchanges its sums with the peer GPUs itself (EhP2P)
 
 struct EhNet {
     int P, K, G, T, F;               // predictors, NN outputs (neural params), global params, targets, forcing columns
@@ -99,6 +99,21 @@ __device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float
 // adds this step's partial sums into the sharded accumulator with float atomics instead of
 // writing a slab row.  Saves the reduce kernel and its launch boundary; the sums are no longer
 // bitwise reproducible (atomic arrival order), so it is opt-in.
+// Cross-GPU exchange without a collective call (data parallel, fused-update mode): the receive buffer of
+// a rank is its own gacc ([3][EH_GSHARDS][n_acc], uncached device memory exported over IPC); shard r of a
+// slot is written by RANK r.  Every workgroup of a step adds its partial sums into a local staging copy;
+// the last workgroup to finish folds the staging shards and stores the vector into shard `rank` of every
+// peer's slot, then raises that peer's flag to the step's sequence number.  The next step's prologue
+// waits for all `world` flags of the slot and sums the shards exactly as in the single-GPU mode.
+struct EhP2P {
+    float* peer_gacc[EH_GSHARDS];        // receive buffers of every rank (own one included), mapped into this process
+    unsigned* peer_flag[EH_GSHARDS];     // [3][EH_GSHARDS] arrival flags of every rank
+    float* stage;                        // local [3][EH_GSHARDS][n_acc] staging accumulators
+    unsigned* counter;                   // workgroups of the current launch that have finished accumulating
+    int* err;                            // set when a wait ran into its deadline
+    int world, rank;
+};
+
 struct EhFused {
     float* gacc;           // nullptr = two-kernel (deterministic) mode; else [3][EH_GSHARDS][n_acc] rotating accumulators
     float* pset;           // [2][3][n_theta] parameter sets {theta, m, v}, then [2][2] running beta products
@@ -136,6 +151,9 @@ struct EhStepArgs {
     int bn_update;          // workgroup 0 also updates the running statistics (a real training step)
     float* bn_run;          // [2][32] running mean, running var
     float* image_out;       // global parameter image: its normalisation block follows the running statistics
+    // (kept last: the single-GPU kernels never read them and the layout of everything above stays put)
+    const EhP2P* p2p;     // EH_MODE_TRAIN_P2P only
+    unsigned p2p_seq;     // sequence number this step publishes; its prologue waits for p2p_seq - 1
 };
 
 #define EH_BN_EPS 1e-5f
@@ -265,6 +283,44 @@ __device__ __forceinline__ void eh_mech_extra(int mech, const float* par, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// cross-GPU exchange helpers (EhP2P).  Every wait has a deadline on the 100 MHz wall clock, so a
+// missing peer turns into an error flag, never into a kernel that does not finish.
+// ------------------------------------------------------------------------------------------
+#define EH_P2P_DEADLINE_TICKS 200000000ull      // 2 s between two steps of a running job
+__device__ __forceinline__ void eh_p2p_wait(const EhP2P* P, const unsigned* flags_slot, unsigned seq, int tid,
+                                            unsigned long long deadline = EH_P2P_DEADLINE_TICKS) {
+    if (tid < P->world) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&flags_slot[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (wall_clock64() - t0 > deadline) { *P->err = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
+// called by every thread of every workgroup once its sums are in the staging shards
+__device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
+    __shared__ unsigned eh_p2p_last;
+    __threadfence();                                  // this thread's atomic adds are performed device-wide
+    __syncthreads();
+    if (tid == 0) eh_p2p_last = (atomicAdd(P->counter, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!eh_p2p_last) return;
+    const float* st = P->stage + (long long)slot * EH_GSHARDS * n_acc;
+    for (int i = tid; i < n_acc; i += nthr) {
+        float v = 0.0f;
+#pragma unroll
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) v += __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < P->world; ++r)
+            __hip_atomic_store(&P->peer_gacc[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();                           // the vector is in every peer's memory before its flag moves
+    __syncthreads();
+    if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(P->counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS / image geometry (floats).  Shared by host (image packing, size query) and device.
 // ------------------------------------------------------------------------------------------
 template <int NBI, int NBH, int NL, int NT, int NW>
@@ -342,7 +398,8 @@ template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
     using G = EhGeom<NBI, NBH, NL, NT, NW>;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, NTHR = 64 * NW;
-    constexpr bool TRAIN = MODE == EH_MODE_TRAIN;
+    constexpr bool TRAIN = MODE != EH_MODE_EVAL;
+    constexpr bool P2PM = MODE == EH_MODE_TRAIN_P2P;      // its own instantiation: the single-GPU kernel carries none of this
     constexpr bool K1 = (FAST & 1) != 0, PS = (FAST & 2) != 0;
     constexpr bool KEEPH = TRAIN && ACT != EH_ACT_SWISH && NL * NBH * NT * 4 <= 64;   // activations stay in registers for act'
     constexpr int NHS = KEEPH ? NL : 1, NHM = KEEPH ? NBH : 1, NHT = KEEPH ? NT : 1;
@@ -424,11 +481,15 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         const EhFused& z = a.fz;
         const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * net.n_theta;
+        if (P2PM && z.pending)       // data parallel without a collective: every rank's sums of the previous step have to be here
+            eh_p2p_wait(a.p2p, a.p2p->peer_flag[a.p2p->rank] + ((z.gslot + 2) % 3) * EH_GSHARDS, a.p2p_seq - 1u, tid);
+        // (EH_MODE_TRAIN_P2P: the receive buffer is written by other GPUs -- system-scope vector loads, never the scalar cache)
+        auto ld = [](const float* q) { return P2PM ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q; };
         if (z.pending) {
 #pragma unroll
             for (int sh = 0; sh < EH_GSHARDS; ++sh) {
                 const float* gp = g_prev + sh * a.n_acc + net.n_theta;
-                f_sse += gp[0]; f_cnt += gp[1]; f_sy += gp[2]; f_syy += gp[3];      // single target: [S | n | Sy | Syy]
+                f_sse += ld(gp); f_cnt += ld(gp + 1); f_sy += ld(gp + 2); f_syy += ld(gp + 3);      // single target: [S | n | Sy | Syy]
             }
         }
         const float* const sc_in = z.pset + 6 * net.n_theta + 2 * z.sc_sel;
@@ -438,7 +499,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             f_map = tid < net.g_off ? z.imap[tid] : 0;
             if (z.pending) {
 #pragma unroll
-                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += g_prev[sh * a.n_acc + tid];
+                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += ld(&g_prev[sh * a.n_acc + tid]);
             }
         }
     }
@@ -484,9 +545,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         const EhFused& z = a.fz;
         const int nth = net.n_theta;
         const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
-        float* const g_zero = z.gacc + ((z.gslot + 1) % 3) * (EH_GSHARDS * a.n_acc);
+        // the accumulators the NEXT step adds into: the receive buffer itself, or the local staging copy under EhP2P
+        float* const g_zero = (P2PM ? a.p2p->stage : z.gacc) + ((z.gslot + 1) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * nth;
         float* const pout = z.pset + (z.cur ^ 1) * 3 * nth;
+        auto ldg = [&](const float* q) { return P2PM ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q; };
         const bool upd = z.pending && f_cnt > 0.0f;
         float inv = 0.0f, lossv = __builtin_nanf("");
         if (upd) eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv);
@@ -499,7 +562,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 mp = idx < net.g_off ? z.imap[idx] : 0;
                 if (upd) {
 #pragma unroll
-                    for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * a.n_acc + idx];
+                    for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += ldg(&g_prev[sh * a.n_acc + idx]);
                 }
             }
             if (upd) eh_opt_update(z.opt, gs * inv, f_bt1, f_bt2, th, mm, vv);
@@ -996,7 +1059,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         EH_STAMP(9);
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = a.fz.gacc ? a.fz.gacc + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
+        float* const gsh = a.fz.gacc ? (P2PM ? a.p2p->stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             const int code = a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
             float sum = 0.0f;
@@ -1022,6 +1085,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             else out[e] = sum;
 #endif
         }
+        if constexpr (P2PM) eh_p2p_publish(a.p2p, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
         EH_STAMP(10);
         return;
     }
@@ -1127,7 +1191,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     {
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = (TRAIN && a.fz.gacc) ? a.fz.gacc + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
+        float* const gsh = (TRAIN && a.fz.gacc) ? (P2PM ? a.p2p->stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             float s = R0[e];
 #pragma unroll
@@ -1135,6 +1199,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             if (gsh) atomicAdd(&gsh[e], s);
             else out[e] = s;
         }
+        if constexpr (P2PM) eh_p2p_publish(a.p2p, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
     }
     EH_STAMP(10);
 }

@@ -66,19 +66,28 @@ class _DevArray:
 class DataParallel:
     """Drives one replica.  `engine` already holds this rank's shard as its train split."""
 
-    def __init__(self, engine, group=None, fused: bool = True):
-        """fused=True: one kernel + one all-reduce per step (the update of step s is applied in the
-        prologue of step s+1; `engine.synchronize()` applies the last one).  fused=False: step kernel,
-        deterministic reduction, all-reduce, optimiser kernel."""
+    def __init__(self, engine, group=None, fused: bool = True, p2p="auto"):
+        """fused=True: one kernel + one exchange per step (the update of step s is applied in the
+        prologue of step s+1; `engine.synchronize()` applies the last one).  The exchange is the
+        engine's own peer-to-peer store protocol over xGMI when `p2p` is on and its start-up self-test
+        passes on every rank (no collective call per step at all), otherwise one RCCL all-reduce.
+        fused=False: step kernel, deterministic reduction, all-reduce, optimiser kernel."""
+        import os
         import torch
         from . import _lib as L
         self.engine, self.group, self.fused = engine, group, fused
         dev = torch.device("cuda", torch.cuda.current_device())
+        self._dev = dev
         ptr, n = engine.device_buffer(L.EH_BUF_GRAD)
         self.buf = torch.as_tensor(_DevArray(ptr, n), device=dev)
+        self.p2p = False
         if fused:
             engine.set_option("fused_update", 1)
-            gptr, gn = engine.device_buffer(L.EH_BUF_GACC)
+            if p2p == "auto":
+                p2p = os.environ.get("EH_DP_P2P", "1") != "0"
+            if p2p:
+                self.p2p = self._negotiate_p2p()
+            gptr, gn = engine.device_buffer(L.EH_BUF_GACC)      # (after the negotiation: it re-allocates the accumulators)
             self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=dev) for k in range(3)]
         # run the engine on torch's current stream so kernels and the collective are ordered
         engine.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -96,13 +105,86 @@ class DataParallel:
             allreduce_partials(tot, group)
             engine.set_bn_shift((tot[:-1] / tot[-1]).cpu().numpy())
 
+    def _all_agree(self, ok: bool) -> bool:
+        import torch
+        import torch.distributed as dist
+        backend = dist.get_backend(self.group)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def _negotiate_p2p(self) -> bool:
+        """Export / map the receive buffers and run the self-test; every rank ends with the same answer."""
+        import os
+        import torch.distributed as dist
+        eng = self.engine
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        if world < 2 or world > 8:
+            return False
+        try:
+            handle = eng.p2p_init(world, rank)
+        except Exception:                                   # no uncached memory / IPC on this system
+            handle = None
+        if not self._all_agree(handle is not None):
+            eng.p2p_disable()
+            return False
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=self.group)
+        try:
+            eng.p2p_attach(handles)
+            ok = True
+        except Exception:
+            ok = False
+        if not self._all_agree(ok):
+            eng.p2p_disable()
+            return False
+        dist.barrier(group=self.group)                      # every rank has every buffer mapped before anyone stores
+        try:
+            ok = eng.p2p_selftest(8)
+        except Exception:
+            ok = False
+        if os.environ.get("EH_DP_P2P_FAIL_SELFTEST") == str(rank):      # test hook: the fallback negotiation
+            ok = False
+        if not self._all_agree(ok):
+            dist.barrier(group=self.group)                  # nobody unmaps while a peer's test kernel may still store
+            eng.p2p_disable()
+            return False
+        return True
+
+    def check(self) -> bool:
+        """Collective: drain the engine and make sure no peer-to-peer wait ran into its deadline anywhere.
+        If one did, every rank drops back to the RCCL all-reduce, rank 0's parameters are re-broadcast and
+        False is returned (the steps since the last check are then not trustworthy)."""
+        import torch
+        import torch.distributed as dist
+        from . import _lib as L
+        try:
+            self.engine.synchronize()
+            ok = True
+        except Exception:
+            ok = False
+        if not self.p2p:
+            return ok
+        if self._all_agree(ok):
+            return True
+        dist.barrier(group=self.group)
+        self.engine.p2p_disable()
+        self.p2p = False
+        gptr, gn = self.engine.device_buffer(L.EH_BUF_GACC)
+        self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=self._dev) for k in range(3)]
+        self.engine.set_option("fused_update", 0)           # parameter buffers are only addressable outside the fused mode
+        self.broadcast_params(0)
+        self.engine.set_option("fused_update", 1)
+        return False
+
     def step(self, first: int, count: int, want_loss: bool = False):
         if self.bn:
             self.engine.dp_bn_stats(first, count)
             allreduce_partials(self.bnbuf, self.group)
         if self.fused and not want_loss:
             k = self.engine.dp_fused_step(first, count)
-            allreduce_partials(self.gacc[k], self.group)      # 8 shards x (n_theta + 2) raw sums
+            if k >= 0:                                        # k < 0: the kernels exchange the sums themselves (p2p)
+                allreduce_partials(self.gacc[k], self.group)  # 8 shards x (n_theta + 2) raw sums
             return None
         self.engine.dp_grad(first, count)
         allreduce_partials(self.buf, self.group)

@@ -224,6 +224,24 @@ class HybridEngine:
         self._chk(self._lib.eh_dp_fused_step(self._h, first, count, C.byref(k)))
         return int(k.value)
 
+    # -- cross-GPU exchange without a collective call (include/easyhybrid_hip.h: eh_p2p_*) -----------
+    def p2p_init(self, world: int, rank: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        self._chk(self._lib.eh_p2p_init(self._h, world, rank, C.cast(buf, C.c_void_p), 64))
+        return buf.raw
+
+    def p2p_attach(self, handles: Sequence[bytes]):
+        blob = C.create_string_buffer(b"".join(handles), 64 * len(handles))
+        self._chk(self._lib.eh_p2p_attach(self._h, C.cast(blob, C.c_void_p), 64))
+
+    def p2p_selftest(self, rounds: int = 8) -> bool:
+        ok = C.c_int32()
+        self._chk(self._lib.eh_p2p_selftest(self._h, rounds, C.byref(ok)))
+        return bool(ok.value)
+
+    def p2p_disable(self):
+        self._chk(self._lib.eh_p2p_disable(self._h))
+
     def device_buffer(self, which: int):
         p = C.c_void_p()
         n = C.c_int64()

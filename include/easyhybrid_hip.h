@@ -213,6 +213,21 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
  * last pending update. */
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index);
 
+/* Cross-GPU exchange without a collective call (2..8 ranks of one node, fused_update mode): the
+ * accumulators become an uncached receive buffer that every peer maps over HIP IPC; the last
+ * workgroup of a step stores the rank's sums into every peer's buffer (xGMI peer-to-peer stores)
+ * and raises a flag, the next step's prologue waits for all flags (2 s deadline -> error at
+ * eh_synchronize, never a hang).  eh_dp_fused_step then needs NO host all-reduce (*buffer_index = -1).
+ *   eh_p2p_init     : allocate + export; writes the 64-byte IPC handle of this rank
+ *   (host: all-gather the handles of all ranks, e.g. over torch.distributed)
+ *   eh_p2p_attach   : map every peer; handles = world consecutive handles, `handle_stride` bytes apart
+ *   eh_p2p_selftest : `rounds` exchanges of known vectors, all ranks together; *ok = 0 -> call
+ *                     eh_p2p_disable on every rank and keep all-reducing EH_BUF_GACC instead */
+int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out, int64_t handle_bytes);
+int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride);
+int32_t eh_p2p_selftest(eh_handle* h, int32_t rounds, int32_t* ok);
+int32_t eh_p2p_disable(eh_handle* h);
+
 /* timing aid for bench.py: when enabled, eh_train_step brackets the fused step kernel with HIP
  * events on its stream; eh_profile_read returns the number of launches and their mean duration. */
 int32_t eh_profile_enable(eh_handle* h, int32_t on);

@@ -18,7 +18,7 @@ HEADER = os.path.join(ROOT, "include", "easyhybrid_hip.h")
 def _declared():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(eh_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(eh_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,39 @@
+"""-m gpu: the peer-to-peer gradient exchange of the fused step kernel (eh_p2p_*) with two ranks.
+A 1-GPU box can only host both ranks on the same device, which still exercises the whole protocol
+(IPC-mapped receive buffers, staging + last-workgroup publish, flags, deadline, bitwise-identical
+replicas, the fallback negotiation); only the xGMI transport itself is not covered.  The ranks run
+in child processes started BEFORE this process touches the GPU (file name sorts ahead of
+test_gpu_parity.py): a process that has initialised HIP must not fork+exec on the GPU boxes."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, port):
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU; run this file first (or alone)")
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "p2p_two_ranks.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in (r.stdout + r.stderr).replace("rank ", "\nrank ").splitlines() if l.startswith("rank ")]
+    assert r.returncode == 0, "\n".join(lines) + "\n" + (r.stdout + r.stderr)[-1500:]
+    return lines
+
+
+def test_two_ranks_peer_to_peer_exchange_matches_single_engine_training():
+    lines = _run({}, 29561)
+    first = [l for l in lines if "max|theta-ref|" in l]
+    assert len(first) == 2 and all("p2p=True" in l and "replicas_identical=True" in l for l in first), lines
+
+
+def test_two_ranks_fall_back_to_the_collective_when_one_rank_fails_the_selftest():
+    lines = _run({"EH_DP_P2P_FAIL_SELFTEST": "1"}, 29562)
+    first = [l for l in lines if "max|theta-ref|" in l]
+    assert len(first) == 2 and all("p2p=False" in l and "replicas_identical=True" in l for l in first), lines
