@@ -219,6 +219,21 @@ function dp_fused_step!(e::HybridEngine, first::Integer, count::Integer)
     check(e, @ccall LIB[].eh_dp_fused_step(e.h::Ptr{Cvoid}, first::Int64, count::Int64, k::Ref{Int32})::Int32)
     return k[]          # which third of EH_BUF_GACC to all-reduce
 end
+# peer-to-peer exchange of the fused step (no collective per step): p2p_init! -> all-gather the handles (MPI) -> p2p_attach! -> p2p_selftest
+function p2p_init!(e::HybridEngine, world::Integer, rank::Integer)
+    hd = zeros(UInt8, 64)
+    check(e, @ccall LIB[].eh_p2p_init(e.h::Ptr{Cvoid}, world::Int32, rank::Int32, hd::Ptr{UInt8}, 64::Int64)::Int32)
+    return hd
+end
+p2p_attach!(e::HybridEngine, handles::Matrix{UInt8}) =            # 64 x world
+    check(e, @ccall LIB[].eh_p2p_attach(e.h::Ptr{Cvoid}, handles::Ptr{UInt8}, 64::Int64)::Int32)
+function p2p_selftest(e::HybridEngine; rounds::Integer = 8)
+    ok = Ref{Int32}(0)
+    check(e, @ccall LIB[].eh_p2p_selftest(e.h::Ptr{Cvoid}, rounds::Int32, ok::Ref{Int32})::Int32)
+    return ok[] != 0
+end
+p2p_disable!(e::HybridEngine) = check(e, @ccall LIB[].eh_p2p_disable(e.h::Ptr{Cvoid})::Int32)
+
 "input BatchNorm under DP: shard sums into EH_BUF_BNSTAT (all-reduce it before dp_grad! / dp_fused_step!)"
 set_bn_shift!(e::HybridEngine, c::Vector{Float32}) = check(e, @ccall LIB[].eh_set_bn_shift(e.h::Ptr{Cvoid}, c::Ptr{Float32}, length(c)::Int64)::Int32)
 dp_bn_stats!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_bn_stats(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)
