@@ -127,10 +127,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    exchange_cal = None
     if dp is not None and dp.p2p:
-        # burn-in of the peer-to-peer exchange: a deadline hit on any rank drops every rank back to the RCCL all-reduce
+        # burn-in of the peer-to-peer exchange (a deadline hit on any rank drops every rank back to the RCCL
+        # all-reduce), then time both exchanges for a few hundred steps and keep the faster one
         run(64, 0)
-        dp.check()
+        if dp.check():
+            exchange_cal = dp.calibrate(0, B, 300)
     run(args.warmup, 0)
     fence()
     t0 = time.perf_counter()
@@ -204,7 +207,8 @@ def main():
                                    f"batch={B} per GPU, fp32 (BASELINE.json configs[1])",
                        "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}",
                        "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
-                                             else "one RCCL all-reduce per step")},
+                                             else "one RCCL all-reduce per step"),
+                       "gradient_exchange_calibration_us_per_step": exchange_cal},
             "roofline": roof,
         }
         out["dataset_upload_ms_once"] = 1e3 * t_up

@@ -289,11 +289,17 @@ __device__ __forceinline__ void eh_mech_extra(int mech, const float* par, const 
 #define EH_P2P_DEADLINE_TICKS 200000000ull      // 2 s between two steps of a running job
 __device__ __forceinline__ void eh_p2p_wait(const EhP2P* P, const unsigned* flags_slot, unsigned seq, int tid,
                                             unsigned long long deadline = EH_P2P_DEADLINE_TICKS) {
-    if (tid < P->world) {
+    // Relaxed, cache-bypassing polls of the (uncached) flag words; every 64th try is an acquire load, whose L2
+    // invalidate guarantees progress even if a memory type ever lets a flag line linger in a cache.  Acquire on
+    // every try costs ~2 us per step (all workgroups invalidate their L2 at kernel start).
+    // (once a wait has timed out the job is lost: later waits return at once, so the total delay stays bounded)
+    if (tid < P->world && !__hip_atomic_load(P->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(&flags_slot[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (wall_clock64() - t0 > deadline) { *P->err = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
+        unsigned tries = 0;
+        while (((++tries & 63u) ? __hip_atomic_load(&flags_slot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                : __hip_atomic_load(&flags_slot[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) != seq) {
+            if (wall_clock64() - t0 > deadline) { __hip_atomic_store(P->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
@@ -301,7 +307,9 @@ __device__ __forceinline__ void eh_p2p_wait(const EhP2P* P, const unsigned* flag
 // called by every thread of every workgroup once its sums are in the staging shards
 __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
     __shared__ unsigned eh_p2p_last;
-    __threadfence();                                  // this thread's atomic adds are performed device-wide
+    // this thread's atomic adds are acknowledged by the memory side (they never live in an L2): no cache write-back,
+    // which a __threadfence() would add 256 times per launch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) eh_p2p_last = (atomicAdd(P->counter, 1u) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
@@ -314,9 +322,15 @@ __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigne
         for (int r = 0; r < P->world; ++r)
             __hip_atomic_store(&P->peer_gacc[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#ifdef EH_P2P_EXP_NOFENCE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
     __threadfence_system();                           // the vector is in every peer's memory before its flag moves
     __syncthreads();
     if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     if (tid == 0) __hip_atomic_store(P->counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -151,6 +151,54 @@ class DataParallel:
             return False
         return True
 
+    def _refresh_gacc(self):
+        import torch
+        from . import _lib as L
+        gptr, gn = self.engine.device_buffer(L.EH_BUF_GACC)
+        self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=self._dev) for k in range(3)]
+
+    def calibrate(self, first: int, count: int, nsteps: int = 300) -> dict:
+        """Collective: time `nsteps` training steps on samples [first, first+count) with the peer-to-peer exchange
+        and with the RCCL all-reduce and keep the faster one (measure, don't guess: the store latency over xGMI
+        and the collective's launch cost both depend on the node).  Trains the model by 2 x nsteps steps."""
+        import time
+        import torch
+        import torch.distributed as dist
+        if not self.p2p:
+            return {"p2p_us": None, "collective_us": None, "chosen": "collective"}
+
+        def timed():
+            for _ in range(20):
+                self.step(first, count)
+            self.engine.synchronize()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                self.step(first, count)
+            self.engine.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                             device=self._dev if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return 1e6 * float(t.item()) / nsteps
+        try:
+            t_p2p = timed()
+            ok = True
+        except Exception:
+            t_p2p, ok = float("inf"), False
+        ok = self._all_agree(ok)
+        dist.barrier(group=self.group)
+        self.engine.p2p_disable()
+        self.p2p = False
+        self._refresh_gacc()
+        if not ok:
+            self.engine.set_option("fused_update", 0); self.broadcast_params(0); self.engine.set_option("fused_update", 1)
+            return {"p2p_us": None, "collective_us": None, "chosen": "collective (peer-to-peer exchange failed)"}
+        t_col = timed()
+        if t_p2p < t_col:
+            self.p2p = self._negotiate_p2p()
+            self._refresh_gacc()
+        return {"p2p_us": t_p2p, "collective_us": t_col, "chosen": "p2p" if self.p2p else "collective"}
+
     def check(self) -> bool:
         """Collective: drain the engine and make sure no peer-to-peer wait ran into its deadline anywhere.
         If one did, every rank drops back to the RCCL all-reduce, rank 0's parameters are re-broadcast and
@@ -170,8 +218,7 @@ class DataParallel:
         dist.barrier(group=self.group)
         self.engine.p2p_disable()
         self.p2p = False
-        gptr, gn = self.engine.device_buffer(L.EH_BUF_GACC)
-        self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=self._dev) for k in range(3)]
+        self._refresh_gacc()
         self.engine.set_option("fused_update", 0)           # parameter buffers are only addressable outside the fused mode
         self.broadcast_params(0)
         self.engine.set_option("fused_update", 1)

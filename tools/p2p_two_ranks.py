@@ -38,6 +38,9 @@ spec, theta, X, f, y = util.rbq10_case(world * b * nsteps, "tanh", True, 0.1)
 sel = np.concatenate([np.arange(i * world * b + rank * b, i * world * b + (rank + 1) * b) for i in range(nsteps)])
 eng = util.load_engine(spec, theta, X[:, sel], {k: v[sel] for k, v in f.items()}, {k: v[sel] for k, v in y.items()})
 eng.opt_init("Adam", 0.01)
+# Both ranks' kernels must fit on the one GPU at the same time: a step kernel fills a CU per workgroup, and a rank
+# whose 256 workgroups all sit waiting for the peer's sums would keep the peer's kernel from ever being scheduled.
+eng.set_option("max_blocks", 64)
 drv = eh.dp.DataParallel(eng, fused=True)
 dist.barrier()
 t0 = time.perf_counter()
@@ -60,13 +63,16 @@ ok = err <= 3e-5 and same
 B = 65536
 spec2, theta2, X2, f2, y2 = util.rbq10_case(8 * B, "tanh", True, 0.0)
 e2 = util.load_engine(spec2, theta2, X2, f2, y2); e2.opt_init("Adam", 0.01)
+e2.set_option("max_blocks", 64)
 d2 = eh.dp.DataParallel(e2, fused=True)
+cal = d2.calibrate(0, B, 100)
+if rank == 0: print("calibration:", cal, flush=True)
 for i in range(50): d2.step((i % 8) * B, B)
 e2.synchronize(); dist.barrier()
 t0 = time.perf_counter()
 for i in range(500): d2.step((i % 8) * B, B)
 e2.synchronize(); torch.cuda.synchronize()
-print(f"rank {rank}: B=65536 per rank, p2p={d2.p2p}: {1e6 * (time.perf_counter() - t0) / 500:.1f} us/step (two ranks share one GPU)", flush=True)
+print(f"rank {rank}: B=65536 per rank, p2p={d2.p2p}: {1e6 * (time.perf_counter() - t0) / 500:.1f} us/step (two ranks share one GPU, 64 workgroups each)", flush=True)
 eng.close(); ref.close(); e2.close()
 dist.barrier()
 dist.destroy_process_group()
