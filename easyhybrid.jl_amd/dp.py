@@ -82,7 +82,11 @@ class DataParallel:
         self.buf = torch.as_tensor(_DevArray(ptr, n), device=dev)
         self.p2p = False
         if fused:
-            engine.set_option("fused_update", 1)
+            try:
+                engine.set_option("fused_update", 1)
+            except NotImplementedError:                     # multi-target models / hidden widths above 64: three-kernel path
+                fused = self.fused = False
+        if fused:
             if p2p == "auto":
                 p2p = os.environ.get("EH_DP_P2P", "1") != "0"
             if p2p:

@@ -468,6 +468,18 @@ def test_data_parallel_driver_world_size_one_nccl():
             assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-5, fused
             eng.close()
         ref.close()
+        # a model without a fused-update kernel (hidden width 128): the driver drops to the three-kernel path by itself
+        spec, theta, X, f, y = _rs6_case(32, (128, 128), 2048)
+        ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.002)
+        eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.002)
+        drv = eh.dp.DataParallel(eng)
+        assert not drv.fused and not drv.p2p
+        for i in range(4):
+            ref.train_step(i * 512, 512, want_loss=False)
+            drv.step(i * 512, 512)
+        eng.synchronize(); torch.cuda.synchronize()
+        assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-5
+        eng.close(); ref.close()
     finally:
         dist.destroy_process_group()
 
