@@ -120,20 +120,35 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
                                                              const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind,
                                                              const EhP2P* p2p, int slot, unsigned seq) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (p2p) eh_p2p_wait(p2p, p2p->peer_flag[p2p->rank] + slot * EH_GSHARDS, seq, (int)threadIdx.x);     // every rank's sums of the last step
-    auto ldg = [&](const float* q) { return p2p ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q; };
-    float cnt = 0.0f, sse = 0.0f, sy = 0.0f, syy = 0.0f;
+    float cnt = 0.0f, sse = 0.0f, sy = 0.0f, syy = 0.0f, gs_p2p = 0.0f;
+    if (p2p) {       // every rank's sums of the last step, straight from the receive shards (see EhP2P)
+        auto ad = [&](int i) -> const unsigned long long* {
+            const int sh = i / 5, k = i % 5;
+            if (sh >= p2p->world || (k == 4 && idx >= n_theta)) return nullptr;
+            const unsigned long long* base = p2p->peer_recv[p2p->rank] + ((long long)slot * EH_GSHARDS + sh) * n_acc;
+            return k < 4 ? base + n_theta + k : base + idx;
+        };
+        unsigned long long w[5 * EH_GSHARDS];
+        float got[5 * EH_GSHARDS];
+        eh_ll_issue(ad, seq, w);
+        eh_ll_finish(p2p, ad, seq, w, got);
 #pragma unroll
-    for (int sh = 0; sh < EH_GSHARDS; ++sh) {
-        const float* gp = g_prev + sh * n_acc + n_theta;
-        sse += ldg(gp); cnt += ldg(gp + 1); sy += ldg(gp + 2); syy += ldg(gp + 3);
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) { sse += got[5 * sh]; cnt += got[5 * sh + 1]; sy += got[5 * sh + 2]; syy += got[5 * sh + 3]; gs_p2p += got[5 * sh + 4]; }
+    } else {
+#pragma unroll
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) {
+            const float* gp = g_prev + sh * n_acc + n_theta;
+            sse += gp[0]; cnt += gp[1]; sy += gp[2]; syy += gp[3];
+        }
     }
     float inv = 0.0f, lossv = 0.0f;
     eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
     if (idx < n_theta && cnt > 0.0f) {
-        float gs = 0.0f;
+        float gs = gs_p2p;
+        if (!p2p) {
 #pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += ldg(&g_prev[sh * n_acc + idx]);
+            for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * n_acc + idx];
+        }
         float th = theta[idx], mm = m[idx], vv = v[idx];
         eh_opt_update(o, gs * inv, sc_in[0], sc_in[1], th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;
@@ -151,22 +166,21 @@ __device__ __forceinline__ float eh_p2p_test_value(int rank, int i, unsigned seq
 __global__ __launch_bounds__(256) void eh_p2p_test_kernel(const EhP2P* P, int slot, unsigned seq, int n_acc, int* bad) {
     const int tid = threadIdx.x;
     for (int i = tid; i < n_acc; i += 256) {
-        const float v = eh_p2p_test_value(P->rank, i, seq);
+        const unsigned long long w = eh_ll_pack(eh_p2p_test_value(P->rank, i, seq), seq);
         for (int r = 0; r < P->world; ++r)
-            __hip_atomic_store(&P->peer_gacc[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
-    __syncthreads();
-    if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    eh_p2p_wait(P, P->peer_flag[P->rank] + slot * EH_GSHARDS, seq, tid, 5ull * EH_P2P_DEADLINE_TICKS / 2);     // 5 s: at start-up the ranks may be a while apart
-    const float* mine = P->peer_gacc[P->rank] + (long long)slot * EH_GSHARDS * n_acc;
     for (int i = tid; i < n_acc; i += 256) {
-        float got = 0.0f, want = 0.0f;
-        for (int r = 0; r < P->world; ++r) {
-            got += __hip_atomic_load(&mine[r * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            want += eh_p2p_test_value(r, i, seq);
-        }
-        if (got != want) atomicAdd(bad, 1);
+        auto ad = [&](int r) -> const unsigned long long* {
+            return r < P->world ? P->peer_recv[P->rank] + ((long long)slot * EH_GSHARDS + r) * n_acc + i : nullptr;
+        };
+        unsigned long long w[EH_GSHARDS];
+        float got[EH_GSHARDS];
+        eh_ll_issue(ad, seq, w);
+        eh_ll_finish(P, ad, seq, w, got, 5ull * EH_P2P_DEADLINE_TICKS / 2);        // 5 s: at start-up the ranks may be a while apart
+        float sum = 0.0f, want = 0.0f;
+        for (int r = 0; r < P->world; ++r) { sum += got[r]; want += eh_p2p_test_value(r, i, seq); }
+        if (sum != want) atomicAdd(bad, 1);
     }
 }
 
@@ -341,8 +355,9 @@ struct eh_handle_s {
     // fused-update mode
     bool fused = false, pending = false;
     float* gacc = nullptr;          // [3][EH_GSHARDS][n_acc] rotating gradient accumulators
-    // cross-GPU exchange (EhP2P): gacc is then an uncached, IPC-exported receive buffer with the arrival flags behind it
+    // cross-GPU exchange (EhP2P): an uncached, IPC-exported receive buffer of {value, sequence} words next to gacc
     bool p2p_on = false, p2p_alloc = false;
+    unsigned long long* p2p_recv = nullptr;
     int p2p_world = 0, p2p_rank = 0;
     unsigned p2p_seq = 0;
     float* p2p_stage = nullptr;
@@ -769,7 +784,7 @@ int32_t eh_destroy(eh_handle* h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
-    (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
+    (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
@@ -1371,30 +1386,29 @@ int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* bu
 }
 
 // ---- cross-GPU exchange without a collective call (EhP2P, csrc/eh_device.hpp) ----------------------
-static size_t p2p_recv_floats(const eh_handle* h) { return ((size_t)3 * EH_GSHARDS * h->n_acc + 63) / 64 * 64; }
+static size_t p2p_recv_words(const eh_handle* h) { return (size_t)3 * EH_GSHARDS * h->n_acc; }
 
 int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out, int64_t handle_bytes) {
     if (!h || !handle_out) return EH_EINVAL;
     if (handle_bytes < (int64_t)sizeof(hipIpcMemHandle_t)) return fail(h, EH_EINVAL, "eh_p2p_init: handle buffer of %lld bytes, need %zu", (long long)handle_bytes, sizeof(hipIpcMemHandle_t));
-    // (world == 1 is a loopback: the rank publishes to and waits for itself -- measures the cost of the machinery)
+    // (world == 1 is a loopback: the rank publishes to and reads from itself -- measures the cost of the machinery)
     if (world < 1 || world > EH_GSHARDS || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_p2p_init: world %d (1..%d), rank %d", world, EH_GSHARDS, rank);
     if (!h->fused) return fail(h, EH_ESTATE, "eh_p2p_init: set the fused_update option first");
     if (h->p2p_on || h->p2p_alloc) return fail(h, EH_ESTATE, "eh_p2p_init: already initialised");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    // receive buffer + flags in ONE uncached allocation (other GPUs store into it; nothing of it may linger in a cache)
-    const size_t nf = p2p_recv_floats(h), bytes = (nf + 3 * EH_GSHARDS + 64) * sizeof(float);
-    float* buf = nullptr;
+    // other GPUs store into the receive buffer: nothing of it may linger in a cache of this one
+    const size_t bytes = p2p_recv_words(h) * sizeof(unsigned long long);
+    unsigned long long* buf = nullptr;
     hipError_t e = hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: no uncached / fine-grained device memory (%s)", hipGetErrorString(e)); }
-    HIPCHK(h, hipMemset(buf, 0, bytes));
+    HIPCHK(h, hipMemset(buf, 0, bytes));                  // sequence 0 everywhere: nothing has arrived
     hipIpcMemHandle_t hd;
     e = hipIpcGetMemHandle(&hd, buf);
     if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
-    (void)hipFree(h->gacc);
-    h->gacc = buf;
+    h->p2p_recv = buf;
     HIPCHK(h, hipMalloc(&h->p2p_stage, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK(h, hipMemset(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->p2p_ctr, 4 * sizeof(unsigned)));
@@ -1413,9 +1427,8 @@ int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride) 
     HIPCHK(h, hipSetDevice(h->device));
     EhP2P P;
     memset(&P, 0, sizeof P);
-    const size_t nf = p2p_recv_floats(h);
     for (int r = 0; r < h->p2p_world; ++r) {
-        void* ptr = h->gacc;
+        void* ptr = h->p2p_recv;
         if (r != h->p2p_rank) {
             hipIpcMemHandle_t hd;
             memcpy(&hd, (const char*)handles + (size_t)r * handle_stride, sizeof hd);
@@ -1423,8 +1436,7 @@ int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride) 
             if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, EH_EUNSUPPORTED, "eh_p2p_attach: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e)); }
         }
         h->p2p_peer[r] = ptr;
-        P.peer_gacc[r] = (float*)ptr;
-        P.peer_flag[r] = (unsigned*)((float*)ptr + nf);
+        P.peer_recv[r] = (unsigned long long*)ptr;
     }
     P.stage = h->p2p_stage; P.counter = h->p2p_ctr; P.err = (int*)(h->p2p_ctr + 1);
     P.world = h->p2p_world; P.rank = h->p2p_rank;
@@ -1451,7 +1463,7 @@ int32_t eh_p2p_selftest(eh_handle* h, int32_t rounds, int32_t* ok) {
     return EH_OK;
 }
 
-// back to the host-side all-reduce (RCCL): ordinary memory for the accumulators again
+// back to the host-side all-reduce (RCCL) of EH_BUF_GACC
 int32_t eh_p2p_disable(eh_handle* h) {
     if (!h) return EH_EINVAL;
     if (!h->p2p_alloc) return EH_OK;
@@ -1463,13 +1475,12 @@ int32_t eh_p2p_disable(eh_handle* h) {
         h->p2p_peer[r] = nullptr;
     }
     h->p2p_on = false; h->p2p_alloc = false;
-    (void)hipFree(h->gacc); h->gacc = nullptr;
+    (void)hipFree(h->p2p_recv); h->p2p_recv = nullptr;
     (void)hipFree(h->p2p_stage); h->p2p_stage = nullptr;
     (void)hipFree(h->p2p_ctr); h->p2p_ctr = nullptr;
     (void)hipFree(h->p2p_dev); h->p2p_dev = nullptr;
-    HIPCHK(h, hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK(h, hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK(h, hipDeviceSynchronize());        // (null-stream memset, see eh_p2p_init)
+    HIPCHK(h, hipMemsetAsync(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return EH_OK;
 }
 

@@ -99,15 +99,15 @@ __device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float
 // adds this step's partial sums into the sharded accumulator with float atomics instead of
 // writing a slab row.  Saves the reduce kernel and its launch boundary; the sums are no longer
 // bitwise reproducible (atomic arrival order), so it is opt-in.
-// Cross-GPU exchange without a collective call (data parallel, fused-update mode): the receive buffer of
-// a rank is its own gacc ([3][EH_GSHARDS][n_acc], uncached device memory exported over IPC); shard r of a
-// slot is written by RANK r.  Every workgroup of a step adds its partial sums into a local staging copy;
-// the last workgroup to finish folds the staging shards and stores the vector into shard `rank` of every
-// peer's slot, then raises that peer's flag to the step's sequence number.  The next step's prologue
-// waits for all `world` flags of the slot and sums the shards exactly as in the single-GPU mode.
+// Cross-GPU exchange without a collective call (data parallel, fused-update mode).  Every rank owns a receive
+// buffer recv[3 slots][EH_GSHARDS ranks][n_acc] of 64-bit words {float value, 32-bit sequence number} in uncached
+// device memory, exported over IPC and mapped by every peer; shard r of a slot is written by RANK r only.  The
+// workgroups of a step add their partial sums into a local staging copy; the last workgroup to finish folds the
+// staging shards and stores {value, seq} into shard `rank` of every peer's slot -- one 8-byte store per element
+// carries its own arrival flag, so no fence and no separate flag round is needed (the "LL" idea of RCCL).  The
+// next step's prologue reads the shards of all ranks, retrying the words whose sequence number is still old.
 struct EhP2P {
-    float* peer_gacc[EH_GSHARDS];        // receive buffers of every rank (own one included), mapped into this process
-    unsigned* peer_flag[EH_GSHARDS];     // [3][EH_GSHARDS] arrival flags of every rank
+    unsigned long long* peer_recv[EH_GSHARDS];   // receive buffers of every rank (own one included), mapped into this process
     float* stage;                        // local [3][EH_GSHARDS][n_acc] staging accumulators
     unsigned* counter;                   // workgroups of the current launch that have finished accumulating
     int* err;                            // set when a wait ran into its deadline
@@ -284,25 +284,40 @@ __device__ __forceinline__ void eh_mech_extra(int mech, const float* par, const 
 
 // ------------------------------------------------------------------------------------------
 // cross-GPU exchange helpers (EhP2P).  Every wait has a deadline on the 100 MHz wall clock, so a
-// missing peer turns into an error flag, never into a kernel that does not finish.
+// missing peer turns into an error flag, never into a kernel that does not finish; once a wait has
+// timed out the job is lost and later waits return at once (the total delay stays bounded).
 // ------------------------------------------------------------------------------------------
 #define EH_P2P_DEADLINE_TICKS 200000000ull      // 2 s between two steps of a running job
-__device__ __forceinline__ void eh_p2p_wait(const EhP2P* P, const unsigned* flags_slot, unsigned seq, int tid,
-                                            unsigned long long deadline = EH_P2P_DEADLINE_TICKS) {
-    // Relaxed, cache-bypassing polls of the (uncached) flag words; every 64th try is an acquire load, whose L2
-    // invalidate guarantees progress even if a memory type ever lets a flag line linger in a cache.  Acquire on
-    // every try costs ~2 us per step (all workgroups invalidate their L2 at kernel start).
-    // (once a wait has timed out the job is lost: later waits return at once, so the total delay stays bounded)
-    if (tid < P->world && !__hip_atomic_load(P->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        const unsigned long long t0 = wall_clock64();
-        unsigned tries = 0;
-        while (((++tries & 63u) ? __hip_atomic_load(&flags_slot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                : __hip_atomic_load(&flags_slot[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) != seq) {
-            if (wall_clock64() - t0 > deadline) { __hip_atomic_store(P->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
+__device__ __forceinline__ unsigned long long eh_ll_pack(float v, unsigned seq) { return ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v); }
+// N words of one reader: eh_ll_issue requests them all (no waiting -- other loads can be queued behind them),
+// eh_ll_finish examines them and keeps re-reading until every word carries `seq`; words that never arrive
+// read as 0.  addr(i) == nullptr -> 0 without a load.
+template <int N, class A>
+__device__ __forceinline__ void eh_ll_issue(A addr, unsigned seq, unsigned long long (&w)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const unsigned long long* q = addr(i);
+        w[i] = q ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)seq << 32);
     }
-    __syncthreads();
+}
+template <int N, class A>
+__device__ __forceinline__ void eh_ll_finish(const EhP2P* P, A addr, unsigned seq, unsigned long long (&w)[N], float (&out)[N],
+                                             unsigned long long deadline = EH_P2P_DEADLINE_TICKS) {
+    unsigned long long t0 = 0;
+    bool timing = false;
+    while (true) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && ((unsigned)(w[i] >> 32) == seq);
+        if (all) break;
+        if (__hip_atomic_load(P->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (!timing) { t0 = wall_clock64(); timing = true; }
+        else if (wall_clock64() - t0 > deadline) { __hip_atomic_store(P->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(2);
+        eh_ll_issue(addr, seq, w);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = ((unsigned)(w[i] >> 32) == seq) ? __uint_as_float((unsigned)w[i]) : 0.0f;
 }
 // called by every thread of every workgroup once its sums are in the staging shards
 __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
@@ -319,18 +334,10 @@ __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigne
         float v = 0.0f;
 #pragma unroll
         for (int sh = 0; sh < EH_GSHARDS; ++sh) v += __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w = eh_ll_pack(v, seq);
         for (int r = 0; r < P->world; ++r)
-            __hip_atomic_store(&P->peer_gacc[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-#ifdef EH_P2P_EXP_NOFENCE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    __threadfence_system();                           // the vector is in every peer's memory before its flag moves
-    __syncthreads();
-    if (tid < P->world) __hip_atomic_store(&P->peer_flag[tid][slot * EH_GSHARDS + P->rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
     if (tid == 0) __hip_atomic_store(P->counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -495,15 +502,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         const EhFused& z = a.fz;
         const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * net.n_theta;
-        if (P2PM && z.pending)       // data parallel without a collective: every rank's sums of the previous step have to be here
-            eh_p2p_wait(a.p2p, a.p2p->peer_flag[a.p2p->rank] + ((z.gslot + 2) % 3) * EH_GSHARDS, a.p2p_seq - 1u, tid);
-        // (EH_MODE_TRAIN_P2P: the receive buffer is written by other GPUs -- system-scope vector loads, never the scalar cache)
-        auto ld = [](const float* q) { return P2PM ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q; };
-        if (z.pending) {
+        if (!P2PM && z.pending) {
 #pragma unroll
             for (int sh = 0; sh < EH_GSHARDS; ++sh) {
                 const float* gp = g_prev + sh * a.n_acc + net.n_theta;
-                f_sse += ld(gp); f_cnt += ld(gp + 1); f_sy += ld(gp + 2); f_syy += ld(gp + 3);      // single target: [S | n | Sy | Syy]
+                f_sse += gp[0]; f_cnt += gp[1]; f_sy += gp[2]; f_syy += gp[3];      // single target: [S | n | Sy | Syy]
             }
         }
         const float* const sc_in = z.pset + 6 * net.n_theta + 2 * z.sc_sel;
@@ -511,11 +514,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         if (tid < net.n_theta) {
             f_th = pin[tid]; f_m = pin[net.n_theta + tid]; f_v = pin[2 * net.n_theta + tid];
             f_map = tid < net.g_off ? z.imap[tid] : 0;
-            if (z.pending) {
+            if (!P2PM && z.pending) {
 #pragma unroll
-                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += ld(&g_prev[sh * a.n_acc + tid]);
+                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += g_prev[sh * a.n_acc + tid];
             }
         }
+    }
+    // EH_MODE_TRAIN_P2P: the shards of all ranks for the previous step, every 64-bit word with its own arrival stamp.
+    // The workgroup fetches the world x (min(n_theta, NTHR) + 4) words it needs cooperatively -- a handful per thread,
+    // requested here together with the loads above and the image below, examined (and re-read while a peer is late)
+    // once the image is staged -- and parks the values in LDS, from where every thread sums its own element over
+    // the ranks in rank order.
+    constexpr int P2P_NW = P2PM ? (EH_GSHARDS * (NTHR + 4) + NTHR - 1) / NTHR : 1;
+    static_assert(!P2PM || EH_GSHARDS * (NTHR + 4) <= NW * G::WAVE_WS, "the received sums are parked in the (still unused) wave workspaces");
+    const int p2p_ne = (net.n_theta < NTHR ? net.n_theta : NTHR) + 4;
+    auto p2p_addr = [&](int u) -> const unsigned long long* {
+        const int j = tid + u * NTHR;
+        if (j >= a.p2p->world * p2p_ne) return nullptr;
+        const int sh = j / p2p_ne, e = j - sh * p2p_ne;
+        const int idx = e < p2p_ne - 4 ? e : net.n_theta + (e - (p2p_ne - 4));
+        return a.p2p->peer_recv[a.p2p->rank] + ((long long)((a.fz.gslot + 2) % 3) * EH_GSHARDS + sh) * a.n_acc + idx;
+    };
+    unsigned long long p2p_w[P2P_NW];
+    if constexpr (P2PM) {
+        if (fusedm && a.fz.pending) eh_ll_issue(p2p_addr, a.p2p_seq - 1u, p2p_w);
     }
     {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
         constexpr int NI = (G::IMG_FLOATS / 4 + NTHR - 1) / NTHR, NIB = NI < 16 ? NI : 16;
@@ -531,6 +553,23 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 const int e = e0 + 4 * NTHR * u;
                 if (e < G::IMG_FLOATS) *(f32x4*)&wl[e] = tmp[u];
             }
+        }
+    }
+    if constexpr (P2PM) {
+        if (fusedm && a.fz.pending) {
+            float got[P2P_NW];
+            eh_ll_finish(a.p2p, p2p_addr, a.p2p_seq - 1u, p2p_w, got);
+            float* const T = smem + G::IMG_FLOATS;               // [world][p2p_ne]
+#pragma unroll
+            for (int u = 0; u < P2P_NW; ++u)
+                if (tid + u * NTHR < a.p2p->world * p2p_ne) T[tid + u * NTHR] = got[u];
+            __syncthreads();
+            for (int sh = 0; sh < a.p2p->world; ++sh) {
+                const float* Ts = T + sh * p2p_ne;
+                f_sse += Ts[p2p_ne - 4]; f_cnt += Ts[p2p_ne - 3]; f_sy += Ts[p2p_ne - 2]; f_syy += Ts[p2p_ne - 1];
+                if (tid < p2p_ne - 4) f_g += Ts[tid];
+            }
+            __syncthreads();                                     // T lives where the X images are about to be cleared
         }
     }
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
@@ -563,7 +602,6 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         float* const g_zero = (P2PM ? a.p2p->stage : z.gacc) + ((z.gslot + 1) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * nth;
         float* const pout = z.pset + (z.cur ^ 1) * 3 * nth;
-        auto ldg = [&](const float* q) { return P2PM ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q; };
         const bool upd = z.pending && f_cnt > 0.0f;
         float inv = 0.0f, lossv = __builtin_nanf("");
         if (upd) eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv);
@@ -575,8 +613,20 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                 th = pin[idx]; mm = pin[nth + idx]; vv = pin[2 * nth + idx];
                 mp = idx < net.g_off ? z.imap[idx] : 0;
                 if (upd) {
+                    if constexpr (P2PM) {
+                        auto ad = [&](int sh) -> const unsigned long long* {
+                            return sh < a.p2p->world ? a.p2p->peer_recv[a.p2p->rank] + ((long long)((z.gslot + 2) % 3) * EH_GSHARDS + sh) * a.n_acc + idx : nullptr;
+                        };
+                        unsigned long long w8[EH_GSHARDS];
+                        float got[EH_GSHARDS];
+                        eh_ll_issue(ad, a.p2p_seq - 1u, w8);
+                        eh_ll_finish(a.p2p, ad, a.p2p_seq - 1u, w8, got);
 #pragma unroll
-                    for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += ldg(&g_prev[sh * a.n_acc + idx]);
+                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += got[sh];
+                    } else {
+#pragma unroll
+                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * a.n_acc + idx];
+                    }
                 }
             }
             if (upd) eh_opt_update(z.opt, gs * inv, f_bt1, f_bt2, th, mm, vv);

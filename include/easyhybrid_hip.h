@@ -213,12 +213,13 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
  * last pending update. */
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index);
 
-/* Cross-GPU exchange without a collective call (2..8 ranks of one node, fused_update mode): the
- * accumulators become an uncached receive buffer that every peer maps over HIP IPC; the last
- * workgroup of a step stores the rank's sums into every peer's buffer (xGMI peer-to-peer stores)
- * and raises a flag, the next step's prologue waits for all flags (2 s deadline -> error at
- * eh_synchronize, never a hang).  eh_dp_fused_step then needs NO host all-reduce (*buffer_index = -1).
- *   eh_p2p_init     : allocate + export; writes the 64-byte IPC handle of this rank
+/* Cross-GPU exchange without a collective call (2..8 ranks of one node, fused_update mode): every rank
+ * owns an uncached receive buffer of {value, sequence number} words that all peers map over HIP IPC;
+ * the last workgroup of a step stores the rank's sums into every peer's buffer (one 8-byte xGMI
+ * peer-to-peer store per element, carrying its own arrival stamp), the next step's prologue reads the
+ * shards of all ranks and re-reads what has not arrived yet (2 s deadline -> error at eh_synchronize,
+ * never a hang).  eh_dp_fused_step then needs NO host all-reduce (*buffer_index = -1).
+ *   eh_p2p_init     : allocate + export; writes the 64-byte IPC handle of this rank (world = 1: loopback)
  *   (host: all-gather the handles of all ranks, e.g. over torch.distributed)
  *   eh_p2p_attach   : map every peer; handles = world consecutive handles, `handle_stride` bytes apart
  *   eh_p2p_selftest : `rounds` exchanges of known vectors, all ranks together; *ok = 0 -> call
