@@ -172,23 +172,28 @@ class DataParallel:
             return {"p2p_us": None, "collective_us": None, "chosen": "collective"}
 
         def timed():
-            for _ in range(20):
-                self.step(first, count)
-            self.engine.synchronize()
+            # every rank runs the same sequence of collectives whatever happens locally (an exception on one rank
+            # must not leave its peers inside a barrier)
+            ok = True
+            try:
+                for _ in range(20):
+                    self.step(first, count)
+                self.engine.synchronize()
+            except Exception:
+                ok = False
             dist.barrier(group=self.group)
             t0 = time.perf_counter()
-            for _ in range(nsteps):
-                self.step(first, count)
-            self.engine.synchronize()
+            try:
+                for _ in range(nsteps):
+                    self.step(first, count)
+                self.engine.synchronize()
+            except Exception:
+                ok = False
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
                              device=self._dev if dist.get_backend(self.group) == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            return 1e6 * float(t.item()) / nsteps
-        try:
-            t_p2p = timed()
-            ok = True
-        except Exception:
-            t_p2p, ok = float("inf"), False
+            return 1e6 * float(t.item()) / nsteps, ok
+        t_p2p, ok = timed()
         ok = self._all_agree(ok)
         dist.barrier(group=self.group)
         self.engine.p2p_disable()
@@ -197,7 +202,7 @@ class DataParallel:
         if not ok:
             self.engine.set_option("fused_update", 0); self.broadcast_params(0); self.engine.set_option("fused_update", 1)
             return {"p2p_us": None, "collective_us": None, "chosen": "collective (peer-to-peer exchange failed)"}
-        t_col = timed()
+        t_col, _ = timed()
         if t_p2p < t_col:
             self.p2p = self._negotiate_p2p()
             self._refresh_gacc()
