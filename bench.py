@@ -78,11 +78,19 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # EH_BENCH_SHARE_GPU=1 (testing only): all ranks on GPU 0 with gloo carrying the collectives -- the only way to walk
+    # the multi-rank flow of this script on a one-GPU box (RCCL refuses two ranks on one device); numbers are meaningless
+    share = os.environ.get("EH_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import easyhybrid_jl_amd as eh
     from easyhybrid_jl_amd.synthetic import RBQ10_PARAMS, make_synth_rbq10
@@ -100,6 +108,8 @@ def main():
     t_up = time.perf_counter() - t_up      # one-time host -> HBM upload (interleave on the host + PCIe); never part of `value`
     eng.set_params(model.initialparameters(161803))                 # same seed on every rank: replicas start equal
     eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
+    if share:
+        eng.set_option("max_blocks", max(1, 128 // world))          # every rank's kernel has to fit on the shared GPU at once
     force_dp = os.environ.get("EH_FORCE_DP", "0") == "1"          # exercise the data-parallel seam on one GPU
     if world > 1 or force_dp:
         if world == 1:
@@ -141,7 +151,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if share else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -186,7 +196,8 @@ def main():
             except Exception:
                 pass
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if (dp is None or dp.fused) else
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train+p2p,K1|PS> (fused update, peer-to-peer exchange)" if (dp is not None and dp.p2p) else
+                    "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if (dp is None or dp.fused) else
                     "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> + eh_reduce_kernel", "kernel_ms": ms_step, "launches_timed": n,
                     "kernel_ms_p10_p50_p90": [float(np.percentile(per_launch, q)) for q in (10, 50, 90)],
                     "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce kernel per launch)" if (dp is not None and not dp.fused) else "")
