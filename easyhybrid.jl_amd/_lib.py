@@ -70,6 +70,7 @@ SIGNATURES = {
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
     "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),
     "eh_dp_apply": (C.c_int32, [_H, _F]),
+    "eh_dp_shuffle": (C.c_int32, [_H, C.c_uint64, C.c_int32]),
     "eh_p2p_init": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "eh_p2p_attach": (C.c_int32, [_H, C.c_void_p, C.c_int64]),
     "eh_p2p_selftest": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_int32)]),

@@ -966,13 +966,14 @@ static int grid_for(const eh_handle* h, long long count) {
 static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool update, EhStepArgs* a) {
     a->bn_part = nullptr; a->bn_nblk = 0; a->bn_update = 0; a->bn_run = h->bn_run; a->image_out = h->image;
     a->bn_c = nullptr; a->bn_n = nullptr;
-    if (!h->bn_on || count <= 0) return EH_OK;
+    if (!h->bn_on) return EH_OK;
     if (h->bn_ext) {          // statistics of the GLOBAL batch, summed over the GPUs by the host since eh_dp_bn_stats
         a->bn_part = h->bn_stat; a->bn_nblk = 1; a->bn_c = h->bn_shift; a->bn_n = h->bn_stat + 64;
         a->bn_update = (update || h->bn_dp_update) ? 1 : 0;
         h->bn_ext = false; h->bn_dp_update = false;
         return EH_OK;
     }
+    if (count <= 0) return EH_OK;
     const int nblk = (int)std::max<long long>(1, std::min<long long>(32, (count + 1023) / 1024));
     hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part, nullptr);
     HIPCHK(h, hipGetLastError());
@@ -1315,6 +1316,23 @@ int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_ou
     return EH_OK;
 }
 
+// device-side keyed permutation of the train split's sample indices into h->perm
+static int make_permutation(eh_handle* h, long long N, uint64_t seed) {
+    if (h->perm_cap < N) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->perm);
+        h->perm = nullptr; h->perm_cap = 0;
+        HIPCHK(h, hipMalloc(&h->perm, (size_t)N * sizeof(int)));
+        h->perm_cap = N;
+    }
+    int bits = 1;
+    while ((1LL << bits) < N) ++bits;
+    const int hb = std::max(1, (bits + 1) / 2);
+    hipLaunchKernelGGL(eh_perm_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->perm, (uint32_t)N, hb, seed);
+    HIPCHK(h, hipGetLastError());
+    return EH_OK;
+}
+
 int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t shuffle, float* mean_loss, int64_t* n_steps) {
     if (!h) return EH_EINVAL;
     if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_train_epoch: call eh_opt_init first");
@@ -1324,18 +1342,8 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
     if (!sp.recs || sp.n == 0) return fail(h, EH_ESTATE, "eh_train_epoch: no training data");
     const long long N = sp.n;
     if (shuffle) {
-        if (h->perm_cap < N) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            (void)hipFree(h->perm);
-            h->perm = nullptr; h->perm_cap = 0;
-            HIPCHK(h, hipMalloc(&h->perm, (size_t)N * sizeof(int)));
-            h->perm_cap = N;
-        }
-        int bits = 1;
-        while ((1LL << bits) < N) ++bits;
-        const int hb = std::max(1, (bits + 1) / 2);
-        hipLaunchKernelGGL(eh_perm_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->perm, (uint32_t)N, hb, seed);
-        HIPCHK(h, hipGetLastError());
+        if (int rc = make_permutation(h, N, seed)) return rc;
+        h->perm_valid = false;          // (the data-parallel window order of eh_dp_shuffle is gone)
     }
     const long long steps = (N + batchsize - 1) / batchsize;
     int rc = ensure_loss_hist(h, steps);
@@ -1359,6 +1367,17 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
     return EH_OK;
 }
 
+int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
+    if (!h) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!on) { h->perm_valid = false; return EH_OK; }      // (stream order keeps earlier steps on the old permutation)
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    if (!sp.recs || sp.n == 0) return fail(h, EH_ESTATE, "eh_dp_shuffle: no training data");
+    if (int rc = make_permutation(h, sp.n, seed)) return rc;
+    h->perm_valid = true;
+    return EH_OK;
+}
+
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
@@ -1369,7 +1388,7 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
     int rc = check_window(h, sp, first, count, "eh_dp_grad");
     if (rc) return rc;
-    return do_step(h, sp, (!h->fused && h->perm_valid) ? h->perm : nullptr, first, count, false, true, nullptr);
+    return do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
 }
 
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index) {
@@ -1382,7 +1401,7 @@ int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* bu
     int rc = check_window(h, sp, first, count, "eh_dp_fused_step");
     if (rc) return rc;
     *buffer_index = h->p2p_on ? -1 : (int32_t)(h->gstep % 3);        // -1: the kernels exchange the sums themselves (eh_p2p_attach)
-    return do_fused_step(h, sp, nullptr, first, count, nullptr);
+    return do_fused_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, nullptr);
 }
 
 // ---- cross-GPU exchange without a collective call (EhP2P, csrc/eh_device.hpp) ----------------------
@@ -1501,7 +1520,7 @@ int32_t eh_dp_bn_stats(eh_handle* h, int64_t first, int64_t count) {
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
     int rc = check_window(h, sp, first, count, "eh_dp_bn_stats");
     if (rc) return rc;
-    const int* idx = (!h->fused && h->perm_valid) ? h->perm : nullptr;      // the same samples eh_dp_grad / eh_dp_fused_step will read
+    const int* idx = h->perm_valid ? h->perm : nullptr;      // the same samples eh_dp_grad / eh_dp_fused_step will read
     const int nblk = (int)std::max<long long>(1, std::min<long long>(32, (count + 1023) / 1024));
     hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part, h->bn_shift);
     HIPCHK(h, hipGetLastError());

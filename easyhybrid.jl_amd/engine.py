@@ -214,6 +214,10 @@ class HybridEngine:
     def dp_bn_stats(self, first: int, count: int):
         self._chk(self._lib.eh_dp_bn_stats(self._h, first, count))
 
+    def dp_shuffle(self, seed: int = 0, on: bool = True):
+        """per-shard epoch shuffle of the windows the dp_* calls take (same permutation generator as train_epoch)"""
+        self._chk(self._lib.eh_dp_shuffle(self._h, seed & (2**64 - 1), int(on)))
+
     def dp_apply(self, want_loss: bool = False):
         loss = C.c_float()
         self._chk(self._lib.eh_dp_apply(self._h, C.byref(loss) if want_loss else None))

@@ -99,6 +99,9 @@ class TrainConfig:
     keep_history: bool = True
     show_progress: bool = False
     device: int = 0
+    # not in the reference (it has no multi-GPU path): None = data parallel iff torch.distributed is initialised with
+    # more than one rank; True / False force it.  `batchsize` stays the GLOBAL minibatch, split evenly over the ranks.
+    distributed: Optional[bool] = None
 
 
 @dataclass
@@ -245,6 +248,106 @@ def _losses(engine, split, targets, loss_types):
     return out
 
 
+def _want_distributed(tc: TrainConfig) -> bool:
+    if tc.distributed is not None:
+        return bool(tc.distributed)
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        return False
+
+
+def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> TrainResults:
+    """The epoch loop of `train` with the steps sharded over the ranks of the default process group (one process per
+    GPU).  Every rank holds a contiguous shard of the training split as its train data and takes batchsize / world
+    samples of it per step (per-shard shuffling: the sample ORDER differs from a global shuffle, the distribution does
+    not); gradients meet through DataParallel (peer-to-peer stores or one RCCL all-reduce per step).  Evaluation is
+    replicated: a second engine per rank holds the full train / validation splits, so history, early stopping and the
+    returned TrainResults are identical on every rank without further communication."""
+    import torch
+    import torch.distributed as dist
+    from .dp import DataParallel, shard_range
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("train(distributed=True) needs an initialised torch.distributed process group (one rank per GPU)")
+    if len(model.targets) != 1:
+        raise NotImplementedError("distributed training: the data-parallel seam supports single-target models")
+    (xtr, ftr, ytr), (xva, fva, yva) = train_split, val_split
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = torch.cuda.current_device()
+    N = xtr.shape[1]
+    lo, hi = shard_range(N, rank, world)
+    ev = model.engine(device)                         # evaluation replica: full splits
+    eng = model.engine(device)                        # training replica: this rank's shard
+    try:
+        ev.set_data(L.EH_SPLIT_TRAIN, xtr, [ftr[f] for f in model.forcing], [ytr[t] for t in model.targets])
+        ev.set_data(L.EH_SPLIT_VAL, xva, [fva[f] for f in model.forcing], [yva[t] for t in model.targets])
+        eng.set_data(L.EH_SPLIT_TRAIN, xtr[:, lo:hi], [ftr[f][lo:hi] for f in model.forcing], [ytr[t][lo:hi] for t in model.targets])
+        if tc.train_from is None:
+            theta = model.initialparameters(rng)      # same seed -> same start on every rank
+        else:
+            theta = np.asarray(tc.train_from.ps if isinstance(tc.train_from, TrainResults) else tc.train_from[0], np.float32)
+        eng.set_params(theta); ev.set_params(theta)
+        eng.opt_init(**_opt_args(tc.opt))
+        eng.set_training_loss(tc.training_loss)
+        drv = DataParallel(eng)
+        has_bn = bool(model.config.get("input_batchnorm"))
+        first_lt = tc.loss_types[0]
+
+        def snapshot():
+            eng.synchronize()
+            ev.set_params(eng.get_params())
+            if has_bn:
+                ev.set_bn_state(*eng.get_bn_state())
+            return EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
+                                 _losses(ev, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
+        init = snapshot()
+        history = [init]
+        best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0
+        seed0 = tc.random_seed if tc.random_seed is not None else 0
+        b = -(-tc.batchsize // world)                 # samples per rank per step
+        steps = -(-(-(-N // world)) // b)             # ceil(largest shard / b): the same number of steps on every rank
+        n_loc = hi - lo
+        for epoch in range(1, tc.nepochs + 1):
+            eng.dp_shuffle(seed0 + epoch + 7919 * rank)
+            for s_ in range(steps):
+                first = min(s_ * b, n_loc)
+                drv.step(first, min(b, n_loc - first))
+            snap = snapshot()
+            if tc.keep_history:
+                history.append(snap)
+            cur = snap.l_val[first_lt]["sum"]
+            if isbetter(cur, best_loss, first_lt):
+                best_loss, best_ps, best_epoch, counter = cur, eng.get_params(), epoch, 0
+                if not tc.keep_history:
+                    history[0] = snap
+            else:
+                counter += 1
+            if counter >= tc.patience:
+                break
+        eng.synchronize()
+        ps = best_ps if tc.return_model == "best" else eng.get_params()
+        ev.set_params(ps)
+
+        def obs_pred(split, y):
+            if ev.n_samples[split] == 0:
+                return {}, None
+            out = ev.forward(split)
+            d = {t: y[t] for t in model.targets}
+            d.update({t + "_pred": out[t] for t in model.targets})
+            return d, out["parameters"]
+        tr_op, tr_diff = obs_pred(L.EH_SPLIT_TRAIN, ytr)
+        va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
+        st = {"fixed": {f: np.float32(model.parameters.default(f)) for f in model.fixed_param_names}}
+        if has_bn:
+            rm, rv = eng.get_bn_state()
+            st["st_nn"] = {"running_mean": rm, "running_var": rv}
+        return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
+                            ps, st, best_epoch, best_loss)
+    finally:
+        eng.close(); ev.close()
+
+
 def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[TrainConfig] = None,
           data_cfg: Optional[DataConfig] = None, engine=None, **kwargs) -> Optional[TrainResults]:
     """train(model, data; kwargs...) -> TrainResults (train.jl:211-219 -> _train :95-136).
@@ -263,6 +366,8 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
     (xtr, ftr, ytr), (xva, fva, yva) = [(a[0][0], a[0][1], a[1]) for a in split_data(data, model, dc, rng)]
     if xtr.shape[1] == 0:
         return None                                                # train.jl:186 ("returns nothing on empty splits")
+    if _want_distributed(tc):
+        return _train_distributed(model, tc, rng, (xtr, ftr, ytr), (xva, fva, yva))
     own = engine is None
     eng = engine if engine is not None else model.engine(tc.device)
     try:

@@ -193,6 +193,12 @@ int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_ta
  * so shards exchange sums and counts, never per-shard means.  Single-target models only (T == 1). */
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count);
 int32_t eh_dp_apply(eh_handle* h, float* loss_out);
+/* per-shard epoch shuffle for the data-parallel calls (the reference shuffles the whole training set,
+ * src/data/loaders.jl:6; here every rank permutes its own shard): on != 0 draws a new keyed
+ * permutation of the train split -- the same generator eh_train_epoch uses -- and the windows
+ * [first, first+count) of eh_dp_grad / eh_dp_fused_step / eh_dp_bn_stats then index THROUGH it;
+ * on == 0 goes back to contiguous windows.  eh_set_data and a shuffled eh_train_epoch drop it. */
+int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on);
 
 /* Input BatchNorm under data parallelism (Lux BatchNorm normalises with the statistics of the WHOLE
  * minibatch, src/models/NNModels.jl:97-105): before eh_dp_grad / eh_dp_fused_step of a step,

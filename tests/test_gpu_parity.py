@@ -930,3 +930,32 @@ def test_width_128_fluxpart_multi_target_and_multinn(targets, nets):
     assert np.allclose(losses, l_ref, rtol=1e-4)
     assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
     eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# train(distributed=True): the epoch loop sharded over ranks (here: one rank, RCCL) must reproduce train()
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bn", [False, True])
+def test_train_front_door_distributed_matches_single_process(bn):
+    import socket
+    import torch
+    import torch.distributed as dist
+    cols = eh.synthetic.make_synth_rbq10(3000, seed=5, nan_frac=0.05)
+    if not bn:
+        cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True, input_batchnorm=bn)
+    kw = dict(nepochs=6, batchsize=256, opt=eh.Adam(0.01), loss_types=["mse", "r2"], random_seed=11)
+    ref = eh.train(model, cols, **kw)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        out = eh.train(model, cols, distributed=True, **kw)
+    finally:
+        dist.destroy_process_group()
+    assert out.best_epoch == ref.best_epoch
+    assert np.max(np.abs(out.ps - ref.ps)) <= 5e-5 * max(1.0, float(np.max(np.abs(ref.ps))))
+    for a, b in zip(out.val_history, ref.val_history):
+        assert a["mse"]["sum"] == pytest.approx(b["mse"]["sum"], rel=2e-4)
+    assert util.relerr(out.val_obs_pred["reco_pred"], ref.val_obs_pred["reco_pred"]) <= 1e-4
