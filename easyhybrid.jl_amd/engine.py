@@ -7,6 +7,7 @@ pieces -> NotImplementedError, call-order / device problems -> RuntimeError).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -53,6 +54,8 @@ class HybridEngine:
         self.param_names = list(param_names)
         self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
         self.x_sum = {}
+        if os.environ.get("EH_MAX_BLOCKS"):               # several ranks sharing one GPU (tests): every kernel must fit beside the others
+            self.set_option("max_blocks", int(os.environ["EH_MAX_BLOCKS"]))
 
     # -- plumbing --------------------------------------------------------------------------------
     def _chk(self, st: int):

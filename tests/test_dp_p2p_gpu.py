@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env, port):
+def _run(extra_env, port, tool="p2p_two_ranks.py"):
     import torch
     if torch.cuda.is_initialized():
         pytest.skip("this process already initialised the GPU; run this file first (or alone)")
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tools", "p2p_two_ranks.py")]
+           "--master-port", str(port), os.path.join(ROOT, "tools", tool)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in (r.stdout + r.stderr).replace("rank ", "\nrank ").splitlines() if l.startswith("rank ")]
     assert r.returncode == 0, "\n".join(lines) + "\n" + (r.stdout + r.stderr)[-1500:]
@@ -37,3 +37,9 @@ def test_two_ranks_fall_back_to_the_collective_when_one_rank_fails_the_selftest(
     lines = _run({"EH_DP_P2P_FAIL_SELFTEST": "1"}, 29562)
     first = [l for l in lines if "max|theta-ref|" in l]
     assert len(first) == 2 and all("p2p=False" in l and "replicas_identical=True" in l for l in first), lines
+
+
+def test_two_ranks_distributed_train_front_door():
+    # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm
+    lines = _run({"EH_MAX_BLOCKS": "64"}, 29563, tool="train_two_ranks.py")
+    assert len(lines) == 4 and all("results_identical_across_ranks=True" in l for l in lines), lines

@@ -1,0 +1,46 @@
+"""train(model, data, distributed=True) with two ranks on ONE GPU (gloo handshake, peer-to-peer gradient exchange):
+both ranks must return bitwise-identical TrainResults, and the fit must be as good as single-process training
+(the sample order differs -- per-shard shuffle -- so the parameters are close, not equal).
+
+    EH_MAX_BLOCKS=64 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29633 tools/train_two_ranks.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+import easyhybrid_jl_amd as eh
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+
+
+def _host_allreduce(buf, group=None):        # (see tools/p2p_two_ranks.py: gloo's own CUDA path races on this build)
+    if buf.is_cuda:
+        torch.cuda.synchronize(); t = buf.cpu(); dist.all_reduce(t, group=group); buf.copy_(t); torch.cuda.synchronize()
+    else:
+        dist.all_reduce(buf, group=group)
+    return buf
+eh.dp.allreduce_partials = _host_allreduce
+
+ok = True
+for bn in (False, True):
+    cols = eh.synthetic.make_synth_rbq10(20000, seed=5, nan_frac=0.05)
+    if not bn:
+        cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True, input_batchnorm=bn)
+    kw = dict(nepochs=8, batchsize=1024, opt=eh.Adam(0.01), loss_types=["mse", "r2"], random_seed=11)
+    out = eh.train(model, cols, distributed=True, **kw)
+    ref = eh.train(model, cols, distributed=False, **kw)
+    t = torch.from_numpy(np.concatenate([out.ps, [out.best_loss], out.val_obs_pred["reco_pred"][:100]]).astype(np.float64))
+    tl = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(tl, t)
+    same = all(bool(torch.equal(tl[0], q)) for q in tl)
+    v_d, v_r = out.val_history[-1]["mse"]["sum"], ref.val_history[-1]["mse"]["sum"]
+    print(f"rank {rank}: input_batchnorm={bn} val mse distributed {v_d:.5f} vs single-process {v_r:.5f}; "
+          f"first-epoch {out.val_history[0]['mse']['sum']:.3f}; results_identical_across_ranks={same}", flush=True)
+    ok = ok and same and v_d <= 1.25 * v_r + 1e-3 and v_d < 0.5 * out.val_history[0]["mse"]["sum"]
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
