@@ -1142,12 +1142,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
 #pragma unroll
                 for (int w = 0; w < NW; ++w) sum += R0[w * AL.rw + pos];
             }
-#ifdef EH_EXP_NOATOMIC
-            out[e] = sum;
-#else
             if (gsh) atomicAdd(&gsh[e], sum);
             else out[e] = sum;
-#endif
         }
         if constexpr (P2PM) eh_p2p_publish(a.p2p, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
         EH_STAMP(10);
