@@ -69,6 +69,9 @@ SIGNATURES = {
     "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
     "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),
+    "eh_graph_begin": (C.c_int32, [_H]),
+    "eh_graph_end": (C.c_int32, [_H, C.POINTER(C.c_int32)]),
+    "eh_graph_launch": (C.c_int32, [_H, C.c_int32]),
     "eh_dp_apply": (C.c_int32, [_H, _F]),
     "eh_dp_shuffle": (C.c_int32, [_H, C.c_uint64, C.c_int32]),
     "eh_p2p_init": (C.c_int32, [_H, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),

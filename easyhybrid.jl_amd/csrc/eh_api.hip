@@ -382,6 +382,10 @@ struct eh_handle_s {
     int* perm = nullptr;
     long long perm_cap = 0;
     bool perm_valid = false;
+    struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
+    std::vector<GraphRec> graphs;         // eh_graph_*: captured step sequences + the rotation state they start (and must end) in
+    bool capturing = false;
+    GraphRec cap{};
     int max_blocks = 256;
     // scratch for forward / eval outputs
     float* out_buf = nullptr;
@@ -782,6 +786,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
@@ -1330,6 +1335,53 @@ static int make_permutation(eh_handle* h, long long N, uint64_t seed) {
     const int hb = std::max(1, (bits + 1) / 2);
     hipLaunchKernelGGL(eh_perm_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->perm, (uint32_t)N, hb, seed);
     HIPCHK(h, hipGetLastError());
+    return EH_OK;
+}
+
+// ---- hipGraph capture of a sequence of training steps -------------------------------------------------
+int32_t eh_graph_begin(eh_handle* h) {
+    if (!h) return EH_EINVAL;
+    if (h->capturing) return fail(h, EH_ESTATE, "eh_graph_begin: already capturing");
+    // a fused-mode step applies the update of the step before it: the recorded sequence has to start (and every replay
+    // has to find the engine) with such an update pending, or its first kernel would skip / re-apply one
+    if (h->fused && !h->pending) return fail(h, EH_ESTATE, "eh_graph_begin: fused_update mode: run one training step first (and do not synchronize before capturing)");
+    h->cap = {nullptr, h->fused, (int)(h->gstep % 3), h->cur, h->sc_sel};
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_loss_hist(h, 1);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+    h->capturing = true;
+    return EH_OK;
+}
+
+int32_t eh_graph_end(eh_handle* h, int32_t* graph_id) {
+    if (!h || !graph_id) return EH_EINVAL;
+    if (!h->capturing) return fail(h, EH_ESTATE, "eh_graph_end: not capturing");
+    h->capturing = false;
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamEndCapture(h->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(h, EH_EHIP, "eh_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+    if (h->fused != h->cap.fused || (int)(h->gstep % 3) != h->cap.gslot || h->cur != h->cap.cur || h->sc_sel != h->cap.sc_sel) {
+        (void)hipGraphExecDestroy(ex);
+        return fail(h, EH_EINVAL, "eh_graph_end: the recorded sequence does not bring the engine's rotation state back (record a multiple of 6 steps in fused_update mode, of 2 otherwise)");
+    }
+    h->cap.exec = ex;
+    h->graphs.push_back(h->cap);
+    *graph_id = (int32_t)h->graphs.size() - 1;
+    return EH_OK;
+}
+
+int32_t eh_graph_launch(eh_handle* h, int32_t graph_id) {
+    if (!h) return EH_EINVAL;
+    if (graph_id < 0 || graph_id >= (int32_t)h->graphs.size()) return fail(h, EH_EINVAL, "eh_graph_launch: graph %d", graph_id);
+    const eh_handle::GraphRec& g = h->graphs[(size_t)graph_id];
+    if (g.fused != h->fused || g.gslot != (int)(h->gstep % 3) || g.cur != h->cur || g.sc_sel != h->sc_sel || (g.fused && !h->pending))
+        return fail(h, EH_ESTATE, "eh_graph_launch: the engine is not in the state the graph was recorded in (steps / synchronize in between: run steps until it is, with an update pending in fused_update mode)");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipGraphLaunch(g.exec, h->stream));
     return EH_OK;
 }
 

@@ -198,6 +198,18 @@ class HybridEngine:
         self._chk(self._lib.eh_train_step(self._h, first, count, C.byref(loss) if want_loss else None))
         return float(loss.value) if want_loss else None
 
+    # -- hipGraph capture of a step sequence (see include/easyhybrid_hip.h) --------------------------
+    def graph_begin(self):
+        self._chk(self._lib.eh_graph_begin(self._h))
+
+    def graph_end(self) -> int:
+        g = C.c_int32()
+        self._chk(self._lib.eh_graph_end(self._h, C.byref(g)))
+        return int(g.value)
+
+    def graph_launch(self, graph_id: int):
+        self._chk(self._lib.eh_graph_launch(self._h, graph_id))
+
     def train_epoch(self, batchsize: int, seed: int = 0, shuffle: bool = True, want_loss: bool = True):
         loss = C.c_float()
         ns = C.c_int64()

@@ -179,6 +179,18 @@ int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_ou
  * stream).  mean_loss: mean of the per-step losses (nullable); n_steps: steps run (nullable). */
 int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t shuffle, float* mean_loss, int64_t* n_steps);
 
+/* hipGraph capture of a sequence of steps: between eh_graph_begin and eh_graph_end the calls
+ * eh_train_step(..., loss_out = NULL) / eh_dp_fused_step are recorded, not run; eh_graph_launch replays the
+ * recorded sequence (same windows, same buffers).  The calls advance the engine's rotation state
+ * (accumulator slot, parameter-set ping-pong) as if they had run, and a graph is only valid in the
+ * state it was recorded in: record a multiple of 6 steps in fused_update mode (of 2 otherwise) so that
+ * it can be replayed back to back, and in fused_update mode begin (and launch) with an update pending,
+ * i.e. right after a step and without an eh_synchronize in between.  Violations are refused.
+ * (Measured: no gain on the RbQ10 step -- the gap between two dependent kernels is on the GPU side.) */
+int32_t eh_graph_begin(eh_handle* h);
+int32_t eh_graph_end(eh_handle* h, int32_t* graph_id);
+int32_t eh_graph_launch(eh_handle* h, int32_t graph_id);
+
 /* evaluate_acc on samples [first, first+count) of a split: metrics per target, optionally the
  * predictions and physical parameters (host arrays as in eh_forward). */
 int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_target_metrics* out,

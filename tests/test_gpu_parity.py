@@ -959,3 +959,36 @@ def test_train_front_door_distributed_matches_single_process(bn):
     for a, b in zip(out.val_history, ref.val_history):
         assert a["mse"]["sum"] == pytest.approx(b["mse"]["sum"], rel=2e-4)
     assert util.relerr(out.val_obs_pred["reco_pred"], ref.val_obs_pred["reco_pred"]) <= 1e-4
+
+
+def test_hipgraph_replay_of_a_step_sequence_equals_plain_steps():
+    spec, theta, X, f, y = util.rbq10_case(7 * 512, "tanh", True, 0.1)
+    for fused in (0, 1):
+        ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01); ref.set_option("fused_update", fused)
+        eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_option("fused_update", fused)
+        if fused:
+            with pytest.raises(eh.EngineError, match="run one training step first"):
+                eng.graph_begin()                            # a fused-mode graph has to start with an update pending
+        ref.train_step(6 * 512, 512, want_loss=False); eng.train_step(6 * 512, 512, want_loss=False)
+        for rep in range(3):
+            for i in range(6):
+                ref.train_step(i * 512, 512, want_loss=False)
+        eng.graph_begin()
+        for i in range(6):                                   # recorded, not run: 6 steps = one full rotation of the engine state
+            eng.train_step(i * 512, 512, want_loss=False)
+        g = eng.graph_end()
+        for rep in range(3):
+            eng.graph_launch(g)
+        assert np.max(np.abs(eng.get_params() - ref.get_params())) <= (2e-6 if fused else 0.0), fused
+        if fused:
+            with pytest.raises(eh.EngineError, match="not in the state"):
+                eng.graph_launch(g)                          # get_params flushed the pending update
+        eng.train_step(0, 512, want_loss=False)
+        with pytest.raises(eh.EngineError, match="not in the state"):
+            eng.graph_launch(g)                              # one step off the recorded rotation
+        eng.graph_begin()
+        for i in range(5):
+            eng.train_step(i * 512, 512, want_loss=False)
+        with pytest.raises(ValueError, match="rotation state"):
+            eng.graph_end()
+        eng.close(); ref.close()
