@@ -182,6 +182,30 @@ __device__ __forceinline__ float eh_act(float z) {
     if (ACT == EH_ACT_SWISH) return z * eh_sigmoid(z);
     return z;
 }
+// Four values at once: tanh's polynomial work goes through packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32, two lanes of
+// a register pair per instruction) -- the same IEEE operations in the same order as eh_tanh, at half the issue slots.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 eh_tanh2(f32x2 x) {
+    x[0] = __builtin_amdgcn_fmed3f(x[0], -8.125f, 8.125f);
+    x[1] = __builtin_amdgcn_fmed3f(x[1], -8.125f, 8.125f);
+    const f32x2 x2 = x * x;
+    auto fma2 = [](f32x2 a, f32x2 b, float c) { return __builtin_elementwise_fma(a, b, f32x2{c, c}); };
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 n = fma2(x2, f32x2{1.587199e-8f, 1.587199e-8f}, 2.2332108e-5f);
+    n = fma2(x2, n, 0.0035974074f); n = fma2(x2, n, 0.1346604f); n = __builtin_elementwise_fma(x2, n, one);
+    f32x2 d = fma2(x2, f32x2{8.7767893e-7f, 8.7767893e-7f}, 0.0003453992f);
+    d = fma2(x2, d, 0.026262015f); d = fma2(x2, d, 0.4679937f); d = __builtin_elementwise_fma(x2, d, one);
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * (n * r);
+}
+template <int ACT>
+__device__ __forceinline__ f32x4 eh_act4(f32x4 z) {
+    if (ACT == EH_ACT_TANH) {
+        const f32x2 a = eh_tanh2(f32x2{z[0], z[1]}), b = eh_tanh2(f32x2{z[2], z[3]});
+        return f32x4{a[0], a[1], b[0], b[1]};
+    }
+    return f32x4{eh_act<ACT>(z[0]), eh_act<ACT>(z[1]), eh_act<ACT>(z[2]), eh_act<ACT>(z[3])};
+}
 // derivative from the stored value: h for tanh/sigmoid/relu/identity, z for swish
 template <int ACT>
 __device__ __forceinline__ float eh_dact(float s) {
@@ -730,13 +754,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                const f32x4 z4 = h[m][t], hv4 = eh_act4<ACT>(z4);
+                h[m][t] = hv4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = h[m][t][r];
-                    const float hv = eh_act<ACT>(z);
-                    h[m][t][r] = hv;
-                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z : hv;
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z4[r] : hv4[r];
                 if constexpr (KEEPH) hs[0][m][t] = h[m][t];
             }
         }
@@ -766,14 +788,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             for (int m = 0; m < NBH; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+                    const f32x4 z4 = hn[m][t], hv4 = eh_act4<ACT>(z4);
+                    h[m][t] = hv4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = hn[m][t][r];
-                        const float hv = eh_act<ACT>(z);
-                        h[m][t][r] = hv;
-                        // the last layer's image is only read back for act' / dWo when those do not have it in registers
-                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z : hv;
-                    }
+                    for (int r = 0; r < 4; ++r)      // the last layer's image is only read back for act' / dWo when those do not have it in registers
+                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z4[r] : hv4[r];
                     if constexpr (KEEPH) hs[l < NHS ? l : 0][m < NHM ? m : 0][t < NHT ? t : 0] = h[m][t];
                 }
         }

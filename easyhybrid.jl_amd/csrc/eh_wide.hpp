@@ -237,12 +237,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 z4 = acc[mm][t], hv4 = (ACT == EH_ACT_SWISH && TRAIN) ? z4 : eh_act4<ACT>(z4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = acc[mm][t][r];
-                        HS[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH && TRAIN) ? z : eh_act<ACT>(z);
-                    }
+                    for (int r = 0; r < 4; ++r) HS[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = hv4[r];
+                }
         }
         eh_lds_barrier();
         EH_STAMP(2);
@@ -276,12 +275,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 z4 = acc[mm][t], hv4 = (ACT == EH_ACT_SWISH && TRAIN) ? z4 : eh_act4<ACT>(z4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = acc[mm][t][r];
-                        Hl[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH && TRAIN) ? z : eh_act<ACT>(z);
-                    }
+                    for (int r = 0; r < 4; ++r) Hl[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = hv4[r];
+                }
             eh_lds_barrier();
         }
         EH_STAMP(3);
