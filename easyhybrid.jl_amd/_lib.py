@@ -16,7 +16,7 @@ EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTA
 
 ACTIVATIONS = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
 OPT_RULES = {"Adam": 0, "AdamW": 1, "RMSProp": 2, "Descent": 3}
-TRAINING_LOSSES = {"mse": 0, "rmse": 1, "mae": 2, "nseLoss": 3}
+TRAINING_LOSSES = {"mse": 0, "rmse": 1, "mae": 2, "nseLoss": 3, "pearsonLoss": 4, "kgeLoss": 5, "pbkgeLoss": 6}
 PAR_NEURAL, PAR_GLOBAL, PAR_FIXED = 0, 1, 2
 
 

@@ -51,7 +51,7 @@ __global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
 template <bool APPLY, int CW>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
-                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
+                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom) {
     constexpr int NQ = 256 / CW;
     __shared__ float part[NQ][CW + 1];
     __shared__ float wsum[4][EH_MAX_TARG + 3];
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     }
     float dscale = 1.0f, dloss = 0.0f;
     if (deferred) eh_loss_finish(loss_kind, cnts[EH_MAX_TARG], cnts[0], cnts[EH_MAX_TARG + 1], cnts[EH_MAX_TARG + 2], dscale, dloss);
+    if (deferred && mom && cnts[0] > 0.0f) { dscale = 1.0f; dloss = mom[7]; }      // moment-based loss: per-sample weights were exact, value from eh_moment_coef_kernel
     if (q == 0 && idx < n_acc) {
         float tot = 0.0f;
 #pragma unroll
@@ -182,6 +183,46 @@ __global__ __launch_bounds__(256) void eh_p2p_test_kernel(const EhP2P* P, int sl
         for (int r = 0; r < P->world; ++r) { sum += got[r]; want += eh_p2p_test_value(r, i, seq); }
         if (sum != want) atomicAdd(bad, 1);
     }
+}
+
+// Moment-based training losses (pearsonLoss, kgeLoss, pbkgeLoss; src/losses/loss_fn.jl:75-77,105-174): from the batch
+// moments the forward-only pass left in the slab ([blocks][EH_EVAL_STATS], shifted by c) to the loss value and the
+// coefficients of  d loss / d yhat_i = k0 + k1 (yhat_i - c) + k2 (y_i - c).  out = [1, -, -, -, k0, k1, k2, loss].
+// With u = yhat - c, w = y - c:  r = Suw_c / sqrt(Suu_c Sww_c),  alpha = sqrt(Suu_c / Sww_c) (the n-1 of std cancels),
+// beta = mean(yhat) / mean(y);  dr/du_i = (w_i - mw) / sqrt(Suu_c Sww_c) - r (u_i - mu) / Suu_c,
+// dalpha/du_i = (u_i - mu) / (alpha Sww_c),  dbeta/du_i = 1 / (n mean(y)).
+__global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int kind, float shift, float* out) {
+    __shared__ double tot[EH_EVAL_STATS];
+    const int tid = threadIdx.x;
+    if (tid < EH_EVAL_STATS) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += (double)slab[b * EH_EVAL_STATS + tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const double n = tot[3], Sw = tot[1], Sww = tot[2], Su = tot[4], Suu = tot[5], Suw = tot[6];
+    float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, loss = __builtin_nanf("");
+    if (n > 0.0) {
+        const double mu = Su / n, mw = Sw / n;
+        const double Suu_c = Suu - Su * Su / n, Sww_c = Sww - Sw * Sw / n, Suw_c = Suw - Su * Sw / n;
+        const double den = sqrt(Suu_c * Sww_c), r = Suw_c / den;
+        // dr = a_u (u_i - mu) + a_w (w_i - mw)
+        const double a_u = -r / Suu_c, a_w = 1.0 / den;
+        double g_r, g_a = 0.0, g_b = 0.0, L;
+        if (kind == EH_LOSS_PEARSONLOSS) { L = 1.0 - r; g_r = -1.0; }
+        else {
+            const double alpha = sqrt(Suu_c / Sww_c), beta = ((double)shift + mu) / ((double)shift + mw);
+            if (kind == EH_LOSS_KGELOSS) { L = sqrt((r - 1) * (r - 1) + (alpha - 1) * (alpha - 1) + (beta - 1) * (beta - 1)); g_a = (alpha - 1) / L / (alpha * Sww_c); }
+            else L = sqrt((r - 1) * (r - 1) + (beta - 1) * (beta - 1));
+            g_r = (r - 1) / L;
+            g_b = (beta - 1) / L / (n * ((double)shift + mw));
+        }
+        const double cu = g_r * a_u + g_a, cw = g_r * a_w;        // coefficients of (u_i - mu), (w_i - mw)
+        k1 = (float)cu; k2 = (float)cw; k0 = (float)(g_b - cu * mu - cw * mw);
+        loss = (float)L;
+    }
+    out[0] = 1.0f; out[4] = k0; out[5] = k1; out[6] = k2; out[7] = loss;
 }
 
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
@@ -382,6 +423,7 @@ struct eh_handle_s {
     int* perm = nullptr;
     long long perm_cap = 0;
     bool perm_valid = false;
+    int fast_user = 3;              // what the fast_paths option allows (default: all)
     struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
     std::vector<GraphRec> graphs;         // eh_graph_*: captured step sequences + the rotation state they start (and must end) in
     bool capturing = false;
@@ -747,7 +789,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->slab, (size_t)h->max_blocks * std::max(h->n_acc, EH_EVAL_STATS * n.T) * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
-    HIPCHK_C(hipMalloc(&h->inv_n, EH_MAX_TARG * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->inv_n, 8 * sizeof(float)));      // per-target 1/n (T > 1), or [1, -, -, -, k0, k1, k2, loss] of a moment-based loss
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
     if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; }
     {   // parameter image (constant parts; theta is mirrored into it by eh_image_kernel / the optimiser)
@@ -834,13 +876,15 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "fast_paths")) {       // 0 forces the generic MFMA kernels (A/B testing)
         const int want = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
-        h->fast = value ? (want & (int)value) : 0;
+        h->fast_user = value ? (int)value : 0;
+        h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         return build_maps(h, false);
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
+        if (value && h->net.loss >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "fused_update: pearson / kge training losses take two passes per step");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
         HIPCHK(h, hipSetDevice(h->device));
@@ -849,11 +893,17 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         return EH_OK;
     }
     if (!strcmp(name, "training_loss")) {
-        if (value < EH_LOSS_MSE || value > EH_LOSS_NSELOSS) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
+        if (value < EH_LOSS_MSE || value > EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
         if (value != EH_LOSS_MSE && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "training losses other than MSE need a single-target model");
+        if (value >= EH_LOSS_PEARSONLOSS && h->fused) return fail(h, EH_EUNSUPPORTED, "pearson / kge training losses take two passes per step: switch fused_update off first");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->net.loss = (int)value;
+        {   // the moment-based losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
+            const int want = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
+            const int fast = (value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
+            if (fast != h->fast) { h->fast = fast; return build_maps(h, false); }
+        }
         return EH_OK;
     }
     if (!strcmp(name, "row_split")) {        // A/B: the row-split kernel family (eh_wide.hpp) where both are built
@@ -865,7 +915,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         FLUSH(h);
         std::swap(h->arch, h->arch_alt);
         h->variant = (h->arch->nvar > 1 && !h->arch->wide) ? 1 : 0;
-        h->fast = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
+        h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : ((h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0) & h->fast_user);
         for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
         return build_maps(h, false);
     }
@@ -992,10 +1042,25 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
         HIPCHK(h, hipGetLastError());
     }
+    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS;
+    if (moment_loss) {
+        // first pass, forward only (train-mode BatchNorm statistics included): the batch moments of (yhat, y) -> the
+        // coefficients of the per-sample d loss / d yhat that the second pass multiplies into the VJP
+        EhStepArgs e{};
+        e.recs = sp.recs; e.C = h->C; e.idx = idx; e.first = first; e.count = count;
+        e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.cmap = h->cmap; e.stamps = nullptr;
+        e.yld = count;
+        for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
+        if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
+        const int egrid = count > 0 ? grid_for(h, count) : 1;
+        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, egrid, h->stream, &h->net, &e));
+        hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, net.loss, sp.shift[0], h->inv_n);
+        HIPCHK(h, hipGetLastError());
+    }
     EhStepArgs a{};
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
-    a.inv_n = net.T > 1 ? h->inv_n : nullptr;
+    a.inv_n = (net.T > 1 || moment_loss) ? h->inv_n : nullptr;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     a.rmap = h->rmap; a.cmap = h->cmap;
     a.stamps = h->stamps;
@@ -1065,13 +1130,14 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (rc) return rc;
     if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
+    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS;
     const bool big = h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
     const int rgrid = big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
 #define EH_REDUCE_GO(AP, CW_)                                                                                                                       \
     hipLaunchKernelGGL((eh_reduce_kernel<AP, CW_>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
-                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss)
+                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr)
     if (apply) {
         if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
@@ -1433,6 +1499,7 @@ int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
+    if (h->net.loss >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     h->bn_dp_update = h->bn_on;
     HIPCHK(h, hipSetDevice(h->device));

@@ -878,6 +878,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
                         if (maeOn != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                        else if (FAST == 0 && net.loss >= EH_LOSS_PEARSONLOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
+                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.shift[t], a.inv_n[4])) : 0.0f;
+                        }
                         else { lacc += w * r * r; d = 2.0f * w * r; }
                         dy += tOut[t] == 0 ? d : 0.0f; dyx[0] += tOut[t] == 1 ? d : 0.0f; dyx[1] += tOut[t] == 2 ? d : 0.0f;
                         cacc[t] += valid ? 1.0f : 0.0f;

@@ -362,6 +362,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
                         if (net.loss == EH_LOSS_MAE) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                        else if (net.loss >= EH_LOSS_PEARSONLOSS) {      // moment-based losses (see eh_step_kernel)
+                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.shift[t], a.inv_n[4])) : 0.0f;
+                        }
                         else { lacc += w * r * r; d = 2.0f * w * r; }
                         dy += ot == 0 ? d : 0.0f; dyx[0] += ot == 1 ? d : 0.0f; dyx[1] += ot == 2 ? d : 0.0f;
                         cacc[t] += valid ? 1.0f : 0.0f;

@@ -177,7 +177,8 @@ class HybridEngine:
         self._chk(self._lib.eh_set_bn_state(self._h, _fptr(m), _fptr(v), m.size))
 
     def set_training_loss(self, name: str):
-        """TrainConfig.training_loss (src/config/TrainingConfig.jl:64): mse | rmse | mae | nseLoss."""
+        """TrainConfig.training_loss (src/config/TrainingConfig.jl:64): mse | rmse | mae | nseLoss (one pass) |
+        pearsonLoss | kgeLoss | pbkgeLoss (two passes per step: batch moments first; not in fused_update mode, not data parallel)."""
         if name not in L.TRAINING_LOSSES:
             raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
         self.set_option("training_loss", L.TRAINING_LOSSES[name])

@@ -125,7 +125,7 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
     check_training_loss(cfg.training_loss)
     if cfg.training_loss not in L.TRAINING_LOSSES:
         raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements {sorted(L.TRAINING_LOSSES)} "
-                                  "(correlation-based losses need a second pass: SURVEY.md section 8f rank 3)")
+                                  "(custom loss functions cannot run inside the kernel)")
     if cfg.agg != "sum":
         raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
     for lt in cfg.loss_types:
@@ -272,6 +272,8 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         raise RuntimeError("train(distributed=True) needs an initialised torch.distributed process group (one rank per GPU)")
     if len(model.targets) != 1:
         raise NotImplementedError("distributed training: the data-parallel seam supports single-target models")
+    if tc.training_loss in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):
+        raise NotImplementedError("distributed training: pearson / kge losses need the moments of the global batch before the backward pass (not built)")
     (xtr, ftr, ytr), (xva, fva, yva) = train_split, val_split
     world, rank = dist.get_world_size(), dist.get_rank()
     device = torch.cuda.current_device()

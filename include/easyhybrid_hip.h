@@ -77,10 +77,14 @@ typedef enum eh_split { EH_SPLIT_TRAIN = 0, EH_SPLIT_VAL = 1 } eh_split;
 /* optimiser rules (Optimisers.jl; reference default Adam(0.01), src/config/TrainingConfig.jl:43) */
 typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2, EH_OPT_DESCENT = 3 } eh_opt_rule;
 
-/* training losses of src/losses/loss_fn.jl:58-86 that the fused kernel can minimise (per target on the valid samples):
- *   MSE mean(r^2) | RMSE sqrt(mean(r^2)) | MAE mean(|r|) | NSELOSS sum(r^2) / sum((y - mean(y))^2);  selected with
- *   eh_set_option(h, "training_loss", k) (TrainConfig.training_loss, src/config/TrainingConfig.jl:64; default MSE) */
-typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LOSS_NSELOSS = 3 } eh_loss;
+/* training losses of src/losses/loss_fn.jl:58-174 that the engine can minimise (per target on the valid samples):
+ *   MSE mean(r^2) | RMSE sqrt(mean(r^2)) | MAE mean(|r|) | NSELOSS sum(r^2) / sum((y - mean(y))^2)      -- one pass;
+ *   PEARSONLOSS 1 - cor | KGELOSS sqrt((r-1)^2 + (alpha-1)^2 + (beta-1)^2) | PBKGELOSS sqrt((r-1)^2 + (beta-1)^2)
+ *   -- two passes: d loss / d yhat_i is affine in (yhat_i, y_i) with coefficients made of the batch moments, so a
+ *   forward-only pass collects the moments first (no fused_update mode, no data-parallel seam for these).
+ * Selected with eh_set_option(h, "training_loss", k) (TrainConfig.training_loss, src/config/TrainingConfig.jl:64; default MSE) */
+typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LOSS_NSELOSS = 3,
+                       EH_LOSS_PEARSONLOSS = 4, EH_LOSS_KGELOSS = 5, EH_LOSS_PBKGELOSS = 6 } eh_loss;
 
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
 typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4, EH_BUF_BNSTAT = 5 } eh_buffer;

@@ -458,7 +458,7 @@ def compute_loss(spec, theta, X, forcings, targets: Dict[str, np.ndarray], dtype
 
 
 def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None):
-    """Training loss (`kind` in mse / rmse / mae / nseLoss, loss_fn.jl:58-86; agg=sum over targets)
+    """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
     (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
     skips all-masked batches, epoch.jl:17-19)."""
@@ -492,6 +492,26 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
                 D = np.sum((yv - np.mean(yv)) ** 2)
                 loss = loss + np.sum(r * r) / D
                 d = dt.type(2) * r / D
+            elif kind in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):          # loss_fn.jl:75-77,105-174 (Statistics.cor / std, n-1 cancels)
+                yh, yv = res[t][m].astype(dt), y[m]
+                mu_s, mu_o = np.mean(yh), np.mean(yv)
+                ds, do_ = yh - mu_s, yv - mu_o
+                Suu, Sww, Suw = np.sum(ds * ds), np.sum(do_ * do_), np.sum(ds * do_)
+                rr = Suw / np.sqrt(Suu * Sww)
+                drr = do_ / np.sqrt(Suu * Sww) - rr * ds / Suu
+                if kind == "pearsonLoss":
+                    lt, dl = 1 - rr, -drr
+                else:
+                    alpha, beta = np.sqrt(Suu / Sww), mu_s / mu_o
+                    dalpha, dbeta = ds / (alpha * Sww), np.full(n, 1 / (n * mu_o), dt)
+                    if kind == "kgeLoss":
+                        lt = np.sqrt((rr - 1) ** 2 + (alpha - 1) ** 2 + (beta - 1) ** 2)
+                        dl = ((rr - 1) * drr + (alpha - 1) * dalpha + (beta - 1) * dbeta) / lt
+                    else:
+                        lt = np.sqrt((rr - 1) ** 2 + (beta - 1) ** 2)
+                        dl = ((rr - 1) * drr + (beta - 1) * dbeta) / lt
+                loss = loss + lt
+                d[m] = dl
             else:
                 raise ValueError(f"training loss {kind}")
         dout[t] = d

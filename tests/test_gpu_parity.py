@@ -992,3 +992,50 @@ def test_hipgraph_replay_of_a_step_sequence_equals_plain_steps():
         with pytest.raises(ValueError, match="rotation state"):
             eng.graph_end()
         eng.close(); ref.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# moment-based training losses (loss_fn.jl:75-77,105-174): two passes per step.  Their gradient is built from
+# differences of batch moments ((r - 1), (alpha - 1), ...), which amplifies fp32 rounding: bound 1e-4, not 1e-5.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["pearsonLoss", "kgeLoss", "pbkgeLoss"])
+@pytest.mark.parametrize("shape", ["rbq10", "rbq10+bn", "wide"])
+def test_moment_based_training_losses(kind, shape):
+    if shape == "wide":
+        spec, theta, X, f, y = _rs6_case(20, (96, 128), 1500)
+    elif shape == "rbq10+bn":
+        spec, theta, X, f, y = _bn_case(1500)
+    else:
+        spec, theta, X, f, y = util.rbq10_case(1500, "tanh", True, 0.1)
+    bn = ho.bn_init(spec) if shape == "rbq10+bn" else None
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind, bn_state=bn)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=1e-4) and util.relerr(grad, g0) <= 1e-4
+    l1, g1, _ = eng.loss_and_grad(first=100, count=777)
+    sl = slice(100, 877)
+    l10, g10, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()},
+                                   kind=kind, bn_state=ho.bn_init(spec) if bn is not None else None)
+    assert l1 == pytest.approx(l10, rel=1e-4) and util.relerr(g1, g10) <= 1e-4
+    eng.opt_init("Adam", 0.003)
+    batches = [(i * 300, 300) for i in range(5)]
+    losses = [eng.train_step(*b) for b in batches]
+    st = ho.bn_init(spec) if bn is not None else None
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, lr=0.003, dtype=np.float32, kind=kind, bn_state=st)
+    assert np.allclose(losses, l_ref, rtol=5e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 2e-4 * max(1.0, float(np.max(np.abs(th_ref))))
+    if shape != "wide":
+        with pytest.raises(NotImplementedError, match="two passes"):
+            eng.set_option("fused_update", 1)
+    eng.close()
+
+
+def test_train_front_door_with_kge_loss_improves_kge():
+    cols = eh.synthetic.make_synth_rbq10(4000, seed=5, nan_frac=0.05)
+    cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=15, batchsize=256, opt=eh.Adam(0.01), training_loss="kgeLoss", loss_types=["kge", "mse"], random_seed=3)
+    assert out.val_history[-1]["kge"]["sum"] > out.val_history[0]["kge"]["sum"] + 0.2
+    assert out.val_history[-1]["kge"]["sum"] > 0.8
