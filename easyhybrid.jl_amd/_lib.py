@@ -69,6 +69,7 @@ SIGNATURES = {
     "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
     "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),
+    "eh_set_weight_l2": (C.c_int32, [_H, C.c_float, C.c_int32]),
     "eh_graph_begin": (C.c_int32, [_H]),
     "eh_graph_end": (C.c_int32, [_H, C.POINTER(C.c_int32)]),
     "eh_graph_launch": (C.c_int32, [_H, C.c_int32]),

@@ -25,7 +25,25 @@ struct EhImg {
     int g_off, phi_off;
     int glob_par[EH_MAX_PARAMS];   // global g -> canonical mech parameter j
     float glo[EH_MAX_PARAMS], ghi[EH_MAX_PARAMS];
+    // extra loss lambda * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91): l2c = lambda or lambda / #weights;
+    // the Dense weight matrices are the canonical entries whose image offset lies below the bias block
+    float l2c;
+    int b_off;
 };
+__device__ __forceinline__ bool eh_is_weight(const EhImg& im, int idx) { return idx < im.g_off && im.imap[idx] < im.b_off; }
+
+// l2c * sum of squared Dense weights of the CURRENT parameters (before the optimiser kernel touches them)
+__global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, EhImg im, float* out) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < im.g_off; i += 256)
+        if (im.imap[i] < im.b_off) { const float w = theta[i]; s += w * w; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = im.l2c * ((red[0] + red[1]) + (red[2] + red[3]));
+}
 
 __device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float th) {
     if (idx < im.g_off) {
@@ -51,7 +69,7 @@ __global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
 template <bool APPLY, int CW>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
-                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom) {
+                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom, const float* l2val) {
     constexpr int NQ = 256 / CW;
     __shared__ float part[NQ][CW + 1];
     __shared__ float wsum[4][EH_MAX_TARG + 3];
@@ -60,6 +78,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     // optimiser inputs are independent of the slab: request them first so they arrive together
     float th = 0.0f, mm = 0.0f, vv = 0.0f, bt1 = 0.0f, bt2 = 0.0f;
     if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; }
+    if (!APPLY && l2val && q == 0 && idx < n_theta) th = theta[idx];
     float s = 0.0f;
     if (idx < n_acc) {
 #pragma unroll 16
@@ -95,7 +114,8 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
         for (int k = 0; k < NQ; ++k) tot += part[k][p];
         const float scale = deferred ? dscale : 1.0f;
         if (idx < n_theta) {
-            const float g = tot * scale;
+            float g = tot * scale;
+            if (l2val && ntot > 0.0f && eh_is_weight(im, idx)) g = fmaf(2.0f * im.l2c, th, g);      // + d/dw (l2c * sum w^2)
             gradbuf[idx] = g;
             if (APPLY && ntot > 0.0f) {
                 eh_opt_update(o, g, bt1, bt2, th, mm, vv);
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
                 eh_image_store(im, idx, th);
             }
         } else if (idx == n_theta) {
-            const float loss = ntot > 0.0f ? (deferred ? dloss : tot) : __builtin_nanf("");
+            const float loss = ntot > 0.0f ? (deferred ? dloss : tot) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
             gradbuf[idx] = loss;
             if (loss_slot) *loss_slot = loss;
         } else {
@@ -424,6 +444,8 @@ struct eh_handle_s {
     long long perm_cap = 0;
     bool perm_valid = false;
     int fast_user = 3;              // what the fast_paths option allows (default: all)
+    float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
+    int n_weights = 0;
     struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
     std::vector<GraphRec> graphs;         // eh_graph_*: captured step sequences + the rotation state they start (and must end) in
     bool capturing = false;
@@ -809,6 +831,14 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
         EhImg& im = h->img;
         im.image = h->image; im.imap = h->imap; im.g_off = n.g_off; im.phi_off = arch->phi_off;
+        im.l2c = 0.0f; im.b_off = arch->b_off;
+        HIPCHK_C(hipMalloc(&h->l2val, sizeof(float)));
+        HIPCHK_C(hipMemset(h->l2val, 0, sizeof(float)));
+        {
+            int nw = 0;
+            for (const EhEntry& e : enumerate_entries(h)) nw += e.col >= 0 ? 1 : 0;
+            h->n_weights = nw;
+        }
         for (int j = 0; j < d->n_params; ++j)
             if (d->param_kind[j] == EH_PAR_GLOBAL) {
                 const int g = d->param_index[j];
@@ -834,7 +864,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
-    (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -885,6 +915,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
         if (value && h->net.loss >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "fused_update: pearson / kge training losses take two passes per step");
+        if (value && h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
         HIPCHK(h, hipSetDevice(h->device));
@@ -1131,13 +1162,18 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
     const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS;
+    const bool l2 = h->img.l2c != 0.0f;
+    if (l2) {
+        hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
+        HIPCHK(h, hipGetLastError());
+    }
     const bool big = h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
     const int rgrid = big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
 #define EH_REDUCE_GO(AP, CW_)                                                                                                                       \
     hipLaunchKernelGGL((eh_reduce_kernel<AP, CW_>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
-                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr)
+                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr)
     if (apply) {
         if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
@@ -1485,6 +1521,16 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
     return EH_OK;
 }
 
+int32_t eh_set_weight_l2(eh_handle* h, float lambda, int32_t normalize) {
+    if (!h) return EH_EINVAL;
+    if (!(lambda >= 0.0f)) return fail(h, EH_EINVAL, "eh_set_weight_l2: lambda = %g", (double)lambda);
+    if (lambda != 0.0f && h->fused) return fail(h, EH_EUNSUPPORTED, "eh_set_weight_l2: not built for the fused_update mode: switch it off first");
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    h->img.l2c = (normalize && h->n_weights > 0) ? lambda / (float)h->n_weights : lambda;
+    return EH_OK;
+}
+
 int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
     if (!h) return EH_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1500,6 +1546,7 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
     if (h->net.loss >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
+    if (h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: the weight_l2 extra loss is not built for the data-parallel seam");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     h->bn_dp_update = h->bn_on;
     HIPCHK(h, hipSetDevice(h->device));

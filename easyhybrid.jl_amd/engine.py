@@ -183,6 +183,10 @@ class HybridEngine:
             raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
         self.set_option("training_loss", L.TRAINING_LOSSES[name])
 
+    def set_weight_l2(self, lam: float, normalize: bool = False):
+        """extra_loss = lam * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91); lam = 0 switches it off"""
+        self._chk(self._lib.eh_set_weight_l2(self._h, float(lam), int(bool(normalize))))
+
     def get_opt_state(self):
         m = np.empty(self.n_theta, np.float32)
         v = np.empty(self.n_theta, np.float32)

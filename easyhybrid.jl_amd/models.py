@@ -238,6 +238,16 @@ class SingleNNHybridModel:
                 parts.append(rng.random(1).astype(np.float32))
         return np.concatenate(parts).astype(np.float32)
 
+    def weight_mask(self) -> np.ndarray:
+        """True at the flat-theta positions of the Dense weight matrices (the leaves weight_l2 sums, src/utils/extract_weights.jl:69-91)"""
+        m = np.zeros(self.n_theta, bool)
+        off = 0
+        for net in self.nets:
+            for o, i in net:
+                m[off:off + o * i] = True
+                off += o * i + o
+        return m
+
     def unpack(self, theta: np.ndarray):
         """flat theta -> (ps = [(weight (out,in), bias)...], {global: raw})"""
         off, nets = 0, []

@@ -85,6 +85,14 @@ def check_training_loss(loss_type):                              # loss_fn.jl:19
 
 
 @dataclass
+class WeightL2:
+    """extra_loss = (yhat, ps) -> (; weight_l2 = lam * weight_l2(ps; normalize)) (src/utils/extract_weights.jl:69-91): the one
+    extra_loss the device knows -- any other closure cannot run inside the kernel."""
+    lam: float
+    normalize: bool = False
+
+
+@dataclass
 class TrainConfig:
     nepochs: int = 200
     batchsize: int = 64
@@ -93,6 +101,7 @@ class TrainConfig:
     training_loss: str = "mse"
     loss_types: List[str] = field(default_factory=lambda: ["mse", "r2"])
     agg: str = "sum"
+    extra_loss: Any = None               # TrainingConfig.jl:74; None or WeightL2(lam, normalize)
     train_from: Any = None
     random_seed: Optional[int] = 161803
     return_model: str = "best"
@@ -128,6 +137,8 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
                                   "(custom loss functions cannot run inside the kernel)")
     if cfg.agg != "sum":
         raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
+    if cfg.extra_loss is not None and not isinstance(cfg.extra_loss, WeightL2):
+        raise NotImplementedError("extra_loss: an arbitrary closure cannot run on the device; WeightL2(lam, normalize) is built")
     for lt in cfg.loss_types:
         if lt not in _DEVICE_METRICS:
             raise NotImplementedError(f"loss type {lt!r} is not computed by the eval kernel (have {sorted(_DEVICE_METRICS)})")
@@ -248,6 +259,14 @@ def _losses(engine, split, targets, loss_types):
     return out
 
 
+def _weight_l2_value(model, theta, spec: WeightL2) -> float:
+    """lam * weight_l2(ps; normalize) of flat parameters `theta` (host side, for the history)"""
+    m = model.weight_mask()
+    w = np.asarray(theta, np.float64)[m]
+    s = float(np.sum(w * w))
+    return float(spec.lam) * (s / max(1, int(m.sum())) if spec.normalize else s)
+
+
 def _want_distributed(tc: TrainConfig) -> bool:
     if tc.distributed is not None:
         return bool(tc.distributed)
@@ -272,6 +291,8 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         raise RuntimeError("train(distributed=True) needs an initialised torch.distributed process group (one rank per GPU)")
     if len(model.targets) != 1:
         raise NotImplementedError("distributed training: the data-parallel seam supports single-target models")
+    if tc.extra_loss is not None:
+        raise NotImplementedError("distributed training: the weight_l2 extra loss is not built for the data-parallel seam")
     if tc.training_loss in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):
         raise NotImplementedError("distributed training: pearson / kge losses need the moments of the global batch before the backward pass (not built)")
     (xtr, ftr, ytr), (xva, fva, yva) = train_split, val_split
@@ -382,11 +403,18 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         eng.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
+        if tc.extra_loss is not None:
+            eng.set_weight_l2(tc.extra_loss.lam, tc.extra_loss.normalize)
         first_lt = tc.loss_types[0]
 
         def snapshot():
-            return EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
+            snap = EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
                                  _losses(eng, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
+            if tc.extra_loss is not None:                # compute_loss.jl:39-44: eval mode reports the extra losses next to the metrics
+                v = _weight_l2_value(model, eng.get_params(), tc.extra_loss)
+                for d in (snap.l_train, snap.l_val):
+                    d["extra_loss"] = {"weight_l2": v, "sum": v}
+            return snap
         init = snapshot()
         history = [init]
         best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0

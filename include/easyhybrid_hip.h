@@ -183,6 +183,13 @@ int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_ou
  * stream).  mean_loss: mean of the per-step losses (nullable); n_steps: steps run (nullable). */
 int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t shuffle, float* mean_loss, int64_t* n_steps);
 
+/* extra_loss = (yhat, ps) -> (; l2 = lambda * weight_l2(ps; normalize)) (src/utils/extract_weights.jl:69-91,
+ * src/losses/compute_loss.jl:31-34 with agg = sum): lambda times the sum -- or, normalize != 0, the mean -- of the squared
+ * Dense WEIGHTS (biases and global parameters excluded) is added to the training loss and its gradient 2 lambda w to the
+ * weight gradients.  lambda = 0 switches it off.  Two-kernel path only (no fused_update, no data-parallel seam).
+ * Other extra_loss closures cannot run on the device. */
+int32_t eh_set_weight_l2(eh_handle* h, float lambda, int32_t normalize);
+
 /* hipGraph capture of a sequence of steps: between eh_graph_begin and eh_graph_end the calls
  * eh_train_step(..., loss_out = NULL) / eh_dp_fused_step are recorded, not run; eh_graph_launch replays the
  * recorded sequence (same windows, same buffers).  The calls advance the engine's rotation state

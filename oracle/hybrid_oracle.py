@@ -457,7 +457,29 @@ def compute_loss(spec, theta, X, forcings, targets: Dict[str, np.ndarray], dtype
     return tot
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None):
+def weight_mask(spec: HybridSpec):
+    """True at the flat-theta positions of the Dense WEIGHT matrices (what weight_l2 walks: leaves named :weight,
+    src/utils/extract_weights.jl:69-91); biases and raw global parameters are False."""
+    m = np.zeros(spec.n_theta, bool)
+    off = 0
+    for _, dims in spec.net_list:
+        for o, i in dims:
+            m[off:off + o * i] = True
+            off += o * i + o
+    return m
+
+
+def weight_l2(spec: HybridSpec, theta, lam, normalize=False):
+    """lam * weight_l2(ps; normalize): sum (or mean) of the squared Dense weights; returns (value, gradient)."""
+    m = weight_mask(spec)
+    th = np.asarray(theta)
+    c = th.dtype.type(lam) / (th.dtype.type(m.sum()) if normalize else th.dtype.type(1))
+    g = np.zeros_like(th)
+    g[m] = 2 * c * th[m]
+    return c * np.sum(th[m] * th[m]), g
+
+
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None):
     """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
     (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
@@ -547,6 +569,9 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         gWs.reverse()
         gnets.append(gWs)
     grad = pack(spec, gnets, graw, dt)
+    if l2 is not None and sum(nvalid) > 0:            # extra_loss through agg = sum (compute_loss.jl:31-34)
+        lv, lg = weight_l2(spec, np.asarray(theta, dt), *l2)
+        loss, grad = loss + lv, grad + lg
     return loss, grad, nvalid
 
 
@@ -577,7 +602,7 @@ def adam_step(theta, grad, st, lr=0.01, b1=0.9, b2=0.999, eps=1e-8, weight_decay
 
 
 def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32, kind="mse",
-                bn_state=None):
+                bn_state=None, l2=None):
     """Run Adam over contiguous batches [(first, count), ...]; all-masked batches are skipped
     (epoch.jl:17-19).  Returns (theta, [loss per batch]); with input_batchnorm `bn_state` (a dict
     from bn_init) is updated in place with the running statistics of every batch that ran."""
@@ -590,7 +615,7 @@ def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int,
         if not any((~np.isnan(v)).any() for v in yb.values()):
             losses.append(float("nan"))          # isemptybatch: the step (and its state update) never runs
             continue
-        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()}, yb, dtype, kind, bn_state)
+        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()}, yb, dtype, kind, bn_state, l2)
         if spec.input_batchnorm and bn_state is not None:
             _, new = batchnorm_input(np.asarray(X[:, sl], np.float64), bn_state, True, np.dtype(np.float64))
             bn_state.update(new)

@@ -1039,3 +1039,61 @@ def test_train_front_door_with_kge_loss_improves_kge():
     out = eh.train(model, cols, nepochs=15, batchsize=256, opt=eh.Adam(0.01), training_loss="kgeLoss", loss_types=["kge", "mse"], random_seed=3)
     assert out.val_history[-1]["kge"]["sum"] > out.val_history[0]["kge"]["sum"] + 0.2
     assert out.val_history[-1]["kge"]["sum"] > 0.8
+
+
+# ----------------------------------------------------------------------------------------------
+# extra_loss = lam * weight_l2(ps; normalize)  (extract_weights.jl:69-91, compute_loss.jl:31-34)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("shape", ["rbq10", "multinn", "wide"])
+def test_weight_l2_extra_loss(normalize, shape):
+    if shape == "wide":
+        spec, theta, X, f, y = _rs6_case(20, (96, 128), 900)
+    elif shape == "multinn":
+        spec = ho.HybridSpec(4, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=[([0, 1], [8, 8]), ([2, 3], [16, 8])])
+        rng = np.random.default_rng(5)
+        X = rng.standard_normal((4, 900)).astype(np.float32)
+        f = {"ta": rng.uniform(0, 30, 900).astype(np.float32)}
+        y = {"reco": rng.uniform(1, 9, 900).astype(np.float32)}
+        theta = ho.init_theta(spec, 6, np.float32)
+    else:
+        spec, theta, X, f, y = util.rbq10_case(900, "tanh", True, 0.1)
+    lam = 0.37 * (int(ho.weight_mask(spec).sum()) / 10 if normalize else 1.0)       # comparable strength either way
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_weight_l2(lam, normalize)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, l2=(lam, normalize))
+    lp, gp, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert util.relerr(g0, gp) > 2e-4                         # the term is not negligible in this test
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.opt_init("Adam", 0.003)
+    batches = [(i * 300, 300) for i in range(3)] * 2
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, lr=0.003, dtype=np.float32, l2=(lam, normalize))
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    eng.set_weight_l2(0.0)
+    l1, g1, _ = eng.loss_and_grad()
+    l10, g10, _ = ho.loss_and_grad(spec, eng.get_params().astype(np.float64), X, f, y)
+    assert l1 == pytest.approx(l10, rel=TOL) and util.relerr(g1, g10) <= TOL
+    if shape == "rbq10":
+        eng.set_weight_l2(lam)
+        with pytest.raises(NotImplementedError, match="weight_l2"):
+            eng.set_option("fused_update", 1)
+    eng.close()
+
+
+def test_train_front_door_with_weight_l2_shrinks_the_weights():
+    cols = eh.synthetic.make_synth_rbq10(3000, seed=5, nan_frac=0.05)
+    cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    kw = dict(nepochs=10, batchsize=256, opt=eh.Adam(0.01), random_seed=3)
+    plain = eh.train(model, cols, **kw)
+    reg = eh.train(model, cols, extra_loss=eh.WeightL2(0.05, normalize=False), **kw)
+    m = model.weight_mask()
+    assert np.sum(reg.ps[m] ** 2) < 0.7 * np.sum(plain.ps[m] ** 2)
+    last = reg.val_history[-1]["extra_loss"]
+    assert last["weight_l2"] == pytest.approx(0.05 * float(np.sum(reg.ps[m].astype(np.float64) ** 2)), rel=0.3) and last["sum"] == last["weight_l2"]
+    with pytest.raises(NotImplementedError, match="extra_loss"):
+        eh.train(model, cols, extra_loss=lambda yhat, ps: 0.0, **kw)
