@@ -40,7 +40,7 @@ eng = util.load_engine(spec, theta, X[:, sel], {k: v[sel] for k, v in f.items()}
 eng.opt_init("Adam", 0.01)
 # Both ranks' kernels must fit on the one GPU at the same time: a step kernel fills a CU per workgroup, and a rank
 # whose 256 workgroups all sit waiting for the peer's sums would keep the peer's kernel from ever being scheduled.
-eng.set_option("max_blocks", 64)
+eng.set_option("max_blocks", max(1, 128 // world))
 drv = eh.dp.DataParallel(eng, fused=True)
 dist.barrier()
 t0 = time.perf_counter()
@@ -63,16 +63,22 @@ ok = err <= 3e-5 and same
 B = 65536
 spec2, theta2, X2, f2, y2 = util.rbq10_case(8 * B, "tanh", True, 0.0)
 e2 = util.load_engine(spec2, theta2, X2, f2, y2); e2.opt_init("Adam", 0.01)
-e2.set_option("max_blocks", 64)
+e2.set_option("max_blocks", max(1, 128 // world))
 d2 = eh.dp.DataParallel(e2, fused=True)
 cal = d2.calibrate(0, B, 100)
 if rank == 0: print("calibration:", cal, flush=True)
 for i in range(50): d2.step((i % 8) * B, B)
 e2.synchronize(); dist.barrier()
 t0 = time.perf_counter()
-for i in range(500): d2.step((i % 8) * B, B)
+NS = int(os.environ.get("EH_SOAK_STEPS", "500"))
+for i in range(NS): d2.step((i % 8) * B, B)
 e2.synchronize(); torch.cuda.synchronize()
-print(f"rank {rank}: B=65536 per rank, p2p={d2.p2p}: {1e6 * (time.perf_counter() - t0) / 500:.1f} us/step (two ranks share one GPU, 64 workgroups each)", flush=True)
+print(f"rank {rank}: B=65536 per rank, p2p={d2.p2p}: {1e6 * (time.perf_counter() - t0) / NS:.1f} us/step ({world} ranks share one GPU, {max(1, 128 // world)} workgroups each)", flush=True)
+t = torch.from_numpy(e2.get_params().copy()); tl = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(tl, t)
+same2 = all(bool(torch.equal(tl[0], q)) for q in tl)
+print(f"rank {rank}: after {NS} steps replicas_identical={same2} finite={bool(np.isfinite(t.numpy()).all())}", flush=True)
+ok = ok and same2
 eng.close(); ref.close(); e2.close()
 dist.barrier()
 dist.destroy_process_group()
