@@ -440,7 +440,7 @@ __host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl
 //   FAST bit 1 (PS): P <= 4 predictors -> the first layer's weight gradient runs on the vector ALU
 // ------------------------------------------------------------------------------------------
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
-__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
+__device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs& a) {
     using G = EhGeom<NBI, NBH, NL, NT, NW>;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, NTHR = 64 * NW;
     constexpr bool TRAIN = MODE != EH_MODE_EVAL;
@@ -1284,4 +1284,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         if constexpr (P2PM) eh_p2p_publish(a.p2p, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
     }
     EH_STAMP(10);
+}
+
+// one training step (or one forward / eval pass) per launch
+template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
+    eh_step_body<NBI, NBH, NL, NT, NW, ACT, MODE, FAST>(net, a);
 }
