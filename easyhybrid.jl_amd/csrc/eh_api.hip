@@ -207,10 +207,23 @@ __global__ __launch_bounds__(256) void eh_p2p_test_kernel(const EhP2P* P, int sl
 
 // Moment-based training losses (pearsonLoss, kgeLoss, pbkgeLoss; src/losses/loss_fn.jl:75-77,105-174): from the batch
 // moments the forward-only pass left in the slab ([blocks][EH_EVAL_STATS], shifted by c) to the loss value and the
-// coefficients of  d loss / d yhat_i = k0 + k1 (yhat_i - c) + k2 (y_i - c).  out = [1, -, -, -, k0, k1, k2, loss].
-// With u = yhat - c, w = y - c:  r = Suw_c / sqrt(Suu_c Sww_c),  alpha = sqrt(Suu_c / Sww_c) (the n-1 of std cancels),
+// coefficients of  d loss / d yhat_i = k0 + k1 (yhat_i - cu) + k2 (y_i - c).  out = [1, cu, -, -, k0, k1, k2, loss].
+// With u = yhat - cu (cu = batch mean of yhat, from a first forward pass), w = y - c:  r = Suw_c / sqrt(Suu_c Sww_c),  alpha = sqrt(Suu_c / Sww_c) (the n-1 of std cancels),
 // beta = mean(yhat) / mean(y);  dr/du_i = (w_i - mw) / sqrt(Suu_c Sww_c) - r (u_i - mu) / Suu_c,
 // dalpha/du_i = (u_i - mu) / (alpha Sww_c),  dbeta/du_i = 1 / (n mean(y)).
+// stage 0: the centre of yhat for the moment pass proper = its batch mean (sum (yhat - c) is accurate; the squares are not)
+__global__ __launch_bounds__(64) void eh_moment_centre_kernel(const float* slab, int nblk, float shift, float* out) {
+    __shared__ double tot[EH_EVAL_STATS];
+    const int tid = threadIdx.x;
+    if (tid < EH_EVAL_STATS) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += (double)slab[b * EH_EVAL_STATS + tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) out[1] = tot[3] > 0.0 ? (float)((double)shift + tot[4] / tot[3]) : shift;
+}
+// stage 1: moments with u = yhat - out[1], w = y - shift
 __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int kind, float shift, float* out) {
     __shared__ double tot[EH_EVAL_STATS];
     const int tid = threadIdx.x;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, i
     }
     __syncthreads();
     if (tid != 0) return;
-    const double n = tot[3], Sw = tot[1], Sww = tot[2], Su = tot[4], Suu = tot[5], Suw = tot[6];
+    const double n = tot[3], Sw = tot[1], Sww = tot[2], Su = tot[4], Suu = tot[5], Suw = tot[6], cu = (double)out[1];
     float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, loss = __builtin_nanf("");
     if (n > 0.0) {
         const double mu = Su / n, mw = Sw / n;
@@ -232,14 +245,14 @@ __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, i
         double g_r, g_a = 0.0, g_b = 0.0, L;
         if (kind == EH_LOSS_PEARSONLOSS) { L = 1.0 - r; g_r = -1.0; }
         else {
-            const double alpha = sqrt(Suu_c / Sww_c), beta = ((double)shift + mu) / ((double)shift + mw);
+            const double alpha = sqrt(Suu_c / Sww_c), beta = (cu + mu) / ((double)shift + mw);
             if (kind == EH_LOSS_KGELOSS) { L = sqrt((r - 1) * (r - 1) + (alpha - 1) * (alpha - 1) + (beta - 1) * (beta - 1)); g_a = (alpha - 1) / L / (alpha * Sww_c); }
             else L = sqrt((r - 1) * (r - 1) + (beta - 1) * (beta - 1));
             g_r = (r - 1) / L;
             g_b = (beta - 1) / L / (n * ((double)shift + mw));
         }
-        const double cu = g_r * a_u + g_a, cw = g_r * a_w;        // coefficients of (u_i - mu), (w_i - mw)
-        k1 = (float)cu; k2 = (float)cw; k0 = (float)(g_b - cu * mu - cw * mw);
+        const double qu = g_r * a_u + g_a, qw = g_r * a_w;        // coefficients of (u_i - mu), (w_i - mw)
+        k1 = (float)qu; k2 = (float)qw; k0 = (float)(g_b - qu * mu - qw * mw);
         loss = (float)L;
     }
     out[0] = 1.0f; out[4] = k0; out[5] = k1; out[6] = k2; out[7] = loss;
@@ -607,6 +620,14 @@ static int build_maps(eh_handle* h, bool with_imap) {
     return EH_OK;
 }
 
+// Which vector-ALU fast paths a model may use: bit 0 = single NN output (K == 1), bit 1 = P <= 4 predictors.  Single-target
+// models only, and the P <= 4 path only on the one-block shapes: with ReLU it produced wrong weight gradients on the wider
+// shapes (found by tests/test_gpu_fuzz.py; root cause not understood, so the path is confined to where it is verified).
+static int fast_wanted(const EhArchInfo* A, int K, int P, int T) {
+    if (!A->has_fast || T != 1 || K != 1) return 0;
+    return 1 | ((P <= 4 && A->nbh == 1) ? 2 : 0);
+}
+
 struct MechInfo { int n_par, n_forc, n_out; };
 static bool mech_info(int mech, MechInfo* mi) {
     switch (mech) {
@@ -761,7 +782,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     for (int f = 0; f < mi.n_forc; ++f) n.forc_col = (n.forc_col & ~(0xFFu << (8 * f))) | ((unsigned)d->forcing_index[f] << (8 * f));
     n.n_out = mi.n_out;
     for (int t = 0; t < d->n_targets; ++t) n.targ_out |= (unsigned)d->target_output[t] << (2 * t);
-    h->fast = (arch->has_fast ? ((K == 1 ? 1 : 0) | ((K == 1 && n.P <= 4) ? 2 : 0)) : 0);
+    h->fast = fast_wanted(arch, K, n.P, n.T);
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T + 2;      // [grad | S | n_valid per target | Sy | Syy]
@@ -905,7 +926,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         return EH_OK;
     }
     if (!strcmp(name, "fast_paths")) {       // 0 forces the generic MFMA kernels (A/B testing)
-        const int want = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
+        const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T);
         h->fast_user = value ? (int)value : 0;
         h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
         HIPCHK(h, hipSetDevice(h->device));
@@ -931,7 +952,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         FLUSH(h);
         h->net.loss = (int)value;
         {   // the moment-based losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
-            const int want = (h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0);
+            const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T);
             const int fast = (value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
             if (fast != h->fast) { h->fast = fast; return build_maps(h, false); }
         }
@@ -946,7 +967,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         FLUSH(h);
         std::swap(h->arch, h->arch_alt);
         h->variant = (h->arch->nvar > 1 && !h->arch->wide) ? 1 : 0;
-        h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : ((h->arch->has_fast ? ((h->net.K == 1 ? 1 : 0) | ((h->net.K == 1 && h->net.P <= 4) ? 2 : 0)) : 0) & h->fast_user);
+        h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : (fast_wanted(h->arch, h->net.K, h->net.P, h->net.T) & h->fast_user);
         for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
         return build_maps(h, false);
     }
@@ -1075,8 +1096,9 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     }
     const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS;
     if (moment_loss) {
-        // first pass, forward only (train-mode BatchNorm statistics included): the batch moments of (yhat, y) -> the
-        // coefficients of the per-sample d loss / d yhat that the second pass multiplies into the VJP
+        // forward-only passes (train-mode BatchNorm statistics included): the batch mean of yhat, then the moments of
+        // (yhat, y) about the means -> the coefficients of the per-sample d loss / d yhat that the training pass multiplies
+        // into the VJP
         EhStepArgs e{};
         e.recs = sp.recs; e.C = h->C; e.idx = idx; e.first = first; e.count = count;
         e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.cmap = h->cmap; e.stamps = nullptr;
@@ -1084,6 +1106,10 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
         if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
         const int egrid = count > 0 ? grid_for(h, count) : 1;
+        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, egrid, h->stream, &h->net, &e));       // -> mean of yhat
+        hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, sp.shift[0], h->inv_n);
+        HIPCHK(h, hipGetLastError());
+        e.inv_n = h->inv_n;                                                                                               // -> moments about it
         HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, egrid, h->stream, &h->net, &e));
         hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, net.loss, sp.shift[0], h->inv_n);
         HIPCHK(h, hipGetLastError());

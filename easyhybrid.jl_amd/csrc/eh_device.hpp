@@ -879,14 +879,16 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
                         float d;
                         if (maeOn != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
                         else if (FAST == 0 && net.loss >= EH_LOSS_PEARSONLOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
-                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.shift[t], a.inv_n[4])) : 0.0f;
+                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
                         }
                         else { lacc += w * r * r; d = 2.0f * w * r; }
                         dy += tOut[t] == 0 ? d : 0.0f; dyx[0] += tOut[t] == 1 ? d : 0.0f; dyx[1] += tOut[t] == 2 ? d : 0.0f;
                         cacc[t] += valid ? 1.0f : 0.0f;
                         syacc += cy; syyacc += cy * cy;
                     } else if (valid) {
-                        const float cy = yobs[t] - a.shift[t], ch = y - a.shift[t];
+                        // (moment pass of the pearson / kge losses: yhat is centred on ITS OWN mean, found by a first pass --
+                        // a common centre would cancel catastrophically when the predictions sit far from the targets)
+                        const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[1] : a.shift[t]);
                         est[t][0] += r * r; est[t][1] += cy; est[t][2] += cy * cy; est[t][3] += 1.0f;
                         est[t][4] += ch; est[t][5] += ch * ch; est[t][6] += ch * cy; est[t][7] += fabsf(r);
                     }

@@ -363,14 +363,14 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                         float d;
                         if (net.loss == EH_LOSS_MAE) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
                         else if (net.loss >= EH_LOSS_PEARSONLOSS) {      // moment-based losses (see eh_step_kernel)
-                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.shift[t], a.inv_n[4])) : 0.0f;
+                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
                         }
                         else { lacc += w * r * r; d = 2.0f * w * r; }
                         dy += ot == 0 ? d : 0.0f; dyx[0] += ot == 1 ? d : 0.0f; dyx[1] += ot == 2 ? d : 0.0f;
                         cacc[t] += valid ? 1.0f : 0.0f;
                         syacc += cy; syyacc += cy * cy;
                     } else if (valid) {
-                        const float cy = yobs[t] - a.shift[t], ch = y - a.shift[t];
+                        const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[1] : a.shift[t]);      // see eh_step_kernel
                         est[t][0] += r * r; est[t][1] += cy; est[t][2] += cy * cy; est[t][3] += 1.0f;
                         est[t][4] += ch; est[t][5] += ch * ch; est[t][6] += ch * cy; est[t][7] += fabsf(r);
                     }

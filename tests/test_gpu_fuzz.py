@@ -1,0 +1,95 @@
+"""-m gpu: seeded random configurations of the whole descriptor space (shape, activation, mechanistic model, which
+parameters are neural / global / fixed, scaling, BatchNorm, NaN pattern, batch size, window, training loss, kernel family
+and variant) through the C ABI against the oracle.  One loss + gradient comparison per case."""
+import numpy as np
+import pytest
+
+from oracle import hybrid_oracle as ho
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TABLES = {
+    "rbq10": dict(ho.RBQ10_PARAMS),
+    "expo": dict(ho.EXPO_PARAMS),
+    "linear": {"alpha": (1.0, -2.0, 3.0), "beta": (0.5, -1.0, 2.0)},
+    "expo2pool": dict(ho.EXPO2POOL_PARAMS),
+    "rs_components": {**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in ("het", "root", "myc")},
+                      **{f"Q10_{c}": (2.0 + 0.3 * i, 1.0, 4.0) for i, c in enumerate(("het", "root", "myc"))}},
+    "fluxpart": {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)},
+}
+FORCING_RANGE = {"ta": (-5, 30), "T": (-0.5, 1.5), "x": (-1, 2), "SW_IN": (0, 800), "TA": (0, 30)}
+
+
+def _case(seed, fastpath=False):
+    """fastpath: only models the K == 1 / P <= 4 vector-ALU kernels serve (one neural parameter, few predictors, one target)"""
+    rng = np.random.default_rng((500000 if fastpath else 1000) + seed)
+    mech = rng.choice(list(TABLES))
+    mm = ho.MECH[mech][0]
+    names = list(mm.params)
+    # every parameter neural / global / fixed at random, at least one neural
+    kinds = rng.integers(0, 3, len(names))
+    if fastpath:
+        kinds = rng.integers(1, 3, len(names))
+        kinds[rng.integers(len(names))] = 0
+    if not (kinds == 0).any():
+        kinds[rng.integers(len(names))] = 0
+    neural = [n for n, k in zip(names, kinds) if k == 0]
+    glob = [n for n, k in zip(names, kinds) if k == 1]
+    rng.shuffle(neural); rng.shuffle(glob)
+    wide = rng.random() < 0.3 and not fastpath
+    nl = int(rng.integers(1, 3 if wide else 4))
+    hidden = [int(rng.integers(65, 129)) if (wide and i == 0) else int(rng.integers(1, 129 if wide else 65)) for i in range(nl)]
+    P = int(rng.integers(1, 7)) if fastpath else int(rng.integers(1, 33))
+    act = str(rng.choice(["tanh", "sigmoid", "relu", "swish", "identity"]))
+    scale = bool(rng.random() < 0.6) or mech in ("rbq10", "rs_components", "fluxpart")     # raw outputs could be negative bases of a power
+    ntarg = 1 if fastpath else int(rng.integers(1, len(mm.outputs) + 1))
+    targets = [str(t) for t in rng.permutation(list(mm.outputs))[:ntarg]]
+    bn = bool(rng.random() < 0.25)
+    spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, scale, input_batchnorm=bn)
+    B = int(rng.choice([1, 7, 31, 32, 33, 64, 257, 1000, 2049]))
+    N = B + int(rng.integers(0, 200))
+    X = (rng.standard_normal((P, N)) * rng.uniform(0.2, 1.5) + (rng.uniform(-3, 3) if bn else 0.0)).astype(np.float32)
+    f = {k: rng.uniform(*FORCING_RANGE[k], N).astype(np.float32) for k in mm.forcings}
+    y = {}
+    for t in targets:
+        v = rng.uniform(0.5, 6, N).astype(np.float32)
+        v[rng.random(N) < rng.choice([0.0, 0.1, 0.6])] = np.nan
+        y[t] = v
+    kind = "mse" if ntarg > 1 else str(rng.choice(["mse", "mse", "rmse", "mae", "nseLoss", "kgeLoss", "pearsonLoss"]))
+    first = int(rng.integers(0, N - B + 1))
+    return spec, ho.init_theta(spec, seed, np.float32), X, f, y, kind, first, B, rng
+
+
+@pytest.mark.parametrize("fastpath", [False, True])
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EH_FUZZ_N", "60"))))
+def test_random_configuration_matches_the_oracle(seed, fastpath):
+    spec, theta, X, f, y, kind, first, B, rng = _case(seed, fastpath)
+    sl = slice(first, first + B)
+    yb = {k: v[sl] for k, v in y.items()}
+    if kind in ("kgeLoss", "pearsonLoss", "nseLoss") and sum(int((~np.isnan(v)).sum()) for v in yb.values()) < 3:
+        kind = "mse"                                              # variance / correlation of fewer than 3 points
+    eng = util.load_engine(spec, theta, X, f, y)
+    if kind != "mse":
+        eng.set_training_loss(kind)
+    for opt, val in (("variant", 0), ("row_split", 1), ("fast_paths", 0)):
+        if rng.random() < 0.3:
+            try:
+                eng.set_option(opt, val)
+            except (NotImplementedError, ValueError):
+                pass
+    loss, grad, nv = eng.loss_and_grad(first=first, count=B)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind,
+                                   bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+    tol = 1e-4 if kind in ("kgeLoss", "pearsonLoss") else 1e-5
+    assert nv == sum(nv0)
+    if sum(nv0) == 0:
+        assert np.isnan(loss) and not grad.any()
+    else:
+        yscale = float(np.nanmax(np.abs(np.concatenate(list(yb.values())))))
+        assert loss == pytest.approx(l0, rel=tol, abs=tol * yscale * (yscale if kind == "mse" else 1.0) if kind in ("mse", "mae", "rmse") else None), (kind, spec)
+        if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):         # (a loss the parameters cannot move has a gradient of pure rounding noise)
+            assert util.relerr(grad, g0) <= tol, (kind, spec)
+        else:
+            assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec)
+    eng.close()
