@@ -46,7 +46,18 @@ def _case(seed, fastpath=False):
     ntarg = 1 if fastpath else int(rng.integers(1, len(mm.outputs) + 1))
     targets = [str(t) for t in rng.permutation(list(mm.outputs))[:ntarg]]
     bn = bool(rng.random() < 0.25)
-    spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, scale, input_batchnorm=bn)
+    nets = None
+    if not fastpath and len(neural) >= 2 and rng.random() < 0.35:
+        # MultiNNHybridModel: one single-output net per neural parameter on its own predictor rows, common depth,
+        # widths that fit side by side (the engine runs them as one block-diagonal MLP)
+        K = len(neural)
+        P = max(P, K)
+        cuts = np.sort(rng.choice(np.arange(1, P), K - 1, replace=False)) if K > 1 else np.array([], int)
+        rows = np.split(rng.permutation(P), cuts)
+        cap = (128 if wide else 64) // K
+        nets = [([int(r) for r in rw], [int(rng.integers(1, cap + 1)) for _ in range(nl)]) for rw in rows]
+        bn = False
+    spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, scale, input_batchnorm=bn, nets=nets)
     B = int(rng.choice([1, 7, 31, 32, 33, 64, 257, 1000, 2049]))
     N = B + int(rng.integers(0, 200))
     X = (rng.standard_normal((P, N)) * rng.uniform(0.2, 1.5) + (rng.uniform(-3, 3) if bn else 0.0)).astype(np.float32)
@@ -81,7 +92,9 @@ def test_random_configuration_matches_the_oracle(seed, fastpath):
     loss, grad, nv = eng.loss_and_grad(first=first, count=B)
     l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind,
                                    bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
-    tol = 1e-4 if kind in ("kgeLoss", "pearsonLoss") else 1e-5
+    # (correlation of nearly constant predictions -- a random sigmoid net squeezed through a one-unit layer -- is as
+    # ill-conditioned as it sounds: 1e-3 here, the well-conditioned cases of test_gpu_parity.py hold 1e-4)
+    tol = 1e-3 if kind in ("kgeLoss", "pearsonLoss") else 1e-5
     assert nv == sum(nv0)
     if sum(nv0) == 0:
         assert np.isnan(loss) and not grad.any()
@@ -92,4 +105,53 @@ def test_random_configuration_matches_the_oracle(seed, fastpath):
             assert util.relerr(grad, g0) <= tol, (kind, spec)
         else:
             assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec)
+    eng.close()
+
+
+@pytest.mark.parametrize("fastpath", [False, True])
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EH_FUZZ_N", "60")) // 2))
+def test_random_configuration_trains_and_predicts_like_the_oracle(seed, fastpath):
+    """a few optimiser steps (random rule, fused-update mode where the model allows it) and the forward / eval outputs"""
+    spec, theta, X, f, y, kind, first, B, rng = _case(7000 + seed, fastpath)
+    if kind in ("kgeLoss", "pearsonLoss", "nseLoss"):
+        kind = "mse"                                    # (statistics of tiny batches: covered by the one-shot test above)
+    N = X.shape[1]
+    eng = util.load_engine(spec, theta, X, f, y)
+    if kind != "mse":
+        eng.set_training_loss(kind)
+    fused = False
+    if len(spec.targets) == 1 and rng.random() < 0.5:
+        try:
+            eng.set_option("fused_update", 1); fused = True
+        except NotImplementedError:
+            pass
+    # plain gradient descent: Adam's first steps are sign-like, so rounding noise in a near-zero gradient entry would be
+    # blown up to a full step (the Adam trajectory has its own, conditioned tests)
+    b = max(1, N // 3)
+    if spec.input_batchnorm and b < 16:
+        pytest.skip("BatchNorm statistics of a handful of samples are ill-conditioned")
+    eng.opt_init("Descent", 0.01)
+    batches = [(i * b, b) for i in range(3)]
+    losses = [eng.train_step(*bt) for bt in batches]
+    st = ho.bn_init(spec) if spec.input_batchnorm else None
+    th_ref = theta.astype(np.float32).copy(); l_ref = []
+    for a0, n0 in batches:
+        sl = slice(a0, a0 + n0)
+        yb = {k: v[sl] for k, v in y.items()}
+        if not any((~np.isnan(v)).any() for v in yb.values()):
+            l_ref.append(float("nan")); continue
+        l, g, _ = ho.loss_and_grad(spec, th_ref.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind, bn_state=st)
+        if st is not None:
+            _, new = ho.batchnorm_input(np.asarray(X[:, sl], np.float64), st, True, np.dtype(np.float64)); st.update(new)
+        th_ref = (th_ref - np.float32(0.01) * g.astype(np.float32)).astype(np.float32); l_ref.append(float(l))
+    ok = ~np.isnan(np.asarray(l_ref))
+    assert np.array_equal(np.isnan(losses), ~ok)
+    yscale = float(np.nanmax(np.abs(np.concatenate(list(y.values())))))
+    assert np.allclose(np.asarray(losses)[ok], np.asarray(l_ref)[ok], rtol=3e-4, atol=1e-5 * yscale * yscale), (kind, fused, spec)
+    th = eng.get_params()
+    assert np.max(np.abs(th - th_ref)) <= 1e-4 * max(1.0, float(np.max(np.abs(th_ref)))), (kind, fused, spec)
+    out = eng.forward(0)
+    ref = ho.forward(spec, th.astype(np.float64), X, f, bn_state=st, train_mode=False)
+    for t in spec.targets:
+        assert util.relerr(out[t], ref[t]) <= 3e-5, (t, spec)
     eng.close()
