@@ -131,7 +131,7 @@ def test_random_configuration_trains_and_predicts_like_the_oracle(seed, fastpath
     if spec.input_batchnorm and b < 16:
         pytest.skip("BatchNorm statistics of a handful of samples are ill-conditioned")
     eng.opt_init("Descent", 0.01)
-    batches = [(i * b, b) for i in range(3)]
+    batches = [(i * b, b) for i in range(3) if (i + 1) * b <= N]
     losses = [eng.train_step(*bt) for bt in batches]
     st = ho.bn_init(spec) if spec.input_batchnorm else None
     th_ref = theta.astype(np.float32).copy(); l_ref = []
