@@ -623,11 +623,14 @@ static int build_maps(eh_handle* h, bool with_imap) {
 
 // Which vector-ALU fast paths a model may use: bit 0 = single NN output (K == 1), bit 1 = P <= 4 predictors.  Single-target
 // models only (the K == 1 kernels keep one residual per sample), and the P <= 4 path only on the one-block shapes: on the
-// wider ones it gives wrong weight gradients with ReLU (tests/test_gpu_fuzz.py found it; which kernels fail changes with
-// the compiler flags, the cause is not understood), so it stays where thousands of random configurations verify it.
+// wider ones the ReLU kernels return a wrong loss or wrong weight gradients (tests/test_gpu_fuzz.py found it).  Which
+// kernels fail, and how, changes with compiler flags and with unrelated edits of the backward loop (tools/ps_relu_repro.py,
+// EH_DEBUG_PS_ALL=1), which points at the code generator rather than the source; the path stays where thousands of random
+// configurations verify it.
 static int fast_wanted(const EhArchInfo* A, int K, int P, int T) {
     if (!A->has_fast || T != 1 || K != 1) return 0;
-    return 1 | ((P <= 4 && A->nbh == 1) ? 2 : 0);
+    static const bool debug_all = getenv("EH_DEBUG_PS_ALL") != nullptr;        // diagnostics: reproduce the confined bug
+    return 1 | ((P <= 4 && (A->nbh == 1 || debug_all)) ? 2 : 0);
 }
 
 struct MechInfo { int n_par, n_forc, n_out; };
