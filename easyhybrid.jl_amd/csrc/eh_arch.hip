@@ -14,6 +14,13 @@ struct Var {
     using Geom = EhGeom<EH_NBI, EH_NBH, EH_NL, NT, NW>;
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+    // the P <= 4 kernels (FAST = 3) exist for the one-block shapes only; `make EXP=-DEH_PS_WIDE` builds them for the wider ones
+    // too, for tools/ps_relu_repro.py (see fast_wanted in eh_api.hip)
+#if EH_NBH == 1 || defined(EH_PS_WIDE)
+    static constexpr bool HASPS = true;
+#else
+    static constexpr bool HASPS = false;
+#endif
     // the cross-GPU (EH_MODE_TRAIN_P2P) kernels are built for the default variant of a shape only
 #ifdef EH_EXTRA_VARIANTS
     static constexpr bool HASP2P = NT == 2 && NW == 8;
@@ -33,11 +40,11 @@ struct Var {
         if constexpr (HASP2P) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 0>(); }
 #ifdef EH_FAST_PATHS
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 1>();
-        if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 3>();
+        if constexpr (HASPS) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 3>(); }
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 1>();
         if constexpr (HASP2P) {
             if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 1>();
-            if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 3>();
+            if constexpr (HASPS) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 3>(); }
         }
 #endif
         return e;
@@ -56,7 +63,7 @@ struct Var {
         if (mode == EH_MODE_TRAIN_P2P) {
             if constexpr (HASP2P) {
 #ifdef EH_FAST_PATHS
-                if (fast == 3) { EH_GO(EH_MODE_TRAIN_P2P, 3); return; }
+                if constexpr (HASPS) { if (fast == 3) { EH_GO(EH_MODE_TRAIN_P2P, 3); return; } }
                 if (fast & 1) { EH_GO(EH_MODE_TRAIN_P2P, 1); return; }
 #endif
                 EH_GO(EH_MODE_TRAIN_P2P, 0);
@@ -64,7 +71,7 @@ struct Var {
             return;
         }
 #ifdef EH_FAST_PATHS
-        if (mode == EH_MODE_TRAIN && fast == 3) { EH_GO(EH_MODE_TRAIN, 3); return; }
+        if constexpr (HASPS) { if (mode == EH_MODE_TRAIN && fast == 3) { EH_GO(EH_MODE_TRAIN, 3); return; } }
         if (mode == EH_MODE_TRAIN && (fast & 1)) { EH_GO(EH_MODE_TRAIN, 1); return; }
         if (mode == EH_MODE_EVAL && (fast & 1)) { EH_GO(EH_MODE_EVAL, 1); return; }
 #endif
@@ -73,6 +80,7 @@ struct Var {
 #undef EH_GO
     static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
         if (mode == EH_MODE_TRAIN_P2P && !HASP2P) return hipErrorNotSupported;
+        if (fast == 3 && !HASPS) return hipErrorNotSupported;
         switch (act) {
             case EH_ACT_TANH: go<EH_ACT_TANH>(mode, fast, grid, stream, net, args); break;
             case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, fast, grid, stream, net, args); break;

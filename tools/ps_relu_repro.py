@@ -1,4 +1,5 @@
 """Diagnostics for the confined fast-path bug (P <= 4 weight-gradient path + ReLU on shapes wider than one block):
+build with `make -C easyhybrid.jl_amd/csrc EXP=-DEH_PS_WIDE` (the wide P <= 4 kernels are not in the normal build), then
 EH_DEBUG_PS_ALL=1 python tools/ps_relu_repro.py   (never part of the test suite)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
