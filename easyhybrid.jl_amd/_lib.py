@@ -10,6 +10,8 @@ import ctypes as C
 import os
 
 EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 4, 8, 4, 4, 8
+EH_MAX_PROG, EH_MAX_PROG_CONST, EH_MAX_PROG_OUT = 64, 16, 3
+EH_MECH_PROGRAM = 6
 EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE = 0, -1, -2, -3, -4, -5
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
 EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT = 0, 1, 2, 3, 4, 5
@@ -31,6 +33,8 @@ class ModelDesc(C.Structure):
         ("n_forcings", C.c_int32), ("forcing_index", C.c_int32 * EH_MAX_FORC),
         ("n_targets", C.c_int32), ("target_output", C.c_int32 * EH_MAX_TARG),
         ("n_nets", C.c_int32), ("net_n_predictors", C.c_int32 * EH_MAX_NETS), ("net_hidden", (C.c_int32 * EH_MAX_HIDDEN) * EH_MAX_NETS),
+        ("prog_len", C.c_int32), ("prog_n_const", C.c_int32), ("prog_n_forc", C.c_int32), ("prog_n_out", C.c_int32),
+        ("prog_out", C.c_int32 * EH_MAX_PROG_OUT), ("prog_code", C.c_uint32 * EH_MAX_PROG), ("prog_const", C.c_float * EH_MAX_PROG_CONST),
     ]
 
 

@@ -398,6 +398,8 @@ struct EhSplit {
     float shift[EH_MAX_TARG] = {0, 0, 0, 0};
 };
 
+// kernel selector handed to EhVariant::launch: the fast-path bits, or 4 = the EH_MECH_PROGRAM kernels
+#define KFAST(h) ((h)->net.mech == EH_MECH_PROGRAM ? 4 : (h)->fast)
 #define TH(h) ((h)->thb[(h)->cur])
 #define MM(h) ((h)->mb[(h)->cur])
 #define VV(h) ((h)->vb[(h)->cur])
@@ -458,6 +460,7 @@ struct eh_handle_s {
     long long perm_cap = 0;
     bool perm_valid = false;
     int fast_user = 3;              // what the fast_paths option allows (default: all)
+    unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
     float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
     int n_weights = 0;
     struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
@@ -627,15 +630,16 @@ static int build_maps(eh_handle* h, bool with_imap) {
 // kernels fail, and how, changes with compiler flags and with unrelated edits of the backward loop (tools/ps_relu_repro.py,
 // EH_DEBUG_PS_ALL=1), which points at the code generator rather than the source; the path stays where thousands of random
 // configurations verify it.
-static int fast_wanted(const EhArchInfo* A, int K, int P, int T) {
-    if (!A->has_fast || T != 1 || K != 1) return 0;
+static int fast_wanted(const EhArchInfo* A, int K, int P, int T, int mech) {
+    if (!A->has_fast || T != 1 || K != 1 || mech == EH_MECH_PROGRAM) return 0;
     static const bool debug_all = getenv("EH_DEBUG_PS_ALL") != nullptr;        // diagnostics: reproduce the confined bug
     return 1 | ((P <= 4 && (A->nbh == 1 || debug_all)) ? 2 : 0);
 }
 
 struct MechInfo { int n_par, n_forc, n_out; };
-static bool mech_info(int mech, MechInfo* mi) {
+static bool mech_info(int mech, MechInfo* mi, const eh_model_desc* d = nullptr) {
     switch (mech) {
+        case EH_MECH_PROGRAM: if (!d) return false; *mi = {d->n_params, d->prog_n_forc, d->prog_n_out}; return true;
         case EH_MECH_RBQ10: *mi = {2, 1, 1}; return true;
         case EH_MECH_EXPO: *mi = {2, 1, 1}; return true;
         case EH_MECH_LINEAR: *mi = {2, 1, 1}; return true;
@@ -675,7 +679,34 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     *out = nullptr;
     if (d->struct_size != (int32_t)sizeof(eh_model_desc)) return fail(nullptr, EH_EINVAL, "eh_create: struct_size %d != %zu", d->struct_size, sizeof(eh_model_desc));
     MechInfo mi;
-    if (!mech_info(d->mech, &mi)) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown mechanistic model id %d (no silent fallback)", d->mech);
+    if (!mech_info(d->mech, &mi, d)) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown mechanistic model id %d (no silent fallback)", d->mech);
+    if (d->mech == EH_MECH_PROGRAM) {
+        // every operand must name a slot that holds a value when the instruction runs: the kernel indexes a per-lane array with them
+        if (d->n_params < 1 || d->n_params > EH_MAX_PARAMS) return fail(nullptr, EH_EINVAL, "eh_create: a program takes 1..%d parameters, descriptor has %d", EH_MAX_PARAMS, d->n_params);
+        if (d->prog_len < 1 || d->prog_len > EH_MAX_PROG) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: program of %d instructions (1..%d)", d->prog_len, EH_MAX_PROG);
+        if (d->prog_n_const < 0 || d->prog_n_const > EH_MAX_PROG_CONST) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: program with %d constants (0..%d)", d->prog_n_const, EH_MAX_PROG_CONST);
+        if (d->prog_n_forc < 0 || d->prog_n_forc > EH_MAX_FORC) return fail(nullptr, EH_EINVAL, "eh_create: program with %d forcings (0..%d)", d->prog_n_forc, EH_MAX_FORC);
+        if (d->prog_n_out < 1 || d->prog_n_out > EH_MAX_PROG_OUT) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: program with %d outputs (1..%d)", d->prog_n_out, EH_MAX_PROG_OUT);
+        auto slot_ok = [&](unsigned sl, int upto) {
+            if (sl < EH_PROG_SLOT_FORC) return (int)sl < d->n_params;
+            if (sl < EH_PROG_SLOT_CONST) return (int)sl - EH_PROG_SLOT_FORC < d->prog_n_forc;
+            if (sl < EH_PROG_SLOT_INSTR) return (int)sl - EH_PROG_SLOT_CONST < d->prog_n_const;
+            return (int)sl - EH_PROG_SLOT_INSTR < upto;
+        };
+        for (int i = 0; i < d->prog_len; ++i) {
+            const unsigned w = d->prog_code[i], op = w & 255u;
+            if (op >= EH_OP_COUNT) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: program instruction %d has unknown opcode %u", i, op);
+            const int nop = (op == EH_OP_SELECT) ? 3 : (op == EH_OP_NEG || op == EH_OP_EXP || op == EH_OP_LOG || op == EH_OP_SQRT || op == EH_OP_TANH ||
+                                                        op == EH_OP_SIGMOID || op == EH_OP_ABS || op == EH_OP_SIN || op == EH_OP_COS) ? 1 : 2;
+            const unsigned sl[3] = {(w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
+            for (int k = 0; k < 3; ++k) {
+                if (k < nop ? !slot_ok(sl[k], i) : sl[k] != 0u)
+                    return fail(nullptr, EH_EINVAL, "eh_create: program instruction %d, operand %d names slot %u (undefined at that point, or a non-zero unused operand)", i, k, sl[k]);
+            }
+        }
+        for (int o = 0; o < d->prog_n_out; ++o)
+            if (d->prog_out[o] < 0 || !slot_ok((unsigned)d->prog_out[o], d->prog_len)) return fail(nullptr, EH_EINVAL, "eh_create: program output %d names slot %d", o, d->prog_out[o]);
+    }
     if (d->activation < 0 || d->activation > EH_ACT_IDENTITY) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d", d->activation);
     if (d->n_params != mi.n_par) return fail(nullptr, EH_EINVAL, "eh_create: model %d takes %d parameters, descriptor has %d", d->mech, mi.n_par, d->n_params);
     if (d->n_predictors < 1) return fail(nullptr, EH_EINVAL, "eh_create: n_predictors must be >= 1");
@@ -787,7 +818,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     for (int f = 0; f < mi.n_forc; ++f) n.forc_col = (n.forc_col & ~(0xFFu << (8 * f))) | ((unsigned)d->forcing_index[f] << (8 * f));
     n.n_out = mi.n_out;
     for (int t = 0; t < d->n_targets; ++t) n.targ_out |= (unsigned)d->target_output[t] << (2 * t);
-    h->fast = fast_wanted(arch, K, n.P, n.T);
+    h->fast = fast_wanted(arch, K, n.P, n.T, d->mech);
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T + 2;      // [grad | S | n_valid per target | Sy | Syy]
@@ -815,6 +846,15 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
+    if (d->mech == EH_MECH_PROGRAM) {
+        std::vector<unsigned> pb(EH_PROG_HDR + EH_MAX_PROG, 0u);
+        pb[0] = (unsigned)d->prog_len; pb[1] = (unsigned)d->prog_n_out;
+        for (int o = 0; o < EH_MAX_PROG_OUT; ++o) pb[2 + o] = (unsigned)(o < d->prog_n_out ? d->prog_out[o] : d->prog_out[0]);
+        for (int k = 0; k < d->prog_n_const; ++k) memcpy(&pb[8 + k], &d->prog_const[k], sizeof(float));
+        for (int i = 0; i < d->prog_len; ++i) pb[EH_PROG_HDR + i] = d->prog_code[i];
+        HIPCHK_C(hipMalloc(&h->prog, pb.size() * sizeof(unsigned)));
+        HIPCHK_C(hipMemcpy(h->prog, pb.data(), pb.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
     const size_t nt = (size_t)n.n_theta;
     // one allocation: [2][3][n_theta] parameter sets {theta, m, v}, then the [2][2] running beta products
     HIPCHK_C(hipMalloc(&h->pset, (6 * nt + 4) * sizeof(float)));
@@ -890,7 +930,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
-    (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -931,7 +971,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         return EH_OK;
     }
     if (!strcmp(name, "fast_paths")) {       // 0 forces the generic MFMA kernels (A/B testing)
-        const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T);
+        const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech);
         h->fast_user = value ? (int)value : 0;
         h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
         HIPCHK(h, hipSetDevice(h->device));
@@ -957,7 +997,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         FLUSH(h);
         h->net.loss = (int)value;
         {   // the moment-based losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
-            const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T);
+            const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech);
             const int fast = (value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
             if (fast != h->fast) { h->fast = fast; return build_maps(h, false); }
         }
@@ -972,7 +1012,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         FLUSH(h);
         std::swap(h->arch, h->arch_alt);
         h->variant = (h->arch->nvar > 1 && !h->arch->wide) ? 1 : 0;
-        h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : (fast_wanted(h->arch, h->net.K, h->net.P, h->net.T) & h->fast_user);
+        h->fast = (h->net.loss >= EH_LOSS_PEARSONLOSS) ? 0 : (fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech) & h->fast_user);
         for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
         return build_maps(h, false);
     }
@@ -1105,21 +1145,23 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         // (yhat, y) about the means -> the coefficients of the per-sample d loss / d yhat that the training pass multiplies
         // into the VJP
         EhStepArgs e{};
+        e.prog = h->prog;
         e.recs = sp.recs; e.C = h->C; e.idx = idx; e.first = first; e.count = count;
         e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.cmap = h->cmap; e.stamps = nullptr;
         e.yld = count;
         for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
         if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
         const int egrid = count > 0 ? grid_for(h, count) : 1;
-        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, egrid, h->stream, &h->net, &e));       // -> mean of yhat
+        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, KFAST(h), egrid, h->stream, &h->net, &e));       // -> mean of yhat
         hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, sp.shift[0], h->inv_n);
         HIPCHK(h, hipGetLastError());
         e.inv_n = h->inv_n;                                                                                               // -> moments about it
-        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, egrid, h->stream, &h->net, &e));
+        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, KFAST(h), egrid, h->stream, &h->net, &e));
         hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, net.loss, sp.shift[0], h->inv_n);
         HIPCHK(h, hipGetLastError());
     }
     EhStepArgs a{};
+    a.prog = h->prog;
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
     a.inv_n = (net.T > 1 || moment_loss) ? h->inv_n : nullptr;
@@ -1130,7 +1172,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &a)) return rc;
     const int grid = grid_for(h, count);
     *grid_out = grid;
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, KFAST(h), grid, h->stream, &h->net, &a));
     return EH_OK;
 }
 
@@ -1145,6 +1187,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
         h->prof_k++;
     }
     EhStepArgs a{};
+    a.prog = h->prog;
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.cmap = h->cmap; a.stamps = h->stamps;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
@@ -1155,7 +1198,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     a.p2p_seq = h->p2p_on ? ++h->p2p_seq : 0u;
     if (int rc = bn_prepare(h, sp, idx, first, count, true, &a)) return rc;
     const int grid = grid_for(h, count);
-    HIPCHK(h, h->arch->var[h->variant].launch(h->p2p_on ? EH_MODE_TRAIN_P2P : EH_MODE_TRAIN, h->act, h->fast, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(h->p2p_on ? EH_MODE_TRAIN_P2P : EH_MODE_TRAIN, h->act, KFAST(h), grid, h->stream, &h->net, &a));
     h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;
     h->pending = true;
     h->pending_loss = loss_slot_for_this_step;
@@ -1255,6 +1298,7 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
         h->out_cap = need;
     }
     EhStepArgs a{};
+    a.prog = h->prog;
     a.recs = sp.recs; a.C = h->C; a.idx = nullptr; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = EH_EVAL_STATS * net.T;
     a.yhat = yhat ? h->out_buf : nullptr;
@@ -1262,7 +1306,7 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     const int grid = count > 0 ? grid_for(h, count) : 1;
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, h->fast, grid, h->stream, &h->net, &a));
+    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, KFAST(h), grid, h->stream, &h->net, &a));
     std::vector<float> part((size_t)grid * a.n_acc);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1610,6 +1654,7 @@ int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out,
     // (world == 1 is a loopback: the rank publishes to and reads from itself -- measures the cost of the machinery)
     if (world < 1 || world > EH_GSHARDS || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_p2p_init: world %d (1..%d), rank %d", world, EH_GSHARDS, rank);
     if (!h->fused) return fail(h, EH_ESTATE, "eh_p2p_init: set the fused_update option first");
+    if (h->net.mech == EH_MECH_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the program kernels have no cross-GPU variant (use the all-reduce seam)");
     if (h->p2p_on || h->p2p_alloc) return fail(h, EH_ESTATE, "eh_p2p_init: already initialised");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);

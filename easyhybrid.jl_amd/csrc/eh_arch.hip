@@ -38,6 +38,8 @@ struct Var {
         hipError_t e = prep1<ACT, EH_MODE_TRAIN, 0>();
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 0>();
         if constexpr (HASP2P) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 0>(); }
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 4>();      // EH_MECH_PROGRAM kernels (no cross-GPU variant)
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 4>();
 #ifdef EH_FAST_PATHS
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 1>();
         if constexpr (HASPS) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 3>(); }
@@ -60,6 +62,10 @@ struct Var {
 #define EH_GO(MODE, FAST) hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args)
     template <int ACT>
     static void go(int mode, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (fast & 4) {
+            if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN, 4); else EH_GO(EH_MODE_EVAL, 4);
+            return;
+        }
         if (mode == EH_MODE_TRAIN_P2P) {
             if constexpr (HASP2P) {
 #ifdef EH_FAST_PATHS
@@ -81,6 +87,7 @@ struct Var {
     static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
         if (mode == EH_MODE_TRAIN_P2P && !HASP2P) return hipErrorNotSupported;
         if (fast == 3 && !HASPS) return hipErrorNotSupported;
+        if ((fast & 4) && (fast != 4 || mode == EH_MODE_TRAIN_P2P)) return hipErrorNotSupported;
         switch (act) {
             case EH_ACT_TANH: go<EH_ACT_TANH>(mode, fast, grid, stream, net, args); break;
             case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, fast, grid, stream, net, args); break;

@@ -26,15 +26,18 @@ struct Var {
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
 
-    template <int ACT, int MODE>
+    template <int ACT, int MODE, bool PROG>
     static hipError_t prep1() {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, MODE>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, MODE, PROG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     template <int ACT>
     static hipError_t prep2() {
-        hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
-        return e == hipSuccess ? prep1<ACT, EH_MODE_EVAL>() : e;
+        hipError_t e = prep1<ACT, EH_MODE_TRAIN, false>();
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, false>();
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, true>();      // EH_MECH_PROGRAM (fast == 4)
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, true>();
+        return e;
     }
     static hipError_t prepare() {
         hipError_t e;
@@ -44,20 +47,21 @@ struct Var {
         if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
         return prep2<EH_ACT_IDENTITY>();
     }
+#define EH_GO(MODE, PROG) hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, MODE, PROG>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args)
     template <int ACT>
-    static void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
-        if (mode == EH_MODE_TRAIN)
-            hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, EH_MODE_TRAIN>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args);
-        else
-            hipLaunchKernelGGL((eh_wide_kernel<EH_NBI, EH_NBH, EH_NL, NT, NWV, ACT, EH_MODE_EVAL>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args);
+    static void go(int mode, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (fast & 4) { if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN, true); else EH_GO(EH_MODE_EVAL, true); }
+        else { if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN, false); else EH_GO(EH_MODE_EVAL, false); }
     }
-    static hipError_t launch(int mode, int act, int /*fast*/, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+#undef EH_GO
+    static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode != EH_MODE_TRAIN && mode != EH_MODE_EVAL) return hipErrorNotSupported;
         switch (act) {
-            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
-            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
-            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
-            case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, grid, stream, net, args); break;
-            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
+            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_SWISH: go<EH_ACT_SWISH>(mode, fast, grid, stream, net, args); break;
+            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, fast, grid, stream, net, args); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -154,6 +154,7 @@ struct EhStepArgs {
     // (kept last: the single-GPU kernels never read them and the layout of everything above stays put)
     const EhP2P* p2p;     // EH_MODE_TRAIN_P2P only
     unsigned p2p_seq;     // sequence number this step publishes; its prologue waits for p2p_seq - 1
+    const unsigned* prog; // EH_MECH_PROGRAM kernels only: [0] length, [1] outputs, [2..4] output slots, [8..23] constants, [24..] code
 };
 
 #define EH_BN_EPS 1e-5f
@@ -291,6 +292,82 @@ __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const 
     }
     dydp[0] = d0; dydp[1] = d1; dydp[2] = d2; dydp[3] = d3; dydp[4] = d4; dydp[5] = d5;
     return y;
+}
+
+// EH_MECH_PROGRAM: a user closure recorded as a straight-line program (include/easyhybrid_hip.h, eh_prog_op).  One
+// sample per lane; the value slots are a per-lane array indexed by the (wave-uniform) operand fields, i.e. they live in
+// scratch memory -- these kernels are their own instantiations (FAST bit 2), the registry models never carry it.
+// The host has checked every operand slot against the instruction's position (eh_create), so no index leaves val[].
+#define EH_PROG_HDR 24
+__device__ __forceinline__ void eh_prog_forward(const unsigned* __restrict__ prog, const float* par, const float* frc, float* val) {
+#pragma unroll
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) val[EH_PROG_SLOT_PAR + j] = par[j];
+#pragma unroll
+    for (int f = 0; f < EH_MAX_FORC; ++f) val[EH_PROG_SLOT_FORC + f] = frc[f];
+#pragma unroll
+    for (int k = 0; k < EH_MAX_PROG_CONST; ++k) val[EH_PROG_SLOT_CONST + k] = __uint_as_float(prog[8 + k]);
+    const int n = (int)prog[0];
+    for (int i = 0; i < n; ++i) {
+        const unsigned w = prog[EH_PROG_HDR + i];
+        const float x = val[(w >> 8) & 255u], y = val[(w >> 16) & 255u], z = val[w >> 24];
+        float r;
+        switch (w & 255u) {
+            case EH_OP_ADD: r = x + y; break;
+            case EH_OP_SUB: r = x - y; break;
+            case EH_OP_MUL: r = x * y; break;
+            case EH_OP_DIV: r = x / y; break;
+            case EH_OP_NEG: r = -x; break;
+            case EH_OP_EXP: r = __expf(x); break;
+            case EH_OP_LOG: r = __logf(x); break;
+            case EH_OP_POW: r = eh_pow(x, y); break;
+            case EH_OP_SQRT: r = sqrtf(x); break;
+            case EH_OP_TANH: r = eh_tanh(x); break;
+            case EH_OP_SIGMOID: r = eh_sigmoid(x); break;
+            case EH_OP_MAX: r = fmaxf(x, y); break;
+            case EH_OP_MIN: r = fminf(x, y); break;
+            case EH_OP_ABS: r = fabsf(x); break;
+            case EH_OP_SIN: r = sinf(x); break;
+            case EH_OP_COS: r = cosf(x); break;
+            case EH_OP_SELECT: r = x > 0.0f ? y : z; break;
+            case EH_OP_GT: r = x > y ? 1.0f : 0.0f; break;
+            default: r = 0.0f; break;
+        }
+        val[EH_PROG_SLOT_INSTR + i] = r;
+    }
+}
+// reverse sweep: adj[] comes in holding the output seeds (zero elsewhere); on return adj[j], j < 8, is d loss / d parameter j
+__device__ __forceinline__ void eh_prog_reverse(const unsigned* __restrict__ prog, const float* val, float* adj) {
+    const int n = (int)prog[0];
+    for (int i = n - 1; i >= 0; --i) {
+        const unsigned w = prog[EH_PROG_HDR + i];
+        const unsigned ia = (w >> 8) & 255u, ib = (w >> 16) & 255u, ic = w >> 24;
+        const float x = val[ia], y = val[ib], r = val[EH_PROG_SLOT_INSTR + i], gr = adj[EH_PROG_SLOT_INSTR + i];
+        float ga = 0.0f, gb = 0.0f, gc = 0.0f;
+        switch (w & 255u) {
+            case EH_OP_ADD: ga = gr; gb = gr; break;
+            case EH_OP_SUB: ga = gr; gb = -gr; break;
+            case EH_OP_MUL: ga = gr * y; gb = gr * x; break;
+            case EH_OP_DIV: ga = gr / y; gb = -(gr / y) * r; break;
+            case EH_OP_NEG: ga = -gr; break;
+            case EH_OP_EXP: ga = gr * r; break;
+            case EH_OP_LOG: ga = gr / x; break;
+            case EH_OP_POW: ga = gr * y * r / x; gb = gr * r * __logf(x); break;
+            case EH_OP_SQRT: ga = gr * 0.5f / r; break;
+            case EH_OP_TANH: ga = gr * (1.0f - r * r); break;
+            case EH_OP_SIGMOID: ga = gr * r * (1.0f - r); break;
+            case EH_OP_MAX: ga = x >= y ? gr : 0.0f; gb = x >= y ? 0.0f : gr; break;
+            case EH_OP_MIN: ga = x <= y ? gr : 0.0f; gb = x <= y ? 0.0f : gr; break;
+            case EH_OP_ABS: ga = x > 0.0f ? gr : (x < 0.0f ? -gr : 0.0f); break;
+            case EH_OP_SIN: ga = gr * cosf(x); break;
+            case EH_OP_COS: ga = -gr * sinf(x); break;
+            case EH_OP_SELECT: gb = x > 0.0f ? gr : 0.0f; gc = x > 0.0f ? 0.0f : gr; break;
+            default: break;
+        }
+        // sequential read-modify-writes: two operands may name the same slot (x * x)
+        adj[ia] += ga;
+        adj[ib] += gb;
+        adj[ic] += gc;
+    }
 }
 
 // outputs 1.. of the multi-output models and their Jacobian rows (only FLUXPART: GPP, RECO)
@@ -446,6 +523,8 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
     constexpr bool TRAIN = MODE != EH_MODE_EVAL;
     constexpr bool P2PM = MODE == EH_MODE_TRAIN_P2P;      // its own instantiation: the single-GPU kernel carries none of this
     constexpr bool K1 = (FAST & 1) != 0, PS = (FAST & 2) != 0;
+    constexpr bool PROG = (FAST & 4) != 0;                // EH_MECH_PROGRAM: the mechanistic stage interprets a.prog
+    static_assert(!PROG || FAST == 4, "the program kernels are generic kernels");
     constexpr bool KEEPH = TRAIN && ACT != EH_ACT_SWISH && NL * NBH * NT * 4 <= 64;   // activations stay in registers for act'
     constexpr int NHS = KEEPH ? NL : 1, NHM = KEEPH ? NBH : 1, NHT = KEEPH ? NT : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -863,9 +942,17 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
             // registers are consumed: measured 2 % faster at 16 tiles per wave (the wait is almost always
             // free at this point and the next prefetch then issues without a stall).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const float y0 = eh_mech_eval(net.mech, par, frc, dydp);
-            float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-            if (multiOn != 0.0f) eh_mech_extra(net.mech, par, frc, yx, Jx);
+            float y0, yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            float pval[PROG ? EH_PROG_SLOTS : 1];
+            if constexpr (PROG) {
+                eh_prog_forward(a.prog, par, frc, pval);
+                y0 = pval[a.prog[2]];
+                if (net.n_out > 1) yx[0] = pval[a.prog[3]];
+                if (net.n_out > 2) yx[1] = pval[a.prog[4]];
+            } else {
+                y0 = eh_mech_eval(net.mech, par, frc, dydp);
+                if (multiOn != 0.0f) eh_mech_extra(net.mech, par, frc, yx, Jx);
+            }
             float dy = 0.0f, dyx[2] = {0.0f, 0.0f};          // d loss / d output 0, outputs 1..2
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t) {
@@ -878,7 +965,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
                         if (maeOn != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
-                        else if (FAST == 0 && net.loss >= EH_LOSS_PEARSONLOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
+                        else if ((FAST & 3) == 0 && net.loss >= EH_LOSS_PEARSONLOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
                             d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
                         }
                         else { lacc += w * r * r; d = 2.0f * w * r; }
@@ -906,10 +993,23 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
                 }
                 continue;
             }
+            float padj[PROG ? EH_PROG_SLOTS : 1];
+            if constexpr (PROG) {
+                const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
+                for (int i = 0; i < nslot; ++i) padj[i] = 0.0f;
+                padj[a.prog[2]] += dy;
+                if (net.n_out > 1) padj[a.prog[3]] += dyx[0];
+                if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
+                eh_prog_reverse(a.prog, pval, padj);
+            }
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
-                float dp = dy * dydp[j];
-                if (j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];     // zero for the single-output models
+                float dp;
+                if constexpr (PROG) dp = padj[j];
+                else {
+                    dp = dy * dydp[j];
+                    if (j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];     // zero for the single-output models
+                }
                 dp = live ? dp : 0.0f;
                 if (kN[j] != 0.0f) {
                     if constexpr (K1) dOm = dp * sg[j];

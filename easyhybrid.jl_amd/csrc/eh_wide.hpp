@@ -43,7 +43,7 @@ struct EhWideGeom : EhGeom<NBI, NBH, NL, NT, 1> {
 // make every barrier wait for the next tile's records (global loads issued a tile ahead on purpose).
 __device__ __forceinline__ void eh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE>
+template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false>
 __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, const EhStepArgs a) {
     using G = EhWideGeom<NBI, NBH, NL, NT, NWV>;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, MB = NBH / NWV, NTH = 64 * NWV;
@@ -346,9 +346,17 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                     sg[j] = SG[pidx(j) * SR + lane];
                 }
             }
-            const float y0 = eh_mech_eval(net.mech, par, frc, dydp);
-            float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-            if (net.n_out > 1) eh_mech_extra(net.mech, par, frc, yx, Jx);
+            float y0, yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            float pval[PROG ? EH_PROG_SLOTS : 1];
+            if constexpr (PROG) {
+                eh_prog_forward(a.prog, par, frc, pval);
+                y0 = pval[a.prog[2]];
+                if (net.n_out > 1) yx[0] = pval[a.prog[3]];
+                if (net.n_out > 2) yx[1] = pval[a.prog[4]];
+            } else {
+                y0 = eh_mech_eval(net.mech, par, frc, dydp);
+                if (net.n_out > 1) eh_mech_extra(net.mech, par, frc, yx, Jx);
+            }
             float dy = 0.0f, dyx[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t) {
@@ -387,11 +395,24 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                         for (int j = 0; j < net.n_par; ++j) a.pout[(long long)j * a.yld + n_loc] = par[j];
                 }
             } else {
+                float padj[PROG ? EH_PROG_SLOTS : 1];
+                if constexpr (PROG) {
+                    const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
+                    for (int i = 0; i < nslot; ++i) padj[i] = 0.0f;
+                    padj[a.prog[2]] += dy;
+                    if (net.n_out > 1) padj[a.prog[3]] += dyx[0];
+                    if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
+                    eh_prog_reverse(a.prog, pval, padj);
+                }
 #pragma unroll
                 for (int j = 0; j < EH_MAX_PARAMS; ++j) {
                     if (j < net.n_par) {
-                        float dp = dy * dydp[j];
-                        if (j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
+                        float dp;
+                        if constexpr (PROG) dp = padj[j];
+                        else {
+                            dp = dy * dydp[j];
+                            if (j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
+                        }
                         dp = live ? dp : 0.0f;
                         const int kd = pkind(j);
                         if (kd == EH_PAR_NEURAL) OS[pidx(j) * SR + lane] = dp * sg[j];

@@ -8,11 +8,13 @@
   build_parameters / ParameterContainer            -- src/models/helpers_for_HybridModel.jl:39-52,95-102
   scale_single_param, inv_sigmoid, ...             -- src/models/GenericHybridModel.jl:348-365
 
-The reference accepts any Julia closure as `mechanistic_model`; a closure cannot run inside a HIP
-kernel, so this engine accepts the mechanistic models of its registry (the reference's own RbQ10,
-Expo, Linear, Rs_components formulas plus the build-defined two-pool Expo of BASELINE config 3),
-either by name or as the tagged Python callables below, and raises NotImplementedError for anything
-else -- never a silent CPU fallback.
+The reference accepts any Julia closure as `mechanistic_model`.  The engine has hand-derived device code
+for the models of its registry (the reference's own RbQ10, Expo, Linear, Rs_components, FluxPart formulas
+plus the build-defined two-pool Expo of BASELINE config 3), selected by name or by the tagged Python
+callables below; any other callable `f(**forcings, **params) -> dict` of elementwise arithmetic is called
+once with tracer values and handed to the device as a straight-line program (program.py, EH_MECH_PROGRAM),
+which the step kernel evaluates and differentiates per sample.  What cannot be recorded raises
+NotImplementedError -- never a silent CPU fallback.
 """
 from __future__ import annotations
 
@@ -36,6 +38,7 @@ class MechSpec:
     params: Tuple[str, ...]
     forcings: Tuple[str, ...]
     outputs: Tuple[str, ...]
+    program: Optional[object] = None     # program.Program for a traced closure (id 6)
 
 
 MECH_REGISTRY: Dict[str, MechSpec] = {
@@ -92,7 +95,7 @@ def FluxPartModelQ10(*, SW_IN, TA, RUE, Rb, Q10):
     raise NotImplementedError("registry tag")
 
 
-def resolve_mech(m) -> MechSpec:
+def resolve_mech(m, params=None, forcing=None, targets=None) -> MechSpec:
     if isinstance(m, MechSpec):
         return m
     if isinstance(m, str):
@@ -101,9 +104,11 @@ def resolve_mech(m) -> MechSpec:
         raise NotImplementedError(f"mechanistic model {m!r} is not in the device registry {sorted(MECH_REGISTRY)}")
     spec = getattr(m, "eh_mech", None)
     if spec is None:
-        raise NotImplementedError(
-            "an arbitrary mechanistic closure cannot run inside the HIP kernel; use one of the registry models "
-            f"{sorted(MECH_REGISTRY)} (no CPU fallback is provided)")
+        if not callable(m) or params is None:
+            raise NotImplementedError(f"mechanistic model {m!r}: pass a registry name {sorted(MECH_REGISTRY)} or a callable")
+        from .program import trace
+        prog = trace(m, params, forcing, targets)      # GenericHybridModel.jl:420-425: f(; forcing..., params...)
+        spec = MechSpec(L.EH_MECH_PROGRAM, getattr(m, "__name__", "closure"), prog.params, prog.forcings, prog.outputs, prog)
     return spec
 
 
@@ -304,6 +309,15 @@ class SingleNNHybridModel:
         d.n_targets = len(self.targets)
         for t, name in enumerate(self.targets):
             d.target_output[t] = ms.outputs.index(name)
+        if ms.program is not None:
+            pg = ms.program
+            d.prog_len, d.prog_n_const, d.prog_n_forc, d.prog_n_out = len(pg.code), len(pg.consts), len(pg.forcings), len(pg.out)
+            for i, w in enumerate(pg.words()):
+                d.prog_code[i] = w
+            for i, c in enumerate(pg.consts):
+                d.prog_const[i] = c
+            for i, o in enumerate(pg.out):
+                d.prog_out[i] = o
         return d
 
     def engine(self, device: int = 0):
@@ -318,8 +332,8 @@ HybridModel = SingleNNHybridModel     # spelling used by BASELINE.json's north_s
 def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mechanistic_model, parameters, global_param_names, *,
                      hidden_layers, activation, scale_nn_outputs, input_batchnorm, start_from_default, **kwargs):
     """MultiNNHybridModel: one single-output MLP per key of `predictors` (= neural parameter) on its own predictor set."""
-    ms = resolve_mech(mechanistic_model)
     parameters = build_parameters(parameters, mechanistic_model)
+    ms = resolve_mech(mechanistic_model, parameters.names(), list(forcing), list(targets))
     all_names = parameters.names()
     neural = list(predictors)
     glob = list(global_param_names or [])
@@ -378,8 +392,8 @@ def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[s
                                 global_param_names if global_param_names is not None else neural_param_names,
                                 hidden_layers=hidden_layers, activation=activation, scale_nn_outputs=scale_nn_outputs,
                                 input_batchnorm=input_batchnorm, start_from_default=start_from_default, **kwargs)
-    ms = resolve_mech(mechanistic_model)
     parameters = build_parameters(parameters, mechanistic_model)
+    ms = resolve_mech(mechanistic_model, parameters.names(), list(forcing), list(targets))
     all_names = parameters.names()
     if not all(n in all_names for n in neural_param_names):
         raise AssertionError("neural_param_names ⊆ param_names")                      # GenericHybridModel.jl:110

@@ -37,6 +37,9 @@ extern "C" {
 #define EH_MAX_FORC 4
 #define EH_MAX_TARG 4
 #define EH_MAX_NETS 8
+#define EH_MAX_PROG 64         /* instructions of a mechanistic program (EH_MECH_PROGRAM) */
+#define EH_MAX_PROG_CONST 16   /* its literal constants */
+#define EH_MAX_PROG_OUT 3      /* its outputs */
 
 typedef enum eh_status {
     EH_OK = 0,
@@ -66,7 +69,30 @@ typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 
  *   FLUXPART       params (RUE, Rb, Q10)          forcings (SW_IN, TA)  outputs (NEE, GPP, RECO)
  *                  GPP = SW_IN*RUE/12.011, RECO = Rb*Q10^(0.1(TA-15)), NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:50-79
  */
-typedef enum eh_mech { EH_MECH_RBQ10 = 0, EH_MECH_EXPO = 1, EH_MECH_LINEAR = 2, EH_MECH_EXPO2POOL = 3, EH_MECH_RS_COMPONENTS = 4, EH_MECH_FLUXPART = 5 } eh_mech;
+typedef enum eh_mech { EH_MECH_RBQ10 = 0, EH_MECH_EXPO = 1, EH_MECH_LINEAR = 2, EH_MECH_EXPO2POOL = 3, EH_MECH_RS_COMPONENTS = 4, EH_MECH_FLUXPART = 5,
+                       EH_MECH_PROGRAM = 6 } eh_mech;
+
+/* EH_MECH_PROGRAM: any other closure `f(; forcing..., params...) -> NamedTuple` of elementwise arithmetic
+ * (src/models/GenericHybridModel.jl:420-425), handed over as a straight-line program that the host binding records by
+ * calling the closure once with tracer numbers.  The step kernel evaluates it per sample and runs the reverse sweep over the
+ * same tape for d loss / d parameter (what Zygote derives from the closure), fp32 like the rest of the path.
+ * Value slots: 0..7 the mechanistic parameters in descriptor order (physical values, after sigma-scaling), 8..11 the
+ * forcings (canonical order = forcing_index[]), 12..27 prog_const[], 28+i the result of instruction i.  An instruction is
+ * op | a << 8 | b << 16 | c << 24 with a, b, c slots defined before it (unused operands 0). */
+typedef enum eh_prog_op {
+    EH_OP_ADD = 0, EH_OP_SUB = 1, EH_OP_MUL = 2, EH_OP_DIV = 3, EH_OP_NEG = 4,
+    EH_OP_EXP = 5, EH_OP_LOG = 6, EH_OP_POW = 7,        /* POW: a^b for a > 0 (exp2(b log2 a)); integer powers are recorded as products */
+    EH_OP_SQRT = 8, EH_OP_TANH = 9, EH_OP_SIGMOID = 10,
+    EH_OP_MAX = 11, EH_OP_MIN = 12, EH_OP_ABS = 13, EH_OP_SIN = 14, EH_OP_COS = 15,
+    EH_OP_SELECT = 16,                                  /* a > 0 ? b : c   (ifelse) */
+    EH_OP_GT = 17,                                      /* a > b ? 1 : 0   (no derivative) */
+    EH_OP_COUNT = 18
+} eh_prog_op;
+#define EH_PROG_SLOT_PAR 0
+#define EH_PROG_SLOT_FORC 8
+#define EH_PROG_SLOT_CONST 12
+#define EH_PROG_SLOT_INSTR 28
+#define EH_PROG_SLOTS (EH_PROG_SLOT_INSTR + EH_MAX_PROG)
 
 /* where a mechanistic parameter comes from (neural_param_names / global_param_names / the rest,
  * src/models/GenericHybridModel.jl:96-97,127) */
@@ -117,6 +143,14 @@ typedef struct eh_model_desc {
     int32_t n_nets;
     int32_t net_n_predictors[EH_MAX_NETS];
     int32_t net_hidden[EH_MAX_NETS][EH_MAX_HIDDEN];
+    /* EH_MECH_PROGRAM only (ignored otherwise): n_params parameters, prog_n_forc forcings, prog_n_out outputs */
+    int32_t prog_len;                        /* 1..EH_MAX_PROG */
+    int32_t prog_n_const;                    /* 0..EH_MAX_PROG_CONST */
+    int32_t prog_n_forc;                     /* 0..EH_MAX_FORC canonical forcings the program reads */
+    int32_t prog_n_out;                      /* 1..EH_MAX_PROG_OUT */
+    int32_t prog_out[EH_MAX_PROG_OUT];       /* slot holding output o */
+    uint32_t prog_code[EH_MAX_PROG];
+    float prog_const[EH_MAX_PROG_CONST];
 } eh_model_desc;
 
 typedef struct eh_target_metrics {           /* src/losses/loss_fn.jl:58-179 on the valid samples of one target */

@@ -209,6 +209,101 @@ MECH: Dict[str, Tuple[MechModel, callable, callable]] = {
 }
 
 
+
+# ----------------------------------------------------------------------------------------------
+# user closures (GenericHybridModel.jl:420-425: `mechanistic_model(; forcing..., params...)`, differentiated by Zygote).
+# The oracle runs the closure itself on NumPy arrays for the forward values; its VJP is the reverse sweep over the
+# recorded straight-line program (plain data: slots 0..7 parameters, 8..11 forcings, 12..27 constants, 28+i instruction
+# i; include/easyhybrid_hip.h `eh_prog_op`), which tests/test_program.py checks against central differences of the closure.
+# ----------------------------------------------------------------------------------------------
+PROG_OPS = ("add", "sub", "mul", "div", "neg", "exp", "log", "pow", "sqrt", "tanh", "sigmoid", "max", "min", "abs", "sin", "cos", "select", "gt")
+
+
+def program_values(prog: dict, par, frc, dt):
+    """All slot values of one evaluation of the program (list indexed by slot; None = unused slot)."""
+    val = [None] * (28 + len(prog["code"]))
+    for j, n in enumerate(prog["params"]):
+        val[j] = np.asarray(par[n], dt)
+    for j, n in enumerate(prog["forcings"]):
+        val[8 + j] = np.asarray(frc[n], dt)
+    for j, c in enumerate(prog["consts"]):
+        val[12 + j] = dt.type(c)
+    one, zero = dt.type(1), dt.type(0)
+    with np.errstate(all="ignore"):
+        for i, (op, a, b, c) in enumerate(prog["code"]):
+            x, y, z = val[a], val[b], val[c]
+            k = PROG_OPS[op]
+            if k == "add": r = x + y
+            elif k == "sub": r = x - y
+            elif k == "mul": r = x * y
+            elif k == "div": r = x / y
+            elif k == "neg": r = -x
+            elif k == "exp": r = np.exp(x)
+            elif k == "log": r = np.log(x)
+            elif k == "pow": r = np.power(x, y)
+            elif k == "sqrt": r = np.sqrt(x)
+            elif k == "tanh": r = np.tanh(x)
+            elif k == "sigmoid": r = one / (one + np.exp(-x))
+            elif k == "max": r = np.maximum(x, y)
+            elif k == "min": r = np.minimum(x, y)
+            elif k == "abs": r = np.abs(x)
+            elif k == "sin": r = np.sin(x)
+            elif k == "cos": r = np.cos(x)
+            elif k == "select": r = np.where(x > 0, y, z)
+            elif k == "gt": r = np.where(x > y, one, zero)
+            else: raise ValueError(f"opcode {op}")
+            val[28 + i] = np.asarray(r, dt)
+    return val
+
+
+def program_mech(name: str, prog: dict, closure=None):
+    """Register a recorded closure as mechanistic model `name`.  With `closure` the forward values come from calling it on
+    the arrays (as the reference does); the program then only supplies the tape for the VJP."""
+    mm = MechModel(name, tuple(prog["params"]), tuple(prog["forcings"]), tuple(prog["outputs"]))
+
+    def fwd(par, frc, dt):
+        val = program_values(prog, par, frc, dt)
+        if closure is not None:
+            res = closure(**{n: np.asarray(frc[n], dt) for n in prog["forcings"]}, **{n: np.asarray(par[n], dt) for n in prog["params"]})
+            out = {o: np.asarray(res[o], dt) for o in prog["outputs"]}
+        else:
+            out = {o: val[s] for o, s in zip(prog["outputs"], prog["out"])}
+        return out, {"val": val}
+
+    def vjp(par, frc, out, aux, dout, dt):
+        val = aux["val"]
+        B = max([np.size(v) for v in val if v is not None] + [1])
+        adj = [np.zeros(B, dt) for _ in val]
+        for o, s in zip(prog["outputs"], prog["out"]):
+            adj[s] = adj[s] + dout[o]
+        one, half = dt.type(1), dt.type(0.5)
+        with np.errstate(all="ignore"):
+            for i in reversed(range(len(prog["code"]))):
+                op, a, b, c = prog["code"][i]
+                x, y, r, g = val[a], val[b], val[28 + i], adj[28 + i]
+                k = PROG_OPS[op]
+                if k == "add": adj[a] = adj[a] + g; adj[b] = adj[b] + g
+                elif k == "sub": adj[a] = adj[a] + g; adj[b] = adj[b] - g
+                elif k == "mul": adj[a] = adj[a] + g * y; adj[b] = adj[b] + g * x
+                elif k == "div": adj[a] = adj[a] + g / y; adj[b] = adj[b] - g * r / y
+                elif k == "neg": adj[a] = adj[a] - g
+                elif k == "exp": adj[a] = adj[a] + g * r
+                elif k == "log": adj[a] = adj[a] + g / x
+                elif k == "pow": adj[a] = adj[a] + g * y * r / x; adj[b] = adj[b] + g * r * np.log(x)
+                elif k == "sqrt": adj[a] = adj[a] + g * half / r
+                elif k == "tanh": adj[a] = adj[a] + g * (one - r * r)
+                elif k == "sigmoid": adj[a] = adj[a] + g * r * (one - r)
+                elif k == "max": adj[a] = adj[a] + np.where(x >= y, g, 0); adj[b] = adj[b] + np.where(x >= y, 0, g)
+                elif k == "min": adj[a] = adj[a] + np.where(x <= y, g, 0); adj[b] = adj[b] + np.where(x <= y, 0, g)
+                elif k == "abs": adj[a] = adj[a] + g * np.sign(x)
+                elif k == "sin": adj[a] = adj[a] + g * np.cos(x)
+                elif k == "cos": adj[a] = adj[a] - g * np.sin(x)
+                elif k == "select": adj[b] = adj[b] + np.where(x > 0, g, 0); adj[c] = adj[c] + np.where(x > 0, 0, g)
+        return {n: adj[j].astype(dt) for j, n in enumerate(prog["params"])}
+
+    MECH[name] = (mm, fwd, vjp)
+    return mm
+
 # ----------------------------------------------------------------------------------------------
 # model spec  (mirror of constructHybridModel's arguments, GenericHybridModel.jl:89-140)
 # ----------------------------------------------------------------------------------------------

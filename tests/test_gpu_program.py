@@ -1,0 +1,141 @@
+"""-m gpu: user closures as device programs (EH_MECH_PROGRAM) through the C ABI against the oracle, which runs the closure
+itself on NumPy arrays and differentiates the recorded tape (oracle/hybrid_oracle.py `program_mech`).  Tolerance 1e-5."""
+import numpy as np
+import pytest
+
+import easyhybrid_jl_amd as eh
+from oracle import hybrid_oracle as ho
+from tests import closures as cl
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _spec(name, fn, table, forc, targets, neural, glob, hidden, n_pred=3, act="tanh", scale=True):
+    util.register_closure(name, fn, list(table), forc, targets)
+    return ho.HybridSpec(n_pred, list(hidden), name, dict(table), list(neural), list(glob), list(targets), act, scale)
+
+
+def _data(spec, forc_ranges, B, seed, nan_frac=0.1, noise=0.05):
+    """Predictors U(-1,1); forcings in their ranges; targets = the model at a perturbed theta + noise, NaN-masked."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (spec.n_pred, B)).astype(np.float32)
+    f = {k: rng.uniform(lo, hi, B).astype(np.float32) for k, (lo, hi) in forc_ranges.items()}
+    theta = ho.init_theta(spec, seed + 1, np.float32)
+    truth = ho.forward(spec, ho.init_theta(spec, seed + 2, np.float32).astype(np.float64), X, f)
+    y = {}
+    for t in spec.targets:
+        v = truth[t] * (1.0 + noise * rng.normal(size=B))
+        v[rng.uniform(size=B) < nan_frac] = np.nan
+        y[t] = v.astype(np.float32)
+    return theta, X, f, y
+
+
+def _check(spec, theta, X, f, y, **kw):
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad(**kw)
+    if "first" in kw:
+        sl = slice(kw["first"], kw["first"] + kw["count"])
+        X, f, y = X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}
+    l0, g0, nv0 = ho.loss_and_grad(spec, np.asarray(theta, np.float64), X, f, y)
+    assert nv == sum(nv0)
+    assert abs(loss - l0) <= TOL * abs(l0)
+    assert util.relerr(grad, g0) <= TOL
+    return eng
+
+
+@pytest.mark.parametrize("hidden", [(16, 16), (64, 64), (128, 128), (24,), (32, 16, 8)])
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_hand_written_rbq10_closure_equals_registry_model(hidden, act):
+    spec, theta, X, f, y = util.rbq10_case(700, act, True, 0.1, hidden=hidden)
+    util.register_closure("rbq10_closure", cl.rbq10_closure, list(cl.RBQ10_TABLE), ["ta"], ["reco"])
+    spec_c = ho.HybridSpec(spec.n_pred, list(spec.hidden), "rbq10_closure", dict(spec.parameters), list(spec.neural), list(spec.glob),
+                           ["reco"], act, True)
+    eng_c = util.load_engine(spec_c, theta, X, f, y)
+    eng_r = util.load_engine(spec, theta, X, f, y)
+    lc, gc, nc = eng_c.loss_and_grad()
+    lr, gr, nr = eng_r.loss_and_grad()
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert nc == nr and abs(lc - l0) <= TOL * abs(l0) and util.relerr(gc, g0) <= TOL
+    assert abs(lc - lr) <= 2e-6 * abs(lr) and util.relerr(gc, gr) <= 4e-6        # the two device paths against each other
+    eng_c.close(); eng_r.close()
+
+
+@pytest.mark.parametrize("targets", [["nee", "gpp", "reco"], ["nee"], ["gpp", "nee"]])
+@pytest.mark.parametrize("hidden", [(32, 32), (128,)])
+def test_three_output_flux_closure(targets, hidden):
+    spec = _spec("flux_closure", cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], targets, ["alpha", "rref", "gmax"], ["e0", "k"], hidden, n_pred=5)
+    mm = ho.MECH["flux_closure"][0]
+    theta, X, f, y = _data(spec, {k: r for k, r in dict(sw=(0, 800), ta=(-5, 30), vpd=(0, 30)).items() if k in mm.forcings}, 1300, 3)
+    eng = _check(spec, theta, X, f, y)
+    _check(spec, theta, X, f, y, first=130, count=1001).close()
+    out = eng.forward(0)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    for t in targets:
+        assert util.relerr(out[t], ref[t]) <= TOL
+    for p in ("alpha", "rref", "gmax", "e0", "k"):
+        assert util.relerr(out["parameters"][p], np.broadcast_to(ref["parameters"][p], (1300,))) <= TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("neural,glob,scale", [(["a", "b", "c", "d"], [], True), (["a"], ["b", "c"], True), (["b", "d"], ["a"], False)])
+def test_every_operation_closure(neural, glob, scale):
+    spec = _spec("allops_closure", cl.allops_closure, cl.ALLOPS_TABLE, ["u", "v"], ["y", "z"], neural, glob, (24, 24), n_pred=4, act="swish", scale=scale)
+    theta, X, f, y = _data(spec, dict(u=(-1, 1), v=(-1, 1)), 900, 11)
+    if not scale:                       # unscaled network outputs: keep c + 1.5 > 0 etc. by shrinking the last layer
+        theta = theta.copy(); theta[:spec.n_nn] *= 0.3
+    _check(spec, theta, X, f, y).close()
+
+
+def test_closure_training_trajectory_eval_and_epoch_driver():
+    for fused, targets in ((0, ["nee", "reco"]), (1, ["nee"])):            # (the one-kernel-per-step mode is single-target)
+        spec = _spec("flux_closure", cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], targets, ["alpha", "rref"], ["gmax", "e0", "k"], (16, 16), n_pred=2)
+        theta, X, f, y = _data(spec, dict(sw=(0, 800), ta=(-5, 30), vpd=(0, 30)), 2048, 21)
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.opt_init("Adam", 0.01)
+        eng.set_option("fused_update", fused)
+        batches = [(i * 256, 256) for i in range(8)]
+        losses = [eng.train_step(a, b) for a, b in batches]
+        th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+        assert np.allclose(losses, l_ref, rtol=1e-4)
+        assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+        eng.close()
+    spec = _spec("flux_closure", cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], ["nee", "reco"], ["alpha", "rref"], ["gmax", "e0", "k"], (16, 16), n_pred=2)
+    theta, X, f, y = _data(spec, dict(sw=(0, 800), ta=(-5, 30), vpd=(0, 30)), 2048, 21)
+    eng = util.load_engine(spec, theta, X, f, y, split=1)
+    metrics, pred = eng.eval(1, predictions=True)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    for t, name in enumerate(spec.targets):
+        yy = y[name].astype(np.float64); mask = ~np.isnan(yy)
+        assert metrics[t]["n"] == mask.sum()
+        for k in ("mse", "r2", "pearson", "kge"):
+            assert metrics[t][k] == pytest.approx(ho.loss_fn(ref[name], yy, mask, k), rel=2e-5, abs=2e-6), (name, k)
+        assert util.relerr(pred[name], ref[name]) <= TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["mae", "nseLoss", "kgeLoss"])
+def test_closure_with_other_training_losses(kind):
+    spec = _spec("rbq10_closure", cl.rbq10_closure, cl.RBQ10_TABLE, ["ta"], ["reco"], ["rb"], ["Q10"], (16, 16), n_pred=2)
+    _, theta, X, f, y = util.rbq10_case(1500, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind)
+    tol = 1e-4 if kind == "kgeLoss" else TOL
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=tol) and util.relerr(grad, g0) <= tol
+    eng.close()
+
+
+def test_front_door_train_with_a_closure():
+    cols = eh.synthetic.make_synth_rbq10(8192, 42)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], cl.rbq10_closure, dict(cl.RBQ10_TABLE), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=8, batchsize=512, opt=eh.Adam(0.01), random_seed=3)
+    reg = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(cl.RBQ10_TABLE), ["rb"], ["Q10"],
+                                  hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    ref = eh.train(reg, cols, nepochs=8, batchsize=512, opt=eh.Adam(0.01), random_seed=3)
+    h, hr = out.train_history, ref.train_history
+    assert h[-1]["mse"]["sum"] < 0.5 * h[0]["mse"]["sum"]
+    assert h[-1]["mse"]["sum"] == pytest.approx(hr[-1]["mse"]["sum"], rel=2e-3)        # same model, two device paths, 128 Adam steps apart

@@ -25,8 +25,10 @@ def test_constructor_mirrors_reference_struct():
 def test_constructor_errors_match_reference():
     with pytest.raises(AssertionError, match="neural_param_names"):           # GenericHybridModel.jl:110 / test_generic_hybrid_model.jl:569-586
         eh.constructHybridModel(["a"], ["ta"], ["reco"], eh.RbQ10, PARAMS, ["nope"], ["Q10"])
-    with pytest.raises(NotImplementedError, match="closure"):
+    with pytest.raises(TypeError, match="dict"):                              # an unregistered callable is recorded as a device program (tests/test_program.py)
         eh.constructHybridModel(["a"], ["ta"], ["reco"], lambda **kw: None, PARAMS, ["rb"], ["Q10"])
+    with pytest.raises(NotImplementedError, match="registry"):
+        eh.constructHybridModel(["a"], ["ta"], ["reco"], "NoSuchModel", PARAMS, ["rb"], ["Q10"])
     assert model(input_batchnorm=True).to_desc().input_batchnorm == 1
     with pytest.raises(ValueError, match="forcing"):
         eh.constructHybridModel(["a"], ["temp"], ["reco"], eh.RbQ10, PARAMS, ["rb"], ["Q10"])

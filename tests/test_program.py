@@ -1,0 +1,142 @@
+"""Mechanistic closures as device programs (EH_MECH_PROGRAM): recording (easyhybrid.jl_amd/program.py), the descriptor, and the
+oracle's side of it -- the program's forward values against the closure itself on NumPy arrays, its reverse sweep against
+central differences of the closure, and the hand-written RbQ10 closure against the registry model.  No GPU."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import easyhybrid_jl_amd as eh
+from easyhybrid_jl_amd import _lib as L
+from easyhybrid_jl_amd import program as P
+from oracle import hybrid_oracle as ho
+from tests import closures as cl
+from tests import util
+
+
+def _inputs(names, B, seed, lo=-1.0, hi=1.0):
+    rng = np.random.default_rng(seed)
+    return {n: rng.uniform(lo, hi, B) for n in names}
+
+
+def test_rbq10_closure_records_four_operations():
+    pg = P.trace(cl.rbq10_closure, ["rb", "Q10"], ["ta"], ["reco"])
+    assert [P.OP_NAMES[c[0]] for c in pg.code] == ["sub", "mul", "pow", "mul"]
+    assert pg.forcings == ("ta",) and pg.outputs == ("reco",) and pg.out == (P.SLOT_INSTR + 3,)
+    assert pg.consts == (float(np.float32(0.1)), 15.0)
+    w = pg.words()[0]
+    assert (w & 255, (w >> 8) & 255, (w >> 16) & 255, w >> 24) == (1, P.SLOT_FORC, P.SLOT_CONST + 1, 0)
+
+
+def test_only_what_the_targets_need_is_recorded():
+    pg3 = P.trace(cl.flux_closure, list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee", "gpp", "reco"])
+    pg1 = P.trace(cl.flux_closure, list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["reco"])
+    assert pg1.forcings == ("ta",) and len(pg1.code) < len(pg3.code) and len(pg3.out) == 3
+    # common subexpressions are shared: alpha * sw appears once
+    muls = [c for c in pg3.code if P.OP_NAMES[c[0]] == "mul" and set(c[1:3]) == {P.SLOT_PAR + 0, P.SLOT_FORC + pg3.forcings.index("sw")}]
+    assert len(muls) == 1
+
+
+@pytest.mark.parametrize("fn,table,forc,targets", [
+    (cl.rbq10_closure, cl.RBQ10_TABLE, ["ta"], ["reco"]),
+    (cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], ["nee", "gpp", "reco"]),
+    (cl.allops_closure, cl.ALLOPS_TABLE, ["u", "v"], ["y", "z"]),
+])
+def test_program_forward_equals_closure_and_vjp_equals_differences(fn, table, forc, targets):
+    B = 257
+    prog = P.trace(fn, list(table), forc, targets).as_dict()
+    dt = np.dtype(np.float64)
+    rng = np.random.default_rng(5)
+    par = {n: rng.uniform(lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo), B) for n, (_, lo, hi) in table.items()}
+    frc = _inputs(forc, B, 6, 0.0, 30.0) if fn is not cl.allops_closure else _inputs(forc, B, 6)
+    val = ho.program_values(prog, par, frc, dt)
+    direct = fn(**frc, **par)
+    for o, s in zip(prog["outputs"], prog["out"]):
+        # (the program holds its constants in fp32, as a Float32 closure of the reference does -- 0.1f0 in RbQ10; allops_closure only uses
+        # constants that fp32 represents exactly and must agree to rounding)
+        assert util.relerr(val[s], direct[o]) <= (1e-13 if fn is cl.allops_closure else 1e-6), o
+    name = "t_" + fn.__name__
+    ho.program_mech(name, prog, None)
+    _, fwd, vjp = ho.MECH[name]
+    out, aux = fwd(par, frc, dt)
+    dout = {o: rng.normal(size=B) for o in prog["outputs"]}
+    dpar = vjp(par, frc, out, aux, dout, dt)
+    for n in table:
+        h = 1e-6 * max(1.0, float(np.max(np.abs(par[n]))))
+        up, dn = dict(par), dict(par)
+        up[n] = par[n] + h; dn[n] = par[n] - h
+        ou, _ = fwd(up, frc, dt); od, _ = fwd(dn, frc, dt)
+        fd = sum(dout[o] * (ou[o] - od[o]) / (2 * h) for o in prog["outputs"])
+        # (kinks of max / min / abs / where: a sample within h of one is skipped)
+        ok = np.abs(dpar[n] - fd) <= 1e-5 * (1.0 + np.abs(fd))
+        assert ok.mean() > 0.98, (n, float(np.max(np.abs(dpar[n] - fd))))
+
+
+def test_closure_rbq10_equals_registry_rbq10_in_the_oracle():
+    spec, theta, X, f, y = util.rbq10_case(300, "tanh", True, 0.1)
+    util.register_closure("rbq10_closure", cl.rbq10_closure, list(cl.RBQ10_TABLE), ["ta"], ["reco"])
+    spec_c = ho.HybridSpec(spec.n_pred, list(spec.hidden), "rbq10_closure", dict(spec.parameters), list(spec.neural), list(spec.glob),
+                           ["reco"], spec.activation, spec.scale_nn_outputs)
+    l0, g0, _ = ho.loss_and_grad(spec, np.asarray(theta, np.float64), X, f, y)
+    l1, g1, _ = ho.loss_and_grad(spec_c, np.asarray(theta, np.float64), X, f, y)
+    assert abs(l0 - l1) <= 1e-7 * abs(l0)                 # 0.1f0 as an fp32 constant vs the fp64 literal
+    assert util.relerr(g1, g0) <= 1e-6
+
+
+def test_descriptor_carries_the_program():
+    m = eh.constructHybridModel(["x0", "x1"], ["ta"], ["reco"], cl.rbq10_closure, dict(cl.RBQ10_TABLE), ["rb"], ["Q10"],
+                                hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    d = m.to_desc()
+    assert d.struct_size == ctypes.sizeof(L.ModelDesc)
+    assert d.mech == L.EH_MECH_PROGRAM and d.n_params == 2 and d.prog_len == 4 and d.prog_n_forc == 1 and d.prog_n_out == 1
+    assert d.prog_out[0] == 31 and list(d.prog_code[:4]) == m.mechanistic_model.program.words()
+    assert m.mechanistic_model.name == "rbq10_closure"
+
+
+def test_what_cannot_be_recorded_is_refused():
+    def branches(*, ta, rb):
+        return dict(y=rb if ta > 0 else -rb)
+    def couples_samples(*, ta, rb):
+        return dict(y=rb * ta / np.sum(ta))
+    def too_long(*, ta, rb):
+        y = rb
+        for i in range(70):
+            y = y * ta + float(i)
+        return dict(y=y)
+    def negative_base(*, ta, rb):
+        return dict(y=(-2.0) ** ta * rb)
+    def not_a_dict(*, ta, rb):
+        return rb * ta
+    for fn, exc in [(branches, NotImplementedError), (couples_samples, NotImplementedError), (too_long, NotImplementedError),
+                    (negative_base, ValueError), (not_a_dict, TypeError)]:
+        with pytest.raises(exc):
+            P.trace(fn, ["rb"], ["ta"], ["y"])
+    with pytest.raises(ValueError):
+        P.trace(cl.rbq10_closure, ["rb", "Q10"], ["ta"], ["gpp"])           # not an output
+    with pytest.raises(NotImplementedError):
+        P.trace(cl.rbq10_closure, [f"p{i}" for i in range(9)], ["ta"], ["reco"])
+
+
+def test_integer_powers_are_products_and_constants_fold():
+    def f(*, x, a):
+        return dict(y=a * x ** 3 + x ** -2 + (2.0 * 3.0 + np.exp(0.0)) * x ** 0.5 + x ** 0)
+    pg = P.trace(f, ["a"], ["x"], ["y"])
+    names = [P.OP_NAMES[c[0]] for c in pg.code]
+    assert "pow" not in names and names.count("sqrt") == 1 and 7.0 in pg.consts and 1.0 in pg.consts
+
+
+def test_bad_programs_are_refused_by_the_library_before_any_device_work():
+    """eh_create checks every operand slot against the instruction's position: the kernel indexes a per-lane array with them."""
+    m = eh.constructHybridModel(["x0", "x1"], ["ta"], ["reco"], cl.rbq10_closure, dict(cl.RBQ10_TABLE), ["rb"], ["Q10"], hidden_layers=[16])
+    for edit, exc, msg in [
+            (lambda d: d.prog_code.__setitem__(1, 2 | 12 << 8 | 40 << 16), ValueError, "undefined"),       # operand = a later instruction
+            (lambda d: d.prog_code.__setitem__(0, 99), NotImplementedError, "opcode"),
+            (lambda d: d.prog_out.__setitem__(0, 200), ValueError, "output"),
+            (lambda d: setattr(d, "prog_len", 65), NotImplementedError, "instructions"),
+            (lambda d: d.prog_code.__setitem__(0, 1 | 9 << 8 | 13 << 16), ValueError, "undefined"),          # a forcing the program does not declare
+            (lambda d: d.prog_code.__setitem__(0, 1 | 2 << 8 | 13 << 16), ValueError, "undefined"),          # a parameter beyond n_params
+            (lambda d: d.prog_code.__setitem__(0, 5 | 8 << 8 | 13 << 16), ValueError, "unused operand")]:
+        d = m.to_desc()
+        edit(d)
+        with pytest.raises(exc, match=msg):
+            eh.HybridEngine(d, 2, ["reco"], ["rb", "Q10"])

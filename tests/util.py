@@ -8,6 +8,15 @@ MECH_NAME = {"rbq10": "RbQ10", "expo": "Expo_resp_model", "linear": "LinearHM", 
              "rs_components": "Rs_components", "fluxpart": "FluxPartModelQ10"}
 
 
+def register_closure(name, fn, params, forcings, targets):
+    """A user closure as mechanistic model `name` on both sides: the package records it when the model is constructed
+    (MECH_NAME[name] = the callable); the oracle gets the recorded program as plain data plus the closure itself."""
+    from easyhybrid_jl_amd.program import trace
+    prog = trace(fn, list(params), list(forcings), list(targets))
+    MECH_NAME[name] = fn
+    return ho.program_mech(name, prog.as_dict(), fn)
+
+
 def model_from_spec(spec: ho.HybridSpec):
     mm = ho.MECH[spec.mech][0]
     if spec.nets is not None:
