@@ -45,6 +45,13 @@ struct EhModelDesc
     n_nets::Int32                                   # 0 = SingleNNHybridModel
     net_n_predictors::NTuple{8, Int32}
     net_hidden::NTuple{32, Int32}                   # [8 nets][4 layers], row-major like the C array
+    prog_len::Int32                                 # EH_MECH_PROGRAM only (a recorded closure, see `record_program`)
+    prog_n_const::Int32
+    prog_n_forc::Int32
+    prog_n_out::Int32
+    prog_out::NTuple{3, Int32}
+    prog_code::NTuple{64, UInt32}
+    prog_const::NTuple{16, Float32}
 end
 
 struct EhTargetMetrics
@@ -55,12 +62,19 @@ end
 # ------------------------------------------------------------------------------------------------
 # mechanistic registry: the Julia functions of the reference, tagged with the device model id
 # ------------------------------------------------------------------------------------------------
+struct Program                       # include/easyhybrid_hip.h `eh_prog_op`: slots 0..7 params, 8..11 forcings, 12..27 constants, 28+i instruction i
+    consts::Vector{Float32}
+    code::Vector{UInt32}             # op | a << 8 | b << 16 | c << 24
+    out::Vector{Int32}
+end
 struct MechSpec
     id::Int32
     params::Vector{Symbol}
     forcings::Vector{Symbol}
     outputs::Vector{Symbol}
+    program::Union{Nothing, Program}
 end
+MechSpec(id, params, forcings, outputs) = MechSpec(id, params, forcings, outputs, nothing)
 
 RbQ10(; ta, Q10, rb, tref = 15.0f0) = (; reco = rb .* Q10 .^ (0.1f0 .* (ta .- tref)), Q10, rb)       # test/test_split_data_train.jl:36-39
 Expo_resp_model(; T, Resp0, k) = (; Resp_obs = Resp0 .* exp.(k .* T), Resp0, k)                      # projects/ExpoHybrid/ExpoHybridEstim.jl:69-85
@@ -87,6 +101,105 @@ const MECH = IdDict{Any, MechSpec}(
 "Register another Julia function under one of the device model ids (see include/easyhybrid_hip.h)."
 register_mechanistic!(f, spec::MechSpec) = (MECH[f] = spec)
 
+# ------------------------------------------------------------------------------------------------
+# any other closure `f(; forcing..., params...) -> NamedTuple` (GenericHybridModel.jl:420-425): called ONCE with tracer
+# numbers, which record its elementwise arithmetic as a straight-line program; the step kernel evaluates the program per
+# sample and runs the reverse sweep over the same tape (what Zygote derives from the closure).  Broadcast dots work as
+# they are (a tracer is a scalar).  Cross-sample operations (sum, mean, cumsum) and `x > 0 ? a : b` cannot be recorded --
+# use `ifelse.(x .> 0, a, b)`.
+# ------------------------------------------------------------------------------------------------
+const OPS = Dict(:add => 0, :sub => 1, :mul => 2, :div => 3, :neg => 4, :exp => 5, :log => 6, :pow => 7, :sqrt => 8, :tanh => 9,
+                 :sigmoid => 10, :max => 11, :min => 12, :abs => 13, :sin => 14, :cos => 15, :select => 16, :gt => 17)
+struct Tape
+    nodes::Vector{Tuple}             # (:par, j) | (:frc, name) | (:const, value) | (op, a, b, c) with node ids
+    index::Dict{Tuple, Int}
+end
+Tape() = Tape(Tuple[], Dict{Tuple, Int}())
+node!(t::Tape, k::Tuple) = get!(() -> (push!(t.nodes, k); length(t.nodes)), t.index, k)
+struct Tr <: Real                    # a traced per-sample value
+    tape::Tape
+    id::Int
+end
+struct TrBool                        # a traced comparison: only `ifelse` takes it
+    v::Tr
+end
+lift(t::Tape, x::Tr) = x
+lift(t::Tape, x::Real) = (isfinite(x) || throw(ArgumentError("constant $x in a mechanistic program")); Tr(t, node!(t, (:const, Float32(x)))))
+rec(op::Symbol, a::Tr, rest...) = Tr(a.tape, node!(a.tape, (op, a.id, (lift(a.tape, r).id for r in rest)...)))
+rec(op::Symbol, a::Real, b::Tr, rest...) = rec(op, lift(b.tape, a), b, rest...)
+for (f, op) in ((:+, :add), (:-, :sub), (:*, :mul), (:/, :div), (:max, :max), (:min, :min))
+    @eval Base.$f(a::Tr, b::Tr) = rec($(QuoteNode(op)), a, b)
+    @eval Base.$f(a::Tr, b::Real) = rec($(QuoteNode(op)), a, b)
+    @eval Base.$f(a::Real, b::Tr) = rec($(QuoteNode(op)), a, b)
+end
+for (f, op) in ((:-, :neg), (:exp, :exp), (:log, :log), (:sqrt, :sqrt), (:tanh, :tanh), (:abs, :abs), (:sin, :sin), (:cos, :cos))
+    @eval Base.$f(a::Tr) = rec($(QuoteNode(op)), a)
+end
+Base.:+(a::Tr) = a
+Base.inv(a::Tr) = 1.0f0 / a
+Base.abs2(a::Tr) = a * a
+Base.exp2(a::Tr) = 2.0f0^a
+Base.log2(a::Tr) = log(a) * Float32(1 / log(2))
+Base.log10(a::Tr) = log(a) * Float32(1 / log(10))
+sigmoid(a::Tr) = rec(:sigmoid, a)
+Base.:^(a::Tr, b::Tr) = rec(:pow, a, b)                                   # base > 0
+function Base.:^(a::Tr, n::Integer)                                       # products: valid for negative bases too
+    n == 0 && return lift(a.tape, 1.0f0)
+    r = Base.power_by_squaring(a, abs(n))
+    return n > 0 ? r : inv(r)
+end
+Base.:^(a::Tr, b::Real) = isinteger(b) && abs(b) <= 8 ? a^Int(b) : (b == 0.5 ? sqrt(a) : rec(:pow, a, b))
+Base.:^(a::Real, b::Tr) = (a > 0 || throw(ArgumentError("power with the non-positive constant base $a")); rec(:pow, a, b))
+Base.:>(a::Tr, b::Tr) = TrBool(rec(:gt, a, b));  Base.:>(a::Tr, b::Real) = TrBool(rec(:gt, a, b));  Base.:>(a::Real, b::Tr) = TrBool(rec(:gt, a, b))
+Base.:<(a::Tr, b::Tr) = b > a;  Base.:<(a::Tr, b::Real) = b > a;  Base.:<(a::Real, b::Tr) = b > a
+Base.:>=(a::Union{Tr, Real}, b::Tr) = TrBool(1.0f0 - (b > a).v);  Base.:>=(a::Tr, b::Real) = TrBool(1.0f0 - (b > a).v)
+Base.:<=(a::Union{Tr, Real}, b::Tr) = b >= a;  Base.:<=(a::Tr, b::Real) = b >= a
+Base.ifelse(c::TrBool, a::Union{Tr, Real}, b::Union{Tr, Real}) = rec(:select, c.v, a, b)
+Base.clamp(x::Tr, lo::Real, hi::Real) = min(max(x, lo), hi)
+
+"Record `f(; forcing..., params...)` and encode what the `targets` outputs depend on."
+function record_program(f, params::Vector{Symbol}, forcing::Vector{Symbol}, targets::Vector{Symbol})
+    1 <= length(params) <= EH_MAX_PARAMS || throw(ArgumentError("a mechanistic program takes 1..$EH_MAX_PARAMS parameters"))
+    t = Tape()
+    kw = merge(NamedTuple{Tuple(forcing)}(Tuple(Tr(t, node!(t, (:frc, n))) for n in forcing)),
+               NamedTuple{Tuple(params)}(Tuple(Tr(t, node!(t, (:par, j - 1))) for j in eachindex(params))))
+    res = f(; kw...)
+    outs = unique(targets)
+    all(o -> haskey(res, o), outs) || throw(ArgumentError("targets $targets are not all outputs of the mechanistic model $(keys(res))"))
+    length(outs) <= 3 || throw(ArgumentError("$(length(outs)) distinct target outputs (device limit 3)"))
+    used = Symbol[]; consts = Float32[]; code = UInt32[]; slot = Dict{Int, Int}()
+    function emit(id::Int)
+        haskey(slot, id) && return slot[id]
+        n = t.nodes[id]
+        s = if n[1] === :par
+            n[2]
+        elseif n[1] === :frc
+            n[2] in used || push!(used, n[2]); 8 + findfirst(==(n[2]), used) - 1
+        elseif n[1] === :const
+            n[2] in consts || push!(consts, n[2]); 12 + findfirst(==(n[2]), consts) - 1
+        else
+            a = [emit(i) for i in n[2:end]]; append!(a, zeros(Int, 3 - length(a)))
+            push!(code, UInt32(OPS[n[1]]) | UInt32(a[1]) << 8 | UInt32(a[2]) << 16 | UInt32(a[3]) << 24)
+            28 + length(code) - 1
+        end
+        return slot[id] = s
+    end
+    out = Int32[]
+    for o in outs
+        v = res[o]
+        v isa Tr || (v = lift(t, v))
+        s = emit(v.id)
+        if s < 28                         # an output that is a bare input: x + 0 gives it an instruction
+            z = emit(lift(t, 0.0f0).id)
+            push!(code, UInt32(OPS[:add]) | UInt32(s) << 8 | UInt32(z) << 16); s = 28 + length(code) - 1
+        end
+        push!(out, s)
+    end
+    length(used) <= EH_MAX_FORC && length(consts) <= 16 && length(code) <= 64 ||
+        throw(ArgumentError("program of $(length(code)) operations / $(length(consts)) constants / $(length(used)) forcings exceeds the device limits 64 / 16 / $EH_MAX_FORC"))
+    return MechSpec(6, params, used, outs, Program(consts, code, out))
+end
+
 const ACT = Dict(:tanh => 0, :sigmoid => 1, :relu => 2, :swish => 3, :identity => 4)
 
 # ------------------------------------------------------------------------------------------------
@@ -111,9 +224,9 @@ const HybridModel = SingleNNHybridModel
 function constructHybridModel(predictors::Vector{Symbol}, forcing, targets, mechanistic_model, parameters,
         neural_param_names, global_param_names; hidden_layers::Vector{Int} = [32, 32], activation = tanh,
         scale_nn_outputs = false, input_batchnorm = false, start_from_default = true, kwargs...)
-    haskey(MECH, mechanistic_model) || throw(ArgumentError("mechanistic_model is not in the device registry; " *
-        "an arbitrary closure cannot run inside the HIP kernel (no CPU fallback)"))
     all_names = collect(keys(parameters))
+    # a closure outside the registry is recorded as a device program (no CPU fallback either way)
+    haskey(MECH, mechanistic_model) || (MECH[mechanistic_model] = record_program(mechanistic_model, all_names, collect(Symbol, forcing), collect(Symbol, targets)))
     @assert all(n in all_names for n in neural_param_names) "neural_param_names ⊆ param_names"
     dims = [length(predictors); hidden_layers; length(neural_param_names)]
     NN = [(dims[i + 1], dims[i]) for i in 1:(length(dims) - 1)]
@@ -129,6 +242,7 @@ pad(v, n, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), n)
 
 function descriptor(m::SingleNNHybridModel; device::Integer = 0)
     ms = MECH[m.mechanistic_model]
+    pg = ms.program
     kind = Int32[]; index = Int32[]; def = Float32[]; lo = Float32[]; hi = Float32[]
     for p in ms.params
         if p in m.neural_param_names
@@ -147,7 +261,10 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
         length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32),
-        Int32(0), pad(Int32[], 8, Int32), pad(Int32[], 32, Int32))       # MultiNN form: fill n_nets / net_* (see include/easyhybrid_hip.h)
+        Int32(0), pad(Int32[], 8, Int32), pad(Int32[], 32, Int32),       # MultiNN form: fill n_nets / net_* (see include/easyhybrid_hip.h)
+        (pg === nothing ? (Int32(0), Int32(0), Int32(0), Int32(0), pad(Int32[], 3, Int32), pad(UInt32[], 64, UInt32), pad(Float32[], 16, Float32)) :
+         (Int32(length(pg.code)), Int32(length(pg.consts)), Int32(length(ms.forcings)), Int32(length(pg.out)), pad(pg.out, 3, Int32),
+          pad(pg.code, 64, UInt32), pad(pg.consts, 16, Float32)))...)
 end
 
 # ------------------------------------------------------------------------------------------------

@@ -67,7 +67,7 @@ class _Graph:
 
 
 def _is_num(x):
-    return isinstance(x, (int, float, np.integer, np.floating)) or (isinstance(x, np.ndarray) and x.ndim == 0)
+    return isinstance(x, (bool, np.bool_, int, float, np.integer, np.floating)) or (isinstance(x, np.ndarray) and x.ndim == 0)
 
 
 class Sym:

