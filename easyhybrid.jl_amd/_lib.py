@@ -90,6 +90,7 @@ SIGNATURES = {
     "eh_profile_enable": (C.c_int32, [_H, C.c_int32]),
     "eh_profile_read": (C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "eh_profile_samples": (C.c_int32, [_H, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
+    "eh_jit_status": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_char_p, C.c_int64]),
     "eh_debug_stamps": (C.c_int32, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "eh_set_option": (C.c_int32, [_H, C.c_char_p, C.c_int64]),
 }

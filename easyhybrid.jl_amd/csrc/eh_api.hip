@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "eh_arch.hpp"
+#include "eh_jit.hpp"
 #include "eh_wide.hpp"
 
 // --------------------------------------------------------------------------------------------
@@ -461,6 +462,11 @@ struct eh_handle_s {
     bool perm_valid = false;
     int fast_user = 3;              // what the fast_paths option allows (default: all)
     unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
+    // EH_MECH_PROGRAM: kernels compiled at run time around the program (eh_jit.hpp), one entry per (kernel family, variant) used
+    struct JitEntry { const EhArchInfo* arch; int variant; bool ok; EhJitKernel k; };
+    std::vector<JitEntry> jit;
+    bool jit_on = true;             // "jit" option / EH_JIT=0: 0 = the interpreting kernels built ahead of time
+    std::string jit_log;
     float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
     int n_weights = 0;
     struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
@@ -668,6 +674,30 @@ static bool arch_fits(const EhArchInfo* A, int need) {
     return true;
 }
 
+// Launches the step kernel of the handle's (family, variant): for a recorded closure the run-time compiled kernel (built on
+// first use; a failed build or launch switches the handle to the interpreting kernels for good), else the table entry.
+static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
+    if (h->net.mech == EH_MECH_PROGRAM && h->jit_on && mode != EH_MODE_TRAIN_P2P) {
+        eh_handle_s::JitEntry* je = nullptr;
+        for (auto& e : h->jit) if (e.arch == h->arch && e.variant == h->variant) je = &e;
+        if (!je) {
+            h->jit.push_back({h->arch, h->variant, false, EhJitKernel{}});
+            je = &h->jit.back();
+            std::string log;
+            je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, &je->k, &log);
+            if (!je->ok) h->jit_log = log;
+        }
+        if (je->ok) {
+            const hipError_t e = eh_jit_launch(&je->k, mode, grid, h->stream, &h->net, a);
+            if (e == hipSuccess) return e;
+            (void)hipGetLastError();
+            je->ok = false;
+            h->jit_log = std::string("launch of the run-time compiled kernel failed: ") + hipGetErrorString(e);
+        }
+    }
+    return h->arch->var[h->variant].launch(mode, h->act, KFAST(h), grid, h->stream, &h->net, a);
+}
+
 extern "C" {
 
 int32_t eh_version(void) { return EH_ABI_VERSION; }
@@ -846,6 +876,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
+    if (const char* ej = getenv("EH_JIT")) h->jit_on = atoi(ej) != 0;
     if (d->mech == EH_MECH_PROGRAM) {
         std::vector<unsigned> pb(EH_PROG_HDR + EH_MAX_PROG, 0u);
         pb[0] = (unsigned)d->prog_len; pb[1] = (unsigned)d->prog_n_out;
@@ -925,6 +956,7 @@ int32_t eh_destroy(eh_handle* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& e : h->jit) eh_jit_release(&e.k);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
@@ -959,6 +991,19 @@ int32_t eh_synchronize(eh_handle* h) {
         unsigned c[3] = {0, 0, 0};
         HIPCHK(h, hipMemcpy(c, h->p2p_ctr, sizeof c, hipMemcpyDeviceToHost));
         if (c[1]) return fail(h, EH_EHIP, "eh_synchronize: a cross-GPU exchange ran into its 2 s deadline (a rank is missing or out of step); results are invalid");
+    }
+    return EH_OK;
+}
+
+int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes) {
+    if (!h || !n_compiled) return EH_EINVAL;
+    int n = 0;
+    for (auto& e : h->jit) n += e.ok ? 1 : 0;
+    *n_compiled = n;
+    if (log && log_bytes > 0) {
+        const size_t m = std::min((size_t)log_bytes - 1, h->jit_log.size());
+        memcpy(log, h->jit_log.data(), m);
+        log[m] = 0;
     }
     return EH_OK;
 }
@@ -1001,6 +1046,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
             const int fast = (value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
             if (fast != h->fast) { h->fast = fast; return build_maps(h, false); }
         }
+        return EH_OK;
+    }
+    if (!strcmp(name, "jit")) {              // recorded closures: 1 = kernels compiled at run time around the program (default), 0 = the interpreter
+        h->jit_on = value != 0;
         return EH_OK;
     }
     if (!strcmp(name, "row_split")) {        // A/B: the row-split kernel family (eh_wide.hpp) where both are built
@@ -1152,11 +1201,11 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
         if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
         const int egrid = count > 0 ? grid_for(h, count) : 1;
-        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, KFAST(h), egrid, h->stream, &h->net, &e));       // -> mean of yhat
+        HIPCHK(h, step_launch(h, EH_MODE_EVAL, egrid, &e));       // -> mean of yhat
         hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, sp.shift[0], h->inv_n);
         HIPCHK(h, hipGetLastError());
         e.inv_n = h->inv_n;                                                                                               // -> moments about it
-        HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, KFAST(h), egrid, h->stream, &h->net, &e));
+        HIPCHK(h, step_launch(h, EH_MODE_EVAL, egrid, &e));
         hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, net.loss, sp.shift[0], h->inv_n);
         HIPCHK(h, hipGetLastError());
     }
@@ -1172,7 +1221,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &a)) return rc;
     const int grid = grid_for(h, count);
     *grid_out = grid;
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, KFAST(h), grid, h->stream, &h->net, &a));
+    HIPCHK(h, step_launch(h, EH_MODE_TRAIN, grid, &a));
     return EH_OK;
 }
 
@@ -1198,7 +1247,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     a.p2p_seq = h->p2p_on ? ++h->p2p_seq : 0u;
     if (int rc = bn_prepare(h, sp, idx, first, count, true, &a)) return rc;
     const int grid = grid_for(h, count);
-    HIPCHK(h, h->arch->var[h->variant].launch(h->p2p_on ? EH_MODE_TRAIN_P2P : EH_MODE_TRAIN, h->act, KFAST(h), grid, h->stream, &h->net, &a));
+    HIPCHK(h, step_launch(h, h->p2p_on ? EH_MODE_TRAIN_P2P : EH_MODE_TRAIN, grid, &a));
     h->cur ^= 1; h->sc_sel ^= 1; h->gstep++;
     h->pending = true;
     h->pending_loss = loss_slot_for_this_step;
@@ -1306,7 +1355,7 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     const int grid = count > 0 ? grid_for(h, count) : 1;
-    HIPCHK(h, h->arch->var[h->variant].launch(EH_MODE_EVAL, h->act, KFAST(h), grid, h->stream, &h->net, &a));
+    HIPCHK(h, step_launch(h, EH_MODE_EVAL, grid, &a));
     std::vector<float> part((size_t)grid * a.n_acc);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

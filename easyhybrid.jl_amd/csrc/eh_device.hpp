@@ -23,8 +23,10 @@
 // carries the physical value and sigmoid slope of every global parameter (computed once per
 // step instead of once per thread).
 #pragma once
+#ifndef __HIPCC_RTC__      // (this header is also compiled at run time, by hiprtc, for the recorded closures: eh_jit.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "easyhybrid_hip.h"   // public enums and EH_MAX_* limits
 
@@ -369,6 +371,12 @@ __device__ __forceinline__ void eh_prog_reverse(const unsigned* __restrict__ pro
         adj[ic] += gc;
     }
 }
+
+// The same program as generated straight-line code: eh_jit.hip writes eh_jit_fwd / eh_jit_rev (every slot a named value, so
+// the tape lives in registers) and compiles this header with hiprtc when a model with a recorded closure is created.
+#ifdef EH_JIT_MECH
+#include "eh_jit_mech.inc"
+#endif
 
 // outputs 1.. of the multi-output models and their Jacobian rows (only FLUXPART: GPP, RECO)
 __device__ __forceinline__ void eh_mech_extra(int mech, const float* par, const float* frc, float* yx, float (*Jx)[3]) {
@@ -943,6 +951,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
             // free at this point and the next prefetch then issues without a stall).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             float y0, yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+#ifdef EH_JIT_MECH
+            EhJitTape jtape;
+            if constexpr (PROG) eh_jit_fwd(par, frc, jtape, y0, yx[0], yx[1]);
+            else {
+#else
             float pval[PROG ? EH_PROG_SLOTS : 1];
             if constexpr (PROG) {
                 eh_prog_forward(a.prog, par, frc, pval);
@@ -950,6 +963,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
                 if (net.n_out > 1) yx[0] = pval[a.prog[3]];
                 if (net.n_out > 2) yx[1] = pval[a.prog[4]];
             } else {
+#endif
                 y0 = eh_mech_eval(net.mech, par, frc, dydp);
                 if (multiOn != 0.0f) eh_mech_extra(net.mech, par, frc, yx, Jx);
             }
@@ -993,6 +1007,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
                 }
                 continue;
             }
+#ifdef EH_JIT_MECH
+            float padj[EH_MAX_PARAMS];
+            if constexpr (PROG) eh_jit_rev(par, frc, jtape, dy, dyx[0], dyx[1], padj);
+#else
             float padj[PROG ? EH_PROG_SLOTS : 1];
             if constexpr (PROG) {
                 const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
@@ -1002,6 +1020,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs&
                 if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
                 eh_prog_reverse(a.prog, pval, padj);
             }
+#endif
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j) {
                 float dp;

@@ -1,0 +1,174 @@
+// see eh_jit.hpp
+#include "eh_jit.hpp"
+
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+// the kernel sources as the build saw them (Makefile: build/eh_sources.inc)
+#include "eh_sources.inc"
+
+std::string slot_val(unsigned s) {
+    char b[32];
+    if (s < EH_PROG_SLOT_FORC) snprintf(b, sizeof b, "par[%u]", s);
+    else if (s < EH_PROG_SLOT_CONST) snprintf(b, sizeof b, "frc[%u]", s - EH_PROG_SLOT_FORC);
+    else if (s < EH_PROG_SLOT_INSTR) snprintf(b, sizeof b, "c%u", s - EH_PROG_SLOT_CONST);
+    else snprintf(b, sizeof b, "T.t[%u]", s - EH_PROG_SLOT_INSTR);
+    return b;
+}
+std::string slot_adj(unsigned s) {
+    char b[32];
+    if (s < EH_PROG_SLOT_FORC) snprintf(b, sizeof b, "ap[%u]", s);
+    else if (s < EH_PROG_SLOT_CONST) snprintf(b, sizeof b, "af[%u]", s - EH_PROG_SLOT_FORC);
+    else if (s < EH_PROG_SLOT_INSTR) return "ac";
+    else snprintf(b, sizeof b, "at[%u]", s - EH_PROG_SLOT_INSTR);
+    return b;
+}
+}   // namespace
+
+std::string eh_jit_mech_source(const eh_model_desc& d) {
+    const int n = d.prog_len;
+    std::string s;
+    char b[256];
+    snprintf(b, sizeof b, "struct EhJitTape { float t[%d]; };\n", n);
+    s += b;
+    std::string consts;
+    for (int k = 0; k < d.prog_n_const; ++k) {
+        unsigned u;
+        memcpy(&u, &d.prog_const[k], 4);
+        snprintf(b, sizeof b, "    const float c%d = __uint_as_float(0x%08xu);   // %.9g\n", k, u, (double)d.prog_const[k]);
+        consts += b;
+    }
+    // ---- forward: the expressions of eh_prog_forward, one statement per instruction
+    s += "__device__ __forceinline__ void eh_jit_fwd(const float* par, const float* frc, EhJitTape& T, float& y0, float& y1, float& y2) {\n" + consts;
+    for (int i = 0; i < n; ++i) {
+        const unsigned w = d.prog_code[i];
+        const std::string x = slot_val((w >> 8) & 255u), y = slot_val((w >> 16) & 255u), z = slot_val(w >> 24);
+        std::string e;
+        switch (w & 255u) {
+            case EH_OP_ADD: e = x + " + " + y; break;
+            case EH_OP_SUB: e = x + " - " + y; break;
+            case EH_OP_MUL: e = x + " * " + y; break;
+            case EH_OP_DIV: e = x + " / " + y; break;
+            case EH_OP_NEG: e = "-" + x; break;
+            case EH_OP_EXP: e = "__expf(" + x + ")"; break;
+            case EH_OP_LOG: e = "__logf(" + x + ")"; break;
+            case EH_OP_POW: e = "eh_pow(" + x + ", " + y + ")"; break;
+            case EH_OP_SQRT: e = "sqrtf(" + x + ")"; break;
+            case EH_OP_TANH: e = "eh_tanh(" + x + ")"; break;
+            case EH_OP_SIGMOID: e = "eh_sigmoid(" + x + ")"; break;
+            case EH_OP_MAX: e = "fmaxf(" + x + ", " + y + ")"; break;
+            case EH_OP_MIN: e = "fminf(" + x + ", " + y + ")"; break;
+            case EH_OP_ABS: e = "fabsf(" + x + ")"; break;
+            case EH_OP_SIN: e = "sinf(" + x + ")"; break;
+            case EH_OP_COS: e = "cosf(" + x + ")"; break;
+            case EH_OP_SELECT: e = x + " > 0.0f ? " + y + " : " + z; break;
+            case EH_OP_GT: e = x + " > " + y + " ? 1.0f : 0.0f"; break;
+            default: e = "0.0f"; break;
+        }
+        snprintf(b, sizeof b, "    T.t[%d] = ", i);
+        s += b + e + ";\n";
+    }
+    for (int o = 0; o < EH_MAX_PROG_OUT; ++o) {
+        snprintf(b, sizeof b, "    y%d = ", o);
+        s += b + (o < d.prog_n_out ? slot_val((unsigned)d.prog_out[o]) : std::string("0.0f")) + ";\n";
+    }
+    s += "}\n";
+    // ---- reverse sweep: the adjoint updates of eh_prog_reverse
+    s += "__device__ __forceinline__ void eh_jit_rev(const float* par, const float* frc, const EhJitTape& T, float dy0, float dy1, float dy2, float* dp) {\n" + consts;
+    snprintf(b, sizeof b, "    float ap[%d] = {}, af[%d] = {}, ac = 0.0f, at[%d] = {};\n", EH_MAX_PARAMS, EH_MAX_FORC, n);
+    s += b;
+    for (int o = 0; o < d.prog_n_out; ++o) {
+        snprintf(b, sizeof b, " += dy%d;\n", o);
+        s += "    " + slot_adj((unsigned)d.prog_out[o]) + b;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const unsigned w = d.prog_code[i], sa = (w >> 8) & 255u, sb = (w >> 16) & 255u, sc = w >> 24;
+        const std::string x = slot_val(sa), y = slot_val(sb), A = slot_adj(sa), B = slot_adj(sb), C = slot_adj(sc);
+        snprintf(b, sizeof b, "    { const float g = at[%d], r = T.t[%d]; ", i, i);
+        s += b;
+        switch (w & 255u) {
+            case EH_OP_ADD: s += A + " += g; " + B + " += g;"; break;
+            case EH_OP_SUB: s += A + " += g; " + B + " += -g;"; break;
+            case EH_OP_MUL: s += A + " += g * " + y + "; " + B + " += g * " + x + ";"; break;
+            case EH_OP_DIV: s += A + " += g / " + y + "; " + B + " += -(g / " + y + ") * r;"; break;
+            case EH_OP_NEG: s += A + " += -g;"; break;
+            case EH_OP_EXP: s += A + " += g * r;"; break;
+            case EH_OP_LOG: s += A + " += g / " + x + ";"; break;
+            case EH_OP_POW: s += A + " += g * " + y + " * r / " + x + "; " + B + " += g * r * __logf(" + x + ");"; break;
+            case EH_OP_SQRT: s += A + " += g * 0.5f / r;"; break;
+            case EH_OP_TANH: s += A + " += g * (1.0f - r * r);"; break;
+            case EH_OP_SIGMOID: s += A + " += g * r * (1.0f - r);"; break;
+            case EH_OP_MAX: s += A + " += " + x + " >= " + y + " ? g : 0.0f; " + B + " += " + x + " >= " + y + " ? 0.0f : g;"; break;
+            case EH_OP_MIN: s += A + " += " + x + " <= " + y + " ? g : 0.0f; " + B + " += " + x + " <= " + y + " ? 0.0f : g;"; break;
+            case EH_OP_ABS: s += A + " += " + x + " > 0.0f ? g : (" + x + " < 0.0f ? -g : 0.0f);"; break;
+            case EH_OP_SIN: s += A + " += g * cosf(" + x + ");"; break;
+            case EH_OP_COS: s += A + " += -g * sinf(" + x + ");"; break;
+            case EH_OP_SELECT: s += B + " += " + x + " > 0.0f ? g : 0.0f; " + C + " += " + x + " > 0.0f ? 0.0f : g;"; break;
+            default: break;
+        }
+        s += " (void)r; }\n";
+    }
+    snprintf(b, sizeof b, "    for (int j = 0; j < %d; ++j) dp[j] = ap[j];\n    (void)af; (void)ac;\n}\n", EH_MAX_PARAMS);
+    s += b;
+    return s;
+}
+
+bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, EhJitKernel* out, std::string* log) {
+    const EhVariant& V = A->var[variant];
+    const std::string mech = eh_jit_mech_source(d);
+    // (hiprtc has the HIP device runtime built in but no C library headers)
+    std::string src = "typedef signed char int8_t; typedef unsigned char uint8_t; typedef int int32_t; typedef unsigned int uint32_t;\n"
+                      "typedef long long int64_t; typedef unsigned long long uint64_t;\n#define EH_JIT_MECH 1\n";
+    src += A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
+    const char* hnames[] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", "eh_jit_mech.inc"};
+    const char* hsrc[] = {eh_src_device, eh_src_wide, eh_src_public, mech.c_str()};
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "eh_jit.hip", 4, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
+    char name[2][160];
+    for (int m = 0; m < 2; ++m) {
+        if (A->wide) snprintf(name[m], sizeof name[m], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, true>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m);
+        else snprintf(name[m], sizeof name[m], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, 4>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m);
+        hiprtcAddNameExpression(prog, name[m]);
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(prog, &(*log)[0]); }
+    if (rc != HIPRTC_SUCCESS) {
+        *log = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + *log;
+        hiprtcDestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    bool ok = hipModuleLoadData(&out->mod, code.data()) == hipSuccess;
+    for (int m = 0; m < 2 && ok; ++m) {
+        const char* lowered = nullptr;
+        ok = hiprtcGetLoweredName(prog, name[m], &lowered) == HIPRTC_SUCCESS && hipModuleGetFunction(&out->fn[m], out->mod, lowered) == hipSuccess;
+        // (raises the dynamic-LDS limit where the runtime wants to be told; a refusal shows up as a failed launch, which the caller handles)
+        if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(out->fn[m]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds_bytes);
+    }
+    (void)hipGetLastError();
+    hiprtcDestroyProgram(&prog);
+    if (!ok) { *log = "hipModuleLoadData / hipModuleGetFunction failed for the compiled program"; eh_jit_release(out); return false; }
+    out->nw = V.nw;
+    out->lds_bytes = V.lds_bytes;
+    return true;
+}
+
+hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+    void* params[] = {const_cast<EhNet*>(net), const_cast<EhStepArgs*>(args)};
+    return hipModuleLaunchKernel(k->fn[mode == EH_MODE_EVAL ? 1 : 0], (unsigned)grid, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)k->lds_bytes, stream, params, nullptr);
+}
+
+void eh_jit_release(EhJitKernel* k) {
+    if (k->mod) (void)hipModuleUnload(k->mod);
+    k->mod = nullptr; k->fn[0] = k->fn[1] = nullptr;
+}

@@ -1,0 +1,23 @@
+// Run-time compilation of the step kernels for a recorded closure (EH_MECH_PROGRAM).  The kernels built ahead of time
+// interpret the program (per-lane value array in scratch memory, eh_device.hpp `eh_prog_forward`); here the same program is
+// written out as straight-line C++ and the kernel template is instantiated around it with hiprtc, so the tape lives in
+// registers and the mechanistic stage costs what a hand-derived registry model costs.  Falls back to the interpreter when
+// hiprtc is unavailable or refuses (reported by eh_jit_status).
+#pragma once
+#include <string>
+
+#include "eh_arch.hpp"
+
+struct EhJitKernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[2] = {nullptr, nullptr};   // EH_MODE_TRAIN, EH_MODE_EVAL
+    int nw = 0;
+    size_t lds_bytes = 0;
+};
+
+// the generated eh_jit_mech.inc (EhJitTape, eh_jit_fwd, eh_jit_rev) for a validated descriptor
+std::string eh_jit_mech_source(const eh_model_desc& d);
+// compiles the train + eval kernels of (arch, variant, activation); false + log on failure
+bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, EhJitKernel* out, std::string* log);
+hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
+void eh_jit_release(EhJitKernel* k);

@@ -347,6 +347,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                 }
             }
             float y0, yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+#ifdef EH_JIT_MECH
+            EhJitTape jtape;
+            if constexpr (PROG) eh_jit_fwd(par, frc, jtape, y0, yx[0], yx[1]);
+            else {
+#else
             float pval[PROG ? EH_PROG_SLOTS : 1];
             if constexpr (PROG) {
                 eh_prog_forward(a.prog, par, frc, pval);
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                 if (net.n_out > 1) yx[0] = pval[a.prog[3]];
                 if (net.n_out > 2) yx[1] = pval[a.prog[4]];
             } else {
+#endif
                 y0 = eh_mech_eval(net.mech, par, frc, dydp);
                 if (net.n_out > 1) eh_mech_extra(net.mech, par, frc, yx, Jx);
             }
@@ -395,6 +401,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                         for (int j = 0; j < net.n_par; ++j) a.pout[(long long)j * a.yld + n_loc] = par[j];
                 }
             } else {
+#ifdef EH_JIT_MECH
+                float padj[EH_MAX_PARAMS];
+                if constexpr (PROG) eh_jit_rev(par, frc, jtape, dy, dyx[0], dyx[1], padj);
+#else
                 float padj[PROG ? EH_PROG_SLOTS : 1];
                 if constexpr (PROG) {
                     const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
@@ -404,6 +414,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, c
                     if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
                     eh_prog_reverse(a.prog, pval, padj);
                 }
+#endif
 #pragma unroll
                 for (int j = 0; j < EH_MAX_PARAMS; ++j) {
                     if (j < net.n_par) {

@@ -277,6 +277,13 @@ class HybridEngine:
         """False/0 off, True/1 = events around every kernel, S > 1 = one event pair per burst of S steps."""
         self._chk(self._lib.eh_profile_enable(self._h, int(on)))
 
+    def jit_status(self):
+        """(kernel pairs compiled at run time for a recorded closure and in use, compiler / failure log)"""
+        n = C.c_int32()
+        buf = C.create_string_buffer(8192)
+        self._chk(self._lib.eh_jit_status(self._h, C.byref(n), buf, len(buf)))
+        return int(n.value), buf.value.decode(errors="replace")
+
     def profile_samples(self, cap: int = 8192) -> np.ndarray:
         """ms of every recorded step (or burst); call before profile_read, which consumes them."""
         buf = np.empty(cap, np.float64)

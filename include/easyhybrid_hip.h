@@ -25,7 +25,9 @@
 #ifndef EASYHYBRID_HIP_H
 #define EASYHYBRID_HIP_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -307,8 +309,15 @@ int32_t eh_profile_samples(eh_handle* h, double* ms, int64_t cap, int64_t* n_out
 int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
 
 /* tuning knobs (name/value): "max_blocks" (1..256), "variant" (tile shape), "fast_paths" (0 = generic MFMA kernels), "training_loss" (eh_loss),
- * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible) */
+ * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible), "row_split" (kernel family),
+ * "jit" (EH_MECH_PROGRAM: 1 = step kernels compiled at run time around the recorded closure (default; also env EH_JIT),
+ * 0 = the interpreting kernels built ahead of time) */
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
+
+/* EH_MECH_PROGRAM: how the recorded closure runs.  *n_compiled = kernel pairs (train + eval) compiled with hiprtc so far and in
+ * use; 0 with a non-empty log = the build or a launch was refused and the handle runs the interpreting kernels instead
+ * (same results, slower mechanistic stage).  log (optional) receives the compiler / failure message, NUL-terminated. */
+int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes);
 
 #ifdef __cplusplus
 }

@@ -34,9 +34,11 @@ def _data(spec, forc_ranges, B, seed, nan_frac=0.1, noise=0.05):
     return theta, X, f, y
 
 
-def _check(spec, theta, X, f, y, **kw):
+def _check(spec, theta, X, f, y, jit=1, **kw):
     eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_option("jit", jit)
     loss, grad, nv = eng.loss_and_grad(**kw)
+    assert eng.jit_status()[0] == jit, eng.jit_status()[1]       # the run-time compiled kernels really ran (or really did not)
     if "first" in kw:
         sl = slice(kw["first"], kw["first"] + kw["count"])
         X, f, y = X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}
@@ -47,16 +49,19 @@ def _check(spec, theta, X, f, y, **kw):
     return eng
 
 
+@pytest.mark.parametrize("jit", [1, 0])
 @pytest.mark.parametrize("hidden", [(16, 16), (64, 64), (128, 128), (24,), (32, 16, 8)])
 @pytest.mark.parametrize("act", ["tanh", "relu"])
-def test_hand_written_rbq10_closure_equals_registry_model(hidden, act):
+def test_hand_written_rbq10_closure_equals_registry_model(hidden, act, jit):
     spec, theta, X, f, y = util.rbq10_case(700, act, True, 0.1, hidden=hidden)
     util.register_closure("rbq10_closure", cl.rbq10_closure, list(cl.RBQ10_TABLE), ["ta"], ["reco"])
     spec_c = ho.HybridSpec(spec.n_pred, list(spec.hidden), "rbq10_closure", dict(spec.parameters), list(spec.neural), list(spec.glob),
                            ["reco"], act, True)
     eng_c = util.load_engine(spec_c, theta, X, f, y)
+    eng_c.set_option("jit", jit)
     eng_r = util.load_engine(spec, theta, X, f, y)
     lc, gc, nc = eng_c.loss_and_grad()
+    assert eng_c.jit_status()[0] == jit and eng_r.jit_status()[0] == 0
     lr, gr, nr = eng_r.loss_and_grad()
     l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
     assert nc == nr and abs(lc - l0) <= TOL * abs(l0) and util.relerr(gc, g0) <= TOL
@@ -64,14 +69,15 @@ def test_hand_written_rbq10_closure_equals_registry_model(hidden, act):
     eng_c.close(); eng_r.close()
 
 
+@pytest.mark.parametrize("jit", [1, 0])
 @pytest.mark.parametrize("targets", [["nee", "gpp", "reco"], ["nee"], ["gpp", "nee"]])
 @pytest.mark.parametrize("hidden", [(32, 32), (128,)])
-def test_three_output_flux_closure(targets, hidden):
+def test_three_output_flux_closure(targets, hidden, jit):
     spec = _spec("flux_closure", cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], targets, ["alpha", "rref", "gmax"], ["e0", "k"], hidden, n_pred=5)
     mm = ho.MECH["flux_closure"][0]
     theta, X, f, y = _data(spec, {k: r for k, r in dict(sw=(0, 800), ta=(-5, 30), vpd=(0, 30)).items() if k in mm.forcings}, 1300, 3)
-    eng = _check(spec, theta, X, f, y)
-    _check(spec, theta, X, f, y, first=130, count=1001).close()
+    eng = _check(spec, theta, X, f, y, jit=jit)
+    _check(spec, theta, X, f, y, jit=jit, first=130, count=1001).close()
     out = eng.forward(0)
     ref = ho.forward(spec, theta.astype(np.float64), X, f)
     for t in targets:
@@ -81,22 +87,24 @@ def test_three_output_flux_closure(targets, hidden):
     eng.close()
 
 
+@pytest.mark.parametrize("jit", [1, 0])
 @pytest.mark.parametrize("neural,glob,scale", [(["a", "b", "c", "d"], [], True), (["a"], ["b", "c"], True), (["b", "d"], ["a"], False)])
-def test_every_operation_closure(neural, glob, scale):
+def test_every_operation_closure(neural, glob, scale, jit):
     spec = _spec("allops_closure", cl.allops_closure, cl.ALLOPS_TABLE, ["u", "v"], ["y", "z"], neural, glob, (24, 24), n_pred=4, act="swish", scale=scale)
     theta, X, f, y = _data(spec, dict(u=(-1, 1), v=(-1, 1)), 900, 11)
     if not scale:                       # unscaled network outputs: keep c + 1.5 > 0 etc. by shrinking the last layer
         theta = theta.copy(); theta[:spec.n_nn] *= 0.3
-    _check(spec, theta, X, f, y).close()
+    _check(spec, theta, X, f, y, jit=jit).close()
 
 
 def test_closure_training_trajectory_eval_and_epoch_driver():
-    for fused, targets in ((0, ["nee", "reco"]), (1, ["nee"])):            # (the one-kernel-per-step mode is single-target)
+    for fused, targets, jit in ((0, ["nee", "reco"], 1), (1, ["nee"], 1), (1, ["nee"], 0)):            # (the one-kernel-per-step mode is single-target)
         spec = _spec("flux_closure", cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], targets, ["alpha", "rref"], ["gmax", "e0", "k"], (16, 16), n_pred=2)
         theta, X, f, y = _data(spec, dict(sw=(0, 800), ta=(-5, 30), vpd=(0, 30)), 2048, 21)
         eng = util.load_engine(spec, theta, X, f, y)
         eng.opt_init("Adam", 0.01)
         eng.set_option("fused_update", fused)
+        eng.set_option("jit", jit)
         batches = [(i * 256, 256) for i in range(8)]
         losses = [eng.train_step(a, b) for a, b in batches]
         th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
@@ -188,8 +196,10 @@ def _random_closure(rng, params, forcings, n_ops, n_out):
     return closure
 
 
+@pytest.mark.parametrize("jit", [0, 1])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EH_FUZZ_PROG_N", "40"))))
-def test_random_closure_matches_the_oracle(seed):
+def test_random_closure_matches_the_oracle(seed, jit):
+    """jit = 0: the interpreting kernels built ahead of time; 1: kernels compiled at run time around the program (about a second each)"""
     rng = np.random.default_rng(90000 + seed)
     n_par, n_forc, n_out = int(rng.integers(1, 9)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
     params, forc = [f"p{j}" for j in range(n_par)], [f"f{j}" for j in range(n_forc)]
@@ -217,7 +227,9 @@ def test_random_closure_matches_the_oracle(seed):
                  act=str(rng.choice(["tanh", "sigmoid", "relu", "swish"])), scale=True)
     theta, X, f, y = _data(spec, {k: (-1.0, 1.0) for k in pg.forcings}, int(rng.integers(1, 700)), 100 + seed, nan_frac=float(rng.choice([0.0, 0.2])))
     eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_option("jit", jit)
     loss, grad, nv = eng.loss_and_grad()
+    assert eng.jit_status()[0] == jit, eng.jit_status()[1]
     l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
     assert nv == sum(nv0)
     if sum(nv0):
