@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-specialize", action="store_true",
+                    help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
     args = ap.parse_args()
 
     import torch
@@ -115,12 +117,19 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
-        dp = eh.dp.DataParallel(eng)
+        dp = eh.dp.DataParallel(eng, specialize=not args.no_specialize)
     else:
         dp = None
         # one kernel per step: the optimiser update of step s runs in the prologue of step s+1 and the
         # partial sums are accumulated with float atomics (opt-in mode)
         eng.set_option("fused_update", int(os.environ.get("EH_FUSED", "1")))
+        if not args.no_specialize:
+            # the "specialize" option: the step kernel is compiled at run time (hiprtc, ~1 s) with this model's descriptor as a
+            # compile-time constant; one forward over one sample builds it here, ahead of the warm-up
+            eng.set_option("specialize", 1)
+            eng.forward(eh.EH_SPLIT_TRAIN, 0, 1, params=False)
+    jit_kernels, jit_log = eng.jit_status()
+    built = "compiled at run time around the model descriptor (hiprtc)" if jit_kernels else "built ahead of time"
 
     def run(nsteps, base):
         for s in range(nsteps):
@@ -198,7 +207,7 @@ def main():
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train+p2p,K1|PS> (fused update, peer-to-peer exchange)" if (dp is not None and dp.p2p) else
                     "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if (dp is None or dp.fused) else
-                    "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> + eh_reduce_kernel", "kernel_ms": ms_step, "launches_timed": n,
+                    "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> + eh_reduce_kernel", "kernel_build": built, "kernel_ms": ms_step, "launches_timed": n,
                     "kernel_ms_p10_p50_p90": [float(np.percentile(per_launch, q)) for q in (10, 50, 90)],
                     "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce kernel per launch)" if (dp is not None and not dp.fused) else "")
                               + (" (includes the wait for the peer GPUs' sums: the exchange is part of the kernel)" if (dp is not None and dp.p2p) else ""),
@@ -219,7 +228,7 @@ def main():
                        "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}",
                        "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
                                              else "one RCCL all-reduce per step"),
-                       "gradient_exchange_calibration_us_per_step": exchange_cal},
+                       "gradient_exchange_calibration_us_per_step": exchange_cal, "step_kernel": built},
             "roofline": roof,
         }
         out["dataset_upload_ms_once"] = 1e3 * t_up

@@ -463,9 +463,11 @@ struct eh_handle_s {
     int fast_user = 3;              // what the fast_paths option allows (default: all)
     unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
     // EH_MECH_PROGRAM: kernels compiled at run time around the program (eh_jit.hpp), one entry per (kernel family, variant) used
-    struct JitEntry { const EhArchInfo* arch; int variant; bool ok; EhJitKernel k; };
+    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; bool ok; EhJitKernel k; };
     std::vector<JitEntry> jit;
     bool jit_on = true;             // "jit" option / EH_JIT=0: 0 = the interpreting kernels built ahead of time
+    bool jit_failed = false;
+    bool specialize = false;        // "specialize" option: every model gets kernels compiled around its descriptor
     std::string jit_log;
     float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
     int n_weights = 0;
@@ -674,24 +676,30 @@ static bool arch_fits(const EhArchInfo* A, int need) {
     return true;
 }
 
-// Launches the step kernel of the handle's (family, variant): for a recorded closure the run-time compiled kernel (built on
-// first use; a failed build or launch switches the handle to the interpreting kernels for good), else the table entry.
+// Launches the step kernel of the handle's (family, variant).  A recorded closure, or any model with the "specialize" option,
+// runs a kernel compiled at run time (eh_jit.hpp; built on first use, one per descriptor state; a failed build or launch
+// switches the handle to the kernels built ahead of time for good); everything else runs the table entry.
 static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
-    if (h->net.mech == EH_MECH_PROGRAM && h->jit_on && mode != EH_MODE_TRAIN_P2P) {
+    const bool prog = h->net.mech == EH_MECH_PROGRAM;
+    if (h->jit_on && !h->jit_failed && (h->specialize ? (mode != EH_MODE_TRAIN_P2P || (!prog && !h->arch->wide)) : (prog && mode != EH_MODE_TRAIN_P2P))) {
+        const int kf = KFAST(h);
+        const bool want_p2p = h->specialize && h->p2p_on;
         eh_handle_s::JitEntry* je = nullptr;
-        for (auto& e : h->jit) if (e.arch == h->arch && e.variant == h->variant) je = &e;
+        for (auto& e : h->jit)
+            if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == h->specialize && (e.p2p || !want_p2p) &&
+                (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) je = &e;
         if (!je) {
-            h->jit.push_back({h->arch, h->variant, false, EhJitKernel{}});
+            h->jit.push_back({h->arch, h->variant, kf, h->specialize, want_p2p, h->net, false, EhJitKernel{}});
             je = &h->jit.back();
             std::string log;
-            je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, &je->k, &log);
-            if (!je->ok) h->jit_log = log;
+            je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, h->specialize ? &h->net : nullptr, want_p2p, &je->k, &log);
+            if (!je->ok) { h->jit_log = log; h->jit_failed = true; }
         }
         if (je->ok) {
             const hipError_t e = eh_jit_launch(&je->k, mode, grid, h->stream, &h->net, a);
             if (e == hipSuccess) return e;
             (void)hipGetLastError();
-            je->ok = false;
+            je->ok = false; h->jit_failed = true;
             h->jit_log = std::string("launch of the run-time compiled kernel failed: ") + hipGetErrorString(e);
         }
     }
@@ -877,6 +885,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->stream = h->own_stream;
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
     if (const char* ej = getenv("EH_JIT")) h->jit_on = atoi(ej) != 0;
+    if (const char* es = getenv("EH_SPECIALIZE")) h->specialize = atoi(es) != 0;      // (test runs: the whole suite on specialised kernels)
     if (d->mech == EH_MECH_PROGRAM) {
         std::vector<unsigned> pb(EH_PROG_HDR + EH_MAX_PROG, 0u);
         pb[0] = (unsigned)d->prog_len; pb[1] = (unsigned)d->prog_n_out;
@@ -1050,6 +1059,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "jit")) {              // recorded closures: 1 = kernels compiled at run time around the program (default), 0 = the interpreter
         h->jit_on = value != 0;
+        return EH_OK;
+    }
+    if (!strcmp(name, "specialize")) {       // 1 = step kernels compiled at run time with the model descriptor as a compile-time constant
+        h->specialize = value != 0;
         return EH_OK;
     }
     if (!strcmp(name, "row_split")) {        // A/B: the row-split kernel family (eh_wide.hpp) where both are built

@@ -525,7 +525,14 @@ __host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl
 //   FAST bit 1 (PS): P <= 4 predictors -> the first layer's weight gradient runs on the vector ALU
 // ------------------------------------------------------------------------------------------
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
-__device__ __forceinline__ void eh_step_body(const EhNet& net, const EhStepArgs& a) {
+__device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepArgs& a) {
+    // Run-time compiled kernels (eh_jit.hip) know the model: the descriptor is a compile-time constant there and the generality
+    // below -- per-parameter kinds, per-target switches, the mechanistic switch -- folds away.
+#ifdef EH_SPEC_NET
+    constexpr EhNet net = {EH_SPEC_NET};
+#else
+    const EhNet& net = net_rt;
+#endif
     using G = EhGeom<NBI, NBH, NL, NT, NW>;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, NTHR = 64 * NW;
     constexpr bool TRAIN = MODE != EH_MODE_EVAL;

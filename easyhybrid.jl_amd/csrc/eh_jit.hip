@@ -117,46 +117,57 @@ std::string eh_jit_mech_source(const eh_model_desc& d) {
     return s;
 }
 
-bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, EhJitKernel* out, std::string* log) {
+bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
+                  EhJitKernel* out, std::string* log) {
     const EhVariant& V = A->var[variant];
-    const std::string mech = eh_jit_mech_source(d);
+    const bool prog = d.mech == EH_MECH_PROGRAM;
+    const std::string mech = prog ? eh_jit_mech_source(d) : std::string();
     // (hiprtc has the HIP device runtime built in but no C library headers)
     std::string src = "typedef signed char int8_t; typedef unsigned char uint8_t; typedef int int32_t; typedef unsigned int uint32_t;\n"
-                      "typedef long long int64_t; typedef unsigned long long uint64_t;\n#define EH_JIT_MECH 1\n";
+                      "typedef long long int64_t; typedef unsigned long long uint64_t;\n";
+    if (prog) src += "#define EH_JIT_MECH 1\n";
+    if (spec) {
+        char b[512];
+        snprintf(b, sizeof b, "#define EH_SPEC_NET %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %uu, %uu, %uu, %uu\n", spec->P, spec->K, spec->G, spec->T, spec->F,
+                 spec->n_theta, spec->g_off, spec->scale_nn, spec->mech, spec->n_par, spec->loss, spec->n_out, spec->targ_out, spec->par_kind, spec->par_idx, spec->forc_col);
+        src += b;
+    }
     src += A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
     const char* hnames[] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", "eh_jit_mech.inc"};
     const char* hsrc[] = {eh_src_device, eh_src_wide, eh_src_public, mech.c_str()};
-    hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "eh_jit.hip", 4, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
-    char name[2][160];
-    for (int m = 0; m < 2; ++m) {
-        if (A->wide) snprintf(name[m], sizeof name[m], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, true>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m);
-        else snprintf(name[m], sizeof name[m], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, 4>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m);
-        hiprtcAddNameExpression(prog, name[m]);
+    hiprtcProgram hp = nullptr;
+    if (hiprtcCreateProgram(&hp, src.c_str(), "eh_jit.hip", prog ? 4 : 3, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
+    const int nmode = (with_p2p && !A->wide && !prog) ? 3 : 2;
+    char name[3][160];
+    for (int m = 0; m < nmode; ++m) {
+        if (A->wide) snprintf(name[m], sizeof name[m], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
+        else snprintf(name[m], sizeof name[m], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m,
+                      (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
+        hiprtcAddNameExpression(hp, name[m]);
     }
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    const hiprtcResult rc = hiprtcCompileProgram(hp, 3, opts);
     size_t ls = 0;
-    hiprtcGetProgramLogSize(prog, &ls);
-    if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(prog, &(*log)[0]); }
+    hiprtcGetProgramLogSize(hp, &ls);
+    if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(hp, &(*log)[0]); }
     if (rc != HIPRTC_SUCCESS) {
         *log = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + *log;
-        hiprtcDestroyProgram(&prog);
+        hiprtcDestroyProgram(&hp);
         return false;
     }
     size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
+    hiprtcGetCodeSize(hp, &cs);
     std::vector<char> code(cs);
-    hiprtcGetCode(prog, code.data());
+    hiprtcGetCode(hp, code.data());
     bool ok = hipModuleLoadData(&out->mod, code.data()) == hipSuccess;
-    for (int m = 0; m < 2 && ok; ++m) {
+    for (int m = 0; m < nmode && ok; ++m) {
         const char* lowered = nullptr;
-        ok = hiprtcGetLoweredName(prog, name[m], &lowered) == HIPRTC_SUCCESS && hipModuleGetFunction(&out->fn[m], out->mod, lowered) == hipSuccess;
+        ok = hiprtcGetLoweredName(hp, name[m], &lowered) == HIPRTC_SUCCESS && hipModuleGetFunction(&out->fn[m], out->mod, lowered) == hipSuccess;
         // (raises the dynamic-LDS limit where the runtime wants to be told; a refusal shows up as a failed launch, which the caller handles)
         if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(out->fn[m]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds_bytes);
     }
     (void)hipGetLastError();
-    hiprtcDestroyProgram(&prog);
+    hiprtcDestroyProgram(&hp);
     if (!ok) { *log = "hipModuleLoadData / hipModuleGetFunction failed for the compiled program"; eh_jit_release(out); return false; }
     out->nw = V.nw;
     out->lds_bytes = V.lds_bytes;
@@ -165,10 +176,11 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
 
 hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
     void* params[] = {const_cast<EhNet*>(net), const_cast<EhStepArgs*>(args)};
-    return hipModuleLaunchKernel(k->fn[mode == EH_MODE_EVAL ? 1 : 0], (unsigned)grid, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)k->lds_bytes, stream, params, nullptr);
+    if (mode < 0 || mode > 2 || !k->fn[mode]) return hipErrorNotSupported;
+    return hipModuleLaunchKernel(k->fn[mode], (unsigned)grid, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)k->lds_bytes, stream, params, nullptr);
 }
 
 void eh_jit_release(EhJitKernel* k) {
     if (k->mod) (void)hipModuleUnload(k->mod);
-    k->mod = nullptr; k->fn[0] = k->fn[1] = nullptr;
+    k->mod = nullptr; k->fn[0] = k->fn[1] = k->fn[2] = nullptr;
 }

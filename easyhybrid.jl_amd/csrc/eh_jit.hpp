@@ -10,14 +10,16 @@
 
 struct EhJitKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2] = {nullptr, nullptr};   // EH_MODE_TRAIN, EH_MODE_EVAL
+    hipFunction_t fn[3] = {nullptr, nullptr, nullptr};   // EH_MODE_TRAIN, EH_MODE_EVAL, EH_MODE_TRAIN_P2P (when asked for)
     int nw = 0;
     size_t lds_bytes = 0;
 };
 
 // the generated eh_jit_mech.inc (EhJitTape, eh_jit_fwd, eh_jit_rev) for a validated descriptor
 std::string eh_jit_mech_source(const eh_model_desc& d);
-// compiles the train + eval kernels of (arch, variant, activation); false + log on failure
-bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, EhJitKernel* out, std::string* log);
+// Compiles the train + eval (+ cross-GPU train) kernels of (arch, variant, activation, fast-path flags); false + log on failure.
+// `spec` (optional) bakes the model descriptor into the kernels as a compile-time constant.
+bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
+                  EhJitKernel* out, std::string* log);
 hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
 void eh_jit_release(EhJitKernel* k);

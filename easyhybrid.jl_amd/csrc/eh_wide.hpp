@@ -44,7 +44,12 @@ struct EhWideGeom : EhGeom<NBI, NBH, NL, NT, 1> {
 __device__ __forceinline__ void eh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false>
-__global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net, const EhStepArgs a) {
+__global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt, const EhStepArgs a) {
+#ifdef EH_SPEC_NET
+    constexpr EhNet net = {EH_SPEC_NET};        // see eh_step_body
+#else
+    const EhNet& net = net_rt;
+#endif
     using G = EhWideGeom<NBI, NBH, NL, NT, NWV>;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, S0 = G::S0, SH = G::SH, MB = NBH / NWV, NTH = 64 * NWV;
     constexpr bool TRAIN = MODE == EH_MODE_TRAIN;

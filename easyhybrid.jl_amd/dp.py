@@ -66,7 +66,7 @@ class _DevArray:
 class DataParallel:
     """Drives one replica.  `engine` already holds this rank's shard as its train split."""
 
-    def __init__(self, engine, group=None, fused: bool = True, p2p="auto"):
+    def __init__(self, engine, group=None, fused: bool = True, p2p="auto", specialize: bool = False):
         """fused=True: one kernel + one exchange per step (the update of step s is applied in the
         prologue of step s+1; `engine.synchronize()` applies the last one).  The exchange is the
         engine's own peer-to-peer store protocol over xGMI when `p2p` is on and its start-up self-test
@@ -108,6 +108,19 @@ class DataParallel:
             tot = torch.tensor(list(sx) + [float(n)], dtype=torch.float64, device=dev)
             allreduce_partials(tot, group)
             engine.set_bn_shift((tot[:-1] / tot[-1]).cpu().numpy())
+        if specialize:
+            engine.set_option("specialize", 1)
+            self.prepare()
+
+    def prepare(self):
+        """Compile the run-time kernels of this configuration now, on every rank, before any step: a forward over one sample
+        builds train / eval / cross-GPU kernels in one go.  (A peer that is still compiling while the others step would run
+        them into the deadline of the peer-to-peer exchange.)"""
+        import torch.distributed as dist
+        from . import _lib as L
+        self.engine.forward(L.EH_SPLIT_TRAIN, 0, 1, params=False)
+        self.engine.synchronize()
+        dist.barrier(group=self.group)
 
     def _all_agree(self, ok: bool) -> bool:
         import torch

@@ -111,6 +111,9 @@ class TrainConfig:
     # not in the reference (it has no multi-GPU path): None = data parallel iff torch.distributed is initialised with
     # more than one rank; True / False force it.  `batchsize` stays the GLOBAL minibatch, split evenly over the ranks.
     distributed: Optional[bool] = None
+    # not in the reference: step kernels compiled at run time (hiprtc, about a second) with this model's descriptor as a
+    # compile-time constant -- about 20 % faster small-model steps; pays off for long runs
+    specialize: bool = False
 
 
 @dataclass
@@ -313,7 +316,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.set_params(theta); ev.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
-        drv = DataParallel(eng)
+        drv = DataParallel(eng, specialize=tc.specialize)
         has_bn = bool(model.config.get("input_batchnorm"))
         first_lt = tc.loss_types[0]
 
@@ -405,6 +408,8 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         eng.set_training_loss(tc.training_loss)
         if tc.extra_loss is not None:
             eng.set_weight_l2(tc.extra_loss.lam, tc.extra_loss.normalize)
+        if tc.specialize:
+            eng.set_option("specialize", 1)
         first_lt = tc.loss_types[0]
 
         def snapshot():

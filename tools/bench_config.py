@@ -13,6 +13,7 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--fused", type=int, default=1)
 ap.add_argument("--nbatches", type=int, default=8)
 ap.add_argument("--variant", type=int, default=-1)
+ap.add_argument("--specialize", type=int, default=0)
 a = ap.parse_args()
 if a.config == "c3":
     B = a.batch or 262144
@@ -40,6 +41,7 @@ eng = model.engine(0)
 eng.set_data(0, X, F, Y)
 eng.set_params(model.initialparameters(1)); eng.opt_init("Adam", 0.01)
 eng.set_option("fused_update", a.fused)
+eng.set_option("specialize", a.specialize)
 if a.variant >= 0:
     eng.set_option("variant", a.variant)
 def run(n, base=0):
@@ -48,7 +50,7 @@ def run(n, base=0):
 run(20); eng.synchronize()
 t0 = time.perf_counter(); run(a.steps, 20); eng.synchronize(); dt = time.perf_counter() - t0
 us = 1e6 * dt / a.steps
-print(json.dumps({"config": a.config, "batch": B, "fused": a.fused, "us_per_step": us, "samples_per_s": B / us * 1e6,
+print(json.dumps({"config": a.config, "batch": B, "fused": a.fused, "specialize": a.specialize, "us_per_step": us, "samples_per_s": B / us * 1e6,
                   "algorithmic_TFLOPs": flop * B / us / 1e6, "frac_f32_peak": flop * B / us / 1e6 / 157.3,
                   "algorithmic_GBps": byts * B / us / 1e3, "final_loss": eng.train_step(0, B)}))
 eng.close()
