@@ -33,6 +33,13 @@ def test_two_ranks_peer_to_peer_exchange_matches_single_engine_training():
     assert len(first) == 2 and all("p2p=True" in l and "replicas_identical=True" in l for l in first), lines
 
 
+def test_two_ranks_peer_to_peer_exchange_with_run_time_specialised_kernels():
+    # DataParallel(specialize=True): every rank compiles its train / eval / cross-GPU kernels before the first step
+    lines = _run({"EH_TOOL_SPECIALIZE": "1"}, 29564)
+    first = [l for l in lines if "max|theta-ref|" in l]
+    assert len(first) == 2 and all("p2p=True" in l and "jit_kernels=1" in l and "replicas_identical=True" in l for l in first), lines
+
+
 def test_two_ranks_fall_back_to_the_collective_when_one_rank_fails_the_selftest():
     lines = _run({"EH_DP_P2P_FAIL_SELFTEST": "1"}, 29562)
     first = [l for l in lines if "max|theta-ref|" in l]

@@ -1097,3 +1097,75 @@ def test_train_front_door_with_weight_l2_shrinks_the_weights():
     assert last["weight_l2"] == pytest.approx(0.05 * float(np.sum(reg.ps[m].astype(np.float64) ** 2)), rel=0.3) and last["sum"] == last["weight_l2"]
     with pytest.raises(NotImplementedError, match="extra_loss"):
         eh.train(model, cols, extra_loss=lambda yhat, ps: 0.0, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# "specialize": step kernels compiled at run time with the model descriptor as a compile-time constant (eh_jit.hip)
+# ----------------------------------------------------------------------------------------------
+def _spec_cases(case):
+    if case == "rbq10":
+        return util.rbq10_case(3000, "tanh", True, 0.1)
+    if case == "rbq10-relu-unscaled":
+        return util.rbq10_case(3000, "relu", False, 0.1, hidden=(32, 8, 16))
+    if case == "config3":
+        spec = ho.expo2pool_spec((64, 64), "tanh", True)
+        X, f, y = ho.make_synth_expo2pool(3000, 7, 0.05)
+        return spec, ho.init_theta(spec, 3, np.float32), X, f, y
+    if case == "wide":
+        return _rs6_case(20, (96, 128), 3000)
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize("case", ["rbq10", "rbq10-relu-unscaled", "config3", "wide"])
+def test_specialized_kernels_equal_the_kernels_built_ahead_of_time(case):
+    spec, theta, X, f, y = _spec_cases(case)
+    a = util.load_engine(spec, theta, X, f, y)
+    b = util.load_engine(spec, theta, X, f, y)
+    b.set_option("specialize", 1)
+    la, ga, na = a.loss_and_grad(first=7, count=2900)
+    lb, gb, nb = b.loss_and_grad(first=7, count=2900)
+    assert b.jit_status()[0] == 1 and a.jit_status()[0] == 0, b.jit_status()[1]
+    sl = slice(7, 2907)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()})
+    assert na == nb == sum(nv0)
+    assert abs(lb - l0) <= TOL * abs(l0) and util.relerr(gb, g0) <= TOL
+    assert abs(la - lb) <= 1e-6 * abs(la) and util.relerr(gb, ga) <= 2e-6          # same arithmetic, possibly different contraction
+    for eng in (a, b):
+        eng.opt_init("Adam", 0.01)
+    batches = [(i * 500, 500) for i in range(6)]
+    loss_a = [a.train_step(*bt) for bt in batches]
+    loss_b = [b.train_step(*bt) for bt in batches]
+    assert np.allclose(loss_a, loss_b, rtol=1e-5)
+    assert np.max(np.abs(a.get_params() - b.get_params())) <= 2e-5
+    ma, mb = a.eval(0)[0], b.eval(0)[0]
+    for k in ("mse", "r2", "kge"):
+        assert ma[0][k] == pytest.approx(mb[0][k], rel=1e-5, abs=1e-6)
+    # a change of the training loss is a different descriptor: a second kernel pair is compiled, the first stays cached
+    b.set_training_loss("mae"); a.set_training_loss("mae")
+    la, ga, _ = a.loss_and_grad(); lb, gb, _ = b.loss_and_grad()
+    assert b.jit_status()[0] == 2 and abs(la - lb) <= 1e-6 * abs(la) and util.relerr(gb, ga) <= 2e-6
+    a.close(); b.close()
+
+
+def test_specialized_fused_update_trajectory_matches_oracle():
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    eng.set_option("fused_update", 1)
+    eng.set_option("specialize", 1)
+    batches = [(i * 256, 256) for i in range(8)]
+    losses = [eng.train_step(a, b) for a, b in batches]
+    assert eng.jit_status()[0] == 1
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    eng.close()
+
+
+def test_train_front_door_with_specialize():
+    cols = eh.synthetic.make_synth_rbq10(4000, seed=3, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    ref = eh.train(model, cols, nepochs=4, batchsize=256, opt=eh.Adam(0.01), random_seed=1)
+    out = eh.train(model, cols, nepochs=4, batchsize=256, opt=eh.Adam(0.01), random_seed=1, specialize=True)
+    assert out.val_history[-1]["mse"]["sum"] == pytest.approx(ref.val_history[-1]["mse"]["sum"], rel=1e-4)

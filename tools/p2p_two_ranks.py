@@ -41,7 +41,8 @@ eng.opt_init("Adam", 0.01)
 # Both ranks' kernels must fit on the one GPU at the same time: a step kernel fills a CU per workgroup, and a rank
 # whose 256 workgroups all sit waiting for the peer's sums would keep the peer's kernel from ever being scheduled.
 eng.set_option("max_blocks", max(1, 128 // world))
-drv = eh.dp.DataParallel(eng, fused=True)
+SPEC = os.environ.get("EH_TOOL_SPECIALIZE", "0") == "1"      # step kernels compiled at run time around the descriptor (incl. the cross-GPU one)
+drv = eh.dp.DataParallel(eng, fused=True, specialize=SPEC)
 dist.barrier()
 t0 = time.perf_counter()
 for i in range(nsteps):
@@ -57,14 +58,14 @@ err = float(np.max(np.abs(th - ref.get_params())))
 t = torch.from_numpy(th.copy()); tl = [torch.empty_like(t) for _ in range(world)]
 dist.all_gather(tl, t)
 same = all(bool(torch.equal(tl[0], q)) for q in tl)
-print(f"rank {rank}: p2p={drv.p2p} steps={nsteps} {1e6 * dt / nsteps:.1f} us/step max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
+print(f"rank {rank}: p2p={drv.p2p} jit_kernels={eng.jit_status()[0]} steps={nsteps} {1e6 * dt / nsteps:.1f} us/step max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
 ok = err <= 3e-5 and same
 # timing at the headline batch
 B = 65536
 spec2, theta2, X2, f2, y2 = util.rbq10_case(8 * B, "tanh", True, 0.0)
 e2 = util.load_engine(spec2, theta2, X2, f2, y2); e2.opt_init("Adam", 0.01)
 e2.set_option("max_blocks", max(1, 128 // world))
-d2 = eh.dp.DataParallel(e2, fused=True)
+d2 = eh.dp.DataParallel(e2, fused=True, specialize=SPEC)
 cal = d2.calibrate(0, B, 100)
 if rank == 0: print("calibration:", cal, flush=True)
 for i in range(50): d2.step((i % 8) * B, B)
