@@ -313,9 +313,18 @@ end
 opt_init!(e::HybridEngine; rule = 0, eta = 0.01f0, beta = (0.9f0, 0.999f0), epsilon = 1.0f-8, lambda = 0.0f0) =
     check(e, @ccall LIB[].eh_opt_init(e.h::Ptr{Cvoid}, rule::Int32, eta::Float32, beta[1]::Float32, beta[2]::Float32, epsilon::Float32, lambda::Float32)::Int32)
 
-"engine options: :max_blocks, :variant, :fast_paths, :row_split, :fused_update, :training_loss (0 mse, 1 rmse, 2 mae, 3 nseLoss)"
+"engine options: :max_blocks, :variant, :fast_paths, :row_split, :fused_update, :training_loss (0 mse, 1 rmse, 2 mae, 3 nseLoss, 4 pearsonLoss, 5 kgeLoss, 6 pbkgeLoss),
+:specialize (1 = step kernels compiled at run time around this model's descriptor, about a second, ~20 % faster small-model steps),
+:jit (recorded closures: 0 = interpret the program instead of compiling it)"
 set_option!(e::HybridEngine, name::Symbol, value::Integer) =
     check(e, @ccall LIB[].eh_set_option(e.h::Ptr{Cvoid}, String(name)::Cstring, value::Int64)::Int32)
+
+"(kernel pairs compiled at run time and in use, compiler / failure log) -- 0 with a log = the kernels built ahead of time run instead"
+function jit_status(e::HybridEngine)
+    n = Ref{Int32}(0); buf = Vector{UInt8}(undef, 8192)
+    check(e, @ccall LIB[].eh_jit_status(e.h::Ptr{Cvoid}, n::Ptr{Int32}, buf::Ptr{UInt8}, length(buf)::Int64)::Int32)
+    return Int(n[]), unsafe_string(pointer(buf))
+end
 synchronize(e::HybridEngine) = check(e, @ccall LIB[].eh_synchronize(e.h::Ptr{Cvoid})::Int32)
 
 # data-parallel seam (one process per GPU; the caller all-reduces the device buffers with RCCL / ROCm-aware MPI)
