@@ -3,7 +3,11 @@
 
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -26,6 +30,60 @@ std::string slot_adj(unsigned s) {
     else if (s < EH_PROG_SLOT_INSTR) return "ac";
     else snprintf(b, sizeof b, "at[%u]", s - EH_PROG_SLOT_INSTR);
     return b;
+}
+// On-disk cache of compiled code objects: $EH_JIT_CACHE (a directory; "0" = off), else $XDG_CACHE_HOME/easyhybrid_hip, else
+// ~/.cache/easyhybrid_hip.  Key = FNV-1a of everything that goes into the compilation.  File: u32 n, n x (u32 len, lowered
+// name), u64 length + u64 FNV of the code object, code object.  Failures of any kind just mean "compile".
+unsigned long long fnv(unsigned long long h, const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+std::string cache_dir() {
+    const char* e = getenv("EH_JIT_CACHE");
+    if (e && !strcmp(e, "0")) return "";
+    std::string d;
+    if (e && *e) d = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/easyhybrid_hip";
+    else if (const char* h = getenv("HOME")) { d = std::string(h) + "/.cache"; (void)mkdir(d.c_str(), 0755); d += "/easyhybrid_hip"; }
+    else return "";
+    (void)mkdir(d.c_str(), 0755);
+    return d;
+}
+bool cache_load(const std::string& path, int nnames, std::vector<std::string>* names, std::vector<char>* code) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    unsigned n = 0;
+    if (fread(&n, 4, 1, f) == 1 && (int)n == nnames) {
+        ok = true;
+        for (unsigned i = 0; i < n && ok; ++i) {
+            unsigned len = 0;
+            ok = fread(&len, 4, 1, f) == 1 && len < 4096;
+            if (ok) { std::string nm(len, 0); ok = fread(&nm[0], 1, len, f) == len; names->push_back(nm); }
+        }
+        if (ok) {       // length + checksum of the code object: the HIP runtime crashes on a truncated ELF instead of refusing it
+            unsigned long long len = 0, sum = 0;
+            ok = fread(&len, 8, 1, f) == 1 && fread(&sum, 8, 1, f) == 1 && len > 0 && len < (64ull << 20);
+            if (ok) { code->resize((size_t)len); ok = fread(code->data(), 1, code->size(), f) == code->size() && fnv(1469598103934665603ull, code->data(), code->size()) == sum; }
+        }
+    }
+    fclose(f);
+    return ok;
+}
+void cache_store(const std::string& path, const std::vector<std::string>& names, const std::vector<char>& code) {
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp%d", (int)getpid());
+    const std::string t = path + tmp;
+    FILE* f = fopen(t.c_str(), "wb");
+    if (!f) return;
+    const unsigned n = (unsigned)names.size();
+    bool ok = fwrite(&n, 4, 1, f) == 1;
+    for (auto& nm : names) { const unsigned len = (unsigned)nm.size(); ok = ok && fwrite(&len, 4, 1, f) == 1 && fwrite(nm.data(), 1, len, f) == len; }
+    const unsigned long long len = code.size(), sum = fnv(1469598103934665603ull, code.data(), code.size());
+    ok = ok && fwrite(&len, 8, 1, f) == 1 && fwrite(&sum, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(t.c_str(), path.c_str()) != 0) (void)unlink(t.c_str());
 }
 }   // namespace
 
@@ -146,26 +204,57 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
         hiprtcAddNameExpression(hp, name[m]);
     }
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const hiprtcResult rc = hiprtcCompileProgram(hp, 3, opts);
-    size_t ls = 0;
-    hiprtcGetProgramLogSize(hp, &ls);
-    if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(hp, &(*log)[0]); }
-    if (rc != HIPRTC_SUCCESS) {
-        *log = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + *log;
-        hiprtcDestroyProgram(&hp);
-        return false;
+    // ---- cached code object?
+    std::string cpath;
+    {
+        const std::string dir = cache_dir();
+        if (!dir.empty()) {
+            unsigned long long h = 1469598103934665603ull;
+            int ver[2] = {0, 0};
+            hiprtcVersion(&ver[0], &ver[1]);
+            h = fnv(h, ver, sizeof ver);
+            h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size());
+            h = fnv(h, eh_src_device, sizeof eh_src_device); h = fnv(h, eh_src_wide, sizeof eh_src_wide); h = fnv(h, eh_src_public, sizeof eh_src_public);
+            for (int m = 0; m < nmode; ++m) h = fnv(h, name[m], strlen(name[m]));
+            for (const char* o : opts) h = fnv(h, o, strlen(o));
+            char fn[64];
+            snprintf(fn, sizeof fn, "/%016llx.eco", h);
+            cpath = dir + fn;
+        }
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(hp, &cs);
-    std::vector<char> code(cs);
-    hiprtcGetCode(hp, code.data());
+    std::vector<std::string> lowered;
+    std::vector<char> code;
+    bool from_cache = !cpath.empty() && cache_load(cpath, nmode, &lowered, &code);
+    if (!from_cache) {
+        lowered.clear();
+        const hiprtcResult rc = hiprtcCompileProgram(hp, 3, opts);
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(hp, &ls);
+        if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(hp, &(*log)[0]); }
+        if (rc != HIPRTC_SUCCESS) {
+            *log = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + *log;
+            hiprtcDestroyProgram(&hp);
+            return false;
+        }
+        size_t cs = 0;
+        hiprtcGetCodeSize(hp, &cs);
+        code.resize(cs);
+        hiprtcGetCode(hp, code.data());
+        bool names_ok = true;
+        for (int m = 0; m < nmode; ++m) {
+            const char* ln = nullptr;
+            names_ok = names_ok && hiprtcGetLoweredName(hp, name[m], &ln) == HIPRTC_SUCCESS && ln;
+            lowered.push_back(ln ? ln : "");
+        }
+        if (names_ok && !cpath.empty()) cache_store(cpath, lowered, code);
+    }
     bool ok = hipModuleLoadData(&out->mod, code.data()) == hipSuccess;
     for (int m = 0; m < nmode && ok; ++m) {
-        const char* lowered = nullptr;
-        ok = hiprtcGetLoweredName(hp, name[m], &lowered) == HIPRTC_SUCCESS && hipModuleGetFunction(&out->fn[m], out->mod, lowered) == hipSuccess;
+        ok = !lowered[m].empty() && hipModuleGetFunction(&out->fn[m], out->mod, lowered[m].c_str()) == hipSuccess;
         // (raises the dynamic-LDS limit where the runtime wants to be told; a refusal shows up as a failed launch, which the caller handles)
         if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(out->fn[m]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds_bytes);
     }
+    if (!ok && from_cache) (void)unlink(cpath.c_str());       // a stale or damaged entry: gone, the next build compiles
     (void)hipGetLastError();
     hiprtcDestroyProgram(&hp);
     if (!ok) { *log = "hipModuleLoadData / hipModuleGetFunction failed for the compiled program"; eh_jit_release(out); return false; }

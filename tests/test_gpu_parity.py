@@ -1169,3 +1169,21 @@ def test_train_front_door_with_specialize():
     ref = eh.train(model, cols, nepochs=4, batchsize=256, opt=eh.Adam(0.01), random_seed=1)
     out = eh.train(model, cols, nepochs=4, batchsize=256, opt=eh.Adam(0.01), random_seed=1, specialize=True)
     assert out.val_history[-1]["mse"]["sum"] == pytest.approx(ref.val_history[-1]["mse"]["sum"], rel=1e-4)
+
+
+def test_compiled_kernels_are_cached_on_disk_and_a_damaged_entry_is_rebuilt(tmp_path, monkeypatch):
+    monkeypatch.setenv("EH_JIT_CACHE", str(tmp_path))
+    spec, theta, X, f, y = util.rbq10_case(900, "swish", True, 0.1, hidden=(24, 24))
+    res = []
+    for attempt in range(3):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_option("specialize", 1)
+        res.append(eng.loss_and_grad())
+        assert eng.jit_status()[0] == 1, eng.jit_status()[1]
+        eng.close()
+        files = list(tmp_path.glob("*.eco"))
+        assert len(files) == 1 and files[0].stat().st_size > 10000
+        if attempt == 1:                                    # damage the entry: the next engine must notice, drop it and compile again
+            files[0].write_bytes(files[0].read_bytes()[:5000])
+    for l, g, n in res[1:]:
+        assert l == res[0][0] and np.array_equal(g, res[0][1]) and n == res[0][2]
