@@ -36,3 +36,8 @@ def allops_closure(*, u, v, a, b, c, d):
 
 
 ALLOPS_TABLE = {"a": (0.8, -2.0, 2.0), "b": (0.5, -2.0, 2.0), "c": (1.0, 0.1, 3.0), "d": (0.7, 0.0, 2.0)}
+
+
+# name -> (closure, parameter table, forcings): what a fixture / spec that names a closure model needs to rebuild it
+CLOSURES = {"rbq10_closure": (rbq10_closure, RBQ10_TABLE, ["ta"]), "flux_closure": (flux_closure, FLUX_TABLE, ["sw", "ta", "vpd"]),
+            "allops_closure": (allops_closure, ALLOPS_TABLE, ["u", "v"])}

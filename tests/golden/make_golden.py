@@ -74,6 +74,22 @@ def main():
     SM = rng.random(300) * 0.8 + 0.1
     resp = 1.1 * np.exp(-8.0 * (SM - 0.6) ** 2) * np.exp(0.07 * T)
     resp = resp + rng.standard_normal(300) * 0.05 * resp.mean()
+    # a user closure (recorded as a device program): three forcings, two targets, neural + global + fixed parameters
+    from tests import closures as cl
+    from tests import util
+    fn, table, forc = cl.CLOSURES["flux_closure"]
+    util.register_closure("flux_closure", fn, list(table), forc, ["nee", "gpp"])
+    cspec = ho.HybridSpec(3, [24, 16], "flux_closure", dict(table), ["alpha", "rref"], ["gmax", "e0"], ["nee", "gpp"], "tanh", True)
+    crng = np.random.default_rng(21)
+    cX = crng.uniform(-1, 1, (3, 400)).astype(np.float32)
+    cf = {"sw": crng.uniform(0, 800, 400).astype(np.float32), "ta": crng.uniform(-5, 30, 400).astype(np.float32), "vpd": crng.uniform(0, 30, 400).astype(np.float32)}
+    truth = ho.forward(cspec, ho.init_theta(cspec, 22, np.float32).astype(np.float64), cX, cf)
+    cy = {}
+    for t in ("nee", "gpp"):
+        v = truth[t] * (1.0 + 0.05 * crng.normal(size=400))
+        v[crng.uniform(size=400) < 0.1] = np.nan
+        cy[t] = v.astype(np.float32)
+    emit("closure_flux_B400", cspec, ho.init_theta(cspec, 23, np.float32), cX, cf, cy, 200)
     emit("expo_ref_B300", spec, ho.init_theta(spec, 12, np.float32), SM[None].astype(np.float32), {"T": T.astype(np.float32)},
          {"Resp_obs": resp.astype(np.float32)}, 100)
 
