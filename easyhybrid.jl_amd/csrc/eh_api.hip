@@ -679,23 +679,28 @@ static bool arch_fits(const EhArchInfo* A, int need) {
 // Launches the step kernel of the handle's (family, variant).  A recorded closure, or any model with the "specialize" option,
 // runs a kernel compiled at run time (eh_jit.hpp; built on first use, one per descriptor state; a failed build or launch
 // switches the handle to the kernels built ahead of time for good); everything else runs the table entry.
-static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
+static bool jit_wanted(const eh_handle* h, int mode) {
     const bool prog = h->net.mech == EH_MECH_PROGRAM;
-    if (h->jit_on && !h->jit_failed && (h->specialize ? (mode != EH_MODE_TRAIN_P2P || (!prog && !h->arch->wide)) : (prog && mode != EH_MODE_TRAIN_P2P))) {
-        const int kf = KFAST(h);
-        const bool want_p2p = h->specialize && h->p2p_on;
-        eh_handle_s::JitEntry* je = nullptr;
-        for (auto& e : h->jit)
-            if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == h->specialize && (e.p2p || !want_p2p) &&
-                (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) je = &e;
-        if (!je) {
-            h->jit.push_back({h->arch, h->variant, kf, h->specialize, want_p2p, h->net, false, EhJitKernel{}});
-            je = &h->jit.back();
-            std::string log;
-            je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, h->specialize ? &h->net : nullptr, want_p2p, &je->k, &log);
-            if (!je->ok) { h->jit_log = log; h->jit_failed = true; }
-        }
-        if (je->ok) {
+    if (!h->jit_on || h->jit_failed) return false;
+    return h->specialize ? (mode != EH_MODE_TRAIN_P2P || (!prog && !h->arch->wide)) : (prog && mode != EH_MODE_TRAIN_P2P);
+}
+// the compiled kernels for the handle's current (family, variant, descriptor); builds them on first use; nullptr = not available
+static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
+    const int kf = KFAST(h);
+    const bool want_p2p = h->specialize && h->p2p_on;
+    for (auto& e : h->jit)
+        if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == h->specialize && (e.p2p || !want_p2p) &&
+            (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) return e.ok ? &e : nullptr;
+    h->jit.push_back({h->arch, h->variant, kf, h->specialize, want_p2p, h->net, false, EhJitKernel{}});
+    eh_handle_s::JitEntry* je = &h->jit.back();
+    std::string log;
+    je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, h->specialize ? &h->net : nullptr, want_p2p, &je->k, &log);
+    if (!je->ok) { h->jit_log = log; h->jit_failed = true; return nullptr; }
+    return je;
+}
+static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
+    if (jit_wanted(h, mode)) {
+        if (eh_handle_s::JitEntry* je = jit_entry(h)) {
             const hipError_t e = eh_jit_launch(&je->k, mode, grid, h->stream, &h->net, a);
             if (e == hipSuccess) return e;
             (void)hipGetLastError();
@@ -1588,6 +1593,7 @@ int32_t eh_graph_begin(eh_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ensure_loss_hist(h, 1);
     if (rc) return rc;
+    if (jit_wanted(h, EH_MODE_TRAIN)) (void)jit_entry(h);       // compile and load now: not inside a stream capture
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
     h->capturing = true;
     return EH_OK;

@@ -1191,3 +1191,22 @@ def test_compiled_kernels_are_cached_on_disk_and_a_damaged_entry_is_rebuilt(tmp_
             files[0].write_bytes(files[0].read_bytes()[:5000])
     for l, g, n in res[1:]:
         assert l == res[0][0] and np.array_equal(g, res[0][1]) and n == res[0][2]
+
+
+def test_hipgraph_capture_as_the_first_use_of_a_specialised_engine():
+    # eh_graph_begin compiles and loads the run-time kernels before the capture starts (a module load inside a capture is not allowed)
+    spec, theta, X, f, y = util.rbq10_case(6 * 512, "tanh", True, 0.1)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    eng.set_option("specialize", 1)
+    eng.graph_begin()
+    for i in range(6):
+        eng.train_step(i * 512, 512, want_loss=False)
+    g = eng.graph_end()
+    assert eng.jit_status()[0] == 1, eng.jit_status()[1]
+    for rep in range(2):
+        eng.graph_launch(g)
+        for i in range(6):
+            ref.train_step(i * 512, 512, want_loss=False)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 1e-6
+    eng.close(); ref.close()

@@ -14,6 +14,7 @@ ap.add_argument("--fused", type=int, default=1)
 ap.add_argument("--nbatches", type=int, default=8)
 ap.add_argument("--variant", type=int, default=-1)
 ap.add_argument("--specialize", type=int, default=0)
+ap.add_argument("--row-split", type=int, default=0)
 a = ap.parse_args()
 if a.config == "c3":
     B = a.batch or 262144
@@ -42,6 +43,8 @@ eng.set_data(0, X, F, Y)
 eng.set_params(model.initialparameters(1)); eng.opt_init("Adam", 0.01)
 eng.set_option("fused_update", a.fused)
 eng.set_option("specialize", a.specialize)
+if a.row_split:
+    eng.set_option("row_split", 1)
 if a.variant >= 0:
     eng.set_option("variant", a.variant)
 def run(n, base=0):
