@@ -12,6 +12,7 @@ import os
 EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 4, 8, 4, 4, 8
 EH_MAX_PROG, EH_MAX_PROG_CONST, EH_MAX_PROG_OUT = 64, 16, 3
 EH_MECH_PROGRAM = 6
+EH_LOSS_PROGRAM = 7
 EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE = 0, -1, -2, -3, -4, -5
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
 EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT = 0, 1, 2, 3, 4, 5
@@ -91,6 +92,7 @@ SIGNATURES = {
     "eh_profile_read": (C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "eh_profile_samples": (C.c_int32, [_H, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
     "eh_jit_status": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_char_p, C.c_int64]),
+    "eh_set_loss_program": (C.c_int32, [_H, C.POINTER(C.c_uint32), C.c_int32, _F, C.c_int32, C.c_int32]),
     "eh_debug_stamps": (C.c_int32, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "eh_set_option": (C.c_int32, [_H, C.c_char_p, C.c_int64]),
 }

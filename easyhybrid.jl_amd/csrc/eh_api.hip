@@ -463,11 +463,12 @@ struct eh_handle_s {
     int fast_user = 3;              // what the fast_paths option allows (default: all)
     unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
     // EH_MECH_PROGRAM: kernels compiled at run time around the program (eh_jit.hpp), one entry per (kernel family, variant) used
-    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; bool ok; EhJitKernel k; };
+    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; bool ok; EhJitKernel k; };
     std::vector<JitEntry> jit;
     bool jit_on = true;             // "jit" option / EH_JIT=0: 0 = the interpreting kernels built ahead of time
     bool jit_failed = false;
     bool specialize = false;        // "specialize" option: every model gets kernels compiled around its descriptor
+    EhLossProg loss_prog;           // eh_set_loss_program (EH_LOSS_PROGRAM)
     std::string jit_log;
     float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
     int n_weights = 0;
@@ -680,21 +681,24 @@ static bool arch_fits(const EhArchInfo* A, int need) {
 // runs a kernel compiled at run time (eh_jit.hpp; built on first use, one per descriptor state; a failed build or launch
 // switches the handle to the kernels built ahead of time for good); everything else runs the table entry.
 static bool jit_wanted(const eh_handle* h, int mode) {
-    const bool prog = h->net.mech == EH_MECH_PROGRAM;
-    if (!h->jit_on || h->jit_failed) return false;
-    return h->specialize ? (mode != EH_MODE_TRAIN_P2P || (!prog && !h->arch->wide)) : (prog && mode != EH_MODE_TRAIN_P2P);
+    const bool prog = h->net.mech == EH_MECH_PROGRAM, closs = h->net.loss == EH_LOSS_PROGRAM;
+    if (mode == EH_MODE_TRAIN_P2P) return h->jit_on && !h->jit_failed && h->specialize && !prog && !closs && !h->arch->wide;
+    if (closs) return true;          // a recorded loss exists in run-time compiled kernels only
+    return h->jit_on && !h->jit_failed && (h->specialize || prog);
 }
 // the compiled kernels for the handle's current (family, variant, descriptor); builds them on first use; nullptr = not available
 static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
     const int kf = KFAST(h);
-    const bool want_p2p = h->specialize && h->p2p_on;
+    const bool closs = h->net.loss == EH_LOSS_PROGRAM;
+    const bool want_p2p = h->specialize && h->p2p_on && !closs;
+    const int lgen = closs ? h->loss_prog.gen : 0;
     for (auto& e : h->jit)
-        if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == h->specialize && (e.p2p || !want_p2p) &&
+        if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == h->specialize && (e.p2p || !want_p2p) && e.loss_gen == lgen &&
             (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) return e.ok ? &e : nullptr;
-    h->jit.push_back({h->arch, h->variant, kf, h->specialize, want_p2p, h->net, false, EhJitKernel{}});
+    h->jit.push_back({h->arch, h->variant, kf, h->specialize, want_p2p, h->net, lgen, false, EhJitKernel{}});
     eh_handle_s::JitEntry* je = &h->jit.back();
     std::string log;
-    je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, h->specialize ? &h->net : nullptr, want_p2p, &je->k, &log);
+    je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, h->specialize ? &h->net : nullptr, want_p2p, closs ? &h->loss_prog : nullptr, &je->k, &log);
     if (!je->ok) { h->jit_log = log; h->jit_failed = true; return nullptr; }
     return je;
 }
@@ -707,6 +711,7 @@ static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs
             je->ok = false; h->jit_failed = true;
             h->jit_log = std::string("launch of the run-time compiled kernel failed: ") + hipGetErrorString(e);
         }
+        if (h->net.loss == EH_LOSS_PROGRAM && mode != EH_MODE_EVAL) return hipErrorNotSupported;     // no other form of a recorded loss exists
     }
     return h->arch->var[h->variant].launch(mode, h->act, KFAST(h), grid, h->stream, &h->net, a);
 }
@@ -1009,6 +1014,33 @@ int32_t eh_synchronize(eh_handle* h) {
     return EH_OK;
 }
 
+int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot) {
+    if (!h || !code || (n_const > 0 && !consts)) return EH_EINVAL;
+    if (n_instr < 1 || n_instr > EH_MAX_PROG) return fail(h, EH_EUNSUPPORTED, "eh_set_loss_program: %d instructions (1..%d)", n_instr, EH_MAX_PROG);
+    if (n_const < 0 || n_const > EH_MAX_PROG_CONST) return fail(h, EH_EUNSUPPORTED, "eh_set_loss_program: %d constants (0..%d)", n_const, EH_MAX_PROG_CONST);
+    auto slot_ok = [&](unsigned sl, int upto) {
+        if (sl < EH_PROG_SLOT_CONST) return sl < 2u;                                   // yhat, y
+        if (sl < EH_PROG_SLOT_INSTR) return (int)sl - EH_PROG_SLOT_CONST < n_const;
+        return (int)sl - EH_PROG_SLOT_INSTR < upto;
+    };
+    for (int i = 0; i < n_instr; ++i) {
+        const unsigned w = code[i], op = w & 255u;
+        if (op >= EH_OP_COUNT) return fail(h, EH_EUNSUPPORTED, "eh_set_loss_program: instruction %d has unknown opcode %u", i, op);
+        const int nop = (op == EH_OP_SELECT) ? 3 : (op == EH_OP_NEG || op == EH_OP_EXP || op == EH_OP_LOG || op == EH_OP_SQRT || op == EH_OP_TANH ||
+                                                    op == EH_OP_SIGMOID || op == EH_OP_ABS || op == EH_OP_SIN || op == EH_OP_COS) ? 1 : 2;
+        const unsigned sl[3] = {(w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
+        for (int k = 0; k < 3; ++k)
+            if (k < nop ? !slot_ok(sl[k], i) : sl[k] != 0u) return fail(h, EH_EINVAL, "eh_set_loss_program: instruction %d, operand %d names slot %u (undefined at that point, or a non-zero unused operand)", i, k, sl[k]);
+    }
+    if (out_slot < 0 || !slot_ok((unsigned)out_slot, n_instr)) return fail(h, EH_EINVAL, "eh_set_loss_program: output slot %d", out_slot);
+    if (h->net.loss == EH_LOSS_PROGRAM) { HIPCHK(h, hipSetDevice(h->device)); FLUSH(h); }
+    h->loss_prog.code.assign(code, code + n_instr);
+    h->loss_prog.consts.assign(consts, consts + n_const);
+    h->loss_prog.out = out_slot;
+    h->loss_prog.gen++;
+    return EH_OK;
+}
+
 int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes) {
     if (!h || !n_compiled) return EH_EINVAL;
     int n = 0;
@@ -1039,7 +1071,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
-        if (value && h->net.loss >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "fused_update: pearson / kge training losses take two passes per step");
+        if (value && h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "fused_update: pearson / kge training losses take two passes per step");
         if (value && h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
@@ -1049,9 +1081,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         return EH_OK;
     }
     if (!strcmp(name, "training_loss")) {
-        if (value < EH_LOSS_MSE || value > EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
+        if (value < EH_LOSS_MSE || value > EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
+        if (value == EH_LOSS_PROGRAM && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
         if (value != EH_LOSS_MSE && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "training losses other than MSE need a single-target model");
-        if (value >= EH_LOSS_PEARSONLOSS && h->fused) return fail(h, EH_EUNSUPPORTED, "pearson / kge training losses take two passes per step: switch fused_update off first");
+        if (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS && h->fused) return fail(h, EH_EUNSUPPORTED, "pearson / kge training losses take two passes per step: switch fused_update off first");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->net.loss = (int)value;
@@ -1206,7 +1239,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
         HIPCHK(h, hipGetLastError());
     }
-    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS;
+    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS;
     if (moment_loss) {
         // forward-only passes (train-mode BatchNorm statistics included): the batch mean of yhat, then the moments of
         // (yhat, y) about the means -> the coefficients of the per-sample d loss / d yhat that the training pass multiplies
@@ -1302,7 +1335,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (rc) return rc;
     if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
-    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS;
+    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS;
     const bool l2 = h->img.l2c != 0.0f;
     if (l2) {
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
@@ -1688,7 +1721,7 @@ int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
-    if (h->net.loss >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
+    if (h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
     if (h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: the weight_l2 extra loss is not built for the data-parallel seam");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     h->bn_dp_update = h->bn_on;

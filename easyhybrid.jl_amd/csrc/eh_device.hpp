@@ -377,6 +377,10 @@ __device__ __forceinline__ void eh_prog_reverse(const unsigned* __restrict__ pro
 #ifdef EH_JIT_MECH
 #include "eh_jit_mech.inc"
 #endif
+// a recorded custom training loss (eh_set_loss_program): eh_jit_loss(yhat, y, dl) -> l, dl = d l / d yhat.  Run-time builds only.
+#ifdef EH_JIT_LOSS
+#include "eh_jit_loss.inc"
+#endif
 
 // outputs 1.. of the multi-output models and their Jacobian rows (only FLUXPART: GPP, RECO)
 __device__ __forceinline__ void eh_mech_extra(int mech, const float* par, const float* frc, float* yx, float (*Jx)[3]) {
@@ -556,6 +560,12 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // Per-parameter / per-target switches as per-lane values pinned in VGPRs: as wave-uniform
     // conditions the compiler would hoist ~30 of them out of the tile loop into SGPR masks and then
     // spill them (measured: 117 SGPR spills); as VGPRs they cost one compare where they are used.
+    // (Not in the run-time specialised kernels: there the switches are compile-time constants and what they guard folds away.)
+#ifdef EH_SPEC_NET
+#define EH_PIN(...)
+#else
+#define EH_PIN(...) asm volatile("" : __VA_ARGS__)
+#endif
     float kN[EH_MAX_PARAMS], kG[EH_MAX_PARAMS], tOn[EH_MAX_TARG], sclOn = net.scale_nn ? 1.0f : 0.0f;
     int oOff[EH_MAX_PARAMS], fCol[EH_MAX_FORC];
 #pragma unroll
@@ -563,24 +573,24 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         kN[j] = (j < net.n_par && pkind(j) == EH_PAR_NEURAL) ? 1.0f : 0.0f;
         kG[j] = (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) ? 1.0f : 0.0f;
         oOff[j] = pidx(j) * SR;
-        asm volatile("" : "+v"(kN[j]), "+v"(kG[j]), "+v"(oOff[j]));
+        EH_PIN("+v"(kN[j]), "+v"(kG[j]), "+v"(oOff[j]));
     }
     int tOut[EH_MAX_TARG];
 #pragma unroll
     for (int t = 0; t < EH_MAX_TARG; ++t) {
         tOn[t] = t < net.T ? 1.0f : 0.0f; tOut[t] = (int)((net.targ_out >> (2 * t)) & 3u);
-        asm volatile("" : "+v"(tOn[t]), "+v"(tOut[t]));
+        EH_PIN("+v"(tOn[t]), "+v"(tOut[t]));
     }
     float multiOn = net.n_out > 1 ? 1.0f : 0.0f;
-    asm volatile("" : "+v"(multiOn));
+    EH_PIN("+v"(multiOn));
 #pragma unroll
     for (int f = 0; f < EH_MAX_FORC; ++f) {
         const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
         fCol[f] = col == 0xFFu ? -1 : (int)(net.P + col);
-        asm volatile("" : "+v"(fCol[f]));
+        EH_PIN("+v"(fCol[f]));
     }
     float maeOn = net.loss == EH_LOSS_MAE ? 1.0f : 0.0f;
-    asm volatile("" : "+v"(sclOn), "+v"(maeOn));
+    EH_PIN("+v"(sclOn), "+v"(maeOn));
     const int tcol0 = net.P + net.F;
 
     // one sample record per lane, fetched one macro-tile ahead of its use
@@ -986,7 +996,15 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
                         if (maeOn != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
-                        else if ((FAST & 3) == 0 && net.loss >= EH_LOSS_PEARSONLOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
+#ifdef EH_JIT_LOSS
+                        else if (net.loss == EH_LOSS_PROGRAM) {
+                            float dl;
+                            const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
+                            lacc += valid ? w * lv : 0.0f;
+                            d = valid ? w * dl : 0.0f;
+                        }
+#endif
+                        else if ((FAST & 3) == 0 && net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
                             d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
                         }
                         else { lacc += w * r * r; d = 2.0f * w * r; }

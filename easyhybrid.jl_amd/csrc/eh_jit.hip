@@ -85,6 +85,102 @@ void cache_store(const std::string& path, const std::vector<std::string>& names,
     ok = (fclose(f) == 0) && ok;
     if (!ok || rename(t.c_str(), path.c_str()) != 0) (void)unlink(t.c_str());
 }
+// one forward statement / one block of adjoint updates for instruction word w; V / A map a slot to its value / adjoint expression
+template <class V>
+std::string fwd_expr(unsigned w, V val) {
+    const std::string x = val((w >> 8) & 255u), y = val((w >> 16) & 255u), z = val(w >> 24);
+    switch (w & 255u) {
+        case EH_OP_ADD: return x + " + " + y;
+        case EH_OP_SUB: return x + " - " + y;
+        case EH_OP_MUL: return x + " * " + y;
+        case EH_OP_DIV: return x + " / " + y;
+        case EH_OP_NEG: return "-" + x;
+        case EH_OP_EXP: return "__expf(" + x + ")";
+        case EH_OP_LOG: return "__logf(" + x + ")";
+        case EH_OP_POW: return "eh_pow(" + x + ", " + y + ")";
+        case EH_OP_SQRT: return "sqrtf(" + x + ")";
+        case EH_OP_TANH: return "eh_tanh(" + x + ")";
+        case EH_OP_SIGMOID: return "eh_sigmoid(" + x + ")";
+        case EH_OP_MAX: return "fmaxf(" + x + ", " + y + ")";
+        case EH_OP_MIN: return "fminf(" + x + ", " + y + ")";
+        case EH_OP_ABS: return "fabsf(" + x + ")";
+        case EH_OP_SIN: return "sinf(" + x + ")";
+        case EH_OP_COS: return "cosf(" + x + ")";
+        case EH_OP_SELECT: return x + " > 0.0f ? " + y + " : " + z;
+        case EH_OP_GT: return x + " > " + y + " ? 1.0f : 0.0f";
+        default: return "0.0f";
+    }
+}
+template <class V, class Aj>
+std::string rev_stmts(unsigned w, V val, Aj adj) {
+    const unsigned sa = (w >> 8) & 255u, sb = (w >> 16) & 255u, sc = w >> 24;
+    const std::string x = val(sa), y = val(sb), A = adj(sa), B = adj(sb), C = adj(sc);
+    switch (w & 255u) {
+        case EH_OP_ADD: return A + " += g; " + B + " += g;";
+        case EH_OP_SUB: return A + " += g; " + B + " += -g;";
+        case EH_OP_MUL: return A + " += g * " + y + "; " + B + " += g * " + x + ";";
+        case EH_OP_DIV: return A + " += g / " + y + "; " + B + " += -(g / " + y + ") * r;";
+        case EH_OP_NEG: return A + " += -g;";
+        case EH_OP_EXP: return A + " += g * r;";
+        case EH_OP_LOG: return A + " += g / " + x + ";";
+        case EH_OP_POW: return A + " += g * " + y + " * r / " + x + "; " + B + " += g * r * __logf(" + x + ");";
+        case EH_OP_SQRT: return A + " += g * 0.5f / r;";
+        case EH_OP_TANH: return A + " += g * (1.0f - r * r);";
+        case EH_OP_SIGMOID: return A + " += g * r * (1.0f - r);";
+        case EH_OP_MAX: return A + " += " + x + " >= " + y + " ? g : 0.0f; " + B + " += " + x + " >= " + y + " ? 0.0f : g;";
+        case EH_OP_MIN: return A + " += " + x + " <= " + y + " ? g : 0.0f; " + B + " += " + x + " <= " + y + " ? 0.0f : g;";
+        case EH_OP_ABS: return A + " += " + x + " > 0.0f ? g : (" + x + " < 0.0f ? -g : 0.0f);";
+        case EH_OP_SIN: return A + " += g * cosf(" + x + ");";
+        case EH_OP_COS: return A + " += -g * sinf(" + x + ");";
+        case EH_OP_SELECT: return B + " += " + x + " > 0.0f ? g : 0.0f; " + C + " += " + x + " > 0.0f ? 0.0f : g;";
+        default: return "";
+    }
+}
+std::string const_decls(const float* c, int n) {
+    std::string s;
+    char b[128];
+    for (int k = 0; k < n; ++k) {
+        unsigned u;
+        memcpy(&u, &c[k], 4);
+        snprintf(b, sizeof b, "    const float c%d = __uint_as_float(0x%08xu);   // %.9g\n", k, u, (double)c[k]);
+        s += b;
+    }
+    return s;
+}
+}   // namespace
+
+std::string eh_jit_loss_source(const EhLossProg& lp) {
+    const int n = (int)lp.code.size();
+    auto val = [](unsigned sl) -> std::string {
+        char b[32];
+        if (sl == 0) return "yhat";
+        if (sl == 1) return "yobs";
+        if (sl < EH_PROG_SLOT_INSTR) snprintf(b, sizeof b, "c%u", sl - EH_PROG_SLOT_CONST);
+        else snprintf(b, sizeof b, "t[%u]", sl - EH_PROG_SLOT_INSTR);
+        return b;
+    };
+    auto adj = [](unsigned sl) -> std::string {
+        char b[32];
+        if (sl == 0) return "ayh";
+        if (sl < EH_PROG_SLOT_INSTR) return "ac";
+        snprintf(b, sizeof b, "at[%u]", sl - EH_PROG_SLOT_INSTR);
+        return b;
+    };
+    char b[160];
+    std::string s = "__device__ __forceinline__ float eh_jit_loss(float yhat, float yobs, float& dl) {\n" + const_decls(lp.consts.data(), (int)lp.consts.size());
+    snprintf(b, sizeof b, "    float t[%d], at[%d] = {}, ayh = 0.0f, ac = 0.0f;\n", n, n);
+    s += b;
+    for (int i = 0; i < n; ++i) { snprintf(b, sizeof b, "    t[%d] = ", i); s += b + fwd_expr(lp.code[i], val) + ";\n"; }
+    s += "    " + adj((unsigned)lp.out) + " += 1.0f;\n";
+    for (int i = n - 1; i >= 0; --i) {
+        snprintf(b, sizeof b, "    { const float g = at[%d], r = t[%d]; ", i, i);
+        s += b + rev_stmts(lp.code[i], val, adj) + " (void)r; }\n";
+    }
+    s += "    dl = ayh; (void)ac;\n    return " + val((unsigned)lp.out) + ";\n}\n";
+    return s;
+}
+
+namespace {
 }   // namespace
 
 std::string eh_jit_mech_source(const eh_model_desc& d) {
@@ -176,14 +272,16 @@ std::string eh_jit_mech_source(const eh_model_desc& d) {
 }
 
 bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
-                  EhJitKernel* out, std::string* log) {
+                  const EhLossProg* loss, EhJitKernel* out, std::string* log) {
     const EhVariant& V = A->var[variant];
     const bool prog = d.mech == EH_MECH_PROGRAM;
     const std::string mech = prog ? eh_jit_mech_source(d) : std::string();
+    const std::string lsrc = loss ? eh_jit_loss_source(*loss) : std::string();
     // (hiprtc has the HIP device runtime built in but no C library headers)
     std::string src = "typedef signed char int8_t; typedef unsigned char uint8_t; typedef int int32_t; typedef unsigned int uint32_t;\n"
                       "typedef long long int64_t; typedef unsigned long long uint64_t;\n";
     if (prog) src += "#define EH_JIT_MECH 1\n";
+    if (loss) src += "#define EH_JIT_LOSS 1\n";
     if (spec) {
         char b[512];
         snprintf(b, sizeof b, "#define EH_SPEC_NET %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %uu, %uu, %uu, %uu\n", spec->P, spec->K, spec->G, spec->T, spec->F,
@@ -191,10 +289,13 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
         src += b;
     }
     src += A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
-    const char* hnames[] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", "eh_jit_mech.inc"};
-    const char* hsrc[] = {eh_src_device, eh_src_wide, eh_src_public, mech.c_str()};
+    const char* hnames[5] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", nullptr, nullptr};
+    const char* hsrc[5] = {eh_src_device, eh_src_wide, eh_src_public, nullptr, nullptr};
+    int nh = 3;
+    if (prog) { hnames[nh] = "eh_jit_mech.inc"; hsrc[nh++] = mech.c_str(); }
+    if (loss) { hnames[nh] = "eh_jit_loss.inc"; hsrc[nh++] = lsrc.c_str(); }
     hiprtcProgram hp = nullptr;
-    if (hiprtcCreateProgram(&hp, src.c_str(), "eh_jit.hip", prog ? 4 : 3, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
+    if (hiprtcCreateProgram(&hp, src.c_str(), "eh_jit.hip", nh, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
     const int nmode = (with_p2p && !A->wide && !prog) ? 3 : 2;
     char name[3][160];
     for (int m = 0; m < nmode; ++m) {
@@ -213,7 +314,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
             int ver[2] = {0, 0};
             hiprtcVersion(&ver[0], &ver[1]);
             h = fnv(h, ver, sizeof ver);
-            h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size());
+            h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size()); h = fnv(h, lsrc.data(), lsrc.size());
             h = fnv(h, eh_src_device, sizeof eh_src_device); h = fnv(h, eh_src_wide, sizeof eh_src_wide); h = fnv(h, eh_src_public, sizeof eh_src_public);
             for (int m = 0; m < nmode; ++m) h = fnv(h, name[m], strlen(name[m]));
             for (const char* o : opts) h = fnv(h, o, strlen(o));

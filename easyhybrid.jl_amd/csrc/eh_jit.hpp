@@ -5,6 +5,7 @@
 // hiprtc is unavailable or refuses (reported by eh_jit_status).
 #pragma once
 #include <string>
+#include <vector>
 
 #include "eh_arch.hpp"
 
@@ -15,11 +16,20 @@ struct EhJitKernel {
     size_t lds_bytes = 0;
 };
 
+// a recorded custom training loss (eh_set_loss_program): value slot 0 = yhat, 1 = y
+struct EhLossProg {
+    std::vector<unsigned> code;
+    std::vector<float> consts;
+    int out = 0;
+    int gen = 0;          // bumped by every eh_set_loss_program: part of the cache key of the compiled kernels
+};
+// the generated eh_jit_loss.inc: float eh_jit_loss(float yhat, float yobs, float& dl)
+std::string eh_jit_loss_source(const EhLossProg& lp);
 // the generated eh_jit_mech.inc (EhJitTape, eh_jit_fwd, eh_jit_rev) for a validated descriptor
 std::string eh_jit_mech_source(const eh_model_desc& d);
 // Compiles the train + eval (+ cross-GPU train) kernels of (arch, variant, activation, fast-path flags); false + log on failure.
 // `spec` (optional) bakes the model descriptor into the kernels as a compile-time constant.
 bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
-                  EhJitKernel* out, std::string* log);
+                  const EhLossProg* loss, EhJitKernel* out, std::string* log);
 hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
 void eh_jit_release(EhJitKernel* k);

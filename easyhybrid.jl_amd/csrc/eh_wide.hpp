@@ -381,7 +381,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
                         if (net.loss == EH_LOSS_MAE) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
-                        else if (net.loss >= EH_LOSS_PEARSONLOSS) {      // moment-based losses (see eh_step_kernel)
+#ifdef EH_JIT_LOSS
+                        else if (net.loss == EH_LOSS_PROGRAM) {
+                            float dl;
+                            const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
+                            lacc += valid ? w * lv : 0.0f;
+                            d = valid ? w * dl : 0.0f;
+                        }
+#endif
+                        else if (net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS) {      // moment-based losses (see eh_step_kernel)
                             d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
                         }
                         else { lacc += w * r * r; d = 2.0f * w * r; }

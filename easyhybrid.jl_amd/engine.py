@@ -176,9 +176,19 @@ class HybridEngine:
         m = np.ascontiguousarray(mean, np.float32); v = np.ascontiguousarray(var, np.float32)
         self._chk(self._lib.eh_set_bn_state(self._h, _fptr(m), _fptr(v), m.size))
 
-    def set_training_loss(self, name: str):
+    def set_training_loss(self, name):
         """TrainConfig.training_loss (src/config/TrainingConfig.jl:64): mse | rmse | mae | nseLoss (one pass) |
-        pearsonLoss | kgeLoss | pbkgeLoss (two passes per step: batch moments first; not in fused_update mode, not data parallel)."""
+        pearsonLoss | kgeLoss | pbkgeLoss (two passes per step: batch moments first; not in fused_update mode, not data parallel),
+        or a function f(yhat, y) = mean of per-sample terms, which is recorded (program.trace_loss) and compiled into the step
+        kernel at run time."""
+        if callable(name):
+            from .program import trace_loss
+            pg = trace_loss(name)
+            words = (C.c_uint32 * len(pg.code))(*pg.words())
+            consts = (C.c_float * max(1, len(pg.consts)))(*pg.consts)
+            self._chk(self._lib.eh_set_loss_program(self._h, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
+            self.set_option("training_loss", L.EH_LOSS_PROGRAM)
+            return
         if name not in L.TRAINING_LOSSES:
             raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
         self.set_option("training_loss", L.TRAINING_LOSSES[name])

@@ -141,6 +141,9 @@ class Sym:
     def __bool__(self):
         raise NotImplementedError("Python control flow on a traced value: use where(cond, a, b)")
 
+    def mean(self, **kw):
+        return MeanOf(self)
+
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         if method != "__call__" or kwargs:
             raise NotImplementedError(f"numpy.{ufunc.__name__}.{method} in a mechanistic program")
@@ -193,7 +196,22 @@ _UFUNCS = {
     "greater_equal": lambda a, b: _sym_of(a, b)._lift(a) >= b, "less_equal": lambda a, b: _sym_of(a, b)._lift(a) <= b,
 }
 
+class MeanOf:
+    """np.mean(<traced per-sample value>): the only reduction a recorded training loss may end in."""
+    def __init__(self, sym: "Sym"):
+        self.sym = sym
+
+    def _no(self, *a, **k):
+        raise NotImplementedError("a recorded training loss has the form mean(l(yhat, y)): nothing can be applied to the mean "
+                                  "(sqrt(mean(...)) etc. are the built-in rmse / nseLoss / kgeLoss)")
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __pow__ = __rpow__ = __neg__ = __abs__ = _no
+
+    def __array_ufunc__(self, *a, **k):
+        self._no()
+
+
 _ARRAY_FUNCS = {
+    "mean": lambda x, **kw: MeanOf(x),
     "where": lambda cond, a, b: where(cond, a, b),
     "clip": lambda x, lo=None, hi=None, **kw: (x if lo is None else maximum(x, lo)) if hi is None else minimum(x if lo is None else maximum(x, lo), hi),
 }
@@ -297,3 +315,46 @@ def trace(fn: Callable, params: Sequence[str], forcings: Sequence[str], targets:
     if len(code) > MAX_PROG:
         raise NotImplementedError(f"the program has {len(code)} operations (device limit {MAX_PROG})")
     return Program(tuple(params), tuple(used_f), tuple(outs), tuple(consts), tuple(code), tuple(out))
+
+
+def trace_loss(fn: Callable) -> Program:
+    """Record a custom training loss `fn(yhat, y)` (loss_fn.jl: training_loss::Function, called on the valid samples of a
+    target).  It must be a mean of per-sample terms: `np.mean(l(yhat, y))` -- or the per-sample term itself, which is then
+    averaged.  Value slot 0 = yhat, slot 1 = y."""
+    g = _Graph()
+    yhat, y = Sym(g, g.node("par", 0)), Sym(g, g.node("par", 1))
+    res = fn(yhat, y)
+    if isinstance(res, MeanOf):
+        res = res.sym
+    if not isinstance(res, Sym):
+        raise TypeError("a training loss function returns np.mean(<elementwise expression of yhat and y>)")
+    root = _fold(g, res.nid, {})
+    consts: List[float] = []
+    code: List[Tuple[int, int, int, int]] = []
+    slot: Dict[int, int] = {}
+
+    def emit(nid: int) -> int:
+        if nid in slot:
+            return slot[nid]
+        n = g.nodes[nid]
+        if n[0] == "par":
+            s = SLOT_PAR + n[1]
+        elif n[0] == "const":
+            if n[1] not in consts:
+                consts.append(n[1])
+            s = SLOT_CONST + consts.index(n[1])
+        else:
+            ops = [emit(a) for a in n[1:]] + [0, 0]
+            code.append((OPS[n[0]], ops[0], ops[1], ops[2]))
+            s = SLOT_INSTR + len(code) - 1
+        slot[nid] = s
+        return s
+
+    out = emit(root)
+    if out < SLOT_INSTR:
+        zero = emit(g.const(0.0))
+        code.append((OPS["add"], out, zero, 0))
+        out = SLOT_INSTR + len(code) - 1
+    if len(consts) > MAX_CONST or len(code) > MAX_PROG:
+        raise NotImplementedError(f"the loss has {len(code)} operations / {len(consts)} constants (device limits {MAX_PROG} / {MAX_CONST})")
+    return Program(("yhat", "y"), (), ("loss",), tuple(consts), tuple(code), (out,))

@@ -98,7 +98,7 @@ class TrainConfig:
     batchsize: int = 64
     opt: Any = field(default_factory=lambda: Adam(0.01))
     patience: int = 2**62
-    training_loss: str = "mse"
+    training_loss: Any = "mse"           # a name, or a function f(yhat, y) -> np.mean(per-sample terms) (loss_fn.jl: training_loss::Function)
     loss_types: List[str] = field(default_factory=lambda: ["mse", "r2"])
     agg: str = "sum"
     extra_loss: Any = None               # TrainingConfig.jl:74; None or WeightL2(lam, normalize)
@@ -134,10 +134,11 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
         raise ValueError("return_model must be :best or :final")
     if not cfg.loss_types:
         raise ValueError("loss_types must not be empty")
-    check_training_loss(cfg.training_loss)
-    if cfg.training_loss not in L.TRAINING_LOSSES:
-        raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements {sorted(L.TRAINING_LOSSES)} "
-                                  "(custom loss functions cannot run inside the kernel)")
+    if not callable(cfg.training_loss):                          # a function f(yhat, y) is recorded and compiled into the step kernel
+        check_training_loss(cfg.training_loss)
+        if cfg.training_loss not in L.TRAINING_LOSSES:
+            raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements {sorted(L.TRAINING_LOSSES)} "
+                                      "or a function f(yhat, y) = mean of per-sample terms")
     if cfg.agg != "sum":
         raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
     if cfg.extra_loss is not None and not isinstance(cfg.extra_loss, WeightL2):

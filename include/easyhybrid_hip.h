@@ -112,7 +112,8 @@ typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2
  *   forward-only pass collects the moments first (no fused_update mode, no data-parallel seam for these).
  * Selected with eh_set_option(h, "training_loss", k) (TrainConfig.training_loss, src/config/TrainingConfig.jl:64; default MSE) */
 typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LOSS_NSELOSS = 3,
-                       EH_LOSS_PEARSONLOSS = 4, EH_LOSS_KGELOSS = 5, EH_LOSS_PBKGELOSS = 6 } eh_loss;
+                       EH_LOSS_PEARSONLOSS = 4, EH_LOSS_KGELOSS = 5, EH_LOSS_PBKGELOSS = 6,
+                       EH_LOSS_PROGRAM = 7 /* a recorded custom loss, see eh_set_loss_program */ } eh_loss;
 
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
 typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4, EH_BUF_BNSTAT = 5 } eh_buffer;
@@ -313,6 +314,14 @@ int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
  * "jit" (EH_MECH_PROGRAM: 1 = step kernels compiled at run time around the recorded closure (default; also env EH_JIT),
  * 0 = the interpreting kernels built ahead of time) */
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
+
+/* A custom training loss `training_loss::Function` (src/losses/loss_fn.jl: called as f(yhat[mask], y[mask])) of the form
+ * mean_i l(yhat_i, y_i): the per-sample term l recorded as a program like a mechanistic closure (eh_prog_op; value slot 0 =
+ * yhat, slot 1 = y, 12.. constants, 28+i instruction i; out_slot = the slot holding l).  The step kernel evaluates l and
+ * d l / d yhat per valid sample; the mean over the valid samples and everything downstream is the MSE path.  Select it with
+ * eh_set_option(h, "training_loss", EH_LOSS_PROGRAM).  It exists only in kernels compiled at run time (hiprtc): without them
+ * the training calls fail with EH_EUNSUPPORTED -- there is no interpreted or CPU form. */
+int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot);
 
 /* EH_MECH_PROGRAM: how the recorded closure runs.  *n_compiled = kernel pairs (train + eval) compiled with hiprtc so far and in
  * use; 0 with a non-empty log = the build or a launch was refused and the handle runs the interpreting kernels instead

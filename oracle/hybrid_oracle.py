@@ -304,6 +304,17 @@ def program_mech(name: str, prog: dict, closure=None):
     MECH[name] = (mm, fwd, vjp)
     return mm
 
+CUSTOM_LOSS: Dict[str, Tuple[str, Optional[callable]]] = {}
+
+
+def loss_program(name: str, prog: dict, closure=None):
+    """Register a recorded custom training loss `closure(yhat, y) -> mean of per-sample terms` as training-loss kind `name`:
+    the value comes from calling the function on the valid samples (as the reference does), the derivative from the reverse
+    sweep over the recorded per-sample program (value slots: yhat, y)."""
+    program_mech("_loss_" + name, prog, None)
+    CUSTOM_LOSS[name] = ("_loss_" + name, closure)
+
+
 # ----------------------------------------------------------------------------------------------
 # model spec  (mirror of constructHybridModel's arguments, GenericHybridModel.jl:89-140)
 # ----------------------------------------------------------------------------------------------
@@ -629,6 +640,15 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
                         dl = ((rr - 1) * drr + (beta - 1) * dbeta) / lt
                 loss = loss + lt
                 d[m] = dl
+            elif kind in CUSTOM_LOSS:            # training_loss::Function (loss_fn.jl): mean over the valid samples of l(yhat, y)
+                pname, closure = CUSTOM_LOSS[kind]
+                _, lfwd, lvjp = MECH[pname]
+                yh, yv = res[t][m].astype(dt), y[m]
+                lpar = {"yhat": yh, "y": yv}
+                lout, laux = lfwd(lpar, {}, dt)
+                value = np.mean(lout["loss"]) if closure is None else dt.type(closure(yh, yv))       # the function itself gives the value
+                loss = loss + value
+                d[m] = lvjp(lpar, {}, lout, laux, {"loss": np.full(n, 1.0 / n, dt)}, dt)["yhat"]
             else:
                 raise ValueError(f"training loss {kind}")
         dout[t] = d

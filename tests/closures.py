@@ -41,3 +41,26 @@ ALLOPS_TABLE = {"a": (0.8, -2.0, 2.0), "b": (0.5, -2.0, 2.0), "c": (1.0, 0.1, 3.
 # name -> (closure, parameter table, forcings): what a fixture / spec that names a closure model needs to rebuild it
 CLOSURES = {"rbq10_closure": (rbq10_closure, RBQ10_TABLE, ["ta"]), "flux_closure": (flux_closure, FLUX_TABLE, ["sw", "ta", "vpd"]),
             "allops_closure": (allops_closure, ALLOPS_TABLE, ["u", "v"])}
+
+
+# custom training losses, as a user writes them for `training_loss = f` (src/losses/loss_fn.jl: f(yhat[mask], y[mask]))
+def huber_loss(yhat, y, delta=0.5):
+    r = np.abs(yhat - y)
+    return np.mean(np.where(r <= delta, 0.5 * r * r, delta * (r - 0.5 * delta)))
+
+
+def logcosh_loss(yhat, y):
+    r = yhat - y
+    return np.mean(np.abs(r) + np.log(1.0 + np.exp(-2.0 * np.abs(r))) - np.log(2.0))
+
+
+def pinball_loss(yhat, y, q=0.75):
+    r = y - yhat
+    return np.mean(np.maximum(q * r, (q - 1.0) * r))
+
+
+def relative_sq_loss(yhat, y):
+    return ((yhat - y) / (np.abs(y) + 1.0)) ** 2          # per-sample terms: averaged by the engine
+
+
+LOSSES = {"huber": huber_loss, "logcosh": logcosh_loss, "pinball": pinball_loss, "relative_sq": relative_sq_loss}

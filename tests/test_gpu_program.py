@@ -244,3 +244,75 @@ def test_random_closure_matches_the_oracle(seed, jit):
         if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
             assert util.relerr(grad, g0) <= gbar, info
     eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# custom training losses f(yhat, y) = mean of per-sample terms (loss_fn.jl: training_loss::Function), recorded and compiled
+# into the step kernel at run time
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(cl.LOSSES))
+@pytest.mark.parametrize("shape", ["rbq10", "config3", "wide", "closure"])
+def test_custom_training_loss(name, shape):
+    fn = util.register_loss(name, cl.LOSSES[name])
+    if shape == "rbq10":
+        spec, theta, X, f, y = util.rbq10_case(1500, "tanh", True, 0.1)
+    elif shape == "config3":
+        spec = ho.expo2pool_spec((64, 64), "tanh", True)
+        X, f, y = ho.make_synth_expo2pool(1500, 7, 0.05)
+        theta = ho.init_theta(spec, 3, np.float32)
+    elif shape == "wide":
+        spec, theta, X, f, y = util.rbq10_case(1500, "swish", True, 0.1, hidden=(128, 96))
+    else:
+        spec = _spec("flux_closure", cl.flux_closure, cl.FLUX_TABLE, ["sw", "ta", "vpd"], ["nee"], ["alpha", "rref"], ["gmax", "e0", "k"], (16, 16), n_pred=2)
+        theta, X, f, y = _data(spec, dict(sw=(0, 800), ta=(-5, 30), vpd=(0, 30)), 1500, 21)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(fn)
+    loss, grad, nv = eng.loss_and_grad()
+    assert eng.jit_status()[0] == 1, eng.jit_status()[1]
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=name)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    l1, g1, _ = eng.loss_and_grad(first=100, count=777)
+    sl = slice(100, 877)
+    l10, g10, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}, kind=name)
+    assert l1 == pytest.approx(l10, rel=TOL) and util.relerr(g1, g10) <= TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_custom_training_loss_trajectory(fused):
+    fn = util.register_loss("huber", cl.LOSSES["huber"])
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(fn)
+    eng.opt_init("Adam", 0.01)
+    eng.set_option("fused_update", fused)
+    batches = [(i * 256, 256) for i in range(8)]
+    losses = [eng.train_step(a, b) for a, b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32, kind="huber")
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    # eval metrics are the named ones, whatever the training loss
+    metrics, _ = eng.eval(0)
+    ref = ho.forward(spec, eng.get_params().astype(np.float64), X, f)["reco"]
+    yy = y["reco"].astype(np.float64); mask = ~np.isnan(yy)
+    assert metrics[0]["mse"] == pytest.approx(ho.loss_fn(ref, yy, mask, "mse"), rel=2e-5)
+    eng.close()
+
+
+def test_custom_training_loss_front_door_and_refusals():
+    cols = eh.synthetic.make_synth_rbq10(4000, seed=3, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=5, batchsize=256, opt=eh.Adam(0.01), random_seed=1, training_loss=cl.huber_loss)
+    assert out.val_history[-1]["mse"]["sum"] < 0.5 * out.val_history[0]["mse"]["sum"]
+    # no other form of a recorded loss exists: with the run-time compiler switched off the step is refused, not emulated
+    spec, theta, X, f, y = util.rbq10_case(300, "tanh", True, 0.1)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_option("jit", 0)
+    eng.set_training_loss(cl.huber_loss)
+    eng.loss_and_grad()                                  # ("jit" governs recorded mechanistic closures; a recorded loss always compiles)
+    assert eng.jit_status()[0] == 1
+    with pytest.raises(eh.EngineError, match="eh_set_loss_program first"):
+        e2 = util.load_engine(spec, theta, X, f, y)
+        e2.set_option("training_loss", 7)
+    eng.close()

@@ -140,3 +140,42 @@ def test_bad_programs_are_refused_by_the_library_before_any_device_work():
         edit(d)
         with pytest.raises(exc, match=msg):
             eh.HybridEngine(d, 2, ["reco"], ["rb", "Q10"])
+
+
+@pytest.mark.parametrize("name", sorted(cl.LOSSES))
+def test_custom_loss_program_value_and_derivative(name):
+    fn = cl.LOSSES[name]
+    pg = P.trace_loss(fn)
+    assert pg.params == ("yhat", "y") and len(pg.out) == 1 and len(pg.code) >= 2
+    util.register_loss(name, fn)
+    rng = np.random.default_rng(3)
+    yh, y = rng.normal(size=400), rng.normal(size=400)
+    dt = np.dtype(np.float64)
+    _, fwd, vjp = ho.MECH["_loss_" + name]
+    out, aux = fwd({"yhat": yh, "y": y}, {}, dt)
+    direct = fn(yh, y)
+    assert np.mean(out["loss"]) == pytest.approx(float(np.mean(direct)), rel=1e-6)            # (constants are held in fp32)
+    d = vjp({"yhat": yh, "y": y}, {}, out, aux, {"loss": np.ones(400)}, dt)["yhat"]
+    h = 1e-6
+    up, _ = fwd({"yhat": yh + h, "y": y}, {}, dt); dn, _ = fwd({"yhat": yh - h, "y": y}, {}, dt)
+    fd = (up["loss"] - dn["loss"]) / (2 * h)
+    assert (np.abs(d - fd) <= 1e-5 * (1 + np.abs(fd))).mean() > 0.99                           # (kinks of |r| and the Huber switch)
+
+
+def test_a_loss_that_is_not_a_mean_of_per_sample_terms_is_refused():
+    with pytest.raises(NotImplementedError, match="nothing can be applied to the mean"):
+        P.trace_loss(lambda yh, y: np.sqrt(np.mean((yh - y) ** 2)))
+    with pytest.raises(NotImplementedError, match="only elementwise"):
+        P.trace_loss(lambda yh, y: np.sum((yh - y) ** 2))
+    with pytest.raises(TypeError):
+        P.trace_loss(lambda yh, y: 1.0)
+
+
+def test_oracle_custom_loss_equals_builtin_mse_and_mae():
+    spec, theta, X, f, y = util.rbq10_case(300, "tanh", True, 0.1)
+    util.register_loss("my_mse", lambda yh, yy: np.mean((yh - yy) ** 2))
+    util.register_loss("my_mae", lambda yh, yy: np.mean(np.abs(yh - yy)))
+    for mine, builtin in (("my_mse", "mse"), ("my_mae", "mae")):
+        l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=builtin)
+        l1, g1, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=mine)
+        assert l1 == pytest.approx(l0, rel=1e-12) and util.relerr(g1, g0) <= 1e-12

@@ -17,6 +17,17 @@ def register_closure(name, fn, params, forcings, targets):
     return ho.program_mech(name, prog.as_dict(), fn)
 
 
+def register_loss(name, fn):
+    """A custom training loss on both sides: returns what the package takes (the callable); the oracle gets the recorded
+    per-sample program plus the function itself under training-loss kind `name`."""
+    from easyhybrid_jl_amd.program import trace_loss
+    wrapped = fn
+    if name == "relative_sq":                        # (a function that returns per-sample terms: the oracle needs the scalar)
+        wrapped = lambda yh, y: np.mean(fn(yh, y))
+    ho.loss_program(name, trace_loss(fn).as_dict(), wrapped)
+    return fn
+
+
 def model_from_spec(spec: ho.HybridSpec):
     mm = ho.MECH[spec.mech][0]
     if spec.nets is not None:
