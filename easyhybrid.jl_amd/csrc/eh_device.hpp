@@ -626,6 +626,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     const bool fusedm = TRAIN && a.fz.gacc != nullptr;
     float f_th = 0.0f, f_m = 0.0f, f_v = 0.0f, f_g = 0.0f, f_cnt = 0.0f, f_sse = 0.0f, f_sy = 0.0f, f_syy = 0.0f, f_bt1 = 0.0f, f_bt2 = 0.0f;
     int f_map = 0;
+    // (and the reduction-map entry of the first element this thread gathers in the epilogue: its load would otherwise sit, a
+    // full memory round trip, between the last barrier and the LDS reads)
+    int f_rcode = 0;
+    if constexpr (TRAIN) f_rcode = (a.rmap && tid < a.n_acc) ? a.rmap[tid] : 0;
     if (fusedm) {
         const EhFused& z = a.fz;
         const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
@@ -1293,7 +1297,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
         float* const gsh = a.fz.gacc ? (P2PM ? a.p2p->stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
-            const int code = a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
+            const int code = e == tid ? f_rcode : a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
             float sum = 0.0f;
             if (nlan == 16) {
                 f32x4 v[NW][4];

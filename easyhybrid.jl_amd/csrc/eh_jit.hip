@@ -280,6 +280,16 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     // (hiprtc has the HIP device runtime built in but no C library headers)
     std::string src = "typedef signed char int8_t; typedef unsigned char uint8_t; typedef int int32_t; typedef unsigned int uint32_t;\n"
                       "typedef long long int64_t; typedef unsigned long long uint64_t;\n";
+    if (const char* dbg = getenv("EH_JIT_DEFINES")) {        // diagnostics: e.g. EH_JIT_DEFINES="EH_STAMPS EH_STAMPS_FINE" (tools/stamps.py)
+        std::string d = dbg;
+        size_t at = 0;
+        while (at < d.size()) {
+            size_t e = d.find(' ', at);
+            if (e == std::string::npos) e = d.size();
+            if (e > at) src += "#define " + d.substr(at, e - at) + " 1\n";
+            at = e + 1;
+        }
+    }
     if (prog) src += "#define EH_JIT_MECH 1\n";
     if (loss) src += "#define EH_JIT_LOSS 1\n";
     if (spec) {

@@ -1,4 +1,5 @@
-"""Diagnostic: phase breakdown of the fused step kernel from in-kernel stamps (build with `make STAMPS=1`)."""
+"""Diagnostic: phase breakdown of the fused step kernel from in-kernel stamps.  Either build the library with `make STAMPS=1`,
+or stamp the run-time specialised kernel of a normal build:  EH_JIT_DEFINES="EH_STAMPS" EH_SPECIALIZE=1 EH_JIT_CACHE=0 python tools/stamps.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
