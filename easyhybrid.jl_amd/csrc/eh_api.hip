@@ -689,16 +689,17 @@ static bool jit_wanted(const eh_handle* h, int mode) {
 // the compiled kernels for the handle's current (family, variant, descriptor); builds them on first use; nullptr = not available
 static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
     const int kf = KFAST(h);
-    const bool closs = h->net.loss == EH_LOSS_PROGRAM;
-    const bool want_p2p = h->specialize && h->p2p_on && !closs;
+    const bool closs = h->net.loss == EH_LOSS_PROGRAM, prog = h->net.mech == EH_MECH_PROGRAM;
+    const bool spec = h->specialize || prog || closs;        // a model that is compiled anyway gets its descriptor baked in as well
+    const bool want_p2p = h->specialize && h->p2p_on && !closs && !prog;
     const int lgen = closs ? h->loss_prog.gen : 0;
     for (auto& e : h->jit)
-        if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == h->specialize && (e.p2p || !want_p2p) && e.loss_gen == lgen &&
+        if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == spec && (e.p2p || !want_p2p) && e.loss_gen == lgen &&
             (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) return e.ok ? &e : nullptr;
-    h->jit.push_back({h->arch, h->variant, kf, h->specialize, want_p2p, h->net, lgen, false, EhJitKernel{}});
+    h->jit.push_back({h->arch, h->variant, kf, spec, want_p2p, h->net, lgen, false, EhJitKernel{}});
     eh_handle_s::JitEntry* je = &h->jit.back();
     std::string log;
-    je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, h->specialize ? &h->net : nullptr, want_p2p, closs ? &h->loss_prog : nullptr, &je->k, &log);
+    je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, spec ? &h->net : nullptr, want_p2p, closs ? &h->loss_prog : nullptr, &je->k, &log);
     if (!je->ok) { h->jit_log = log; h->jit_failed = true; return nullptr; }
     return je;
 }
