@@ -643,7 +643,7 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
             elif kind in CUSTOM_LOSS:            # training_loss::Function (loss_fn.jl): mean over the valid samples of l(yhat, y)
                 pname, closure = CUSTOM_LOSS[kind]
                 _, lfwd, lvjp = MECH[pname]
-                yh, yv = res[t][m].astype(dt), y[m]
+                yh, yv = np.broadcast_to(res[t], (B,))[m].astype(dt), y[m]      # (an output no per-sample input reaches has one element)
                 lpar = {"yhat": yh, "y": yv}
                 lout, laux = lfwd(lpar, {}, dt)
                 value = np.mean(lout["loss"]) if closure is None else dt.type(closure(yh, yv))       # the function itself gives the value

@@ -228,18 +228,22 @@ def test_random_closure_matches_the_oracle(seed, jit):
     theta, X, f, y = _data(spec, {k: (-1.0, 1.0) for k in pg.forcings}, int(rng.integers(1, 700)), 100 + seed, nan_frac=float(rng.choice([0.0, 0.2])))
     eng = util.load_engine(spec, theta, X, f, y)
     eng.set_option("jit", jit)
+    kind = "mse"
+    if jit and n_out == 1 and rng.random() < 0.4:               # a recorded training loss on top of the recorded closure
+        kind = str(rng.choice(sorted(cl.LOSSES)))
+        eng.set_training_loss(util.register_loss(kind, cl.LOSSES[kind]))
     loss, grad, nv = eng.loss_and_grad()
     assert eng.jit_status()[0] == jit, eng.jit_status()[1]
-    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind)
     assert nv == sum(nv0)
     if sum(nv0):
         # The bar is 1e-5 against the fp64 oracle, widened where fp32 itself cannot hold it: a gradient that is a small remainder
         # of cancelling per-sample terms, or a `where` whose two sides tie within rounding (the fp32 and fp64 evaluations then
         # take different branches of a discontinuous function).  What the oracle loses when it runs in fp32 measures both.
-        l32, g32, _ = ho.loss_and_grad(spec, theta.astype(np.float32), X, f, y, dtype=np.float32)
+        l32, g32, _ = ho.loss_and_grad(spec, theta.astype(np.float32), X, f, y, dtype=np.float32, kind=kind)
         lbar = max(TOL, 30.0 * abs(l32 - l0) / abs(l0))
         gbar = max(2.0 * TOL, 30.0 * util.relerr(g32, g0))      # (2e-5 floor: 4 of 6 000 random cases sit at 1.05e-5 .. 1.8e-5; the curated tests above hold 1e-5)
-        info = f"seed {seed}: B={X.shape[1]} ops={len(pg.code)} loss hip={loss!r} fp64={l0!r} fp32={l32!r} hidden={hidden} neural={neural} glob={glob}"
+        info = f"seed {seed}: kind={kind} B={X.shape[1]} ops={len(pg.code)} loss hip={loss!r} fp64={l0!r} fp32={l32!r} hidden={hidden} neural={neural} glob={glob}"
         assert abs(loss - l0) <= lbar * abs(l0) + 1e-9, info
         if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
             assert util.relerr(grad, g0) <= gbar, info
