@@ -441,6 +441,7 @@ struct eh_handle_s {
     float* p2p_stage = nullptr;
     unsigned* p2p_ctr = nullptr;    // [0] workgroup counter, [1] error flag, [2] self-test mismatches
     EhP2P* p2p_dev = nullptr;
+    EhP2P p2p_host{};               // the same descriptor, handed to the step kernels by value
     void* p2p_peer[EH_GSHARDS] = {nullptr};
     long long gstep = 0;
     float* pending_loss = nullptr;
@@ -1296,6 +1297,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
     z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
     a.p2p = h->p2p_on ? h->p2p_dev : nullptr;
+    if (h->p2p_on) a.p2pv = h->p2p_host;
     a.p2p_seq = h->p2p_on ? ++h->p2p_seq : 0u;
     if (int rc = bn_prepare(h, sp, idx, first, count, true, &a)) return rc;
     const int grid = grid_for(h, count);
@@ -1804,6 +1806,7 @@ int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride) 
     P.stage = h->p2p_stage; P.counter = h->p2p_ctr; P.err = (int*)(h->p2p_ctr + 1);
     P.world = h->p2p_world; P.rank = h->p2p_rank;
     HIPCHK(h, hipMemcpy(h->p2p_dev, &P, sizeof P, hipMemcpyHostToDevice));
+    h->p2p_host = P;
     h->p2p_on = true;
     return EH_OK;
 }

@@ -6,8 +6,9 @@ import numpy as np
 from tests import util
 B = 65536
 spec, theta, X, f, y = util.rbq10_case(8 * B, "tanh", True, 0.0)
+SPEC = int(os.environ.get("EH_TOOL_SPECIALIZE", "1"))        # the run-time specialised kernels (what bench.py runs), 0 = built ahead of time
 for mode in ("plain fused", "p2p loopback"):
-    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_option("fused_update", 1)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_option("fused_update", 1); eng.set_option("specialize", SPEC)
     if mode != "plain fused":
         hd = eng.p2p_init(1, 0); eng.p2p_attach([hd]); assert eng.p2p_selftest(4)
     for i in range(200): eng.dp_fused_step((i % 8) * B, B)
@@ -15,7 +16,7 @@ for mode in ("plain fused", "p2p loopback"):
     t0 = time.perf_counter()
     for i in range(3000): eng.dp_fused_step((i % 8) * B, B)
     eng.synchronize()
-    print(f"{mode}: {1e6 * (time.perf_counter() - t0) / 3000:.2f} us/step", flush=True)
+    print(f"{mode}: {1e6 * (time.perf_counter() - t0) / 3000:.2f} us/step (kernels compiled at run time: {eng.jit_status()[0]})", flush=True)
     th = eng.get_params(); eng.close()
     if mode == "plain fused": th0 = th
 print("max |theta_p2p - theta_plain| =", float(np.max(np.abs(th - th0))))
