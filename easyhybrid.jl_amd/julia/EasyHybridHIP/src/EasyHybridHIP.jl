@@ -126,11 +126,10 @@ end
 lift(t::Tape, x::Tr) = x
 lift(t::Tape, x::Real) = (isfinite(x) || throw(ArgumentError("constant $x in a mechanistic program")); Tr(t, node!(t, (:const, Float32(x)))))
 rec(op::Symbol, a::Tr, rest...) = Tr(a.tape, node!(a.tape, (op, a.id, (lift(a.tape, r).id for r in rest)...)))
-rec(op::Symbol, a::Real, b::Tr, rest...) = rec(op, lift(b.tape, a), b, rest...)
 for (f, op) in ((:+, :add), (:-, :sub), (:*, :mul), (:/, :div), (:max, :max), (:min, :min))
     @eval Base.$f(a::Tr, b::Tr) = rec($(QuoteNode(op)), a, b)
     @eval Base.$f(a::Tr, b::Real) = rec($(QuoteNode(op)), a, b)
-    @eval Base.$f(a::Real, b::Tr) = rec($(QuoteNode(op)), a, b)
+    @eval Base.$f(a::Real, b::Tr) = rec($(QuoteNode(op)), lift(b.tape, a), b)
 end
 for (f, op) in ((:-, :neg), (:exp, :exp), (:log, :log), (:sqrt, :sqrt), (:tanh, :tanh), (:abs, :abs), (:sin, :sin), (:cos, :cos))
     @eval Base.$f(a::Tr) = rec($(QuoteNode(op)), a)
@@ -145,15 +144,25 @@ sigmoid(a::Tr) = rec(:sigmoid, a)
 Base.:^(a::Tr, b::Tr) = rec(:pow, a, b)                                   # base > 0
 function Base.:^(a::Tr, n::Integer)                                       # products: valid for negative bases too
     n == 0 && return lift(a.tape, 1.0f0)
-    r = Base.power_by_squaring(a, abs(n))
+    r = nothing; b = a; k = abs(n)
+    while k > 0
+        isodd(k) && (r = r === nothing ? b : r * b)
+        k >>= 1
+        k > 0 && (b = b * b)
+    end
     return n > 0 ? r : inv(r)
 end
 Base.:^(a::Tr, b::Real) = isinteger(b) && abs(b) <= 8 ? a^Int(b) : (b == 0.5 ? sqrt(a) : rec(:pow, a, b))
-Base.:^(a::Real, b::Tr) = (a > 0 || throw(ArgumentError("power with the non-positive constant base $a")); rec(:pow, a, b))
-Base.:>(a::Tr, b::Tr) = TrBool(rec(:gt, a, b));  Base.:>(a::Tr, b::Real) = TrBool(rec(:gt, a, b));  Base.:>(a::Real, b::Tr) = TrBool(rec(:gt, a, b))
-Base.:<(a::Tr, b::Tr) = b > a;  Base.:<(a::Tr, b::Real) = b > a;  Base.:<(a::Real, b::Tr) = b > a
-Base.:>=(a::Union{Tr, Real}, b::Tr) = TrBool(1.0f0 - (b > a).v);  Base.:>=(a::Tr, b::Real) = TrBool(1.0f0 - (b > a).v)
-Base.:<=(a::Union{Tr, Real}, b::Tr) = b >= a;  Base.:<=(a::Tr, b::Real) = b >= a
+Base.:^(a::Real, b::Tr) = (a > 0 || throw(ArgumentError("power with the non-positive constant base $a")); rec(:pow, lift(b.tape, a), b))
+gt(a::Tr, b) = TrBool(rec(:gt, a, b))
+gt(a::Real, b::Tr) = TrBool(rec(:gt, lift(b.tape, a), b))
+ge(a, b) = TrBool(1.0f0 - gt(b, a).v)                                     # a >= b  <=>  !(b > a)
+for (A, B) in ((:Tr, :Tr), (:Tr, :Real), (:Real, :Tr))                    # (every pair spelled out: Tr <: Real, so a Union would be ambiguous)
+    @eval Base.:>(a::$A, b::$B) = gt(a, b)
+    @eval Base.:<(a::$A, b::$B) = gt(b, a)
+    @eval Base.:>=(a::$A, b::$B) = ge(a, b)
+    @eval Base.:<=(a::$A, b::$B) = ge(b, a)
+end
 Base.ifelse(c::TrBool, a::Union{Tr, Real}, b::Union{Tr, Real}) = rec(:select, c.v, a, b)
 Base.clamp(x::Tr, lo::Real, hi::Real) = min(max(x, lo), hi)
 
