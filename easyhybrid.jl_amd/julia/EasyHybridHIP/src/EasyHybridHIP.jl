@@ -154,7 +154,8 @@ function Base.:^(a::Tr, n::Integer)                                       # prod
 end
 Base.:^(a::Tr, b::Real) = isinteger(b) && abs(b) <= 8 ? a^Int(b) : (b == 0.5 ? sqrt(a) : rec(:pow, a, b))
 Base.:^(a::Real, b::Tr) = (a > 0 || throw(ArgumentError("power with the non-positive constant base $a")); rec(:pow, lift(b.tape, a), b))
-gt(a::Tr, b) = TrBool(rec(:gt, a, b))
+gt(a::Tr, b::Tr) = TrBool(rec(:gt, a, b))
+gt(a::Tr, b::Real) = TrBool(rec(:gt, a, b))
 gt(a::Real, b::Tr) = TrBool(rec(:gt, lift(b.tape, a), b))
 ge(a, b) = TrBool(1.0f0 - gt(b, a).v)                                     # a >= b  <=>  !(b > a)
 for (A, B) in ((:Tr, :Tr), (:Tr, :Real), (:Real, :Tr))                    # (every pair spelled out: Tr <: Real, so a Union would be ambiguous)
