@@ -18,6 +18,7 @@ EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
 EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT = 0, 1, 2, 3, 4, 5
 
 ACTIVATIONS = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
+EH_ACT_PER_NET = 5        # MultiNN: net k uses net_activation[k]
 OPT_RULES = {"Adam": 0, "AdamW": 1, "RMSProp": 2, "Descent": 3}
 TRAINING_LOSSES = {"mse": 0, "rmse": 1, "mae": 2, "nseLoss": 3, "pearsonLoss": 4, "kgeLoss": 5, "pbkgeLoss": 6}
 PAR_NEURAL, PAR_GLOBAL, PAR_FIXED = 0, 1, 2
@@ -34,6 +35,7 @@ class ModelDesc(C.Structure):
         ("n_forcings", C.c_int32), ("forcing_index", C.c_int32 * EH_MAX_FORC),
         ("n_targets", C.c_int32), ("target_output", C.c_int32 * EH_MAX_TARG),
         ("n_nets", C.c_int32), ("net_n_predictors", C.c_int32 * EH_MAX_NETS), ("net_hidden", (C.c_int32 * EH_MAX_HIDDEN) * EH_MAX_NETS),
+        ("net_activation", C.c_int32 * EH_MAX_NETS),
         ("prog_len", C.c_int32), ("prog_n_const", C.c_int32), ("prog_n_forc", C.c_int32), ("prog_n_out", C.c_int32),
         ("prog_out", C.c_int32 * EH_MAX_PROG_OUT), ("prog_code", C.c_uint32 * EH_MAX_PROG), ("prog_const", C.c_float * EH_MAX_PROG_CONST),
     ]

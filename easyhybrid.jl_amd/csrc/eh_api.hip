@@ -683,15 +683,16 @@ static bool arch_fits(const EhArchInfo* A, int need) {
 // switches the handle to the kernels built ahead of time for good); everything else runs the table entry.
 static bool jit_wanted(const eh_handle* h, int mode) {
     const bool prog = h->net.mech == EH_MECH_PROGRAM, closs = h->net.loss == EH_LOSS_PROGRAM;
+    if (mode == EH_MODE_TRAIN_P2P && h->act == EH_ACT_PER_NET) return false;
     if (mode == EH_MODE_TRAIN_P2P) return h->jit_on && !h->jit_failed && h->specialize && !prog && !closs && !h->arch->wide;
-    if (closs) return true;          // a recorded loss exists in run-time compiled kernels only
+    if (closs || h->act == EH_ACT_PER_NET) return mode != EH_MODE_TRAIN_P2P;          // a recorded loss / per-net activations exist in run-time compiled kernels only
     return h->jit_on && !h->jit_failed && (h->specialize || prog);
 }
 // the compiled kernels for the handle's current (family, variant, descriptor); builds them on first use; nullptr = not available
 static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
     const int kf = KFAST(h);
     const bool closs = h->net.loss == EH_LOSS_PROGRAM, prog = h->net.mech == EH_MECH_PROGRAM;
-    const bool spec = h->specialize || prog || closs;        // a model that is compiled anyway gets its descriptor baked in as well
+    const bool spec = h->specialize || prog || closs || h->act == EH_ACT_PER_NET;        // a model that is compiled anyway gets its descriptor baked in as well
     const bool want_p2p = h->specialize && h->p2p_on && !closs && !prog;
     const int lgen = closs ? h->loss_prog.gen : 0;
     for (auto& e : h->jit)
@@ -715,6 +716,7 @@ static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs
         }
         if (h->net.loss == EH_LOSS_PROGRAM && mode != EH_MODE_EVAL) return hipErrorNotSupported;     // no other form of a recorded loss exists
     }
+    if (h->act == EH_ACT_PER_NET) return hipErrorNotSupported;       // (the table below has no such kernel; eh_create made sure the compiled one exists)
     return h->arch->var[h->variant].launch(mode, h->act, KFAST(h), grid, h->stream, &h->net, a);
 }
 
@@ -757,7 +759,17 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         for (int o = 0; o < d->prog_n_out; ++o)
             if (d->prog_out[o] < 0 || !slot_ok((unsigned)d->prog_out[o], d->prog_len)) return fail(nullptr, EH_EINVAL, "eh_create: program output %d names slot %d", o, d->prog_out[o]);
     }
-    if (d->activation < 0 || d->activation > EH_ACT_IDENTITY) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d", d->activation);
+    if (d->activation < 0 || d->activation > EH_ACT_PER_NET) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d", d->activation);
+    int act = d->activation;
+    if (act == EH_ACT_PER_NET) {             // activation::NamedTuple of the MultiNN constructor (GenericHybridModel.jl:168-176)
+        if (d->n_nets < 1 || d->n_nets > EH_MAX_NETS) return fail(nullptr, EH_EINVAL, "eh_create: per-net activations need the MultiNN form (n_nets = %d)", d->n_nets);
+        bool same = true;
+        for (int k = 0; k < d->n_nets; ++k) {
+            if (d->net_activation[k] < 0 || d->net_activation[k] > EH_ACT_IDENTITY) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d for net %d", d->net_activation[k], k);
+            same = same && d->net_activation[k] == d->net_activation[0];
+        }
+        if (same) act = d->net_activation[0];          // one activation after all: the kernels built ahead of time
+    }
     if (d->n_params != mi.n_par) return fail(nullptr, EH_EINVAL, "eh_create: model %d takes %d parameters, descriptor has %d", d->mech, mi.n_par, d->n_params);
     if (d->n_predictors < 1) return fail(nullptr, EH_EINVAL, "eh_create: n_predictors must be >= 1");
     if (d->n_hidden < 1 || d->n_hidden > EH_MAX_HIDDEN) return fail(nullptr, EH_EINVAL, "eh_create: n_hidden must be 1..%d", EH_MAX_HIDDEN);
@@ -857,7 +869,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     n.g_off = off;
     n.n_theta = off + G;
-    h->act = d->activation; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
+    h->act = act; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
     n.mech = d->mech; n.n_par = d->n_params;
     for (int j = 0; j < d->n_params; ++j) {
         n.par_kind |= (unsigned)d->param_kind[j] << (2 * j);
@@ -967,6 +979,11 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipStreamSynchronize(h->stream));
     }
 #undef HIPCHK_C
+    if (h->act == EH_ACT_PER_NET && !jit_entry(h)) {         // built now, so that a missing run-time compiler is an error of the constructor
+        const std::string log = h->jit_log;
+        eh_destroy(h);
+        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: per-net activations need the run-time compiled kernel, which failed to build: %.600s", log.c_str());
+    }
     *out = h;
     return EH_OK;
 }
@@ -1759,6 +1776,7 @@ int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out,
     if (world < 1 || world > EH_GSHARDS || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_p2p_init: world %d (1..%d), rank %d", world, EH_GSHARDS, rank);
     if (!h->fused) return fail(h, EH_ESTATE, "eh_p2p_init: set the fused_update option first");
     if (h->net.mech == EH_MECH_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the program kernels have no cross-GPU variant (use the all-reduce seam)");
+    if (h->act == EH_ACT_PER_NET) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the per-net activation kernels have no cross-GPU variant (use the all-reduce seam)");
     if (h->p2p_on || h->p2p_alloc) return fail(h, EH_ESTATE, "eh_p2p_init: already initialised");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);

@@ -221,6 +221,54 @@ __device__ __forceinline__ float eh_dact(float s) {
     return 1.0f;
 }
 
+// EH_ACT_PER_NET (MultiNNHybridModel with activation::NamedTuple, GenericHybridModel.jl:168-176): the nets sit side by side in
+// the block-diagonal MLP, so the activation is a function of (layer, row).  Such kernels exist only compiled at run time: the
+// generated header defines eh_row_act(layer, row) -> eh_activation from the descriptor's net widths.  The images hold the
+// pre-activation z for every row (like swish), so value and derivative are both taken from z.
+#ifdef EH_JIT_ROWACT
+#include "eh_jit_rowact.inc"
+#else
+__device__ __forceinline__ int eh_row_act(int, int) { return EH_ACT_IDENTITY; }
+#endif
+template <int ACT> struct EhStoresZ { static constexpr bool value = ACT == EH_ACT_SWISH || ACT == EH_ACT_PER_NET; };
+__device__ __forceinline__ float eh_act_id(int id, float z) {
+    switch (id) {
+        case EH_ACT_TANH: return eh_tanh(z);
+        case EH_ACT_SIGMOID: return eh_sigmoid(z);
+        case EH_ACT_RELU: return fmaxf(z, 0.0f);
+        case EH_ACT_SWISH: return z * eh_sigmoid(z);
+        default: return z;
+    }
+}
+__device__ __forceinline__ float eh_dact_z_id(int id, float z) {       // act'(z) from the pre-activation
+    switch (id) {
+        case EH_ACT_TANH: { const float t = eh_tanh(z); return 1.0f - t * t; }
+        case EH_ACT_SIGMOID: { const float g = eh_sigmoid(z); return g * (1.0f - g); }
+        case EH_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
+        case EH_ACT_SWISH: { const float g = eh_sigmoid(z); return g * (1.0f + z * (1.0f - g)); }
+        default: return 1.0f;
+    }
+}
+// the three things the kernels do with an activation, by (layer, row): z -> h; stored value -> h; stored value -> act'
+template <int ACT>
+__device__ __forceinline__ f32x4 eh_act4_rows(f32x4 z, int l, int row0) {      // rows row0 .. row0 + 3
+    if constexpr (ACT == EH_ACT_PER_NET)
+        return f32x4{eh_act_id(eh_row_act(l, row0), z[0]), eh_act_id(eh_row_act(l, row0 + 1), z[1]),
+                     eh_act_id(eh_row_act(l, row0 + 2), z[2]), eh_act_id(eh_row_act(l, row0 + 3), z[3])};
+    else return eh_act4<ACT>(z);
+}
+template <int ACT>
+__device__ __forceinline__ float eh_hval(float s, int l, int row) {
+    if constexpr (ACT == EH_ACT_PER_NET) return eh_act_id(eh_row_act(l, row), s);
+    else if constexpr (ACT == EH_ACT_SWISH) return s * eh_sigmoid(s);
+    else return s;
+}
+template <int ACT>
+__device__ __forceinline__ float eh_dact_row(float s, int l, int row) {
+    if constexpr (ACT == EH_ACT_PER_NET) return eh_dact_z_id(eh_row_act(l, row), s);
+    else return eh_dact<ACT>(s);
+}
+
 // cross-lane sums on the DPP network (no LDS round trips): rotate-and-add inside each row of 16
 // lanes, then combine the four rows through scalar lane reads.
 template <int CTRL>
@@ -546,7 +594,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     constexpr bool K1 = (FAST & 1) != 0, PS = (FAST & 2) != 0;
     constexpr bool PROG = (FAST & 4) != 0;                // EH_MECH_PROGRAM: the mechanistic stage interprets a.prog
     static_assert(!PROG || FAST == 4, "the program kernels are generic kernels");
-    constexpr bool KEEPH = TRAIN && ACT != EH_ACT_SWISH && NL * NBH * NT * 4 <= 64;   // activations stay in registers for act'
+    constexpr bool KEEPH = TRAIN && !EhStoresZ<ACT>::value && NL * NBH * NT * 4 <= 64;   // activations stay in registers for act'
     constexpr int NHS = KEEPH ? NL : 1, NHM = KEEPH ? NBH : 1, NHT = KEEPH ? NT : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;
@@ -864,11 +912,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f32x4 z4 = h[m][t], hv4 = eh_act4<ACT>(z4);
+                const f32x4 z4 = h[m][t], hv4 = eh_act4_rows<ACT>(z4, 0, 16 * m + 4 * g);
                 h[m][t] = hv4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z4[r] : hv4[r];
+                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = EhStoresZ<ACT>::value ? z4[r] : hv4[r];
                 if constexpr (KEEPH) hs[0][m][t] = h[m][t];
             }
         }
@@ -898,11 +946,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             for (int m = 0; m < NBH; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x4 z4 = hn[m][t], hv4 = eh_act4<ACT>(z4);
+                    const f32x4 z4 = hn[m][t], hv4 = eh_act4_rows<ACT>(z4, l, 16 * m + 4 * g);
                     h[m][t] = hv4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)      // the last layer's image is only read back for act' / dWo when those do not have it in registers
-                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = (ACT == EH_ACT_SWISH) ? z4[r] : hv4[r];
+                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = EhStoresZ<ACT>::value ? z4[r] : hv4[r];
                     if constexpr (KEEPH) hs[l < NHS ? l : 0][m < NHM ? m : 0][t < NHT ? t : 0] = h[m][t];
                 }
         }
@@ -1089,9 +1137,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     for (int r = 0; r < 4; ++r) {
                         const int ad = (16 * m + 4 * g + r) * SR + 16 * t + c;
                         const float sv = KEEPH ? hs[NL - 1 < NHS ? NL - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hl[ad];
-                        const float hv = (ACT == EH_ACT_SWISH) ? sv * eh_sigmoid(sv) : sv;
+                        const float hv = eh_hval<ACT>(sv, NL - 1, 16 * m + 4 * g + r);
                         aWoV[m][r] = fmaf(dOt[t], hv, aWoV[m][r]);
-                        const float d = w4[r] * dOt[t] * eh_dact<ACT>(sv);
+                        const float d = w4[r] * dOt[t] * eh_dact_row<ACT>(sv, NL - 1, 16 * m + 4 * g + r);
                         dz[m][t][r] = d;
                         if constexpr (DZ_LAST) DZ[ad] = d;
                     }
@@ -1114,9 +1162,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     f32x4 b4 = *(const f32x4*)&Hl[(16 * n + c) * SR + 16 * t + 4 * g];
-                    if (ACT == EH_ACT_SWISH) {
+                    if (EhStoresZ<ACT>::value) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) b4[s] = b4[s] * eh_sigmoid(b4[s]);
+                        for (int s = 0; s < 4; ++s) b4[s] = eh_hval<ACT>(b4[s], NL - 1, 16 * n + c);
                     }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) aWo[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWo[n], 0, 0, 0);
@@ -1142,7 +1190,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     for (int r = 0; r < 4; ++r) {
                         const int ad = (16 * m + 4 * g + r) * SR + 16 * t + c;
                         const float sv = KEEPH ? hs[NL - 1 < NHS ? NL - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hl[ad];
-                        const float d = dh[t][r] * eh_dact<ACT>(sv);
+                        const float d = dh[t][r] * eh_dact_row<ACT>(sv, NL - 1, 16 * m + 4 * g + r);
                         dz[m][t][r] = d;
                         if constexpr (DZ_LAST) DZ[ad] = d;
                     }
@@ -1165,9 +1213,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         f32x4 b4 = *(const f32x4*)&Hp[(16 * n + c) * SR + 16 * t + 4 * g];
-                        if (ACT == EH_ACT_SWISH) {
+                        if (EhStoresZ<ACT>::value) {
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) b4[s] = b4[s] * eh_sigmoid(b4[s]);
+                            for (int s = 0; s < 4; ++s) b4[s] = eh_hval<ACT>(b4[s], l - 1, 16 * n + c);
                         }
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
@@ -1201,7 +1249,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     for (int r = 0; r < 4; ++r) {
                         const int ad = (16 * m + 4 * g + r) * SR + 16 * t + c;
                         const float sv = KEEPH ? hs[l - 1 < NHS ? l - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hp[ad];
-                        const float d = dn[m][t][r] * eh_dact<ACT>(sv);
+                        const float d = dn[m][t][r] * eh_dact_row<ACT>(sv, l - 1, 16 * m + 4 * g + r);
                         dz[m][t][r] = d;
                         if (need_dz) DZ[ad] = d;
                     }

@@ -271,12 +271,36 @@ std::string eh_jit_mech_source(const eh_model_desc& d) {
     return s;
 }
 
+// eh_row_act(layer, row) for EH_ACT_PER_NET: net k owns rows [sum_{j<k} net_hidden[j][l], + net_hidden[k][l]) of hidden layer l
+// (the block placement of eh_create); rows past the last net are padding (zero weights on both sides): identity
+static std::string eh_jit_rowact_source(const eh_model_desc& d) {
+    std::string s = "__device__ __forceinline__ int eh_row_act(int l, int row) {\n";
+    char b[96];
+    for (int l = 0; l < d.n_hidden; ++l) {
+        snprintf(b, sizeof b, "    if (l == %d) return", l);
+        s += b;
+        int r0 = 0;
+        for (int k = 0; k < d.n_nets; ++k) {
+            r0 += d.net_hidden[k][l];
+            snprintf(b, sizeof b, " row < %d ? %d :", r0, d.net_activation[k]);
+            s += b;
+        }
+        snprintf(b, sizeof b, " %d;\n", (int)EH_ACT_IDENTITY);
+        s += b;
+    }
+    snprintf(b, sizeof b, "    return %d;\n}\n", (int)EH_ACT_IDENTITY);
+    s += b;
+    return s;
+}
+
 bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
                   const EhLossProg* loss, EhJitKernel* out, std::string* log) {
     const EhVariant& V = A->var[variant];
     const bool prog = d.mech == EH_MECH_PROGRAM;
     const std::string mech = prog ? eh_jit_mech_source(d) : std::string();
     const std::string lsrc = loss ? eh_jit_loss_source(*loss) : std::string();
+    const bool rowact = act == EH_ACT_PER_NET;
+    const std::string rsrc = rowact ? eh_jit_rowact_source(d) : std::string();
     // (hiprtc has the HIP device runtime built in but no C library headers)
     std::string src = "typedef signed char int8_t; typedef unsigned char uint8_t; typedef int int32_t; typedef unsigned int uint32_t;\n"
                       "typedef long long int64_t; typedef unsigned long long uint64_t;\n";
@@ -292,6 +316,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     }
     if (prog) src += "#define EH_JIT_MECH 1\n";
     if (loss) src += "#define EH_JIT_LOSS 1\n";
+    if (rowact) src += "#define EH_JIT_ROWACT 1\n";
     if (spec) {
         char b[512];
         snprintf(b, sizeof b, "#define EH_SPEC_NET %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %uu, %uu, %uu, %uu\n", spec->P, spec->K, spec->G, spec->T, spec->F,
@@ -299,11 +324,12 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
         src += b;
     }
     src += A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
-    const char* hnames[5] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", nullptr, nullptr};
-    const char* hsrc[5] = {eh_src_device, eh_src_wide, eh_src_public, nullptr, nullptr};
+    const char* hnames[6] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", nullptr, nullptr, nullptr};
+    const char* hsrc[6] = {eh_src_device, eh_src_wide, eh_src_public, nullptr, nullptr, nullptr};
     int nh = 3;
     if (prog) { hnames[nh] = "eh_jit_mech.inc"; hsrc[nh++] = mech.c_str(); }
     if (loss) { hnames[nh] = "eh_jit_loss.inc"; hsrc[nh++] = lsrc.c_str(); }
+    if (rowact) { hnames[nh] = "eh_jit_rowact.inc"; hsrc[nh++] = rsrc.c_str(); }
     hiprtcProgram hp = nullptr;
     if (hiprtcCreateProgram(&hp, src.c_str(), "eh_jit.hip", nh, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
     const int nmode = (with_p2p && !A->wide && !prog) ? 3 : 2;
@@ -324,7 +350,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
             int ver[2] = {0, 0};
             hiprtcVersion(&ver[0], &ver[1]);
             h = fnv(h, ver, sizeof ver);
-            h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size()); h = fnv(h, lsrc.data(), lsrc.size());
+            h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size()); h = fnv(h, lsrc.data(), lsrc.size()); h = fnv(h, rsrc.data(), rsrc.size());
             h = fnv(h, eh_src_device, sizeof eh_src_device); h = fnv(h, eh_src_wide, sizeof eh_src_wide); h = fnv(h, eh_src_public, sizeof eh_src_public);
             for (int m = 0; m < nmode; ++m) h = fnv(h, name[m], strlen(name[m]));
             for (const char* o : opts) h = fnv(h, o, strlen(o));

@@ -189,13 +189,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
     const int ksK = net.K < 4 ? net.K : 4;
 
     // B operand of an MFMA whose k index runs over the features of block q: lane (c, g), step s <-> feature 16q+4g+s, sample 16t+c
-    auto load_b = [&](const float* img, int q, f32x4 (&bq)[NT], bool unswish) {
+    auto load_b = [&](const float* img, int q, f32x4 (&bq)[NT], bool unswish, int layer) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float v = img[(16 * q + 4 * g + s) * SR + 16 * t + c];
-                if (ACT == EH_ACT_SWISH && unswish) v = v * eh_sigmoid(v);      // the image holds z for swish
+                if (EhStoresZ<ACT>::value && unswish) v = eh_hval<ACT>(v, layer, 16 * q + 4 * g + s);      // the image holds z for swish / per-net activations
                 bq[t][s] = v;
             }
     };
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x4 z4 = acc[mm][t], hv4 = (ACT == EH_ACT_SWISH && TRAIN) ? z4 : eh_act4<ACT>(z4);
+                    const f32x4 z4 = acc[mm][t], hv4 = (EhStoresZ<ACT>::value && TRAIN) ? z4 : eh_act4_rows<ACT>(z4, 0, 16 * (m0 + mm) + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) HS[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = hv4[r];
                 }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #pragma unroll
             for (int q = 0; q < NBH; ++q) {
                 f32x4 bq[NT];
-                load_b(Hp, q, bq, TRAIN);
+                load_b(Hp, q, bq, TRAIN, l - 1);
 #pragma unroll
                 for (int mm = 0; mm < MB; ++mm) {
                     const f32x4 a4 = *(const f32x4*)&W[(16 * (m0 + mm) + c) * SH + 16 * q + 4 * g];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x4 z4 = acc[mm][t], hv4 = (ACT == EH_ACT_SWISH && TRAIN) ? z4 : eh_act4<ACT>(z4);
+                    const f32x4 z4 = acc[mm][t], hv4 = (EhStoresZ<ACT>::value && TRAIN) ? z4 : eh_act4_rows<ACT>(z4, l, 16 * (m0 + mm) + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Hl[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = hv4[r];
                 }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
             for (int qq = 0; qq < MB; ++qq) {
                 const int q = m0 + qq;
                 f32x4 bq[NT];
-                load_b(Hp, q, bq, TRAIN);
+                load_b(Hp, q, bq, TRAIN, NL - 1);
                 const f32x4 a4 = *(const f32x4*)&W[c * SH + 16 * q + 4 * g];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -468,9 +468,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     f32x4 b4 = *(const f32x4*)&Hl[(16 * m + c) * SR + 16 * t + 4 * g];
-                    if (ACT == EH_ACT_SWISH) {
+                    if (EhStoresZ<ACT>::value) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) b4[s] = b4[s] * eh_sigmoid(b4[s]);
+                        for (int s = 0; s < 4; ++s) b4[s] = eh_hval<ACT>(b4[s], NL - 1, 16 * m + c);
                     }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) aWo[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWo[mm], 0, 0, 0);
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dh[t][r] * eh_dact<ACT>(Hl[(16 * m + 4 * g + r) * SR + 16 * t + c]);
+                    for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dh[t][r] * eh_dact_row<ACT>(Hl[(16 * m + 4 * g + r) * SR + 16 * t + c], NL - 1, 16 * m + 4 * g + r);
                     aB[NL - 1][mm] += dzr[mm][t];
                 }
             }
@@ -519,9 +519,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         f32x4 b4 = *(const f32x4*)&Hp[(16 * n + c) * SR + 16 * t + 4 * g];
-                        if (ACT == EH_ACT_SWISH) {
+                        if (EhStoresZ<ACT>::value) {
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) b4[s] = b4[s] * eh_sigmoid(b4[s]);
+                            for (int s = 0; s < 4; ++s) b4[s] = eh_hval<ACT>(b4[s], l - 1, 16 * n + c);
                         }
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #pragma unroll
             for (int q = 0; q < NBH; ++q) {
                 f32x4 bq[NT];
-                load_b(DZ, q, bq, false);
+                load_b(DZ, q, bq, false, 0);
 #pragma unroll
                 for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ad = (16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c;
-                        const float d = dn[mm][t][r] * eh_dact<ACT>(Hp[ad]);
+                        const float d = dn[mm][t][r] * eh_dact_row<ACT>(Hp[ad], l - 1, 16 * (m0 + mm) + 4 * g + r);
                         dzr[mm][t][r] = d;
                         DZ[ad] = d;
                     }

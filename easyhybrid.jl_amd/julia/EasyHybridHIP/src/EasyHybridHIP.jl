@@ -45,6 +45,7 @@ struct EhModelDesc
     n_nets::Int32                                   # 0 = SingleNNHybridModel
     net_n_predictors::NTuple{8, Int32}
     net_hidden::NTuple{32, Int32}                   # [8 nets][4 layers], row-major like the C array
+    net_activation::NTuple{8, Int32}                # read when activation == 5 (EH_ACT_PER_NET): activation id of net k
     prog_len::Int32                                 # EH_MECH_PROGRAM only (a recorded closure, see `record_program`)
     prog_n_const::Int32
     prog_n_forc::Int32
@@ -271,7 +272,7 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
         length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32),
-        Int32(0), pad(Int32[], 8, Int32), pad(Int32[], 32, Int32),       # MultiNN form: fill n_nets / net_* (see include/easyhybrid_hip.h)
+        Int32(0), pad(Int32[], 8, Int32), pad(Int32[], 32, Int32), pad(Int32[], 8, Int32),    # MultiNN form: fill n_nets / net_* (see include/easyhybrid_hip.h)
         (pg === nothing ? (Int32(0), Int32(0), Int32(0), Int32(0), pad(Int32[], 3, Int32), pad(UInt32[], 64, UInt32), pad(Float32[], 16, Float32)) :
          (Int32(length(pg.code)), Int32(length(pg.consts)), Int32(length(ms.forcings)), Int32(length(pg.out)), pad(pg.out, 3, Int32),
           pad(pg.code, 64, UInt32), pad(pg.consts, 16, Float32)))...)

@@ -201,6 +201,7 @@ class SingleNNHybridModel:
     # MultiNNHybridModel: NNs[name] = Dense shapes of the single-output net predicting `name`, predictor_sets[name] = its columns
     NNs: Optional[Dict[str, List[Tuple[int, int]]]] = None
     predictor_sets: Optional[Dict[str, List[str]]] = None
+    net_activations: Optional[List[str]] = None      # MultiNN with activation::NamedTuple: the activation of net k (None = one for all)
 
     # -- sizes ---------------------------------------------------------------------------------
     @property
@@ -220,8 +221,12 @@ class SingleNNHybridModel:
         return self.n_nn + len(self.global_param_names)
 
     @property
-    def activation(self) -> str:
+    def activation(self):
+        """the name, or {network: name} when the networks differ (the reference keeps the NamedTuple in `config`)"""
         return self.config["activation"]
+
+    def activation_of(self, k: int) -> str:
+        return self.config["activation"] if self.net_activations is None else self.net_activations[k]
 
     # -- LuxCore.initialparameters analogue (GenericHybridModel.jl:236-256) ----------------------
     def initialparameters(self, rng: Union[int, np.random.Generator] = 0) -> np.ndarray:
@@ -230,9 +235,9 @@ class SingleNNHybridModel:
         U(+-1/sqrt(fan_in)).  NumPy's stream, not Julia's Xoshiro -- parity tests inject theta."""
         rng = np.random.default_rng(rng) if not isinstance(rng, np.random.Generator) else rng
         parts = []
-        for net in self.nets:
+        for k, net in enumerate(self.nets):
             for li, (o, i) in enumerate(net):
-                gain = _ACT_GAIN[self.activation] if li < len(net) - 1 else 1.0
+                gain = _ACT_GAIN[self.activation_of(k)] if li < len(net) - 1 else 1.0
                 bw = gain * math.sqrt(3.0 / i)
                 parts.append(rng.uniform(-bw, bw, (o, i)).astype(np.float32).flatten(order="F"))
                 parts.append(rng.uniform(-1 / math.sqrt(i), 1 / math.sqrt(i), o).astype(np.float32))
@@ -288,7 +293,12 @@ class SingleNNHybridModel:
                 d.net_n_predictors[k] = net[0][1]
                 for l, (o, _) in enumerate(net[:-1]):
                     d.net_hidden[k][l] = o
-        d.activation = L.ACTIVATIONS[self.activation]
+        if self.net_activations is not None:       # per-net activations: kernels compiled at run time around the descriptor
+            d.activation = L.EH_ACT_PER_NET
+            for k, a in enumerate(self.net_activations):
+                d.net_activation[k] = L.ACTIVATIONS[a]
+        else:
+            d.activation = L.ACTIVATIONS[self.activation]
         d.scale_nn_outputs = int(self.scale_nn_outputs)
         d.input_batchnorm = int(bool(self.config.get("input_batchnorm", False)))
         d.mech = ms.id
@@ -339,11 +349,14 @@ def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mec
     glob = list(global_param_names or [])
     if not all(n in all_names for n in neural):
         raise AssertionError("neural_param_names ⊆ param_names")
-    if isinstance(activation, dict):
-        acts = {_act_name(a) for a in activation.values()}
-        if len(acts) != 1:
-            raise NotImplementedError("per-network activations are not built: the fused kernel has one activation")
-        act = acts.pop()
+    net_acts = None
+    if isinstance(activation, dict):               # activation::NamedTuple (GenericHybridModel.jl:168-176)
+        if not isinstance(hidden_layers, dict):    # the reference reads activation[nn_name] only next to hidden_layers[nn_name]
+            raise TypeError("activation given per network needs hidden_layers given per network as well")
+        net_acts = [_act_name(activation[k]) for k in neural]
+        act = net_acts[0]
+        if len(set(net_acts)) == 1:
+            net_acts = None
     else:
         act = _act_name(activation)
     hl = {k: list(hidden_layers[k]) for k in neural} if isinstance(hidden_layers, dict) else {k: list(hidden_layers) for k in neural}
@@ -371,10 +384,11 @@ def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mec
     tot = [sum(hl[k][l] for k in neural) for l in range(nl)]
     NN = [(a, b) for a, b in zip(tot + [len(neural)], [len(flat_pred)] + tot)]     # the block-diagonal envelope
     fixed = [n for n in all_names if n not in neural and n not in glob]
-    config = dict(hidden_layers=hidden_layers, activation=act, scale_nn_outputs=scale_nn_outputs, input_batchnorm=input_batchnorm,
-                  start_from_default=start_from_default, **kwargs)
+    config = dict(hidden_layers=hidden_layers, activation=act if net_acts is None else dict(zip(neural, net_acts)),
+                  scale_nn_outputs=scale_nn_outputs, input_batchnorm=input_batchnorm, start_from_default=start_from_default, **kwargs)
     return SingleNNHybridModel(NN, flat_pred, forcing, targets, ms, parameters, neural, glob, fixed, bool(scale_nn_outputs),
-                               bool(start_from_default), config, NNs=NNs, predictor_sets={k: list(v) for k, v in predictors.items()})
+                               bool(start_from_default), config, NNs=NNs, predictor_sets={k: list(v) for k, v in predictors.items()},
+                               net_activations=net_acts)
 
 
 MultiNNHybridModel = SingleNNHybridModel      # one class serves both; `.NNs is not None` marks the multi-network form

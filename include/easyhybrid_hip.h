@@ -53,7 +53,9 @@ typedef enum eh_status {
 } eh_status;
 
 /* activation of the hidden Dense layers (src/models/NNModels.jl:225-230; last layer is linear) */
-typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 2, EH_ACT_SWISH = 3, EH_ACT_IDENTITY = 4 } eh_activation;
+typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 2, EH_ACT_SWISH = 3, EH_ACT_IDENTITY = 4,
+                             EH_ACT_PER_NET = 5 /* MultiNN only: net k uses net_activation[k] (activation::NamedTuple,
+                                                   GenericHybridModel.jl:168-176); such kernels are compiled at run time */ } eh_activation;
 
 /* registry of mechanistic models (the reference takes an arbitrary Julia closure,
  * src/models/GenericHybridModel.jl:425; a closure cannot run in a kernel, so the engine ships
@@ -146,6 +148,7 @@ typedef struct eh_model_desc {
     int32_t n_nets;
     int32_t net_n_predictors[EH_MAX_NETS];
     int32_t net_hidden[EH_MAX_NETS][EH_MAX_HIDDEN];
+    int32_t net_activation[EH_MAX_NETS];     /* read when activation == EH_ACT_PER_NET: eh_activation of net k (TANH..IDENTITY) */
     /* EH_MECH_PROGRAM only (ignored otherwise): n_params parameters, prog_n_forc forcings, prog_n_out outputs */
     int32_t prog_len;                        /* 1..EH_MAX_PROG */
     int32_t prog_n_const;                    /* 0..EH_MAX_PROG_CONST */

@@ -335,6 +335,11 @@ class HybridSpec:
     # MultiNNHybridModel (GenericHybridModel.jl:142-206,458-530): one MLP with ONE output per neural parameter, each on
     # its own predictor rows.  nets[k] = (rows of X feeding net k, hidden widths of net k); None = SingleNN.
     nets: Optional[List[Tuple[List[int], List[int]]]] = None
+    # MultiNN with activation::NamedTuple (GenericHybridModel.jl:168-176): the activation of net k; None = `activation` for all
+    net_activations: Optional[List[str]] = None
+
+    def act_of(self, k: int) -> str:
+        return self.activation if self.net_activations is None else self.net_activations[k]
 
     def __post_init__(self):
         mm = MECH[self.mech][0]
@@ -482,13 +487,13 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
         glob[g] = dt.type(spec.lo(g)) + dt.type(spec.hi(g) - spec.lo(g)) * _sigmoid(r.reshape(1))
     # k2: MLP(s): one chain for SingleNN, one single-output chain per neural parameter for MultiNN
     tapes, outs = [], []
-    for (rows, _), Ws in zip(spec.net_list, nets):
+    for k_net, ((rows, _), Ws) in enumerate(zip(spec.net_list, nets)):
         h = X[rows]
         zs, hs = [], [h]
         for li, (W, b) in enumerate(Ws):
             z = (W @ h + b[:, None]).astype(dt)
             last = li == len(Ws) - 1
-            h = z if last else act_fwd(spec.activation, z).astype(dt)
+            h = z if last else act_fwd(spec.act_of(k_net), z).astype(dt)
             zs.append(z); hs.append(h)
         tapes.append((Ws, zs, hs))
         outs.append(h)
@@ -671,7 +676,7 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         do[k] = d
     # MLP backward (each net sees the rows of dO that belong to its outputs)
     gnets, k0 = [], 0
-    for Ws, zs, hs in tp["nets"]:
+    for k_net, (Ws, zs, hs) in enumerate(tp["nets"]):
         kout = Ws[-1][0].shape[0]
         delta = do[k0:k0 + kout]
         k0 += kout
@@ -680,7 +685,7 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
             W, b = Ws[li]
             gWs.append((delta @ hs[li].T, delta.sum(axis=1)))
             if li > 0:
-                delta = (W.T @ delta) * act_bwd(spec.activation, zs[li - 1], hs[li])
+                delta = (W.T @ delta) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
         gWs.reverse()
         gnets.append(gWs)
     grad = pack(spec, gnets, graw, dt)

@@ -56,7 +56,7 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
     if getattr(spec, "input_batchnorm", False):            # train-mode batch statistics, biased variance, eps = 1e-5
         h = (h - h.mean(dim=1, keepdim=True)) / torch.sqrt(h.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
     X0, outs = h, []
-    for rows, dims in spec.net_list:
+    for k_net, (rows, dims) in enumerate(spec.net_list):
         h = X0[rows]
         for li, (o, i) in enumerate(dims):
             W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)
@@ -64,7 +64,7 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
             b = theta[off:off + o]
             off += o
             z = W @ h + b[:, None]
-            h = z if li == len(dims) - 1 else _act(spec.activation, z)
+            h = z if li == len(dims) - 1 else _act(spec.act_of(k_net), z)
         outs.append(h)
     h = torch.cat(outs, dim=0)
     par = {}

@@ -57,7 +57,15 @@ def _case(seed, fastpath=False):
         cap = (128 if wide else 64) // K
         nets = [([int(r) for r in rw], [int(rng.integers(1, cap + 1)) for _ in range(nl)]) for rw in rows]
         bn = False
-    spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, scale, input_batchnorm=bn, nets=nets)
+    net_acts = None
+    if nets is not None:
+        # activation::NamedTuple: every second MultiNN model gives each net its own activation (a stream of its own, so the
+        # configurations drawn before this existed stay what they were)
+        rng_a = np.random.default_rng(900000 + seed)
+        if rng_a.random() < 0.5:
+            net_acts = [str(a) for a in rng_a.choice(["tanh", "sigmoid", "relu", "swish", "identity"], len(nets))]
+    spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, scale, input_batchnorm=bn, nets=nets,
+                         net_activations=net_acts)
     B = int(rng.choice([1, 7, 31, 32, 33, 64, 257, 1000, 2049]))
     N = B + int(rng.integers(0, 200))
     X = (rng.standard_normal((P, N)) * rng.uniform(0.2, 1.5) + (rng.uniform(-3, 3) if bn else 0.0)).astype(np.float32)

@@ -611,6 +611,61 @@ def test_multinn_hybrid_model(nets, glob):
     eng.close()
 
 
+@pytest.mark.parametrize("nets,acts,glob", [
+    ([([0, 1], [16, 16]), ([1, 2], [8, 8])], ["swish", "tanh"], []),           # per-wave kernel, 24 units side by side
+    ([([0], [24, 12]), ([1, 2, 3], [30, 20])], ["relu", "sigmoid"], []),        # a net boundary inside a 16-row block; 64-wide kernel
+    ([([0, 1], [8]), ([2], [5])], ["tanh", "identity"], []),                    # one hidden layer
+    ([([0, 1, 2], [40, 60]), ([1, 3], [50, 60])], ["sigmoid", "swish"], []),    # 90 / 120 units: the row-split kernel
+    ([([0, 1], [16, 16]), ([2, 3], [16, 16]), ([0, 3], [16, 16])], ["tanh", "relu", "swish"], ["Q10_het", "Q10_root", "Q10_myc"]),
+])
+def test_multinn_per_network_activations(nets, acts, glob):
+    """activation::NamedTuple of the MultiNN constructor (GenericHybridModel.jl:168-176): net k runs activation[k].  On the device
+    the nets are one block-diagonal MLP whose activation depends on the row; that kernel is compiled at run time."""
+    if len(nets) == 3:
+        tab = {"Rb_het": (1.0, 0.0, 5.0), "Rb_root": (1.0, 0.0, 5.0), "Rb_myc": (0.5, 0.0, 3.0),
+               "Q10_het": (2.0, 1.0, 4.0), "Q10_root": (2.0, 1.0, 4.0), "Q10_myc": (2.0, 1.0, 4.0)}
+        mech, neural, tname = "rs_components", ["Rb_het", "Rb_root", "Rb_myc"], "R_soil"
+    else:
+        tab, mech, neural, tname = dict(ho.RBQ10_PARAMS), "rbq10", ["rb", "Q10"], "reco"
+    spec = ho.HybridSpec(4, [1], mech, tab, neural, glob, [tname], "tanh", True, nets=nets, net_activations=acts)
+    rng = np.random.default_rng(9)
+    B = 1100
+    X = rng.standard_normal((4, B)).astype(np.float32)
+    f = {"ta": rng.uniform(0, 30, B).astype(np.float32)}
+    yv = rng.uniform(1, 9, B).astype(np.float32); yv[rng.random(B) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 8, np.float32)
+    eng = util.load_engine(spec, theta, X, f, {tname: yv})
+    njit, jlog = eng.jit_status()
+    assert njit >= 1, jlog                       # no kernel built ahead of time can run this model
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, {tname: yv})
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    out = eng.forward(0)
+    assert util.relerr(out[tname], ref[tname]) <= TOL
+    for n in neural:
+        assert util.relerr(out["parameters"][n], ref["parameters"][n]) <= TOL
+    m, _ = eng.eval(0)
+    yy = yv.astype(np.float64)
+    assert m[0]["mse"] == pytest.approx(ho.loss_fn(ref[tname], yy, ~np.isnan(yy), "mse"), rel=3e-5)
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 150, 150) for i in range(7)]
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, {tname: yv}, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    if max(sum(h[l] for _, h in nets) for l in range(len(nets[0][1]))) <= 64:
+        eng.set_option("fused_update", 1)        # one kernel per step: the same compiled kernel, update in its prologue
+        more = [(i * 100, 100) for i in range(3)]
+        for b in more:
+            eng.train_step(*b, want_loss=False)
+        th_ref, _ = ho.train_steps(spec, theta, X, f, {tname: yv}, batches + more, dtype=np.float32)
+        assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+        with pytest.raises(NotImplementedError):
+            eng.p2p_init(1, 0)                   # no cross-GPU variant of these kernels: the all-reduce seam instead
+    eng.close()
+
+
 # ----------------------------------------------------------------------------------------------
 # multi-target losses through the multi-output FluxPart model (compute_loss.jl:50-53,115-126: L = sum_t mean_t)
 # ----------------------------------------------------------------------------------------------

@@ -110,3 +110,23 @@ def test_multinn_constructor_mirrors_reference():
     assert th.size == m.n_theta and nets["Q10"][0][0].shape == (8, 1) and glob == {}
     with pytest.raises(NotImplementedError):
         eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [], hidden_layers={"rb": [16], "Q10": [8, 4]})
+
+
+def test_multinn_per_network_activations():
+    # activation::NamedTuple next to hidden_layers::NamedTuple (GenericHybridModel.jl:168-176): net k gets activation[k]
+    m = eh.constructHybridModel({"rb": ["sw_pot", "dsw_pot"], "Q10": ["dsw_pot"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [],
+                                hidden_layers={"rb": [16, 16], "Q10": [8, 4]}, activation={"rb": "swish", "Q10": "tanh"})
+    assert m.net_activations == ["swish", "tanh"] and m.activation == {"rb": "swish", "Q10": "tanh"}
+    d = m.to_desc()
+    assert d.activation == eh._lib.EH_ACT_PER_NET and list(d.net_activation)[:2] == [eh._lib.ACTIVATIONS["swish"], eh._lib.ACTIVATIONS["tanh"]]
+    assert m.initialparameters(0).size == m.n_theta
+    # the same activation everywhere is the plain single-activation model (kernels built ahead of time)
+    m1 = eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [],
+                                 hidden_layers={"rb": [16], "Q10": [8]}, activation={"rb": "relu", "Q10": "relu"})
+    assert m1.net_activations is None and m1.activation == "relu" and m1.to_desc().activation == eh._lib.ACTIVATIONS["relu"]
+    with pytest.raises(TypeError):         # the reference reads activation[nn_name] only when hidden_layers is a NamedTuple too
+        eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [], hidden_layers=[8, 8],
+                                activation={"rb": "relu", "Q10": "tanh"})
+    with pytest.raises(NotImplementedError):
+        eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [],
+                                hidden_layers={"rb": [16], "Q10": [8]}, activation={"rb": "relu", "Q10": "gelu"})

@@ -54,6 +54,35 @@ def test_hand_vjp_matches_finite_differences(act, scale):
         assert fd == pytest.approx(g[k], rel=2e-5, abs=1e-8)
 
 
+@pytest.mark.parametrize("acts", [["tanh", "swish"], ["relu", "sigmoid"], ["swish", "identity"]])
+def test_per_net_activations_vjp(acts):
+    # MultiNN with activation::NamedTuple (GenericHybridModel.jl:168-176): hand VJP against autograd and central differences,
+    # and the forward against the two nets evaluated one by one with their own activation
+    nets = [([0, 1], [8, 6]), ([1, 2], [5, 7])]
+    spec = ho.HybridSpec(3, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=nets, net_activations=acts)
+    rng = np.random.default_rng(2)
+    B = 60
+    X = rng.standard_normal((3, B)); f = {"ta": rng.uniform(0, 30, B)}
+    y = {"reco": rng.uniform(1, 9, B)}; y["reco"][::7] = np.nan
+    th = ho.init_theta(spec, 4, np.float64)
+    l, g, _ = ho.loss_and_grad(spec, th, X, f, y)
+    l2, g2 = tt.loss_and_grad(spec, th, X, f, y)
+    assert l == pytest.approx(l2, rel=1e-12) and np.max(np.abs(g - g2)) <= 1e-11 * np.max(np.abs(g2))
+    for k in rng.choice(th.size, 20, replace=False):
+        e = np.zeros_like(th); e[k] = 1e-6
+        fd = (ho.compute_loss(spec, th + e, X, f, y) - ho.compute_loss(spec, th - e, X, f, y)) / 2e-6
+        assert fd == pytest.approx(g[k], rel=2e-5, abs=2e-7)        # (abs: rounding of a loss of O(10) over a 2e-6 step)
+    nets_w, _ = ho.unpack(spec, th)
+    par = ho.forward(spec, th, X, f)["parameters"]
+    for k, (name, (rows, _)) in enumerate(zip(spec.neural, nets)):
+        h = X[rows]
+        for li, (W, b) in enumerate(nets_w[k]):
+            z = W @ h + b[:, None]
+            h = z if li == 2 else ho.act_fwd(acts[k], z)
+        lo, hi = spec.lo(name), spec.hi(name)
+        assert np.allclose(par[name], lo + (hi - lo) / (1 + np.exp(-h[0])), rtol=1e-12)
+
+
 @pytest.mark.parametrize("mech", ["expo", "linear", "expo2pool", "rs_components"])
 def test_other_mech_models_vjp(mech):
     rng = np.random.default_rng(3)

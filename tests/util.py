@@ -34,7 +34,8 @@ def model_from_spec(spec: ho.HybridSpec):
         preds = {n: [f"x{i}" for i in rows] for n, (rows, _) in zip(spec.neural, spec.nets)}
         hl = {n: list(h) for n, (_, h) in zip(spec.neural, spec.nets)}
         return eh.constructHybridModel(preds, list(mm.forcings), list(spec.targets), MECH_NAME[spec.mech], dict(spec.parameters),
-                                       list(spec.glob), hidden_layers=hl, activation=spec.activation,
+                                       list(spec.glob), hidden_layers=hl,
+                                       activation=spec.activation if spec.net_activations is None else dict(zip(spec.neural, spec.net_activations)),
                                        scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False))
     return eh.constructHybridModel([f"x{i}" for i in range(spec.n_pred)], list(mm.forcings), list(spec.targets),
                                    MECH_NAME[spec.mech], dict(spec.parameters), list(spec.neural), list(spec.glob),
