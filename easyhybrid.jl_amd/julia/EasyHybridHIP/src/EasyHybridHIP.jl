@@ -13,7 +13,7 @@ module EasyHybridHIP
 
 using Libdl
 
-export constructHybridModel, SingleNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model,
+export constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model,
     LinearHM, Expo2Pool, Rs_components, FluxPartModelQ10
 
 const LIB = Ref{String}(get(ENV, "EASYHYBRID_HIP_LIB", joinpath(@__DIR__, "..", "..", "..", "libeasyhybrid_hip.so")))
@@ -247,7 +247,54 @@ function constructHybridModel(predictors::Vector{Symbol}, forcing, targets, mech
         collect(neural_param_names), collect(global_param_names), fixed, scale_nn_outputs, start_from_default, config)
 end
 
-n_theta(m::SingleNNHybridModel) = sum(o * i + o for (o, i) in m.NN) + length(m.global_param_names)
+"""
+    constructHybridModel(predictors::NamedTuple, forcing, targets, mechanistic_model, parameters, global_param_names; ...)
+
+MultiNNHybridModel form (GenericHybridModel.jl:142-206): `predictors = (rb = [:sw_pot, :dsw_pot], Q10 = [:ta_lag], ...)` gives every
+neural parameter its own single-output MLP on its own predictor columns; `hidden_layers` and `activation` may be NamedTuples
+over the same keys.  The device runs the nets as ONE block-diagonal MLP (`NN` below is that envelope); `predictors` of the
+returned model is the per-net predictor lists one after the other, and `X` handed to `set_data!` has its rows in that order
+(a column used by two nets appears twice).  Different activations per net select kernels compiled at run time
+(`activation = 5`, `net_activation[k]` in the descriptor).
+"""
+function constructHybridModel(predictors::NamedTuple, forcing, targets, mechanistic_model, parameters, global_param_names;
+        hidden_layers::Union{Vector{Int}, NamedTuple} = [32, 32], activation::Union{Function, NamedTuple} = tanh,
+        scale_nn_outputs = false, input_batchnorm = false, start_from_default = true, kwargs...)
+    all_names = collect(keys(parameters))
+    neural = collect(Symbol, keys(predictors))
+    haskey(MECH, mechanistic_model) || (MECH[mechanistic_model] = record_program(mechanistic_model, all_names, collect(Symbol, forcing), collect(Symbol, targets)))
+    @assert all(n in all_names for n in neural) "neural_param_names ⊆ param_names"
+    # the reference reads activation[nn_name] only next to hidden_layers[nn_name] (GenericHybridModel.jl:168-176)
+    activation isa NamedTuple && !(hidden_layers isa NamedTuple) &&
+        throw(ArgumentError("activation given per network needs hidden_layers given per network as well"))
+    hl = [hidden_layers isa NamedTuple ? collect(Int, hidden_layers[k]) : collect(Int, hidden_layers) for k in neural]
+    length(unique(length.(hl))) == 1 || throw(ArgumentError("unsupported: networks with different numbers of hidden layers"))
+    acts = [Symbol(nameof(activation isa NamedTuple ? activation[k] : activation)) for k in neural]
+    all(a -> haskey(ACT, a), acts) || throw(ArgumentError("unsupported: activation without a device implementation in $(acts)"))
+    preds = [collect(Symbol, predictors[k]) for k in neural]
+    all(!isempty, preds) || throw(ArgumentError("unsupported: a network without predictors"))
+    flat = reduce(vcat, preds)
+    tot = [sum(h[l] for h in hl) for l in 1:length(hl[1])]                  # widths of the block-diagonal envelope
+    dims = [length(flat); tot; length(neural)]
+    NN = [(dims[i + 1], dims[i]) for i in 1:(length(dims) - 1)]
+    glob = collect(Symbol, global_param_names)
+    fixed = [n for n in all_names if !(n in neural) && !(n in glob)]
+    config = (; hidden_layers, activation = (length(unique(acts)) == 1 ? acts[1] : NamedTuple{Tuple(neural)}(Tuple(acts))),
+        scale_nn_outputs, input_batchnorm, start_from_default, multi = (; predictors = preds, hidden = hl, activations = acts), kwargs...)
+    return SingleNNHybridModel(NN, flat, collect(Symbol, forcing), collect(Symbol, targets), mechanistic_model, parameters,
+        neural, glob, fixed, scale_nn_outputs, start_from_default, config)
+end
+const MultiNNHybridModel = SingleNNHybridModel      # one struct serves both; `haskey(m.config, :multi)` marks the multi-network form
+
+function n_theta(m::SingleNNHybridModel)
+    haskey(m.config, :multi) || return sum(o * i + o for (o, i) in m.NN) + length(m.global_param_names)
+    n = 0
+    for (p, h) in zip(m.config.multi.predictors, m.config.multi.hidden)     # theta holds the nets one after the other
+        d = [length(p); h; 1]
+        n += sum(d[i + 1] * d[i] + d[i + 1] for i in 1:(length(d) - 1))
+    end
+    return n + length(m.global_param_names)
+end
 
 pad(v, n, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), n)
 
@@ -267,12 +314,22 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         push!(def, d); push!(lo, l); push!(hi, u)
     end
     hidden = [o for (o, _) in m.NN[1:(end - 1)]]
+    n_nets = Int32(0); net_p = Int32[]; net_h = zeros(Int32, 32); net_a = Int32[]
+    act = m.config.activation isa Symbol ? ACT[m.config.activation] : 5          # 5 = EH_ACT_PER_NET
+    if haskey(m.config, :multi)
+        mu = m.config.multi
+        length(mu.hidden) <= 8 || throw(ArgumentError("unsupported: more than 8 networks"))
+        n_nets = Int32(length(mu.hidden)); net_p = Int32.(length.(mu.predictors)); net_a = Int32[ACT[a] for a in mu.activations]
+        for (k, h) in enumerate(mu.hidden), (l, w) in enumerate(h)
+            net_h[(k - 1) * 4 + l] = w                                           # int32_t net_hidden[8][4], row-major
+        end
+    end
     return EhModelDesc(sizeof(EhModelDesc), device, length(m.predictors), length(hidden), pad(hidden, 4, Int32),
-        ACT[m.config.activation], m.scale_nn_outputs, m.config.input_batchnorm, ms.id, length(ms.params),
+        act, m.scale_nn_outputs, m.config.input_batchnorm, ms.id, length(ms.params),
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
         length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32),
-        Int32(0), pad(Int32[], 8, Int32), pad(Int32[], 32, Int32), pad(Int32[], 8, Int32),    # MultiNN form: fill n_nets / net_* (see include/easyhybrid_hip.h)
+        n_nets, pad(net_p, 8, Int32), pad(net_h, 32, Int32), pad(net_a, 8, Int32),             # MultiNN form (n_nets = 0: SingleNN)
         (pg === nothing ? (Int32(0), Int32(0), Int32(0), Int32(0), pad(Int32[], 3, Int32), pad(UInt32[], 64, UInt32), pad(Float32[], 16, Float32)) :
          (Int32(length(pg.code)), Int32(length(pg.consts)), Int32(length(ms.forcings)), Int32(length(pg.out)), pad(pg.out, 3, Int32),
           pad(pg.code, 64, UInt32), pad(pg.consts, 16, Float32)))...)

@@ -43,6 +43,32 @@ def test_struct_layout_matches_header(tmp_path):
     assert c == L.ModelDesc.param_default.offset and d == L.ModelDesc.n_targets.offset
 
 
+def test_julia_shim_struct_mirrors_the_ctypes_layout():
+    """No `julia` in this image: the shim's `struct EhModelDesc` (what `@ccall eh_create` hands over) is checked field by field --
+    name, order, element type, length -- against the ctypes mirror that the test above pins to the header."""
+    jl = open(os.path.join(ROOT, "easyhybrid.jl_amd", "julia", "EasyHybridHIP", "src", "EasyHybridHIP.jl")).read()
+    body = re.search(r"struct EhModelDesc\n(.*?)\nend", jl, flags=re.S).group(1)
+    jt = {"Int32": (C.c_int32, 4), "UInt32": (C.c_uint32, 4), "Float32": (C.c_float, 4)}
+    fields = []
+    for line in body.splitlines():
+        line = line.split("#")[0].strip()
+        if not line:
+            continue
+        name, typ = [x.strip() for x in line.split("::")]
+        m = re.fullmatch(r"NTuple\{(\d+), (\w+)\}", typ)
+        fields.append((name, jt[m.group(2) if m else typ][0], int(m.group(1)) if m else 1))
+    assert [f[0] for f in fields] == [n for n, _ in L.ModelDesc._fields_]
+    off = 0
+    for (name, ct, count), (_, pyt) in zip(fields, L.ModelDesc._fields_):
+        assert getattr(L.ModelDesc, name).offset == off and C.sizeof(pyt) == 4 * count, name
+        base = pyt
+        while hasattr(base, "_type_") and not isinstance(base._type_, str):
+            base = base._type_
+        assert base is ct, name
+        off += 4 * count
+    assert off == C.sizeof(L.ModelDesc)
+
+
 def _model(**kw):
     args = dict(hidden_layers=[16, 16])
     args.update(kw)
