@@ -36,6 +36,7 @@ class ModelDesc(C.Structure):
         ("n_targets", C.c_int32), ("target_output", C.c_int32 * EH_MAX_TARG),
         ("n_nets", C.c_int32), ("net_n_predictors", C.c_int32 * EH_MAX_NETS), ("net_hidden", (C.c_int32 * EH_MAX_HIDDEN) * EH_MAX_NETS),
         ("net_activation", C.c_int32 * EH_MAX_NETS),
+        ("net_depth", C.c_int32 * EH_MAX_NETS),
         ("prog_len", C.c_int32), ("prog_n_const", C.c_int32), ("prog_n_forc", C.c_int32), ("prog_n_out", C.c_int32),
         ("prog_out", C.c_int32 * EH_MAX_PROG_OUT), ("prog_code", C.c_uint32 * EH_MAX_PROG), ("prog_const", C.c_float * EH_MAX_PROG_CONST),
     ]

@@ -419,6 +419,7 @@ struct eh_handle_s {
     int n_nets = 1;                                     // 1 for SingleNN
     int net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0};
     int net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}};      // hidden widths of net k
+    int net_d[EH_MAX_NETS] = {0};                       // hidden layers of net k (layers past them: identity blocks, not in theta)
     int net_c0[EH_MAX_NETS] = {0};                      // first predictor row of net k
     int net_r0[EH_MAX_NETS][EH_MAX_HIDDEN + 1] = {{0}}; // first row of net k in layer l (l == n_hidden: output row)
     int tot_w[EH_MAX_HIDDEN] = {0};                     // total (summed) hidden widths
@@ -545,6 +546,7 @@ static std::vector<EhEntry> enumerate_entries(const eh_handle* h) {
         for (int l = 0; l <= nl; ++l) {
             const int o = l < nl ? h->net_w[k][l] : h->net_K[k];
             const int r0 = h->net_r0[k][l], c0 = l == 0 ? h->net_c0[k] : h->net_r0[k][l - 1];
+            if (l < nl && l >= h->net_d[k]) continue;            // identity block of a shallower net
             for (int col = 0; col < in; ++col)
                 for (int row = 0; row < o; ++row) v.push_back({off + row + o * col, l, r0 + row, c0 + col});
             off += o * in;
@@ -797,6 +799,9 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     // nets and their block placement (SingleNN = one net with K outputs)
     const int nl = d->n_hidden;
     int n_nets = 1, net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0}, net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}}, tot_w[EH_MAX_HIDDEN] = {0};
+    int net_d[EH_MAX_NETS];                  // hidden layers of net k; layers past them are identity blocks as wide as its last one
+    for (int k = 0; k < EH_MAX_NETS; ++k) net_d[k] = nl;
+    bool mixed_depth = false;
     if (d->n_nets < 0 || d->n_nets > EH_MAX_NETS) return fail(nullptr, EH_EINVAL, "eh_create: n_nets = %d (0..%d)", d->n_nets, EH_MAX_NETS);
     if (d->n_nets > 0) {
         if (d->n_nets != K) return fail(nullptr, EH_EINVAL, "eh_create: MultiNN needs one net per neural parameter (%d nets, %d neural parameters)", d->n_nets, K);
@@ -805,10 +810,19 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         for (int k = 0; k < n_nets; ++k) {
             if (d->net_n_predictors[k] < 1) return fail(nullptr, EH_EINVAL, "eh_create: net %d has no predictors", k);
             net_P[k] = d->net_n_predictors[k]; net_K[k] = 1; ptot += net_P[k];
+            if (d->net_depth[k] < 0 || d->net_depth[k] > nl) return fail(nullptr, EH_EINVAL, "eh_create: net_depth[%d] = %d (n_hidden = %d)", k, d->net_depth[k], nl);
+            if (d->net_depth[k] > 0) net_d[k] = d->net_depth[k];
+            mixed_depth = mixed_depth || net_d[k] != nl;
             for (int l = 0; l < nl; ++l) {
-                if (d->net_hidden[k][l] < 1) return fail(nullptr, EH_EINVAL, "eh_create: net_hidden[%d][%d] = %d", k, l, d->net_hidden[k][l]);
-                net_w[k][l] = d->net_hidden[k][l]; tot_w[l] += net_w[k][l];
+                if (l < net_d[k] && d->net_hidden[k][l] < 1) return fail(nullptr, EH_EINVAL, "eh_create: net_hidden[%d][%d] = %d", k, l, d->net_hidden[k][l]);
+                net_w[k][l] = d->net_hidden[k][l < net_d[k] ? l : net_d[k] - 1]; tot_w[l] += net_w[k][l];
             }
+        }
+        if (mixed_depth) {
+            bool full = false;
+            for (int k = 0; k < n_nets; ++k) full = full || net_d[k] == nl;
+            if (!full) return fail(nullptr, EH_EINVAL, "eh_create: n_hidden = %d but no net is that deep", nl);
+            act = EH_ACT_PER_NET;            // the identity blocks need the row-dependent activation (kernels compiled at run time)
         }
         if (ptot != d->n_predictors) return fail(nullptr, EH_EINVAL, "eh_create: net_n_predictors sum to %d, n_predictors = %d", ptot, d->n_predictors);
     } else {
@@ -838,6 +852,14 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
 
     eh_handle* h = new eh_handle_s();
     h->desc = *d;
+    if (d->n_nets > 0) {                     // the descriptor the run-time compiler reads: depths and identity-block widths spelled out
+        for (int k = 0; k < n_nets; ++k) {
+            h->desc.net_depth[k] = net_d[k];
+            for (int l = 0; l < nl; ++l) h->desc.net_hidden[k][l] = net_w[k][l];
+            if (act == EH_ACT_PER_NET) h->desc.net_activation[k] = d->activation == EH_ACT_PER_NET ? d->net_activation[k] : d->activation;
+        }
+        if (act == EH_ACT_PER_NET) h->desc.activation = EH_ACT_PER_NET;
+    }
     h->device = d->device;
     h->arch = arch;
     h->variant = (arch->nvar > 1 && !arch->wide) ? 1 : 0;   // narrow nets: two waves per SIMD hide the latency of the short tile
@@ -851,6 +873,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
             h->net_P[k] = net_P[k]; h->net_K[k] = net_K[k]; h->net_c0[k] = c0; c0 += net_P[k];
             for (int l = 0; l < nl; ++l) { h->net_w[k][l] = net_w[k][l]; h->net_r0[k][l] = r0[l]; r0[l] += net_w[k][l]; }
             h->net_r0[k][nl] = d->n_nets > 0 ? k : 0;            // output row
+            h->net_d[k] = net_d[k];
         }
         for (int l = 0; l < nl; ++l) h->tot_w[l] = tot_w[l];
     }
@@ -861,6 +884,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         for (int l = 0; l <= nl; ++l) {
             const int o = l < nl ? net_w[k][l] : net_K[k];
             if (k == 0) lw_off[l] = off;
+            if (l < nl && l >= net_d[k]) { if (k == 0) lb_off[l] = off; continue; }       // identity block: nothing of it in theta
             off += o * in;
             if (k == 0) lb_off[l] = off;
             off += o;
@@ -952,6 +976,10 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
             img0[arch->phi_off + EH_IMG_SC + j] = d->param_upper[j] - d->param_lower[j];
         }
         for (int p = 0; p < 32; ++p) { img0[arch->phi_off + EH_IMG_BNM + p] = 0.0f; img0[arch->phi_off + EH_IMG_BNR + p] = d->input_batchnorm ? 1.0f / std::sqrt(1.0f + EH_BN_EPS) : 1.0f; }
+        for (int k = 0; k < n_nets; ++k)                    // identity blocks that carry a shallower net to the output layer
+            for (int l = net_d[k]; l < nl; ++l)
+                for (int i = 0; i < net_w[k][l]; ++i)
+                    img0[arch->wh_off + (size_t)(l - 1) * arch->hp * arch->sh + (size_t)(h->net_r0[k][l] + i) * arch->sh + h->net_r0[k][l - 1] + i] = 1.0f;
         auto put_int = [&](int slot, int v) { memcpy(&img0[arch->phi_off + slot], &v, sizeof(int)); };
         for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
         for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, tot_w[l]);

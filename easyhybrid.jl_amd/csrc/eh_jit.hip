@@ -272,7 +272,8 @@ std::string eh_jit_mech_source(const eh_model_desc& d) {
 }
 
 // eh_row_act(layer, row) for EH_ACT_PER_NET: net k owns rows [sum_{j<k} net_hidden[j][l], + net_hidden[k][l]) of hidden layer l
-// (the block placement of eh_create); rows past the last net are padding (zero weights on both sides): identity
+// (the block placement of eh_create; `d` is the handle's normalised copy: net_depth filled in, net_hidden of an identity block =
+// the net's last width); rows past the last net are padding (zero weights on both sides): identity
 static std::string eh_jit_rowact_source(const eh_model_desc& d) {
     std::string s = "__device__ __forceinline__ int eh_row_act(int l, int row) {\n";
     char b[96];
@@ -282,7 +283,7 @@ static std::string eh_jit_rowact_source(const eh_model_desc& d) {
         int r0 = 0;
         for (int k = 0; k < d.n_nets; ++k) {
             r0 += d.net_hidden[k][l];
-            snprintf(b, sizeof b, " row < %d ? %d :", r0, d.net_activation[k]);
+            snprintf(b, sizeof b, " row < %d ? %d :", r0, l < d.net_depth[k] ? d.net_activation[k] : (int)EH_ACT_IDENTITY);     // past its depth: identity block
             s += b;
         }
         snprintf(b, sizeof b, " %d;\n", (int)EH_ACT_IDENTITY);

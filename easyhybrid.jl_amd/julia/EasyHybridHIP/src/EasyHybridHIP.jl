@@ -46,6 +46,7 @@ struct EhModelDesc
     net_n_predictors::NTuple{8, Int32}
     net_hidden::NTuple{32, Int32}                   # [8 nets][4 layers], row-major like the C array
     net_activation::NTuple{8, Int32}                # read when activation == 5 (EH_ACT_PER_NET): activation id of net k
+    net_depth::NTuple{8, Int32}                     # hidden layers of net k (0 = n_hidden); n_hidden is the deepest net's
     prog_len::Int32                                 # EH_MECH_PROGRAM only (a recorded closure, see `record_program`)
     prog_n_const::Int32
     prog_n_forc::Int32
@@ -254,8 +255,8 @@ MultiNNHybridModel form (GenericHybridModel.jl:142-206): `predictors = (rb = [:s
 neural parameter its own single-output MLP on its own predictor columns; `hidden_layers` and `activation` may be NamedTuples
 over the same keys.  The device runs the nets as ONE block-diagonal MLP (`NN` below is that envelope); `predictors` of the
 returned model is the per-net predictor lists one after the other, and `X` handed to `set_data!` has its rows in that order
-(a column used by two nets appears twice).  Different activations per net select kernels compiled at run time
-(`activation = 5`, `net_activation[k]` in the descriptor).
+(a column used by two nets appears twice).  Different activations per net (`activation = 5`, `net_activation[k]` in the
+descriptor) or different depths (`net_depth[k]`) select kernels compiled at run time.
 """
 function constructHybridModel(predictors::NamedTuple, forcing, targets, mechanistic_model, parameters, global_param_names;
         hidden_layers::Union{Vector{Int}, NamedTuple} = [32, 32], activation::Union{Function, NamedTuple} = tanh,
@@ -268,13 +269,14 @@ function constructHybridModel(predictors::NamedTuple, forcing, targets, mechanis
     activation isa NamedTuple && !(hidden_layers isa NamedTuple) &&
         throw(ArgumentError("activation given per network needs hidden_layers given per network as well"))
     hl = [hidden_layers isa NamedTuple ? collect(Int, hidden_layers[k]) : collect(Int, hidden_layers) for k in neural]
-    length(unique(length.(hl))) == 1 || throw(ArgumentError("unsupported: networks with different numbers of hidden layers"))
+    all(!isempty, hl) || throw(ArgumentError("unsupported: a network without a hidden layer"))
     acts = [Symbol(nameof(activation isa NamedTuple ? activation[k] : activation)) for k in neural]
     all(a -> haskey(ACT, a), acts) || throw(ArgumentError("unsupported: activation without a device implementation in $(acts)"))
     preds = [collect(Symbol, predictors[k]) for k in neural]
     all(!isempty, preds) || throw(ArgumentError("unsupported: a network without predictors"))
     flat = reduce(vcat, preds)
-    tot = [sum(h[l] for h in hl) for l in 1:length(hl[1])]                  # widths of the block-diagonal envelope
+    # widths of the block-diagonal envelope; a shallower net rides identity blocks as wide as its last hidden layer
+    tot = [sum(h[min(l, length(h))] for h in hl) for l in 1:maximum(length.(hl))]
     dims = [length(flat); tot; length(neural)]
     NN = [(dims[i + 1], dims[i]) for i in 1:(length(dims) - 1)]
     glob = collect(Symbol, global_param_names)
@@ -314,12 +316,13 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         push!(def, d); push!(lo, l); push!(hi, u)
     end
     hidden = [o for (o, _) in m.NN[1:(end - 1)]]
-    n_nets = Int32(0); net_p = Int32[]; net_h = zeros(Int32, 32); net_a = Int32[]
+    n_nets = Int32(0); net_p = Int32[]; net_h = zeros(Int32, 32); net_a = Int32[]; net_d = Int32[]
     act = m.config.activation isa Symbol ? ACT[m.config.activation] : 5          # 5 = EH_ACT_PER_NET
     if haskey(m.config, :multi)
         mu = m.config.multi
         length(mu.hidden) <= 8 || throw(ArgumentError("unsupported: more than 8 networks"))
         n_nets = Int32(length(mu.hidden)); net_p = Int32.(length.(mu.predictors)); net_a = Int32[ACT[a] for a in mu.activations]
+        net_d = Int32.(length.(mu.hidden))
         for (k, h) in enumerate(mu.hidden), (l, w) in enumerate(h)
             net_h[(k - 1) * 4 + l] = w                                           # int32_t net_hidden[8][4], row-major
         end
@@ -329,7 +332,7 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
         length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32),
-        n_nets, pad(net_p, 8, Int32), pad(net_h, 32, Int32), pad(net_a, 8, Int32),             # MultiNN form (n_nets = 0: SingleNN)
+        n_nets, pad(net_p, 8, Int32), pad(net_h, 32, Int32), pad(net_a, 8, Int32), pad(net_d, 8, Int32),    # MultiNN form (n_nets = 0: SingleNN)
         (pg === nothing ? (Int32(0), Int32(0), Int32(0), Int32(0), pad(Int32[], 3, Int32), pad(UInt32[], 64, UInt32), pad(Float32[], 16, Float32)) :
          (Int32(length(pg.code)), Int32(length(pg.consts)), Int32(length(ms.forcings)), Int32(length(pg.out)), pad(pg.out, 3, Int32),
           pad(pg.code, 64, UInt32), pad(pg.consts, 16, Float32)))...)

@@ -291,6 +291,7 @@ class SingleNNHybridModel:
             for k, name in enumerate(self.neural_param_names):
                 net = self.NNs[name]
                 d.net_n_predictors[k] = net[0][1]
+                d.net_depth[k] = len(net) - 1
                 for l, (o, _) in enumerate(net[:-1]):
                     d.net_hidden[k][l] = o
         if self.net_activations is not None:       # per-net activations: kernels compiled at run time around the descriptor
@@ -360,8 +361,8 @@ def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mec
     else:
         act = _act_name(activation)
     hl = {k: list(hidden_layers[k]) for k in neural} if isinstance(hidden_layers, dict) else {k: list(hidden_layers) for k in neural}
-    if len({len(v) for v in hl.values()}) != 1:
-        raise NotImplementedError("networks with different numbers of hidden layers are not built")
+    if any(len(v) < 1 for v in hl.values()):
+        raise NotImplementedError("a network without a hidden layer")
     for p in ms.params:
         if p not in all_names:
             raise ValueError(f"mechanistic model {ms.name} needs parameter {p!r}; the table has {all_names}")
@@ -380,8 +381,10 @@ def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mec
         dims = [len(preds)] + [int(w) for w in hl[k]] + [1]
         NNs[k] = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
         flat_pred += preds                                   # the per-net predictor matrices stacked row-wise
-    nl = len(next(iter(hl.values())))
-    tot = [sum(hl[k][l] for k in neural) for l in range(nl)]
+    # hidden_layers::NamedTuple may give the nets different depths (test/test_generic_hybrid_model.jl:346): in the block-diagonal
+    # envelope a shallower net is carried to the output layer by identity blocks as wide as its last hidden layer
+    nl = max(len(v) for v in hl.values())
+    tot = [sum(hl[k][min(l, len(hl[k]) - 1)] for k in neural) for l in range(nl)]
     NN = [(a, b) for a, b in zip(tot + [len(neural)], [len(flat_pred)] + tot)]     # the block-diagonal envelope
     fixed = [n for n in all_names if n not in neural and n not in glob]
     config = dict(hidden_layers=hidden_layers, activation=act if net_acts is None else dict(zip(neural, net_acts)),

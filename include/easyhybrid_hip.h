@@ -149,6 +149,11 @@ typedef struct eh_model_desc {
     int32_t net_n_predictors[EH_MAX_NETS];
     int32_t net_hidden[EH_MAX_NETS][EH_MAX_HIDDEN];
     int32_t net_activation[EH_MAX_NETS];     /* read when activation == EH_ACT_PER_NET: eh_activation of net k (TANH..IDENTITY) */
+    int32_t net_depth[EH_MAX_NETS];          /* hidden layers of net k (hidden_layers::NamedTuple with vectors of different length,
+                                              * test/test_generic_hybrid_model.jl:346): 1..n_hidden, 0 = n_hidden; n_hidden is the deepest
+                                              * net's.  A shallower net is carried through the remaining layers of the block-diagonal MLP
+                                              * by identity blocks (constant weights 1, identity activation, outside theta); such models
+                                              * run on kernels compiled at run time, like EH_ACT_PER_NET */
     /* EH_MECH_PROGRAM only (ignored otherwise): n_params parameters, prog_n_forc forcings, prog_n_out outputs */
     int32_t prog_len;                        /* 1..EH_MAX_PROG */
     int32_t prog_n_const;                    /* 0..EH_MAX_PROG_CONST */

@@ -5,7 +5,8 @@ not the reference's; what pins the oracle to the reference is tests/test_oracle_
 fixtures freeze the oracle so that (a) an accidental change of the oracle is caught on CPU and
 (b) the GPU box can check the HIP path against committed numbers.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 # all of them
+    python tests/golden/make_golden.py NAME [NAME ...]  # only these (the others stay as committed)
 """
 import json
 import os
@@ -21,12 +22,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def spec_dict(spec):
-    return dict(n_pred=spec.n_pred, hidden=list(spec.hidden), mech=spec.mech, parameters={k: list(map(float, v)) for k, v in spec.parameters.items()},
-                neural=list(spec.neural), glob=list(spec.glob), targets=list(spec.targets), activation=spec.activation,
-                scale_nn_outputs=bool(spec.scale_nn_outputs))
+    d = dict(n_pred=spec.n_pred, hidden=list(spec.hidden), mech=spec.mech, parameters={k: list(map(float, v)) for k, v in spec.parameters.items()},
+             neural=list(spec.neural), glob=list(spec.glob), targets=list(spec.targets), activation=spec.activation,
+             scale_nn_outputs=bool(spec.scale_nn_outputs))
+    if spec.nets is not None:              # MultiNN fixtures only (the keys are absent from the older files)
+        d["nets"] = [[list(map(int, rows)), list(map(int, hidden))] for rows, hidden in spec.nets]
+        d["net_activations"] = None if spec.net_activations is None else list(spec.net_activations)
+    return d
+
+
+ONLY = set(sys.argv[1:])
 
 
 def emit(name, spec, theta, X, f, y, batch):
+    if ONLY and name not in ONLY:
+        return
     th64 = theta.astype(np.float64)
     loss, grad, nv = ho.loss_and_grad(spec, th64, X, f, y)
     fw = ho.forward(spec, th64, X, f)
@@ -90,6 +100,15 @@ def main():
         v[crng.uniform(size=400) < 0.1] = np.nan
         cy[t] = v.astype(np.float32)
     emit("closure_flux_B400", cspec, ho.init_theta(cspec, 23, np.float32), cX, cf, cy, 200)
+    # MultiNNHybridModel, the reference's own constructor case: hidden_layers = (a = [16, 8], d = [8]), activation = (a = tanh,
+    # d = sigmoid) (test/test_generic_hybrid_model.jl:346-347) -- two nets of different depth and activation, on RbQ10
+    mspec = ho.HybridSpec(3, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True,
+                          nets=[([0, 1], [16, 8]), ([2], [8])], net_activations=["tanh", "sigmoid"])
+    mrng = np.random.default_rng(31)
+    mX = mrng.standard_normal((3, 500)).astype(np.float32)
+    mf = {"ta": mrng.uniform(0, 30, 500).astype(np.float32)}
+    my = mrng.uniform(1, 9, 500).astype(np.float32); my[mrng.random(500) < 0.15] = np.nan
+    emit("multinn_depth_act_B500", mspec, ho.init_theta(mspec, 32, np.float32), mX, mf, {"reco": my}, 250)
     emit("expo_ref_B300", spec, ho.init_theta(spec, 12, np.float32), SM[None].astype(np.float32), {"T": T.astype(np.float32)},
          {"Resp_obs": resp.astype(np.float32)}, 100)
 

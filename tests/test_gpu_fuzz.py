@@ -64,6 +64,9 @@ def _case(seed, fastpath=False):
         rng_a = np.random.default_rng(900000 + seed)
         if rng_a.random() < 0.5:
             net_acts = [str(a) for a in rng_a.choice(["tanh", "sigmoid", "relu", "swish", "identity"], len(nets))]
+        if nl > 1 and rng_a.random() < 0.4:          # hidden_layers::NamedTuple with vectors of different length: some nets shallower
+            keep = int(rng_a.integers(len(nets)))    # (one keeps the full depth)
+            nets = [(rw, hw if k == keep else hw[: int(rng_a.integers(1, nl + 1))]) for k, (rw, hw) in enumerate(nets)]
     spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, scale, input_batchnorm=bn, nets=nets,
                          net_activations=net_acts)
     B = int(rng.choice([1, 7, 31, 32, 33, 64, 257, 1000, 2049]))

@@ -272,7 +272,8 @@ def _load_spec(d):
         fn, table, forc = cl.CLOSURES[s["mech"]]
         util.register_closure(s["mech"], fn, list(table), forc, s["targets"])
     return ho.HybridSpec(s["n_pred"], s["hidden"], s["mech"], {k: tuple(v) for k, v in s["parameters"].items()}, s["neural"],
-                         s["glob"], s["targets"], s["activation"], s["scale_nn_outputs"])
+                         s["glob"], s["targets"], s["activation"], s["scale_nn_outputs"],
+                         nets=[(r, h) for r, h in s["nets"]] if s.get("nets") else None, net_activations=s.get("net_activations"))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))),
@@ -617,6 +618,12 @@ def test_multinn_hybrid_model(nets, glob):
     ([([0, 1], [8]), ([2], [5])], ["tanh", "identity"], []),                    # one hidden layer
     ([([0, 1, 2], [40, 60]), ([1, 3], [50, 60])], ["sigmoid", "swish"], []),    # 90 / 120 units: the row-split kernel
     ([([0, 1], [16, 16]), ([2, 3], [16, 16]), ([0, 3], [16, 16])], ["tanh", "relu", "swish"], ["Q10_het", "Q10_root", "Q10_myc"]),
+    # nets of different depth: hidden_layers = (a = [16, 8], d = [8]), activation = (a = tanh, d = sigmoid) is the reference's own
+    # constructor test (test/test_generic_hybrid_model.jl:346-347); the shallower net rides identity blocks to the output layer
+    ([([0, 1], [16, 8]), ([2], [8])], ["tanh", "sigmoid"], []),
+    ([([0, 1], [12]), ([1, 2, 3], [20, 10, 6])], None, []),                     # one activation for all, depths 1 and 3
+    ([([0, 1, 2], [70]), ([3], [50, 40])], ["relu", "tanh"], []),               # envelope 120 / 110 wide: the row-split kernel
+    ([([0], [8, 8]), ([1, 2], [16]), ([3], [4, 12])], ["swish", "tanh", "relu"], ["Q10_het", "Q10_root", "Q10_myc"]),
 ])
 def test_multinn_per_network_activations(nets, acts, glob):
     """activation::NamedTuple of the MultiNN constructor (GenericHybridModel.jl:168-176): net k runs activation[k].  On the device
@@ -627,7 +634,7 @@ def test_multinn_per_network_activations(nets, acts, glob):
         mech, neural, tname = "rs_components", ["Rb_het", "Rb_root", "Rb_myc"], "R_soil"
     else:
         tab, mech, neural, tname = dict(ho.RBQ10_PARAMS), "rbq10", ["rb", "Q10"], "reco"
-    spec = ho.HybridSpec(4, [1], mech, tab, neural, glob, [tname], "tanh", True, nets=nets, net_activations=acts)
+    spec = ho.HybridSpec(4, [1], mech, tab, neural, glob, [tname], "swish", True, nets=nets, net_activations=acts)
     rng = np.random.default_rng(9)
     B = 1100
     X = rng.standard_normal((4, B)).astype(np.float32)
@@ -654,7 +661,8 @@ def test_multinn_per_network_activations(nets, acts, glob):
     th_ref, l_ref = ho.train_steps(spec, theta, X, f, {tname: yv}, batches, dtype=np.float32)
     assert np.allclose(losses, l_ref, rtol=1e-4)
     assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
-    if max(sum(h[l] for _, h in nets) for l in range(len(nets[0][1]))) <= 64:
+    depth = max(len(h) for _, h in nets)
+    if max(sum(h[min(l, len(h) - 1)] for _, h in nets) for l in range(depth)) <= 64:
         eng.set_option("fused_update", 1)        # one kernel per step: the same compiled kernel, update in its prologue
         more = [(i * 100, 100) for i in range(3)]
         for b in more:

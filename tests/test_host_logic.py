@@ -108,8 +108,13 @@ def test_multinn_constructor_mirrors_reference():
     th = m.initialparameters(0)
     nets, glob = m.unpack(th)
     assert th.size == m.n_theta and nets["Q10"][0][0].shape == (8, 1) and glob == {}
-    with pytest.raises(NotImplementedError):
-        eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [], hidden_layers={"rb": [16], "Q10": [8, 4]})
+    # nets of different depth (test/test_generic_hybrid_model.jl:346): theta holds each net with its own layers; the envelope
+    # carries the shallower one through an identity block as wide as its last hidden layer
+    m2 = eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [], hidden_layers={"rb": [16], "Q10": [8, 4]})
+    assert m2.NNs["rb"] == [(16, 1), (1, 16)] and m2.NNs["Q10"] == [(8, 1), (4, 8), (1, 4)] and m2.hidden_layers == [24, 20]
+    assert m2.n_theta == (16 + 16 + 16 + 1) + (8 + 8 + 32 + 4 + 4 + 1)
+    d2 = m2.to_desc()
+    assert d2.n_hidden == 2 and list(d2.net_depth)[:2] == [1, 2] and list(d2.net_hidden[0])[:2] == [16, 0]
 
 
 def test_multinn_per_network_activations():

@@ -54,6 +54,20 @@ def test_hand_vjp_matches_finite_differences(act, scale):
         assert fd == pytest.approx(g[k], rel=2e-5, abs=1e-8)
 
 
+def test_nets_of_different_depth_vjp():
+    # hidden_layers = (a = [16, 8], d = [8]) (test/test_generic_hybrid_model.jl:346): theta holds every net with its own layers
+    nets = [([0, 1], [16, 8]), ([2], [8])]
+    spec = ho.HybridSpec(3, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=nets, net_activations=["tanh", "sigmoid"])
+    assert spec.n_theta == (32 + 16 + 128 + 8 + 8 + 1) + (8 + 8 + 8 + 1)
+    rng = np.random.default_rng(3)
+    B = 50
+    X = rng.standard_normal((3, B)); f = {"ta": rng.uniform(0, 30, B)}; y = {"reco": rng.uniform(1, 9, B)}
+    th = ho.init_theta(spec, 4, np.float64)
+    l, g, _ = ho.loss_and_grad(spec, th, X, f, y)
+    l2, g2 = tt.loss_and_grad(spec, th, X, f, y)
+    assert l == pytest.approx(l2, rel=1e-12) and np.max(np.abs(g - g2)) <= 1e-11 * np.max(np.abs(g2))
+
+
 @pytest.mark.parametrize("acts", [["tanh", "swish"], ["relu", "sigmoid"], ["swish", "identity"]])
 def test_per_net_activations_vjp(acts):
     # MultiNN with activation::NamedTuple (GenericHybridModel.jl:168-176): hand VJP against autograd and central differences,
@@ -138,7 +152,8 @@ def _load_spec(d):
         fn, table, forc = cl.CLOSURES[s["mech"]]
         util.register_closure(s["mech"], fn, list(table), forc, s["targets"])
     return ho.HybridSpec(s["n_pred"], s["hidden"], s["mech"], {k: tuple(v) for k, v in s["parameters"].items()}, s["neural"],
-                         s["glob"], s["targets"], s["activation"], s["scale_nn_outputs"])
+                         s["glob"], s["targets"], s["activation"], s["scale_nn_outputs"],
+                         nets=[(r, h) for r, h in s["nets"]] if s.get("nets") else None, net_activations=s.get("net_activations"))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))),
