@@ -373,6 +373,40 @@ def test_dp_seam_virtual_shards_equal_single_step():
     ref.close(); eng.close()
 
 
+def test_dp_seam_and_front_door_with_per_network_activations_and_depths():
+    """the reference's MultiNN constructor case (hidden_layers = (a = [16, 8], d = [8]), activation = (a = tanh, d = sigmoid),
+    test/test_generic_hybrid_model.jl:346-347) through the data-parallel seam and through `train`: kernels compiled at run time"""
+    import torch
+    nets = [([0, 1], [16, 8]), ([2], [8])]
+    spec = ho.HybridSpec(3, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=nets, net_activations=["tanh", "sigmoid"])
+    rng = np.random.default_rng(12)
+    B = 2048
+    X = rng.standard_normal((3, B)).astype(np.float32); f = {"ta": rng.uniform(0, 30, B).astype(np.float32)}
+    yv = rng.uniform(1, 9, B).astype(np.float32); yv[rng.random(B) < 0.1] = np.nan
+    y = {"reco": yv}
+    theta = ho.init_theta(spec, 13, np.float32)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    l_ref = ref.train_step(0, B)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    ptr, n = eng.device_buffer(eh._lib.EH_BUF_GRAD)
+    buf = torch.as_tensor(eh.dp._DevArray(ptr, n), device="cuda")
+    acc = torch.zeros_like(buf)
+    for k in range(4):
+        eng.dp_grad(k * 512, 512); eng.synchronize(); acc += buf
+    buf.copy_(acc); torch.cuda.synchronize()
+    assert eng.dp_apply(want_loss=True) == pytest.approx(l_ref, rel=1e-5)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-6
+    th_ref, _ = ho.train_steps(spec, theta, X, f, y, [(0, B)], dtype=np.float32)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 2e-5
+    # epoch driver (eh_train_epoch) on the same kernels, against step-by-step
+    a = util.load_engine(spec, theta, X, f, y); a.opt_init("Adam", 0.01)
+    la, na = a.train_epoch(256, shuffle=False)
+    th_ep, l_ep = ho.train_steps(spec, theta, X, f, y, [(i * 256, 256) for i in range(8)], dtype=np.float32)
+    assert na == 8 and la == pytest.approx(float(np.mean(l_ep)), rel=1e-4)
+    assert np.max(np.abs(a.get_params() - th_ep)) <= 1e-4
+    ref.close(); eng.close(); a.close()
+
+
 def test_set_data_from_device_pointers():
     import torch
     spec, theta, X, f, y = util.rbq10_case(777, "tanh", True, 0.1)
