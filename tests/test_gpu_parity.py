@@ -405,6 +405,10 @@ def test_dp_seam_and_front_door_with_per_network_activations_and_depths():
     assert na == 8 and la == pytest.approx(float(np.mean(l_ep)), rel=1e-4)
     assert np.max(np.abs(a.get_params() - th_ep)) <= 1e-4
     ref.close(); eng.close(); a.close()
+    # the front door: train(model, data) on a table of columns
+    cols = {"x0": X[0], "x1": X[1], "x2": X[2], "ta": f["ta"], "reco": yv}
+    out = eh.train(util.model_from_spec(spec), cols, nepochs=4, batchsize=256, random_seed=2)
+    assert len(out.val_history) == 5 and out.val_history[-1]["mse"]["sum"] < out.val_history[0]["mse"]["sum"]
 
 
 def test_set_data_from_device_pointers():
