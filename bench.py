@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mech-stage", action="store_true", help="skip the secondary measurement of the stand-alone mechanistic + VJP kernel")
     ap.add_argument("--no-specialize", action="store_true",
                     help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
     args = ap.parse_args()
@@ -236,6 +237,17 @@ def main():
             out["final_loss"] = loss
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
+        if world == 1 and dp is None and not args.no_mech_stage:
+            # the HBM-bound stage of the path measured as its own kernel (the fused step is compute / latency
+            # bound, so the north_star's HBM yardstick applies to the mechanistic + loss + VJP stage alone): eh_mech_loss_vjp on
+            # 256 resident batches of the headline workload.  A secondary figure; `roofline` above stays the step kernel's.
+            try:
+                import importlib.util
+                spec_ = importlib.util.spec_from_file_location("eh_bench_mech", os.path.join(ROOT, "tools", "bench_mech.py"))
+                bm = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bm)
+                out["hbm_stage"] = bm.measure("rbq10", 256 * B, 50)
+            except Exception as e:      # never lose the headline line over the secondary measurement
+                out["hbm_stage"] = {"error": repr(e)}
         print(json.dumps(out))
     eng.close()
     if dist.is_initialized():

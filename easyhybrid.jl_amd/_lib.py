@@ -67,6 +67,8 @@ SIGNATURES = {
     "eh_set_params": (C.c_int32, [_H, _F, C.c_int64]),
     "eh_get_params": (C.c_int32, [_H, _F, C.c_int64]),
     "eh_forward": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, _FP, _FP]),
+    "eh_mech_loss_vjp": (C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                     C.c_void_p, C.c_void_p, _F, _F, C.POINTER(C.c_int64)]),
     "eh_loss_and_grad": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64, _F, _F, C.POINTER(C.c_int64)]),
     "eh_get_bn_state": (C.c_int32, [_H, _F, _F, C.c_int64]),
     "eh_set_bn_state": (C.c_int32, [_H, _F, _F, C.c_int64]),

@@ -63,6 +63,192 @@ __global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
     if (idx < n_theta) eh_image_store(im, idx, theta[idx]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mechanistic stage on its own (eh_mech_loss_vjp): o = NN outputs of an MLP that lives OUTSIDE this library -> physical
+// parameters (sigma-scaling) -> M(par, forcings) -> masked MSE summed over the targets -> d loss / d o and the gradient of
+// the raw global parameters.  Pure streaming: 4 (K + F + T) bytes read and 4 K written per sample, ~20-60 flop -- the one
+// stage of the path that the HBM roof bounds.  Every lane owns V consecutive samples (V = 4: 16-byte
+// loads and stores, a wave covers 1 KiB runs of every array); sums leave a workgroup once, as one row of partials.
+// ---------------------------------------------------------------------------------------------------------------------
+struct EhMechArgs {
+    const float* o;                          // [K][ld] NN outputs (raw)
+    const float* frc[EH_MAX_FORC];           // the F forcing arrays in eh_set_data order
+    const float* y[EH_MAX_TARG];             // the T target arrays (NaN = missing)
+    float* d_o;                              // [K][ld] d loss / d o
+    float* yhat;                             // [T][ld] or nullptr
+    long long n, ld;
+    const float* meta;                       // parameter image, PHI block (values / d value d raw of the global and fixed parameters, lo, hi - lo)
+    const unsigned long long* counts;        // valid samples per target (whole call), counted on the device ...
+    unsigned long long counts_v[EH_MAX_TARG];   // ... or handed in by the caller (use_v)
+    int use_v;
+    float* part;                             // [gridDim.x][EH_MECH_PART] partial sums
+};
+enum { EH_MECH_PART = 16 };                  // [dL/dpar_j (8) | S_t (4) | pad]
+
+template <int V>
+__global__ __launch_bounds__(256) void eh_count_valid_kernel(EhMechArgs a, int T, unsigned long long* counts) {
+    unsigned c[EH_MAX_TARG] = {0, 0, 0, 0};
+    const long long stride = (long long)gridDim.x * 256 * V;
+    for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * V; i0 < a.n; i0 += 4 * stride)
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t)
+            if (t < T) {
+                if constexpr (V == 4) {
+                    f32x4 v[4];                                  // four trips requested before the first is examined
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = i0 + u * stride < a.n ? *(const f32x4*)(a.y[t] + i0 + u * stride) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * stride < a.n) c[t] += !__builtin_isnan(v[u][0]) + !__builtin_isnan(v[u][1]) + !__builtin_isnan(v[u][2]) + !__builtin_isnan(v[u][3]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * stride < a.n) c[t] += !__builtin_isnan(a.y[t][i0 + u * stride]);
+                }
+            }
+    __shared__ unsigned sh[4][EH_MAX_TARG];
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) {
+        unsigned v = c[t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < T) atomicAdd(&counts[threadIdx.x], (unsigned long long)(sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+}
+
+// (parameters, forcings, outputs) of a registry model: compile-time array sizes, so that a two-parameter model keeps a dozen
+// values per sample in registers, not the 8 + 4 + 4 of the largest one (occupancy is what a streaming kernel lives on)
+constexpr int eh_mech_np(int m) { return m == EH_MECH_EXPO2POOL ? 4 : m == EH_MECH_RS_COMPONENTS ? 6 : m == EH_MECH_FLUXPART ? 3 : 2; }
+constexpr int eh_mech_nf(int m) { return m == EH_MECH_FLUXPART ? 2 : 1; }
+constexpr int eh_mech_no(int m) { return m == EH_MECH_FLUXPART ? 3 : 1; }
+
+template <int V, int MECH>
+__global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMechArgs a) {
+    constexpr int NP = eh_mech_np(MECH), NF = eh_mech_nf(MECH), NO = eh_mech_no(MECH), NTG = NO > 1 ? EH_MAX_TARG : 1;
+    float cpar[NP], lo[NP], sc[NP], w[NTG];
+    int row[NP];                                                 // NN output row of a neural parameter, -1 otherwise
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        cpar[j] = a.meta[EH_IMG_PHI + j]; lo[j] = a.meta[EH_IMG_LO + j]; sc[j] = a.meta[EH_IMG_SC + j];
+        row[j] = (((net.par_kind >> (2 * j)) & 3u) == EH_PAR_NEURAL) ? (int)((net.par_idx >> (4 * j)) & 15u) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) {
+        const unsigned long long c = a.use_v ? a.counts_v[t] : a.counts[t];
+        w[t] = (t < net.T && c > 0) ? 1.0f / (float)c : 0.0f;
+    }
+    float gp[NP], S[NTG];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) gp[j] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NTG; ++t) S[t] = 0.0f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * V; i < a.n; i += (long long)gridDim.x * 256 * V) {
+        float ov[NP][V], fv[NF][V], yv[NTG][V], dov[NP][V], yh[NTG][V];
+        auto ld = [&](const float* p, float (&dst)[V]) {
+            if constexpr (V == 4) { const f32x4 v = *(const f32x4*)(p + i); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+            else dst[0] = p[i];
+        };
+        auto st = [&](float* p, const float (&src)[V]) {
+            if constexpr (V == 4) *(f32x4*)(p + i) = f32x4{src[0], src[1], src[2], src[3]};
+            else p[i] = src[0];
+        };
+        // every load of the tile is requested before the first use
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (row[j] >= 0) ld(a.o + (long long)row[j] * a.ld, ov[j]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ld(a.frc[(net.forc_col >> (8 * f)) & 255u], fv[f]);
+#pragma unroll
+        for (int t = 0; t < NTG; ++t)
+            if (t < net.T) ld(a.y[t], yv[t]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float par[EH_MAX_PARAMS], sg[NP], dydp[EH_MAX_PARAMS], frc[EH_MAX_FORC];
+#pragma unroll
+            for (int j = NP; j < EH_MAX_PARAMS; ++j) { par[j] = 0.0f; dydp[j] = 0.0f; }
+#pragma unroll
+            for (int f = NF; f < EH_MAX_FORC; ++f) frc[f] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                par[j] = cpar[j]; sg[j] = 0.0f; dydp[j] = 0.0f;
+                if (row[j] >= 0) {
+                    if (net.scale_nn) { const float s = eh_sigmoid(ov[j][e]); par[j] = fmaf(sc[j], s, lo[j]); sg[j] = sc[j] * s * (1.0f - s); }
+                    else { par[j] = ov[j][e]; sg[j] = 1.0f; }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) frc[f] = fv[f][e];
+            float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            const float y0 = eh_mech_eval(MECH, par, frc, dydp);
+            if constexpr (NO > 1) eh_mech_extra(MECH, par, frc, yx, Jx);
+            float dy = 0.0f, dyx[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < NTG; ++t)
+                if (t < net.T) {
+                    const int oi = NO > 1 ? (int)((net.targ_out >> (2 * t)) & 3u) : 0;
+                    const float y = oi == 0 ? y0 : (oi == 1 ? yx[0] : yx[1]);
+                    yh[t][e] = y;
+                    const float r = __builtin_isnan(yv[t][e]) ? 0.0f : y - yv[t][e];
+                    S[t] = fmaf(r, r, S[t]);
+                    const float d = 2.0f * w[t] * r;
+                    dy += oi == 0 ? d : 0.0f; dyx[0] += oi == 1 ? d : 0.0f; dyx[1] += oi == 2 ? d : 0.0f;
+                }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                float dp = dy * dydp[j];
+                if (NO > 1 && j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
+                gp[j] += row[j] >= 0 ? 0.0f : dp;
+                dov[j][e] = dp * sg[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (row[j] >= 0) st(a.d_o + (long long)row[j] * a.ld, dov[j]);
+        if (a.yhat)
+#pragma unroll
+            for (int t = 0; t < NTG; ++t)
+                if (t < net.T) st(a.yhat + (long long)t * a.ld, yh[t]);
+    }
+    __shared__ float sh[4][EH_MECH_PART];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float v = eh_wave_sum(k < 8 ? (k < NP ? gp[k < NP ? k : 0] : 0.0f) : (k - 8 < NTG ? S[k - 8 < NTG ? k - 8 : 0] : 0.0f));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) a.part[(long long)blockIdx.x * EH_MECH_PART + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// rows of partials -> out[0] = loss, out[1 + j] = d loss / d raw global parameter j (canonical parameter order), fixed order
+__global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part, int nblk, const EhNet net, const float* meta, const EhMechArgs a, float* out) {
+    const int k = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 64 row groups x 16 columns: 64-byte rows, independent loads
+    __shared__ float red[64][EH_MECH_PART];
+    // the rows were written by other XCDs: every load is a trip to memory, so all of a thread's loads (nblk <= 4096: at most
+    // 64) are requested before the first is used -- one latency instead of one per row
+    float v[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) v[u] = grp + 64 * u < nblk ? part[(long long)(grp + 64 * u) * EH_MECH_PART + k] : 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 64; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+    red[grp][k] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    float s = 0.0f;
+    if (grp == 0)
+        for (int g2 = 0; g2 < 64; ++g2) s += red[g2][k];
+    if (grp != 0) return;
+    __shared__ float St[EH_MAX_TARG];
+    if (k >= 8 && k < 12) {
+        const unsigned long long c = a.use_v ? a.counts_v[k - 8] : a.counts[k - 8];
+        St[k - 8] = (k - 8 < net.T && c > 0) ? s / (float)c : 0.0f;
+    }
+    else if (k < 8) out[1 + k] = (k < net.n_par && ((net.par_kind >> (2 * k)) & 3u) == EH_PAR_GLOBAL) ? s * meta[EH_IMG_DPHI + k] : 0.0f;
+    EH_WAVE_SYNC();                                              // (the 16 threads left are lanes of one wave)
+    if (k == 0) out[0] = (St[0] + St[1]) + (St[2] + St[3]);
+}
+
 // Sum the per-workgroup partials of the step kernel (fixed order: deterministic), normalise by the
 // valid count when the step ran with deferred normalisation, and (APPLY) update theta and its
 // image in place.  Block = CW columns x 256/CW row groups (CW = 16 for small models: many blocks; CW = 64 for
@@ -420,6 +606,8 @@ struct eh_handle_s {
     int net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0};
     int net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}};      // hidden widths of net k
     int net_d[EH_MAX_NETS] = {0};                       // hidden layers of net k (layers past them: identity blocks, not in theta)
+    char* mech_ws = nullptr;                            // eh_mech_loss_vjp: [counts | out | partial rows]
+    size_t mech_ws_bytes = 0;
     int net_c0[EH_MAX_NETS] = {0};                      // first predictor row of net k
     int net_r0[EH_MAX_NETS][EH_MAX_HIDDEN + 1] = {{0}}; // first row of net k in layer l (l == n_hidden: output row)
     int tot_w[EH_MAX_HIDDEN] = {0};                     // total (summed) hidden widths
@@ -1029,6 +1217,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->mech_ws);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1506,6 +1695,78 @@ int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_ta
         o.kge = 1.0 - std::sqrt((o.pearson - 1) * (o.pearson - 1) + (o.alpha - 1) * (o.alpha - 1) + (o.beta - 1) * (o.beta - 1));
         o.pbkge = 1.0 - std::sqrt((o.pearson - 1) * (o.pearson - 1) + (o.beta - 1) * (o.beta - 1));
     }
+    return EH_OK;
+}
+
+int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o_dev, const float* const* forcings_dev, const float* const* targets_dev,
+                         const int64_t* n_valid_in, float* d_o_dev, float* yhat_dev, float* loss, float* grad_global, int64_t* n_valid) {
+    if (!h || !o_dev || !forcings_dev || !targets_dev || !d_o_dev) return EH_EINVAL;
+    const EhNet& net = h->net;
+    if (net.mech == EH_MECH_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: recorded closures are evaluated inside the fused step kernels only");
+    if (net.loss != EH_LOSS_MSE) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: training loss %d (built: mse)", net.loss);
+    if (count < 1 || ld < count) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: count %lld, ld %lld", (long long)count, (long long)ld);
+    for (int f = 0; f < net.F; ++f) if (!forcings_dev[f]) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: forcing %d is null", f);
+    for (int t = 0; t < net.T; ++t) if (!targets_dev[t]) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: target %d is null", t);
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    EhMechArgs a{};
+    a.o = o_dev; a.d_o = d_o_dev; a.yhat = yhat_dev; a.n = count; a.ld = ld; a.meta = h->image + h->arch->phi_off;
+    bool vec = count % 4 == 0 && ld % 4 == 0 && ((uintptr_t)o_dev | (uintptr_t)d_o_dev | (uintptr_t)yhat_dev) % 16 == 0;
+    for (int f = 0; f < net.F; ++f) { a.frc[f] = forcings_dev[f]; vec = vec && (uintptr_t)forcings_dev[f] % 16 == 0; }
+    for (int t = 0; t < net.T; ++t) { a.y[t] = targets_dev[t]; vec = vec && (uintptr_t)targets_dev[t] % 16 == 0; }
+    const int per = vec ? 1024 : 256;                                      // samples per workgroup and trip
+    if (net.n_out == 1 && net.T > 1) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: %d targets on a single-output model", net.T);
+    const int nblk = (int)std::min<int64_t>((count + per - 1) / per, 4096);
+    const size_t need = (size_t)nblk * EH_MECH_PART * sizeof(float) + 64 + EH_MAX_TARG * sizeof(unsigned long long);
+    if (need > h->mech_ws_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->mech_ws);
+        h->mech_ws = nullptr; h->mech_ws_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->mech_ws, (size_t)4096 * EH_MECH_PART * sizeof(float) + 64 + EH_MAX_TARG * sizeof(unsigned long long)));
+        h->mech_ws_bytes = (size_t)4096 * EH_MECH_PART * sizeof(float) + 64 + EH_MAX_TARG * sizeof(unsigned long long);
+    }
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(h->mech_ws);
+    float* out = reinterpret_cast<float*>(h->mech_ws + EH_MAX_TARG * sizeof(unsigned long long));        // [loss | 8 gradients]
+    a.part = out + 16;
+    a.counts = counts;
+    unsigned long long hc[EH_MAX_TARG] = {0, 0, 0, 0};
+    if (n_valid_in) {                        // masks are a property of the data set (src/training/train.jl:221-232): the caller may know the counts
+        for (int t = 0; t < net.T; ++t) { if (n_valid_in[t] < 0 || n_valid_in[t] > count) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: n_valid_in[%d] = %lld", t, (long long)n_valid_in[t]); hc[t] = (unsigned long long)n_valid_in[t]; }
+        for (int t = 0; t < EH_MAX_TARG; ++t) a.counts_v[t] = hc[t];
+        a.use_v = 1;                                             // travels in the kernarg segment: no copy, no counting pass
+    } else {
+        HIPCHK(h, hipMemsetAsync(counts, 0, sizeof hc, h->stream));
+        const unsigned ncb = (unsigned)std::min(nblk, 512);      // (one atomic per workgroup and target on ONE address: they serialise, ~13 ns each)
+        if (vec) hipLaunchKernelGGL(eh_count_valid_kernel<4>, dim3(ncb), dim3(256), 0, h->stream, a, net.T, counts);
+        else hipLaunchKernelGGL(eh_count_valid_kernel<1>, dim3(ncb), dim3(256), 0, h->stream, a, net.T, counts);
+        HIPCHK(h, hipGetLastError());
+    }
+#define EH_MECH_GO(M)                                                                                                              \
+    case M:                                                                                                                      \
+        if (vec) hipLaunchKernelGGL((eh_mech_vjp_kernel<4, M>), dim3((unsigned)nblk), dim3(256), 0, h->stream, net, a);           \
+        else hipLaunchKernelGGL((eh_mech_vjp_kernel<1, M>), dim3((unsigned)nblk), dim3(256), 0, h->stream, net, a);               \
+        break;
+    switch (net.mech) {
+        EH_MECH_GO(EH_MECH_RBQ10) EH_MECH_GO(EH_MECH_EXPO) EH_MECH_GO(EH_MECH_LINEAR) EH_MECH_GO(EH_MECH_EXPO2POOL)
+        EH_MECH_GO(EH_MECH_RS_COMPONENTS) EH_MECH_GO(EH_MECH_FLUXPART)
+        default: return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: mechanistic model %d", net.mech);
+    }
+#undef EH_MECH_GO
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(eh_mech_finish_kernel, dim3(1), dim3(1024), 0, h->stream, a.part, nblk, net, a.meta, a, out);
+    HIPCHK(h, hipGetLastError());
+    if (!loss && !grad_global && !n_valid) return EH_OK;         // asynchronous use: results stay on the device, ordered on the handle's stream
+    float ho[9];
+    HIPCHK(h, hipMemcpyAsync(ho, out, sizeof ho, hipMemcpyDeviceToHost, h->stream));
+    if (!a.use_v) HIPCHK(h, hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    long long nv = 0;
+    for (int t = 0; t < net.T; ++t) nv += (long long)hc[t];
+    if (n_valid) *n_valid = nv;
+    if (loss) *loss = nv > 0 ? ho[0] : __builtin_nanf("");      // all-masked batch: skipped (epoch.jl:17-19)
+    if (grad_global)
+        for (int j = 0; j < h->desc.n_params; ++j)
+            if (h->desc.param_kind[j] == EH_PAR_GLOBAL) grad_global[h->desc.param_index[j]] = ho[1 + j];
     return EH_OK;
 }
 

@@ -232,6 +232,23 @@ class HybridEngine:
                                            C.byref(loss) if want_loss else None, C.byref(ns)))
         return (float(loss.value) if want_loss else None), int(ns.value)
 
+    # -- the mechanistic stage on its own (NN outside the library) ----------------------------------
+    def mech_loss_vjp(self, count: int, o_ptr: int, forcing_ptrs: Sequence[int], target_ptrs: Sequence[int], d_o_ptr: int,
+                      yhat_ptr: int = 0, ld: Optional[int] = None, n_valid_in: Optional[Sequence[int]] = None, results: bool = True):
+        """Device pointers in (o [K][ld], the F forcing and T target arrays), d loss / d o out ([K][ld]); returns
+        (loss, gradient of the raw global parameters, n_valid), or None with results=False (asynchronous on the stream).
+        include/easyhybrid_hip.h: eh_mech_loss_vjp."""
+        fp = (C.c_void_p * max(1, len(forcing_ptrs)))(*forcing_ptrs)
+        tp = (C.c_void_p * max(1, len(target_ptrs)))(*target_ptrs)
+        nin = (C.c_int64 * len(n_valid_in))(*n_valid_in) if n_valid_in is not None else None
+        G = sum(1 for j in range(self.desc.n_params) if self.desc.param_kind[j] == L.PAR_GLOBAL)
+        loss, nv = C.c_float(), C.c_int64()
+        gg = np.zeros(max(G, 1), np.float32)
+        self._chk(self._lib.eh_mech_loss_vjp(self._h, count, ld if ld is not None else count, o_ptr, fp, tp, nin, d_o_ptr, yhat_ptr or None,
+                                             C.byref(loss) if results else None, gg.ctypes.data_as(L._F) if results else None,
+                                             C.byref(nv) if results else None))
+        return (float(loss.value), gg[:G], int(nv.value)) if results else None
+
     # -- data-parallel seam ----------------------------------------------------------------------
     def dp_grad(self, first: int, count: int):
         self._chk(self._lib.eh_dp_grad(self._h, first, count))

@@ -199,6 +199,21 @@ int32_t eh_get_params(eh_handle* h, float* theta, int64_t n);
  * yhat: T host arrays of count floats (or NULL); params: n_params host arrays of count floats (or NULL). */
 int32_t eh_forward(eh_handle* h, int32_t split, int64_t first, int64_t count, float* const* yhat, float* const* params);
 
+/* The mechanistic stage on its own, for a neural network that lives OUTSIDE this library (a Lux / Flux chain on the caller's GPU):
+ * o = its outputs for `count` samples -> physical parameters (sigmoid scaling when scale_nn_outputs; GenericHybridModel.jl:404-411)
+ * -> mechanistic model -> masked MSE summed over the targets (compute_loss.jl:50-53, loss_fn.jl:61-63) -> d loss / d o, the
+ * gradient of the raw global parameters and, optionally, the predictions.  What `Zygote.pullback` hands back at the NN boundary
+ * of GenericHybridModel.jl:389-425.  ALL array arguments are DEVICE pointers: o_dev / d_o_dev are [K][ld] (row k = neural
+ * parameter k, ld >= count floats apart), forcings_dev / targets_dev the F / T arrays in eh_set_data order (NaN target =
+ * missing), yhat_dev [T][ld] or NULL.  Global / fixed parameters are those of the handle (eh_set_params).  n_valid_in: valid
+ * samples per target if the caller knows them (masks belong to the data set, train.jl:221-232), NULL = counted here by a pass
+ * over the targets.  loss / grad_global (G floats, global_param_names order) / n_valid are HOST outputs; pass all three NULL to
+ * leave the call asynchronous on the handle's stream.  A pure streaming kernel: 4 (K + F + T) bytes read and 4 K written per
+ * sample (16-byte accesses when count, ld and the pointers allow).  EH_EUNSUPPORTED: recorded closures, losses other than mse. */
+int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o_dev, const float* const* forcings_dev,
+                         const float* const* targets_dev, const int64_t* n_valid_in, float* d_o_dev, float* yhat_dev,
+                         float* loss, float* grad_global, int64_t* n_valid);
+
 /* compute_loss(train_mode) value and its gradient wrt flat theta on one minibatch, no update
  * (the objective Zygote differentiates, src/training/epoch.jl:40-51; also the seam
  * train_optimization.jl:121-133 would use).  idx: optional count sample indices (host, int32) into the

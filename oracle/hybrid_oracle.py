@@ -695,6 +695,51 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
     return loss, grad, nvalid
 
 
+def mech_loss_vjp(spec: HybridSpec, theta, o, forcings, targets, dtype=np.float64):
+    """The mechanistic stage on its own: o (K, B) = raw NN outputs of a network evaluated elsewhere -> physical parameters
+    (GenericHybridModel.jl:404-411) -> M -> masked MSE summed over targets (compute_loss.jl:50-53, loss_fn.jl:61-63) and its
+    pullback to o and to the raw global parameters.  Returns (loss, d loss / d o (K, B), d loss / d raw globals (G,), n_valid per
+    target, {target: yhat}).  Same arithmetic as forward() / loss_and_grad() from k3 on."""
+    dt = np.dtype(dtype)
+    o = np.asarray(o, dt)
+    B = o.shape[1]
+    _, raw = unpack(spec, np.asarray(theta, dt))
+    glob = {g: dt.type(spec.lo(g)) + dt.type(spec.hi(g) - spec.lo(g)) * _sigmoid(r.reshape(1)) for g, r in zip(spec.glob, raw)}
+    nn = {n: (dt.type(spec.lo(n)) + dt.type(spec.hi(n) - spec.lo(n)) * _sigmoid(o[k])) if spec.scale_nn_outputs else o[k]
+          for k, n in enumerate(spec.neural)}
+    par = {**nn, **glob, **{f: np.full(1, spec.default(f), dt) for f in spec.fixed}}
+    frc = {k: np.asarray(v, dt) for k, v in forcings.items()}
+    mm, fwd, vjp = MECH[spec.mech]
+    out, aux = fwd(par, frc, dt)
+    out = {k: np.broadcast_to(v, (B,)).astype(dt) for k, v in out.items()}
+    loss, dout, nvalid = dt.type(0), {}, []
+    for t in spec.targets:
+        y = np.asarray(targets[t], dt)
+        m = valid_mask(y)
+        n = int(m.sum()); nvalid.append(n)
+        d = np.zeros(B, dt)
+        if n > 0:
+            r = np.where(m, out[t] - np.where(m, y, 0), 0).astype(dt)
+            loss = loss + np.sum(r * r) / dt.type(n)
+            d = dt.type(2) * r / dt.type(n)
+        dout[t] = d
+    for oname in mm.outputs:
+        dout.setdefault(oname, np.zeros(B, dt))
+    dpar = vjp(par, frc, out, aux, dout, dt)
+    graw = []
+    for g, r in zip(spec.glob, raw):
+        s = _sigmoid(r.reshape(1))[0]
+        graw.append(np.sum(dpar[g]) * dt.type(spec.hi(g) - spec.lo(g)) * s * (1 - s))
+    do = np.zeros_like(o)
+    for k, n in enumerate(spec.neural):
+        d = np.broadcast_to(dpar[n], (B,)).astype(dt)
+        if spec.scale_nn_outputs:
+            s = _sigmoid(o[k])
+            d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
+        do[k] = d
+    return float(loss), do, np.asarray(graw, dt), nvalid, {t: out[t] for t in spec.targets}
+
+
 # ----------------------------------------------------------------------------------------------
 # optimiser rules (Optimisers.jl restated; state is a dict)
 # ----------------------------------------------------------------------------------------------

@@ -411,6 +411,88 @@ def test_dp_seam_and_front_door_with_per_network_activations_and_depths():
     assert len(out.val_history) == 5 and out.val_history[-1]["mse"]["sum"] < out.val_history[0]["mse"]["sum"]
 
 
+# ----------------------------------------------------------------------------------------------
+# the mechanistic stage on its own (eh_mech_loss_vjp): NN outputs in, d loss / d o out, all on the device
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mech,B,scale", [("rbq10", 4096, True), ("rbq10", 1001, False), ("expo2pool", 2048, True), ("rs_components", 777, True),
+                                          ("fluxpart", 4000, True), ("linear", 64, False)])
+def test_mech_stage_alone(mech, B, scale):
+    import torch
+    tabs = {"rbq10": (dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], None),
+            "expo2pool": (dict(ho.EXPO2POOL_PARAMS), ["R0a", "R0b"], ["ka", "kb"], None),
+            "rs_components": ({**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in ("het", "root", "myc")}, **{f"Q10_{c}": (2.0, 1.0, 4.0) for c in ("het", "root", "myc")}},
+                              ["Rb_het", "Rb_root", "Rb_myc"], ["Q10_het", "Q10_myc"], None),       # Q10_root fixed at its default
+            "fluxpart": (dict(FLUX_PARAMS), ["RUE", "Rb"], ["Q10"], ["NEE", "RECO", "GPP"]),
+            "linear": ({"alpha": (1.0, -2.0, 3.0), "beta": (0.5, -1.0, 2.0)}, ["alpha", "beta"], [], None)}
+    tab, neural, glob, targets = tabs[mech]
+    mm = ho.MECH[mech][0]
+    targets = targets or [mm.outputs[0]]
+    spec = ho.HybridSpec(3, [8], mech, tab, neural, glob, targets, "tanh", scale)
+    rng = np.random.default_rng(17)
+    K = len(neural)
+    o = (rng.standard_normal((K, B)) * (1.0 if scale else 0.3) + (0.0 if scale else 1.5)).astype(np.float32)
+    f = {k: rng.uniform(1, 25, B).astype(np.float32) for k in mm.forcings}
+    y = {t: rng.uniform(0.5, 6, B).astype(np.float32) for t in targets}
+    for v in y.values():
+        v[rng.random(B) < 0.15] = np.nan
+    theta = ho.init_theta(spec, 18, np.float32)
+    theta[spec.n_nn:] += rng.uniform(-0.5, 0.5, len(glob)).astype(np.float32)        # globals away from their defaults
+    eng = util.model_from_spec(spec).engine()
+    eng.set_params(theta)
+    od = torch.from_numpy(o).cuda(); dod = torch.full_like(od, float("nan")); yh = torch.empty((len(targets), B), device="cuda")
+    fd = [torch.from_numpy(f[k]).cuda() for k in mm.forcings]; yd = [torch.from_numpy(y[t]).cuda() for t in targets]
+    loss, gg, nv = eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in yd], dod.data_ptr(), yh.data_ptr())
+    l0, do0, gg0, nv0, yh0 = ho.mech_loss_vjp(spec, theta.astype(np.float64), o, f, y)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL)
+    assert util.relerr(dod.cpu().numpy(), do0) <= TOL
+    if glob:
+        assert util.relerr(gg, gg0) <= TOL
+    for i, t in enumerate(targets):
+        assert util.relerr(yh[i].cpu().numpy(), yh0[t]) <= TOL
+    # the caller knows the masks' counts (they belong to the data set): same result without the counting pass
+    loss2, gg2, nv2 = eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in yd], dod.data_ptr(), n_valid_in=nv0)
+    assert loss2 == loss and nv2 == nv and np.array_equal(gg2, gg)
+    # a window inside wider planes (ld > count) at an odd offset: the scalar-access kernel
+    if B > 100:
+        c = B - 37
+        dod.fill_(float("nan"))
+        l3, _, nv3 = eng.mech_loss_vjp(c, od.data_ptr() + 4 * 5, [t.data_ptr() + 4 * 5 for t in fd], [t.data_ptr() + 4 * 5 for t in yd], dod.data_ptr() + 4 * 5, ld=B)
+        l30, do30, _, nv30, _ = ho.mech_loss_vjp(spec, theta.astype(np.float64), o[:, 5:5 + c], {k: v[5:5 + c] for k, v in f.items()}, {k: v[5:5 + c] for k, v in y.items()})
+        assert nv3 == sum(nv30) and l3 == pytest.approx(l30, rel=TOL) and util.relerr(dod.cpu().numpy()[:, 5:5 + c], do30) <= TOL
+        assert np.isnan(dod.cpu().numpy()[:, :5]).all() and np.isnan(dod.cpu().numpy()[:, 5 + c:]).all()      # nothing outside the window is written
+    # all targets missing: skipped batch (epoch.jl:17-19)
+    ynan = [torch.full((B,), float("nan"), device="cuda") for _ in targets]
+    l4, _, nv4 = eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in ynan], dod.data_ptr())
+    assert nv4 == 0 and np.isnan(l4) and not dod.cpu().numpy().any()
+    eng.close()
+
+
+def test_mech_stage_alone_full_size_properties():
+    """B = 4 194 304 (64 batches of BASELINE configs[1]): the loss is the count-weighted mean of the losses of its quarters, and
+    d loss / d o of the whole is the quarters' scaled by n_q / n (size-independent properties; no oracle run at this size)"""
+    import torch
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    B = 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(5)
+    od = torch.randn((1, B), device="cuda", generator=g)
+    ta = torch.rand(B, device="cuda", generator=g) * 30
+    yv = torch.rand(B, device="cuda", generator=g) * 8 + 1
+    yv[torch.rand(B, device="cuda", generator=g) < 0.05] = float("nan")
+    eng = util.model_from_spec(spec).engine(); eng.set_params(ho.init_theta(spec, 1, np.float32))
+    dod = torch.empty_like(od)
+    loss, gg, nv = eng.mech_loss_vjp(B, od.data_ptr(), [ta.data_ptr()], [yv.data_ptr()], dod.data_ptr())
+    assert nv == int((~torch.isnan(yv)).sum())
+    q = B // 4
+    acc, gacc = 0.0, 0.0
+    dq = torch.empty((1, q), device="cuda")
+    for i in range(4):
+        lq, gq, nq = eng.mech_loss_vjp(q, od.data_ptr() + 4 * i * q, [ta.data_ptr() + 4 * i * q], [yv.data_ptr() + 4 * i * q], dq.data_ptr())
+        acc += lq * nq; gacc += float(gq[0]) * nq
+        assert torch.allclose(dod[:, i * q:(i + 1) * q], dq * (nq / nv), rtol=2e-6, atol=1e-12)
+    assert loss == pytest.approx(acc / nv, rel=2e-6) and float(gg[0]) == pytest.approx(gacc / nv, rel=2e-5)
+    eng.close()
+
+
 def test_set_data_from_device_pointers():
     import torch
     spec, theta, X, f, y = util.rbq10_case(777, "tanh", True, 0.1)

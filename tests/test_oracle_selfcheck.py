@@ -54,6 +54,50 @@ def test_hand_vjp_matches_finite_differences(act, scale):
         assert fd == pytest.approx(g[k], rel=2e-5, abs=1e-8)
 
 
+@pytest.mark.parametrize("mech", ["rbq10", "expo2pool", "fluxpart"])
+def test_mech_stage_alone_is_the_tail_of_the_full_path(mech):
+    """ho.mech_loss_vjp (the oracle of eh_mech_loss_vjp) fed with the NN outputs of the full forward: same loss, same gradient of
+    the globals, and d loss / d o pushed through the network's own backward gives the full gradient (chain rule); d loss / d o
+    itself against central differences of the loss in o."""
+    tabs = {"rbq10": (dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], None), "expo2pool": (dict(ho.EXPO2POOL_PARAMS), ["R0a", "R0b"], ["ka", "kb"], None),
+            "fluxpart": ({"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}, ["RUE", "Rb"], ["Q10"], ["NEE", "RECO"])}
+    tab, neural, glob, targets = tabs[mech]
+    mm = ho.MECH[mech][0]
+    targets = targets or [mm.outputs[0]]
+    spec = ho.HybridSpec(3, [8, 8], mech, tab, neural, glob, targets, "tanh", True)
+    rng = np.random.default_rng(8)
+    B = 70
+    X = rng.standard_normal((3, B))
+    f = {k: rng.uniform(1, 25, B) for k in mm.forcings}
+    y = {t: rng.uniform(0.5, 6, B) for t in targets}
+    for v in y.values():
+        v[rng.random(B) < 0.2] = np.nan
+    th = ho.init_theta(spec, 9, np.float64)
+    res = ho.forward(spec, th, X, f, keep=True)
+    o = res["_tape"]["o"]
+    l0, g0, nv0 = ho.loss_and_grad(spec, th, X, f, y)
+    l, do, gg, nv, yh = ho.mech_loss_vjp(spec, th, o, f, y)
+    assert nv == nv0 and l == pytest.approx(l0, rel=1e-13)
+    assert np.allclose(gg, g0[spec.n_nn:], rtol=1e-12, atol=1e-15)
+    for t in targets:
+        assert np.allclose(yh[t], res[t], rtol=1e-13)
+    # the network's backward applied to do: last layer first
+    (Ws, zs, hs), = res["_tape"]["nets"]
+    delta, gW = do, []
+    for li in reversed(range(len(Ws))):
+        W, b = Ws[li]
+        gW.append((delta @ hs[li].T, delta.sum(axis=1)))
+        if li > 0:
+            delta = (W.T @ delta) * ho.act_bwd("tanh", zs[li - 1], hs[li])
+    gW.reverse()
+    assert np.allclose(ho.pack(spec, [gW], gg, np.float64), g0, rtol=1e-11, atol=1e-14)
+    for _ in range(10):
+        k, i = int(rng.integers(o.shape[0])), int(rng.integers(B))
+        e = np.zeros_like(o); e[k, i] = 1e-6
+        fd = (ho.mech_loss_vjp(spec, th, o + e, f, y)[0] - ho.mech_loss_vjp(spec, th, o - e, f, y)[0]) / 2e-6
+        assert fd == pytest.approx(do[k, i], rel=2e-5, abs=2e-8)
+
+
 def test_nets_of_different_depth_vjp():
     # hidden_layers = (a = [16, 8], d = [8]) (test/test_generic_hybrid_model.jl:346): theta holds every net with its own layers
     nets = [([0, 1], [16, 8]), ([2], [8])]
