@@ -454,6 +454,25 @@ function loss_and_grad(e::HybridEngine, split::Integer, first::Integer, count::I
     return loss[], g, nv[]
 end
 "evaluate_acc (src/training/train.jl:347-355): nested (mse = (reco = .., sum = ..), r2 = ...) like compute_loss.jl:55-66"
+"""
+    mech_loss_vjp!(e, o, forcings, targets, ∂o; n_valid = nothing) -> (loss, ∇globals, n_valid)
+
+The mechanistic stage on its own (`eh_mech_loss_vjp`): `o` = outputs of a neural network evaluated elsewhere on the same GPU,
+`B × K` (column k = neural parameter k), `forcings` / `targets` vectors of B — all DEVICE arrays (anything `pointer` returns a
+device address for, e.g. `ROCArray{Float32}`); `∂o` receives d loss / d o.  Feed it to the network's pullback.
+"""
+function mech_loss_vjp!(e::HybridEngine, o, forcings, targets, ∂o; n_valid = nothing)
+    B = size(o, 1)
+    fp = Ptr{Float32}[reinterpret(Ptr{Float32}, pointer(f)) for f in forcings]; tp = Ptr{Float32}[reinterpret(Ptr{Float32}, pointer(t)) for t in targets]
+    loss = Ref{Float32}(NaN32); nv = Ref{Int64}(0); g = zeros(Float32, max(1, length(e.model.global_param_names)))
+    nvec = n_valid === nothing ? Int64[] : Int64.(collect(n_valid))
+    nin = n_valid === nothing ? Ptr{Int64}(C_NULL) : pointer(nvec)
+    GC.@preserve o ∂o forcings targets fp tp nvec check(e, @ccall LIB[].eh_mech_loss_vjp(e.h::Ptr{Cvoid}, B::Int64, B::Int64,
+        reinterpret(Ptr{Float32}, pointer(o))::Ptr{Float32}, fp::Ptr{Ptr{Float32}}, tp::Ptr{Ptr{Float32}}, nin::Ptr{Int64},
+        reinterpret(Ptr{Float32}, pointer(∂o))::Ptr{Float32}, C_NULL::Ptr{Float32}, loss::Ref{Float32}, g::Ptr{Float32}, nv::Ref{Int64})::Int32)
+    return loss[], g[1:length(e.model.global_param_names)], nv[]
+end
+
 function evaluate(e::HybridEngine, split::Integer, n::Integer; loss_types = [:mse, :r2])
     T = length(e.model.targets)
     m = Vector{EhTargetMetrics}(undef, T)
