@@ -103,6 +103,22 @@ def test_create_rejects_bad_descriptors_before_touching_a_device():
     assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL
     assert lib.eh_create(None, C.byref(h)) == L.EH_EINVAL
     assert lib.eh_destroy(None) == L.EH_OK
+    # per-net activations / depths are MultiNN fields
+    d = _model().to_desc()
+    d.activation = L.EH_ACT_PER_NET                       # SingleNN descriptor
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL and b"MultiNN" in lib.eh_last_error(None)
+    mm = eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, {"rb": (3, 0, 13), "Q10": (2, 1, 4)}, [],
+                                 hidden_layers={"rb": [16], "Q10": [8, 4]}, activation={"rb": "relu", "Q10": "tanh"})
+    d = mm.to_desc()
+    d.net_activation[1] = 17
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EUNSUPPORTED and b"activation id 17" in lib.eh_last_error(None)
+    d = mm.to_desc()
+    d.net_depth[0] = 3                                    # deeper than n_hidden
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL and b"net_depth" in lib.eh_last_error(None)
+    d = mm.to_desc()
+    d.net_depth[1] = 1                                    # nobody is n_hidden deep any more
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL and b"no net is that deep" in lib.eh_last_error(None)
+    assert lib.eh_mech_loss_vjp(None, 4, 4, None, None, None, None, None, None, None, None, None) == L.EH_EINVAL
 
 
 def test_descriptor_from_model():
