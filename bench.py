@@ -240,12 +240,12 @@ def main():
         if world == 1 and dp is None and not args.no_mech_stage:
             # the HBM-bound stage of the path measured as its own kernel (the fused step is compute / latency
             # bound, so the north_star's HBM yardstick applies to the mechanistic + loss + VJP stage alone): eh_mech_loss_vjp on
-            # 256 resident batches of the headline workload.  A secondary figure; `roofline` above stays the step kernel's.
+            # 1 024 resident batches of the headline workload (a working set the Infinity Cache cannot hold).  A secondary figure; `roofline` above stays the step kernel's.
             try:
                 import importlib.util
                 spec_ = importlib.util.spec_from_file_location("eh_bench_mech", os.path.join(ROOT, "tools", "bench_mech.py"))
                 bm = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bm)
-                out["hbm_stage"] = bm.measure("rbq10", 256 * B, 50)
+                out["hbm_stage"] = bm.measure("rbq10", 1024 * B, 50)      # 1 GiB of planes: four times the 256 MB Infinity Cache
             except Exception as e:      # never lose the headline line over the secondary measurement
                 out["hbm_stage"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -25,7 +25,7 @@ CONFIGS = {
 }
 
 
-def measure(mech="rbq10", batch=1 << 24, steps=50):
+def measure(mech="rbq10", batch=1 << 24, steps=50, stagger=0):
     """-> dict (one JSON line of this tool).  Needs a GPU; creates its own engine and a named torch stream."""
     import torch
     import easyhybrid_jl_amd as eh
@@ -43,14 +43,26 @@ def measure(mech="rbq10", batch=1 << 24, steps=50):
         eng.set_params(model.initialparameters(1))
         B, K, F, T = batch, len(neural), len(forc), len(targ)
         g = torch.Generator(device="cuda").manual_seed(0)
-        o = torch.randn((K, B), device="cuda", generator=g)
-        fr = [torch.rand(B, device="cuda", generator=g) * 25 + 1 for _ in forc]
+        nplane = [0]
+
+        def plane(rows, fill):
+            """a [rows][B] array whose start is shifted by (its ordinal x stagger) bytes: experiment on how the planes' relative
+            placement meets the HBM channel interleave (stagger = 0: wherever the allocator puts them)"""
+            pad = (nplane[0] * stagger) // 4
+            nplane[0] += 1
+            buf = torch.empty(rows * B + pad, device="cuda")
+            v = buf[pad:].view(rows, B)
+            fill(v)
+            return v
+
+        o = plane(K, lambda v: v.normal_(generator=g))
+        fr = [plane(1, lambda v: v.uniform_(1, 26, generator=g))[0] for _ in forc]
         ys = []
         for _ in targ:
-            y = torch.rand(B, device="cuda", generator=g) * 6 + 0.5
+            y = plane(1, lambda v: v.uniform_(0.5, 6.5, generator=g))[0]
             y[torch.rand(B, device="cuda", generator=g) < 0.05] = float("nan")
             ys.append(y)
-        d_o = torch.empty_like(o)
+        d_o = plane(K, lambda v: v.zero_())
         nvalid = [int((~torch.isnan(y)).sum()) for y in ys]
         fp, tp = [t.data_ptr() for t in fr], [t.data_ptr() for t in ys]
         bytes_alg = 4 * (K + F + T) * B + 4 * K * B
@@ -74,7 +86,7 @@ def measure(mech="rbq10", batch=1 << 24, steps=50):
         torch.cuda.set_stream(prev)
         eng.close()
     return {"kernel": "eh_mech_vjp_kernel<4, %s> + eh_mech_finish_kernel (one eh_mech_loss_vjp call, counts of valid targets handed in)" % mech,
-            "mech": mech, "batch": B, "K": K, "F": F, "T": T, "bound": "hbm",
+            "mech": mech, "batch": B, "stagger_bytes": stagger, "K": K, "F": F, "T": T, "bound": "hbm",
             "algorithmic_bytes_per_sample": bytes_alg // B, "ms_per_call": ms_known, "achieved": bytes_alg / ms_known / 1e6, "peak": 8000.0,
             "unit": "GB/s", "frac": bytes_alg / ms_known / 1e6 / 8000, "ms_per_call_with_counting_pass": ms_count,
             "GBps_with_counting_pass": (bytes_alg + 4 * T * B) / ms_count / 1e6, "samples_per_s": B / ms_known * 1e3,
@@ -86,8 +98,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 24)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--mech", default="rbq10", choices=sorted(CONFIGS))
+    ap.add_argument("--stagger", type=int, default=0, help="shift the start of plane k by k x this many bytes (multiple of 16)")
     args = ap.parse_args()
-    print(json.dumps(measure(args.mech, args.batch, args.steps)))
+    print(json.dumps(measure(args.mech, args.batch, args.steps, args.stagger)))
 
 
 if __name__ == "__main__":
