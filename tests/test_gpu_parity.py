@@ -467,6 +467,46 @@ def test_mech_stage_alone(mech, B, scale):
     eng.close()
 
 
+def test_mech_stage_trains_an_external_torch_network_like_the_fused_engine():
+    """The seam end to end: a torch MLP (autograd) on the GPU + eh_mech_loss_vjp for everything after the network, five plain
+    gradient-descent steps, against the fused engine training the same model from the same theta (one kernel does it all there)."""
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1)
+    B, lr = 2048, 0.01
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Descent", lr)
+    for _ in range(5):
+        ref.train_step(0, B, want_loss=False)
+    th_ref = ref.get_params(); ref.close()
+    (layers,), raw = ho.unpack(spec, theta.astype(np.float64))
+    Ws = [torch.tensor(W, dtype=torch.float32, device="cuda", requires_grad=True) for W, _ in layers]
+    bs = [torch.tensor(b, dtype=torch.float32, device="cuda", requires_grad=True) for _, b in layers]
+    q_raw = np.float32(raw[0])
+    xd = torch.from_numpy(X).cuda(); tad = torch.from_numpy(f["ta"]).cuda(); yd = torch.from_numpy(y["reco"]).cuda()
+    eng = util.model_from_spec(spec).engine()
+    th = theta.copy()
+    for _ in range(5):
+        eng.set_params(th)                                   # the engine holds the global parameter (Q10); the network lives in torch
+        h = xd
+        for li, (W, b) in enumerate(zip(Ws, bs)):
+            h = W @ h + b[:, None]
+            if li < len(Ws) - 1:
+                h = torch.tanh(h)
+        o = h.contiguous()                                   # (1, B) raw NN output
+        d_o = torch.empty_like(o)
+        torch.cuda.synchronize()                             # (the engine runs on its own stream)
+        loss, gg, nv = eng.mech_loss_vjp(B, o.data_ptr(), [tad.data_ptr()], [yd.data_ptr()], d_o.data_ptr())
+        o.backward(d_o)                                      # the network's pullback, by autograd
+        with torch.no_grad():
+            for p_ in Ws + bs:
+                p_ -= lr * p_.grad; p_.grad = None
+        q_raw = np.float32(q_raw - np.float32(lr) * gg[0])
+        nets = [[(W.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64)) for W, b in zip(Ws, bs)]]
+        th = ho.pack(spec, nets, [np.array([q_raw], np.float64)], np.float64).astype(np.float32)
+    # torch.tanh is the exact function, the engine's NN uses NNlib's tanh_fast rational like LuxLib (DESIGN section 5): 1e-6 apart
+    assert np.max(np.abs(th - th_ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    eng.close()
+
+
 def test_mech_stage_alone_full_size_properties():
     """B = 4 194 304 (64 batches of BASELINE configs[1]): the loss is the count-weighted mean of the losses of its quarters, and
     d loss / d o of the whole is the quarters' scaled by n_q / n (size-independent properties; no oracle run at this size)"""
