@@ -83,6 +83,7 @@ struct EhMechArgs {
     unsigned long long counts_v[EH_MAX_TARG];   // ... or handed in by the caller (use_v)
     int use_v;
     float* part;                             // [gridDim.x][EH_MECH_PART] partial sums
+    const unsigned* prog;                    // EH_MECH_PROGRAM: the recorded closure (EhStepArgs::prog layout)
 };
 enum { EH_MECH_PART = 16 };                  // [dL/dpar_j (8) | S_t (4) | pad]
 
@@ -120,9 +121,10 @@ __global__ __launch_bounds__(256) void eh_count_valid_kernel(EhMechArgs a, int T
 
 // (parameters, forcings, outputs) of a registry model: compile-time array sizes, so that a two-parameter model keeps a dozen
 // values per sample in registers, not the 8 + 4 + 4 of the largest one (occupancy is what a streaming kernel lives on)
-constexpr int eh_mech_np(int m) { return m == EH_MECH_EXPO2POOL ? 4 : m == EH_MECH_RS_COMPONENTS ? 6 : m == EH_MECH_FLUXPART ? 3 : 2; }
-constexpr int eh_mech_nf(int m) { return m == EH_MECH_FLUXPART ? 2 : 1; }
-constexpr int eh_mech_no(int m) { return m == EH_MECH_FLUXPART ? 3 : 1; }
+// (EH_MECH_PROGRAM, a recorded closure run by the interpreter of eh_device.hpp: the limits of the program format)
+constexpr int eh_mech_np(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_PARAMS : m == EH_MECH_EXPO2POOL ? 4 : m == EH_MECH_RS_COMPONENTS ? 6 : m == EH_MECH_FLUXPART ? 3 : 2; }
+constexpr int eh_mech_nf(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_FORC : m == EH_MECH_FLUXPART ? 2 : 1; }
+constexpr int eh_mech_no(int m) { return (m == EH_MECH_PROGRAM || m == EH_MECH_FLUXPART) ? 3 : 1; }
 
 template <int V, int MECH>
 __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMechArgs a) {
@@ -159,7 +161,13 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
         for (int j = 0; j < NP; ++j)
             if (row[j] >= 0) ld(a.o + (long long)row[j] * a.ld, ov[j]);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) ld(a.frc[(net.forc_col >> (8 * f)) & 255u], fv[f]);
+        for (int f = 0; f < NF; ++f) {
+            const unsigned col = (net.forc_col >> (8 * f)) & 255u;
+            if (col != 255u) ld(a.frc[col], fv[f]);
+            else
+#pragma unroll
+                for (int e = 0; e < V; ++e) fv[f][e] = 0.0f;
+        }
 #pragma unroll
         for (int t = 0; t < NTG; ++t)
             if (t < net.T) ld(a.y[t], yv[t]);
@@ -181,8 +189,17 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
 #pragma unroll
             for (int f = 0; f < NF; ++f) frc[f] = fv[f][e];
             float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-            const float y0 = eh_mech_eval(MECH, par, frc, dydp);
-            if constexpr (NO > 1) eh_mech_extra(MECH, par, frc, yx, Jx);
+            constexpr bool PROG = MECH == EH_MECH_PROGRAM;
+            float pval[PROG ? EH_PROG_SLOTS : 1], y0;
+            if constexpr (PROG) {
+                eh_prog_forward(a.prog, par, frc, pval);
+                y0 = pval[a.prog[2]];
+                if (net.n_out > 1) yx[0] = pval[a.prog[3]];
+                if (net.n_out > 2) yx[1] = pval[a.prog[4]];
+            } else {
+                y0 = eh_mech_eval(MECH, par, frc, dydp);
+                if constexpr (NO > 1) eh_mech_extra(MECH, par, frc, yx, Jx);
+            }
             float dy = 0.0f, dyx[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int t = 0; t < NTG; ++t)
@@ -195,10 +212,19 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
                     const float d = 2.0f * w[t] * r;
                     dy += oi == 0 ? d : 0.0f; dyx[0] += oi == 1 ? d : 0.0f; dyx[1] += oi == 2 ? d : 0.0f;
                 }
+            float padj[PROG ? EH_PROG_SLOTS : 1];
+            if constexpr (PROG) {                                // reverse sweep over the tape (what Zygote derives from the closure)
+                const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
+                for (int q = 0; q < nslot; ++q) padj[q] = 0.0f;
+                padj[a.prog[2]] += dy;
+                if (net.n_out > 1) padj[a.prog[3]] += dyx[0];
+                if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
+                eh_prog_reverse(a.prog, pval, padj);
+            }
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                float dp = dy * dydp[j];
-                if (NO > 1 && j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
+                float dp = PROG ? padj[PROG ? j : 0] : dy * dydp[j];
+                if (!PROG && NO > 1 && j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
                 gp[j] += row[j] >= 0 ? 0.0f : dp;
                 dov[j][e] = dp * sg[j];
             }
@@ -1702,7 +1728,6 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
                          const int64_t* n_valid_in, float* d_o_dev, float* yhat_dev, float* loss, float* grad_global, int64_t* n_valid) {
     if (!h || !o_dev || !forcings_dev || !targets_dev || !d_o_dev) return EH_EINVAL;
     const EhNet& net = h->net;
-    if (net.mech == EH_MECH_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: recorded closures are evaluated inside the fused step kernels only");
     if (net.loss != EH_LOSS_MSE) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: training loss %d (built: mse)", net.loss);
     if (count < 1 || ld < count) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: count %lld, ld %lld", (long long)count, (long long)ld);
     for (int f = 0; f < net.F; ++f) if (!forcings_dev[f]) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: forcing %d is null", f);
@@ -1714,6 +1739,7 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
     bool vec = count % 4 == 0 && ld % 4 == 0 && ((uintptr_t)o_dev | (uintptr_t)d_o_dev | (uintptr_t)yhat_dev) % 16 == 0;
     for (int f = 0; f < net.F; ++f) { a.frc[f] = forcings_dev[f]; vec = vec && (uintptr_t)forcings_dev[f] % 16 == 0; }
     for (int t = 0; t < net.T; ++t) { a.y[t] = targets_dev[t]; vec = vec && (uintptr_t)targets_dev[t] % 16 == 0; }
+    if (net.mech == EH_MECH_PROGRAM) { vec = false; a.prog = h->prog; }        // the interpreter keeps its tape in scratch: one sample per lane
     const int per = vec ? 1024 : 256;                                      // samples per workgroup and trip
     if (net.n_out == 1 && net.T > 1) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: %d targets on a single-output model", net.T);
     const int nblk = (int)std::min<int64_t>((count + per - 1) / per, 4096);
@@ -1749,6 +1775,7 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
     switch (net.mech) {
         EH_MECH_GO(EH_MECH_RBQ10) EH_MECH_GO(EH_MECH_EXPO) EH_MECH_GO(EH_MECH_LINEAR) EH_MECH_GO(EH_MECH_EXPO2POOL)
         EH_MECH_GO(EH_MECH_RS_COMPONENTS) EH_MECH_GO(EH_MECH_FLUXPART)
+        case EH_MECH_PROGRAM: hipLaunchKernelGGL((eh_mech_vjp_kernel<1, EH_MECH_PROGRAM>), dim3((unsigned)nblk), dim3(256), 0, h->stream, net, a); break;
         default: return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: mechanistic model %d", net.mech);
     }
 #undef EH_MECH_GO

@@ -467,6 +467,41 @@ def test_mech_stage_alone(mech, B, scale):
     eng.close()
 
 
+@pytest.mark.parametrize("name,neural,glob,targets,ranges", [
+    ("flux_closure", ["alpha", "rref"], ["gmax", "e0"], ["nee", "gpp"], {"sw": (0, 800), "ta": (-5, 30), "vpd": (0, 30)}),
+    ("rbq10_closure", ["rb"], ["Q10"], ["reco"], {"ta": (0, 30)}),
+])
+def test_mech_stage_alone_with_a_recorded_closure(name, neural, glob, targets, ranges):
+    """any closure f(; forcing..., params...) (GenericHybridModel.jl:420-425) behind a network that lives outside the library: the
+    recorded program runs in the stand-alone stage too (interpreted, one sample per lane)"""
+    import torch
+    from tests import closures as cl
+    fn, table, forc = cl.CLOSURES[name]
+    util.register_closure(name, fn, list(table), forc, targets)
+    spec = ho.HybridSpec(3, [8], name, dict(table), neural, glob, targets, "tanh", True)
+    rng = np.random.default_rng(23)
+    B = 1500
+    o = rng.standard_normal((len(neural), B)).astype(np.float32)
+    f = {k: rng.uniform(lo, hi, B).astype(np.float32) for k, (lo, hi) in ranges.items()}
+    truth = ho.mech_loss_vjp(spec, ho.init_theta(spec, 1, np.float64), o * 0.5, f, {t: np.zeros(B) for t in targets})[4]
+    y = {}
+    for t in targets:
+        v = (truth[t] * (1 + 0.1 * rng.standard_normal(B))).astype(np.float32); v[rng.random(B) < 0.1] = np.nan
+        y[t] = v
+    theta = ho.init_theta(spec, 24, np.float32)
+    eng = util.model_from_spec(spec).engine(); eng.set_params(theta)
+    od = torch.from_numpy(o).cuda(); dod = torch.empty_like(od); yh = torch.empty((len(targets), B), device="cuda")
+    fd = [torch.from_numpy(f[k]).cuda() for k in ho.MECH[name][0].forcings]         # the model's forcing order (eh_set_data order)
+    yd = [torch.from_numpy(y[t]).cuda() for t in targets]
+    loss, gg, nv = eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in yd], dod.data_ptr(), yh.data_ptr())
+    l0, do0, gg0, nv0, yh0 = ho.mech_loss_vjp(spec, theta.astype(np.float64), o, f, y)
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL)
+    assert util.relerr(dod.cpu().numpy(), do0) <= TOL and util.relerr(gg, gg0) <= TOL
+    for i, t in enumerate(targets):
+        assert util.relerr(yh[i].cpu().numpy(), yh0[t]) <= TOL
+    eng.close()
+
+
 def test_mech_stage_trains_an_external_torch_network_like_the_fused_engine():
     """The seam end to end: a torch MLP (autograd) on the GPU + eh_mech_loss_vjp for everything after the network, five plain
     gradient-descent steps, against the fused engine training the same model from the same theta (one kernel does it all there)."""
