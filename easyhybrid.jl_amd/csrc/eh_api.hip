@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
         w[t] = (t < net.T && c > 0) ? 1.0f / (float)c : 0.0f;
     }
     float gp[NP], S[NTG];
+    const bool mae = net.loss == EH_LOSS_MAE;
 #pragma unroll
     for (int j = 0; j < NP; ++j) gp[j] = 0.0f;
 #pragma unroll
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
                     const float y = oi == 0 ? y0 : (oi == 1 ? yx[0] : yx[1]);
                     yh[t][e] = y;
                     const float r = __builtin_isnan(yv[t][e]) ? 0.0f : y - yv[t][e];
-                    S[t] = fmaf(r, r, S[t]);
-                    const float d = 2.0f * w[t] * r;
+                    float d;
+                    if (mae) { S[t] += fabsf(r); d = r > 0.0f ? w[t] : (r < 0.0f ? -w[t] : 0.0f); }      // mean |r| (loss_fn.jl:64-66)
+                    else { S[t] = fmaf(r, r, S[t]); d = 2.0f * w[t] * r; }                              // mean r^2 (loss_fn.jl:61-63)
                     dy += oi == 0 ? d : 0.0f; dyx[0] += oi == 1 ? d : 0.0f; dyx[1] += oi == 2 ? d : 0.0f;
                 }
             float padj[PROG ? EH_PROG_SLOTS : 1];
@@ -1728,7 +1730,7 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
                          const int64_t* n_valid_in, float* d_o_dev, float* yhat_dev, float* loss, float* grad_global, int64_t* n_valid) {
     if (!h || !o_dev || !forcings_dev || !targets_dev || !d_o_dev) return EH_EINVAL;
     const EhNet& net = h->net;
-    if (net.loss != EH_LOSS_MSE) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: training loss %d (built: mse)", net.loss);
+    if (net.loss != EH_LOSS_MSE && net.loss != EH_LOSS_MAE) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: training loss %d (built: mse, mae)", net.loss);
     if (count < 1 || ld < count) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: count %lld, ld %lld", (long long)count, (long long)ld);
     for (int f = 0; f < net.F; ++f) if (!forcings_dev[f]) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: forcing %d is null", f);
     for (int t = 0; t < net.T; ++t) if (!targets_dev[t]) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: target %d is null", t);

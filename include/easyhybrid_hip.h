@@ -210,7 +210,8 @@ int32_t eh_forward(eh_handle* h, int32_t split, int64_t first, int64_t count, fl
  * over the targets.  loss / grad_global (G floats, global_param_names order) / n_valid are HOST outputs; pass all three NULL to
  * leave the call asynchronous on the handle's stream.  A pure streaming kernel: 4 (K + F + T) bytes read and 4 K written per
  * sample (16-byte accesses when count, ld and the pointers allow; a recorded closure, EH_MECH_PROGRAM, is interpreted one sample
- * per lane).  EH_EUNSUPPORTED: training losses other than mse. */
+ * per lane).  The training loss is the handle's (eh_set_option "training_loss"): mse or mae; the others need batch statistics
+ * before the pass and return EH_EUNSUPPORTED. */
 int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o_dev, const float* const* forcings_dev,
                          const float* const* targets_dev, const int64_t* n_valid_in, float* d_o_dev, float* yhat_dev,
                          float* loss, float* grad_global, int64_t* n_valid);

@@ -695,11 +695,13 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
     return loss, grad, nvalid
 
 
-def mech_loss_vjp(spec: HybridSpec, theta, o, forcings, targets, dtype=np.float64):
+def mech_loss_vjp(spec: HybridSpec, theta, o, forcings, targets, dtype=np.float64, kind="mse"):
     """The mechanistic stage on its own: o (K, B) = raw NN outputs of a network evaluated elsewhere -> physical parameters
     (GenericHybridModel.jl:404-411) -> M -> masked MSE summed over targets (compute_loss.jl:50-53, loss_fn.jl:61-63) and its
     pullback to o and to the raw global parameters.  Returns (loss, d loss / d o (K, B), d loss / d raw globals (G,), n_valid per
-    target, {target: yhat}).  Same arithmetic as forward() / loss_and_grad() from k3 on."""
+    target, {target: yhat}).  Same arithmetic as forward() / loss_and_grad() from k3 on.  kind: "mse" or "mae" (loss_fn.jl:61-66)."""
+    if kind not in ("mse", "mae"):
+        raise ValueError(f"training loss {kind}")
     dt = np.dtype(dtype)
     o = np.asarray(o, dt)
     B = o.shape[1]
@@ -720,8 +722,12 @@ def mech_loss_vjp(spec: HybridSpec, theta, o, forcings, targets, dtype=np.float6
         d = np.zeros(B, dt)
         if n > 0:
             r = np.where(m, out[t] - np.where(m, y, 0), 0).astype(dt)
-            loss = loss + np.sum(r * r) / dt.type(n)
-            d = dt.type(2) * r / dt.type(n)
+            if kind == "mae":
+                loss = loss + np.sum(np.abs(r)) / dt.type(n)
+                d = np.sign(r) / dt.type(n)
+            else:
+                loss = loss + np.sum(r * r) / dt.type(n)
+                d = dt.type(2) * r / dt.type(n)
         dout[t] = d
     for oname in mm.outputs:
         dout.setdefault(oname, np.zeros(B, dt))

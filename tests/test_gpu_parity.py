@@ -460,6 +460,18 @@ def test_mech_stage_alone(mech, B, scale):
         l30, do30, _, nv30, _ = ho.mech_loss_vjp(spec, theta.astype(np.float64), o[:, 5:5 + c], {k: v[5:5 + c] for k, v in f.items()}, {k: v[5:5 + c] for k, v in y.items()})
         assert nv3 == sum(nv30) and l3 == pytest.approx(l30, rel=TOL) and util.relerr(dod.cpu().numpy()[:, 5:5 + c], do30) <= TOL
         assert np.isnan(dod.cpu().numpy()[:, :5]).all() and np.isnan(dod.cpu().numpy()[:, 5 + c:]).all()      # nothing outside the window is written
+    # mean absolute error as the training loss (loss_fn.jl:64-66); the other losses need batch statistics first: refused
+    if len(targets) == 1:                                  # (the engine takes losses other than mse for single-target models)
+        eng.set_training_loss("mae")
+        l5, g5, nv5 = eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in yd], dod.data_ptr())
+        l50, do50, g50, _, _ = ho.mech_loss_vjp(spec, theta.astype(np.float64), o, f, y, kind="mae")
+        assert nv5 == nv and l5 == pytest.approx(l50, rel=TOL) and util.relerr(dod.cpu().numpy(), do50) <= TOL
+        if glob:
+            assert util.relerr(g5, g50) <= TOL
+        eng.set_training_loss("rmse")
+        with pytest.raises(NotImplementedError):
+            eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in yd], dod.data_ptr())
+        eng.set_training_loss("mse")
     # all targets missing: skipped batch (epoch.jl:17-19)
     ynan = [torch.full((B,), float("nan"), device="cuda") for _ in targets]
     l4, _, nv4 = eng.mech_loss_vjp(B, od.data_ptr(), [t.data_ptr() for t in fd], [t.data_ptr() for t in ynan], dod.data_ptr())
