@@ -48,7 +48,8 @@ class TargetMetrics(C.Structure):
 
 
 LIB_NAME = "libeasyhybrid_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# (EASYHYBRID_HIP_LIB: another build of the same library, e.g. one of tools/ps_variants.sh's diagnostic builds)
+LIB_PATH = os.environ.get("EASYHYBRID_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 _F = C.POINTER(C.c_float)
 _FP = C.POINTER(_F)
@@ -75,7 +76,7 @@ SIGNATURES = {
     "eh_opt_init": (C.c_int32, [_H, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "eh_get_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
     "eh_set_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
-    "eh_train_step": (C.c_int32, [_H, C.c_int64, C.c_int64, _F]),
+    "eh_train_step": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64, _F]),
     "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
     "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void eh_count_valid_kernel(EhMechArgs a, int T
 // (parameters, forcings, outputs) of a registry model: compile-time array sizes, so that a two-parameter model keeps a dozen
 // values per sample in registers, not the 8 + 4 + 4 of the largest one (occupancy is what a streaming kernel lives on)
 // (EH_MECH_PROGRAM, a recorded closure run by the interpreter of eh_device.hpp: the limits of the program format)
-constexpr int eh_mech_np(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_PARAMS : m == EH_MECH_EXPO2POOL ? 4 : m == EH_MECH_RS_COMPONENTS ? 6 : m == EH_MECH_FLUXPART ? 3 : 2; }
-constexpr int eh_mech_nf(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_FORC : m == EH_MECH_FLUXPART ? 2 : 1; }
+constexpr int eh_mech_np(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_PARAMS : m == EH_MECH_EXPO2POOL ? 4 : (m == EH_MECH_RS_COMPONENTS || m == EH_MECH_RS_COMPONENTS3F) ? 6 : m == EH_MECH_FLUXPART ? 3 : 2; }
+constexpr int eh_mech_nf(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_FORC : m == EH_MECH_FLUXPART ? 2 : m == EH_MECH_RS_COMPONENTS3F ? 3 : 1; }
 constexpr int eh_mech_no(int m) { return (m == EH_MECH_PROGRAM || m == EH_MECH_FLUXPART) ? 3 : 1; }
 
 template <int V, int MECH>
@@ -873,6 +873,7 @@ static bool mech_info(int mech, MechInfo* mi, const eh_model_desc* d = nullptr) 
         case EH_MECH_LINEAR: *mi = {2, 1, 1}; return true;
         case EH_MECH_EXPO2POOL: *mi = {4, 1, 1}; return true;
         case EH_MECH_RS_COMPONENTS: *mi = {6, 1, 1}; return true;
+        case EH_MECH_RS_COMPONENTS3F: *mi = {6, 3, 1}; return true;
         case EH_MECH_FLUXPART: *mi = {3, 2, 3}; return true;
         default: return false;
     }
@@ -1372,6 +1373,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         if ((value != 0) == now) return EH_OK;
         if (!h->arch_alt) return fail(h, EH_EUNSUPPORTED, "row_split: this model has only the %s kernel", now ? "row-split" : "per-wave");
         if (value && h->fused) return fail(h, EH_EUNSUPPORTED, "row_split: switch fused_update off first");
+        if (h->arch->var[h->variant].bf16) return fail(h, EH_ESTATE, "row_split: the bf16-forward kernels exist in the row-split family only (set precision 0 first)");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         std::swap(h->arch, h->arch_alt);
@@ -1380,8 +1382,33 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
         return build_maps(h, false);
     }
+    if (!strcmp(name, "precision")) {        // 0 = fp32 end to end (the reference's arithmetic); 1 = bf16 forward products, fp32 accumulate / backward (eh_wide_bf16.hpp)
+        if (value != 0 && value != 1) return fail(h, EH_EINVAL, "precision must be 0 (f32) or 1 (bf16 forward / fp32 accumulate)");
+        const bool now = h->arch->var[h->variant].bf16 != 0;
+        if ((value != 0) == now) return EH_OK;
+        if (value) {
+            if (h->act == EH_ACT_SWISH || h->act == EH_ACT_PER_NET)
+                return fail(h, EH_EUNSUPPORTED, "precision: the bf16-forward kernels keep only the rounded activation (tanh / sigmoid / relu / identity; not swish, not per-net activations)");
+            if (h->fused) return fail(h, EH_EUNSUPPORTED, "precision: switch fused_update off first (the row-split kernels have no such mode)");
+            const EhArchInfo* W = h->arch->wide ? h->arch : h->arch_alt;
+            int vb = -1;
+            if (W) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16) { vb = vi; break; }
+            if (vb < 0) return fail(h, EH_EUNSUPPORTED, "precision: no bf16-forward kernel is built for this shape (row-split shapes only: hidden width 33..128)");
+            HIPCHK(h, hipSetDevice(h->device));
+            FLUSH(h);
+            if (W != h->arch) { std::swap(h->arch, h->arch_alt); h->fast = 0; }
+            h->variant = vb;
+            for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
+        } else {
+            HIPCHK(h, hipSetDevice(h->device));
+            FLUSH(h);
+            h->variant = 0;
+        }
+        return build_maps(h, false);
+    }
     if (!strcmp(name, "variant")) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
+        if (h->arch->var[value].bf16 != h->arch->var[h->variant].bf16) return fail(h, EH_EINVAL, "variant %lld belongs to the other precision (set the \"precision\" option)", (long long)value);
         h->variant = (int)value;
         if (h->arch->wide) {                 // the scatter map depends on the number of waves
             HIPCHK(h, hipSetDevice(h->device));
@@ -1646,6 +1673,25 @@ static int check_window(eh_handle* h, const EhSplit& sp, long long first, long l
     return EH_OK;
 }
 
+// host minibatch indices -> the handle's device scratch (range-checked); the step then gathers through it from offset 0
+static int stage_host_idx(eh_handle* h, const EhSplit& sp, const int32_t* idx, int64_t first, int64_t count, const char* who) {
+    if (!sp.recs) return fail(h, EH_ESTATE, "%s: no data set for this split", who);
+    if (count < 0 || first < 0) return fail(h, EH_EINVAL, "%s: first %lld, count %lld", who, (long long)first, (long long)count);
+    if (h->capturing) return fail(h, EH_ESTATE, "%s: host indices cannot be recorded into a graph (upload them and pass idx_on_device = 1)", who);
+    for (int64_t i = 0; i < count; ++i)
+        if (idx[first + i] < 0 || idx[first + i] >= sp.n) return fail(h, EH_EINVAL, "%s: idx[%lld] = %d outside 0..%lld", who, (long long)(first + i), idx[first + i], sp.n);
+    if (count > h->idx_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->idx_buf);
+        h->idx_buf = nullptr; h->idx_cap = 0;
+        HIPCHK(h, hipMalloc(&h->idx_buf, (size_t)std::max<int64_t>(count, 1) * sizeof(int)));
+        h->idx_cap = count;
+    }
+    // (the previous step that read idx_buf is ahead of this copy in stream order)
+    HIPCHK(h, hipMemcpyAsync(h->idx_buf, idx + first, (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return EH_OK;
+}
+
 // forward / eval on a window; stats (host, double) per target may be null
 static int do_eval(eh_handle* h, int split, long long first, long long count, double* stats, float* const* yhat, float* const* params) {
     const EhNet& net = h->net;
@@ -1776,7 +1822,7 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
         break;
     switch (net.mech) {
         EH_MECH_GO(EH_MECH_RBQ10) EH_MECH_GO(EH_MECH_EXPO) EH_MECH_GO(EH_MECH_LINEAR) EH_MECH_GO(EH_MECH_EXPO2POOL)
-        EH_MECH_GO(EH_MECH_RS_COMPONENTS) EH_MECH_GO(EH_MECH_FLUXPART)
+        EH_MECH_GO(EH_MECH_RS_COMPONENTS) EH_MECH_GO(EH_MECH_RS_COMPONENTS3F) EH_MECH_GO(EH_MECH_FLUXPART)
         case EH_MECH_PROGRAM: hipLaunchKernelGGL((eh_mech_vjp_kernel<1, EH_MECH_PROGRAM>), dim3((unsigned)nblk), dim3(256), 0, h->stream, net, a); break;
         default: return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: mechanistic model %d", net.mech);
     }
@@ -1808,18 +1854,7 @@ int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_
     int rc;
     const int* didx = nullptr;
     if (idx) {
-        if (!sp.recs) return fail(h, EH_ESTATE, "eh_loss_and_grad: no data set for this split");
-        if (count < 0) return fail(h, EH_EINVAL, "eh_loss_and_grad: count < 0");
-        for (int64_t i = 0; i < count; ++i)
-            if (idx[i] < 0 || idx[i] >= sp.n) return fail(h, EH_EINVAL, "eh_loss_and_grad: idx[%lld] = %d outside 0..%lld", (long long)i, idx[i], sp.n);
-        if (count > h->idx_cap) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            (void)hipFree(h->idx_buf);
-            h->idx_buf = nullptr; h->idx_cap = 0;
-            HIPCHK(h, hipMalloc(&h->idx_buf, (size_t)std::max<int64_t>(count, 1) * sizeof(int)));
-            h->idx_cap = count;
-        }
-        HIPCHK(h, hipMemcpyAsync(h->idx_buf, idx, (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if ((rc = stage_host_idx(h, sp, idx, 0, count, "eh_loss_and_grad"))) return rc;
         didx = h->idx_buf;
         first = 0;
     } else {
@@ -1912,21 +1947,30 @@ int32_t eh_set_opt_state(eh_handle* h, const float* m, const float* v, int64_t n
     return EH_OK;
 }
 
-int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out) {
+int32_t eh_train_step(eh_handle* h, const int32_t* idx, int32_t idx_on_device, int64_t first, int64_t count, float* loss_out) {
     if (!h) return EH_EINVAL;
     if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_train_step: call eh_opt_init first");
     HIPCHK(h, hipSetDevice(h->device));
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
-    int rc = check_window(h, sp, first, count, "eh_train_step");
-    if (rc) return rc;
+    int rc;
+    const int* didx = nullptr;
+    if (idx && !idx_on_device) {
+        if ((rc = stage_host_idx(h, sp, idx, first, count, "eh_train_step"))) return rc;
+        didx = h->idx_buf;
+        first = 0;
+    } else if (idx) {
+        if (!sp.recs || sp.n == 0) return fail(h, EH_ESTATE, "eh_train_step: no data set for this split (call eh_set_data)");
+        if (first < 0 || count < 0) return fail(h, EH_EINVAL, "eh_train_step: first %lld, count %lld", (long long)first, (long long)count);
+        didx = idx;
+    } else if ((rc = check_window(h, sp, first, count, "eh_train_step"))) return rc;
     rc = ensure_loss_hist(h, 1);
     if (rc) return rc;
     if (h->fused) {
-        rc = do_fused_step(h, sp, nullptr, first, count, loss_out ? h->loss_hist : nullptr);
+        rc = do_fused_step(h, sp, didx, first, count, loss_out ? h->loss_hist : nullptr);
         if (rc) return rc;
         if (loss_out) FLUSH(h);
     } else {
-        rc = do_step(h, sp, nullptr, first, count, true, false, loss_out ? h->loss_hist : nullptr);
+        rc = do_step(h, sp, didx, first, count, true, false, loss_out ? h->loss_hist : nullptr);
         if (rc) return rc;
     }
     if (loss_out) {

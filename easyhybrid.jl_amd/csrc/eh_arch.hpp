@@ -17,6 +17,7 @@ struct EhVariant {
     // fast: bit 0 = single NN output (K == 1), bit 1 = P <= 4; only honoured by shapes built with EH_FAST_PATHS
     hipError_t (*launch)(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
     int tiles;               // macro-tiles a workgroup works on at a time; 0 = nw (one per wave)
+    int bf16;                // 1 = eh_widebf_kernel (eh_wide_bf16.hpp): bf16 forward products, fp32 accumulate / backward ("precision" option)
 };
 
 struct EhArchInfo {

@@ -3,6 +3,7 @@
 // one wave's LDS round trips hide behind the other's MFMAs) and 4 waves (two blocks each).
 #include "eh_arch.hpp"
 #include "eh_wide.hpp"
+#include "eh_wide_bf16.hpp"
 
 #ifndef EH_NBI
 #error "build with -DEH_NBI -DEH_NBH -DEH_NL"
@@ -66,7 +67,58 @@ struct Var {
         }
         return hipGetLastError();
     }
-    static constexpr EhVariant info() { return EhVariant{NT, NWV, LDS, 1 << 30, &prepare, &launch, 1}; }
+    static constexpr EhVariant info() { return EhVariant{NT, NWV, LDS, 1 << 30, &prepare, &launch, 1, 0}; }
+};
+
+// the bf16-forward kernels (eh_wide_bf16.hpp): NWV waves, the largest sample tile whose LDS map fits; tanh / sigmoid / relu /
+// identity, registry models (a recorded closure gets its kernel compiled at run time, eh_jit.hip)
+template <int NWV>
+constexpr int pick_nt_bf() {
+    if (sizeof(float) * EhBfGeom<EH_NBI, EH_NBH, EH_NL, 4, NWV>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
+    return 2;
+}
+template <int NWV>
+struct VarBf {
+    static constexpr int NTB = pick_nt_bf<NWV>();
+    using Geom = EhBfGeom<EH_NBI, EH_NBH, EH_NL, NTB, NWV>;
+    static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
+    static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+    template <int ACT, int MODE>
+    static hipError_t prep1() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_widebf_kernel<EH_NBI, EH_NBH, EH_NL, NTB, NWV, ACT, MODE, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    }
+    template <int ACT>
+    static hipError_t prep2() {
+        hipError_t e = prep1<ACT, EH_MODE_TRAIN>();
+        if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL>();
+        return e;
+    }
+    static hipError_t prepare() {
+        hipError_t e;
+        if ((e = prep2<EH_ACT_TANH>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_SIGMOID>()) != hipSuccess) return e;
+        if ((e = prep2<EH_ACT_RELU>()) != hipSuccess) return e;
+        return prep2<EH_ACT_IDENTITY>();
+    }
+#define EH_GO(MODE) hipLaunchKernelGGL((eh_widebf_kernel<EH_NBI, EH_NBH, EH_NL, NTB, NWV, ACT, MODE, false>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args)
+    template <int ACT>
+    static void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN); else EH_GO(EH_MODE_EVAL);
+    }
+#undef EH_GO
+    static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if ((mode != EH_MODE_TRAIN && mode != EH_MODE_EVAL) || (fast & 4)) return hipErrorNotSupported;
+        switch (act) {
+            case EH_ACT_TANH: go<EH_ACT_TANH>(mode, grid, stream, net, args); break;
+            case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, grid, stream, net, args); break;
+            case EH_ACT_RELU: go<EH_ACT_RELU>(mode, grid, stream, net, args); break;
+            case EH_ACT_IDENTITY: go<EH_ACT_IDENTITY>(mode, grid, stream, net, args); break;
+            default: return hipErrorNotSupported;
+        }
+        return hipGetLastError();
+    }
+    static constexpr EhVariant info() { return EhVariant{NTB, NWV, LDS, 1 << 30, &prepare, &launch, 1, 1}; }
 };
 
 using G0 = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT, 4>;
@@ -75,9 +127,9 @@ const EhArchInfo info = {
     G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
     0,
 #if EH_NBH == 8
-    2, {Var<8>::info(), Var<4>::info(), {}, {}},
+    3, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), {}},
 #else
-    1, {Var<4>::info(), {}, {}, {}},
+    2, {Var<4>::info(), VarBf<4>::info(), {}, {}},
 #endif
     1,
 };

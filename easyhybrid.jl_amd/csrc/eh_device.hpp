@@ -331,6 +331,15 @@ __device__ __forceinline__ float eh_mech_eval(int mech, const float* par, const 
             d0 = q0; d1 = q1; d2 = q2;
             d3 = r0 * e * __builtin_amdgcn_rcpf(p3); d4 = r1 * e * __builtin_amdgcn_rcpf(p4); d5 = r2 * e * __builtin_amdgcn_rcpf(p5);
         } break;
+        case EH_MECH_RS_COMPONENTS3F: {   // build-defined (BASELINE.json config 5): R_het + sw_in R_root + vpd R_myc, pools as Rs_components.jl:45-55
+            const float p2 = par[2], p3 = par[3], p4 = par[4], p5 = par[5];
+            const float e = 0.1f * (f0 - 15.0f);
+            const float q0 = eh_pow(p3, e), q1 = frc[1] * eh_pow(p4, e), q2 = frc[2] * eh_pow(p5, e);
+            const float r0 = p0 * q0, r1 = p1 * q1, r2 = p2 * q2;
+            y = (r0 + r1) + r2;
+            d0 = q0; d1 = q1; d2 = q2;
+            d3 = r0 * e * __builtin_amdgcn_rcpf(p3); d4 = r1 * e * __builtin_amdgcn_rcpf(p4); d5 = r2 * e * __builtin_amdgcn_rcpf(p5);
+        } break;
         case EH_MECH_FLUXPART: {    // output 0: NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:66-74
             const float p2 = par[2], f1 = frc[1];
             const float e = 0.1f * (f1 - 15.0f);
@@ -565,9 +574,15 @@ __host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl
 #define EH_STAMP_FINE(i)
 #endif
 
+// Orders one wave's LDS traffic: what its lanes wrote before is visible to what any of its lanes reads after (the hardware
+// runs a wave's LDS operations in order; the fence is for the compiler, and it is acquire + release: a release-only fence
+// would leave later READS free to move up across it).
+#ifndef EH_SYNC_ORDER
+#define EH_SYNC_ORDER __ATOMIC_ACQ_REL
+#endif
 #define EH_WAVE_SYNC()                                         \
     do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_fence(EH_SYNC_ORDER, "wavefront");    \
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 
@@ -598,7 +613,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     constexpr int NHS = KEEPH ? NL : 1, NHM = KEEPH ? NBH : 1, NHT = KEEPH ? NT : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    // (the wave index as a SCALAR: derived from threadIdx it counts as divergent, and every loop / branch on it -- the tile loop
+    //  first of all -- would run under an exec mask with saved / restored mask pairs instead of scalar branches)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const ws = smem + G::IMG_FLOATS + wave * G::WAVE_WS;
     float* const XS = ws + G::XS_OFF;
     float* const HS = ws + G::HS_OFF;
@@ -1292,6 +1310,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     }
 
     EH_STAMP(8);
+#ifdef EH_DBG_LACC
+    if (a.stamps && blockIdx.x == 0 && lane < 2) reinterpret_cast<float*>(a.stamps)[wave * 2 + lane] = lacc;      // diagnostics: lanes 0 / 1 of every wave, before the wave sums
+#endif
     // ---- 7. workgroup reduction -> one partial per workgroup -------------------------------------
     constexpr EhAccLayout AL = eh_acc_layout(NBI, NBH, NL, FAST);
     constexpr bool REDV2 = TRAIN && AL.rw <= G::WAVE_WS;
@@ -1415,6 +1436,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
         }
         lacc = eh_wave_sum(lacc); syacc = eh_wave_sum(syacc); syyacc = eh_wave_sum(syyacc);
+#ifdef EH_DBG_LACC
+        if (a.stamps && blockIdx.x == 0 && lane == 0) reinterpret_cast<float*>(a.stamps)[16 + wave] = lacc;      // ... and after
+#endif
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t)
             if (t < net.T) cacc[t] = eh_wave_sum(cacc[t]);

@@ -324,10 +324,10 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
                  spec->n_theta, spec->g_off, spec->scale_nn, spec->mech, spec->n_par, spec->loss, spec->n_out, spec->targ_out, spec->par_kind, spec->par_idx, spec->forc_col);
         src += b;
     }
-    src += A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
-    const char* hnames[6] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", nullptr, nullptr, nullptr};
-    const char* hsrc[6] = {eh_src_device, eh_src_wide, eh_src_public, nullptr, nullptr, nullptr};
-    int nh = 3;
+    src += V.bf16 ? "#include \"eh_wide_bf16.hpp\"\n" : A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
+    const char* hnames[7] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", "eh_wide_bf16.hpp", nullptr, nullptr, nullptr};
+    const char* hsrc[7] = {eh_src_device, eh_src_wide, eh_src_public, eh_src_widebf, nullptr, nullptr, nullptr};
+    int nh = 4;
     if (prog) { hnames[nh] = "eh_jit_mech.inc"; hsrc[nh++] = mech.c_str(); }
     if (loss) { hnames[nh] = "eh_jit_loss.inc"; hsrc[nh++] = lsrc.c_str(); }
     if (rowact) { hnames[nh] = "eh_jit_rowact.inc"; hsrc[nh++] = rsrc.c_str(); }
@@ -336,7 +336,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     const int nmode = (with_p2p && !A->wide && !prog) ? 3 : 2;
     char name[3][160];
     for (int m = 0; m < nmode; ++m) {
-        if (A->wide) snprintf(name[m], sizeof name[m], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
+        if (A->wide) snprintf(name[m], sizeof name[m], "%s<%d, %d, %d, %d, %d, %d, %d, %s>", V.bf16 ? "eh_widebf_kernel" : "eh_wide_kernel", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
         else snprintf(name[m], sizeof name[m], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m,
                       (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
         hiprtcAddNameExpression(hp, name[m]);
@@ -353,6 +353,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
             h = fnv(h, ver, sizeof ver);
             h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size()); h = fnv(h, lsrc.data(), lsrc.size()); h = fnv(h, rsrc.data(), rsrc.size());
             h = fnv(h, eh_src_device, sizeof eh_src_device); h = fnv(h, eh_src_wide, sizeof eh_src_wide); h = fnv(h, eh_src_public, sizeof eh_src_public);
+            h = fnv(h, eh_src_widebf, sizeof eh_src_widebf);
             for (int m = 0; m < nmode; ++m) h = fnv(h, name[m], strlen(name[m]));
             for (const char* o : opts) h = fnv(h, o, strlen(o));
             char fn[64];

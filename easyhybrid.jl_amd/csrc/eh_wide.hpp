@@ -56,7 +56,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
     constexpr EhWideLayout WL = eh_wide_layout(NBI, NBH, NL, NWV);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    // (the wave index as a SCALAR: derived from threadIdx it counts as divergent, and every loop / branch on it -- the tile loop
+    //  first of all -- would run under an exec mask with saved / restored mask pairs instead of scalar branches)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const ws = smem + G::IMG_FLOATS;
     float* const XS = ws + G::XS_OFF;
     float* const HS = ws + G::HS_OFF;

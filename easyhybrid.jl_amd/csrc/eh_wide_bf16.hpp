@@ -1,0 +1,649 @@
+// bf16-forward / fp32-accumulate variant of the row-split kernel (eh_wide.hpp): BASELINE.json configs[4]
+// "MLP [32,128,128,6] ... bf16 fwd / fp32 accumulate".  NOT a mode of the reference (Float32 end to end,
+// src/data/prepare_data.jl:58-60); its semantics are fixed by oracle/hybrid_oracle.py `precision = "bf16_fwd"`:
+//
+//   * every Dense product of the FORWARD pass takes its two operands -- weights and the layer's input (normalised predictors,
+//     hidden activations) -- rounded to bfloat16 (nearest even) and accumulates in fp32 on v_mfma_f32_16x16x32_bf16
+//     (16x the rate of the fp32 MFMA); biases, activations, sigma-scaling, mechanistic model and loss stay fp32;
+//   * what a layer hands on IS the rounded activation, so the BACKWARD pass -- fp32 MFMA, as in eh_wide_kernel -- is the exact
+//     derivative of that function with round() as the identity: dW = dZ * bf16(h)^T, dH = bf16(W)^T dZ, act' from the stored
+//     rounded activation.  Activations whose derivative needs the pre-activation (swish, per-net) are not built.
+//
+// Because nothing but the rounded operands is ever needed again, the LDS holds ONLY bf16 weights and activations:
+//   weights  [row][k]          (row stride k + 8 elements: 16-byte fragments of the A operand, conflict-free)
+//   images   [sample][feature] (same stride: 16-byte fragments of the B operand; the C/D layout of a forward MFMA -- four
+//                               consecutive features of one sample per lane -- packs into one 8-byte store)
+// half of what eh_wide_kernel needs, which buys 64-sample tiles (NT = 4: four independent accumulators per wave, half the
+// barriers per sample).  The backward pass reads the same images element-wise (2-byte LDS reads + a shift) where it needs the
+// sample index on the MFMA k dimension; deltas stay fp32 in a [feature][sample] image.  Same slab / rmap contract as
+// eh_wide_kernel (the accumulators are the same registers in the same order).
+#pragma once
+#include "eh_wide.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float eh_bf2f(__bf16 v) { return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16); }
+
+template <int NBI, int NBH, int NL, int NT, int NWV>
+struct EhBfGeom {
+    using F = EhGeom<NBI, NBH, NL, NT, 1>;                 // the fp32 parameter image in global memory (what the optimiser kernel maintains)
+    static_assert(NBH % NWV == 0, "the waves split the feature blocks evenly");
+    static_assert(NT <= 4, "the mechanistic stage runs one sample per lane of wave 0");
+    static constexpr int MT = 16 * NT, SR = MT + 4, HP = 16 * NBH, IP = 16 * NBI;
+    static constexpr int KP0 = 32 * ((IP + 31) / 32);      // k extent of layer 0 in whole MFMA steps (zero padded)
+    static constexpr int S0B = KP0 + 8, SHB = HP + 8;      // bf16 row strides: 16-byte multiples, == 4 dwords mod 64 banks apart per row group
+    static constexpr int NPART = NWV >= NT ? NWV / NT : 1; // split of the output layer's k-steps over the waves (wave w: sample block w % NT, k part w / NT)
+    static_assert(NWV % NT == 0 || NWV < NT, "output-layer split");
+    static_assert((HP / 32) % NPART == 0, "the output layer's k-steps divide over the wave parts");
+    // LDS map, in floats (4-byte units); every offset a multiple of 4
+    static constexpr int WB0_OFF = 0;                                       // bf16 [HP][S0B]
+    static constexpr int WBH_OFF = WB0_OFF + HP * S0B / 2;                  // (NL-1) x bf16 [HP][SHB]
+    static constexpr int WBO_OFF = WBH_OFF + (NL - 1) * HP * SHB / 2;       // bf16 [16][SHB]
+    static constexpr int B_OFF = WBO_OFF + 16 * SHB / 2;                    // fp32 biases: NL * HP + 16
+    static constexpr int PHI_OFF = B_OFF + NL * HP + 16;                    // fp32 EH_IMG_* block
+    static constexpr int IMG_FLOATS = PHI_OFF + EH_IMG_META;
+    static constexpr int XB_OFF = IMG_FLOATS;                               // bf16 [MT][S0B] normalised, rounded predictors
+    static constexpr int HB_OFF = XB_OFF + MT * S0B / 2;                    // NL x bf16 [MT][SHB] rounded activations
+    static constexpr int DZ_OFF = HB_OFF + NL * MT * SHB / 2;               // fp32 [HP][SR] deltas; the split-K output partials [NPART][16][SR] alias it
+    static constexpr int OS_OFF = DZ_OFF + HP * SR;                         // fp32 [16][SR] NN outputs -> physical parameters -> d loss / d output
+    static constexpr int RS_OFF = OS_OFF + 16 * SR;                         // fp32 forcings (rows 0..3), targets (rows 4..7)
+    static constexpr int SG_OFF = RS_OFF + (EH_MAX_FORC + EH_MAX_TARG) * SR; // fp32 [16][SR] d parameter / d output
+    static constexpr int TOTAL_FLOATS = SG_OFF + 16 * SR;
+    static_assert(NPART * 16 <= HP, "the split-K output partials alias the delta image");
+    static_assert(NWV * eh_wide_layout(NBI, NBH, NL, NWV).na * 256 <= TOTAL_FLOATS, "the end-of-kernel staging of the accumulators overlays the whole LDS");
+};
+
+// sums of one wave's mechanistic stage (train: gradient of the global parameters, loss terms; eval: metric sums)
+struct EhMechAcc {
+    float gacc[EH_MAX_PARAMS], lacc, syacc, syyacc, cacc[EH_MAX_TARG], est[EH_MAX_TARG][EH_EVAL_STATS];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) gacc[j] = 0.0f;
+        lacc = syacc = syyacc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) {
+            cacc[t] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < EH_EVAL_STATS; ++k) est[t][k] = 0.0f;
+        }
+    }
+};
+
+// Mechanistic model + masked loss + its pullback for ONE sample per lane (the caller's wave 0, lane = sample of the tile):
+// physical parameters in OS[row k][lane] with d parameter / d NN output in SG, forcings / targets in RS -> (train) d loss / d NN
+// output back into OS, sums into `acc`; (eval) predictions / parameters written out.  Same arithmetic as stage 5 of eh_wide_kernel.
+template <bool TRAIN, bool PROG, class NET>
+__device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepArgs& a, int lane, bool live, int n_loc, int SR, const float* RS,
+                                                   float* OS, const float* SG, const float* meta, EhMechAcc& A) {
+    auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
+    auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
+    float par[EH_MAX_PARAMS], sg[EH_MAX_PARAMS], dydp[EH_MAX_PARAMS], frc[EH_MAX_FORC], yobs[EH_MAX_TARG];
+#pragma unroll
+    for (int f = 0; f < EH_MAX_FORC; ++f) {
+        const unsigned col = (net.forc_col >> (8 * f)) & 0xFFu;
+        frc[f] = col != 0xFFu ? RS[col * SR + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) yobs[t] = t < net.T ? RS[(EH_MAX_FORC + t) * SR + lane] : __builtin_nanf("");
+#pragma unroll
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) {
+        par[j] = meta[EH_IMG_PHI + j]; sg[j] = 1.0f; dydp[j] = 0.0f;
+        if (j < net.n_par && pkind(j) == EH_PAR_NEURAL) {
+            par[j] = OS[pidx(j) * SR + lane];
+            sg[j] = SG[pidx(j) * SR + lane];
+        }
+    }
+    float y0, yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+#ifdef EH_JIT_MECH
+    EhJitTape jtape;
+    if constexpr (PROG) eh_jit_fwd(par, frc, jtape, y0, yx[0], yx[1]);
+    else {
+#else
+    float pval[PROG ? EH_PROG_SLOTS : 1];
+    if constexpr (PROG) {
+        eh_prog_forward(a.prog, par, frc, pval);
+        y0 = pval[a.prog[2]];
+        if (net.n_out > 1) yx[0] = pval[a.prog[3]];
+        if (net.n_out > 2) yx[1] = pval[a.prog[4]];
+    } else {
+#endif
+        y0 = eh_mech_eval(net.mech, par, frc, dydp);
+        if (net.n_out > 1) eh_mech_extra(net.mech, par, frc, yx, Jx);
+    }
+    float dy = 0.0f, dyx[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) {
+        if (t < net.T) {
+            const int ot = (int)((net.targ_out >> (2 * t)) & 3u);
+            const float y = ot == 0 ? y0 : (ot == 1 ? yx[0] : yx[1]);
+            const bool valid = live && !__builtin_isnan(yobs[t]);
+            const float r = valid ? y - yobs[t] : 0.0f;
+            if constexpr (TRAIN) {
+                const float w = a.inv_n ? a.inv_n[t] : 1.0f;
+                const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
+                float d;
+                if (net.loss == EH_LOSS_MAE) { A.lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+#ifdef EH_JIT_LOSS
+                else if (net.loss == EH_LOSS_PROGRAM) {
+                    float dl;
+                    const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
+                    A.lacc += valid ? w * lv : 0.0f;
+                    d = valid ? w * dl : 0.0f;
+                }
+#endif
+                else if (net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS) {      // moment-based losses (see eh_step_kernel)
+                    d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
+                }
+                else { A.lacc += w * r * r; d = 2.0f * w * r; }
+                dy += ot == 0 ? d : 0.0f; dyx[0] += ot == 1 ? d : 0.0f; dyx[1] += ot == 2 ? d : 0.0f;
+                A.cacc[t] += valid ? 1.0f : 0.0f;
+                A.syacc += cy; A.syyacc += cy * cy;
+            } else if (valid) {
+                const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[1] : a.shift[t]);      // see eh_step_kernel
+                A.est[t][0] += r * r; A.est[t][1] += cy; A.est[t][2] += cy * cy; A.est[t][3] += 1.0f;
+                A.est[t][4] += ch; A.est[t][5] += ch * ch; A.est[t][6] += ch * cy; A.est[t][7] += fabsf(r);
+            }
+        }
+    }
+    if constexpr (!TRAIN) {
+        if (live) {
+            if (a.yhat)
+                for (int t = 0; t < net.T; ++t) {
+                    const int o = (int)((net.targ_out >> (2 * t)) & 3u);
+                    a.yhat[(long long)t * a.yld + n_loc] = o == 0 ? y0 : (o == 1 ? yx[0] : yx[1]);
+                }
+            if (a.pout)
+                for (int j = 0; j < net.n_par; ++j) a.pout[(long long)j * a.yld + n_loc] = par[j];
+        }
+    } else {
+#ifdef EH_JIT_MECH
+        float padj[EH_MAX_PARAMS];
+        if constexpr (PROG) eh_jit_rev(par, frc, jtape, dy, dyx[0], dyx[1], padj);
+#else
+        float padj[PROG ? EH_PROG_SLOTS : 1];
+        if constexpr (PROG) {
+            const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
+            for (int i = 0; i < nslot; ++i) padj[i] = 0.0f;
+            padj[a.prog[2]] += dy;
+            if (net.n_out > 1) padj[a.prog[3]] += dyx[0];
+            if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
+            eh_prog_reverse(a.prog, pval, padj);
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) {
+            if (j < net.n_par) {
+                float dp;
+                if constexpr (PROG) dp = padj[j];
+                else {
+                    dp = dy * dydp[j];
+                    if (j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
+                }
+                dp = live ? dp : 0.0f;
+                const int kd = pkind(j);
+                if (kd == EH_PAR_NEURAL) OS[pidx(j) * SR + lane] = dp * sg[j];
+                else if (kd == EH_PAR_GLOBAL) A.gacc[j] += dp;
+            }
+        }
+    }
+}
+
+template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false>
+__global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_rt, const EhStepArgs a) {
+#ifdef EH_SPEC_NET
+    constexpr EhNet net = {EH_SPEC_NET};        // see eh_step_body
+#else
+    const EhNet& net = net_rt;
+#endif
+    static_assert(!EhStoresZ<ACT>::value, "the bf16-forward kernel keeps only the rounded activation");
+    using G = EhBfGeom<NBI, NBH, NL, NT, NWV>;
+    using F = typename G::F;
+    constexpr int MT = G::MT, SR = G::SR, HP = G::HP, IP = G::IP, KP0 = G::KP0, S0B = G::S0B, SHB = G::SHB, MB = NBH / NWV, NTH = 64 * NWV;
+    constexpr int NPART = G::NPART, KSH = HP / 32, KS0 = KP0 / 32;
+    constexpr bool TRAIN = MODE == EH_MODE_TRAIN;
+    constexpr EhWideLayout WL = eh_wide_layout(NBI, NBH, NL, NWV);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    // (the wave index as a SCALAR: derived from threadIdx it counts as divergent, and every loop / branch on it -- the tile loop
+    //  first of all -- would run under an exec mask with saved / restored mask pairs instead of scalar branches)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __bf16* const WB0 = reinterpret_cast<__bf16*>(smem + G::WB0_OFF);
+    __bf16* const WBH = reinterpret_cast<__bf16*>(smem + G::WBH_OFF);
+    __bf16* const WBO = reinterpret_cast<__bf16*>(smem + G::WBO_OFF);
+    float* const BIAS = smem + G::B_OFF;
+    __bf16* const XB = reinterpret_cast<__bf16*>(smem + G::XB_OFF);
+    __bf16* const HB = reinterpret_cast<__bf16*>(smem + G::HB_OFF);
+    float* const DZ = smem + G::DZ_OFF;
+    float* const OSP = DZ;                      // [NPART][16][SR] partial outputs of the split-K output layer
+    float* const OS = smem + G::OS_OFF;
+    float* const RS = smem + G::RS_OFF;
+    float* const SG = smem + G::SG_OFF;
+    const float* const meta = smem + G::PHI_OFF;
+    const int m0 = wave * MB;
+    auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
+    auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
+    const bool mechw = wave == 0 && lane < MT;   // the lanes that own one sample each in the mechanistic stage
+
+    // ---- records: the tile's MT records are MT*C consecutive floats (or MT gathered runs of C); thread-owned elements, loaded
+    // coalesced one tile ahead, predictors normalised + rounded into the [sample][feature] bf16 image, forcings / targets into RS
+    constexpr int NEL = (MT * (IP + EH_MAX_FORC + EH_MAX_TARG) + NTH - 1) / NTH;
+    const int count = (int)a.count, first = (int)a.first, C = a.C;
+    const int ntiles = (count + MT - 1) / MT;
+    int epk[NEL], nidx[NEL];          // element k: destination (bf16 index into XB for predictors, float index into RS otherwise) | column << 16 | sample << 24 ; -1 = none
+    float nx[NEL];
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+        const int e = tid + k * NTH;
+        epk[k] = -1; nidx[k] = 0; nx[k] = 0.0f;
+        if (e < MT * C) {
+            const int smp = e / C, col = e - smp * C;
+            const int row = col < net.P ? -1 : (col - net.P < net.F ? col - net.P : EH_MAX_FORC + (col - net.P - net.F));
+            const int dst = row < 0 ? smp * S0B + col : row * SR + smp;
+            epk[k] = dst | (col << 16) | (smp << 24);
+        }
+    }
+    auto fetch_idx = [&](int tile) {
+        if (!a.idx) return;
+#pragma unroll
+        for (int k = 0; k < NEL; ++k) {
+            const int s_loc = tile * MT + (epk[k] >> 24);
+            nidx[k] = (epk[k] >= 0 && tile < ntiles && s_loc < count) ? a.idx[first + s_loc] : 0;
+        }
+    };
+    auto fetch = [&](int tile) {      // data of `tile` (its gather indices are already in nidx), then the indices one tile further
+#pragma unroll
+        for (int k = 0; k < NEL; ++k) {
+            const int col = (epk[k] >> 16) & 0xFF, s_loc = tile * MT + (epk[k] >> 24);
+            const bool live = epk[k] >= 0 && tile < ntiles && s_loc < count;
+            const long long src = a.idx ? (long long)nidx[k] * C + col : (long long)(first + tile * MT) * C + (tid + k * NTH);
+            nx[k] = live ? a.recs[src] : (col >= net.P + net.F ? __builtin_nanf("") : 0.0f);
+        }
+        fetch_idx(tile + (int)gridDim.x);
+    };
+    fetch_idx((int)blockIdx.x);
+    fetch((int)blockIdx.x);
+
+    // ---- parameter image (fp32, EhGeom layout, kept by the optimiser kernel) -> bf16 weights, fp32 biases + meta block
+    {
+        auto cvt_rows = [&](const float* src, int sld, int scols, __bf16* dst, int dld, int rows, int kcols) {
+            const int hp = kcols / 2, tot = rows * hp;
+            for (int i0 = tid; i0 < tot; i0 += 8 * NTH) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * NTH, row = i / hp, col = 2 * (i - row * hp);
+                    v[u] = (i < tot && col < scols) ? *(const float2*)&src[row * sld + col] : float2{0.0f, 0.0f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * NTH, row = i / hp, col = 2 * (i - row * hp);
+                    if (i < tot) *(bf16x2*)&dst[row * dld + col] = bf16x2{(__bf16)v[u].x, (__bf16)v[u].y};
+                }
+            }
+        };
+        cvt_rows(a.image + F::W0_OFF, F::S0, IP, WB0, S0B, HP, KP0);
+#pragma unroll
+        for (int l = 1; l < NL; ++l) cvt_rows(a.image + F::WH_OFF + (l - 1) * HP * F::SH, F::SH, HP, WBH + (l - 1) * HP * SHB, SHB, HP, HP);
+        cvt_rows(a.image + F::WO_OFF, F::SH, HP, WBO, SHB, 16, HP);
+        for (int e = tid; e < NL * HP + 16 + EH_IMG_META; e += NTH) smem[G::B_OFF + e] = a.image[F::B_OFF + e];      // (B_OFF .. PHI_OFF + META is one run in both layouts)
+    }
+    for (int e = tid; e < MT * S0B / 2; e += NTH) smem[G::XB_OFF + e] = 0.0f;     // columns >= P of the predictor image stay 0
+    for (int e = tid; e < 16 * SR; e += NTH) OS[e] = 0.0f;                        // rows >= K of the output / dO image stay 0
+    __syncthreads();
+    if (a.bn_part) {       // input BatchNorm, train mode: statistics of this minibatch (see eh_step_kernel)
+        if (tid < net.P) {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
+            const float m = a.bn_n ? *a.bn_n : (float)count, c0 = a.bn_c[tid];
+            const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
+            smem[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
+            smem[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);
+            if (a.bn_update && blockIdx.x == 0) {
+                const float rm = (1.0f - EH_BN_MOMENTUM) * a.bn_run[tid] + EH_BN_MOMENTUM * mu;
+                const float rv = (1.0f - EH_BN_MOMENTUM) * a.bn_run[32 + tid] + EH_BN_MOMENTUM * (m > 1.0f ? m / (m - 1.0f) : 1.0f) * var;
+                a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
+                a.image_out[F::PHI_OFF + EH_IMG_BNM + tid] = rm;
+                a.image_out[F::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
+            }
+        }
+        __syncthreads();
+    }
+
+    // split-K partials -> physical parameters: element (k, sample) = tid + u*NTH, its bounds fixed for the whole launch
+    constexpr int NEO = (16 * MT + NTH - 1) / NTH;
+    float klo[NEO], ksc[NEO];
+#pragma unroll
+    for (int u = 0; u < NEO; ++u) {
+        const int k = (tid + u * NTH) / MT;
+        klo[u] = 0.0f; ksc[u] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j)
+            if (j < net.n_par && pkind(j) == EH_PAR_NEURAL && pidx(j) == k) { klo[u] = meta[EH_IMG_LO + j]; ksc[u] = meta[EH_IMG_SC + j]; }
+    }
+
+    // accumulators: this wave's row slice of every weight gradient
+    f32x4 aW0[MB][NBI], aWh[NL > 1 ? NL - 1 : 1][MB][NBH], aWo[MB], aB[NL][MB], aBo = f32x4{0, 0, 0, 0};
+    EhMechAcc MA;
+    MA.clear();
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm) {
+#pragma unroll
+        for (int n = 0; n < NBI; ++n) aW0[mm][n] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+            for (int n = 0; n < NBH; ++n) aWh[l][mm][n] = f32x4{0, 0, 0, 0};
+        aWo[mm] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int l = 0; l < NL; ++l) aB[l][mm] = f32x4{0, 0, 0, 0};
+    }
+    const int ksK = net.K < 4 ? net.K : 4;
+    // the output layer's k-steps split over the waves: wave w contracts k part w / NT for sample block w % NT
+    const int o_t = wave % NT, o_part = wave / NT;
+    const bool o_on = wave < NT * NPART;
+
+    // one forward layer: this wave's output blocks = act(W[own rows] * in + b), rounded, into the [sample][feature] image
+    auto forward_layer = [&](const __bf16* W, int ldw, int ksteps, const __bf16* in, int ldin, int layer, __bf16* out) {
+        f32x4 acc[MB][NT];
+#pragma unroll
+        for (int mm = 0; mm < MB; ++mm) {
+            const f32x4 bias = *(const f32x4*)&BIAS[layer * HP + 16 * (m0 + mm) + 4 * g];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[mm][t] = bias;
+        }
+        for (int kk = 0; kk < ksteps; ++kk) {
+            bf16x8 bq[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bq[t] = *(const bf16x8*)&in[(16 * t + c) * ldin + 32 * kk + 8 * g];
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm) {
+                const bf16x8 a8 = *(const bf16x8*)&W[(16 * (m0 + mm) + c) * ldw + 32 * kk + 8 * g];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, bq[t], acc[mm][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 h = eh_act4_rows<ACT>(acc[mm][t], layer, 16 * (m0 + mm) + 4 * g);
+                *(bf16x4*)&out[(16 * t + c) * SHB + 16 * (m0 + mm) + 4 * g] = bf16x4{(__bf16)h[0], (__bf16)h[1], (__bf16)h[2], (__bf16)h[3]};
+            }
+    };
+    // B operand of an fp32 MFMA whose k index runs over the features of block q of the fp32 delta image: lane (c, g), step s <-> feature 16q+4g+s, sample 16t+c
+    auto load_dz = [&](int q, f32x4 (&bq)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bq[t][s] = DZ[(16 * q + 4 * g + s) * SR + 16 * t + c];
+    };
+    // B operand with the SAMPLE index on k, from a [sample][feature] bf16 image: step s <-> sample 16t+4g+s, column = feature 16n+c
+    auto load_ht = [&](const __bf16* img, int ld, int n, int t) {
+        f32x4 b4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b4[s] = eh_bf2f(img[(16 * t + 4 * g + s) * ld + 16 * n + c]);
+        return b4;
+    };
+    // stored (rounded) activations of features 16m+4g .. +3 of sample 16t+c
+    auto load_h4 = [&](const __bf16* img, int m, int t) {
+        const bf16x4 p = *(const bf16x4*)&img[(16 * t + c) * SHB + 16 * m + 4 * g];
+        return f32x4{eh_bf2f(p[0]), eh_bf2f(p[1]), eh_bf2f(p[2]), eh_bf2f(p[3])};
+    };
+
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        const int n_loc = tile * MT + lane;
+        const bool live = mechw && (n_loc < count);
+        // ---- 1. records -> normalised, rounded predictor image + forcing / target rows; next tile's records in flight
+#pragma unroll
+        for (int k = 0; k < NEL; ++k)
+            if (epk[k] >= 0) {
+                const int col = (epk[k] >> 16) & 0xFF;
+                const float v = nx[k];
+                if (col < net.P) XB[epk[k] & 0xFFFF] = (__bf16)((v - meta[EH_IMG_BNM + col]) * meta[EH_IMG_BNR + col]);
+                else RS[epk[k] & 0xFFFF] = v;
+            }
+        fetch(tile + (int)gridDim.x);
+        eh_lds_barrier();
+        // ---- 2. / 3. forward: layer 0, hidden layers ----------------------------------------------
+        forward_layer(WB0, S0B, KS0, XB, S0B, 0, HB);
+        eh_lds_barrier();
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+            forward_layer(WBH + (l - 1) * HP * SHB, SHB, KSH, HB + (l - 1) * MT * SHB, SHB, l, HB + l * MT * SHB);
+            eh_lds_barrier();
+        }
+        const __bf16* const Hlast = HB + (NL - 1) * MT * SHB;
+        // ---- 4. output layer (K <= 16 rows), k-steps split over the waves --------------------------
+        if (o_on) {
+            const f32x4 bias = *(const f32x4*)&BIAS[NL * HP + 4 * g];
+            f32x4 o = o_part == 0 ? bias : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kq = 0; kq < KSH / NPART; ++kq) {
+                const int kk = o_part * (KSH / NPART) + kq;
+                const bf16x8 a8 = *(const bf16x8*)&WBO[c * SHB + 32 * kk + 8 * g];
+                const bf16x8 b8 = *(const bf16x8*)&Hlast[(16 * o_t + c) * SHB + 32 * kk + 8 * g];
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) OSP[(o_part * 16 + 4 * g + r) * SR + 16 * o_t + c] = o[r];
+        }
+        eh_lds_barrier();
+        // ---- 4b. all threads: sum the partials, sigmoid-scale into the parameter range (GenericHybridModel.jl:348-352)
+#pragma unroll
+        for (int u = 0; u < NEO; ++u) {
+            const int e = tid + u * NTH, k = e / MT, smp = e % MT;
+            if (k < net.K && (NEO * NTH == 16 * MT || e < 16 * MT)) {
+                float ov = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NPART; ++w) ov += OSP[(16 * w + k) * SR + smp];
+                float pv = ov, sv = 1.0f;
+                if (net.scale_nn) {
+                    const float sgm = eh_sigmoid(ov);
+                    pv = fmaf(ksc[u], sgm, klo[u]);
+                    sv = ksc[u] * sgm * (1.0f - sgm);
+                }
+                OS[k * SR + smp] = pv;
+                SG[k * SR + smp] = sv;
+            }
+        }
+        eh_lds_barrier();
+        // ---- 5. mechanistic model + masked loss: wave 0, one sample per lane -----------------------
+        if (mechw) eh_mech_stage_lane<TRAIN, PROG>(net, a, lane, live, n_loc, SR, RS, OS, SG, meta, MA);
+        eh_lds_barrier();
+        if constexpr (!TRAIN) continue;
+
+        // ---- 6. backward through the output layer (fp32 MFMA from here on) --------------------------
+        f32x4 dzr[MB][NT];
+        {
+            f32x4 dO[NT], aT[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dO[t][r] = OS[(4 * g + r) * SR + 16 * t + c];
+                aT[t] = *(const f32x4*)&OS[c * SR + 16 * t + 4 * g];
+                if (wave == 0) aBo += dO[t];
+            }
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm) {
+                const int m = m0 + mm;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 b4 = load_ht(Hlast, SHB, m, t);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) aWo[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWo[mm], 0, 0, 0);
+                }
+                f32x4 dh[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dh[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s < ksK) {
+                        const float av = eh_bf2f(WBO[(4 * g + s) * SHB + 16 * m + c]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dO[t][s], dh[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 hv = load_h4(Hlast, m, t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dh[t][r] * eh_dact_row<ACT>(hv[r], NL - 1, 16 * m + 4 * g + r);
+                    aB[NL - 1][mm] += dzr[mm][t];
+                }
+            }
+        }
+        // the split-K partials (aliasing DZ) were last read in step 4b: safe to overwrite now
+#pragma unroll
+        for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) DZ[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = dzr[mm][t][r];
+        eh_lds_barrier();
+        // ---- 7. hidden layers backward -------------------------------------------------------------
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            const __bf16* Hp = HB + (l - 1) * MT * SHB;
+            const __bf16* W = WBH + (l - 1) * HP * SHB;
+            // dW_l[own rows][all columns] += dZ_l (own rows) * bf16(H_{l-1})^T
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm) {
+                f32x4 aT[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * (m0 + mm) + c) * SR + 16 * t + 4 * g];
+#pragma unroll
+                for (int n = 0; n < NBH; ++n)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const f32x4 b4 = load_ht(Hp, SHB, n, t);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            aWh[l - 1][mm][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWh[l - 1][mm][n], 0, 0, 0);
+                    }
+            }
+            // dH_{l-1}[own rows] = bf16(W_l)^T dZ_l  (k runs over ALL rows of dZ_l: the shared image)
+            f32x4 dn[MB][NT];
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dn[mm][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NBH; ++q) {
+                f32x4 bq[NT];
+                load_dz(q, bq);
+#pragma unroll
+                for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float av = eh_bf2f(W[(16 * q + 4 * g + s) * SHB + 16 * (m0 + mm) + c]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) dn[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[t][s], dn[mm][t], 0, 0, 0);
+                    }
+            }
+            eh_lds_barrier();                         // every wave is done reading dZ_l
+#pragma unroll
+            for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 hv = load_h4(Hp, m0 + mm, t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = dn[mm][t][r] * eh_dact_row<ACT>(hv[r], l - 1, 16 * (m0 + mm) + 4 * g + r);
+                        dzr[mm][t][r] = d;
+                        DZ[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = d;
+                    }
+                    aB[l - 1][mm] += dzr[mm][t];
+                }
+            eh_lds_barrier();
+        }
+        // ---- 8. layer 0: dW0[own rows] += dZ_0 * bf16(X)^T -------------------------------------------
+#pragma unroll
+        for (int mm = 0; mm < MB; ++mm) {
+            f32x4 aT[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * (m0 + mm) + c) * SR + 16 * t + 4 * g];
+#pragma unroll
+            for (int n = 0; n < NBI; ++n)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 b4 = load_ht(XB, S0B, n, t);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) aW0[mm][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aW0[mm][n], 0, 0, 0);
+                }
+        }
+        eh_lds_barrier();                             // the images are rewritten by the next tile
+    }
+
+    // ---- 9. one partial per workgroup (as eh_wide_kernel: the waves own disjoint entries) ------------
+    float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
+    if constexpr (!TRAIN) {
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < EH_MAX_TARG; ++t)
+#pragma unroll
+                for (int k = 0; k < EH_EVAL_STATS; ++k) {
+                    const float v = eh_wave_sum(MA.est[t][k]);
+                    if (t < net.T && lane == 0) out[t * EH_EVAL_STATS + k] = v;
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aB[l][mm][r] = eh_row16_sum(aB[l][mm][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
+    float gs[EH_MAX_PARAMS];
+#pragma unroll
+    for (int j = 0; j < EH_MAX_PARAMS; ++j) gs[j] = meta[EH_IMG_DPHI + j];
+    __syncthreads();
+    float* const st = smem + (long long)wave * WL.na * 256 + lane * 4;
+    auto putc = [&](int k, const f32x4& v) { *(f32x4*)&st[k * 256] = v; };
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm) {
+#pragma unroll
+        for (int n = 0; n < NBI; ++n) putc(WL.kw0 + mm * NBI + n, aW0[mm][n]);
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+            for (int n = 0; n < NBH; ++n) putc(WL.kwh + (l * MB + mm) * NBH + n, aWh[l][mm][n]);
+        putc(WL.kwo + mm, aWo[mm]);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) putc(WL.kb + l * MB + mm, aB[l][mm]);
+    }
+    putc(WL.kbo, aBo);                                // only wave 0's copy is referenced
+    __syncthreads();
+    constexpr int GU = 16;                            // independent map loads in flight per thread (each is an L2 round trip)
+    for (int i0 = tid; i0 < net.g_off; i0 += GU * NTH) {
+        int pos[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) pos[u] = (i0 + u * NTH < net.g_off) ? a.rmap[i0 + u * NTH] : 0;
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+            if (i0 + u * NTH < net.g_off) out[i0 + u * NTH] = smem[pos[u]];
+    }
+    if (wave == 0) {
+        const float lacc = eh_wave_sum(MA.lacc), syacc = eh_wave_sum(MA.syacc), syyacc = eh_wave_sum(MA.syyacc);
+        float cacc[EH_MAX_TARG], gacc[EH_MAX_PARAMS];
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) cacc[t] = t < net.T ? eh_wave_sum(MA.cacc[t]) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) gacc[j] = j < net.n_par ? eh_wave_sum(MA.gacc[j]) * gs[j] : 0.0f;
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                if (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) out[net.g_off + pidx(j)] = gacc[j];
+            out[net.n_theta] = lacc;
+#pragma unroll
+            for (int t = 0; t < EH_MAX_TARG; ++t)
+                if (t < net.T) out[net.n_theta + 1 + t] = cacc[t];
+            out[net.n_theta + 1 + net.T] = syacc;
+            out[net.n_theta + 2 + net.T] = syyacc;
+        }
+    }
+}

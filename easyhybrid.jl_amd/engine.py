@@ -208,9 +208,18 @@ class HybridEngine:
         m = np.ascontiguousarray(m, np.float32); v = np.ascontiguousarray(v, np.float32); bt = np.ascontiguousarray(bt, np.float32)
         self._chk(self._lib.eh_set_opt_state(self._h, _fptr(m), _fptr(v), m.size, _fptr(bt)))
 
-    def train_step(self, first: int, count: int, want_loss: bool = True):
+    def train_step(self, first: int, count: int, want_loss: bool = True, idx=None):
+        """One training step on train samples [first, first+count), or -- idx given -- on the minibatch idx[first : first+count]
+        the caller's own loader drew: a host int32 array, or a device pointer (int; e.g. `tensor.data_ptr()` of a whole epoch's
+        permutation) that must stay alive until the step has run."""
         loss = C.c_float()
-        self._chk(self._lib.eh_train_step(self._h, first, count, C.byref(loss) if want_loss else None))
+        ip, on_dev = None, 0
+        if isinstance(idx, int):
+            ip, on_dev = C.cast(C.c_void_p(idx), C.POINTER(C.c_int32)), 1
+        elif idx is not None:
+            self._idx_keep = np.ascontiguousarray(idx, np.int32)        # (kept until the next call: the copy is asynchronous)
+            ip = self._idx_keep.ctypes.data_as(C.POINTER(C.c_int32))
+        self._chk(self._lib.eh_train_step(self._h, ip, on_dev, first, count, C.byref(loss) if want_loss else None))
         return float(loss.value) if want_loss else None
 
     # -- hipGraph capture of a step sequence (see include/easyhybrid_hip.h) --------------------------

@@ -14,7 +14,7 @@ module EasyHybridHIP
 using Libdl
 
 export constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model,
-    LinearHM, Expo2Pool, Rs_components, FluxPartModelQ10
+    LinearHM, Expo2Pool, Rs_components, Rs_components3F, FluxPartModelQ10
 
 const LIB = Ref{String}(get(ENV, "EASYHYBRID_HIP_LIB", joinpath(@__DIR__, "..", "..", "..", "libeasyhybrid_hip.so")))
 
@@ -87,6 +87,11 @@ function Rs_components(; ta, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc
     R_het = Rb_het .* Q10_het .^ e; R_root = Rb_root .* Q10_root .^ e; R_myc = Rb_myc .* Q10_myc .^ e
     return (; R_soil = R_het .+ R_root .+ R_myc, R_het, R_root, R_myc)
 end
+function Rs_components3F(; ta, sw_in, vpd, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc, tref = 15.0f0)   # build-defined (BASELINE config 5)
+    e = 0.1f0 .* (ta .- tref)
+    R_het = Rb_het .* Q10_het .^ e; R_root = sw_in .* Rb_root .* Q10_root .^ e; R_myc = vpd .* Rb_myc .* Q10_myc .^ e
+    return (; R_soil = R_het .+ R_root .+ R_myc, R_het, R_root, R_myc)
+end
 function FluxPartModelQ10(; SW_IN, TA, RUE, Rb, Q10, tref = 15.0f0)                                     # src/models/FluxPartModel_Q10_Lux.jl:66-74
     GPP = SW_IN .* RUE ./ 12.011f0
     RECO = Rb .* Q10 .^ (0.1f0 .* (TA .- tref))
@@ -98,6 +103,7 @@ const MECH = IdDict{Any, MechSpec}(
     LinearHM => MechSpec(2, [:alpha, :beta], [:x], [:obs]),
     Expo2Pool => MechSpec(3, [:R0a, :ka, :R0b, :kb], [:T], [:Resp_obs]),
     Rs_components => MechSpec(4, [:Rb_het, :Rb_root, :Rb_myc, :Q10_het, :Q10_root, :Q10_myc], [:ta], [:R_soil]),
+    Rs_components3F => MechSpec(7, [:Rb_het, :Rb_root, :Rb_myc, :Q10_het, :Q10_root, :Q10_myc], [:ta, :sw_in, :vpd], [:R_soil]),
     FluxPartModelQ10 => MechSpec(5, [:RUE, :Rb, :Q10], [:SW_IN, :TA], [:NEE, :GPP, :RECO]),
 )
 "Register another Julia function under one of the device model ids (see include/easyhybrid_hip.h)."
@@ -438,7 +444,14 @@ dp_bn_stats!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall 
 "one Lux.Training.single_train_step! (src/training/epoch.jl:20-26) on train samples first+1 : first+count"
 function train_step!(e::HybridEngine, first::Integer, count::Integer)
     loss = Ref{Float32}(NaN32)
-    check(e, @ccall LIB[].eh_train_step(e.h::Ptr{Cvoid}, first::Int64, count::Int64, loss::Ref{Float32})::Int32)
+    check(e, @ccall LIB[].eh_train_step(e.h::Ptr{Cvoid}, C_NULL::Ptr{Int32}, 0::Int32, first::Int64, count::Int64, loss::Ref{Float32})::Int32)
+    return loss[]
+end
+"the same step on the minibatch an MLUtils.DataLoader drew (src/data/loaders.jl:1-12): `batch` = 1-based sample indices of the train split"
+function train_step!(e::HybridEngine, batch::AbstractVector{<:Integer})
+    idx = Int32.(batch .- 1)
+    loss = Ref{Float32}(NaN32)
+    GC.@preserve idx check(e, @ccall LIB[].eh_train_step(e.h::Ptr{Cvoid}, idx::Ptr{Int32}, 0::Int32, 0::Int64, length(idx)::Int64, loss::Ref{Float32})::Int32)
     return loss[]
 end
 "one run_epoch! (src/training/epoch.jl:13-33)"

@@ -48,6 +48,8 @@ MECH_REGISTRY: Dict[str, MechSpec] = {
     "Expo2Pool": MechSpec(3, "Expo2Pool", ("R0a", "ka", "R0b", "kb"), ("T",), ("Resp_obs",)),
     "Rs_components": MechSpec(4, "Rs_components", ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
                               ("ta",), ("R_soil",)),
+    "Rs_components3F": MechSpec(7, "Rs_components3F", ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
+                                ("ta", "sw_in", "vpd"), ("R_soil",)),
     "FluxPartModelQ10": MechSpec(5, "FluxPartModelQ10", ("RUE", "Rb", "Q10"), ("SW_IN", "TA"), ("NEE", "GPP", "RECO")),
 }
 
@@ -86,6 +88,13 @@ def Expo2Pool(*, T, R0a, ka, R0b, kb):
 @_tag("Rs_components")
 def Rs_components(*, ta, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc):
     """src/models/Rs_components.jl:40-57"""
+    raise NotImplementedError("registry tag")
+
+
+@_tag("Rs_components3F")
+def Rs_components3F(*, ta, sw_in, vpd, Rb_het, Rb_root, Rb_myc, Q10_het, Q10_root, Q10_myc):
+    """build-defined (BASELINE.json config 5, "3 forcings ... RbQ10-family M"): R_het + sw_in*R_root + vpd*R_myc with the pools of
+    src/models/Rs_components.jl:45-55, R_c = Rb_c*Q10_c^(0.1(ta-15))"""
     raise NotImplementedError("registry tag")
 
 
@@ -332,9 +341,17 @@ class SingleNNHybridModel:
         return d
 
     def engine(self, device: int = 0):
+        """precision = "bf16_fwd" (a build extension, BASELINE.json config 5; the reference is Float32 end to end): Dense products of
+        the forward pass on bf16 operands with fp32 accumulation, fp32 backward (csrc/eh_wide_bf16.hpp)."""
         from .engine import HybridEngine
-        return HybridEngine(self.to_desc(device), len(self.mechanistic_model.params), self.targets,
-                            list(self.mechanistic_model.params))
+        eng = HybridEngine(self.to_desc(device), len(self.mechanistic_model.params), self.targets,
+                           list(self.mechanistic_model.params))
+        prec = self.config.get("precision", "f32")
+        if prec not in ("f32", "bf16_fwd"):
+            raise ValueError(f"precision {prec!r}: 'f32' or 'bf16_fwd'")
+        if prec == "bf16_fwd":
+            eng.set_option("precision", 1)
+        return eng
 
 
 HybridModel = SingleNNHybridModel     # spelling used by BASELINE.json's north_star

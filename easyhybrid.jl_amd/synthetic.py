@@ -64,3 +64,25 @@ def make_synth_fluxnet32(n: int, seed: int = 42, nan_frac: float = 0.0):
     cols["ta"] = ta
     cols["R_soil"] = y
     return cols
+
+
+def make_synth_fluxnet32_3f(n: int, seed: int = 42, nan_frac: float = 0.0):
+    """BASELINE.json configs[4] as stated: 32 covariates x0..x31 ~ N(0, 0.5), three forcings -- air temperature ta, an
+    irradiance-like sw_in and a vapour-pressure-deficit-like vpd, both U(0.2, 1.2) -- and the target of the build-defined
+    three-forcing soil-respiration model Rs_components3F (R_het + sw_in R_root + vpd R_myc) whose base rates depend on the
+    covariates, 5 % multiplicative noise.  -> dict of float32 columns."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((32, n)).astype(np.float32) * 0.5
+    ta = (10 + 10 * rng.standard_normal(n)).astype(np.float32)
+    sw = (0.2 + rng.random(n)).astype(np.float32)
+    vpd = (0.2 + rng.random(n)).astype(np.float32)
+    e = 0.1 * (ta - 15.0)
+    rb = [1.0 + 0.8 * np.tanh(X[3 * c] + 0.5 * X[3 * c + 1]) for c in range(3)]
+    w = [1.0, sw, vpd]
+    y = sum(w[c] * rb[c] * np.power(1.6 + 0.4 * c, e) for c in range(3)).astype(np.float32)
+    y *= (1 + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    if nan_frac > 0:
+        y[rng.random(n) < nan_frac] = np.nan
+    cols = {f"x{i}": X[i] for i in range(32)}
+    cols.update(ta=ta, sw_in=sw, vpd=vpd, R_soil=y)
+    return cols

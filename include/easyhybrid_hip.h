@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 1
+#define EH_ABI_VERSION 2      /* 2: eh_train_step takes the minibatch indices; eh_comm_* */
 #define EH_MAX_HIDDEN 4
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
@@ -70,11 +70,13 @@ typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 
  *                                                  (build-defined 4-parameter model of BASELINE.json config 3)
  *   RS_COMPONENTS  params (Rb_het,Rb_root,Rb_myc,Q10_het,Q10_root,Q10_myc) forcing (ta) output (R_soil)
  *                                                  src/models/Rs_components.jl:40-57
+ *   RS_COMPONENTS3F  the same six parameters, forcings (ta, sw_in, vpd), output (R_soil): R_het + sw_in*R_root + vpd*R_myc,
+ *                  R_c = Rb_c*Q10_c^(0.1(ta-15))   (build-defined three-forcing model of BASELINE.json config 5; not in the reference)
  *   FLUXPART       params (RUE, Rb, Q10)          forcings (SW_IN, TA)  outputs (NEE, GPP, RECO)
  *                  GPP = SW_IN*RUE/12.011, RECO = Rb*Q10^(0.1(TA-15)), NEE = RECO - GPP   src/models/FluxPartModel_Q10_Lux.jl:50-79
  */
 typedef enum eh_mech { EH_MECH_RBQ10 = 0, EH_MECH_EXPO = 1, EH_MECH_LINEAR = 2, EH_MECH_EXPO2POOL = 3, EH_MECH_RS_COMPONENTS = 4, EH_MECH_FLUXPART = 5,
-                       EH_MECH_PROGRAM = 6 } eh_mech;
+                       EH_MECH_PROGRAM = 6, EH_MECH_RS_COMPONENTS3F = 7 } eh_mech;
 
 /* EH_MECH_PROGRAM: any other closure `f(; forcing..., params...) -> NamedTuple` of elementwise arithmetic
  * (src/models/GenericHybridModel.jl:420-425), handed over as a straight-line program that the host binding records by
@@ -233,11 +235,16 @@ int32_t eh_opt_init(eh_handle* h, int32_t rule, float lr, float beta1, float bet
 int32_t eh_get_opt_state(eh_handle* h, float* m, float* v, int64_t n, float* beta_t /* [2] */);
 int32_t eh_set_opt_state(eh_handle* h, const float* m, const float* v, int64_t n, const float* beta_t);
 
-/* one single_train_step! on train samples [first, first+count) (or idx_dev gather if
- * eh_shuffle_epoch was called): fused forward + mechanistic model + masked MSE + VJP, then reduce +
- * optimiser update.  loss_out == NULL: fully asynchronous on the stream.  An all-masked batch is
- * skipped without touching theta or the optimiser state (src/training/epoch.jl:17-19). */
-int32_t eh_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out);
+/* one single_train_step! (src/training/epoch.jl:20-26): fused forward + mechanistic model + masked loss + VJP, then reduce +
+ * optimiser update, on one minibatch of the resident train split.
+ *   idx == NULL : the contiguous window [first, first+count)
+ *   idx != NULL : the minibatch the CALLER's loader drew (MLUtils.DataLoader(shuffle = true), src/data/loaders.jl:1-12): sample
+ *                 i of the batch is train sample idx[first + i], int32, 0-based.  idx_on_device == 0: a host array (range-checked,
+ *                 copied on the handle's stream); != 0: a device array the caller keeps alive until the step has run (e.g. a
+ *                 whole epoch's permutation uploaded once; not range-checked).
+ * loss_out == NULL: fully asynchronous on the stream.  An all-masked batch is skipped without touching theta or the optimiser
+ * state (src/training/epoch.jl:17-19). */
+int32_t eh_train_step(eh_handle* h, const int32_t* idx, int32_t idx_on_device, int64_t first, int64_t count, float* loss_out);
 
 /* one run_epoch! over the train split (src/training/epoch.jl:13-33): ceil(N/batchsize) steps, the
  * last one partial (MLUtils.DataLoader default), shuffled on the device when shuffle != 0

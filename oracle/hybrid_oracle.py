@@ -96,6 +96,15 @@ def act_bwd(name: str, z, h):
     raise ValueError(f"unknown activation {name}")
 
 
+def round_bf16(x):
+    """Round to the nearest bfloat16 (ties to even, what v_cvt_pk_bf16_f32 does) and return the value in x's dtype.  A float64
+    input goes through float32 first, like the device, where the value rounded is an fp32 number."""
+    x = np.asarray(x)
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(x.dtype)
+
+
 # ----------------------------------------------------------------------------------------------
 # mechanistic model registry: forward + hand VJP.  par/frc are dicts name -> array (B,) or scalar.
 # ----------------------------------------------------------------------------------------------
@@ -181,6 +190,22 @@ def _rs_vjp(par, frc, out, aux, dout, dt):
     return g
 
 
+def _rs3f_fwd(par, frc, dt):
+    # build-defined (BASELINE.json configs[4]: "3 forcings ... RbQ10-family M", the reference has no such model): the three
+    # Rs_components pools (Rs_components.jl:45-55) with the root pool scaled by an irradiance-like forcing and the mycorrhizal
+    # pool by a vapour-pressure-deficit-like one:  R_soil = R_het + sw_in R_root + vpd R_myc,  R_c = Rb_c Q10_c^(0.1 (ta - 15))
+    e = dt.type(0.1) * (frc["ta"] - dt.type(15.0))
+    aux = {"e": e}
+    tot = 0
+    for c, w in (("het", None), ("root", "sw_in"), ("myc", "vpd")):
+        p = np.power(par[f"Q10_{c}"], e)
+        wv = dt.type(1) if w is None else frc[w]
+        aux[f"p_{c}"] = wv * p
+        aux[f"R_{c}"] = par[f"Rb_{c}"] * aux[f"p_{c}"]
+        tot = tot + aux[f"R_{c}"]
+    return {"R_soil": tot}, aux
+
+
 def _fluxpart_fwd(par, frc, dt):
     # GPP = sw_in .* RUE ./ 12.011f0 ; RECO = Rb .* Q10 .^ (0.1f0 .* (ta .- 15f0)) ; NEE = RECO .- GPP   (FluxPartModel_Q10_Lux.jl:66-74)
     e = dt.type(0.1) * (frc["TA"] - dt.type(15.0))
@@ -205,6 +230,9 @@ MECH: Dict[str, Tuple[MechModel, callable, callable]] = {
     "rs_components": (MechModel("rs_components",
                                 ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
                                 ("ta",), ("R_soil",)), _rs_fwd, _rs_vjp),
+    "rs_components3f": (MechModel("rs_components3f",
+                                  ("Rb_het", "Rb_root", "Rb_myc", "Q10_het", "Q10_root", "Q10_myc"),
+                                  ("ta", "sw_in", "vpd"), ("R_soil",)), _rs3f_fwd, _rs_vjp),
     "fluxpart": (MechModel("fluxpart", ("RUE", "Rb", "Q10"), ("SW_IN", "TA"), ("NEE", "GPP", "RECO")), _fluxpart_fwd, _fluxpart_vjp),
 }
 
@@ -337,6 +365,14 @@ class HybridSpec:
     nets: Optional[List[Tuple[List[int], List[int]]]] = None
     # MultiNN with activation::NamedTuple (GenericHybridModel.jl:168-176): the activation of net k; None = `activation` for all
     net_activations: Optional[List[str]] = None
+    # "f32": the reference's arithmetic (Float32 end to end, src/data/prepare_data.jl:58-60).
+    # "bf16_fwd": BASELINE.json configs[4] "bf16 fwd / fp32 accumulate" (NOT a reference mode; build-defined): every Dense
+    # product takes its two operands -- weights and the layer's input (predictors, hidden activations) -- rounded to bfloat16
+    # and accumulates exactly (fp32 on the device); biases, activations, sigma-scaling, the mechanistic model and the loss stay
+    # fp32.  What a layer hands on IS the rounded activation, so the backward pass -- fp32 -- is the exact derivative of that
+    # function with round() treated as the identity (straight-through): dW = dZ * bf16(h)^T, dH = bf16(W)^T dZ, and act' taken
+    # from the stored (rounded) activation, as a mixed-precision framework that keeps bf16 activations does.
+    precision: str = "f32"
 
     def act_of(self, k: int) -> str:
         return self.activation if self.net_activations is None else self.net_activations[k]
@@ -351,6 +387,10 @@ class HybridSpec:
                 raise AssertionError("neural_param_names ⊆ param_names")   # GenericHybridModel.jl:110
         if not self.targets:
             self.targets = [mm.outputs[0]]
+        if self.precision not in ("f32", "bf16_fwd"):
+            raise ValueError(f"precision {self.precision}")
+        if self.precision == "bf16_fwd" and any(self.act_of(k) == "swish" for k in range(len(self.neural) if self.nets else 1)):
+            raise NotImplementedError("bf16_fwd keeps only the rounded activation: swish needs the pre-activation")
         self.fixed = [n for n in self.parameters if n not in self.neural and n not in self.glob]
 
     # -- sizes / flat layout (a11 in SURVEY section 8a) ---------------------------------------
@@ -488,12 +528,17 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
     # k2: MLP(s): one chain for SingleNN, one single-output chain per neural parameter for MultiNN
     tapes, outs = [], []
     for k_net, ((rows, _), Ws) in enumerate(zip(spec.net_list, nets)):
-        h = X[rows]
+        bf = spec.precision == "bf16_fwd"
+        h = round_bf16(X[rows]) if bf else X[rows]
+        if bf:
+            Ws = [(round_bf16(W), b) for W, b in Ws]          # the rounded weights are what forward AND backward multiply by
         zs, hs = [], [h]
         for li, (W, b) in enumerate(Ws):
             z = (W @ h + b[:, None]).astype(dt)
             last = li == len(Ws) - 1
             h = z if last else act_fwd(spec.act_of(k_net), z).astype(dt)
+            if bf and not last:
+                h = round_bf16(h)
             zs.append(z); hs.append(h)
         tapes.append((Ws, zs, hs))
         outs.append(h)
@@ -859,3 +904,31 @@ def make_synth_expo2pool(n: int, seed: int = 42, nan_frac: float = 0.0):
     if nan_frac > 0:
         resp[rng.random(n) < nan_frac] = np.nan
     return X.astype(np.float32), {"T": T.astype(np.float32)}, {"Resp_obs": resp.astype(np.float32)}
+
+
+RS6_PARAMS = {**{f"Rb_{c}": (1.0, 0.0, 5.0) for c in ("het", "root", "myc")},
+              **{f"Q10_{c}": (2.0 + 0.3 * i, 1.0, 4.0) for i, c in enumerate(("het", "root", "myc"))}}
+
+
+def c5_spec(hidden=(128, 128), activation="tanh", precision="bf16_fwd", n_pred=32):
+    """BASELINE.json configs[4]: MLP [32,128,128,6] -> the six parameters of the three-forcing Rs_components model, all neural,
+    sigma-scaled; bf16 forward / fp32 accumulate."""
+    return HybridSpec(n_pred, list(hidden), "rs_components3f", dict(RS6_PARAMS), list(RS6_PARAMS), [], ["R_soil"], activation, True,
+                      precision=precision)
+
+
+def make_synth_c5(n: int, seed: int = 42, nan_frac: float = 0.0, n_pred=32):
+    """same distributions as easyhybrid.jl_amd/synthetic.py make_synth_fluxnet32_3f (kept apart: the product never imports oracle/)"""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n_pred, n)).astype(np.float32) * 0.5
+    ta = (10 + 10 * rng.standard_normal(n)).astype(np.float32)
+    sw = (0.2 + rng.random(n)).astype(np.float32)
+    vpd = (0.2 + rng.random(n)).astype(np.float32)
+    e = 0.1 * (ta - 15.0)
+    rb = [1.0 + 0.8 * np.tanh(X[(3 * c) % n_pred] + 0.5 * X[(3 * c + 1) % n_pred]) for c in range(3)]
+    w = [1.0, sw, vpd]
+    y = sum(w[c] * rb[c] * np.power(1.6 + 0.4 * c, e) for c in range(3)).astype(np.float32)
+    y *= (1 + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    if nan_frac > 0:
+        y[rng.random(n) < nan_frac] = np.nan
+    return X, {"ta": ta, "sw_in": sw, "vpd": vpd}, {"R_soil": y}

@@ -29,6 +29,29 @@ def _act(name, z):
     raise ValueError(name)
 
 
+def _round_bf16(x):
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundedAct(torch.autograd.Function):
+    """spec.precision == "bf16_fwd": a hidden layer hands on bf16(act(z)) and its derivative is taken from that stored value
+    (tanh: 1 - h^2, sigmoid: h (1 - h), relu: h > 0), the rounding itself treated as the identity."""
+
+    @staticmethod
+    def forward(ctx, z, name):
+        h = _round_bf16(_act(name, z))
+        ctx.save_for_backward(h)
+        ctx.name = name
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        n = ctx.name
+        d = 1 - h * h if n == "tanh" else h * (1 - h) if n == "sigmoid" else (h > 0).to(h.dtype) if n == "relu" else torch.ones_like(h)
+        return g * d, None
+
+
 def _mech(spec, par, frc):
     m = spec.mech
     if m == "rbq10":
@@ -42,6 +65,9 @@ def _mech(spec, par, frc):
     if m == "rs_components":
         e = 0.1 * (frc["ta"] - 15.0)
         return {"R_soil": sum(par[f"Rb_{c}"] * par[f"Q10_{c}"] ** e for c in ("het", "root", "myc"))}
+    if m == "rs_components3f":
+        e = 0.1 * (frc["ta"] - 15.0)
+        return {"R_soil": par["Rb_het"] * par["Q10_het"] ** e + frc["sw_in"] * par["Rb_root"] * par["Q10_root"] ** e + frc["vpd"] * par["Rb_myc"] * par["Q10_myc"] ** e}
     if m == "fluxpart":
         gpp = frc["SW_IN"] * par["RUE"] / 12.011
         reco = par["Rb"] * par["Q10"] ** (0.1 * (frc["TA"] - 15.0))
@@ -57,14 +83,19 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
         h = (h - h.mean(dim=1, keepdim=True)) / torch.sqrt(h.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
     X0, outs = h, []
     for k_net, (rows, dims) in enumerate(spec.net_list):
-        h = X0[rows]
+        bf = getattr(spec, "precision", "f32") == "bf16_fwd"
+        h = _round_bf16(X0[rows]) if bf else X0[rows]
         for li, (o, i) in enumerate(dims):
             W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)
+            if bf:
+                W = W + (_round_bf16(W) - W).detach()           # value bf16(W), gradient passed straight through to W
             off += o * i
             b = theta[off:off + o]
             off += o
             z = W @ h + b[:, None]
-            h = z if li == len(dims) - 1 else _act(spec.act_of(k_net), z)
+            if li == len(dims) - 1: h = z
+            elif bf: h = _RoundedAct.apply(z, spec.act_of(k_net))
+            else: h = _act(spec.act_of(k_net), z)
         outs.append(h)
     h = torch.cat(outs, dim=0)
     par = {}

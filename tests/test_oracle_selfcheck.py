@@ -211,3 +211,43 @@ def test_golden_fixtures_reproduce(path):
     assert l == pytest.approx(float(d["loss"]), rel=1e-12)
     assert np.allclose(g, d["grad"], rtol=1e-10, atol=1e-14)
     assert list(nv) == list(d["n_valid"])
+
+
+# ---- bf16-forward / fp32-accumulate mode (BASELINE.json configs[4]; build-defined, not a reference mode) -----------------
+def test_round_bf16_is_round_to_nearest_even():
+    import torch
+    r = np.random.default_rng(3).standard_normal(200000) * np.exp(np.random.default_rng(4).uniform(-30, 30, 200000))
+    want = torch.tensor(r, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    assert np.array_equal(ho.round_bf16(r), want)
+    assert ho.round_bf16(np.array([1.00390625]))[0] == 1.0 and ho.round_bf16(np.array([1.01171875]))[0] == 1.015625     # ties go to the even mantissa
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "relu"])
+def test_bf16_forward_vjp_matches_straight_through_autograd(act):
+    """the hand VJP of the bf16-forward mode against autograd of the same forward with round() as the identity and act' taken
+    from the stored rounded activation (oracle/torch_twin.py `_RoundedAct`)"""
+    spec = ho.c5_spec(hidden=(24, 20), activation=act, n_pred=7)
+    X, f, y = ho.make_synth_c5(300, 5, 0.1, n_pred=7)
+    theta = ho.init_theta(spec, 2, np.float64)
+    l0, g0, nv = ho.loss_and_grad(spec, theta, X, f, y)
+    l1, g1 = tt.loss_and_grad(spec, theta, X, f, y)
+    assert abs(l0 - l1) <= 1e-12 * abs(l1)
+    assert np.max(np.abs(g0 - g1)) <= 1e-11 * np.max(np.abs(g1))
+    # and it IS a different function from the fp32 one: the rounding shows at the 1e-3 level
+    spec32 = ho.c5_spec(hidden=(24, 20), activation=act, n_pred=7, precision="f32")
+    l32, g32, _ = ho.loss_and_grad(spec32, theta, X, f, y)
+    assert 1e-6 < abs(l32 - l0) / abs(l32) < 5e-2
+
+
+def test_bf16_forward_refuses_swish():
+    with pytest.raises(NotImplementedError):
+        ho.c5_spec(activation="swish")
+
+
+def test_three_forcing_components_model_vjp():
+    spec = ho.c5_spec(hidden=(12,), activation="tanh", n_pred=5, precision="f32")
+    X, f, y = ho.make_synth_c5(200, 9, 0.05, n_pred=5)
+    theta = ho.init_theta(spec, 4, np.float64)
+    l0, g0, _ = ho.loss_and_grad(spec, theta, X, f, y)
+    l1, g1 = tt.loss_and_grad(spec, theta, X, f, y)
+    assert abs(l0 - l1) <= 1e-12 * abs(l1) and np.max(np.abs(g0 - g1)) <= 1e-11 * np.max(np.abs(g1))

@@ -5,7 +5,7 @@ import easyhybrid_jl_amd as eh
 from oracle import hybrid_oracle as ho
 
 MECH_NAME = {"rbq10": "RbQ10", "expo": "Expo_resp_model", "linear": "LinearHM", "expo2pool": "Expo2Pool",
-             "rs_components": "Rs_components", "fluxpart": "FluxPartModelQ10"}
+             "rs_components": "Rs_components", "rs_components3f": "Rs_components3F", "fluxpart": "FluxPartModelQ10"}
 
 
 def register_closure(name, fn, params, forcings, targets):
@@ -36,11 +36,13 @@ def model_from_spec(spec: ho.HybridSpec):
         return eh.constructHybridModel(preds, list(mm.forcings), list(spec.targets), MECH_NAME[spec.mech], dict(spec.parameters),
                                        list(spec.glob), hidden_layers=hl,
                                        activation=spec.activation if spec.net_activations is None else dict(zip(spec.neural, spec.net_activations)),
-                                       scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False))
+                                       scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False),
+                                       precision=getattr(spec, "precision", "f32"))
     return eh.constructHybridModel([f"x{i}" for i in range(spec.n_pred)], list(mm.forcings), list(spec.targets),
                                    MECH_NAME[spec.mech], dict(spec.parameters), list(spec.neural), list(spec.glob),
                                    hidden_layers=list(spec.hidden), activation=spec.activation,
-                                   scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False))
+                                   scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False),
+                                   precision=getattr(spec, "precision", "f32"))
 
 
 def load_engine(spec, theta, X, forcings, targets, split=0, engine=None):
@@ -54,8 +56,17 @@ def load_engine(spec, theta, X, forcings, targets, split=0, engine=None):
 
 
 def relerr(a, b):
+    """max |a - b| over max |b|: the error of the largest entries (what a norm-wise bound sees)"""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def elem_relerr(a, b, floor_frac=1e-3):
+    """element-wise relative error max_i |a_i - b_i| / max(|b_i|, floor), floor = floor_frac * max |b|: every entry that is not
+    tiny against the largest one has to be right to the stated number of digits on its own"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    floor = max(floor_frac * float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
 
 
 def rbq10_case(B, act="tanh", scale=False, nan_frac=0.0, seed=42, hidden=(16, 16), theta_seed=1):

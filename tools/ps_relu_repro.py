@@ -1,16 +1,36 @@
-"""Diagnostics for the confined fast-path bug (P <= 4 weight-gradient path + ReLU on shapes wider than one block):
-build with `make -C easyhybrid.jl_amd/csrc EXP=-DEH_PS_WIDE` (the wide P <= 4 kernels are not in the normal build), then
-EH_DEBUG_PS_ALL=1 python tools/ps_relu_repro.py   (never part of the test suite)"""
+"""Diagnostics for the P <= 4 weight-gradient path (FAST bit 1) on shapes wider than one block, where the fuzz once found wrong
+ReLU gradients: a library from tools/ps_variants.sh (built with -DEH_PS_WIDE; the normal build has no such kernels), then
+EH_DEBUG_PS_ALL=1 EASYHYBRID_HIP_LIB=dbg/lib_<name>.so python tools/ps_relu_repro.py   (never part of the test suite)
+Per case: loss and gradient error against the oracle, per parameter block, for fast_paths = 3 (K1 | PS) and 1 (K1 only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import hybrid_oracle as ho
 from tests import util
-for hidden in ((48, 33, 16), (61, 20, 22), (64, 64)):
-    for act in ("tanh", "relu"):
-        spec, theta, X, f, y = util.rbq10_case(1000, act, True, 0.1, hidden=hidden)
-        eng = util.load_engine(spec, theta, X, f, y)
-        loss, grad, nv = eng.loss_and_grad()
-        l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
-        print("CASE", hidden, act, f"loss err {abs(loss - l0) / abs(l0):.1e} grad err {util.relerr(grad, g0):.1e}", flush=True)
-        eng.close()
+
+def blocks(spec):
+    out, off, inw = [], 0, spec.n_pred
+    for l, w in enumerate(list(spec.hidden) + [len(spec.neural)]):
+        out.append((f"W{l}", off, off + w * inw)); off += w * inw
+        out.append((f"b{l}", off, off + w)); off += w
+        inw = w
+    out.append(("glob", off, off + len(spec.glob)))
+    return out
+
+bad = 0
+for hidden in ((48, 33, 16), (61, 20, 22), (64, 64), (40, 40)):
+    for act in ("tanh", "relu", "sigmoid", "swish"):
+        for B in (1000, 16, 4096):
+            spec, theta, X, f, y = util.rbq10_case(B, act, True, 0.1, hidden=hidden)
+            l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+            for fp in (3, 1):
+                eng = util.load_engine(spec, theta, X, f, y)
+                eng.set_option("fast_paths", fp)
+                loss, grad, nv = eng.loss_and_grad()
+                le, ge = abs(loss - l0) / abs(l0), util.relerr(grad, g0)
+                flag = "" if (le < 1e-5 and ge < 1e-5) else "  <-- WRONG"
+                bad += bool(flag)
+                det = " ".join(f"{n}:{util.relerr(grad[a:b], g0[a:b]):.0e}" for n, a, b in blocks(spec) if b > a) if flag else ""
+                print("CASE", hidden, act, B, f"fast={fp} loss err {le:.1e} grad err {ge:.1e}{flag} {det}", flush=True)
+                eng.close()
+print("WRONG CASES:", bad)
