@@ -77,9 +77,9 @@ constexpr int pick_nt_bf() {
     if (sizeof(float) * EhBfGeom<EH_NBI, EH_NBH, EH_NL, 4, NWV>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
     return 2;
 }
-template <int NWV>
+template <int NWV, int NTW = 0>
 struct VarBf {
-    static constexpr int NTB = pick_nt_bf<NWV>();
+    static constexpr int NTB = NTW ? NTW : pick_nt_bf<NWV>();
     using Geom = EhBfGeom<EH_NBI, EH_NBH, EH_NL, NTB, NWV>;
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
@@ -127,7 +127,7 @@ const EhArchInfo info = {
     G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
     0,
 #if EH_NBH == 8
-    3, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), {}},
+    4, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), VarBf<8, 2>::info()},
 #else
     2, {Var<4>::info(), VarBf<4>::info(), {}, {}},
 #endif

@@ -5,18 +5,23 @@
 //   * every Dense product of the FORWARD pass takes its two operands -- weights and the layer's input (normalised predictors,
 //     hidden activations) -- rounded to bfloat16 (nearest even) and accumulates in fp32 on v_mfma_f32_16x16x32_bf16
 //     (16x the rate of the fp32 MFMA); biases, activations, sigma-scaling, mechanistic model and loss stay fp32;
-//   * what a layer hands on IS the rounded activation, so the BACKWARD pass -- fp32 MFMA, as in eh_wide_kernel -- is the exact
-//     derivative of that function with round() as the identity: dW = dZ * bf16(h)^T, dH = bf16(W)^T dZ, act' from the stored
-//     rounded activation.  Activations whose derivative needs the pre-activation (swish, per-net) are not built.
+//   * what a layer hands on IS the rounded activation, so the BACKWARD pass is the exact derivative of that function with
+//     round() as the identity: dW = dZ * bf16(h)^T, dH = bf16(W)^T dZ, act' from the stored rounded activation -- in fp32.
+//     Activations whose derivative needs the pre-activation (swish, per-net) are not built.
 //
-// Because nothing but the rounded operands is ever needed again, the LDS holds ONLY bf16 weights and activations:
-//   weights  [row][k]          (row stride k + 8 elements: 16-byte fragments of the A operand, conflict-free)
-//   images   [sample][feature] (same stride: 16-byte fragments of the B operand; the C/D layout of a forward MFMA -- four
-//                               consecutive features of one sample per lane -- packs into one 8-byte store)
-// half of what eh_wide_kernel needs, which buys 64-sample tiles (NT = 4: four independent accumulators per wave, half the
-// barriers per sample).  The backward pass reads the same images element-wise (2-byte LDS reads + a shift) where it needs the
-// sample index on the MFMA k dimension; deltas stay fp32 in a [feature][sample] image.  Same slab / rmap contract as
-// eh_wide_kernel (the accumulators are the same registers in the same order).
+// The backward products run on the bf16 MFMA as well, WITHOUT giving up fp32: one operand of each (the stored activation, the
+// weight) is exactly a bfloat16 already, and the other -- the fp32 delta dZ -- is split into three bfloat16 terms
+// d = d1 + d2 + d3 (8 + 8 + 8 mantissa bits: the split is exact).  A bf16 x bf16 product is exact in fp32, so
+// sum_p MFMA_bf16(d_p, h) accumulates exactly the products the fp32 MFMA would, at 3 x 16 cycles per 32 k-values instead of
+// 8 x 32: a fifth of the matrix-pipe time, bit-for-bit the same operands.
+//
+// Because nothing but bf16 operands is ever needed, the LDS holds ONLY bf16 images, each stored once:
+//   weights  [out feature][in feature]   (row stride k + 8 elements: 16-byte fragments, conflict-free)
+//   images   [sample][feature]           activations; deltas as three planes
+// A product that contracts over an image's COLUMN index (forward: features of the layer input; dH: features of dZ) reads
+// 16-byte row fragments; one that contracts over its ROW index (dW: samples of dZ and of the activations; dH: out-features of
+// W) reads the same image through gfx950's transposing LDS read (ds_read_b64_tr_b16, CDNA4 guide T10).  64-sample tiles
+// (NT = 4).  Same slab / rmap contract as eh_wide_kernel (the accumulators are the same registers in the same order).
 #pragma once
 #include "eh_wide.hpp"
 
@@ -24,13 +29,37 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 eh_lds_s16x4;
+
 __device__ __forceinline__ float eh_bf2f(__bf16 v) { return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16); }
+
+// d == a + b + c exactly (a, b, c bfloat16: 8 + 8 + 8 mantissa bits, round to nearest even each time; the remainders are exact in fp32)
+__device__ __forceinline__ void eh_split3(float d, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)d;
+    const float r1 = d - eh_bf2f(a);
+    b = (__bf16)r1;
+    c = (__bf16)(r1 - eh_bf2f(b));
+}
+
+// Fragment of a 16x16x32 bf16 MFMA operand whose k index runs over the ROWS of a [row][col] bf16 LDS image (row stride ld
+// elements, a multiple of 4): element j of lane (c = lane & 15, g = lane >> 4) = image[row0 + 8 g + j][col0 + c] -- A[row c][k]
+// or B[k][col c] alike.  Two hardware-transposed reads: lane 4q + p of a 16-lane group supplies the address of row q,
+// columns 4p .. 4p+3 of the group's 4 x 16 block and receives column (lane & 15) of its four rows.  Every lane of the wave
+// must be active and every address in bounds (rows row0 .. row0 + 31).
+__device__ __forceinline__ bf16x8 eh_tr_frag(const __bf16* img, int ld, int row0, int col0, int lane) {
+    const __bf16* const a0 = img + (row0 + 8 * (lane >> 4) + ((lane >> 2) & 3)) * ld + col0 + 4 * (lane & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((eh_lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((eh_lds_s16x4*)(a0 + 4 * ld));
+    return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
 
 template <int NBI, int NBH, int NL, int NT, int NWV>
 struct EhBfGeom {
     using F = EhGeom<NBI, NBH, NL, NT, 1>;                 // the fp32 parameter image in global memory (what the optimiser kernel maintains)
     static_assert(NBH % NWV == 0, "the waves split the feature blocks evenly");
-    static_assert(NT <= 4, "the mechanistic stage runs one sample per lane of wave 0");
+    static_assert(NT == 2 || NT == 4, "whole 32-sample k-steps in the weight-gradient products; one sample per lane of wave 0 in the mechanistic stage");
     static constexpr int MT = 16 * NT, SR = MT + 4, HP = 16 * NBH, IP = 16 * NBI;
     static constexpr int KP0 = 32 * ((IP + 31) / 32);      // k extent of layer 0 in whole MFMA steps (zero padded)
     static constexpr int S0B = KP0 + 8, SHB = HP + 8;      // bf16 row strides: 16-byte multiples, == 4 dwords mod 64 banks apart per row group
@@ -46,13 +75,16 @@ struct EhBfGeom {
     static constexpr int IMG_FLOATS = PHI_OFF + EH_IMG_META;
     static constexpr int XB_OFF = IMG_FLOATS;                               // bf16 [MT][S0B] normalised, rounded predictors
     static constexpr int HB_OFF = XB_OFF + MT * S0B / 2;                    // NL x bf16 [MT][SHB] rounded activations
-    static constexpr int DZ_OFF = HB_OFF + NL * MT * SHB / 2;               // fp32 [HP][SR] deltas; the split-K output partials [NPART][16][SR] alias it
-    static constexpr int OS_OFF = DZ_OFF + HP * SR;                         // fp32 [16][SR] NN outputs -> physical parameters -> d loss / d output
+    static constexpr int DOB = 16 + 8;                                      // row stride of the d loss / d NN output planes
+    static constexpr int DZ_OFF = HB_OFF + NL * MT * SHB / 2;               // 3 x bf16 [MT][SHB]: the three terms of the current layer's delta; the fp32 split-K output partials [NPART][16][SR] alias it
+    static constexpr int DO_OFF = DZ_OFF + 3 * MT * SHB / 2;                // 3 x bf16 [MT][DOB]: the three terms of d loss / d NN output
+    static constexpr int OS_OFF = DO_OFF + 3 * MT * DOB / 2;                // fp32 [16][SR] NN outputs -> physical parameters -> d loss / d output
     static constexpr int RS_OFF = OS_OFF + 16 * SR;                         // fp32 forcings (rows 0..3), targets (rows 4..7)
     static constexpr int SG_OFF = RS_OFF + (EH_MAX_FORC + EH_MAX_TARG) * SR; // fp32 [16][SR] d parameter / d output
-    static constexpr int TOTAL_FLOATS = SG_OFF + 16 * SR;
-    static_assert(NPART * 16 <= HP, "the split-K output partials alias the delta image");
-    static_assert(NWV * eh_wide_layout(NBI, NBH, NL, NWV).na * 256 <= TOTAL_FLOATS, "the end-of-kernel staging of the accumulators overlays the whole LDS");
+    static constexpr int MAP_FLOATS = SG_OFF + 16 * SR;
+    static constexpr int STAGE_FLOATS = NWV * eh_wide_layout(NBI, NBH, NL, NWV).na * 256;      // the end-of-kernel staging of the accumulators overlays the (then dead) map
+    static constexpr int TOTAL_FLOATS = MAP_FLOATS > STAGE_FLOATS ? MAP_FLOATS : STAGE_FLOATS;
+    static_assert(NPART * 16 * SR <= 3 * MT * SHB / 2, "the split-K output partials alias the delta planes");
 };
 
 // sums of one wave's mechanistic stage (train: gradient of the global parameters, loss terms; eval: metric sums)
@@ -215,8 +247,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     float* const BIAS = smem + G::B_OFF;
     __bf16* const XB = reinterpret_cast<__bf16*>(smem + G::XB_OFF);
     __bf16* const HB = reinterpret_cast<__bf16*>(smem + G::HB_OFF);
-    float* const DZ = smem + G::DZ_OFF;
-    float* const OSP = DZ;                      // [NPART][16][SR] partial outputs of the split-K output layer
+    __bf16* const DZP = reinterpret_cast<__bf16*>(smem + G::DZ_OFF);      // [3][MT][SHB]
+    __bf16* const DOP = reinterpret_cast<__bf16*>(smem + G::DO_OFF);      // [3][MT][DOB]
+    float* const OSP = smem + G::DZ_OFF;        // [NPART][16][SR] partial outputs of the split-K output layer (before the deltas exist)
     float* const OS = smem + G::OS_OFF;
     float* const RS = smem + G::RS_OFF;
     float* const SG = smem + G::SG_OFF;
@@ -262,6 +295,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
         }
         fetch_idx(tile + (int)gridDim.x);
     };
+    EH_STAMP(13);
     fetch_idx((int)blockIdx.x);
     fetch((int)blockIdx.x);
 
@@ -372,19 +406,14 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
                 *(bf16x4*)&out[(16 * t + c) * SHB + 16 * (m0 + mm) + 4 * g] = bf16x4{(__bf16)h[0], (__bf16)h[1], (__bf16)h[2], (__bf16)h[3]};
             }
     };
-    // B operand of an fp32 MFMA whose k index runs over the features of block q of the fp32 delta image: lane (c, g), step s <-> feature 16q+4g+s, sample 16t+c
-    auto load_dz = [&](int q, f32x4 (&bq)[NT]) {
+    constexpr int DOB = G::DOB, PZ = MT * SHB, PO = MT * DOB;      // plane sizes (elements) of the delta / output-delta terms
+    // a C/D block of deltas (features 16m+4g .. +3 of sample 16t+c per lane), split into its three bf16 terms, into the delta planes
+    auto store_dz = [&](const f32x4& d, int m, int t) {
+        bf16x4 p0, p1, p2;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) bq[t][s] = DZ[(16 * q + 4 * g + s) * SR + 16 * t + c];
-    };
-    // B operand with the SAMPLE index on k, from a [sample][feature] bf16 image: step s <-> sample 16t+4g+s, column = feature 16n+c
-    auto load_ht = [&](const __bf16* img, int ld, int n, int t) {
-        f32x4 b4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b4[s] = eh_bf2f(img[(16 * t + 4 * g + s) * ld + 16 * n + c]);
-        return b4;
+        for (int r = 0; r < 4; ++r) { __bf16 x, y, z; eh_split3(d[r], x, y, z); p0[r] = x; p1[r] = y; p2[r] = z; }
+        __bf16* const q = DZP + (16 * t + c) * SHB + 16 * m + 4 * g;
+        *(bf16x4*)q = p0; *(bf16x4*)(q + PZ) = p1; *(bf16x4*)(q + 2 * PZ) = p2;
     };
     // stored (rounded) activations of features 16m+4g .. +3 of sample 16t+c
     auto load_h4 = [&](const __bf16* img, int m, int t) {
@@ -392,7 +421,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
         return f32x4{eh_bf2f(p[0]), eh_bf2f(p[1]), eh_bf2f(p[2]), eh_bf2f(p[3])};
     };
 
+    EH_STAMP(14);
     for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        EH_STAMP(0);
         const int n_loc = tile * MT + lane;
         const bool live = mechw && (n_loc < count);
         // ---- 1. records -> normalised, rounded predictor image + forcing / target rows; next tile's records in flight
@@ -406,14 +437,17 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
             }
         fetch(tile + (int)gridDim.x);
         eh_lds_barrier();
+        EH_STAMP(1);
         // ---- 2. / 3. forward: layer 0, hidden layers ----------------------------------------------
         forward_layer(WB0, S0B, KS0, XB, S0B, 0, HB);
         eh_lds_barrier();
+        EH_STAMP(2);
 #pragma unroll
         for (int l = 1; l < NL; ++l) {
             forward_layer(WBH + (l - 1) * HP * SHB, SHB, KSH, HB + (l - 1) * MT * SHB, SHB, l, HB + l * MT * SHB);
             eh_lds_barrier();
         }
+        EH_STAMP(3);
         const __bf16* const Hlast = HB + (NL - 1) * MT * SHB;
         // ---- 4. output layer (K <= 16 rows), k-steps split over the waves --------------------------
         if (o_on) {
@@ -449,132 +483,159 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
             }
         }
         eh_lds_barrier();
+        EH_STAMP(4);
         // ---- 5. mechanistic model + masked loss: wave 0, one sample per lane -----------------------
         if (mechw) eh_mech_stage_lane<TRAIN, PROG>(net, a, lane, live, n_loc, SR, RS, OS, SG, meta, MA);
         eh_lds_barrier();
+        EH_STAMP(5);
         if constexpr (!TRAIN) continue;
 
-        // ---- 6. backward through the output layer (fp32 MFMA from here on) --------------------------
-        f32x4 dzr[MB][NT];
-        {
-            f32x4 dO[NT], aT[NT];
+        // ---- 6. backward through the output layer: d loss / d NN output (fp32 in OS) -> three bf16 terms [sample][k] -------
+        if (wave == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                f32x4 dO;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dO[t][r] = OS[(4 * g + r) * SR + 16 * t + c];
-                aT[t] = *(const f32x4*)&OS[c * SR + 16 * t + 4 * g];
-                if (wave == 0) aBo += dO[t];
-            }
-#pragma unroll
-            for (int mm = 0; mm < MB; ++mm) {
-                const int m = m0 + mm;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 b4 = load_ht(Hlast, SHB, m, t);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) aWo[mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWo[mm], 0, 0, 0);
-                }
-                f32x4 dh[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) dh[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (s < ksK) {
-                        const float av = eh_bf2f(WBO[(4 * g + s) * SHB + 16 * m + c]);
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dO[t][s], dh[t], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 hv = load_h4(Hlast, m, t);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dh[t][r] * eh_dact_row<ACT>(hv[r], NL - 1, 16 * m + 4 * g + r);
-                    aB[NL - 1][mm] += dzr[mm][t];
-                }
+                for (int r = 0; r < 4; ++r) dO[r] = OS[(4 * g + r) * SR + 16 * t + c];
+                aBo += dO;
             }
         }
-        // the split-K partials (aliasing DZ) were last read in step 4b: safe to overwrite now
+#pragma unroll
+        for (int u = 0; u < NEO; ++u) {
+            const int e = tid + u * NTH, k = e & 15, smp = e >> 4;
+            if (NEO * NTH == 16 * MT || e < 16 * MT) {
+                __bf16 x, y, z;
+                eh_split3(OS[k * SR + smp], x, y, z);
+                DOP[smp * DOB + k] = x; DOP[PO + smp * DOB + k] = y; DOP[2 * PO + smp * DOB + k] = z;
+            }
+        }
+        eh_lds_barrier();
+        f32x4 dzr[MB][NT];
+#pragma unroll
+        for (int mm = 0; mm < MB; ++mm) {
+            const int m = m0 + mm;
+            // dWo[k-out][own features] += dO * bf16(H_last)^T : both operands contract over the samples (rows of their images)
+#pragma unroll
+            for (int kk = 0; kk < MT / 32; ++kk) {
+                const bf16x8 bfr = eh_tr_frag(Hlast, SHB, 32 * kk, 16 * m, lane);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    aWo[mm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh_tr_frag(DOP + p * PO, DOB, 32 * kk, 0, lane), bfr, aWo[mm], 0, 0, 0);
+            }
+            // dH_last[own features][samples] = bf16(Wo)^T dO : k = the 16 (padded) output rows, the upper half of the k-step is zero
+            const bf16x8 zero8 = __builtin_bit_cast(bf16x8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+            bf16x8 afr = eh_tr_frag(WBO, SHB, -8 * (g & 2), 16 * m, lane);      // (lanes g >= 2 re-read rows 0..15: in bounds, discarded)
+            afr = g < 2 ? afr : zero8;
+            f32x4 dh[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dh[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bf16x8 bfr = *(const bf16x8*)&DOP[p * PO + (16 * t + c) * DOB + 8 * (g & 1)];
+                    bfr = g < 2 ? bfr : zero8;
+                    dh[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, dh[t], 0, 0, 0);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 hv = load_h4(Hlast, m, t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dh[t][r] * eh_dact_row<ACT>(hv[r], NL - 1, 16 * m + 4 * g + r);
+                aB[NL - 1][mm] += dzr[mm][t];
+            }
+        }
+        // the split-K partials (aliasing the delta planes) were last read in step 4b: safe to overwrite now
 #pragma unroll
         for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) DZ[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = dzr[mm][t][r];
+            for (int t = 0; t < NT; ++t) store_dz(dzr[mm][t], m0 + mm, t);
         eh_lds_barrier();
+        EH_STAMP(6);
         // ---- 7. hidden layers backward -------------------------------------------------------------
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
             const __bf16* Hp = HB + (l - 1) * MT * SHB;
             const __bf16* W = WBH + (l - 1) * HP * SHB;
-            // dW_l[own rows][all columns] += dZ_l (own rows) * bf16(H_{l-1})^T
+            // dW_l[own rows][all columns] += dZ_l (own rows) * bf16(H_{l-1})^T : contraction over the samples, both fragments transposed reads
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm) {
-                f32x4 aT[NT];
+                constexpr int NG = NBH < 4 ? NBH : 4;           // column blocks in flight: independent accumulators
 #pragma unroll
-                for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * (m0 + mm) + c) * SR + 16 * t + 4 * g];
+                for (int kk = 0; kk < MT / 32; ++kk) {
+                    bf16x8 afr[3];
 #pragma unroll
-                for (int n = 0; n < NBH; ++n)
+                    for (int p = 0; p < 3; ++p) afr[p] = eh_tr_frag(DZP + p * PZ, SHB, 32 * kk, 16 * (m0 + mm), lane);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const f32x4 b4 = load_ht(Hp, SHB, n, t);
+                    for (int n0 = 0; n0 < NBH; n0 += NG) {
+                        bf16x8 bfr[NG];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            aWh[l - 1][mm][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWh[l - 1][mm][n], 0, 0, 0);
+                        for (int u = 0; u < NG; ++u) bfr[u] = eh_tr_frag(Hp, SHB, 32 * kk, 16 * (n0 + u), lane);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+#pragma unroll
+                            for (int u = 0; u < NG; ++u)
+                                aWh[l - 1][mm][n0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[p], bfr[u], aWh[l - 1][mm][n0 + u], 0, 0, 0);
                     }
+                }
             }
-            // dH_{l-1}[own rows] = bf16(W_l)^T dZ_l  (k runs over ALL rows of dZ_l: the shared image)
+            // dH_{l-1}[own rows][samples] = bf16(W_l)^T dZ_l : contraction over the rows of W_l (transposed read) and the columns of dZ_l (row fragments)
             f32x4 dn[MB][NT];
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dn[mm][t] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < NBH; ++q) {
-                f32x4 bq[NT];
-                load_dz(q, bq);
+            for (int kk = 0; kk < KSH; ++kk) {
+                bf16x8 afr[MB];
 #pragma unroll
-                for (int mm = 0; mm < MB; ++mm)
+                for (int mm = 0; mm < MB; ++mm) afr[mm] = eh_tr_frag(W, SHB, 32 * kk, 16 * (m0 + mm), lane);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const float av = eh_bf2f(W[(16 * q + 4 * g + s) * SHB + 16 * (m0 + mm) + c]);
+                for (int p = 0; p < 3; ++p) {
+                    bf16x8 bfr[NT];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) dn[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[t][s], dn[mm][t], 0, 0, 0);
-                    }
+                    for (int t = 0; t < NT; ++t) bfr[t] = *(const bf16x8*)&DZP[p * PZ + (16 * t + c) * SHB + 32 * kk + 8 * g];
+#pragma unroll
+                    for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) dn[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[mm], bfr[t], dn[mm][t], 0, 0, 0);
+                }
             }
+            EH_STAMP(7);
             eh_lds_barrier();                         // every wave is done reading dZ_l
+            EH_STAMP(8);
 #pragma unroll
             for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x4 hv = load_h4(Hp, m0 + mm, t);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d = dn[mm][t][r] * eh_dact_row<ACT>(hv[r], l - 1, 16 * (m0 + mm) + 4 * g + r);
-                        dzr[mm][t][r] = d;
-                        DZ[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = d;
-                    }
+                    for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dn[mm][t][r] * eh_dact_row<ACT>(hv[r], l - 1, 16 * (m0 + mm) + 4 * g + r);
+                    store_dz(dzr[mm][t], m0 + mm, t);
                     aB[l - 1][mm] += dzr[mm][t];
                 }
             eh_lds_barrier();
         }
+        EH_STAMP(9);
         // ---- 8. layer 0: dW0[own rows] += dZ_0 * bf16(X)^T -------------------------------------------
 #pragma unroll
-        for (int mm = 0; mm < MB; ++mm) {
-            f32x4 aT[NT];
+        for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * (m0 + mm) + c) * SR + 16 * t + 4 * g];
+            for (int kk = 0; kk < MT / 32; ++kk) {
+                bf16x8 bfr[NBI];
 #pragma unroll
-            for (int n = 0; n < NBI; ++n)
+                for (int n = 0; n < NBI; ++n) bfr[n] = eh_tr_frag(XB, S0B, 32 * kk, 16 * n, lane);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 b4 = load_ht(XB, S0B, n, t);
+                for (int p = 0; p < 3; ++p) {
+                    const bf16x8 afr = eh_tr_frag(DZP + p * PZ, SHB, 32 * kk, 16 * (m0 + mm), lane);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) aW0[mm][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aW0[mm][n], 0, 0, 0);
+                    for (int n = 0; n < NBI; ++n) aW0[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n], aW0[mm][n], 0, 0, 0);
                 }
-        }
+            }
         eh_lds_barrier();                             // the images are rewritten by the next tile
+        EH_STAMP(10);
     }
+    EH_STAMP(11);
 
     // ---- 9. one partial per workgroup (as eh_wide_kernel: the waves own disjoint entries) ------------
     float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
@@ -646,4 +707,5 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
             out[net.n_theta + 2 + net.T] = syyacc;
         }
     }
+    EH_STAMP(12);
 }

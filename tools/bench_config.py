@@ -4,7 +4,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import easyhybrid_jl_amd as eh
-from easyhybrid_jl_amd.synthetic import EXPO2POOL_PARAMS, RBQ10_PARAMS, RS6_PARAMS, make_synth_expo2pool, make_synth_fluxnet32, make_synth_rbq10
+from easyhybrid_jl_amd.synthetic import EXPO2POOL_PARAMS, RBQ10_PARAMS, RS6_PARAMS, make_synth_expo2pool, make_synth_fluxnet32, make_synth_fluxnet32_3f, make_synth_rbq10
 
 ap = argparse.ArgumentParser()
 ap.add_argument("config", choices=["c1", "c2", "c3", "c5"])
@@ -15,6 +15,8 @@ ap.add_argument("--nbatches", type=int, default=8)
 ap.add_argument("--variant", type=int, default=-1)
 ap.add_argument("--specialize", type=int, default=0)
 ap.add_argument("--row-split", type=int, default=0)
+ap.add_argument("--precision", default="", help="c5: bf16_fwd (default, as BASELINE states the config) or f32")
+ap.add_argument("--n", type=int, default=0, help="resident samples (c5 default: 152 batches ~ 1e7 as BASELINE states; others nbatches * batch)")
 a = ap.parse_args()
 if a.config == "c3":
     B = a.batch or 262144
@@ -23,14 +25,17 @@ if a.config == "c3":
     cols = make_synth_expo2pool(a.nbatches * B, 1)
     X = np.stack([cols[f"x{i}"] for i in range(8)]); F = [cols["T"]]; Y = [cols["Resp_obs"]]
     flop, byts = 29184, 40
-elif a.config == "c5":          # configs[4]: MLP [32,128,128,6] + Rs_components (RbQ10 family, three pools), fp32 here
+elif a.config == "c5":          # configs[4]: 1e7 samples, 32 covariates, 3 forcings, MLP [32,128,128,6] + the three-forcing RbQ10-family model, bf16 fwd / fp32 accumulate
     B = a.batch or 65536
-    model = eh.constructHybridModel([f"x{i}" for i in range(32)], ["ta"], ["R_soil"], eh.Rs_components, dict(RS6_PARAMS),
-                                    list(RS6_PARAMS), [], hidden_layers=[128, 128], activation="tanh", scale_nn_outputs=True)
-    cols = make_synth_fluxnet32(a.nbatches * B, 1)
-    X = np.stack([cols[f"x{i}"] for i in range(32)]); F = [cols["ta"]]; Y = [cols["R_soil"]]
-    flop, byts = 6 * (32 * 128 + 128 * 128 + 128 * 6), 4 * 34
-    a.fused = 0                   # the row-split kernel has no fused-update mode
+    prec = a.precision or "bf16_fwd"
+    model = eh.constructHybridModel([f"x{i}" for i in range(32)], ["ta", "sw_in", "vpd"], ["R_soil"], eh.Rs_components3F, dict(RS6_PARAMS),
+                                    list(RS6_PARAMS), [], hidden_layers=[128, 128], activation="tanh", scale_nn_outputs=True, precision=prec)
+    a.nbatches = max(1, (a.n or 10_000_000) // B)
+    cols = make_synth_fluxnet32_3f(a.nbatches * B, 1)
+    X = np.stack([cols[f"x{i}"] for i in range(32)]); F = [cols["ta"], cols["sw_in"], cols["vpd"]]; Y = [cols["R_soil"]]
+    del cols
+    flop, byts = 6 * (32 * 128 + 128 * 128 + 128 * 6), 4 * 36
+    a.fused = 0                   # the row-split kernels have no fused-update mode
 else:
     B = a.batch or (1024 if a.config == "c1" else 65536)
     model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"],
@@ -53,7 +58,13 @@ def run(n, base=0):
 run(20); eng.synchronize()
 t0 = time.perf_counter(); run(a.steps, 20); eng.synchronize(); dt = time.perf_counter() - t0
 us = 1e6 * dt / a.steps
-print(json.dumps({"config": a.config, "batch": B, "fused": a.fused, "specialize": a.specialize, "us_per_step": us, "samples_per_s": B / us * 1e6,
+extra = {}
+if a.config == "c5":
+    fwd = flop / 3
+    # mixed roof: the forward third of the algorithmic flops on the bf16 MFMA (2516 TFLOP/s dense), the rest on the fp32 MFMA (157.3)
+    t_roof = (fwd / 2516.6e12 + 2 * fwd / 157.3e12) if prec == "bf16_fwd" else flop / 157.3e12
+    extra = {"precision": prec, "resident_samples": a.nbatches * B, "frac_mixed_roof": t_roof * B / (us * 1e-6)}
+print(json.dumps({**extra, "config": a.config, "batch": B, "fused": a.fused, "specialize": a.specialize, "us_per_step": us, "samples_per_s": B / us * 1e6,
                   "algorithmic_TFLOPs": flop * B / us / 1e6, "frac_f32_peak": flop * B / us / 1e6 / 157.3,
                   "algorithmic_GBps": byts * B / us / 1e3, "final_loss": eng.train_step(0, B)}))
 eng.close()

@@ -8,6 +8,7 @@ hidden = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else
 spec, theta, X, f, y = tg._rs6_case(int(os.environ.get("EH_P", "32")), hidden, B)
 eng = util.load_engine(spec, theta, X, f, y)
 eng.opt_init("Adam", 1e-3)
+if "EH_PRECISION" in os.environ: eng.set_option("precision", int(os.environ["EH_PRECISION"]))
 if "EH_VARIANT" in os.environ: eng.set_option("variant", int(os.environ["EH_VARIANT"]))
 if "EH_ROW_SPLIT" in os.environ: eng.set_option("row_split", int(os.environ["EH_ROW_SPLIT"]))
 buf = (C.c_uint64 * 32)()
