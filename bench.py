@@ -53,10 +53,25 @@ def cpu_baseline(batch, seconds=12.0):
         co.train_steps(spec, theta, X, f, y, batch, chunk, nthreads=best)
         n += chunk
     dt = time.perf_counter() - t0
-    return {"value": batch * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
-            "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the plain-C oracle port, "
-                      f"OpenMP over samples on {best} of {avail} host threads (fastest of a short sweep)",
-            "ms_per_step": 1e3 * dt / n}
+    out = {"value": batch * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
+           "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the plain-C oracle port, "
+                     f"OpenMP over samples on {best} of {avail} host threads (fastest of a short sweep)",
+           "ms_per_step": 1e3 * dt / n}
+    # PyTorch-CPU eager autograd + Adam on the same batch -- the structurally closest stand-in for the
+    # reference's Lux + Zygote step this box can run (BLAS GEMMs, un-fused broadcasts, tape, boolean-mask gather); ~3 s
+    try:
+        from oracle import torch_twin as tt
+        import torch
+        eager = None
+        for nt in sorted({min(avail, k) for k in (8, 32, 64)}):
+            sec = tt.train_step_timed(spec, theta, X[:, :batch], {k: v[:batch] for k, v in f.items()}, {k: v[:batch] for k, v in y.items()}, 8, threads=nt)
+            if eager is None or sec < eager[1]:
+                eager = (nt, sec)
+        out["eager"] = {"value": batch / eager[1], "unit": "samples/s", "cores": eager[0], "kind": "port", "ms_per_step": 1e3 * eager[1],
+                        "sample": f"8 steps of batch {batch}, torch {torch.__version__} CPU eager autograd + torch.optim.Adam (oracle/torch_twin.py), best of 8 / 32 / 64 threads"}
+    except Exception as e:
+        out["eager"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -71,9 +86,14 @@ def main():
                     help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
     args = ap.parse_args()
 
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world == 1 and not args.no_cpu_baseline:
+        # the CPU checker is compiled (gcc: a fork + exec) BEFORE this process touches the GPU -- a process that has initialised
+        # HIP must not start other programs on the GPU boxes; once the GPU is up, c_oracle.build() refuses instead of compiling
+        from oracle import c_oracle
+        c_oracle.build()
+    import torch
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

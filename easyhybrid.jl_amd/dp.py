@@ -66,7 +66,7 @@ class _DevArray:
 class DataParallel:
     """Drives one replica.  `engine` already holds this rank's shard as its train split."""
 
-    def __init__(self, engine, group=None, fused: bool = True, p2p="auto", specialize: bool = False):
+    def __init__(self, engine, group=None, fused: bool = True, p2p="auto", specialize: bool = False, debug_fail_selftest_rank=None):
         """fused=True: one kernel + one exchange per step (the update of step s is applied in the
         prologue of step s+1; `engine.synchronize()` applies the last one).  The exchange is the
         engine's own peer-to-peer store protocol over xGMI when `p2p` is on and its start-up self-test
@@ -76,6 +76,7 @@ class DataParallel:
         import torch
         from . import _lib as L
         self.engine, self.group, self.fused = engine, group, fused
+        self._debug_fail_rank = debug_fail_selftest_rank            # tests only: this rank reports a failed self-test (exercises the fallback negotiation)
         dev = torch.device("cuda", torch.cuda.current_device())
         self._dev = dev
         ptr, n = engine.device_buffer(L.EH_BUF_GRAD)
@@ -160,7 +161,7 @@ class DataParallel:
             ok = eng.p2p_selftest(8)
         except Exception:
             ok = False
-        if os.environ.get("EH_DP_P2P_FAIL_SELFTEST") == str(rank):      # test hook: the fallback negotiation
+        if self._debug_fail_rank is not None and int(self._debug_fail_rank) == rank:
             ok = False
         if not self._all_agree(ok):
             dist.barrier(group=self.group)                  # nobody unmaps while a peer's test kernel may still store
@@ -213,7 +214,7 @@ class DataParallel:
         self.p2p = False
         self._refresh_gacc()
         if not ok:
-            self.engine.set_option("fused_update", 0); self.broadcast_params(0); self.engine.set_option("fused_update", 1)
+            self.broadcast_state(0)
             return {"p2p_us": None, "collective_us": None, "chosen": "collective (peer-to-peer exchange failed)"}
         t_col, _ = timed()
         if t_p2p < t_col:
@@ -241,9 +242,7 @@ class DataParallel:
         self.engine.p2p_disable()
         self.p2p = False
         self._refresh_gacc()
-        self.engine.set_option("fused_update", 0)           # parameter buffers are only addressable outside the fused mode
-        self.broadcast_params(0)
-        self.engine.set_option("fused_update", 1)
+        self.broadcast_state(0)
         return False
 
     def step(self, first: int, count: int, want_loss: bool = False):
@@ -266,3 +265,25 @@ class DataParallel:
         ptr, n = self.engine.device_buffer(L.EH_BUF_THETA)
         t = torch.as_tensor(_DevArray(ptr, n), device=self.buf.device)
         dist.broadcast(t, src=src, group=self.group)
+
+    def broadcast_state(self, src: int = 0):
+        """Collective: every replica takes rank `src`'s parameters AND optimiser state (moments, running beta products) -- after a
+        missed exchange a rank substitutes zeros for what never arrived, so all of them can differ, and replicas that only agreed
+        on theta would drift apart again with the next update.  Goes through the host API (get / set): the engine applies any
+        pending update first and refreshes the parameter image the step kernels read."""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        eng = self.engine
+        theta = eng.get_params()
+        m, v, bt = eng.get_opt_state()
+        pack = np.concatenate([theta, m, v, np.asarray(bt, np.float32)]).astype(np.float32)
+        backend = dist.get_backend(self.group)
+        t = torch.from_numpy(pack).to(self._dev if backend == "nccl" else "cpu")
+        dist.broadcast(t, src=src, group=self.group)
+        pack = t.cpu().numpy()
+        n = theta.size
+        eng.set_params(pack[:n])
+        eng.set_opt_state(pack[n:2 * n], pack[2 * n:3 * n], pack[3 * n:3 * n + 2])
+        if self.fused:
+            self._refresh_gacc()

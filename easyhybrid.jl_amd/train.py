@@ -331,6 +331,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         init = snapshot()
         history = [init]
         best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0
+        best_bn = eng.get_bn_state() if has_bn else None            # early_stopping.jl update!: best_ps AND best_st
         seed0 = tc.random_seed if tc.random_seed is not None else 0
         b = -(-tc.batchsize // world)                 # samples per rank per step
         steps = -(-(-(-N // world)) // b)             # ceil(largest shard / b): the same number of steps on every rank
@@ -346,6 +347,8 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
             cur = snap.l_val[first_lt]["sum"]
             if isbetter(cur, best_loss, first_lt):
                 best_loss, best_ps, best_epoch, counter = cur, eng.get_params(), epoch, 0
+                if has_bn:
+                    best_bn = eng.get_bn_state()
                 if not tc.keep_history:
                     history[0] = snap
             else:
@@ -354,7 +357,10 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
                 break
         eng.synchronize()
         ps = best_ps if tc.return_model == "best" else eng.get_params()
+        bn_out = (best_bn if tc.return_model == "best" else eng.get_bn_state()) if has_bn else None      # best_or_final
         ev.set_params(ps)
+        if has_bn:
+            ev.set_bn_state(*bn_out)
 
         def obs_pred(split, y):
             if ev.n_samples[split] == 0:
@@ -367,8 +373,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
         st = {"fixed": {f: np.float32(model.parameters.default(f)) for f in model.fixed_param_names}}
         if has_bn:
-            rm, rv = eng.get_bn_state()
-            st["st_nn"] = {"running_mean": rm, "running_var": rv}
+            st["st_nn"] = {"running_mean": bn_out[0], "running_var": bn_out[1]}
         return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
                             ps, st, best_epoch, best_loss)
     finally:
@@ -424,6 +429,8 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         init = snapshot()
         history = [init]
         best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0
+        has_bn = bool(model.config.get("input_batchnorm"))
+        best_bn = eng.get_bn_state() if has_bn else None            # early_stopping.jl update!: best_ps AND best_st
         seed0 = tc.random_seed if tc.random_seed is not None else int(rng.integers(2**31))
         for epoch in range(1, tc.nepochs + 1):
             eng.train_epoch(tc.batchsize, seed=seed0 + epoch, shuffle=True, want_loss=False)      # run_epoch!
@@ -433,6 +440,8 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
             cur = snap.l_val[first_lt]["sum"]
             if isbetter(cur, best_loss, first_lt):                                             # early_stopping.jl:16-42
                 best_loss, best_ps, best_epoch, counter = cur, eng.get_params(), epoch, 0
+                if has_bn:
+                    best_bn = eng.get_bn_state()
                 if not tc.keep_history:
                     history[0] = snap
             else:
@@ -440,7 +449,10 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
             if counter >= tc.patience:
                 break
         ps = best_ps if tc.return_model == "best" else eng.get_params()                        # best_or_final
+        bn_out = (best_bn if tc.return_model == "best" else eng.get_bn_state()) if has_bn else None
         eng.set_params(ps)
+        if has_bn:
+            eng.set_bn_state(*bn_out)                                # the predictions below use the state that belongs to `ps`
 
         def obs_pred(split, y):
             if eng.n_samples[split] == 0:
@@ -453,9 +465,8 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
         fixed = {f: np.float32(model.parameters.default(f)) for f in model.fixed_param_names}
         st = {"fixed": fixed}
-        if model.config.get("input_batchnorm"):
-            rm, rv = eng.get_bn_state()
-            st["st_nn"] = {"running_mean": rm, "running_var": rv}          # Lux BatchNorm state (final, not best-epoch)
+        if has_bn:
+            st["st_nn"] = {"running_mean": bn_out[0], "running_var": bn_out[1]}      # Lux BatchNorm state of the returned model (best_or_final)
         return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
                             ps, st, best_epoch, best_loss)
     finally:

@@ -26,8 +26,20 @@ class Spec(C.Structure):
                 ("F", C.c_int), ("forc_col", C.c_int * 4), ("T", C.c_int), ("targ_out", C.c_int * 4)]
 
 
+def _gpu_is_up() -> bool:
+    import sys
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
 def build(force: bool = False) -> str:
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(SRC):
+        if _gpu_is_up():      # compiling means fork + exec, which a process that has initialised the GPU must not do on the GPU boxes
+            raise RuntimeError("oracle/libeh_oracle.so is missing or stale and this process has already initialised the GPU: build it first "
+                               "(python -c 'from oracle import c_oracle; c_oracle.build()', __graft_entry__.build(), or the start of a pytest session)")
         subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", SRC, "-o", SO, "-lm"])
     return SO
 

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the plain-C checker is compiled here, at session start, before any test can have initialised the GPU (compiling is a
+    # fork + exec; oracle/c_oracle.py refuses to do that once HIP is up)
+    try:
+        from oracle import c_oracle
+        c_oracle.build()
+    except Exception as e:          # no gcc: the tests that need the C port fail with the reason, the others run
+        print(f"conftest: C oracle not built: {e!r}")
 
 
 def _has_gpu():

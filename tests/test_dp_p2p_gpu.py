@@ -41,9 +41,17 @@ def test_two_ranks_peer_to_peer_exchange_with_run_time_specialised_kernels():
 
 
 def test_two_ranks_fall_back_to_the_collective_when_one_rank_fails_the_selftest():
-    lines = _run({"EH_DP_P2P_FAIL_SELFTEST": "1"}, 29562)
+    lines = _run({"EH_TOOL_FAIL_SELFTEST": "1"}, 29562)
     first = [l for l in lines if "max|theta-ref|" in l]
     assert len(first) == 2 and all("p2p=False" in l and "replicas_identical=True" in l for l in first), lines
+
+
+def test_two_ranks_recover_from_a_missed_exchange():
+    # one rank runs a step the other does not: the exchange hits its 2 s deadline, DataParallel.check() moves every rank to the
+    # all-reduce exchange and re-broadcasts parameters + optimiser state; replicas must be bitwise identical again afterwards
+    lines = _run({"EH_TOOL_FORCE_TIMEOUT": "1"}, 29565)
+    rec = [l for l in lines if "forced timeout" in l]
+    assert len(rec) == 2 and all("check() -> False" in l and "identical=True" in l and "finite=True" in l for l in rec), lines
 
 
 def test_two_ranks_distributed_train_front_door():

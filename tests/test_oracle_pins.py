@@ -97,3 +97,46 @@ def test_adam_first_step_is_lr_sign():
     th2 = ho.adam_step(th, g, st, lr=0.01)
     assert np.allclose(th - th2, 0.01 * np.sign(g), rtol=1e-4)
     assert st["t"] == 1
+
+
+def test_weight_l2_relations():
+    # test/test_extract_weights.jl:21-39 on a Dense(2 => 16, tanh), Dense(16 => 1) chain: weight_l2(ps) = sum of the squared
+    # WEIGHT matrices; its gradient is nowhere zero on the weights; biases are not regularised; normalize = true divides by the
+    # number of weights (the BatchNorm layer of the reference's chain has no :weight leaf with affine = false and adds nothing)
+    spec = ho.HybridSpec(2, [16], "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "tanh", False)
+    theta = ho.init_theta(spec, 11, np.float64)
+    (Ws,), raw = ho.unpack(spec, theta)
+    manual = sum(np.sum(W ** 2) for W, _ in Ws)
+    val, grad = ho.weight_l2(spec, theta, 1.0)
+    assert val == pytest.approx(manual, rel=1e-14)
+    lam = 1e-3
+    val_l, grad_l = ho.weight_l2(spec, theta, lam)
+    assert val_l == pytest.approx(lam * manual, rel=1e-14)
+    m = ho.weight_mask(spec)
+    assert np.all(grad_l[m] != 0) and np.all(grad_l[~m] == 0)            # every weight gets a gradient, no bias / global does
+    assert np.allclose(grad_l[m], 2 * lam * theta[m])
+    n_weights = sum(W.size for W, _ in Ws)
+    assert m.sum() == n_weights == 2 * 16 + 16
+    val_n, _ = ho.weight_l2(spec, theta, 1.0, normalize=True)
+    assert val_n == pytest.approx(manual / n_weights, rel=1e-14)
+
+
+def test_extra_loss_is_added_through_agg_sum():
+    # test/test_compute_loss.jl:257-285: compute_loss(train mode, extra_loss) = sum([main_loss, extra...]); :287-308: without
+    # extra_loss it is the main loss, which is _compute_loss(HM(x), y, mask, targets, :mse, sum)
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    X, f, y = ho.make_synth_rbq10(64, 3, 0.2)
+    X = X / 50
+    theta = ho.init_theta(spec, 5, np.float64)
+    main = ho.compute_loss(spec, theta, X, f, y)
+    res = ho.forward(spec, theta, X, f)
+    yv = np.asarray(y["reco"], np.float64)
+    msk = ho.valid_mask(yv)
+    assert main == pytest.approx(ho.loss_fn(res["reco"], yv, msk, "mse"), rel=1e-14)
+    l_plain, g_plain, _ = ho.loss_and_grad(spec, theta, X, f, y)
+    assert l_plain == pytest.approx(main, rel=1e-13)
+    lam = 0.05
+    extra, gextra = ho.weight_l2(spec, theta, lam)
+    l_extra, g_extra, _ = ho.loss_and_grad(spec, theta, X, f, y, l2=(lam, False))
+    assert l_extra == pytest.approx(sum([main, extra]), rel=1e-13)
+    assert np.allclose(g_extra, g_plain + gextra, rtol=1e-13, atol=0)

@@ -42,7 +42,7 @@ eng.opt_init("Adam", 0.01)
 # whose 256 workgroups all sit waiting for the peer's sums would keep the peer's kernel from ever being scheduled.
 eng.set_option("max_blocks", max(1, 128 // world))
 SPEC = os.environ.get("EH_TOOL_SPECIALIZE", "0") == "1"      # step kernels compiled at run time around the descriptor (incl. the cross-GPU one)
-drv = eh.dp.DataParallel(eng, fused=True, specialize=SPEC)
+drv = eh.dp.DataParallel(eng, fused=True, specialize=SPEC, debug_fail_selftest_rank=os.environ.get("EH_TOOL_FAIL_SELFTEST"))
 dist.barrier()
 t0 = time.perf_counter()
 for i in range(nsteps):
@@ -60,6 +60,26 @@ dist.all_gather(tl, t)
 same = all(bool(torch.equal(tl[0], q)) for q in tl)
 print(f"rank {rank}: p2p={drv.p2p} jit_kernels={eng.jit_status()[0]} steps={nsteps} {1e6 * dt / nsteps:.1f} us/step max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
 ok = err <= 3e-5 and same
+if os.environ.get("EH_TOOL_FORCE_TIMEOUT") == "1":
+    # recovery: rank 0 runs one step more than rank 1, so its exchange never completes and runs into the 2 s deadline; check() must
+    # notice on every rank, drop to the all-reduce exchange and re-synchronise parameters AND optimiser state from rank 0
+    for i in range(3):
+        drv.step(i * b, b)
+    if rank == 0:
+        drv.step(3 * b, b)
+    healthy = drv.check()
+    for i in range(12):
+        drv.step((4 + i) * b, b)
+    eng.synchronize(); torch.cuda.synchronize()
+    m_, v_, bt_ = eng.get_opt_state()
+    state = torch.from_numpy(np.concatenate([eng.get_params(), m_, v_, bt_]).copy()); sl = [torch.empty_like(state) for _ in range(world)]
+    dist.all_gather(sl, state)
+    same_state = all(bool(torch.equal(sl[0], q)) for q in sl)
+    print(f"rank {rank}: forced timeout: check() -> {healthy}, p2p={drv.p2p}, after recovery + 12 steps theta/m/v/beta identical={same_state} finite={bool(np.isfinite(state.numpy()).all())}", flush=True)
+    ok = ok and (not healthy) and (not drv.p2p) and same_state
+    eng.close(); ref.close()
+    dist.barrier(); dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
 # timing at the headline batch
 B = 65536
 spec2, theta2, X2, f2, y2 = util.rbq10_case(8 * B, "tanh", True, 0.0)
