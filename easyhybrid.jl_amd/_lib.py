@@ -13,7 +13,8 @@ EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 4, 8, 4, 4
 EH_MAX_PROG, EH_MAX_PROG_CONST, EH_MAX_PROG_OUT = 64, 16, 3
 EH_MECH_PROGRAM = 6
 EH_LOSS_PROGRAM = 7
-EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE = 0, -1, -2, -3, -4, -5
+EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE, EH_ERCCL = 0, -1, -2, -3, -4, -5, -6
+EH_COMM_ID_BYTES = 128
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
 EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT = 0, 1, 2, 3, 4, 5
 
@@ -76,6 +77,13 @@ SIGNATURES = {
     "eh_opt_init": (C.c_int32, [_H, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "eh_get_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
     "eh_set_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
+    "eh_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_int64]),
+    "eh_comm_init": (C.c_int32, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
+    "eh_comm_destroy": (C.c_int32, [_H]),
+    "eh_comm_group_begin": (C.c_int32, []),
+    "eh_comm_group_end": (C.c_int32, []),
+    "eh_dp_allreduce": (C.c_int32, [_H, C.c_int32, C.c_int32]),
+    "eh_dp_train_step": (C.c_int32, [_H, C.c_int64, C.c_int64, _F]),
     "eh_train_step": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64, _F]),
     "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),

@@ -3,6 +3,7 @@
 // permutation, record packing.  Everything here runs on one HIP stream per handle; there is no CPU
 // compute path.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -671,6 +672,8 @@ struct eh_handle_s {
     bool bn_ext = false;            // bn_stat holds the statistics of the step about to run
     bool bn_dp_update = false;
     bool opt_ready = false;
+    ncclComm_t comm = nullptr;      // eh_comm_init: the library's own RCCL communicator (data parallelism without a host-side collective library)
+    int comm_world = 0, comm_rank = 0;
     EhOpt opt{};
     EhSplit split[2];
     float *slab = nullptr, *gradbuf = nullptr, *inv_n = nullptr, *loss_hist = nullptr;
@@ -853,15 +856,11 @@ static int build_maps(eh_handle* h, bool with_imap) {
 }
 
 // Which vector-ALU fast paths a model may use: bit 0 = single NN output (K == 1), bit 1 = P <= 4 predictors.  Single-target
-// models only (the K == 1 kernels keep one residual per sample), and the P <= 4 path only on the one-block shapes: on the
-// wider ones the ReLU kernels return a wrong loss or wrong weight gradients (tests/test_gpu_fuzz.py found it).  Which
-// kernels fail, and how, changes with compiler flags and with unrelated edits of the backward loop (tools/ps_relu_repro.py,
-// EH_DEBUG_PS_ALL=1), which points at the code generator rather than the source; the path stays where thousands of random
-// configurations verify it.
+// models only (the K == 1 kernels keep one residual per sample).  (Round 1 confined the P <= 4 path to the one-block shapes
+// because the wider ReLU kernels lost the loss sum; that was the SLP vectoriser -- see the Makefile -- and is gone with it.)
 static int fast_wanted(const EhArchInfo* A, int K, int P, int T, int mech) {
     if (!A->has_fast || T != 1 || K != 1 || mech == EH_MECH_PROGRAM) return 0;
-    static const bool debug_all = getenv("EH_DEBUG_PS_ALL") != nullptr;        // diagnostics: reproduce the confined bug
-    return 1 | ((P <= 4 && (A->nbh == 1 || debug_all)) ? 2 : 0);
+    return 1 | (P <= 4 ? 2 : 0);
 }
 
 struct MechInfo { int n_par, n_forc, n_out; };
@@ -1240,6 +1239,7 @@ int32_t eh_destroy(eh_handle* h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& e : h->jit) eh_jit_release(&e.k);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
@@ -2275,6 +2275,87 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return EH_OK;
+}
+
+// ---- the collective inside the library (RCCL) -------------------------------------------------------------------------
+#define NCCLCHK(h, expr)                                                                                     \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) return fail(h, EH_ERCCL, "%s: %s", #expr, ncclGetErrorString(r_));            \
+    } while (0)
+
+int32_t eh_comm_unique_id(void* id_out, int64_t id_bytes) {
+    if (!id_out || id_bytes < (int64_t)sizeof(ncclUniqueId)) return fail(nullptr, EH_EINVAL, "eh_comm_unique_id: buffer of %lld bytes, need %zu", (long long)id_bytes, sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    NCCLCHK(nullptr, ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return EH_OK;
+}
+
+int32_t eh_comm_init(eh_handle* h, const void* unique_id, int64_t id_bytes, int32_t world, int32_t rank) {
+    if (!h || !unique_id) return EH_EINVAL;
+    if (id_bytes < (int64_t)sizeof(ncclUniqueId)) return fail(h, EH_EINVAL, "eh_comm_init: id of %lld bytes, need %zu", (long long)id_bytes, sizeof(ncclUniqueId));
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_comm_init: world %d, rank %d", world, rank);
+    if (h->comm) return fail(h, EH_ESTATE, "eh_comm_init: the handle already has a communicator (eh_comm_destroy first)");
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    NCCLCHK(h, ncclCommInitRank(&h->comm, world, id, rank));
+    h->comm_world = world; h->comm_rank = rank;
+    return EH_OK;
+}
+
+int32_t eh_comm_destroy(eh_handle* h) {
+    if (!h) return EH_EINVAL;
+    if (!h->comm) return EH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    NCCLCHK(h, ncclCommDestroy(h->comm));
+    h->comm = nullptr; h->comm_world = 0;
+    return EH_OK;
+}
+
+int32_t eh_comm_group_begin(void) { NCCLCHK(nullptr, ncclGroupStart()); return EH_OK; }
+int32_t eh_comm_group_end(void) { NCCLCHK(nullptr, ncclGroupEnd()); return EH_OK; }
+
+int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
+    if (!h) return EH_EINVAL;
+    if (!h->comm) return fail(h, EH_ESTATE, "eh_dp_allreduce: call eh_comm_init first");
+    float* buf = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case EH_BUF_GRAD: buf = h->gradbuf; n = (size_t)h->n_acc; break;
+        case EH_BUF_GACC:
+            if (index < 0 || index > 2) return fail(h, EH_EINVAL, "eh_dp_allreduce: accumulator %d (0..2)", index);
+            if (h->p2p_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the step kernels exchange their sums themselves (eh_p2p_attach); nothing to reduce");
+            n = (size_t)EH_GSHARDS * h->n_acc; buf = h->gacc + (size_t)index * n; break;
+        case EH_BUF_BNSTAT:
+            if (!h->bn_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the model has no input BatchNorm");
+            buf = h->bn_stat; n = 65; break;
+        default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC or EH_BUF_BNSTAT)", which);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    NCCLCHK(h, ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, h->comm, h->stream));
+    return EH_OK;
+}
+
+int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out) {
+    if (!h) return EH_EINVAL;
+    if (!h->comm) return fail(h, EH_ESTATE, "eh_dp_train_step: call eh_comm_init first");
+    int rc;
+    if (h->bn_on) {
+        if ((rc = eh_dp_bn_stats(h, first, count))) return rc;
+        if ((rc = eh_dp_allreduce(h, EH_BUF_BNSTAT, 0))) return rc;
+    }
+    if (h->fused) {
+        if (loss_out) return fail(h, EH_EINVAL, "eh_dp_train_step: fused_update mode reports no per-step loss (pass NULL)");
+        int32_t k = 0;
+        if ((rc = eh_dp_fused_step(h, first, count, &k))) return rc;
+        return k >= 0 ? eh_dp_allreduce(h, EH_BUF_GACC, k) : EH_OK;
+    }
+    if ((rc = eh_dp_grad(h, first, count))) return rc;
+    if ((rc = eh_dp_allreduce(h, EH_BUF_GRAD, 0))) return rc;
+    return eh_dp_apply(h, loss_out);
 }
 
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {

@@ -14,13 +14,7 @@ struct Var {
     using Geom = EhGeom<EH_NBI, EH_NBH, EH_NL, NT, NW>;
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
-    // the P <= 4 kernels (FAST = 3) exist for the one-block shapes only; `make EXP=-DEH_PS_WIDE` builds them for the wider ones
-    // too, for tools/ps_relu_repro.py (see fast_wanted in eh_api.hip)
-#if EH_NBH == 1 || defined(EH_PS_WIDE)
-    static constexpr bool HASPS = true;
-#else
-    static constexpr bool HASPS = false;
-#endif
+    static constexpr bool HASPS = true;      // the P <= 4 kernels (FAST = 3) of every shape built with the fast paths
     // the cross-GPU (EH_MODE_TRAIN_P2P) kernels are built for the default variant of a shape only
 #ifdef EH_EXTRA_VARIANTS
     static constexpr bool HASP2P = NT == 2 && NW == 8;

@@ -341,7 +341,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
                       (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
         hiprtcAddNameExpression(hp, name[m]);
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17"};      // (the flags of the Makefile: see there for -fno-slp-vectorize)
     // ---- cached code object?
     std::string cpath;
     {
@@ -366,7 +366,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     bool from_cache = !cpath.empty() && cache_load(cpath, nmode, &lowered, &code);
     if (!from_cache) {
         lowered.clear();
-        const hiprtcResult rc = hiprtcCompileProgram(hp, 3, opts);
+        const hiprtcResult rc = hiprtcCompileProgram(hp, (int)(sizeof opts / sizeof opts[0]), opts);
         size_t ls = 0;
         hiprtcGetProgramLogSize(hp, &ls);
         if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(hp, &(*log)[0]); }

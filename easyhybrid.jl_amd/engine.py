@@ -302,6 +302,31 @@ class HybridEngine:
     def p2p_disable(self):
         self._chk(self._lib.eh_p2p_disable(self._h))
 
+    # -- the library's own RCCL communicator (include/easyhybrid_hip.h, eh_comm_*) ---------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the id of a new communicator, to be handed to every rank over any host channel"""
+        lib = L.lib()
+        buf = C.create_string_buffer(L.EH_COMM_ID_BYTES)
+        st = lib.eh_comm_unique_id(buf, L.EH_COMM_ID_BYTES)
+        if st != L.EH_OK:
+            _raise(st, lib.eh_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, world: int, rank: int):
+        self._chk(self._lib.eh_comm_init(self._h, C.c_char_p(unique_id), len(unique_id), world, rank))
+
+    def comm_destroy(self):
+        self._chk(self._lib.eh_comm_destroy(self._h))
+
+    def dp_allreduce(self, which: int, index: int = 0):
+        self._chk(self._lib.eh_dp_allreduce(self._h, which, index))
+
+    def dp_train_step(self, first: int, count: int, want_loss: bool = False):
+        loss = C.c_float()
+        self._chk(self._lib.eh_dp_train_step(self._h, first, count, C.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
     def device_buffer(self, which: int):
         p = C.c_void_p()
         n = C.c_int64()

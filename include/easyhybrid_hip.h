@@ -49,7 +49,8 @@ typedef enum eh_status {
     EH_EHIP = -2,          /* HIP runtime error or no device */
     EH_ENOMEM = -3,
     EH_EUNSUPPORTED = -4,  /* unknown mechanistic model / activation / shape outside the compiled kernels */
-    EH_ESTATE = -5         /* call order (e.g. train step before eh_opt_init / eh_set_data) */
+    EH_ESTATE = -5,        /* call order (e.g. train step before eh_opt_init / eh_set_data) */
+    EH_ERCCL = -6          /* an RCCL call of the eh_comm_* / eh_dp_allreduce family failed */
 } eh_status;
 
 /* activation of the hidden Dense layers (src/models/NNModels.jl:225-230; last layer is linear) */
@@ -302,6 +303,26 @@ int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on);
 int32_t eh_set_bn_shift(eh_handle* h, const float* shift, int64_t n);
 int32_t eh_dp_bn_stats(eh_handle* h, int64_t first, int64_t count);
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats);
+
+/* The collective inside the library (RCCL over xGMI): a host that has no collective library of its own --
+ * the Julia shim, or ONE process driving all GPUs of a node with one handle per device -- gets the all-reduce of the seam
+ * above from the library itself, in stream order on the handle's stream:
+ *   eh_comm_unique_id : rank 0 draws the 128-byte id of a new communicator; the host hands it to every rank (any channel)
+ *   eh_comm_init      : ncclCommInitRank on the handle's device; world = number of handles in the job, rank = this one's
+ *   eh_dp_allreduce   : SUM all-reduce, in place, of EH_BUF_GRAD (after eh_dp_grad), of the third `index` of EH_BUF_GACC
+ *                       (*buffer_index of eh_dp_fused_step) or of EH_BUF_BNSTAT (after eh_dp_bn_stats)
+ *   eh_dp_train_step  : the whole data-parallel step of one rank: [eh_dp_bn_stats + all-reduce] + eh_dp_grad + all-reduce +
+ *                       eh_dp_apply, or eh_dp_fused_step + all-reduce in fused_update mode (loss_out then must be NULL)
+ * A single thread that drives several handles must bracket the calls of one step over all its handles with
+ * eh_comm_group_begin / eh_comm_group_end (ncclGroupStart / ncclGroupEnd), as RCCL requires; eh_comm_init likewise. */
+#define EH_COMM_ID_BYTES 128
+int32_t eh_comm_unique_id(void* id_out, int64_t id_bytes);
+int32_t eh_comm_init(eh_handle* h, const void* unique_id, int64_t id_bytes, int32_t world, int32_t rank);
+int32_t eh_comm_destroy(eh_handle* h);
+int32_t eh_comm_group_begin(void);
+int32_t eh_comm_group_end(void);
+int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index);
+int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out);
 
 /* One-kernel-per-step variant of the data-parallel seam (needs eh_set_option("fused_update", 1)):
  * eh_dp_fused_step launches the fused step kernel, whose prologue applies the (already all-reduced)

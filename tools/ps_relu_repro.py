@@ -1,7 +1,12 @@
-"""Diagnostics for the P <= 4 weight-gradient path (FAST bit 1) on shapes wider than one block, where the fuzz once found wrong
-ReLU gradients: a library from tools/ps_variants.sh (built with -DEH_PS_WIDE; the normal build has no such kernels), then
-EH_DEBUG_PS_ALL=1 EASYHYBRID_HIP_LIB=dbg/lib_<name>.so python tools/ps_relu_repro.py   (never part of the test suite)
-Per case: loss and gradient error against the oracle, per parameter block, for fast_paths = 3 (K1 | PS) and 1 (K1 only)."""
+"""The P <= 4 weight-gradient path (FAST bit 1) on shapes wider than one block, against the oracle per parameter block, for
+fast_paths = 3 (K1 | PS) and 1 (K1 only).  Round 1's fuzz found ReLU kernels of the 64-wide three-layer shape whose loss sum came
+out as exactly 0 (gradients right); round 2 traced it to the SLP vectoriser (-O3 packs the loss sum and the valid count into one
+<2 x float> accumulator): the normal build now carries -fno-slp-vectorize and passes.  To see the failure again build the two
+translation units with the vectoriser on and point the loader at that library:
+    tools/ps_variants.sh slp "-fslp-vectorize"
+    EASYHYBRID_HIP_LIB=dbg/lib_slp.so python tools/ps_relu_repro.py        (never part of the test suite)
+tools/ps_probe.py prints the raw batch sums [S, n, Sy, Syy] of the same kernels, tools/ps_probe2.py (variant built with
+-DEH_DBG_LACC) the per-wave loss accumulators -- with that extra store the miscompile disappears as well."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

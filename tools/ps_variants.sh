@@ -11,11 +11,11 @@ while [ $# -ge 2 ]; do
   out=$ROOT/dbg/$name; mkdir -p $out
   for s in 1_4_2 1_4_3; do
     IFS=_ read a b c <<< "$s"
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS -DEH_NBI=$a -DEH_NBH=$b -DEH_NL=$c -DEH_FAST_PATHS -DEH_PS_WIDE $flags \
+    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS -DEH_NBI=$a -DEH_NBH=$b -DEH_NL=$c -DEH_FAST_PATHS $flags \
         -c $CS/eh_arch.hip -o $out/eh_arch_$s.o ) &
   done
   wait
   objs=$(ls $CS/build/*.o | grep -v -e eh_arch_1_4_2.o -e eh_arch_1_4_3.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/dbg/lib_$name.so $objs $out/eh_arch_1_4_2.o $out/eh_arch_1_4_3.o -L/opt/rocm/lib -lhiprtc -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/dbg/lib_$name.so $objs $out/eh_arch_1_4_2.o $out/eh_arch_1_4_3.o -L/opt/rocm/lib -lhiprtc -lrccl -Wl,-rpath,/opt/rocm/lib
   echo built dbg/lib_$name.so
 done
