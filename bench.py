@@ -249,7 +249,9 @@ def main():
                        "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}",
                        "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
                                              else "one RCCL all-reduce per step"),
-                       "gradient_exchange_calibration_us_per_step": exchange_cal, "step_kernel": built},
+                       "gradient_exchange_calibration_us_per_step": exchange_cal, "step_kernel": built,
+                       "step_mode": "one kernel per step (fused_update) on the run-time specialised kernel: what train() runs by default "
+                                    "(TrainConfig.fused_update = specialize = 'auto')" if dp is None and not args.no_specialize else "see step_kernel / gradient_exchange"},
             "roofline": roof,
         }
         out["dataset_upload_ms_once"] = 1e3 * t_up

@@ -6,12 +6,15 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "eh_arch.hpp"
@@ -684,8 +687,10 @@ struct eh_handle_s {
     int fast_user = 3;              // what the fast_paths option allows (default: all)
     unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
     // EH_MECH_PROGRAM: kernels compiled at run time around the program (eh_jit.hpp), one entry per (kernel family, variant) used
-    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; bool ok; EhJitKernel k; };
-    std::vector<JitEntry> jit;
+    // state: 0 = being compiled by `worker` ("specialize" = 2: the steps run the kernels built ahead of time meanwhile), 1 = ready, -1 = failed
+    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; std::atomic<int> state{0}; EhJitKernel k; std::thread worker; std::string log; };
+    std::vector<std::unique_ptr<JitEntry>> jit;
+    bool specialize_async = false;  // "specialize" = 2
     bool jit_on = true;             // "jit" option / EH_JIT=0: 0 = the interpreting kernels built ahead of time
     bool jit_failed = false;
     bool specialize = false;        // "specialize" option: every model gets kernels compiled around its descriptor
@@ -913,14 +918,33 @@ static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
     const bool spec = h->specialize || prog || closs || h->act == EH_ACT_PER_NET;        // a model that is compiled anyway gets its descriptor baked in as well
     const bool want_p2p = h->specialize && h->p2p_on && !closs && !prog;
     const int lgen = closs ? h->loss_prog.gen : 0;
-    for (auto& e : h->jit)
+    for (auto& up : h->jit) {
+        eh_handle_s::JitEntry& e = *up;
         if (e.arch == h->arch && e.variant == h->variant && e.fast == kf && e.spec == spec && (e.p2p || !want_p2p) && e.loss_gen == lgen &&
-            (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) return e.ok ? &e : nullptr;
-    h->jit.push_back({h->arch, h->variant, kf, spec, want_p2p, h->net, lgen, false, EhJitKernel{}});
-    eh_handle_s::JitEntry* je = &h->jit.back();
-    std::string log;
-    je->ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, spec ? &h->net : nullptr, want_p2p, closs ? &h->loss_prog : nullptr, &je->k, &log);
-    if (!je->ok) { h->jit_log = log; h->jit_failed = true; return nullptr; }
+            (!e.spec || !memcmp(&e.net, &h->net, sizeof(EhNet)))) {
+            const int st = e.state.load(std::memory_order_acquire);
+            if (st < 0 && !h->jit_failed) { h->jit_log = e.log; h->jit_failed = true; }       // (a background build that failed: reported like a synchronous one)
+            return st > 0 ? &e : nullptr;
+        }
+    }
+    h->jit.emplace_back(new eh_handle_s::JitEntry());
+    eh_handle_s::JitEntry* je = h->jit.back().get();
+    je->arch = h->arch; je->variant = h->variant; je->fast = kf; je->spec = spec; je->p2p = want_p2p; je->net = h->net; je->loss_gen = lgen;
+    // Only a kernel that merely REPLACES one built ahead of time may arrive later; a recorded closure / loss / per-net activation has no other form
+    const bool async = h->specialize_async && !prog && !closs && h->act != EH_ACT_PER_NET && !want_p2p && !h->capturing;
+    if (async) {
+        const eh_model_desc desc = h->desc;
+        const int act = h->act, device = h->device;
+        je->worker = std::thread([je, desc, act, device]() {
+            (void)hipSetDevice(device);
+            const bool ok = eh_jit_build(desc, je->arch, je->variant, act, je->fast, &je->net, false, nullptr, &je->k, &je->log);
+            je->state.store(ok ? 1 : -1, std::memory_order_release);
+        });
+        return nullptr;
+    }
+    const bool ok = eh_jit_build(h->desc, h->arch, h->variant, h->act, kf, spec ? &h->net : nullptr, want_p2p, closs ? &h->loss_prog : nullptr, &je->k, &je->log);
+    je->state.store(ok ? 1 : -1, std::memory_order_release);
+    if (!ok) { h->jit_log = je->log; h->jit_failed = true; return nullptr; }
     return je;
 }
 static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
@@ -929,7 +953,7 @@ static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs
             const hipError_t e = eh_jit_launch(&je->k, mode, grid, h->stream, &h->net, a);
             if (e == hipSuccess) return e;
             (void)hipGetLastError();
-            je->ok = false; h->jit_failed = true;
+            je->state.store(-1); h->jit_failed = true;
             h->jit_log = std::string("launch of the run-time compiled kernel failed: ") + hipGetErrorString(e);
         }
         if (h->net.loss == EH_LOSS_PROGRAM && mode != EH_MODE_EVAL) return hipErrorNotSupported;     // no other form of a recorded loss exists
@@ -1238,7 +1262,7 @@ int32_t eh_destroy(eh_handle* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (auto& e : h->jit) eh_jit_release(&e.k);
+    for (auto& e : h->jit) { if (e->worker.joinable()) e->worker.join(); eh_jit_release(&e->k); }
     if (h->comm) (void)ncclCommDestroy(h->comm);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
@@ -1309,7 +1333,7 @@ int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr,
 int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes) {
     if (!h || !n_compiled) return EH_EINVAL;
     int n = 0;
-    for (auto& e : h->jit) n += e.ok ? 1 : 0;
+    for (auto& e : h->jit) n += e->state.load(std::memory_order_acquire) > 0 ? 1 : 0;
     *n_compiled = n;
     if (log && log_bytes > 0) {
         const size_t m = std::min((size_t)log_bytes - 1, h->jit_log.size());
@@ -1364,8 +1388,9 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->jit_on = value != 0;
         return EH_OK;
     }
-    if (!strcmp(name, "specialize")) {       // 1 = step kernels compiled at run time with the model descriptor as a compile-time constant
-        h->specialize = value != 0;
+    if (!strcmp(name, "specialize")) {       // 1 = step kernels compiled at run time with the model descriptor as a compile-time constant;
+        h->specialize = value != 0;          // 2 = the same in a background thread: steps run the kernels built ahead of time until the
+        h->specialize_async = value == 2;    //     compiled one is ready (~1 s, or a disk-cache hit), then switch -- same arithmetic, same results
         return EH_OK;
     }
     if (!strcmp(name, "row_split")) {        // A/B: the row-split kernel family (eh_wide.hpp) where both are built

@@ -111,9 +111,18 @@ class TrainConfig:
     # not in the reference (it has no multi-GPU path): None = data parallel iff torch.distributed is initialised with
     # more than one rank; True / False force it.  `batchsize` stays the GLOBAL minibatch, split evenly over the ranks.
     distributed: Optional[bool] = None
-    # not in the reference: step kernels compiled at run time (hiprtc, about a second) with this model's descriptor as a
-    # compile-time constant -- about 20 % faster small-model steps; pays off for long runs
-    specialize: bool = False
+    # not in the reference -- how the device runs the step (DESIGN.md sections 3.8 and 6):
+    #   specialize   "auto" (default): step kernels compiled at run time (hiprtc) with this model's descriptor as a compile-time
+    #                constant, in a background thread -- training starts on the kernels built ahead of time and switches when the
+    #                compiled one is ready (about a second; instant from the disk cache).  True: compile before the first step.
+    #                False: only the kernels built ahead of time.
+    #   fused_update "auto" (default): one kernel per step where the model allows it (single target, per-wave kernel family, no
+    #                weight_l2 / moment-based loss) -- the optimiser update of a step runs in the prologue of the next one and the
+    #                partial sums meet through float atomics, so results are reproducible to ~1e-7, not bitwise.  False: the
+    #                deterministic step kernel + reduce/optimiser kernel pair.  True: insist (raises where it is not built).
+    # Both defaults are what bench.py measures.
+    specialize: Any = "auto"
+    fused_update: Any = "auto"
 
 
 @dataclass
@@ -123,6 +132,19 @@ class DataConfig:
     split_data_at: float = 0.8
     folds: Any = None
     val_fold: Optional[int] = None
+
+
+def _apply_step_mode(eng, tc: "TrainConfig"):
+    """TrainConfig.specialize / fused_update -> engine options (single-GPU training)"""
+    if tc.fused_update not in (True, False, "auto") or tc.specialize not in (True, False, "auto"):
+        raise ValueError("specialize / fused_update must be True, False or 'auto'")
+    if tc.fused_update is not False:
+        try:
+            eng.set_option("fused_update", 1)
+        except (NotImplementedError, RuntimeError):
+            if tc.fused_update is True:
+                raise
+    eng.set_option("specialize", 2 if tc.specialize == "auto" else int(bool(tc.specialize)))
 
 
 def validate_config(cfg: TrainConfig):                           # TrainingConfig.jl:162-185
@@ -317,7 +339,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.set_params(theta); ev.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
-        drv = DataParallel(eng, specialize=tc.specialize)
+        drv = DataParallel(eng, fused=tc.fused_update is not False, specialize=bool(tc.specialize))      # ("auto" compiles before the first step here: every rank has to be ready together)
         has_bn = bool(model.config.get("input_batchnorm"))
         first_lt = tc.loss_types[0]
 
@@ -414,8 +436,7 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         eng.set_training_loss(tc.training_loss)
         if tc.extra_loss is not None:
             eng.set_weight_l2(tc.extra_loss.lam, tc.extra_loss.normalize)
-        if tc.specialize:
-            eng.set_option("specialize", 1)
+        _apply_step_mode(eng, tc)
         first_lt = tc.loss_types[0]
 
         def snapshot():

@@ -365,7 +365,11 @@ int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
 /* tuning knobs (name/value): "max_blocks" (1..256), "variant" (tile shape), "fast_paths" (0 = generic MFMA kernels), "training_loss" (eh_loss),
  * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible), "row_split" (kernel family),
  * "jit" (EH_MECH_PROGRAM: 1 = step kernels compiled at run time around the recorded closure (default; also env EH_JIT),
- * 0 = the interpreting kernels built ahead of time) */
+ * 0 = the interpreting kernels built ahead of time),
+ * "specialize" (1 = every model's step kernels compiled at run time (hiprtc, ~1 s, cached on disk) with the descriptor as a compile-time
+ * constant; 2 = the same in a background thread -- steps run the kernels built ahead of time until the compiled one is ready),
+ * "precision" (0 = fp32 end to end, the reference's arithmetic; 1 = bf16 forward products with fp32 accumulation and an fp32-exact
+ * backward pass, BASELINE.json config 5 -- row-split shapes with tanh / sigmoid / relu / identity only) */
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
 
 /* A custom training loss `training_loss::Function` (src/losses/loss_fn.jl: called as f(yhat[mask], y[mask])) of the form
