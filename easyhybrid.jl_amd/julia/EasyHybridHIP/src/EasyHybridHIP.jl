@@ -12,8 +12,10 @@
 module EasyHybridHIP
 
 using Libdl
+using Random
 
-export constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, RbQ10, Expo_resp_model,
+export constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
+    Adam, AdamW, RMSProp, Descent, RbQ10, Expo_resp_model,
     LinearHM, Expo2Pool, Rs_components, Rs_components3F, FluxPartModelQ10
 
 const LIB = Ref{String}(get(ENV, "EASYHYBRID_HIP_LIB", joinpath(@__DIR__, "..", "..", "..", "libeasyhybrid_hip.so")))
@@ -541,6 +543,126 @@ function train(m::SingleNNHybridModel, train_data, val_data; θ0::Vector{Float32
     e = HybridEngine(m; device)
     set_params!(e, θ0)
     return train!(e, train_data, val_data; kwargs...)
+end
+
+# ------------------------------------------------------------------------------------------------
+# the reference's front door: train(model, data; kwargs...)  (src/training/train.jl:211-219)
+# ------------------------------------------------------------------------------------------------
+"Optimisers.jl-style rules the device implements (EasyHybrid.jl:59 re-exports the originals; pass those or these)"
+struct Adam; eta::Float32; beta::Tuple{Float32, Float32}; epsilon::Float32; end
+Adam(eta = 0.001f0, beta = (0.9f0, 0.999f0)) = Adam(eta, beta, 1.0f-8)
+struct AdamW; eta::Float32; beta::Tuple{Float32, Float32}; lambda::Float32; epsilon::Float32; end
+AdamW(eta = 0.001f0, beta = (0.9f0, 0.999f0), lambda = 0.0f0) = AdamW(eta, beta, lambda, 1.0f-8)
+struct RMSProp; eta::Float32; rho::Float32; epsilon::Float32; end
+RMSProp(eta = 0.001f0, rho = 0.9f0) = RMSProp(eta, rho, 1.0f-8)
+struct Descent; eta::Float32; end
+# (duck-typed on the field names, so Optimisers.Adam(0.01) etc. work as well)
+function _opt_args(o)
+    n = nameof(typeof(o))
+    n == :Adam && return (; rule = 0, eta = Float32(o.eta), beta = Float32.(o.beta), epsilon = Float32(o.epsilon), lambda = 0.0f0)
+    n == :AdamW && return (; rule = 1, eta = Float32(o.eta), beta = Float32.(o.beta), epsilon = Float32(o.epsilon), lambda = Float32(o.lambda))
+    n == :RMSProp && return (; rule = 2, eta = Float32(o.eta), beta = (Float32(o.rho), 0.0f0), epsilon = Float32(o.epsilon), lambda = 0.0f0)
+    n == :Descent && return (; rule = 3, eta = Float32(o.eta), beta = (0.0f0, 0.0f0), epsilon = 0.0f0, lambda = 0.0f0)
+    throw(ArgumentError("optimiser $(typeof(o)): the device runs Adam / AdamW / RMSProp / Descent"))
+end
+
+_col(data, n::Symbol) = Float32.(collect(data isa AbstractDict ? data[n] : getproperty(data, n)))   # NamedTuple / Dict of columns, DataFrame, ...
+
+"""
+    prepare_data(model, data) -> ((X, forcings), targets)
+
+`src/data/prepare_data.jl:6-60`: the columns the model names, as Float32 -- predictors as a (P x N) matrix, forcings and targets
+as NamedTuples of vectors; rows with a missing (NaN) predictor or forcing are dropped, missing targets stay NaN (they become the
+mask, `src/training/train.jl:221-232`).
+"""
+function prepare_data(m::SingleNNHybridModel, data)
+    X = permutedims(reduce(hcat, [_col(data, p) for p in m.predictors]))
+    F = [_col(data, f) for f in m.forcing]; Y = [_col(data, t) for t in m.targets]
+    keep = vec(.!any(isnan, X; dims = 1))
+    for f in F; keep .&= .!isnan.(f); end
+    return (Matrix{Float32}(X[:, keep]), NamedTuple{Tuple(m.forcing)}(Tuple(f[keep] for f in F))), NamedTuple{Tuple(m.targets)}(Tuple(y[keep] for y in Y))
+end
+
+"`src/data/split_data.jl:74-78` (the default branch): `splitobs(1:n; at = split_data_at, shuffle = shuffleobs)`"
+function split_data(m::SingleNNHybridModel, data; split_data_at::Real = 0.8, shuffleobs::Bool = false, rng = Random.default_rng())
+    (X, F), Y = prepare_data(m, data)
+    n = size(X, 2)
+    idx = shuffleobs ? Random.randperm(rng, n) : collect(1:n)
+    ntr = round(Int, split_data_at * n)
+    pick(ix) = ((X[:, ix], map(v -> v[ix], F)), map(v -> v[ix], Y))
+    return pick(idx[1:ntr]), pick(idx[(ntr + 1):end])
+end
+
+"""
+    initialparameters(rng, model) -> Vector{Float32}
+
+Flat θ in the reference's ComponentArray order (`GenericHybridModel.jl:236-256`): per Dense layer the weight (column-major
+`(out, in)`: `kaiming_uniform` with the activation's gain, Lux ≥ 1.0) and bias (`U(±1/√fan_in)`), then every global
+parameter's raw value from its default (`start_from_default`, `:244-249`).  Julia's own RNG stream: not the reference's values.
+"""
+function initialparameters(rng, m::SingleNNHybridModel)
+    act = get(m.config, :activation, :tanh)                  # (the constructor keeps the activation's name)
+    gain = act === :tanh ? 5.0f0 / 3 : (act === :relu ? sqrt(2.0f0) : 1.0f0)
+    θ = Float32[]
+    for (li, (o, i)) in enumerate(m.NN)
+        bw = (li < length(m.NN) ? gain : 1.0f0) * sqrt(3.0f0 / i)
+        append!(θ, (2 .* rand(rng, Float32, o * i) .- 1) .* bw)
+        append!(θ, (2 .* rand(rng, Float32, o) .- 1) ./ sqrt(Float32(i)))
+    end
+    for g in m.global_param_names
+        d, lo, hi = m.parameters[g]
+        push!(θ, m.start_from_default ? log((d - lo) / (hi - lo) / (1 - (d - lo) / (hi - lo))) : rand(rng, Float32))   # scale_single_param_minmax, :361-365
+    end
+    return θ
+end
+
+"""
+    train(model, data; nepochs = 200, batchsize = 64, opt = Adam(0.01), patience, loss_types = [:mse, :r2],
+          training_loss = :mse, random_seed = 161803, return_model = :best, split_data_at = 0.8, shuffleobs = false,
+          train_from = nothing, device = 0)
+
+The reference's `train(model, data; kwargs...)` (`src/training/train.jl:211-219` → `_train`, `:95-136`): prepare and split the
+table, initial parameters, then per epoch one `run_epoch!` (`eh_train_epoch`: every minibatch of the shuffled train split on the
+device) and one `evaluate_epoch` (`eh_eval` on both splits), early stopping on the first `loss_types` entry.  Returns the fields
+of `TrainResults` the device path produces: `(; train_history, val_history, train_obs_pred, val_obs_pred, ps, st, best_epoch,
+best_loss)`.  `data`: a DataFrame or a NamedTuple / Dict of equally long columns.
+"""
+function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt = Adam(0.01f0), patience = typemax(Int),
+        loss_types = [:mse, :r2], training_loss = :mse, random_seed = 161803, return_model = :best, split_data_at = 0.8,
+        shuffleobs = false, train_from = nothing, device = 0)
+    nepochs >= 0 || throw(ArgumentError("nepochs must be >= 0"))                               # validate_config, TrainingConfig.jl:162-180
+    batchsize >= 1 || throw(ArgumentError("batchsize must be >= 1"))
+    training_loss == :mse || throw(ArgumentError("this shim drives training_loss = :mse (the library's other losses: eh_set_option \"training_loss\")"))
+    rng = random_seed === nothing ? Random.default_rng() : Random.Xoshiro(random_seed)
+    tr, va = split_data(m, data; split_data_at, shuffleobs, rng)
+    size(tr[1][1], 2) == 0 && return nothing                                                    # train.jl:186
+    e = HybridEngine(m; device)
+    set_params!(e, train_from === nothing ? initialparameters(rng, m) : Float32.(train_from))
+    o = _opt_args(opt)
+    ((xt, ft), yt), ((xv, fv), yv) = tr, va
+    set_data!(e, EH_SPLIT_TRAIN, xt, ft, yt); set_data!(e, EH_SPLIT_VAL, xv, fv, yv)
+    opt_init!(e; rule = o.rule, eta = o.eta, beta = o.beta, epsilon = o.epsilon, lambda = o.lambda)
+    nt, nv = size(xt, 2), size(xv, 2)
+    hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types)]
+    best_loss = hist_v[1][1].sum; best_ps = get_params(e); best_epoch = 0; counter = 0
+    better = first(loss_types) in (:pearson, :r2, :nse, :kge) ? (>) : (<)                       # loss_fn.jl:181-194
+    seed0 = random_seed === nothing ? rand(rng, UInt32) : random_seed
+    for epoch in 1:nepochs
+        train_epoch!(e, batchsize; seed = seed0 + epoch, shuffle = true)
+        push!(hist_t, evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)); push!(hist_v, evaluate(e, EH_SPLIT_VAL, nv; loss_types))
+        cur = hist_v[end][1].sum
+        if better(cur, best_loss)
+            best_loss, best_ps, best_epoch, counter = cur, get_params(e), epoch, 0              # early_stopping.jl:16-42
+        else
+            counter += 1
+        end
+        counter >= patience && break
+    end
+    return_model == :best && set_params!(e, best_ps)                                            # best_or_final
+    obs_pred(split, y, n) = n == 0 ? (;) : merge(y, NamedTuple{Tuple(Symbol(t, :_pred) for t in m.targets)}(Tuple(values(forward(e, split, n)))))
+    st = (; fixed = NamedTuple{Tuple(m.fixed_param_names)}(Tuple(Float32(m.parameters[f][1]) for f in m.fixed_param_names)))
+    return (; train_history = hist_t, val_history = hist_v, train_obs_pred = obs_pred(EH_SPLIT_TRAIN, yt, nt),
+            val_obs_pred = obs_pred(EH_SPLIT_VAL, yv, nv), ps = get_params(e), st, best_epoch, best_loss)
 end
 
 end # module

@@ -373,6 +373,33 @@ def test_dp_seam_virtual_shards_equal_single_step():
     ref.close(); eng.close()
 
 
+def test_config4_size_eight_virtual_shards_of_65536():
+    """BASELINE.json configs[3]: RbQ10, global batch 524 288 = 8 shards x 65 536 (one per GPU there; eight "ranks" on the one GPU
+    here, the sum of their raw partial vectors standing in for the RCCL all-reduce).  Five steps; the replica must land where a
+    single engine training on the whole 524 288-sample batches lands, and the loss is the mean over the GLOBAL valid count."""
+    import torch
+    W, b, steps = 8, 65536, 5
+    spec, theta, X, f, y = util.rbq10_case(W * b * 2, "tanh", True, 0.05)      # two distinct global batches, visited alternately
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    ptr, n = eng.device_buffer(eh._lib.EH_BUF_GRAD)
+    buf = torch.as_tensor(eh.dp._DevArray(ptr, n), device="cuda")
+    for s_ in range(steps):
+        g0 = (s_ % 2) * W * b
+        l_ref = ref.train_step(g0, W * b)
+        acc = torch.zeros_like(buf)
+        for k in range(W):
+            eng.dp_grad(g0 + k * b, b)
+            eng.synchronize()
+            acc += buf
+        buf.copy_(acc)
+        torch.cuda.synchronize()
+        l = eng.dp_apply(want_loss=True)
+        assert l == pytest.approx(l_ref, rel=2e-6)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 5e-6
+    ref.close(); eng.close()
+
+
 def test_dp_seam_and_front_door_with_per_network_activations_and_depths():
     """the reference's MultiNN constructor case (hidden_layers = (a = [16, 8], d = [8]), activation = (a = tanh, d = sigmoid),
     test/test_generic_hybrid_model.jl:346-347) through the data-parallel seam and through `train`: kernels compiled at run time"""
