@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 4, 8, 4, 4, 8
+EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG, EH_MAX_NETS = 8, 8, 4, 4, 8
 EH_MAX_PROG, EH_MAX_PROG_CONST, EH_MAX_PROG_OUT = 64, 16, 3
 EH_MECH_PROGRAM = 6
 EH_LOSS_PROGRAM = 7

@@ -3,7 +3,8 @@
 // permutation, record packing.  Everything here runs on one HIP stream per handle; there is no CPU
 // compute path.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types only: the library is bound at run time, by the first eh_comm_* call (see EhRccl)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -20,6 +21,7 @@
 #include "eh_arch.hpp"
 #include "eh_jit.hpp"
 #include "eh_wide.hpp"
+#include "eh_lform.hpp"
 
 // --------------------------------------------------------------------------------------------
 // small kernels
@@ -35,15 +37,16 @@ struct EhImg {
     // the Dense weight matrices are the canonical entries whose image offset lies below the bias block
     float l2c;
     int b_off;
+    const unsigned char* wflag;   // layer-wise form (no image, imap == nullptr): 1 at the canonical positions of Dense weights
 };
-__device__ __forceinline__ bool eh_is_weight(const EhImg& im, int idx) { return idx < im.g_off && im.imap[idx] < im.b_off; }
+__device__ __forceinline__ bool eh_is_weight(const EhImg& im, int idx) { return idx < im.g_off && (im.imap ? im.imap[idx] < im.b_off : im.wflag[idx] != 0); }
 
 // l2c * sum of squared Dense weights of the CURRENT parameters (before the optimiser kernel touches them)
 __global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, EhImg im, float* out) {
     __shared__ float red[4];
     float s = 0.0f;
     for (int i = threadIdx.x; i < im.g_off; i += 256)
-        if (im.imap[i] < im.b_off) { const float w = theta[i]; s += w * w; }
+        if (eh_is_weight(im, i)) { const float w = theta[i]; s += w * w; }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, E
 
 __device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float th) {
     if (idx < im.g_off) {
-        im.image[im.imap[idx]] = th;
+        if (im.imap) im.image[im.imap[idx]] = th;      // (layer-wise form: the kernels read the canonical theta itself)
     } else {   // raw global -> physical value and sigmoid slope (GenericHybridModel.jl:348-352)
         const int g = idx - im.g_off, j = im.glob_par[g];
         const float s = 1.0f / (1.0f + expf(-th));
@@ -675,6 +678,14 @@ struct eh_handle_s {
     bool bn_ext = false;            // bn_stat holds the statistics of the step about to run
     bool bn_dp_update = false;
     bool opt_ready = false;
+    // layer-wise execution form (eh_lform.hpp): networks no fused kernel holds
+    bool lform = false;
+    int l_nl = 0;                                        // Dense layers (hidden + output)
+    int l_in[EH_MAX_HIDDEN + 1] = {0}, l_out[EH_MAX_HIDDEN + 1] = {0}, l_woff[EH_MAX_HIDDEN + 1] = {0}, l_boff[EH_MAX_HIDDEN + 1] = {0};
+    float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
+    long long l_cap = 0;                                 // samples the workspace holds
+    unsigned char* wflag = nullptr;
+    int slab_rows = 256;
     ncclComm_t comm = nullptr;      // eh_comm_init: the library's own RCCL communicator (data parallelism without a host-side collective library)
     int comm_world = 0, comm_rank = 0;
     EhOpt opt{};
@@ -733,6 +744,42 @@ static int fail(eh_handle* h, int code, const char* fmt, ...) {
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) return fail(h, e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// RCCL is bound with dlopen by the first eh_comm_* call, not linked: a process that never asks for the library's own communicator
+// (every single-GPU user; a host that brings its own collective, like the torch.distributed harness) loads neither RCCL nor
+// the rocm_smi it drags in -- whose static destructors were seen to abort at exit -- and a host that already has an RCCL in the
+// process (torch bundles one) shares that copy instead of getting a second one.
+struct EhRccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)(void) = nullptr;
+    ncclResult_t (*GroupEnd)(void) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static EhRccl g_rccl;
+static bool rccl_bind(std::string* why) {
+    if (g_rccl.so) return true;
+    void* so = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((so = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!so) { *why = std::string("librccl not found: ") + dlerror(); return false; }
+    EhRccl r;
+    r.so = so;
+#define EH_SYM(field, sym) *(void**)(&r.field) = dlsym(so, sym); if (!r.field) { *why = std::string("librccl lacks ") + sym; return false; }
+    EH_SYM(GetUniqueId, "ncclGetUniqueId") EH_SYM(CommInitRank, "ncclCommInitRank") EH_SYM(CommDestroy, "ncclCommDestroy")
+    EH_SYM(AllReduce, "ncclAllReduce") EH_SYM(GroupStart, "ncclGroupStart") EH_SYM(GroupEnd, "ncclGroupEnd") EH_SYM(GetErrorString, "ncclGetErrorString")
+#undef EH_SYM
+    g_rccl = r;                      // (never unloaded)
+    return true;
+}
+#define RCCL_BIND(h)                                                                           \
+    do {                                                                                       \
+        std::string why_;                                                                      \
+        if (!rccl_bind(&why_)) return fail(h, EH_ERCCL, "RCCL: %s", why_.c_str());             \
     } while (0)
 
 // ---- fused-update mode: apply the pending gradient so theta / m / v / image are current -----------
@@ -895,6 +942,13 @@ static const EhArchInfo* find_wide(int nbi, int nbh, int nl) {
 #undef EH_ARCH_TRY
     return nullptr;
 }
+// The "shape" of a model that runs layer by layer (eh_lform.hpp): no fused kernel, no parameter image beyond the EH_IMG_* block
+static hipError_t lform_prepare(void) { return hipSuccess; }
+static hipError_t lform_launch(int, int, int, int, hipStream_t, const EhNet*, const EhStepArgs*) { return hipErrorNotSupported; }
+static const EhArchInfo g_lform_arch = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, /*phi_off*/ 0, /*img_floats*/ EH_IMG_META, /*has_fast*/ 0, /*nvar*/ 1,
+                                        {{4, 4, 0, 1 << 30, &lform_prepare, &lform_launch, 1, 0}, {}, {}, {}}, /*wide*/ 1};
+enum { EH_LFORM_ROWS = 32 };      // partial slabs of the weight gradients (split over the samples of a minibatch)
+
 static bool arch_fits(const EhArchInfo* A, int need) {
     for (int vi = 0; vi < A->nvar; ++vi)
         if ((long long)A->var[vi].nw * need > A->var[vi].red_floats) return false;
@@ -1082,9 +1136,17 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     const EhArchInfo* arch = (nbh && K <= 16) ? find_arch(nbi, nbh, d->n_hidden) : nullptr;
     const EhArchInfo* const wide_arch = (nbh && K <= 16) ? find_wide(nbi, nbh, d->n_hidden) : nullptr;
     if (!arch) arch = wide_arch;
-    if (!arch)
-        return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no compiled kernel for P=%d, hidden max width %d%s, %d hidden layers, K=%d (built: P<=32, K<=16, width<=64 with <=3 layers or width<=128 with <=2)",
-                    d->n_predictors, maxw, d->n_nets > 0 ? " (nets side by side)" : "", d->n_hidden, K);
+    bool lform = false;
+    if (!arch) {
+        // no fused kernel holds this network: run it layer by layer (eh_lform.hpp) where that form is built
+        const bool act_ok = act == EH_ACT_TANH || act == EH_ACT_SIGMOID || act == EH_ACT_RELU || act == EH_ACT_IDENTITY;
+        if (d->n_nets > 0 || !act_ok || K > 16 || (d->input_batchnorm && d->n_predictors > 32))
+            return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no kernel for P=%d, hidden max width %d%s, %d hidden layers, K=%d, activation %d (fused kernels: P<=32, K<=16, "
+                        "width<=64 with <=3 layers or width<=128 with <=2; layer-wise form: one network (SingleNN), tanh / sigmoid / relu / identity, K<=16, "
+                        "input BatchNorm with P<=32)", d->n_predictors, maxw, d->n_nets > 0 ? " (nets side by side)" : "", d->n_hidden, K, act);
+        arch = &g_lform_arch;
+        lform = true;
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, EH_EHIP, "eh_create: no HIP device (this library has no CPU path)");
@@ -1102,6 +1164,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     h->device = d->device;
     h->arch = arch;
+    h->lform = lform;
     h->variant = (arch->nvar > 1 && !arch->wide) ? 1 : 0;   // narrow nets: two waves per SIMD hide the latency of the short tile
     EhNet& n = h->net;
     memset(&n, 0, sizeof n);
@@ -1133,6 +1196,15 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     n.g_off = off;
     n.n_theta = off + G;
+    if (lform) {              // Dense layers of the one network: shapes and canonical offsets
+        h->l_nl = nl + 1;
+        int in = d->n_predictors, o2 = 0;
+        for (int l = 0; l <= nl; ++l) {
+            const int o = l < nl ? d->hidden[l] : K;
+            h->l_in[l] = in; h->l_out[l] = o; h->l_woff[l] = o2; h->l_boff[l] = o2 + o * in;
+            o2 += o * in + o; in = o;
+        }
+    }
     h->act = act; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
     n.mech = d->mech; n.n_par = d->n_params;
     for (int j = 0; j < d->n_params; ++j) {
@@ -1148,7 +1220,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->C = n.P + n.F + n.T;
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T + 2;      // [grad | S | n_valid per target | Sy | Syy]
-    if (!arch_fits(arch, std::max(h->n_acc, EH_EVAL_STATS * n.T))) {
+    if (!lform && !arch_fits(arch, std::max(h->n_acc, EH_EVAL_STATS * n.T))) {
         // the per-wave kernel parks one gradient copy per wave in LDS; the row-split kernel needs none
         if (!wide_arch) {
             delete h;
@@ -1201,13 +1273,22 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         for (int p = 0; p < 32; ++p) { run0[p] = 0.0f; run0[32 + p] = 1.0f; }     // LuxCore.initialstates(BatchNorm)
         HIPCHK_C(hipMemcpy(h->bn_run, run0, sizeof run0, hipMemcpyHostToDevice));
     }
-    HIPCHK_C(hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK_C(hipMalloc(&h->slab, (size_t)h->max_blocks * std::max(h->n_acc, EH_EVAL_STATS * n.T) * sizeof(float)));
+    if (!lform) {             // (the fused-update accumulators: that mode exists for the per-wave kernels only)
+        HIPCHK_C(hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+        HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    }
+    h->slab_rows = lform ? (int)EH_LFORM_ROWS : h->max_blocks;
+    HIPCHK_C(hipMalloc(&h->slab, std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, 8 * sizeof(float)));      // per-target 1/n (T > 1), or [1, -, -, -, k0, k1, k2, loss] of a moment-based loss
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
-    if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; }
+    if (!lform) { if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; } }
+    else {
+        std::vector<unsigned char> wf((size_t)n.n_theta, 0);
+        for (int l = 0; l < h->l_nl; ++l) std::fill(wf.begin() + h->l_woff[l], wf.begin() + h->l_boff[l], (unsigned char)1);
+        HIPCHK_C(hipMalloc(&h->wflag, wf.size()));
+        HIPCHK_C(hipMemcpy(h->wflag, wf.data(), wf.size(), hipMemcpyHostToDevice));
+    }
     {   // parameter image (constant parts; theta is mirrored into it by eh_image_kernel / the optimiser)
         std::vector<float> img0((size_t)arch->img_floats, 0.0f);
         for (int j = 0; j < d->n_params; ++j) {
@@ -1221,20 +1302,23 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
                 for (int i = 0; i < net_w[k][l]; ++i)
                     img0[arch->wh_off + (size_t)(l - 1) * arch->hp * arch->sh + (size_t)(h->net_r0[k][l] + i) * arch->sh + h->net_r0[k][l - 1] + i] = 1.0f;
         auto put_int = [&](int slot, int v) { memcpy(&img0[arch->phi_off + slot], &v, sizeof(int)); };
-        for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
-        for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, tot_w[l]);
+        if (!lform) {         // (read by the fused kernels' end-of-kernel reduction only; sized for their four layers)
+            for (int l = 0; l <= d->n_hidden; ++l) { put_int(EH_IMG_WOFF + l, lw_off[l]); put_int(EH_IMG_BOFF + l, lb_off[l]); }
+            for (int l = 0; l < d->n_hidden; ++l) put_int(EH_IMG_WIDTH + l, tot_w[l]);
+        }
         for (int j = 0; j < d->n_params; ++j)
             if (d->param_kind[j] == EH_PAR_GLOBAL) put_int(EH_IMG_GPAR + d->param_index[j], j);
         HIPCHK_C(hipMalloc(&h->image, img0.size() * sizeof(float)));
         HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
         EhImg& im = h->img;
         im.image = h->image; im.imap = h->imap; im.g_off = n.g_off; im.phi_off = arch->phi_off;
-        im.l2c = 0.0f; im.b_off = arch->b_off;
+        im.l2c = 0.0f; im.b_off = arch->b_off; im.wflag = h->wflag;
         HIPCHK_C(hipMalloc(&h->l2val, sizeof(float)));
         HIPCHK_C(hipMemset(h->l2val, 0, sizeof(float)));
         {
             int nw = 0;
-            for (const EhEntry& e : enumerate_entries(h)) nw += e.col >= 0 ? 1 : 0;
+            if (lform) for (int l = 0; l < h->l_nl; ++l) nw += h->l_in[l] * h->l_out[l];
+            else for (const EhEntry& e : enumerate_entries(h)) nw += e.col >= 0 ? 1 : 0;
             h->n_weights = nw;
         }
         for (int j = 0; j < d->n_params; ++j)
@@ -1263,14 +1347,14 @@ int32_t eh_destroy(eh_handle* h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& e : h->jit) { if (e->worker.joinable()) e->worker.join(); eh_jit_release(&e->k); }
-    if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    (void)hipFree(h->mech_ws);
+    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1345,6 +1429,10 @@ int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_
 
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!h || !name) return EH_EINVAL;
+    if (h->lform && (!strcmp(name, "fast_paths") || !strcmp(name, "row_split") || !strcmp(name, "variant") || !strcmp(name, "precision"))) {
+        if (!strcmp(name, "precision") && value) return fail(h, EH_EUNSUPPORTED, "precision: the layer-wise form computes in fp32");
+        return EH_OK;                        // tile / kernel-family knobs of the fused kernels: nothing to choose in the layer-wise form
+    }
     if (!strcmp(name, "max_blocks")) {
         if (value < 1 || value > 256) return fail(h, EH_EINVAL, "max_blocks must be 1..256 (one workgroup per CU)");
         h->max_blocks = (int)value;
@@ -1374,6 +1462,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         if (value == EH_LOSS_PROGRAM && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
         if (value != EH_LOSS_MSE && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "training losses other than MSE need a single-target model");
         if (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS && h->fused) return fail(h, EH_EUNSUPPORTED, "pearson / kge training losses take two passes per step: switch fused_update off first");
+        if (h->lform && value >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) implements the one-pass training losses mse / rmse / mae / nseLoss");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->net.loss = (int)value;
@@ -1549,7 +1638,149 @@ static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long
     return EH_OK;
 }
 
+// ---- layer-wise execution form (eh_lform.hpp) ---------------------------------------------------------------------------
+struct EhLWs { float *Xb, *H[EH_MAX_HIDDEN], *D[2], *O, *part; long long ldo; };
+static long long lform_floats_per_sample(const eh_handle* h) {
+    long long w = h->net.P + 16, maxw = 0;
+    for (int l = 0; l + 1 < h->l_nl; ++l) { w += h->l_out[l]; maxw = std::max<long long>(maxw, h->l_out[l]); }
+    return w + 2 * maxw;
+}
+static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
+    const long long cap_need = (count + 127) / 128 * 128;
+    if (cap_need > h->l_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->l_ws);
+        h->l_ws = nullptr; h->l_cap = 0;
+        HIPCHK(h, hipMalloc(&h->l_ws, ((size_t)cap_need * lform_floats_per_sample(h) + (size_t)4096 * EH_EVAL_STATS * EH_MAX_TARG) * sizeof(float)));
+        h->l_cap = cap_need;
+    }
+    const long long cap = h->l_cap;
+    float* p = h->l_ws;
+    long long maxw = 0;
+    for (int l = 0; l + 1 < h->l_nl; ++l) maxw = std::max<long long>(maxw, h->l_out[l]);
+    W->Xb = p; p += cap * h->net.P;
+    for (int l = 0; l + 1 < h->l_nl; ++l) { W->H[l] = p; p += cap * h->l_out[l]; }
+    W->D[0] = p; p += cap * maxw;
+    W->D[1] = p; p += cap * maxw;
+    W->O = p; p += cap * 16; W->ldo = cap;
+    W->part = p;
+    return EH_OK;
+}
+template <bool ATR, bool BTR, int EPI>
+static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
+    hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI>), dim3((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz), dim3(256), 0, h->stream, g);
+}
+// minibatch -> Xb (input BatchNorm applied), forward through every Dense layer; O^T [K][ldo] = the raw NN outputs
+static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool train_mode, bool bn_update, const EhLWs& W) {
+    const EhNet& net = h->net;
+    const int B = (int)count;
+    EhStepArgs bn{};
+    if (train_mode) { if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &bn)) return rc; }
+    EhLPrepArgs pa{};
+    pa.recs = sp.recs; pa.C = h->C; pa.P = net.P; pa.idx = idx; pa.first = first; pa.count = B; pa.Xb = W.Xb; pa.meta = h->image;
+    pa.bn_part = bn.bn_part; pa.bn_nblk = bn.bn_nblk; pa.bn_c = bn.bn_c; pa.bn_n = bn.bn_n; pa.bn_update = bn.bn_update; pa.bn_run = h->bn_run;
+    const long long tot = (long long)B * net.P;
+    hipLaunchKernelGGL(eh_lform_prep_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa);
+    HIPCHK(h, hipGetLastError());
+    const float* theta = TH(h);
+    for (int l = 0; l < h->l_nl; ++l) {
+        EhGemmArgs g{};
+        g.A = l == 0 ? W.Xb : W.H[l - 1]; g.lda = h->l_in[l];
+        g.B = theta + h->l_woff[l]; g.ldb = h->l_out[l];                 // canonical (out, in) column-major == [in][out] row-major
+        g.M = B; g.N = h->l_out[l]; g.K = h->l_in[l]; g.kchunk = g.K; g.c_zstride = 0;
+        g.bias = theta + h->l_boff[l]; g.act = h->act;
+        if (l + 1 < h->l_nl) { g.C = W.H[l]; g.ldc = h->l_out[l]; lform_gemm<false, false, EH_GEPI_BIAS_ACT>(h, g, 1); }
+        else { g.C = W.O; g.ldc = W.ldo; lform_gemm<false, false, EH_GEPI_BIAS_T>(h, g, 1); }
+        HIPCHK(h, hipGetLastError());
+    }
+    return EH_OK;
+}
+// one training step's gradient sums into `rows` partial slab rows (the contract of the fused step kernels: eh_reduce_kernel follows)
+static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* rows_out, bool bn_update) {
+    const EhNet& net = h->net;
+    EhLWs W;
+    if (int rc = lform_workspace(h, std::max<long long>(count, 1), &W)) return rc;
+    const int B = (int)count;
+    const int rows = (int)std::max<long long>(1, std::min<long long>(EH_LFORM_ROWS, (count + 2047) / 2048));
+    const int chunk = std::max(16, (int)(((count + rows - 1) / rows + 15) / 16 * 16));
+    *rows_out = rows;
+    if (net.T > 1) {
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (count <= 0) {                          // nothing to do: an all-zero partial (the reduce kernel then skips the update)
+        HIPCHK(h, hipMemsetAsync(h->slab, 0, (size_t)h->n_acc * sizeof(float), h->stream));
+        return EH_OK;
+    }
+    if (int rc = lform_forward(h, sp, idx, first, count, true, bn_update, W)) return rc;
+    EhStepArgs a{};
+    a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
+    a.inv_n = net.T > 1 ? h->inv_n : nullptr;
+    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
+    EhLMechArgs m{W.O, W.ldo, W.part};
+    const int mgrid = (int)std::min<long long>(2048, (count + 255) / 256);
+    if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+    else hipLaunchKernelGGL((eh_lform_mech_kernel<true, false>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(eh_lform_tail_kernel, dim3(1), dim3(256), 0, h->stream, W.part, mgrid, net, h->slab, rows, (long long)h->n_acc);
+    HIPCHK(h, hipGetLastError());
+    // backward, from the output layer down; dZ of the output layer = d loss / d O^T, still [K][ldo]
+    const float* theta = TH(h);
+    const float* dZ = W.O;
+    bool dz_t = true;                          // dZ stored transposed ([out][B])
+    int which = 0;
+    for (int l = h->l_nl - 1; l >= 0; --l) {
+        const int in = h->l_in[l], out = h->l_out[l];
+        const float* Hprev = l == 0 ? W.Xb : W.H[l - 1];
+        EhGemmArgs g{};                        // dW_l^T [in x out] = Hprev^T [in x B] * dZ_l [B x out], split over the samples
+        g.A = Hprev; g.lda = in; g.B = dZ; g.ldb = dz_t ? W.ldo : out;
+        g.C = h->slab + h->l_woff[l]; g.ldc = out; g.M = in; g.N = out; g.K = B; g.kchunk = chunk; g.c_zstride = h->n_acc;
+        if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
+        HIPCHK(h, hipGetLastError());
+        hipLaunchKernelGGL(eh_colsum_kernel, dim3((unsigned)((out + 63) / 64), (unsigned)rows), dim3(256), 0, h->stream, dZ, dz_t ? 1LL : (long long)out, dz_t ? W.ldo : 1LL, B, out, chunk,
+                           h->slab + h->l_boff[l], (long long)h->n_acc);
+        HIPCHK(h, hipGetLastError());
+        if (l > 0) {                           // dZ_{l-1} [B x in] = (dZ_l [B x out] * W_l [out x in]) .* act'(H_{l-1})
+            EhGemmArgs b{};
+            b.A = dZ; b.lda = dz_t ? W.ldo : out; b.B = theta + h->l_woff[l]; b.ldb = out;        // W_l element (k = out, n = in) at n * out + k
+            b.C = W.D[which]; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
+            b.H = Hprev; b.ldh = in; b.act = h->act;
+            if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
+            HIPCHK(h, hipGetLastError());
+            dZ = W.D[which]; dz_t = false; which ^= 1;
+        }
+    }
+    return EH_OK;
+}
+// forward + metric sums of samples [first, first+count) in chunks; per-workgroup rows of EH_EVAL_STATS * T sums land in the slab
+static int lform_eval(eh_handle* h, const EhSplit& sp, long long first, long long count, float* yhat, float* pout, int* rows_out) {
+    const EhNet& net = h->net;
+    const long long CH = 65536;
+    int rows = 0;
+    const int ncol = EH_EVAL_STATS * net.T;
+    for (long long c0 = 0; c0 < count; c0 += CH) {
+        const long long n = std::min(CH, count - c0);
+        EhLWs W;
+        if (int rc = lform_workspace(h, n, &W)) return rc;
+        if (int rc = lform_forward(h, sp, nullptr, first + c0, n, false, false, W)) return rc;
+        EhStepArgs a{};
+        a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = nullptr; a.first = first + c0; a.count = n;
+        a.yhat = yhat ? yhat + c0 : nullptr; a.pout = pout ? pout + c0 : nullptr; a.yld = count;
+        for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
+        const int mgrid = (int)std::min<long long>(256, (n + 255) / 256);
+        if ((size_t)(rows + mgrid) * ncol > std::max((size_t)h->slab_rows * std::max(h->n_acc, ncol), (size_t)1 << 20)) return fail(h, EH_ENOMEM, "eh_eval: window too large for the metric rows");
+        EhLMechArgs m{W.O, W.ldo, h->slab + (size_t)rows * ncol};
+        if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<false, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+        else hipLaunchKernelGGL((eh_lform_mech_kernel<false, false>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+        HIPCHK(h, hipGetLastError());
+        rows += mgrid;
+    }
+    *rows_out = std::max(rows, 0);
+    return EH_OK;
+}
+
 static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* grid_out, bool bn_update) {
+    if (h->lform) return lform_train(h, sp, idx, first, count, grid_out, bn_update);
     const EhNet& net = h->net;
     if (net.T > 1) {
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
@@ -1741,8 +1972,9 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     a.pout = params ? h->out_buf + (yhat ? (long long)net.T * count : 0) : nullptr;
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
-    const int grid = count > 0 ? grid_for(h, count) : 1;
-    HIPCHK(h, step_launch(h, EH_MODE_EVAL, grid, &a));
+    int grid = count > 0 ? grid_for(h, count) : 1;
+    if (h->lform) { if ((rc = lform_eval(h, sp, first, count, a.yhat, a.pout, &grid))) return rc; }
+    else HIPCHK(h, step_launch(h, EH_MODE_EVAL, grid, &a));
     std::vector<float> part((size_t)grid * a.n_acc);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2306,13 +2538,14 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
 #define NCCLCHK(h, expr)                                                                                     \
     do {                                                                                                     \
         ncclResult_t r_ = (expr);                                                                            \
-        if (r_ != ncclSuccess) return fail(h, EH_ERCCL, "%s: %s", #expr, ncclGetErrorString(r_));            \
+        if (r_ != ncclSuccess) return fail(h, EH_ERCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
     } while (0)
 
 int32_t eh_comm_unique_id(void* id_out, int64_t id_bytes) {
     if (!id_out || id_bytes < (int64_t)sizeof(ncclUniqueId)) return fail(nullptr, EH_EINVAL, "eh_comm_unique_id: buffer of %lld bytes, need %zu", (long long)id_bytes, sizeof(ncclUniqueId));
+    RCCL_BIND(nullptr);
     ncclUniqueId id;
-    NCCLCHK(nullptr, ncclGetUniqueId(&id));
+    NCCLCHK(nullptr, g_rccl.GetUniqueId(&id));
     memcpy(id_out, &id, sizeof id);
     return EH_OK;
 }
@@ -2325,7 +2558,8 @@ int32_t eh_comm_init(eh_handle* h, const void* unique_id, int64_t id_bytes, int3
     HIPCHK(h, hipSetDevice(h->device));
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    NCCLCHK(h, ncclCommInitRank(&h->comm, world, id, rank));
+    RCCL_BIND(h);
+    NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
     h->comm_world = world; h->comm_rank = rank;
     return EH_OK;
 }
@@ -2335,13 +2569,13 @@ int32_t eh_comm_destroy(eh_handle* h) {
     if (!h->comm) return EH_OK;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    NCCLCHK(h, ncclCommDestroy(h->comm));
+    NCCLCHK(h, g_rccl.CommDestroy(h->comm));
     h->comm = nullptr; h->comm_world = 0;
     return EH_OK;
 }
 
-int32_t eh_comm_group_begin(void) { NCCLCHK(nullptr, ncclGroupStart()); return EH_OK; }
-int32_t eh_comm_group_end(void) { NCCLCHK(nullptr, ncclGroupEnd()); return EH_OK; }
+int32_t eh_comm_group_begin(void) { RCCL_BIND(nullptr); NCCLCHK(nullptr, g_rccl.GroupStart()); return EH_OK; }
+int32_t eh_comm_group_end(void) { RCCL_BIND(nullptr); NCCLCHK(nullptr, g_rccl.GroupEnd()); return EH_OK; }
 
 int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
     if (!h) return EH_EINVAL;
@@ -2360,7 +2594,7 @@ int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
         default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC or EH_BUF_BNSTAT)", which);
     }
     HIPCHK(h, hipSetDevice(h->device));
-    NCCLCHK(h, ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, h->comm, h->stream));
+    NCCLCHK(h, g_rccl.AllReduce(buf, buf, n, ncclFloat, ncclSum, h->comm, h->stream));
     return EH_OK;
 }
 

@@ -1,0 +1,289 @@
+// Layer-wise execution form ("L-form") of the training step, for networks the fused kernels cannot hold: hidden widths above 128,
+// more than three hidden layers -- e.g. the reference's own GPU tutorial net hidden_layers = [1024, 512, 256, 128, 64]
+// (docs/literate/tutorials/synthetic_respiration_gpu.jl:87).  A weight image of that size (2.8 MB) does not fit a CU's LDS, so the
+// activations live in HBM as [sample][feature] planes and every Dense layer is one tiled GEMM on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) with its elementwise tail fused into the epilogue:
+//
+//   forward    H_l  [B x out]  = act(H_{l-1} [B x in] * W_l^T + b_l)         (last layer: O^T [K][B] = ... + b, no activation)
+//   mechanistic stage + masked loss + its pullback, one sample per lane (eh_mech_stage_lane, the code of the fused kernels)
+//   backward   dW_l^T [in x out] = H_{l-1}^T * dZ_l      split over the samples into S partial slabs (-> eh_reduce_kernel + optimiser)
+//              db_l   [out]      = column sums of dZ_l   (same split)
+//              dZ_{l-1} [B x in] = (dZ_l * W_l) .* act'(H_{l-1})
+//
+// The canonical flat theta of the reference (ComponentArray of Lux Dense parameters: weight column-major (out, in), then bias,
+// GenericHybridModel.jl:236-256) IS the [in][out] row-major operand these GEMMs want, and dW^T comes out in the same order: no
+// parameter image, no index maps.  Same arithmetic as the fused kernels (fp32 products, fp32 sums; only the summation order
+// differs), same slab / gradbuf contract, so reduce + optimiser, the data-parallel seam and the epoch driver are shared.
+#pragma once
+#include "eh_wide_bf16.hpp"      // EhMechAcc, eh_mech_stage_lane
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EH_GEPI_STORE = 0, EH_GEPI_BIAS_ACT = 1, EH_GEPI_BIAS_T = 2, EH_GEPI_DACT = 3 };
+
+struct EhGemmArgs {
+    const float* A; long long lda;       // !ATR: A[m][k] at A + m*lda + k ; ATR: A[k][m] at A + k*lda + m
+    const float* B; long long ldb;       // !BTR: B[k][n] at B + k*ldb + n ; BTR: B[n][k] at B + n*ldb + k
+    float* C; long long ldc;             // C[m][n] at C + m*ldc + n  (EH_GEPI_BIAS_T: C[n][m] at C + n*ldc + m)
+    int M, N, K;
+    int kchunk;                          // split-K: blockIdx.z covers k in [z*kchunk, min(K, (z+1)*kchunk)), C advanced by z * c_zstride
+    long long c_zstride;
+    const float* bias;                   // EH_GEPI_BIAS_*: [N]
+    const float* H; long long ldh;       // EH_GEPI_DACT: stored activations, same shape as C
+    int act;                             // eh_activation of the epilogue
+};
+
+__device__ __forceinline__ float eh_act_rt(int act, float z) {
+    switch (act) {
+        case EH_ACT_TANH: return eh_tanh(z);
+        case EH_ACT_SIGMOID: return eh_sigmoid(z);
+        case EH_ACT_RELU: return fmaxf(z, 0.0f);
+        default: return z;
+    }
+}
+__device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' from the stored activation
+    switch (act) {
+        case EH_ACT_TANH: return 1.0f - h * h;
+        case EH_ACT_SIGMOID: return h * (1.0f - h);
+        case EH_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+
+// C (M x N) = A (M x K) * B (K x N), fp32 in, fp32 out, on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered fmaf chain per output).
+// 128 x 128 output tile per workgroup of four waves (2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles); K in steps of 16 through LDS as
+// k-major tiles, so both MFMA operands are conflict-free row reads; the next step's global loads are in flight during the MFMAs.
+template <bool ATR, bool BTR, int EPI>
+__global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = BM + 4;
+    __shared__ float As[BK][LDS_LD], Bs[BK][LDS_LD];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = (int)blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    constexpr int NE = BM * BK / 256;      // tile elements per thread (8)
+    float ra[NE], rb[NE];
+    // element e of a tile: the thread order follows the operand's contiguous dimension (coalesced global loads)
+    auto tile_a = [&](int e, int& mm, int& kk) { if (ATR) { kk = e / BM; mm = e % BM; } else { mm = e / BK; kk = e % BK; } };
+    auto tile_b = [&](int e, int& nn, int& kk) { if (BTR) { nn = e / BK; kk = e % BK; } else { kk = e / BN; nn = e % BN; } };
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            int mm, nn, ka, kb;
+            tile_a(tid + 256 * j, mm, ka);
+            tile_b(tid + 256 * j, nn, kb);
+            const int m = m0 + mm, n = n0 + nn;
+            ra[j] = (m < g.M && k0 + ka < kend) ? (ATR ? g.A[(long long)(k0 + ka) * g.lda + m] : g.A[(long long)m * g.lda + k0 + ka]) : 0.0f;
+            rb[j] = (n < g.N && k0 + kb < kend) ? (BTR ? g.B[(long long)n * g.ldb + k0 + kb] : g.B[(long long)(k0 + kb) * g.ldb + n]) : 0.0f;
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                       // the previous step's MFMAs are done with the tiles
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            int mm, nn, ka, kb;
+            tile_a(tid + 256 * j, mm, ka);
+            tile_b(tid + 256 * j, nn, kb);
+            As[ka][mm] = ra[j];
+            Bs[kb][nn] = rb[j];
+        }
+        __syncthreads();
+        if (k0 + BK < kend) load(k0 + BK);
+#pragma unroll
+        for (int k2 = 0; k2 < BK; k2 += 2) {
+            const float a0 = As[k2 + lh][wm * 64 + l32], a1 = As[k2 + lh][wm * 64 + 32 + l32];
+            const float b0 = Bs[k2 + lh][wn * 64 + l32], b1 = Bs[k2 + lh][wn * 64 + 32 + l32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: lane -> column (lane & 31); register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* const C = g.C + (long long)blockIdx.z * g.c_zstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + 32 * j + l32;
+            const float bv = ((EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_BIAS_T) && n < g.N) ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < g.M && n < g.N) {
+                    float v = acc[i][j][r];
+                    if (EPI == EH_GEPI_BIAS_ACT) v = eh_act_rt(g.act, v + bv);
+                    else if (EPI == EH_GEPI_BIAS_T) v += bv;
+                    else if (EPI == EH_GEPI_DACT) v *= eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
+                    if (EPI == EH_GEPI_BIAS_T) C[(long long)n * g.ldc + m] = v;
+                    else C[(long long)m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
+// out[z * zstride + n] = sum over rows m of chunk z of D(m, n), D(m, n) at D + m*sm + n*sn  (bias gradients: column sums of the deltas)
+__global__ __launch_bounds__(256) void eh_colsum_kernel(const float* D, long long sm, long long sn, int M, int N, int mchunk, float* out, long long zstride) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, nl = tid & 63, q = tid >> 6, n = blockIdx.x * 64 + nl, z = blockIdx.y;
+    const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
+    float s = 0.0f;
+    if (n < N)
+        for (int m = mbeg + q; m < mend; m += 4) s += D[(long long)m * sm + (long long)n * sn];
+    red[q][nl] = s;
+    __syncthreads();
+    if (q == 0 && n < N) out[(long long)z * zstride + n] = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
+}
+
+// The minibatch as the GEMMs want it: Xb [count][P] = the predictors of samples idx[first + i] (or first + i), normalised by the
+// input BatchNorm when the model has one (train mode: the statistics of THIS minibatch from eh_bn_stats_kernel's partial sums, and
+// block 0 advances the running statistics; test mode: the running statistics in `meta`).
+struct EhLPrepArgs {
+    const float* recs; int C, P;
+    const int* idx; long long first; int count;
+    float* Xb;
+    float* meta;              // the handle's EH_IMG_* block (global memory)
+    const float* bn_part; int bn_nblk; const float* bn_c; const float* bn_n; int bn_update; float* bn_run;
+};
+__global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a) {
+    __shared__ float mu[32], rs[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        float m = a.meta[EH_IMG_BNM + tid], r = a.meta[EH_IMG_BNR + tid];
+        if (a.bn_part && tid < a.P) {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
+            const float cnt = a.bn_n ? *a.bn_n : (float)a.count, c0 = a.bn_c[tid];
+            const float d = s1 / cnt, var = fmaxf(s2 / cnt - d * d, 0.0f);
+            m = c0 + d; r = 1.0f / sqrtf(var + EH_BN_EPS);
+            if (a.bn_update && blockIdx.x == 0) {
+                const float rm = (1.0f - EH_BN_MOMENTUM) * a.bn_run[tid] + EH_BN_MOMENTUM * m;
+                const float rv = (1.0f - EH_BN_MOMENTUM) * a.bn_run[32 + tid] + EH_BN_MOMENTUM * (cnt > 1.0f ? cnt / (cnt - 1.0f) : 1.0f) * var;
+                a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
+                a.meta[EH_IMG_BNM + tid] = rm;                          // what forward / eval (test mode) will use
+                a.meta[EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
+            }
+        }
+        mu[tid] = m; rs[tid] = r;
+    }
+    __syncthreads();
+    const long long tot = (long long)a.count * a.P;
+    for (long long e = (long long)blockIdx.x * 256 + tid; e < tot; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / a.P), p = (int)(e - (long long)i * a.P);
+        const long long n = a.idx ? (long long)a.idx[a.first + i] : a.first + i;
+        const float x = a.recs[n * a.C + p];
+        a.Xb[e] = p < 32 ? (x - mu[p]) * rs[p] : x;        // (the normalisation block holds 32 predictors; wider inputs come without input BatchNorm)
+    }
+}
+
+// Mechanistic model + masked loss (+ its pullback), one sample per lane, between the forward and the backward GEMMs:
+// O [K][ldo] raw NN outputs in -> (TRAIN) d loss / d O in place, one row of partial sums per workgroup
+// [grad of the raw globals (8) | S | n_t (4) | Sy | Syy]; (eval) predictions / parameters out, metric sums per workgroup.
+struct EhLMechArgs {
+    float* O; long long ldo;
+    float* part;              // [gridDim][EH_LMECH_PART] (train) / [gridDim][EH_EVAL_STATS * T] (eval)
+};
+enum { EH_LMECH_PART = 16 };
+template <bool TRAIN, bool PROG>
+__global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, const EhStepArgs a, const EhLMechArgs m, const float* meta_g) {
+    constexpr int SR = 64;
+    __shared__ float OSs[4][16 * SR], SGs[4][16 * SR], RSs[4][(EH_MAX_FORC + EH_MAX_TARG) * SR], metas[EH_IMG_META], red[4][32];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int e = tid; e < EH_IMG_META; e += 256) metas[e] = meta_g[e];
+    __syncthreads();
+    float* const OS = OSs[wave]; float* const SG = SGs[wave]; float* const RS = RSs[wave];
+    auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
+    auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
+    EhMechAcc MA;
+    MA.clear();
+    const int count = (int)a.count;
+    for (int base = ((int)blockIdx.x * 4 + wave) * 64; base < count; base += (int)gridDim.x * 256) {
+        const int n_loc = base + lane;
+        const bool live = n_loc < count;
+        const long long n_glb = live ? (a.idx ? (long long)a.idx[a.first + n_loc] : a.first + n_loc) : 0;
+        const float* const rec = a.recs + n_glb * a.C;
+#pragma unroll
+        for (int f = 0; f < EH_MAX_FORC; ++f) RS[f * SR + lane] = (f < net.F && live) ? rec[net.P + f] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) RS[(EH_MAX_FORC + t) * SR + lane] = (t < net.T && live) ? rec[net.P + net.F + t] : __builtin_nanf("");
+        for (int k = 0; k < net.K; ++k) {
+            const float ov = live ? m.O[(long long)k * m.ldo + n_loc] : 0.0f;
+            float pv = ov, sv = 1.0f;
+            if (net.scale_nn) {
+                float lo = 0.0f, sc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                    if (j < net.n_par && pkind(j) == EH_PAR_NEURAL && pidx(j) == k) { lo = metas[EH_IMG_LO + j]; sc = metas[EH_IMG_SC + j]; }
+                const float sgm = eh_sigmoid(ov);
+                pv = fmaf(sc, sgm, lo);
+                sv = sc * sgm * (1.0f - sgm);
+            }
+            OS[k * SR + lane] = pv; SG[k * SR + lane] = sv;
+        }
+        eh_mech_stage_lane<TRAIN, PROG>(net, a, lane, live, n_loc, SR, RS, OS, SG, metas, MA);      // (every access of a lane is to its own column: no cross-lane traffic)
+        if constexpr (TRAIN) {
+            if (live)
+                for (int k = 0; k < net.K; ++k) m.O[(long long)k * m.ldo + n_loc] = OS[k * SR + lane];
+        }
+    }
+    // one row of sums per workgroup (fixed order: deterministic)
+    constexpr int NS = TRAIN ? EH_LMECH_PART : EH_EVAL_STATS * EH_MAX_TARG;
+    float v[NS];
+    if constexpr (TRAIN) {
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) v[j] = (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) ? MA.gacc[j] * metas[EH_IMG_DPHI + j] : 0.0f;
+        v[8] = MA.lacc;
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) v[9 + t] = MA.cacc[t];
+        v[13] = MA.syacc; v[14] = MA.syyacc; v[15] = 0.0f;
+    } else {
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t)
+#pragma unroll
+            for (int k = 0; k < EH_EVAL_STATS; ++k) v[t * EH_EVAL_STATS + k] = MA.est[t][k];
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float s = eh_wave_sum(v[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    const int nout = TRAIN ? EH_LMECH_PART : EH_EVAL_STATS * net.T;
+    if (tid < nout) m.part[(long long)blockIdx.x * nout + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// rows of mechanistic-stage sums -> the tail of slab row 0 ([grad of the raw globals | S | n_t | Sy | Syy] in the fused kernels'
+// column order); the same columns of the other slab rows are cleared.  One workgroup.
+__global__ __launch_bounds__(256) void eh_lform_tail_kernel(const float* part, int nblk, const EhNet net, float* slab, int nrows, long long n_acc) {
+    __shared__ float tot[EH_LMECH_PART];
+    const int tid = threadIdx.x;
+    if (tid < EH_LMECH_PART) {
+        float s = 0.0f;
+        for (int b = 0; b < nblk; ++b) s += part[(long long)b * EH_LMECH_PART + tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    const int ntail = net.G + 1 + net.T + 2;
+    for (int e = tid; e < nrows * ntail; e += 256) {
+        const int row = e / ntail, c = e % ntail;
+        float v = 0.0f;
+        if (row == 0) {
+            if (c < net.G) {
+#pragma unroll
+                for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                    if (j < net.n_par && ((net.par_kind >> (2 * j)) & 3u) == EH_PAR_GLOBAL && (int)((net.par_idx >> (4 * j)) & 15u) == c) v = tot[j];
+            } else if (c == net.G) v = tot[8];
+            else if (c <= net.G + net.T) v = tot[9 + (c - net.G - 1)];
+            else v = tot[13 + (c - net.G - 1 - net.T)];
+        }
+        slab[(long long)row * n_acc + net.g_off + c] = v;
+    }
+}

@@ -20,7 +20,7 @@ export constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridMode
 
 const LIB = Ref{String}(get(ENV, "EASYHYBRID_HIP_LIB", joinpath(@__DIR__, "..", "..", "..", "libeasyhybrid_hip.so")))
 
-const EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG = 4, 8, 4, 4
+const EH_MAX_HIDDEN, EH_MAX_PARAMS, EH_MAX_FORC, EH_MAX_TARG = 8, 8, 4, 4
 const EH_SPLIT_TRAIN, EH_SPLIT_VAL = Int32(0), Int32(1)
 
 # mirror of `eh_model_desc` (field order and widths exactly as in the header)
@@ -29,7 +29,7 @@ struct EhModelDesc
     device::Int32
     n_predictors::Int32
     n_hidden::Int32
-    hidden::NTuple{4, Int32}
+    hidden::NTuple{8, Int32}
     activation::Int32
     scale_nn_outputs::Int32
     input_batchnorm::Int32
@@ -46,7 +46,7 @@ struct EhModelDesc
     target_output::NTuple{4, Int32}
     n_nets::Int32                                   # 0 = SingleNNHybridModel
     net_n_predictors::NTuple{8, Int32}
-    net_hidden::NTuple{32, Int32}                   # [8 nets][4 layers], row-major like the C array
+    net_hidden::NTuple{64, Int32}                   # [8 nets][8 layers], row-major like the C array
     net_activation::NTuple{8, Int32}                # read when activation == 5 (EH_ACT_PER_NET): activation id of net k
     net_depth::NTuple{8, Int32}                     # hidden layers of net k (0 = n_hidden); n_hidden is the deepest net's
     prog_len::Int32                                 # EH_MECH_PROGRAM only (a recorded closure, see `record_program`)
@@ -324,7 +324,7 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         push!(def, d); push!(lo, l); push!(hi, u)
     end
     hidden = [o for (o, _) in m.NN[1:(end - 1)]]
-    n_nets = Int32(0); net_p = Int32[]; net_h = zeros(Int32, 32); net_a = Int32[]; net_d = Int32[]
+    n_nets = Int32(0); net_p = Int32[]; net_h = zeros(Int32, 64); net_a = Int32[]; net_d = Int32[]
     act = m.config.activation isa Symbol ? ACT[m.config.activation] : 5          # 5 = EH_ACT_PER_NET
     if haskey(m.config, :multi)
         mu = m.config.multi
@@ -332,15 +332,15 @@ function descriptor(m::SingleNNHybridModel; device::Integer = 0)
         n_nets = Int32(length(mu.hidden)); net_p = Int32.(length.(mu.predictors)); net_a = Int32[ACT[a] for a in mu.activations]
         net_d = Int32.(length.(mu.hidden))
         for (k, h) in enumerate(mu.hidden), (l, w) in enumerate(h)
-            net_h[(k - 1) * 4 + l] = w                                           # int32_t net_hidden[8][4], row-major
+            net_h[(k - 1) * 8 + l] = w                                           # int32_t net_hidden[8][8], row-major
         end
     end
-    return EhModelDesc(sizeof(EhModelDesc), device, length(m.predictors), length(hidden), pad(hidden, 4, Int32),
+    return EhModelDesc(sizeof(EhModelDesc), device, length(m.predictors), length(hidden), pad(hidden, 8, Int32),
         act, m.scale_nn_outputs, m.config.input_batchnorm, ms.id, length(ms.params),
         pad(kind, 8, Int32), pad(index, 8, Int32), pad(def, 8, Float32), pad(lo, 8, Float32), pad(hi, 8, Float32),
         length(m.forcing), pad([findfirst(==(f), m.forcing) - 1 for f in ms.forcings], 4, Int32),
         length(m.targets), pad([findfirst(==(t), ms.outputs) - 1 for t in m.targets], 4, Int32),
-        n_nets, pad(net_p, 8, Int32), pad(net_h, 32, Int32), pad(net_a, 8, Int32), pad(net_d, 8, Int32),    # MultiNN form (n_nets = 0: SingleNN)
+        n_nets, pad(net_p, 8, Int32), pad(net_h, 64, Int32), pad(net_a, 8, Int32), pad(net_d, 8, Int32),    # MultiNN form (n_nets = 0: SingleNN)
         (pg === nothing ? (Int32(0), Int32(0), Int32(0), Int32(0), pad(Int32[], 3, Int32), pad(UInt32[], 64, UInt32), pad(Float32[], 16, Float32)) :
          (Int32(length(pg.code)), Int32(length(pg.consts)), Int32(length(ms.forcings)), Int32(length(pg.out)), pad(pg.out, 3, Int32),
           pad(pg.code, 64, UInt32), pad(pg.consts, 16, Float32)))...)

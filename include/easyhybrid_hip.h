@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define EH_ABI_VERSION 2      /* 2: eh_train_step takes the minibatch indices; eh_comm_* */
-#define EH_MAX_HIDDEN 4
+#define EH_MAX_HIDDEN 8       /* hidden layers: up to 3 run as ONE fused kernel per step, more (or widths above 128) layer by layer (csrc/eh_lform.hpp) */
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
 #define EH_MAX_TARG 4

@@ -1,0 +1,160 @@
+"""-m gpu: the layer-wise execution form (csrc/eh_lform.hpp) -- networks no fused kernel holds: hidden widths above 128 or more
+than three hidden layers, first of all the reference's own GPU tutorial net hidden_layers = [1024, 512, 256, 128, 64], sigmoid,
+scale_nn_outputs, input_batchnorm (docs/literate/tutorials/synthetic_respiration_gpu.jl:79-92) -- through the C ABI against the
+fp64 oracle at the north_star's 1e-5."""
+import numpy as np
+import pytest
+
+import easyhybrid_jl_amd as eh
+from oracle import hybrid_oracle as ho
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+TUTORIAL = (1024, 512, 256, 128, 64)
+
+
+def _check(spec, theta, X, f, y, eng=None, bn_state=None, **kw):
+    own = eng is None
+    eng = eng or util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad(**kw)
+    if "idx" in kw:
+        ix = kw["idx"]
+        X, f, y = X[:, ix], {k: v[ix] for k, v in f.items()}, {k: v[ix] for k, v in y.items()}
+    l0, g0, nv0 = ho.loss_and_grad(spec, np.asarray(theta, np.float64), X, f, y, bn_state=bn_state)
+    assert nv == sum(nv0)
+    assert abs(loss - l0) <= TOL * abs(l0), (loss, l0)
+    assert util.relerr(grad, g0) <= TOL, util.relerr(grad, g0)
+    assert util.elem_relerr(grad, g0, 1e-3) <= 5e-4          # entry by entry, down to a thousandth of the largest one
+    if own:
+        eng.close()
+
+
+@pytest.mark.parametrize("B", [64, 300, 2049])
+def test_tutorial_network_loss_and_gradient(B):
+    _check(*util.rbq10_case(B, "sigmoid", True, 0.1, hidden=TUTORIAL))
+
+
+def test_tutorial_network_with_input_batchnorm_and_rmsprop():
+    spec, theta, X, f, y = util.rbq10_case(512, "sigmoid", True, 0.05, hidden=TUTORIAL)
+    X = (X * np.float32(50)).astype(np.float32)            # raw predictor scale: what the BatchNorm layer is there for
+    spec.input_batchnorm = True
+    eng = util.load_engine(spec, theta, X, f, y)
+    _check(spec, theta, X, f, y, eng=eng, bn_state=ho.bn_init(spec))
+    eng.opt_init("RMSProp", 0.001)                           # the tutorial's optimiser family (RMSProp(0.01) there)
+    bn = ho.bn_init(spec)
+    batches = [(0, 256), (256, 256), (100, 300)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th, mm = theta.copy(), None
+    # Optimisers.RMSProp(eta, rho = 0.9, eps = 1e-8): v = rho v + (1 - rho) g^2 ; theta -= eta g / (sqrt(v) + eps)
+    v = np.zeros_like(th)
+    for (a, n), l_dev in zip(batches, losses):
+        sl = slice(a, a + n)
+        l0, g0, _ = ho.loss_and_grad(spec, th.astype(np.float64), X[:, sl], {k: q[sl] for k, q in f.items()}, {k: q[sl] for k, q in y.items()}, bn_state=bn)
+        _, new = ho.batchnorm_input(np.asarray(X[:, sl], np.float64), bn, True, np.dtype(np.float64)); bn.update(new)
+        assert abs(l_dev - l0) <= 2e-5 * abs(l0)
+        g = g0.astype(np.float32)
+        v = np.float32(0.9) * v + np.float32(0.1) * g * g
+        th = th - g * (np.float32(0.001) / (np.sqrt(v) + np.float32(1e-8)))
+    d = np.abs(eng.get_params() - th)
+    assert np.mean(d <= 2e-5) >= 0.999 and d.max() <= 2.5e-3, (np.mean(d <= 2e-5), d.max())      # first RMSProp steps are sign-like: see test_gpu_parity.py
+    rm, rv = eng.get_bn_state()
+    assert np.allclose(rm, bn["mean"], rtol=1e-5, atol=1e-6) and np.allclose(rv, bn["var"], rtol=1e-5, atol=1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("act,hidden,n_pred", [("tanh", (40, 30, 20, 10), 8), ("relu", (200, 150), 12), ("identity", (129,), 3), ("tanh", (300,), 40)])
+def test_other_deep_and_wide_shapes(act, hidden, n_pred):
+    """four hidden layers of narrow width; two wide layers; one layer just past the fused kernels' 128; more predictors than the fused kernels take"""
+    rng = np.random.default_rng(5)
+    spec = ho.HybridSpec(n_pred, list(hidden), "expo2pool", dict(ho.EXPO2POOL_PARAMS), ["R0a", "ka", "R0b", "kb"], [], ["Resp_obs"], act, True)
+    B = 700
+    X = rng.random((n_pred, B)).astype(np.float32)
+    f = {"T": (rng.random(B) * 40 - 10).astype(np.float32)}
+    yv = (1.0 + rng.random(B)).astype(np.float32); yv[rng.random(B) < 0.1] = np.nan
+    _check(spec, ho.init_theta(spec, 9, np.float32), X, f, {"Resp_obs": yv})
+
+
+def test_two_targets_global_and_fixed_parameters():
+    rng = np.random.default_rng(8)
+    B = 500
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(6, [160, 96, 48, 24], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((6, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][rng.random(B) < 0.2] = np.nan; y["GPP"][rng.random(B) < 0.1] = np.nan
+    _check(spec, ho.init_theta(spec, 3, np.float32), X, f, y)
+
+
+def test_forward_metrics_and_gathered_minibatch():
+    spec, theta, X, f, y = util.rbq10_case(3000, "sigmoid", True, 0.1, hidden=(256, 192, 64, 32))
+    eng = util.load_engine(spec, theta, X, f, y)
+    out = eng.forward(eh.EH_SPLIT_TRAIN)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    assert util.relerr(out["reco"], ref["reco"]) <= TOL and util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= TOL
+    m, _ = eng.eval(eh.EH_SPLIT_TRAIN)
+    ev, _ = ho.evaluate(spec, theta.astype(np.float64), X, f, y, ("mse", "r2"))
+    assert m[0]["mse"] == pytest.approx(ev["mse"]["reco"], rel=2e-5) and m[0]["r2"] == pytest.approx(ev["r2"]["reco"], abs=2e-5)
+    idx = np.random.default_rng(2).permutation(3000)[:1100].astype(np.int32)
+    _check(spec, theta, X, f, y, eng=eng, idx=idx)
+    eng.close()
+
+
+def test_adam_trajectory_and_epoch_driver():
+    spec, theta, X, f, y = util.rbq10_case(1024, "tanh", True, 0.1, hidden=(160, 80, 40, 20))
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 256, 256) for i in range(4)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=2e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 2e-5) >= 0.999 and d.max() <= 4 * 0.01 * 1.01
+    mean_loss, nsteps = eng.train_epoch(300, seed=5, shuffle=True)
+    assert nsteps == 4 and np.isfinite(mean_loss)
+    eng.close()
+
+
+def test_weight_l2_and_data_parallel_seam():
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1, hidden=(144, 72, 36, 18))
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_weight_l2(0.01, False)
+    loss, grad, _ = eng.loss_and_grad()
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, l2=(0.01, False))
+    assert abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL
+    eng.set_weight_l2(0.0, False)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01); eng.opt_init("Adam", 0.01)
+    l_ref = ref.train_step(0, 2048)
+    ptr, n = eng.device_buffer(eh._lib.EH_BUF_GRAD)
+    buf = torch.as_tensor(eh.dp._DevArray(ptr, n), device="cuda")
+    acc = torch.zeros_like(buf)
+    for k in range(4):                                    # four "ranks": the sum of their raw partial vectors stands in for the all-reduce
+        eng.dp_grad(k * 512, 512); eng.synchronize(); acc += buf
+    buf.copy_(acc); torch.cuda.synchronize()
+    assert eng.dp_apply(want_loss=True) == pytest.approx(l_ref, rel=1e-5)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 5e-6
+    eng.close(); ref.close()
+
+
+def test_train_front_door_on_the_tutorial_network():
+    cols = eh.synthetic.make_synth_rbq10(1500, seed=4, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=list(TUTORIAL), activation="sigmoid", scale_nn_outputs=True, input_batchnorm=True)
+    out = eh.train(model, cols, nepochs=3, batchsize=64, opt=eh.RMSProp(0.001), loss_types=["mse", "nse"], random_seed=7, keep_history=True)
+    assert len(out.val_history) == 4 and all(np.isfinite(h["mse"]["sum"]) for h in out.val_history)
+    assert out.val_history[-1]["mse"]["sum"] < out.val_history[0]["mse"]["sum"]
+    assert out.ps.size == 2 * 1024 + 1024 + 1024 * 512 + 512 + 512 * 256 + 256 + 256 * 128 + 128 + 128 * 64 + 64 + 64 + 1 + 1
+
+
+def test_refusals():
+    spec = ho.rbq10_spec(TUTORIAL, "swish", True)
+    with pytest.raises(NotImplementedError, match="layer-wise"):
+        util.model_from_spec(spec).engine()
+    eng = util.model_from_spec(ho.rbq10_spec((256, 256), "tanh", True)).engine()
+    with pytest.raises(NotImplementedError):
+        eng.set_option("fused_update", 1)
+    with pytest.raises(NotImplementedError):
+        eng.set_training_loss("kgeLoss")
+    eng.close()

@@ -16,6 +16,6 @@ while [ $# -ge 2 ]; do
   done
   wait
   objs=$(ls $CS/build/*.o | grep -v -e eh_arch_1_4_2.o -e eh_arch_1_4_3.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/dbg/lib_$name.so $objs $out/eh_arch_1_4_2.o $out/eh_arch_1_4_3.o -L/opt/rocm/lib -lhiprtc -lrccl -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/dbg/lib_$name.so $objs $out/eh_arch_1_4_2.o $out/eh_arch_1_4_3.o -L/opt/rocm/lib -lhiprtc -ldl -Wl,-rpath,/opt/rocm/lib
   echo built dbg/lib_$name.so
 done
