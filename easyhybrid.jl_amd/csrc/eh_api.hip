@@ -1735,10 +1735,8 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         EhGemmArgs g{};                        // dW_l^T [in x out] = Hprev^T [in x B] * dZ_l [B x out], split over the samples
         g.A = Hprev; g.lda = in; g.B = dZ; g.ldb = dz_t ? W.ldo : out;
         g.C = h->slab + h->l_woff[l]; g.ldc = out; g.M = in; g.N = out; g.K = B; g.kchunk = chunk; g.c_zstride = h->n_acc;
+        g.colsum = h->slab + h->l_boff[l];       // db_l = column sums of dZ_l, from the same tiles
         if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
-        HIPCHK(h, hipGetLastError());
-        hipLaunchKernelGGL(eh_colsum_kernel, dim3((unsigned)((out + 63) / 64), (unsigned)rows), dim3(256), 0, h->stream, dZ, dz_t ? 1LL : (long long)out, dz_t ? W.ldo : 1LL, B, out, chunk,
-                           h->slab + h->l_boff[l], (long long)h->n_acc);
         HIPCHK(h, hipGetLastError());
         if (l > 0) {                           // dZ_{l-1} [B x in] = (dZ_l [B x out] * W_l [out x in]) .* act'(H_{l-1})
             EhGemmArgs b{};

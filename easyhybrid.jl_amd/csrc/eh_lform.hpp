@@ -31,6 +31,8 @@ struct EhGemmArgs {
     const float* bias;                   // EH_GEPI_BIAS_*: [N]
     const float* H; long long ldh;       // EH_GEPI_DACT: stored activations, same shape as C
     int act;                             // eh_activation of the epilogue
+    float* colsum;                       // (split-K weight gradients) nullable: colsum[z * c_zstride + n] = sum over the k chunk of B[k][n] -- the bias gradient,
+                                         // taken from the B tiles the first row of workgroups stages anyway
 };
 
 __device__ __forceinline__ float eh_act_rt(int act, float z) {
@@ -84,6 +86,8 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
             rb[j] = (n < g.N && k0 + kb < kend) ? (BTR ? g.B[(long long)n * g.ldb + k0 + kb] : g.B[(long long)(k0 + kb) * g.ldb + n]) : 0.0f;
         }
     };
+    const bool do_cs = EPI == EH_GEPI_STORE && g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
+    float cs = 0.0f;
     if (kbeg < kend) load(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                       // the previous step's MFMAs are done with the tiles
@@ -97,6 +101,10 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
         }
         __syncthreads();
         if (k0 + BK < kend) load(k0 + BK);
+        if (do_cs) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) cs += Bs[kk][tid];      // (k order: deterministic)
+        }
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
             const float a0 = As[k2 + lh][wm * 64 + l32], a1 = As[k2 + lh][wm * 64 + 32 + l32];
@@ -107,6 +115,7 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    if (do_cs && n0 + tid < g.N) g.colsum[(long long)blockIdx.z * g.c_zstride + n0 + tid] = cs;
     // C/D layout of the 32x32 MFMA: lane -> column (lane & 31); register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* const C = g.C + (long long)blockIdx.z * g.c_zstride;
 #pragma unroll
@@ -263,12 +272,16 @@ __global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, con
 // rows of mechanistic-stage sums -> the tail of slab row 0 ([grad of the raw globals | S | n_t | Sy | Syy] in the fused kernels'
 // column order); the same columns of the other slab rows are cleared.  One workgroup.
 __global__ __launch_bounds__(256) void eh_lform_tail_kernel(const float* part, int nblk, const EhNet net, float* slab, int nrows, long long n_acc) {
-    __shared__ float tot[EH_LMECH_PART];
-    const int tid = threadIdx.x;
+    __shared__ float tot[EH_LMECH_PART], red[16][EH_LMECH_PART];
+    const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4;       // 16 row groups x 16 columns, fixed order: deterministic
+    float s = 0.0f;
+    for (int b = grp; b < nblk; b += 16) s += part[(long long)b * EH_LMECH_PART + col];
+    red[grp][col] = s;
+    __syncthreads();
     if (tid < EH_LMECH_PART) {
-        float s = 0.0f;
-        for (int b = 0; b < nblk; ++b) s += part[(long long)b * EH_LMECH_PART + tid];
-        tot[tid] = s;
+        float t = 0.0f;
+        for (int q = 0; q < 16; ++q) t += red[q][tid];
+        tot[tid] = t;
     }
     __syncthreads();
     const int ntail = net.G + 1 + net.T + 2;
