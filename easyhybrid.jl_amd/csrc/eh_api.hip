@@ -1887,7 +1887,8 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
         HIPCHK(h, hipGetLastError());
     }
-    const bool big = h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
+    static const int cw_env = getenv("EH_REDUCE_CW") ? atoi(getenv("EH_REDUCE_CW")) : 0;      // (A/B switch of the measurement tools)
+    const bool big = cw_env ? cw_env == 64 : h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
     const int rgrid = big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);

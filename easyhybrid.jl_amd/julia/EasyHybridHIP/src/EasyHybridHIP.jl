@@ -406,7 +406,8 @@ function jit_status(e::HybridEngine)
 end
 synchronize(e::HybridEngine) = check(e, @ccall LIB[].eh_synchronize(e.h::Ptr{Cvoid})::Int32)
 
-# data-parallel seam (one process per GPU; the caller all-reduces the device buffers with RCCL / ROCm-aware MPI)
+# data-parallel seam (one process per GPU, or one task per device): the gradient sums are all-reduced by the library itself
+# (comm_init! / dp_allreduce! / dp_train_step! below: RCCL inside libeasyhybrid_hip.so) or by the caller's own collective on the device buffers
 const EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT = Int32(0), Int32(4), Int32(5)
 function device_buffer(e::HybridEngine, which::Integer)
     p = Ref{Ptr{Cvoid}}(C_NULL); n = Ref{Int64}(0)
@@ -438,6 +439,22 @@ function p2p_selftest(e::HybridEngine; rounds::Integer = 8)
     return ok[] != 0
 end
 p2p_disable!(e::HybridEngine) = check(e, @ccall LIB[].eh_p2p_disable(e.h::Ptr{Cvoid})::Int32)
+
+"the library's own RCCL communicator (include/easyhybrid_hip.h, eh_comm_*): data parallelism without NCCL.jl / MPI.jl"
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    st = @ccall LIB[].eh_comm_unique_id(id::Ptr{UInt8}, 128::Int64)::Int32
+    st == 0 || error("eh_comm_unique_id: status $st")
+    return id
+end
+comm_init!(e::HybridEngine, id::Vector{UInt8}, world::Integer, rank::Integer) =
+    check(e, @ccall LIB[].eh_comm_init(e.h::Ptr{Cvoid}, id::Ptr{UInt8}, length(id)::Int64, world::Int32, rank::Int32)::Int32)
+comm_destroy!(e::HybridEngine) = check(e, @ccall LIB[].eh_comm_destroy(e.h::Ptr{Cvoid})::Int32)
+"SUM all-reduce, in stream order, of EH_BUF_GRAD (0), a third of EH_BUF_GACC (4, `index`) or EH_BUF_BNSTAT (5)"
+dp_allreduce!(e::HybridEngine, which::Integer, index::Integer = 0) = check(e, @ccall LIB[].eh_dp_allreduce(e.h::Ptr{Cvoid}, which::Int32, index::Int32)::Int32)
+"one data-parallel step of this rank on its shard window (statistics + gradient exchange + update); every rank calls it"
+dp_train_step!(e::HybridEngine, first::Integer, count::Integer) =
+    check(e, @ccall LIB[].eh_dp_train_step(e.h::Ptr{Cvoid}, first::Int64, count::Int64, C_NULL::Ptr{Float32})::Int32)
 
 "input BatchNorm under DP: shard sums into EH_BUF_BNSTAT (all-reduce it before dp_grad! / dp_fused_step!)"
 set_bn_shift!(e::HybridEngine, c::Vector{Float32}) = check(e, @ccall LIB[].eh_set_bn_shift(e.h::Ptr{Cvoid}, c::Ptr{Float32}, length(c)::Int64)::Int32)
