@@ -792,8 +792,10 @@ static int flush_pending(eh_handle* h) {
     hipLaunchKernelGGL(eh_fused_flush_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, g_prev, h->n_acc, nt, TH(h), MM(h), VV(h), sc_in, sc_out,
                        h->opt, h->pending_loss, h->img, h->net.loss, h->p2p_on ? h->p2p_dev : nullptr, (int)((h->gstep + 2) % 3), h->p2p_seq);
     HIPCHK(h, hipGetLastError());
-    // clear what the next steps add into (under EhP2P that is the staging copy; the receive shards are always overwritten whole)
-    HIPCHK(h, hipMemsetAsync(h->p2p_on ? h->p2p_stage : h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
+    // Single GPU: nothing to clear -- the rotation keeps itself clean (the step that accumulates into slot g clears slot g + 1 in
+    // its prologue and nobody reads a slot before the step after its clearing has filled it).  Under EhP2P the workgroups add
+    // into a staging copy that the publishing workgroup reads whole: cleared here.
+    if (h->p2p_on) HIPCHK(h, hipMemsetAsync(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
     h->sc_sel ^= 1;
     h->pending = false;
     h->pending_loss = nullptr;
