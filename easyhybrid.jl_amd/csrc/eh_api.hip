@@ -502,23 +502,32 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
     }
 }
 
-// per-target 1/n_valid of one batch (only needed when T > 1: the normaliser differs per target)
+// Per-target weight of one batch (multi-target models: the normaliser differs per target, so it has to be known before the pass):
+// the residual terms of target t enter the loss as w_t r^2 (w_t |r| for MAE) with  w_t = 1 / n_t  for mse / mae  (loss_fn.jl:61-66)
+// and  w_t = 1 / sum (y - mean y)^2  for nseLoss (:79-81) -- all of it a function of the targets alone.  One workgroup per target.
+struct EhShift4 { float c[EH_MAX_TARG]; };
 __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
-                                                       float* inv_n) {
-    __shared__ float red[256];
+                                                       float* inv_n, unsigned loss_t, EhShift4 shift) {
+    __shared__ float red[3][256];
     const int t = blockIdx.x;
-    float c = 0.0f;
+    float c = 0.0f, s1 = 0.0f, s2 = 0.0f;
     for (long long i = threadIdx.x; i < count; i += 256) {
         const long long n = idx ? (long long)idx[first + i] : first + i;
-        c += __builtin_isnan(recs[n * C + toff + t]) ? 0.0f : 1.0f;
+        const float y = recs[n * C + toff + t];
+        if (!__builtin_isnan(y)) { const float d = y - shift.c[t]; c += 1.0f; s1 += d; s2 += d * d; }
     }
-    red[threadIdx.x] = c;
+    red[0][threadIdx.x] = c; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
     __syncthreads();
     for (int w = 128; w >= 1; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; red[2][threadIdx.x] += red[2][threadIdx.x + w]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) inv_n[t] = red[0] > 0.0f ? 1.0f / red[0] : 0.0f;
+    if (threadIdx.x == 0) {
+        const float n = red[0][0];
+        float w = n > 0.0f ? 1.0f / n : 0.0f;
+        if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (red[2][0] - red[1][0] * red[1][0] / n);
+        inv_n[t] = w;
+    }
 }
 
 // input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample
@@ -1416,6 +1425,26 @@ int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr,
     return EH_OK;
 }
 
+int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
+    if (!h || !kinds) return EH_EINVAL;
+    if (n != h->net.T) return fail(h, EH_EINVAL, "eh_set_target_losses: %d losses for %d targets", n, h->net.T);
+    unsigned lt = 0;
+    bool same = true;
+    for (int t = 0; t < n; ++t) {
+        if (kinds[t] != EH_LOSS_MSE && kinds[t] != EH_LOSS_MAE && kinds[t] != EH_LOSS_NSELOSS && !(n == 1 && kinds[t] == EH_LOSS_RMSE))
+            return fail(h, EH_EUNSUPPORTED, "eh_set_target_losses: loss %d for target %d (per target: mse, mae, nseLoss)", kinds[t], t);
+        lt |= (unsigned)kinds[t] << (4 * t);
+        same = same && kinds[t] == kinds[0];
+    }
+    if (same) return eh_set_option(h, "training_loss", kinds[0]);
+    if (h->fused) return fail(h, EH_EUNSUPPORTED, "eh_set_target_losses: switch fused_update off first");
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    h->net.loss = EH_LOSS_MSE;               // (what the single-kind code paths read; the kernels take the per-target kinds from loss_t)
+    h->net.loss_t = lt;
+    return EH_OK;
+}
+
 int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes) {
     if (!h || !n_compiled) return EH_EINVAL;
     int n = 0;
@@ -1462,12 +1491,15 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "training_loss")) {
         if (value < EH_LOSS_MSE || value > EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
         if (value == EH_LOSS_PROGRAM && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
-        if (value != EH_LOSS_MSE && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "training losses other than MSE need a single-target model");
+        if (h->net.T != 1 && value != EH_LOSS_MSE && value != EH_LOSS_MAE && value != EH_LOSS_NSELOSS)
+            return fail(h, EH_EUNSUPPORTED, "multi-target models train on mse / mae / nseLoss (per target: eh_set_target_losses); the others need a single-target model");
         if (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS && h->fused) return fail(h, EH_EUNSUPPORTED, "pearson / kge training losses take two passes per step: switch fused_update off first");
         if (h->lform && value >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) implements the one-pass training losses mse / rmse / mae / nseLoss");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->net.loss = (int)value;
+        h->net.loss_t = 0;
+        for (int t = 0; t < h->net.T; ++t) h->net.loss_t |= (unsigned)value << (4 * t);
         {   // the moment-based losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
             const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech);
             const int fast = (value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
@@ -1707,7 +1739,8 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     const int chunk = std::max(16, (int)(((count + rows - 1) / rows + 15) / 16 * 16));
     *rows_out = rows;
     if (net.T > 1) {
-        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
+        EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
         HIPCHK(h, hipGetLastError());
     }
     if (count <= 0) {                          // nothing to do: an all-zero partial (the reduce kernel then skips the update)
@@ -1783,7 +1816,8 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     if (h->lform) return lform_train(h, sp, idx, first, count, grid_out, bn_update);
     const EhNet& net = h->net;
     if (net.T > 1) {
-        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n);
+        EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
         HIPCHK(h, hipGetLastError());
     }
     const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS;

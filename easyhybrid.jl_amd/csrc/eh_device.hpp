@@ -46,7 +46,9 @@ struct EhNet {
     unsigned par_kind;               // 2 bits per canonical mech parameter: eh_param_kind
     unsigned par_idx;                // 4 bits per canonical mech parameter: NN output row / global index
     unsigned forc_col;               // 8 bits per canonical forcing: column among the F forcing columns (0xFF unused)
+    unsigned loss_t;                 // 4 bits per target: its training loss (eh_loss; PerTarget, src/losses/compute_loss.jl:128-145).  One target: == loss.
 };
+__device__ __forceinline__ bool eh_target_mae(unsigned loss_t, int t) { return ((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_MAE; }
 // Per-layer offsets / widths and the (lower, upper-lower) table travel in the parameter image
 // (EhGeom::PHI_OFF block) instead of the kernarg: they are read from LDS where they are used,
 // which keeps them out of the scalar register file during the tile loop.
@@ -657,8 +659,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         fCol[f] = col == 0xFFu ? -1 : (int)(net.P + col);
         EH_PIN("+v"(fCol[f]));
     }
-    float maeOn = net.loss == EH_LOSS_MAE ? 1.0f : 0.0f;
-    EH_PIN("+v"(sclOn), "+v"(maeOn));
+    float maeT[EH_MAX_TARG];
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t) { maeT[t] = eh_target_mae(net.loss_t, t) ? 1.0f : 0.0f; EH_PIN("+v"(maeT[t])); }
+    EH_PIN("+v"(sclOn));
     const int tcol0 = net.P + net.F;
 
     // one sample record per lane, fetched one macro-tile ahead of its use
@@ -1067,7 +1071,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                         const float w = a.inv_n ? a.inv_n[t] : 1.0f;
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
-                        if (maeOn != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                        if (maeT[t] != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
 #ifdef EH_JIT_LOSS
                         else if (net.loss == EH_LOSS_PROGRAM) {
                             float dl;

@@ -320,8 +320,8 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     if (rowact) src += "#define EH_JIT_ROWACT 1\n";
     if (spec) {
         char b[512];
-        snprintf(b, sizeof b, "#define EH_SPEC_NET %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %uu, %uu, %uu, %uu\n", spec->P, spec->K, spec->G, spec->T, spec->F,
-                 spec->n_theta, spec->g_off, spec->scale_nn, spec->mech, spec->n_par, spec->loss, spec->n_out, spec->targ_out, spec->par_kind, spec->par_idx, spec->forc_col);
+        snprintf(b, sizeof b, "#define EH_SPEC_NET %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %uu, %uu, %uu, %uu, %uu\n", spec->P, spec->K, spec->G, spec->T, spec->F,
+                 spec->n_theta, spec->g_off, spec->scale_nn, spec->mech, spec->n_par, spec->loss, spec->n_out, spec->targ_out, spec->par_kind, spec->par_idx, spec->forc_col, spec->loss_t);
         src += b;
     }
     src += V.bf16 ? "#include \"eh_wide_bf16.hpp\"\n" : A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";

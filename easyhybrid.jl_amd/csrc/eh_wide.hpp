@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
                         const float w = a.inv_n ? a.inv_n[t] : 1.0f;
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
-                        if (net.loss == EH_LOSS_MAE) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                        if (eh_target_mae(net.loss_t, t)) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
 #ifdef EH_JIT_LOSS
                         else if (net.loss == EH_LOSS_PROGRAM) {
                             float dl;

@@ -156,7 +156,7 @@ __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepA
                 const float w = a.inv_n ? a.inv_n[t] : 1.0f;
                 const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                 float d;
-                if (net.loss == EH_LOSS_MAE) { A.lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
+                if (eh_target_mae(net.loss_t, t)) { A.lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
 #ifdef EH_JIT_LOSS
                 else if (net.loss == EH_LOSS_PROGRAM) {
                     float dl;

@@ -35,6 +35,14 @@ def _fptr(a: Optional[np.ndarray]):
     return a.ctypes.data_as(_F) if a is not None else None
 
 
+class PerTarget:
+    """loss_spec = PerTarget((l_1, ..., l_T)) of the reference (src/losses/compute_loss.jl:128-145): target t is trained on its own
+    loss; the device builds mse / mae / nseLoss per target."""
+
+    def __init__(self, losses):
+        self.losses = tuple(losses)
+
+
 class HybridEngine:
     """Device-resident hybrid model: parameters, optimiser state and datasets live in HBM."""
 
@@ -181,6 +189,23 @@ class HybridEngine:
         pearsonLoss | kgeLoss | pbkgeLoss (two passes per step: batch moments first; not in fused_update mode, not data parallel),
         or a function f(yhat, y) = mean of per-sample terms, which is recorded (program.trace_loss) and compiled into the step
         kernel at run time."""
+        if isinstance(name, PerTarget):
+            name = list(name.losses)
+        if isinstance(name, (list, tuple)) and name and callable(name[0]):
+            # (f, args) / (f, kwargs) / (f, args, kwargs)  (src/losses/loss_fn.jl:92-107): f(yhat, y, args...; kwargs...)
+            f, rest = name[0], list(name[1:])
+            args = next((tuple(r) for r in rest if isinstance(r, (tuple, list))), ())
+            kwargs = next((dict(r) for r in rest if isinstance(r, dict)), {})
+            name = (lambda yh, y, _f=f, _a=args, _k=kwargs: _f(yh, y, *_a, **_k))
+        if isinstance(name, (list, tuple)):                      # PerTarget: one loss name per target (compute_loss.jl:128-145)
+            if len(name) != len(self.target_names):
+                raise AssertionError("Length of targets and PerTarget losses tuple must match")
+            for n in name:
+                if n not in L.TRAINING_LOSSES:
+                    raise NotImplementedError(f"training loss {n!r} is not implemented on the device (have {sorted(L.TRAINING_LOSSES)})")
+            kinds = (C.c_int32 * len(name))(*[L.TRAINING_LOSSES[n] for n in name])
+            self._chk(self._lib.eh_set_target_losses(self._h, kinds, len(name)))
+            return
         if callable(name):
             from .program import trace_loss
             pg = trace_loss(name)

@@ -14,7 +14,7 @@ module EasyHybridHIP
 using Libdl
 using Random
 
-export constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
+export PerTarget, set_training_loss!, constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
     Adam, AdamW, RMSProp, Descent, RbQ10, Expo_resp_model,
     LinearHM, Expo2Pool, Rs_components, Rs_components3F, FluxPartModelQ10
 
@@ -395,6 +395,17 @@ opt_init!(e::HybridEngine; rule = 0, eta = 0.01f0, beta = (0.9f0, 0.999f0), epsi
 "engine options: :max_blocks, :variant, :fast_paths, :row_split, :fused_update, :training_loss (0 mse, 1 rmse, 2 mae, 3 nseLoss, 4 pearsonLoss, 5 kgeLoss, 6 pbkgeLoss),
 :specialize (1 = step kernels compiled at run time around this model's descriptor, about a second, ~20 % faster small-model steps),
 :jit (recorded closures: 0 = interpret the program instead of compiling it)"
+const LOSS_KINDS = (; mse = 0, rmse = 1, mae = 2, nseLoss = 3, pearsonLoss = 4, kgeLoss = 5, pbkgeLoss = 6)
+"PerTarget((:mse, :mae)): one training loss per target, summed (src/losses/compute_loss.jl:128-145)"
+struct PerTarget{T <: Tuple}
+    losses::T
+end
+"training_loss = :mae (all targets alike) | PerTarget((...)) / a tuple or vector of symbols (one per target; mse / mae / nseLoss)"
+function set_training_loss!(e::HybridEngine, spec)
+    spec isa Symbol && return set_option!(e, :training_loss, LOSS_KINDS[spec])
+    kinds = Int32[LOSS_KINDS[k] for k in (spec isa PerTarget ? spec.losses : spec)]
+    check(e, @ccall LIB[].eh_set_target_losses(e.h::Ptr{Cvoid}, kinds::Ptr{Int32}, length(kinds)::Int32)::Int32)
+end
 set_option!(e::HybridEngine, name::Symbol, value::Integer) =
     check(e, @ccall LIB[].eh_set_option(e.h::Ptr{Cvoid}, String(name)::Cstring, value::Int64)::Int32)
 
@@ -649,7 +660,7 @@ function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt 
         shuffleobs = false, train_from = nothing, device = 0)
     nepochs >= 0 || throw(ArgumentError("nepochs must be >= 0"))                               # validate_config, TrainingConfig.jl:162-180
     batchsize >= 1 || throw(ArgumentError("batchsize must be >= 1"))
-    training_loss == :mse || throw(ArgumentError("this shim drives training_loss = :mse (the library's other losses: eh_set_option \"training_loss\")"))
+    training_loss isa Function && throw(ArgumentError("this shim has no tracer for a custom loss function (the Python front door records one: program.trace_loss)"))
     rng = random_seed === nothing ? Random.default_rng() : Random.Xoshiro(random_seed)
     tr, va = split_data(m, data; split_data_at, shuffleobs, rng)
     size(tr[1][1], 2) == 0 && return nothing                                                    # train.jl:186
@@ -659,6 +670,7 @@ function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt 
     ((xt, ft), yt), ((xv, fv), yv) = tr, va
     set_data!(e, EH_SPLIT_TRAIN, xt, ft, yt); set_data!(e, EH_SPLIT_VAL, xv, fv, yv)
     opt_init!(e; rule = o.rule, eta = o.eta, beta = o.beta, epsilon = o.epsilon, lambda = o.lambda)
+    set_training_loss!(e, training_loss)
     nt, nv = size(xt, 2), size(xv, 2)
     hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types)]
     best_loss = hist_v[1][1].sum; best_ps = get_params(e); best_epoch = 0; counter = 0

@@ -156,7 +156,15 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
         raise ValueError("return_model must be :best or :final")
     if not cfg.loss_types:
         raise ValueError("loss_types must not be empty")
-    if not callable(cfg.training_loss):                          # a function f(yhat, y) is recorded and compiled into the step kernel
+    from .engine import PerTarget
+    tl = cfg.training_loss
+    per_target = tl.losses if isinstance(tl, PerTarget) else (tl if isinstance(tl, (list, tuple)) and tl and not callable(tl[0]) else None)
+    if per_target is not None:                                   # PerTarget((l_1, ..., l_T)), compute_loss.jl:128-145
+        for lt in per_target:
+            check_training_loss(lt)
+            if lt not in L.TRAINING_LOSSES:
+                raise NotImplementedError(f"training_loss {lt!r}: the device implements {sorted(L.TRAINING_LOSSES)}")
+    elif not callable(tl) and not (isinstance(tl, (list, tuple)) and tl and callable(tl[0])):      # a function (or (f, args), (f, kwargs): loss_fn.jl:92-107) is recorded and compiled into the step kernel
         check_training_loss(cfg.training_loss)
         if cfg.training_loss not in L.TRAINING_LOSSES:
             raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements {sorted(L.TRAINING_LOSSES)} "

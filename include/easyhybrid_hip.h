@@ -380,6 +380,12 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
  * the training calls fail with EH_EUNSUPPORTED -- there is no interpreted or CPU form. */
 int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot);
 
+/* loss_spec = PerTarget((l_1, ..., l_T)) (src/losses/compute_loss.jl:128-145): target t is trained on its own loss, the total is
+ * their sum (agg = sum).  Built per target: EH_LOSS_MSE, EH_LOSS_MAE, EH_LOSS_NSELOSS -- the losses whose per-sample weight is a
+ * function of the targets alone (1 / n_t, 1 / n_t, 1 / sum (y - mean y)^2), found by a pre-pass; n must equal n_targets.  The same
+ * three are what eh_set_option("training_loss") accepts on a multi-target model. */
+int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n);
+
 /* EH_MECH_PROGRAM: how the recorded closure runs.  *n_compiled = kernel pairs (train + eval) compiled with hiprtc so far and in
  * use; 0 with a non-empty log = the build or a launch was refused and the handle runs the interpreting kernels instead
  * (same results, slower mechanistic stage).  log (optional) receives the compiler / failure message, NUL-terminated. */

@@ -647,7 +647,10 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
     loss = dt.type(0)
     dout = {}
     nvalid = []
-    for t in spec.targets:
+    kinds = list(kind) if isinstance(kind, (list, tuple)) else [kind] * len(spec.targets)      # PerTarget((l_1, ..., l_T)), compute_loss.jl:128-145
+    if len(kinds) != len(spec.targets):
+        raise AssertionError("Length of targets and PerTarget losses tuple must match")
+    for t, kind in zip(spec.targets, kinds):
         y = np.asarray(targets[t], dt)
         m = valid_mask(y)
         n = int(m.sum())

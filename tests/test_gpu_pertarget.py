@@ -1,0 +1,72 @@
+"""-m gpu: PerTarget training losses (src/losses/compute_loss.jl:128-145), non-MSE losses on multi-target models, and the tuple forms
+(f, args) / (f, kwargs) of a custom training loss (src/losses/loss_fn.jl:92-107), on every kernel family, against the fp64 oracle."""
+import numpy as np
+import pytest
+
+import easyhybrid_jl_amd as eh
+from oracle import hybrid_oracle as ho
+from tests import util
+
+pytestmark = pytest.mark.gpu
+PARS = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+
+
+def _flux_case(hidden, B=900, seed=8):
+    rng = np.random.default_rng(seed)
+    spec = ho.HybridSpec(6, list(hidden), "fluxpart", dict(PARS), ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((6, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][rng.random(B) < 0.2] = np.nan; y["GPP"][rng.random(B) < 0.1] = np.nan
+    return spec, ho.init_theta(spec, 3, np.float32), X, f, y
+
+
+@pytest.mark.parametrize("hidden", [(16, 16), (48, 48), (128, 96), (160, 96, 48, 24)])      # per-wave, per-wave 64-wide family, row-split, layer-wise
+@pytest.mark.parametrize("kinds", [("mse", "mae"), ("nseLoss", "mse"), ("mae", "mae"), ("nseLoss", "nseLoss")])
+def test_per_target_losses(hidden, kinds):
+    spec, theta, X, f, y = _flux_case(hidden)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(eh.PerTarget(kinds) if kinds[0] != kinds[1] else kinds[0])
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kinds)
+    assert nv == sum(nv0) and abs(loss - l0) <= 1e-5 * abs(l0) and util.relerr(grad, g0) <= 1e-5, (loss, l0, util.relerr(grad, g0))
+    eng.opt_init("Adam", 0.01)
+    batches = [(0, 300), (300, 300), (600, 300)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32, kind=kinds)
+    assert np.allclose(losses, l_ref, rtol=5e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 3e-5) >= 0.995
+    eng.close()
+
+
+def test_train_front_door_with_per_target_losses():
+    rng = np.random.default_rng(3)
+    n = 1200
+    cols = {f"x{i}": rng.standard_normal(n).astype(np.float32) for i in range(6)}
+    cols["SW_IN"] = (rng.random(n) * 400).astype(np.float32); cols["TA"] = (rng.random(n) * 30).astype(np.float32)
+    cols["NEE"] = rng.standard_normal(n).astype(np.float32); cols["GPP"] = (rng.random(n) * 3).astype(np.float32)
+    model = eh.constructHybridModel([f"x{i}" for i in range(6)], ["SW_IN", "TA"], ["NEE", "GPP"], eh.FluxPartModelQ10, dict(PARS), ["RUE", "Rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=3, batchsize=200, training_loss=eh.PerTarget(("mae", "mse")), random_seed=1)
+    assert len(out.val_history) == 4 and np.isfinite(out.best_loss)
+    with pytest.raises(AssertionError):
+        eh.train(model, cols, nepochs=1, batchsize=200, training_loss=eh.PerTarget(("mae",)), random_seed=1)
+    with pytest.raises(NotImplementedError):
+        eh.train(model, cols, nepochs=1, batchsize=200, training_loss=eh.PerTarget(("kgeLoss", "mse")), random_seed=1)
+
+
+def test_tuple_forms_of_a_custom_training_loss():
+    """training_loss = (f, args) / (f, kwargs): f(yhat[mask], y[mask], args...; kwargs...)   (loss_fn.jl:92-107)"""
+    def huber(yh, y, delta):
+        r = yh - y
+        return np.mean(np.where(np.abs(r) <= delta, 0.5 * r * r, delta * (np.abs(r) - 0.5 * delta)))
+    spec, theta, X, f, y = util.rbq10_case(800, "tanh", True, 0.1)
+    name = util.register_loss("huber_0p7", lambda yh, y: huber(yh, y, 0.7)) and "huber_0p7"
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=name)
+    for form in ((huber, (0.7,)), (huber, {"delta": 0.7}), (huber, (), {"delta": 0.7})):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_training_loss(form)
+        loss, grad, _ = eng.loss_and_grad()
+        assert abs(loss - l0) <= 1e-5 * abs(l0) and util.relerr(grad, g0) <= 2e-5
+        eng.close()

@@ -251,3 +251,25 @@ def test_three_forcing_components_model_vjp():
     l0, g0, _ = ho.loss_and_grad(spec, theta, X, f, y)
     l1, g1 = tt.loss_and_grad(spec, theta, X, f, y)
     assert abs(l0 - l1) <= 1e-12 * abs(l1) and np.max(np.abs(g0 - g1)) <= 1e-11 * np.max(np.abs(g1))
+
+
+def test_per_target_losses_vjp_matches_finite_differences():
+    """PerTarget((l_1, l_2)) (compute_loss.jl:128-145): each target its own loss, summed; hand VJP against central differences"""
+    rng = np.random.default_rng(4)
+    B = 80
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(3, [8], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((3, B)); f = {"SW_IN": rng.random(B) * 400, "TA": rng.random(B) * 30}
+    y = {"NEE": rng.standard_normal(B), "GPP": rng.random(B) * 3}
+    y["NEE"][rng.random(B) < 0.2] = np.nan
+    theta = ho.init_theta(spec, 5, np.float64)
+    for kinds in (("mse", "mae"), ("nseLoss", "mse"), ("mae", "nseLoss")):
+        l0, g0, _ = ho.loss_and_grad(spec, theta, X, f, y, kind=kinds)
+        ref = sum(ho.loss_fn(ho.forward(spec, theta, X, f)[t], y[t], ho.valid_mask(y[t]), k) for t, k in zip(spec.targets, kinds))
+        assert l0 == pytest.approx(ref, rel=1e-13)
+        for i in rng.choice(theta.size, 12, replace=False):
+            e = np.zeros_like(theta); e[i] = 1e-6
+            lp = ho.loss_and_grad(spec, theta + e, X, f, y, kind=kinds)[0]; lm = ho.loss_and_grad(spec, theta - e, X, f, y, kind=kinds)[0]
+            assert (lp - lm) / 2e-6 == pytest.approx(g0[i], rel=2e-5, abs=1e-8)
+    with pytest.raises(AssertionError):
+        ho.loss_and_grad(spec, theta, X, f, y, kind=("mse",))
