@@ -302,10 +302,22 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     float th = 0.0f, mm = 0.0f, vv = 0.0f, bt1 = 0.0f, bt2 = 0.0f;
     if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; }
     if (!APPLY && l2val && q == 0 && idx < n_theta) th = theta[idx];
+    // (all of a thread's rows in flight at once: the step is one memory round trip, not nblk / NQ / 16 of them)
     float s = 0.0f;
     if (idx < n_acc) {
+        const float* col = slab + (size_t)q * n_acc + idx;
+        const size_t rstride = (size_t)NQ * n_acc;
+        int r = q;
+        for (; r + 31 * NQ < nblk; r += 32 * NQ) {
+            float t[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t[u] = col[u * rstride];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += t[u];
+            col += 32 * rstride;
+        }
 #pragma unroll 16
-        for (int r = q; r < nblk; r += NQ) s += slab[(size_t)r * n_acc + idx];
+        for (; r < nblk; r += NQ) { s += *col; col += rstride; }
     }
     part[q][p] = s;
     // valid counts: every block needs them (nblk <= 256: one row per thread)
@@ -962,7 +974,7 @@ enum { EH_LFORM_ROWS = 32 };      // partial slabs of the weight gradients (spli
 
 static bool arch_fits(const EhArchInfo* A, int need) {
     for (int vi = 0; vi < A->nvar; ++vi)
-        if ((long long)A->var[vi].nw * need > A->var[vi].red_floats) return false;
+        if ((long long)(A->var[vi].nw / 2) * need > A->var[vi].red_floats) return false;      // (half the waves park at a time where all of them do not fit: eh_step_body, workgroup reduction)
     return true;
 }
 

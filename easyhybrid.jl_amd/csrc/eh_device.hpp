@@ -518,6 +518,22 @@ __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigne
 // ------------------------------------------------------------------------------------------
 // LDS / image geometry (floats).  Shared by host (image packing, size query) and device.
 // ------------------------------------------------------------------------------------------
+// Order of the per-lane f32x4 gradient accumulators as the step kernel parks them in LDS for the
+// end-of-kernel reduction ("v2" layout: region[k][lane][r], then 16 scalars).  Shared with the host,
+// which builds the canonical-index -> region-position map (rmap) from it.
+struct EhAccLayout { int kw0, nw0, kwh, nwh, kwo, kb, kbo, na, rw; };
+__host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl, int fast) {
+    EhAccLayout L{};
+    L.kw0 = 0; L.nw0 = (fast & 2) ? nbh * 4 : nbh * nbi;
+    L.kwh = L.kw0 + L.nw0; L.nwh = (nl - 1) * nbh * nbh;
+    L.kwo = L.kwh + L.nwh;
+    L.kb = L.kwo + nbh;
+    L.kbo = L.kb + nl * nbh;
+    L.na = L.kbo + ((fast & 1) ? 0 : 1);
+    L.rw = L.na * 256 + 16;      // tail scalars: [0..7] global-param sums, [8] loss, [9..12] counts, [13] output bias (K1)
+    return L;
+}
+
 template <int NBI, int NBH, int NL, int NT, int NW>
 struct EhGeom {
     static constexpr int MT = 16 * NT;          // samples per macro-tile
@@ -534,28 +550,15 @@ struct EhGeom {
     static constexpr int IMG_FLOATS = PHI_OFF + EH_IMG_META;         // multiple of 4
     // per-wave workspace
     static constexpr int XS_OFF = 0;
-    static constexpr int HS_OFF = XS_OFF + IP * SR;                  // NL images of HP rows
-    static constexpr int DZ_OFF = HS_OFF + NL * HP * SR;
-    static constexpr int OS_OFF = DZ_OFF + HP * SR;                  // 16 rows
-    static constexpr int WAVE_WS = OS_OFF + 16 * SR;
+    static constexpr int HS_OFF = XS_OFF + IP * SR;                  // NL images of HP rows; in the backward pass layer l's delta replaces its activations in place
+    static constexpr int OS_OFF = HS_OFF + NL * HP * SR;             // 16 rows
+    static constexpr int WS_MIN = OS_OFF + 16 * SR;
+    // the end-of-kernel reduction parks every lane's raw accumulators in the wave's workspace ("v2", EhAccLayout::rw floats) where
+    // that fits within one more image of HP rows -- the room a separate delta image used to take
+    static constexpr int RW0 = eh_acc_layout(NBI, NBH, NL, 0).rw;
+    static constexpr int WAVE_WS = (RW0 > WS_MIN && RW0 <= WS_MIN + HP * SR) ? RW0 : WS_MIN;
     static constexpr int TOTAL_FLOATS = IMG_FLOATS + NW * WAVE_WS;
 };
-
-// Order of the per-lane f32x4 gradient accumulators as the step kernel parks them in LDS for the
-// end-of-kernel reduction ("v2" layout: region[k][lane][r], then 16 scalars).  Shared with the host,
-// which builds the canonical-index -> region-position map (rmap) from it.
-struct EhAccLayout { int kw0, nw0, kwh, nwh, kwo, kb, kbo, na, rw; };
-__host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl, int fast) {
-    EhAccLayout L{};
-    L.kw0 = 0; L.nw0 = (fast & 2) ? nbh * 4 : nbh * nbi;
-    L.kwh = L.kw0 + L.nw0; L.nwh = (nl - 1) * nbh * nbh;
-    L.kwo = L.kwh + L.nwh;
-    L.kb = L.kwo + nbh;
-    L.kbo = L.kb + nl * nbh;
-    L.na = L.kbo + ((fast & 1) ? 0 : 1);
-    L.rw = L.na * 256 + 16;      // tail scalars: [0..7] global-param sums, [8] loss, [9..12] counts, [13] output bias (K1)
-    return L;
-}
 
 #ifdef EH_STAMPS
 #define EH_STAMP(i)                                                                      \
@@ -576,6 +579,9 @@ __host__ __device__ constexpr EhAccLayout eh_acc_layout(int nbi, int nbh, int nl
 #define EH_STAMP_FINE(i)
 #endif
 
+#ifndef EH_KEEPH_MAX
+#define EH_KEEPH_MAX 64
+#endif
 // Orders one wave's LDS traffic: what its lanes wrote before is visible to what any of its lanes reads after (the hardware
 // runs a wave's LDS operations in order; the fence is for the compiler, and it is acquire + release: a release-only fence
 // would leave later READS free to move up across it).
@@ -611,7 +617,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     constexpr bool K1 = (FAST & 1) != 0, PS = (FAST & 2) != 0;
     constexpr bool PROG = (FAST & 4) != 0;                // EH_MECH_PROGRAM: the mechanistic stage interprets a.prog
     static_assert(!PROG || FAST == 4, "the program kernels are generic kernels");
-    constexpr bool KEEPH = TRAIN && !EhStoresZ<ACT>::value && NL * NBH * NT * 4 <= 64;   // activations stay in registers for act'
+    constexpr bool KEEPH = TRAIN && !EhStoresZ<ACT>::value && NL * NBH * NT * 4 <= EH_KEEPH_MAX;   // activations stay in registers for act'
     constexpr int NHS = KEEPH ? NL : 1, NHM = KEEPH ? NBH : 1, NHT = KEEPH ? NT : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;
@@ -622,7 +628,6 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     float* const ws = smem + G::IMG_FLOATS + wave * G::WAVE_WS;
     float* const XS = ws + G::XS_OFF;
     float* const HS = ws + G::HS_OFF;
-    float* const DZ = ws + G::DZ_OFF;
     float* const OS = ws + G::OS_OFF;
     const float* const meta = wl + G::PHI_OFF;
     auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
@@ -1149,7 +1154,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
             for (int t = 0; t < NT; ++t) dOt[t] = __shfl(dOm, 16 * t + c, 64);   // sample 16t + c lives in lane 16t + c
             aBoS += dOm;
-            const float* Hl = HS + (NL - 1) * HP * SR;
+            float* const Hl = HS + (NL - 1) * HP * SR;
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
                 const f32x4 w4 = *(const f32x4*)&wl[G::WO_OFF + 16 * m + 4 * g];
@@ -1163,7 +1168,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                         aWoV[m][r] = fmaf(dOt[t], hv, aWoV[m][r]);
                         const float d = w4[r] * dOt[t] * eh_dact_row<ACT>(sv, NL - 1, 16 * m + 4 * g + r);
                         dz[m][t][r] = d;
-                        if constexpr (DZ_LAST) DZ[ad] = d;
+                        if constexpr (DZ_LAST) Hl[ad] = d;         // delta replaces the activation it was derived from (same lane, same word)
                     }
                     aB[NL - 1][m] += dz[m][t];
                 }
@@ -1178,7 +1183,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 aT[t] = *(const f32x4*)&OS[c * SR + 16 * t + 4 * g];
                 aBo += dO[t];
             }
-            const float* Hl = HS + (NL - 1) * HP * SR;
+            float* const Hl = HS + (NL - 1) * HP * SR;
 #pragma unroll
             for (int n = 0; n < NBH; ++n)
 #pragma unroll
@@ -1214,7 +1219,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                         const float sv = KEEPH ? hs[NL - 1 < NHS ? NL - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hl[ad];
                         const float d = dh[t][r] * eh_dact_row<ACT>(sv, NL - 1, 16 * m + 4 * g + r);
                         dz[m][t][r] = d;
-                        if constexpr (DZ_LAST) DZ[ad] = d;
+                        if constexpr (DZ_LAST) Hl[ad] = d;
                     }
                     aB[NL - 1][m] += dz[m][t];
                 }
@@ -1224,7 +1229,8 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         for (int l = NL - 1; l >= 1; --l) {
             EH_WAVE_SYNC();
             // dW_l += dZ_l * H_{l-1}^T
-            const float* Hp = HS + (l - 1) * HP * SR;
+            float* const Hp = HS + (l - 1) * HP * SR;
+            const float* const DZ = HS + l * HP * SR;
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
                 f32x4 aT[NT];
@@ -1273,7 +1279,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                         const float sv = KEEPH ? hs[l - 1 < NHS ? l - 1 : 0][m < NHM ? m : 0][t < NHT ? t : 0][r] : Hp[ad];
                         const float d = dn[m][t][r] * eh_dact_row<ACT>(sv, l - 1, 16 * m + 4 * g + r);
                         dz[m][t][r] = d;
-                        if (need_dz) DZ[ad] = d;
+                        if (need_dz) Hp[ad] = d;
                     }
                     aB[l - 1][m] += dz[m][t];
                 }
@@ -1295,6 +1301,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                         for (int r = 0; r < 4; ++r) aW0V[m][pp][r] = fmaf(dz[m][t][r], xv[pp][t], aW0V[m][pp][r]);
         } else {
             EH_WAVE_SYNC();
+            const float* const DZ = HS;
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
                 f32x4 aT[NT];
@@ -1407,7 +1414,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     EH_STAMP(13);
     __syncthreads();                               // the wave workspaces are dead from here on
     EH_STAMP(14);
-    float* const RED = smem + G::IMG_FLOATS + wave * a.n_acc;
+    // The waves' canonical-order regions share the space of the (dead) wave workspaces.  Where NW regions do not fit, the upper
+    // half of the waves parks first and the lower half adds its own sums on top (one more barrier per halving).
+    int nreg = NW;
+    if constexpr (TRAIN) { while (nreg > 1 && nreg * a.n_acc > NW * G::WAVE_WS) nreg >>= 1; }
+    float* const RED = smem + G::IMG_FLOATS + (wave & (nreg - 1)) * a.n_acc;
     if constexpr (!TRAIN) {
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t)
@@ -1454,12 +1465,13 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         // (handles padding, bias rows and the block-diagonal MultiNN placement alike)
         struct I4 { int x, y, z, w; };
         const I4* const cm = reinterpret_cast<const I4*>(a.cmap);
+        for (int round = NW / nreg - 1; round >= 0; --round) {
+        if (wave / nreg == round) {
+        const bool add = round != NW / nreg - 1;
+        auto put1 = [&](int i, float v) { if (i >= 0) RED[i] = add ? RED[i] + v : v; };
         auto putc = [&](int k, const f32x4& v) {
             const I4 ix = cm[k * 64 + lane];
-            if (ix.x >= 0) RED[ix.x] = v[0];
-            if (ix.y >= 0) RED[ix.y] = v[1];
-            if (ix.z >= 0) RED[ix.z] = v[2];
-            if (ix.w >= 0) RED[ix.w] = v[3];
+            put1(ix.x, v[0]); put1(ix.y, v[1]); put1(ix.z, v[2]); put1(ix.w, v[3]);
         };
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
@@ -1479,20 +1491,23 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             for (int l = 0; l < NL; ++l) putc(AL.kb + l * NBH + m, aB[l][m]);
         }
         if constexpr (K1) {
-            if (lane == 0) RED[b_off[NL]] = aBoS;
+            if (lane == 0) put1(b_off[NL], aBoS);
         } else {
             putc(AL.kbo, aBo);
         }
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < EH_MAX_PARAMS; ++j)
-                if (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) RED[net.g_off + pidx(j)] = gacc[j];
-            RED[net.n_theta] = lacc;
+                if (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) put1(net.g_off + pidx(j), gacc[j]);
+            put1(net.n_theta, lacc);
 #pragma unroll
             for (int t = 0; t < EH_MAX_TARG; ++t)
-                if (t < net.T) RED[net.n_theta + 1 + t] = cacc[t];
-            RED[net.n_theta + 1 + net.T] = syacc;
-            RED[net.n_theta + 2 + net.T] = syyacc;
+                if (t < net.T) put1(net.n_theta + 1 + t, cacc[t]);
+            put1(net.n_theta + 1 + net.T, syacc);
+            put1(net.n_theta + 2 + net.T, syyacc);
+        }
+        }
+        if (round > 0) __syncthreads();
         }
     }
     EH_STAMP(12);
@@ -1504,8 +1519,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         float* const gsh = (TRAIN && a.fz.gacc) ? (P2PM ? a.p2pv.stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             float s = R0[e];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) s += R0[w * a.n_acc + e];
+            for (int w = 1; w < nreg; ++w) s += R0[w * a.n_acc + e];
             if (gsh) atomicAdd(&gsh[e], s);
             else out[e] = s;
         }

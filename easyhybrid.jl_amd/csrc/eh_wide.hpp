@@ -32,7 +32,8 @@ struct EhWideGeom : EhGeom<NBI, NBH, NL, NT, 1> {
     using B = EhGeom<NBI, NBH, NL, NT, 1>;
     static_assert(NBH % NWV == 0, "the waves split the feature blocks evenly");
     static_assert(NWV * 16 <= B::HP, "the split-K output partials alias the delta image");
-    static constexpr int RS_OFF = B::WAVE_WS;                           // forcings (rows 0..3) and targets (rows 4..7) of the tile
+    static constexpr int DZ_OFF = B::WS_MIN;                            // the delta image (the waves share the tile: not in place as in the per-wave kernel)
+    static constexpr int RS_OFF = DZ_OFF + B::HP * B::SR;               // forcings (rows 0..3) and targets (rows 4..7) of the tile
     static constexpr int SG_OFF = RS_OFF + (EH_MAX_FORC + EH_MAX_TARG) * B::SR;   // d(parameter)/d(network output), 16 rows
     static constexpr int WS_FLOATS = SG_OFF + 16 * B::SR;
     static constexpr int TOTAL_FLOATS = B::IMG_FLOATS + WS_FLOATS;      // one shared workspace per workgroup

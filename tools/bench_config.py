@@ -21,7 +21,7 @@ a = ap.parse_args()
 if a.config == "c3":
     B = a.batch or 262144
     model = eh.constructHybridModel([f"x{i}" for i in range(8)], ["T"], ["Resp_obs"], eh.Expo2Pool, dict(EXPO2POOL_PARAMS),
-                                    ["R0a", "ka", "R0b", "kb"], [], hidden_layers=[64, 64], activation="tanh", scale_nn_outputs=True)
+                                    ["R0a", "ka", "R0b", "kb"], [], hidden_layers=[64, 64], activation="tanh", scale_nn_outputs=True, **({"precision": a.precision} if a.precision else {}))
     cols = make_synth_expo2pool(a.nbatches * B, 1)
     X = np.stack([cols[f"x{i}"] for i in range(8)]); F = [cols["T"]]; Y = [cols["Resp_obs"]]
     flop, byts = 29184, 40
