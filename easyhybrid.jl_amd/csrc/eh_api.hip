@@ -656,7 +656,6 @@ struct eh_handle_s {
     float* image = nullptr;
     int* imap = nullptr;
     int* rmap = nullptr;            // v2 reduction map for the current fast-path flags
-    int* cmap = nullptr;            // accumulator element -> canonical index (reduction of the wide shapes)
     // block placement of every net inside the padded (block-diagonal) MLP
     int n_nets = 1;                                     // 1 for SingleNN
     int net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0};
@@ -853,7 +852,7 @@ static std::vector<EhEntry> enumerate_entries(const eh_handle* h) {
 }
 
 // canonical index -> parameter-image offset; canonical index <-> accumulator element of the step
-// kernel (rmap for the v2 reduction region, cmap for the canonical-order region; see eh_acc_layout)
+// kernel (rmap: where the element sits among the parked accumulators; see eh_acc_layout)
 static int build_maps(eh_handle* h, bool with_imap) {
     const eh_model_desc& d = h->desc;
     const EhNet& n = h->net;
@@ -863,9 +862,10 @@ static int build_maps(eh_handle* h, bool with_imap) {
     const std::vector<EhEntry> ent = enumerate_entries(h);
     const int nwv = A->wide ? A->var[h->variant].nw : 4;
     const EhWideLayout WL = eh_wide_layout(nbi, nbh, nl, nwv);
-    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0), cmap((size_t)L.na * 256, -1);
-    auto at = [](int k, int lane, int r) { return k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15); };   // v2 region[k][g][r][c]
-    auto cm = [](int k, int lane, int r) { return k * 256 + lane * 4 + r; };                              // cmap[k][lane][r]
+    std::vector<int> imap((size_t)n.n_theta, -1), rmap((size_t)h->n_acc, 0);
+    // v2 region[k][g][r][c] where one wave workspace holds a wave's raw accumulators, else v3 region[k][c][g][r] (eh_step_body, workgroup reduction)
+    const bool v2 = A->wide || L.rw <= A->var[h->variant].red_floats / A->var[h->variant].nw;
+    auto at = [v2](int k, int lane, int r) { return v2 ? k * 256 + (lane >> 4) * 64 + r * 16 + (lane & 15) : k * 256 + (lane & 15) * 16 + (lane >> 4) * 4 + r; };
     for (const EhEntry& e : ent) {
         const int m = e.row / 16, g = (e.row % 16) / 4, r = e.row % 4;
         int img, k, lane, rr, nlan;
@@ -908,7 +908,7 @@ static int build_maps(eh_handle* h, bool with_imap) {
             continue;
         }
         if (k < 0) { rmap[e.canon] = (L.na * 256 + 13) | (1 << 24); }
-        else { rmap[e.canon] = at(k, lane, rr) | (nlan << 24); cmap[cm(k, lane, rr)] = e.canon; }
+        else rmap[e.canon] = at(k, lane, rr) | (nlan << 24);
     }
     for (int j = 0; j < d.n_params; ++j)
         if (d.param_kind[j] == EH_PAR_GLOBAL) rmap[n.g_off + d.param_index[j]] = (L.na * 256 + j) | (1 << 24);
@@ -923,10 +923,6 @@ static int build_maps(eh_handle* h, bool with_imap) {
     }
     if (!h->rmap) HIPCHK(h, hipMalloc(&h->rmap, rmap.size() * sizeof(int)));
     HIPCHK(h, hipMemcpy(h->rmap, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice));
-    (void)hipFree(h->cmap);
-    h->cmap = nullptr;
-    HIPCHK(h, hipMalloc(&h->cmap, cmap.size() * sizeof(int)));
-    HIPCHK(h, hipMemcpy(h->cmap, cmap.data(), cmap.size() * sizeof(int), hipMemcpyHostToDevice));
     return EH_OK;
 }
 
@@ -974,7 +970,7 @@ enum { EH_LFORM_ROWS = 32 };      // partial slabs of the weight gradients (spli
 
 static bool arch_fits(const EhArchInfo* A, int need) {
     for (int vi = 0; vi < A->nvar; ++vi)
-        if ((long long)(A->var[vi].nw / 2) * need > A->var[vi].red_floats) return false;      // (half the waves park at a time where all of them do not fit: eh_step_body, workgroup reduction)
+        if ((long long)(A->var[vi].nw / 2) * need > A->var[vi].red_floats) return false;      // (family choice, not a hard limit: a gradient this large relative to the workspaces is summed across the waves in several rounds, the row-split kernel needs no such sum)
     return true;
 }
 
@@ -1244,7 +1240,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->n_par = d->n_params;
     h->n_acc = n.n_theta + 1 + n.T + 2;      // [grad | S | n_valid per target | Sy | Syy]
     if (!lform && !arch_fits(arch, std::max(h->n_acc, EH_EVAL_STATS * n.T))) {
-        // the per-wave kernel parks one gradient copy per wave in LDS; the row-split kernel needs none
+        // the per-wave kernel parks every wave's accumulators in LDS to sum them; the row-split kernel needs no such sum
         if (!wide_arch) {
             delete h;
             return fail(nullptr, EH_EUNSUPPORTED, "eh_create: %d accumulators exceed the kernel's reduction space", n.n_theta + 1 + n.T);
@@ -1378,7 +1374,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->wflag);
-    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap); (void)hipFree(h->cmap);
+    (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1570,11 +1566,8 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
         if (h->arch->var[value].bf16 != h->arch->var[h->variant].bf16) return fail(h, EH_EINVAL, "variant %lld belongs to the other precision (set the \"precision\" option)", (long long)value);
         h->variant = (int)value;
-        if (h->arch->wide) {                 // the scatter map depends on the number of waves
-            HIPCHK(h, hipSetDevice(h->device));
-            return build_maps(h, false);
-        }
-        return EH_OK;
+        HIPCHK(h, hipSetDevice(h->device));      // the reduction map depends on the variant (waves of a row-split workgroup; layout of the parked accumulators)
+        return build_maps(h, false);
     }
     return fail(h, EH_EINVAL, "unknown option %s", name);
 }
@@ -1840,7 +1833,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         EhStepArgs e{};
         e.prog = h->prog;
         e.recs = sp.recs; e.C = h->C; e.idx = idx; e.first = first; e.count = count;
-        e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.cmap = h->cmap; e.stamps = nullptr;
+        e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.stamps = nullptr;
         e.yld = count;
         for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
         if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
@@ -1859,7 +1852,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc;
     a.inv_n = (net.T > 1 || moment_loss) ? h->inv_n : nullptr;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
-    a.rmap = h->rmap; a.cmap = h->cmap;
+    a.rmap = h->rmap;
     a.stamps = h->stamps;
     a.fz.gacc = nullptr;
     if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &a)) return rc;
@@ -1882,7 +1875,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     EhStepArgs a{};
     a.prog = h->prog;
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
-    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.cmap = h->cmap; a.stamps = h->stamps;
+    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;

@@ -140,8 +140,7 @@ struct EhStepArgs {
     int n_acc;            // train: n_theta + 1 + T ; eval: EH_EVAL_STATS*T
     const float* inv_n;   // train: per-target 1/n_t (device) or nullptr = deferred normalisation (weight 1)
     float* yhat;          // eval (optional): [T][yld] predictions for samples first..first+count
-    const int* rmap;      // train: canonical index -> (position | lanes<<24) in the v2 reduction region
-    const int* cmap;      // train: [accumulator k][lane][r] -> canonical index or -1 (reduction of the wide shapes)
+    const int* rmap;      // train: canonical index -> (position | lanes<<24) among the parked accumulators (v2 / v3 workgroup reduction; row-split staging)
     float* pout;          // eval (optional): [n_par][yld] physical parameters per sample
     long long yld;
     float shift[EH_MAX_TARG];   // eval: metric shift c_t
@@ -579,6 +578,12 @@ struct EhGeom {
 #define EH_STAMP_FINE(i)
 #endif
 
+// Nothing moves across: keeps a block of LDS requests in front of the MFMA chain it is meant to hide behind.
+#ifdef EH_NO_SCHED_FENCE
+#define EH_SCHED_FENCE()
+#else
+#define EH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef EH_KEEPH_MAX
 #define EH_KEEPH_MAX 64
 #endif
@@ -954,20 +959,32 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             const float* W = wl + G::WH_OFF + (l - 1) * HP * SH;
             float* Hl = HS + l * HP * SR;
             f32x4 hn[NBH][NT];
+            // (the A operands of row block m + 1 are requested before the MFMA chain of block m is issued: a wave issues in
+            //  order, so a load placed right in front of its use exposes the whole LDS latency once per block)
+            f32x4 a4c[NBH], a4n[NBH];
+#pragma unroll
+            for (int q = 0; q < NBH; ++q) a4c[q] = *(const f32x4*)&W[c * SH + 16 * q + 4 * g];
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
                 const f32x4 bias = *(const f32x4*)&wl[G::B_OFF + l * HP + 16 * m + 4 * g];
+                if (m + 1 < NBH) {
+#pragma unroll
+                    for (int q = 0; q < NBH; ++q) a4n[q] = *(const f32x4*)&W[(16 * (m + 1) + c) * SH + 16 * q + 4 * g];
+                }
+                EH_SCHED_FENCE();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) hn[m][t] = bias;
 #pragma unroll
                 for (int q = 0; q < NBH; ++q) {
-                    const f32x4 a4 = *(const f32x4*)&W[(16 * m + c) * SH + 16 * q + 4 * g];
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            hn[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], h[q][t][s], hn[m][t], 0, 0, 0);
+                            hn[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4c[q][s], h[q][t][s], hn[m][t], 0, 0, 0);
                 }
+                EH_SCHED_FENCE();
+#pragma unroll
+                for (int q = 0; q < NBH; ++q) a4c[q] = a4n[q];
             }
 #pragma unroll
             for (int m = 0; m < NBH; ++m)
@@ -1231,41 +1248,72 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             // dW_l += dZ_l * H_{l-1}^T
             float* const Hp = HS + (l - 1) * HP * SR;
             const float* const DZ = HS + l * HP * SR;
+            // (the B operands -- the previous layer's activations in operand order -- do not depend on the row block: read once;
+            //  the A operands of block m + 1 are requested ahead of block m's MFMA chain, as in the forward pass)
+            f32x4 bH[NBH][NT];
+#pragma unroll
+            for (int n = 0; n < NBH; ++n)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bH[n][t] = *(const f32x4*)&Hp[(16 * n + c) * SR + 16 * t + 4 * g];
+                    if (EhStoresZ<ACT>::value) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) bH[n][t][s] = eh_hval<ACT>(bH[n][t][s], l - 1, 16 * n + c);
+                    }
+                }
+            f32x4 aTc[NT], aTn[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) aTc[t] = *(const f32x4*)&DZ[c * SR + 16 * t + 4 * g];
+            const float* W = wl + G::WH_OFF + (l - 1) * HP * SH;
+            float avc[NBH][4], avn[NBH][4];
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
-                f32x4 aT[NT];
+                if (m + 1 < NBH) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) aT[t] = *(const f32x4*)&DZ[(16 * m + c) * SR + 16 * t + 4 * g];
+                    for (int t = 0; t < NT; ++t) aTn[t] = *(const f32x4*)&DZ[(16 * (m + 1) + c) * SR + 16 * t + 4 * g];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NBH; ++q)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) avc[q][s] = W[(16 * q + 4 * g + s) * SH + c];
+                }
+                EH_SCHED_FENCE();
 #pragma unroll
                 for (int n = 0; n < NBH; ++n)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        f32x4 b4 = *(const f32x4*)&Hp[(16 * n + c) * SR + 16 * t + 4 * g];
-                        if (EhStoresZ<ACT>::value) {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) b4[s] = eh_hval<ACT>(b4[s], l - 1, 16 * n + c);
-                        }
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
-                            aWh[l - 1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWh[l - 1][m][n], 0, 0, 0);
-                    }
+                            aWh[l - 1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aTc[t][s], bH[n][t][s], aWh[l - 1][m][n], 0, 0, 0);
+                EH_SCHED_FENCE();
+#pragma unroll
+                for (int t = 0; t < NT; ++t) aTc[t] = aTn[t];
             }
             // dH_{l-1} = W_l^T dZ_l ; dZ_{l-1} = dH ⊙ act'
-            const float* W = wl + G::WH_OFF + (l - 1) * HP * SH;
             f32x4 dn[NBH][NT];
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
+                if (m + 1 < NBH) {
+#pragma unroll
+                    for (int q = 0; q < NBH; ++q)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) avn[q][s] = W[(16 * q + 4 * g + s) * SH + 16 * (m + 1) + c];
+                }
+                EH_SCHED_FENCE();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dn[m][t] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < NBH; ++q)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const float av = W[(16 * q + 4 * g + s) * SH + 16 * m + c];
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            dn[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dz[q][t][s], dn[m][t], 0, 0, 0);
-                    }
+                            dn[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(avc[q][s], dz[q][t][s], dn[m][t], 0, 0, 0);
+                EH_SCHED_FENCE();
+#pragma unroll
+                for (int q = 0; q < NBH; ++q)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) avc[q][s] = avn[q][s];
             }
             EH_WAVE_SYNC();
             const bool need_dz = l > 1 || !PS;
@@ -1403,127 +1451,136 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         EH_STAMP(10);
         return;
     }
-    float gscale[EH_MAX_PARAMS];
+    // v3 (shapes whose raw accumulators do not fit one wave workspace): as v2, but the waves park KH accumulators at a time --
+    // region[kk][c][g][r], one 16-byte store per lane and accumulator, bank-conflict free -- and every canonical element is
+    // gathered in the round that holds its accumulator.  (A canonical-order region per wave, "v1" below, costs sixteen-way
+    // bank conflicts on every scattered store: consecutive lanes of a weight block are one output-width apart.)
+    constexpr int KH = (G::WAVE_WS - 16) / 256;
+    constexpr bool REDV3 = TRAIN && !REDV2 && KH >= 1;
+    if constexpr (REDV3) {
+        constexpr int NR = (AL.na + KH - 1) / KH;
+        // every map entry this thread will need, requested before anything else: one global round trip for the whole epilogue
+        constexpr int MAXACC = G::IP * HP + (NL - 1) * HP * HP + 16 * HP + NL * HP + 16 + EH_MAX_PARAMS + 1 + EH_MAX_TARG + 2;
+        constexpr int NE = (MAXACC + NTHR - 1) / NTHR;
+        int code[NE];
 #pragma unroll
-    for (int j = 0; j < EH_MAX_PARAMS; ++j) gscale[j] = meta[EH_IMG_DPHI + j];
-    int w_off[NL + 1], b_off[NL + 1], width[NL];
-#pragma unroll
-    for (int l = 0; l <= NL; ++l) { w_off[l] = __float_as_int(meta[EH_IMG_WOFF + l]); b_off[l] = __float_as_int(meta[EH_IMG_BOFF + l]); }
-#pragma unroll
-    for (int l = 0; l < NL; ++l) width[l] = __float_as_int(meta[EH_IMG_WIDTH + l]);
-    EH_STAMP(13);
-    __syncthreads();                               // the wave workspaces are dead from here on
-    EH_STAMP(14);
-    // The waves' canonical-order regions share the space of the (dead) wave workspaces.  Where NW regions do not fit, the upper
-    // half of the waves parks first and the lower half adds its own sums on top (one more barrier per halving).
-    int nreg = NW;
-    if constexpr (TRAIN) { while (nreg > 1 && nreg * a.n_acc > NW * G::WAVE_WS) nreg >>= 1; }
-    float* const RED = smem + G::IMG_FLOATS + (wave & (nreg - 1)) * a.n_acc;
-    if constexpr (!TRAIN) {
-#pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t)
-#pragma unroll
-            for (int k = 0; k < EH_EVAL_STATS; ++k) {
-                const float v = eh_wave_sum(est[t][k]);
-                if (t < net.T && lane == 0) RED[t * EH_EVAL_STATS + k] = v;
-            }
-    } else {
-#pragma unroll
-        for (int m = 0; m < NBH; ++m) {
-#pragma unroll
-            for (int l = 0; l < NL; ++l)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) aB[l][m][r] = eh_row16_sum(aB[l][m][r]);
-            if constexpr (K1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) aWoV[m][r] = eh_row16_sum(aWoV[m][r]);
-            }
-            if constexpr (PS) {
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) aW0V[m][pp][r] = eh_row16_sum(aW0V[m][pp][r]);
-            }
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + u * NTHR;
+            code[u] = e < a.n_acc ? (u == 0 ? f_rcode : a.rmap[e]) : -1;
         }
-        if constexpr (K1) aBoS = eh_wave_sum(aBoS);
-        else {
+        float tailv[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aBo[r] = eh_row16_sum(aBo[r]);
-        }
-        lacc = eh_wave_sum(lacc); syacc = eh_wave_sum(syacc); syyacc = eh_wave_sum(syyacc);
-#ifdef EH_DBG_LACC
-        if (a.stamps && blockIdx.x == 0 && lane == 0) reinterpret_cast<float*>(a.stamps)[16 + wave] = lacc;      // ... and after
-#endif
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) tailv[j] = (j < net.n_par) ? eh_wave_sum(gacc[j]) * meta[EH_IMG_DPHI + j] : 0.0f;
+        tailv[8] = eh_wave_sum(lacc);
 #pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t)
-            if (t < net.T) cacc[t] = eh_wave_sum(cacc[t]);
-#pragma unroll
-        for (int j = 0; j < EH_MAX_PARAMS; ++j)
-            if (j < net.n_par) gacc[j] = eh_wave_sum(gacc[j]) * gscale[j];
-        EH_STAMP(11);
-        // scatter the accumulators into the wave's canonical-order region through the host-built map
-        // (handles padding, bias rows and the block-diagonal MultiNN placement alike)
-        struct I4 { int x, y, z, w; };
-        const I4* const cm = reinterpret_cast<const I4*>(a.cmap);
-        for (int round = NW / nreg - 1; round >= 0; --round) {
-        if (wave / nreg == round) {
-        const bool add = round != NW / nreg - 1;
-        auto put1 = [&](int i, float v) { if (i >= 0) RED[i] = add ? RED[i] + v : v; };
-        auto putc = [&](int k, const f32x4& v) {
-            const I4 ix = cm[k * 64 + lane];
-            put1(ix.x, v[0]); put1(ix.y, v[1]); put1(ix.z, v[2]); put1(ix.w, v[3]);
-        };
+        for (int t = 0; t < EH_MAX_TARG; ++t) tailv[9 + t] = (t < net.T) ? eh_wave_sum(cacc[t]) : 0.0f;
+        tailv[13] = K1 ? eh_wave_sum(aBoS) : 0.0f;
+        tailv[14] = eh_wave_sum(syacc); tailv[15] = eh_wave_sum(syyacc);
+        f32x4 vals[AL.na];
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
             if constexpr (PS) {
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) putc(AL.kw0 + m * 4 + pp, aW0V[m][pp]);
+                for (int pp = 0; pp < 4; ++pp) vals[AL.kw0 + m * 4 + pp] = aW0V[m][pp];
             } else {
 #pragma unroll
-                for (int n = 0; n < NBI; ++n) putc(AL.kw0 + m * NBI + n, aW0[m][n]);
+                for (int n = 0; n < NBI; ++n) vals[AL.kw0 + m * NBI + n] = aW0[m][n];
             }
 #pragma unroll
             for (int l = 0; l < NL - 1; ++l)
 #pragma unroll
-                for (int n = 0; n < NBH; ++n) putc(AL.kwh + (l * NBH + m) * NBH + n, aWh[l][m][n]);
-            if constexpr (K1) putc(AL.kwo + m, aWoV[m]); else putc(AL.kwo + m, aWo[m]);
+                for (int n = 0; n < NBH; ++n) vals[AL.kwh + (l * NBH + m) * NBH + n] = aWh[l][m][n];
+            if constexpr (K1) vals[AL.kwo + m] = aWoV[m]; else vals[AL.kwo + m] = aWo[m];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) putc(AL.kb + l * NBH + m, aB[l][m]);
+            for (int l = 0; l < NL; ++l) vals[AL.kb + l * NBH + m] = aB[l][m];
         }
-        if constexpr (K1) {
-            if (lane == 0) put1(b_off[NL], aBoS);
-        } else {
-            putc(AL.kbo, aBo);
-        }
-        if (lane == 0) {
+        if constexpr (!K1) vals[AL.kbo] = aBo;
+        // accumulators that are per-lane partial sums over the 16 samples of a row (biases; the K1 / PS vectors) are summed across
+        // the row here, so that the gather reads one word per wave for every kind of element
 #pragma unroll
-            for (int j = 0; j < EH_MAX_PARAMS; ++j)
-                if (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) put1(net.g_off + pidx(j), gacc[j]);
-            put1(net.n_theta, lacc);
+        for (int k = 0; k < AL.na; ++k) {
+            const bool rowsum = k >= AL.kb || (K1 && k >= AL.kwo && k < AL.kb) || (PS && k < AL.kwh);
+            if (rowsum) {
 #pragma unroll
-            for (int t = 0; t < EH_MAX_TARG; ++t)
-                if (t < net.T) put1(net.n_theta + 1 + t, cacc[t]);
-            put1(net.n_theta + 1 + net.T, syacc);
-            put1(net.n_theta + 2 + net.T, syyacc);
+                for (int r = 0; r < 4; ++r) vals[k][r] = eh_row16_sum(vals[k][r]);
+            }
         }
+        EH_STAMP(13);
+        float* const R = smem + G::IMG_FLOATS + wave * G::WAVE_WS;
+        const float* const R0 = smem + G::IMG_FLOATS;
+        float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
+        float* const gsh = a.fz.gacc ? (P2PM ? a.p2pv.stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd) {
+            __syncthreads();                       // the wave workspaces are dead / the previous round has been gathered
+            if (rd == 0) EH_STAMP(14);
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk)
+                if (rd * KH + kk < AL.na) *(f32x4*)&R[kk * 256 + c * 16 + g * 4] = vals[rd * KH + kk];
+            if (rd == NR - 1 && lane < 16) {
+                float tv = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tv = (lane == k) ? tailv[k] : tv;
+                R[KH * 256 + lane] = tv;
+            }
+            if (rd == 0) EH_STAMP(12);
+            __syncthreads();
+            if (rd == 0) EH_STAMP(9);
+            {
+                // branch-free reads (an element of another round reads word 0 and drops it): the LDS requests of all of a
+                // thread's elements are in flight together instead of one round trip per element
+                float sumv[NE];
+#pragma unroll
+                for (int u = 0; u < NE; ++u) {
+                    const int pos = code[u] & 0xFFFFFF, k = pos >> 8, in = pos & 255;
+                    const bool mine = code[u] >= 0 && (k == AL.na ? rd == NR - 1 : k / KH == rd);
+                    const int base = mine ? (k == AL.na ? KH * 256 + in : (k - rd * KH) * 256 + in) : 0;
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += R0[w * G::WAVE_WS + base];
+                    sumv[u] = sum;
+                }
+#pragma unroll
+                for (int u = 0; u < NE; ++u) {
+                    const int e = tid + u * NTHR;
+                    const int k = (code[u] & 0xFFFFFF) >> 8;
+                    const bool mine = code[u] >= 0 && (k == AL.na ? rd == NR - 1 : k / KH == rd);
+                    if (mine) {
+                        if (gsh) atomicAdd(&gsh[e], sumv[u]);
+                        else out[e] = sumv[u];
+                    }
+                }
+            }
         }
-        if (round > 0) __syncthreads();
-        }
+        if constexpr (P2PM) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
+        EH_STAMP(10);
+        return;
     }
+    // forward / eval passes: the per-target metric sums, one small region per wave
+    static_assert(!TRAIN || REDV2 || REDV3, "every training shape parks its accumulators the v2 / v3 way");
+    EH_STAMP(13);
+    __syncthreads();                               // the wave workspaces are dead from here on
+    EH_STAMP(14);
+    float* const RED = smem + G::IMG_FLOATS + wave * a.n_acc;
+#pragma unroll
+    for (int t = 0; t < EH_MAX_TARG; ++t)
+#pragma unroll
+        for (int k = 0; k < EH_EVAL_STATS; ++k) {
+            const float v = eh_wave_sum(est[t][k]);
+            if (t < net.T && lane == 0) RED[t * EH_EVAL_STATS + k] = v;
+        }
     EH_STAMP(12);
     __syncthreads();
     EH_STAMP(9);
     {
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = (TRAIN && a.fz.gacc) ? (P2PM ? a.p2pv.stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             float s = R0[e];
-            for (int w = 1; w < nreg; ++w) s += R0[w * a.n_acc + e];
-            if (gsh) atomicAdd(&gsh[e], s);
-            else out[e] = s;
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += R0[w * a.n_acc + e];
+            out[e] = s;
         }
-        if constexpr (P2PM) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
     }
     EH_STAMP(10);
 }

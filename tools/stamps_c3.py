@@ -19,6 +19,8 @@ eng._lib.eh_debug_stamps(eng._h, buf, 32)
 st = np.array(list(buf), dtype=np.int64).reshape(16, 2)
 names = ["stage weights", "init acc", "load record (last tile)", "layer0", "hidden", "out layer", "mech+loss", "backward", "block reduce", "slab write"]
 print(f"B={B}: kernel {st[10,0]-st[0,0]} cycles = {(st[10,1]-st[0,1])*10} ns -> {(st[10,0]-st[0,0])/((st[10,1]-st[0,1])*10):.2f} GHz (workgroup 0, thread 0; tile stamps = its last tile)")
+print("   end-of-kernel reduction (cycles): wave sums %d, barrier 1 (waits for the slowest wave) %d, row sums %d, scatter into the wave's region %d, barrier 2 %d" % (
+    st[13,0]-st[8,0], st[14,0]-st[13,0], st[11,0]-st[14,0], st[12,0]-st[11,0], st[9,0]-st[12,0]))
 for i, nme in enumerate(names):
     j = i + 1
     while j < 10 and st[j, 0] == 0: j += 1
