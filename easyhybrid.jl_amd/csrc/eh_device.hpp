@@ -1214,18 +1214,25 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     for (int s = 0; s < 4; ++s) aWo[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b4[s], aWo[n], 0, 0, 0);
                 }
             const float* W = wl + G::WO_OFF;
-            const int ksK = net.K < 4 ? net.K : 4;
+            // dH = Wo^T dO over the K real output rows only: MFMA j contracts rows 4j + g (k-slot g of the instruction), whose
+            // dO values come back from the OS image in that order -- ceil(K / 4) instructions per block instead of min(K, 4)
+            const int nks = (net.K + 3) >> 2;
+            float dOk[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dOk[j][t] = j < nks ? OS[(4 * j + g) * SR + 16 * t + c] : 0.0f;
 #pragma unroll
             for (int m = 0; m < NBH; ++m) {
                 f32x4 dh[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dh[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (s < ksK) {
-                        const float av = W[(4 * g + s) * SH + 16 * m + c];
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nks) {
+                        const float av = W[(4 * j + g) * SH + 16 * m + c];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dO[t][s], dh[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t) dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dOk[j][t], dh[t], 0, 0, 0);
                     }
                 }
 #pragma unroll
