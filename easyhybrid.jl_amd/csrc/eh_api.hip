@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     const int idx = blockIdx.x * CW + p;
     // optimiser inputs are independent of the slab: request them first so they arrive together
     float th = 0.0f, mm = 0.0f, vv = 0.0f, bt1 = 0.0f, bt2 = 0.0f;
-    if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; }
+    int mp = -1;
+    if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; if (idx < im.g_off && im.imap) mp = im.imap[idx]; }
     if (!APPLY && l2val && q == 0 && idx < n_theta) th = theta[idx];
     // (all of a thread's rows in flight at once: the step is one memory round trip, not nblk / NQ / 16 of them)
     float s = 0.0f;
@@ -322,13 +323,28 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     part[q][p] = s;
     // valid counts: every block needs them (nblk <= 256: one row per thread)
     // wsum columns: [0..3] n_valid per target, [4] S, [5] Sy, [6] Syy
+    // (a row's scalars [S | n_t ... | Sy | Syy] are 3 + T consecutive floats behind the gradient: two wide loads per row -- one
+    //  instruction per column made every workgroup walk 7 x 256 cache lines and cost 2-3 us of a launch, tools/ubench/reduce.hip;
+    //  4-byte aligned only, and up to 3 floats past a row's end when T < 4: the slab is allocated with that much slack)
     float cs[EH_MAX_TARG + 3];
 #pragma unroll
+    for (int t = 0; t < EH_MAX_TARG + 3; ++t) cs[t] = 0.0f;
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    for (int r = tid; r < nblk; r += 256) {
+        const float* const row = slab + (size_t)r * n_acc + n_theta;
+        const f32x4u lo = *reinterpret_cast<const f32x4u*>(row);
+        const f32x3u hi = *reinterpret_cast<const f32x3u*>(row + 4);
+        const float f[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) cs[t] += t < T ? f[1 + t] : 0.0f;
+        cs[EH_MAX_TARG] += f[0];
+#pragma unroll
+        for (int t = 1; t <= EH_MAX_TARG; ++t)
+            if (t == T) { cs[EH_MAX_TARG + 1] += f[1 + t]; cs[EH_MAX_TARG + 2] += f[2 + t]; }
+    }
+#pragma unroll
     for (int t = 0; t < EH_MAX_TARG + 3; ++t) {
-        cs[t] = 0.0f;
-        const int col = t < EH_MAX_TARG ? (t < T ? n_theta + 1 + t : -1) : (t == EH_MAX_TARG ? n_theta : n_theta + T + (t - EH_MAX_TARG));
-        if (col >= 0)
-            for (int r = tid; r < nblk; r += 256) cs[t] += slab[(size_t)r * n_acc + col];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cs[t] += __shfl_xor(cs[t], off, 64);
         if ((tid & 63) == 0) wsum[tid >> 6][t] = cs[t];
@@ -355,7 +371,8 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
             if (APPLY && ntot > 0.0f) {
                 eh_opt_update(o, g, bt1, bt2, th, mm, vv);
                 theta[idx] = th; m[idx] = mm; v[idx] = vv;
-                eh_image_store(im, idx, th);
+                if (idx < im.g_off) { if (mp >= 0) im.image[mp] = th; }
+                else eh_image_store(im, idx, th);
             }
         } else if (idx == n_theta) {
             const float loss = ntot > 0.0f ? (deferred ? dloss : tot) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
@@ -1297,7 +1314,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     }
     h->slab_rows = lform ? (int)EH_LFORM_ROWS : h->max_blocks;
-    HIPCHK_C(hipMalloc(&h->slab, std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
+    HIPCHK_C(hipMalloc(&h->slab, (std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) + 16) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, 8 * sizeof(float)));      // per-target 1/n (T > 1), or [1, -, -, -, k0, k1, k2, loss] of a moment-based loss
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
