@@ -301,26 +301,38 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
 
     // ---- parameter image (fp32, EhGeom layout, kept by the optimiser kernel) -> bf16 weights, fp32 biases + meta block
     {
-        auto cvt_rows = [&](const float* src, int sld, int scols, __bf16* dst, int dld, int rows, int kcols) {
-            const int hp = kcols / 2, tot = rows * hp;
-            for (int i0 = tid; i0 < tot; i0 += 8 * NTH) {
-                float2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * NTH, row = i / hp, col = 2 * (i - row * hp);
-                    v[u] = (i < tot && col < scols) ? *(const float2*)&src[row * sld + col] : float2{0.0f, 0.0f};
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * NTH, row = i / hp, col = 2 * (i - row * hp);
-                    if (i < tot) *(bf16x2*)&dst[row * dld + col] = bf16x2{(__bf16)v[u].x, (__bf16)v[u].y};
+        // every 16-byte piece of the three weight matrices is requested before the first one is converted: the whole image
+        // arrives in one memory round trip (rows of the fp32 image are 16-byte multiples: strides IP + 4 and HP + 4 floats)
+        constexpr int N0 = (HP * KP0 / 4 + NTH - 1) / NTH, NH = (HP * HP / 4 + NTH - 1) / NTH, NO = (16 * HP / 4 + NTH - 1) / NTH;
+        f32x4 r0[N0], rh[NL > 1 ? NL - 1 : 1][NH], ro[NO];
+        auto ld_rows = [&](const float* src, int sld, int scols, int rows, int kcols, f32x4* v, int n) {
+            const int qp = kcols / 4, tot = rows * qp;
+            for (int u = 0; u < n; ++u) {
+                const int i = tid + u * NTH, row = i / qp, col = 4 * (i - row * qp);
+                v[u] = (i < tot && col < scols) ? *(const f32x4*)&src[row * sld + col] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        };
+        auto st_rows = [&](__bf16* dst, int dld, int rows, int kcols, const f32x4* v, int n) {
+            const int qp = kcols / 4, tot = rows * qp;
+            for (int u = 0; u < n; ++u) {
+                const int i = tid + u * NTH, row = i / qp, col = 4 * (i - row * qp);
+                if (i < tot) {
+                    *(bf16x2*)&dst[row * dld + col] = bf16x2{(__bf16)v[u][0], (__bf16)v[u][1]};
+                    *(bf16x2*)&dst[row * dld + col + 2] = bf16x2{(__bf16)v[u][2], (__bf16)v[u][3]};
                 }
             }
         };
-        cvt_rows(a.image + F::W0_OFF, F::S0, IP, WB0, S0B, HP, KP0);
 #pragma unroll
-        for (int l = 1; l < NL; ++l) cvt_rows(a.image + F::WH_OFF + (l - 1) * HP * F::SH, F::SH, HP, WBH + (l - 1) * HP * SHB, SHB, HP, HP);
-        cvt_rows(a.image + F::WO_OFF, F::SH, HP, WBO, SHB, 16, HP);
+        for (int rep = 0; rep < 1; ++rep) {
+            ld_rows(a.image + F::W0_OFF, F::S0, IP, HP, KP0, r0, N0);
+#pragma unroll
+            for (int l = 1; l < NL; ++l) ld_rows(a.image + F::WH_OFF + (l - 1) * HP * F::SH, F::SH, HP, HP, HP, rh[l - 1], NH);
+            ld_rows(a.image + F::WO_OFF, F::SH, HP, 16, HP, ro, NO);
+        }
+        st_rows(WB0, S0B, HP, KP0, r0, N0);
+#pragma unroll
+        for (int l = 1; l < NL; ++l) st_rows(WBH + (l - 1) * HP * SHB, SHB, HP, HP, rh[l - 1], NH);
+        st_rows(WBO, SHB, 16, HP, ro, NO);
         for (int e = tid; e < NL * HP + 16 + EH_IMG_META; e += NTH) smem[G::B_OFF + e] = a.image[F::B_OFF + e];      // (B_OFF .. PHI_OFF + META is one run in both layouts)
     }
     for (int e = tid; e < MT * S0B / 2; e += NTH) smem[G::XB_OFF + e] = 0.0f;     // columns >= P of the predictor image stay 0
