@@ -1724,7 +1724,22 @@ static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
 }
 template <bool ATR, bool BTR, int EPI>
 static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
-    hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI>), dim3((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz), dim3(256), 0, h->stream, g);
+    static const bool novec = getenv("EH_GEMM_NOVEC") != nullptr;      // (A/B switch of the measurement tools)
+    if (EPI == EH_GEPI_STORE && ATR && !novec && (g.M <= 8 || g.N <= 8) && (g.M <= 8 ? !BTR : BTR)) {
+        // a weight gradient with a thin side: streaming kernel (eh_thin_gemm_kernel)
+        EhThinArgs t{};
+        t.K = g.K; t.kchunk = g.kchunk; t.C = g.C; t.c_z = g.c_zstride; t.cs_z = g.c_zstride;
+        if (g.M <= 8) {          // few inputs: wide = B (dZ [B x out]), thin = A (the layer's input [B x in])
+            t.wide = g.B; t.ldw = g.ldb; t.ncols = g.N; t.thin = g.A; t.tsb = g.lda; t.tsj = 1; t.J = g.M; t.c_col = 1; t.c_j = g.ldc; t.cs_wide = g.colsum;
+        } else {                 // few outputs, dO stored [K][ldo]: wide = A (the layer's input [B x in]), thin = B
+            t.wide = g.A; t.ldw = g.lda; t.ncols = g.M; t.thin = g.B; t.tsb = 1; t.tsj = g.ldb; t.J = g.N; t.c_col = g.ldc; t.c_j = 1; t.cs_thin = g.colsum;
+        }
+        hipLaunchKernelGGL(eh_thin_gemm_kernel, dim3((unsigned)((t.ncols + 63) / 64), (unsigned)nz), dim3(256), 0, h->stream, t);
+        return;
+    }
+    const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz);
+    if (!novec && eh_gemm_vec_ok(g, ATR, BTR)) hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, true>), grid, dim3(256), 0, h->stream, g);
+    else hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, false>), grid, dim3(256), 0, h->stream, g);
 }
 // minibatch -> Xb (input BatchNorm applied), forward through every Dense layer; O^T [K][ldo] = the raw NN outputs
 static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool train_mode, bool bn_update, const EhLWs& W) {

@@ -55,10 +55,16 @@ __device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' fr
 // C (M x N) = A (M x K) * B (K x N), fp32 in, fp32 out, on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered fmaf chain per output).
 // 128 x 128 output tile per workgroup of four waves (2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles); K in steps of 16 through LDS as
 // k-major tiles, so both MFMA operands are conflict-free row reads; the next step's global loads are in flight during the MFMAs.
-template <bool ATR, bool BTR, int EPI>
+// VEC (chosen by the host, eh_gemm_vec_ok): every operand base 16-byte aligned, leading dimensions multiples of 4, the k chunk a
+// whole number of BK steps, the extent along an operand's contiguous dimension a multiple of 4.  The tiles then come in as 16-byte
+// loads through pointers set up once (rows beyond the matrix are clamped to its last row: their products land in outputs the
+// epilogue masks), the LDS tiles are double-buffered (one barrier per step) -- the main loop is loads, LDS traffic and MFMAs with
+// a handful of vector-ALU instructions: on gfx950 an fp32 MFMA does not overlap with the vector ALU, so every
+// address computation or bounds predicate in the loop is time taken from the matrix pipe.
+template <bool ATR, bool BTR, int EPI, bool VEC = false>
 __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
     constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = BM + 4;
-    __shared__ float As[BK][LDS_LD], Bs[BK][LDS_LD];
+    __shared__ __attribute__((aligned(16))) float As[VEC ? 2 : 1][BK][LDS_LD], Bs[VEC ? 2 : 1][BK][LDS_LD];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -70,6 +76,64 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const bool do_cs_v = EPI == EH_GEPI_STORE && g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
+    float cs_v = 0.0f;
+    if constexpr (VEC) {
+        // two 16-byte pieces of each tile per thread and step
+        //   operand contiguous along k (A: !ATR, B: BTR): piece j = row (tid >> 2) + 64 j, k quad tid & 3  -> four b32 LDS stores [4q + i][row]
+        //   operand contiguous along m / n (A: ATR, B: !BTR): piece j = k row (tid >> 5) + 8 j, quad tid & 31 -> one b128 LDS store [k][4 quad]
+        const float* pa[2]; const float* pb[2];
+        long long sa, sb;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (ATR) { const int mq = m0 + 4 * (tid & 31); pa[j] = g.A + (long long)(kbeg + (tid >> 5) + 8 * j) * g.lda + (mq < g.M ? mq : 0); }
+            else { const int m = min(m0 + (tid >> 2) + 64 * j, g.M - 1); pa[j] = g.A + (long long)m * g.lda + kbeg + 4 * (tid & 3); }
+            if (BTR) { const int n = min(n0 + (tid >> 2) + 64 * j, g.N - 1); pb[j] = g.B + (long long)n * g.ldb + kbeg + 4 * (tid & 3); }
+            else { const int nq = n0 + 4 * (tid & 31); pb[j] = g.B + (long long)(kbeg + (tid >> 5) + 8 * j) * g.ldb + (nq < g.N ? nq : 0); }
+        }
+        sa = ATR ? (long long)BK * g.lda : BK; sb = BTR ? BK : (long long)BK * g.ldb;
+        f32x4 ra[2], rb[2];
+        auto gload = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { ra[j] = *(const f32x4*)pa[j]; rb[j] = *(const f32x4*)pb[j]; pa[j] += sa; pb[j] += sb; }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (ATR) *(f32x4*)&As[buf][(tid >> 5) + 8 * j][4 * (tid & 31)] = ra[j];
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) As[buf][4 * (tid & 3) + i][(tid >> 2) + 64 * j] = ra[j][i];
+                }
+                if (BTR) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Bs[buf][4 * (tid & 3) + i][(tid >> 2) + 64 * j] = rb[j][i];
+                } else *(f32x4*)&Bs[buf][(tid >> 5) + 8 * j][4 * (tid & 31)] = rb[j];
+            }
+        };
+        const int nsteps = (kend - kbeg) / BK;
+        if (nsteps > 0) { gload(); lstore(0); }
+        __syncthreads();
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < nsteps) gload();             // in flight behind this step's MFMAs
+            if (do_cs_v) {
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) cs_v += Bs[cur][kk][tid];
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < BK; k2 += 2) {
+                const float a0 = As[cur][k2 + lh][wm * 64 + l32], a1 = As[cur][k2 + lh][wm * 64 + 32 + l32];
+                const float b0 = Bs[cur][k2 + lh][wn * 64 + l32], b1 = Bs[cur][k2 + lh][wn * 64 + 32 + l32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (st + 1 < nsteps) lstore(cur ^ 1);     // the other buffer: its readers passed the barrier that ended the previous step
+            __syncthreads();
+        }
+    }
     constexpr int NE = BM * BK / 256;      // tile elements per thread (8)
     float ra[NE], rb[NE];
     // element e of a tile: the thread order follows the operand's contiguous dimension (coalesced global loads)
@@ -86,29 +150,29 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
             rb[j] = (n < g.N && k0 + kb < kend) ? (BTR ? g.B[(long long)n * g.ldb + k0 + kb] : g.B[(long long)(k0 + kb) * g.ldb + n]) : 0.0f;
         }
     };
-    const bool do_cs = EPI == EH_GEPI_STORE && g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
-    float cs = 0.0f;
-    if (kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool do_cs = do_cs_v;
+    float cs = cs_v;
+    if (!VEC && kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; !VEC && k0 < kend; k0 += BK) {
         __syncthreads();                       // the previous step's MFMAs are done with the tiles
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             int mm, nn, ka, kb;
             tile_a(tid + 256 * j, mm, ka);
             tile_b(tid + 256 * j, nn, kb);
-            As[ka][mm] = ra[j];
-            Bs[kb][nn] = rb[j];
+            As[0][ka][mm] = ra[j];
+            Bs[0][kb][nn] = rb[j];
         }
         __syncthreads();
         if (k0 + BK < kend) load(k0 + BK);
         if (do_cs) {
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) cs += Bs[kk][tid];      // (k order: deterministic)
+            for (int kk = 0; kk < BK; ++kk) cs += Bs[0][kk][tid];      // (k order: deterministic)
         }
 #pragma unroll
         for (int k2 = 0; k2 < BK; k2 += 2) {
-            const float a0 = As[k2 + lh][wm * 64 + l32], a1 = As[k2 + lh][wm * 64 + 32 + l32];
-            const float b0 = Bs[k2 + lh][wn * 64 + l32], b1 = Bs[k2 + lh][wn * 64 + 32 + l32];
+            const float a0 = As[0][k2 + lh][wm * 64 + l32], a1 = As[0][k2 + lh][wm * 64 + 32 + l32];
+            const float b0 = Bs[0][k2 + lh][wn * 64 + l32], b1 = Bs[0][k2 + lh][wn * 64 + 32 + l32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -137,6 +201,79 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
                 }
             }
         }
+}
+
+// may this product run the 16-byte-load form of eh_gemm_kernel?
+inline bool eh_gemm_vec_ok(const EhGemmArgs& g, bool atr, bool btr) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
+    if (!al16(g.A) || !al16(g.B) || (g.lda & 3) || (g.ldb & 3)) return false;
+    if (g.K <= 0 || (g.K % 16) || (g.kchunk % 16)) return false;
+    if (atr && (g.M & 3)) return false;          // 16-byte pieces along m
+    if (!btr && (g.N & 3)) return false;         // 16-byte pieces along n
+    return g.M > 0 && g.N > 0;
+}
+
+// Weight gradient of a layer with a thin side (the first layer's few predictors, the last layer's few outputs): C(col, j) =
+// sum over the samples b of chunk z of wide[b][col] * thin(b, j), j < J <= 8 -- a streaming pass over `wide` (a 128 x 128 MFMA
+// tile would spend 94 % and more of its work on padding: 277 us against 70 for the tutorial net's first layer at B = 65 536).
+// Also the bias gradient that the tiled product takes from its B tiles: column sums of `wide` (cs_wide) or of `thin` (cs_thin).
+struct EhThinArgs {
+    const float* wide; long long ldw; int ncols;
+    const float* thin; long long tsb, tsj; int J;
+    int K, kchunk;
+    float* C; long long c_col, c_j, c_z;
+    float* cs_wide; float* cs_thin; long long cs_z;
+};
+__global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) {
+    constexpr int SB = 512, U = 8;              // samples staged per round; wide loads in flight per thread
+    __shared__ float sT[8][SB];                 // the thin operand of the round, [j][sample]: every lane of a wave reads the same word (broadcast)
+    __shared__ float red[4][64][10];
+    __shared__ float redt[4][8];
+    const int tid = threadIdx.x, cl = tid & 63, q = tid >> 6, col = blockIdx.x * 64 + cl, z = blockIdx.y;
+    const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const bool live = col < a.ncols;
+    float acc[8], cst[8], csw = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[j] = 0.0f; cst[j] = 0.0f; }
+    for (int s0 = kbeg; s0 < kend; s0 += SB) {
+        const int ns = min(SB, kend - s0);
+        __syncthreads();
+        for (int e = tid; e < a.J * SB; e += 256) {
+            const int j = a.tsb == 1 ? e / SB : e % a.J, bl = a.tsb == 1 ? e % SB : e / a.J;      // follow the operand's contiguous dimension
+            sT[j][bl] = bl < ns ? a.thin[(long long)(s0 + bl) * a.tsb + (long long)j * a.tsj] : 0.0f;
+        }
+        __syncthreads();
+        for (int b0 = q; b0 < ns; b0 += 4 * U) {
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int bl = b0 + 4 * u; w[u] = (live && bl < ns) ? a.wide[(long long)(s0 + bl) * a.ldw + col] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int bl = b0 + 4 * u;
+                if (bl < ns) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < a.J) { const float t = sT[j][bl]; acc[j] = fmaf(t, w[u], acc[j]); cst[j] += t; }
+                    csw += w[u];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[q][cl][j] = acc[j];
+    red[q][cl][8] = csw;
+    if (cl == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) redt[q][j] = cst[j];
+    }
+    __syncthreads();
+    if (q == 0 && live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < a.J) a.C[(long long)z * a.c_z + (long long)col * a.c_col + (long long)j * a.c_j] = (red[0][cl][j] + red[1][cl][j]) + (red[2][cl][j] + red[3][cl][j]);
+        if (a.cs_wide) a.cs_wide[(long long)z * a.cs_z + col] = (red[0][cl][8] + red[1][cl][8]) + (red[2][cl][8] + red[3][cl][8]);
+    }
+    if (a.cs_thin && blockIdx.x == 0 && tid < a.J) a.cs_thin[(long long)z * a.cs_z + tid] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
 }
 
 // out[z * zstride + n] = sum over rows m of chunk z of D(m, n), D(m, n) at D + m*sm + n*sn  (bias gradients: column sums of the deltas)

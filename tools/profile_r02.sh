@@ -41,6 +41,16 @@ cd $ROOT
   timeout -k 10 300 python3 tools/bench_config.py c1 --steps 2000 --specialize 1
 } > $OUT/bench_config_all.jsonl 2> $OUT/bench_config_all.err
 timeout -k 10 300 python3 tools/bench_lform.py > $OUT/bench_lform.jsonl 2>&1
+# the micro-benchmarks DESIGN section 8 quotes (compiled on the box; nothing of the library involved)
+for u in overlap atomics reduce; do
+  hipcc --offload-arch=gfx950 -O3 -w tools/ubench/$u.hip -o /tmp/ubench_$u && timeout -k 5 120 /tmp/ubench_$u > $OUT/ubench_$u.txt 2>&1
+done
+# config 3 / config 5 (bf16) instruction, wait and LDS counters
+bash tools/pmc_c3.sh 0 1 > $OUT/pmc_c3_counters.txt 2>&1
+bash tools/pmc_wide.sh > $OUT/pmc_c5_bf16_counters.txt 2>&1
+EH_JIT_DEFINES="EH_STAMPS" EH_SPECIALIZE=1 EH_JIT_CACHE=0 timeout -k 10 200 python3 tools/stamps_c3.py > $OUT/stamps_c3.txt 2>&1
+EH_JIT_DEFINES="EH_STAMPS EH_STAMPS_FINE" EH_SPECIALIZE=1 EH_JIT_CACHE=0 timeout -k 10 200 python3 tools/stamps_c3.py > $OUT/stamps_c3_fine.txt 2>&1
+EH_PRECISION=1 EH_JIT_DEFINES="EH_STAMPS" EH_SPECIALIZE=1 EH_JIT_CACHE=0 timeout -k 10 200 python3 tools/stamps_wide.py > $OUT/stamps_c5_bf16.txt 2>&1
 python3 - "$OUT" > $OUT/pmc_summary.txt <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
