@@ -1738,7 +1738,13 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
         return;
     }
     const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz);
-    if (!novec && eh_gemm_vec_ok(g, ATR, BTR)) hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, true>), grid, dim3(256), 0, h->stream, g);
+    const bool vec = !novec && eh_gemm_vec_ok(g, ATR, BTR);
+    if (vec && (long long)grid.x * grid.y * grid.z < 256) {      // fewer 128 x 128 tiles than CUs: 64 x 64 ones (four times the workgroups, a quarter of the work each)
+        const dim3 grid64((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)nz);
+        hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, true, 64>), grid64, dim3(256), 0, h->stream, g);
+        return;
+    }
+    if (vec) hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, true>), grid, dim3(256), 0, h->stream, g);
     else hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, false>), grid, dim3(256), 0, h->stream, g);
 }
 // minibatch -> Xb (input BatchNorm applied), forward through every Dense layer; O^T [K][ldo] = the raw NN outputs

@@ -61,46 +61,48 @@ __device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' fr
 // epilogue masks), the LDS tiles are double-buffered (one barrier per step) -- the main loop is loads, LDS traffic and MFMAs with
 // a handful of vector-ALU instructions: on gfx950 an fp32 MFMA does not overlap with the vector ALU, so every
 // address computation or bounds predicate in the loop is time taken from the matrix pipe.
-template <bool ATR, bool BTR, int EPI, bool VEC = false>
+// BT = 64: 64 x 64 tiles (one MFMA tile per wave) for products too small to fill the chip with 128 x 128 ones.
+template <bool ATR, bool BTR, int EPI, bool VEC = false, int BT = 128>
 __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
-    constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = BM + 4;
+    static_assert(BT == 128 || (BT == 64 && VEC), "64 x 64 tiles exist in the 16-byte-load form only");
+    constexpr int BM = BT, BN = BT, BK = 16, LDS_LD = BM + 4, TI = BT / 64, WT = BT / 2, NP = BT / 64, QT = BT / 4, RP = 256 / QT;
     __shared__ __attribute__((aligned(16))) float As[VEC ? 2 : 1][BK][LDS_LD], Bs[VEC ? 2 : 1][BK][LDS_LD];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = (int)blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bool do_cs_v = EPI == EH_GEPI_STORE && g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
     float cs_v = 0.0f;
     if constexpr (VEC) {
-        // two 16-byte pieces of each tile per thread and step
+        // NP (= BT / 64) 16-byte pieces of each tile per thread and step
         //   operand contiguous along k (A: !ATR, B: BTR): piece j = row (tid >> 2) + 64 j, k quad tid & 3  -> four b32 LDS stores [4q + i][row]
-        //   operand contiguous along m / n (A: ATR, B: !BTR): piece j = k row (tid >> 5) + 8 j, quad tid & 31 -> one b128 LDS store [k][4 quad]
-        const float* pa[2]; const float* pb[2];
+        //   operand contiguous along m / n (A: ATR, B: !BTR): piece j = k row tid / QT + RP j, quad tid % QT -> one b128 LDS store [k][4 quad]
+        const float* pa[NP]; const float* pb[NP];
         long long sa, sb;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (ATR) { const int mq = m0 + 4 * (tid & 31); pa[j] = g.A + (long long)(kbeg + (tid >> 5) + 8 * j) * g.lda + (mq < g.M ? mq : 0); }
+        for (int j = 0; j < NP; ++j) {
+            if (ATR) { const int mq = m0 + 4 * (tid % QT); pa[j] = g.A + (long long)(kbeg + tid / QT + RP * j) * g.lda + (mq < g.M ? mq : 0); }
             else { const int m = min(m0 + (tid >> 2) + 64 * j, g.M - 1); pa[j] = g.A + (long long)m * g.lda + kbeg + 4 * (tid & 3); }
             if (BTR) { const int n = min(n0 + (tid >> 2) + 64 * j, g.N - 1); pb[j] = g.B + (long long)n * g.ldb + kbeg + 4 * (tid & 3); }
-            else { const int nq = n0 + 4 * (tid & 31); pb[j] = g.B + (long long)(kbeg + (tid >> 5) + 8 * j) * g.ldb + (nq < g.N ? nq : 0); }
+            else { const int nq = n0 + 4 * (tid % QT); pb[j] = g.B + (long long)(kbeg + tid / QT + RP * j) * g.ldb + (nq < g.N ? nq : 0); }
         }
         sa = ATR ? (long long)BK * g.lda : BK; sb = BTR ? BK : (long long)BK * g.ldb;
-        f32x4 ra[2], rb[2];
+        f32x4 ra[NP], rb[NP];
         auto gload = [&]() {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { ra[j] = *(const f32x4*)pa[j]; rb[j] = *(const f32x4*)pb[j]; pa[j] += sa; pb[j] += sb; }
+            for (int j = 0; j < NP; ++j) { ra[j] = *(const f32x4*)pa[j]; rb[j] = *(const f32x4*)pb[j]; pa[j] += sa; pb[j] += sb; }
         };
         auto lstore = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (ATR) *(f32x4*)&As[buf][(tid >> 5) + 8 * j][4 * (tid & 31)] = ra[j];
+            for (int j = 0; j < NP; ++j) {
+                if (ATR) *(f32x4*)&As[buf][tid / QT + RP * j][4 * (tid % QT)] = ra[j];
                 else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) As[buf][4 * (tid & 3) + i][(tid >> 2) + 64 * j] = ra[j][i];
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
                 if (BTR) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) Bs[buf][4 * (tid & 3) + i][(tid >> 2) + 64 * j] = rb[j][i];
-                } else *(f32x4*)&Bs[buf][(tid >> 5) + 8 * j][4 * (tid & 31)] = rb[j];
+                } else *(f32x4*)&Bs[buf][tid / QT + RP * j][4 * (tid % QT)] = rb[j];
             }
         };
         const int nsteps = (kend - kbeg) / BK;
@@ -123,17 +125,21 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
             }
 #pragma unroll
             for (int k2 = 0; k2 < BK; k2 += 2) {
-                const float a0 = As[cur][k2 + lh][wm * 64 + l32], a1 = As[cur][k2 + lh][wm * 64 + 32 + l32];
-                const float b0 = Bs[cur][k2 + lh][wn * 64 + l32], b1 = Bs[cur][k2 + lh][wn * 64 + 32 + l32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                float av[TI], bv[TI];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) { av[i] = As[cur][k2 + lh][wm * WT + 32 * i + l32]; bv[i] = Bs[cur][k2 + lh][wn * WT + 32 * i + l32]; }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
             if (st + 1 < nsteps) lstore(cur ^ 1);     // the other buffer: its readers passed the barrier that ended the previous step
             __syncthreads();
         }
     }
+    const bool do_cs = do_cs_v;
+    float cs = cs_v;
+    if constexpr (!VEC) {
     constexpr int NE = BM * BK / 256;      // tile elements per thread (8)
     float ra[NE], rb[NE];
     // element e of a tile: the thread order follows the operand's contiguous dimension (coalesced global loads)
@@ -150,10 +156,8 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
             rb[j] = (n < g.N && k0 + kb < kend) ? (BTR ? g.B[(long long)n * g.ldb + k0 + kb] : g.B[(long long)(k0 + kb) * g.ldb + n]) : 0.0f;
         }
     };
-    const bool do_cs = do_cs_v;
-    float cs = cs_v;
-    if (!VEC && kbeg < kend) load(kbeg);
-    for (int k0 = kbeg; !VEC && k0 < kend; k0 += BK) {
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                       // the previous step's MFMAs are done with the tiles
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
@@ -179,18 +183,19 @@ __global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    }
     if (do_cs && n0 + tid < g.N) g.colsum[(long long)blockIdx.z * g.c_zstride + n0 + tid] = cs;
     // C/D layout of the 32x32 MFMA: lane -> column (lane & 31); register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* const C = g.C + (long long)blockIdx.z * g.c_zstride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + 32 * j + l32;
+        for (int j = 0; j < TI; ++j) {
+            const int n = n0 + wn * WT + 32 * j + l32;
             const float bv = ((EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_BIAS_T) && n < g.N) ? g.bias[n] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + wm * WT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < g.M && n < g.N) {
                     float v = acc[i][j][r];
                     if (EPI == EH_GEPI_BIAS_ACT) v = eh_act_rt(g.act, v + bv);
