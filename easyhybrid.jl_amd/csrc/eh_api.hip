@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
 // fused-update mode: apply the still-pending gradient (sharded accumulator g_prev) in place
 __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev, int n_acc, int n_theta, float* theta, float* m, float* v,
                                                              const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind,
-                                                             const EhP2P* p2p, int slot, unsigned seq) {
+                                                             const EhP2P* p2p, int slot, unsigned seq, int T) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float cnt = 0.0f, sse = 0.0f, sy = 0.0f, syy = 0.0f, gs_p2p = 0.0f;
     if (p2p) {       // every rank's sums of the last step, straight from the receive shards (see EhP2P)
@@ -411,11 +411,14 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
 #pragma unroll
         for (int sh = 0; sh < EH_GSHARDS; ++sh) {
             const float* gp = g_prev + sh * n_acc + n_theta;
-            sse += gp[0]; cnt += gp[1]; sy += gp[2]; syy += gp[3];
+            sse += gp[0];
+            if (T == 1) { cnt += gp[1]; sy += gp[2]; syy += gp[3]; }
+            else for (int t = 0; t < T; ++t) cnt += gp[1 + t];
         }
     }
     float inv = 0.0f, lossv = 0.0f;
-    eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
+    if (T == 1) eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
+    else { inv = cnt > 0.0f ? 1.0f : 0.0f; lossv = cnt > 0.0f ? sse : __builtin_nanf(""); }      // multi-target: the step used exact per-target weights
     if (idx < n_theta && cnt > 0.0f) {
         float gs = gs_p2p;
         if (!p2p) {
@@ -827,7 +830,7 @@ static int flush_pending(eh_handle* h) {
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     hipLaunchKernelGGL(eh_fused_flush_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, g_prev, h->n_acc, nt, TH(h), MM(h), VV(h), sc_in, sc_out,
-                       h->opt, h->pending_loss, h->img, h->net.loss, h->p2p_on ? h->p2p_dev : nullptr, (int)((h->gstep + 2) % 3), h->p2p_seq);
+                       h->opt, h->pending_loss, h->img, h->net.loss, h->p2p_on ? h->p2p_dev : nullptr, (int)((h->gstep + 2) % 3), h->p2p_seq, h->net.T);
     HIPCHK(h, hipGetLastError());
     // Single GPU: nothing to clear -- the rotation keeps itself clean (the step that accumulates into slot g clears slot g + 1 in
     // its prologue and nobody reads a slot before the step after its clearing has filled it).  Under EhP2P the workgroups add
@@ -1462,7 +1465,6 @@ int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
         same = same && kinds[t] == kinds[0];
     }
     if (same) return eh_set_option(h, "training_loss", kinds[0]);
-    if (h->fused) return fail(h, EH_EUNSUPPORTED, "eh_set_target_losses: switch fused_update off first");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     h->net.loss = EH_LOSS_MSE;               // (what the single-kind code paths read; the kernels take the per-target kinds from loss_t)
@@ -1503,7 +1505,6 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         return build_maps(h, false);
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
-        if (value && h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "fused_update needs a single-target model");
         if (value && h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "fused_update: pearson / kge training losses take two passes per step");
         if (value && h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
@@ -1915,6 +1916,12 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
     a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
+    if (h->net.T > 1) {      // multi-target: the per-target weights (1 / n_t, 1 / sum (y - ybar)^2) have to be known inside the streaming pass
+        EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
+        hipLaunchKernelGGL(eh_count_kernel, dim3(h->net.T), dim3(256), 0, h->stream, sp.recs, h->C, h->net.P + h->net.F, h->net.T, idx, first, count, h->inv_n, h->net.loss_t, sh4);
+        HIPCHK(h, hipGetLastError());
+        a.inv_n = h->inv_n;
+    }
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
     z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
@@ -2453,6 +2460,7 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index) {
     if (!h || !buffer_index) return EH_EINVAL;
     if (!h->fused) return fail(h, EH_ESTATE, "eh_dp_fused_step: set the fused_update option first");
+    if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_fused_step: multi-target models need the global per-target counts before the pass: use eh_dp_counts + eh_dp_grad (fused_update off)");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_fused_step: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     if (!h->opt_ready) return fail(h, EH_ESTATE, "eh_dp_fused_step: call eh_opt_init first");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2472,6 +2480,7 @@ int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out,
     // (world == 1 is a loopback: the rank publishes to and reads from itself -- measures the cost of the machinery)
     if (world < 1 || world > EH_GSHARDS || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_p2p_init: world %d (1..%d), rank %d", world, EH_GSHARDS, rank);
     if (!h->fused) return fail(h, EH_ESTATE, "eh_p2p_init: set the fused_update option first");
+    if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the peer-to-peer exchange is built for single-target models (use the all-reduce seam)");
     if (h->net.mech == EH_MECH_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the program kernels have no cross-GPU variant (use the all-reduce seam)");
     if (h->act == EH_ACT_PER_NET) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the per-net activation kernels have no cross-GPU variant (use the all-reduce seam)");
     if (h->p2p_on || h->p2p_alloc) return fail(h, EH_ESTATE, "eh_p2p_init: already initialised");

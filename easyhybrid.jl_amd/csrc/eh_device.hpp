@@ -720,7 +720,12 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
             for (int sh = 0; sh < EH_GSHARDS; ++sh) {
                 const float* gp = g_prev + sh * a.n_acc + net.n_theta;
-                f_sse += gp[0]; f_cnt += gp[1]; f_sy += gp[2]; f_syy += gp[3];      // single target: [S | n | Sy | Syy]
+                if (net.T == 1) { f_sse += gp[0]; f_cnt += gp[1]; f_sy += gp[2]; f_syy += gp[3]; }      // single target: [S | n | Sy | Syy]
+                else {                                                                                // [S | n_t ... | Sy | Syy]: the weights were exact (a.inv_n), only "any valid sample" matters
+                    f_sse += gp[0];
+#pragma unroll
+                    for (int t = 0; t < EH_MAX_TARG; ++t) f_cnt += t < net.T ? gp[1 + t] : 0.0f;
+                }
             }
         }
         const float* const sc_in = z.pset + 6 * net.n_theta + 2 * z.sc_sel;
@@ -818,7 +823,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         float* const pout = z.pset + (z.cur ^ 1) * 3 * nth;
         const bool upd = z.pending && f_cnt > 0.0f;
         float inv = 0.0f, lossv = __builtin_nanf("");
-        if (upd) eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv);
+        if (upd) {
+            if (a.inv_n) { inv = 1.0f; lossv = f_sse; }      // multi-target: per-target weights from the counting pre-pass, the sums are final
+            else eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv);
+        }
         for (int idx = tid; idx < nth; idx += NTHR) {
             float th, mm, vv, gs = 0.0f;
             int mp;

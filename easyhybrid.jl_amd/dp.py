@@ -82,10 +82,12 @@ class DataParallel:
         ptr, n = engine.device_buffer(L.EH_BUF_GRAD)
         self.buf = torch.as_tensor(_DevArray(ptr, n), device=dev)
         self.p2p = False
+        if fused and int(engine.desc.n_targets) > 1:        # the per-target weights need the GLOBAL counts before the pass: eh_dp_counts + three-kernel path
+            fused = self.fused = False
         if fused:
             try:
                 engine.set_option("fused_update", 1)
-            except NotImplementedError:                     # multi-target models / hidden widths above 64: three-kernel path
+            except NotImplementedError:                     # hidden widths above 64: three-kernel path
                 fused = self.fused = False
         if fused:
             if p2p == "auto":

@@ -953,8 +953,13 @@ def test_fluxpart_multi_target(targets, nets):
     assert np.allclose(losses, l_ref, rtol=1e-4)
     assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
     if len(targets) > 1:
-        with pytest.raises(NotImplementedError):
-            eng.set_option("fused_update", 1)
+        # one kernel per step on a multi-target model (since round 2: counting pre-pass + fused step), same trajectory
+        eng.set_params(theta); eng.opt_init("Adam", 0.01)
+        eng.set_option("fused_update", 1)
+        lf = [eng.train_step(*b) for b in batches]
+        assert np.allclose(lf, l_ref, rtol=1e-4)
+        assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+        eng.set_option("fused_update", 0)
         yt2 = dict(yt); yt2[targets[0]] = np.full(B, np.nan, np.float32)          # one target entirely missing: it contributes 0
         eng2 = util.load_engine(spec, theta, X, f, yt2)
         l2, g2, n2 = eng2.loss_and_grad()
@@ -1026,6 +1031,38 @@ def test_width_128_forward_eval_and_adam_trajectory():
     with pytest.raises(NotImplementedError, match="fused_update"):
         eng.set_option("fused_update", 1)
     eng.close()
+
+
+@pytest.mark.parametrize("kinds", ["mse", ("mse", "mae"), ("nseLoss", "mse")])
+def test_fused_update_mode_on_a_multi_target_model(kinds):
+    """one kernel per step for T > 1: the counting pre-pass supplies the per-target weights, the next step's prologue applies the update"""
+    rng = np.random.default_rng(11)
+    B = 1200
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(5, [16, 16], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((5, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][rng.random(B) < 0.25] = np.nan; y["GPP"][rng.random(B) < 0.1] = np.nan
+    y["NEE"][600:800] = np.nan; y["GPP"][600:800] = np.nan                  # one all-masked batch: skipped (epoch.jl:17-19)
+    theta = ho.init_theta(spec, 4, np.float32)
+    batches = [(i * 200, 200) for i in range(6)]
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    eng.set_option("fused_update", 1)
+    eng.set_training_loss(kinds)
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32, kind=kinds)
+    ok = ~np.isnan(l_ref)
+    assert np.array_equal(np.isnan(losses), ~ok) and np.allclose(np.asarray(losses)[ok], np.asarray(l_ref)[ok], rtol=5e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 3e-5) >= 0.995, float(d.max())
+    # and through an epoch of the shuffled driver, against the two-kernel mode
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01); ref.set_training_loss(kinds)
+    eng.set_params(theta); eng.opt_init("Adam", 0.01)
+    for e_ in (eng, ref):
+        e_.train_epoch(128, seed=5, shuffle=True, want_loss=False)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-5
+    eng.close(); ref.close()
 
 
 def test_width_128_three_layers_runs_layer_by_layer():
