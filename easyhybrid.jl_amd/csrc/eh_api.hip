@@ -1313,8 +1313,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMemcpy(h->bn_run, run0, sizeof run0, hipMemcpyHostToDevice));
     }
     if (!lform) {             // (the fused-update accumulators: that mode exists for the per-wave kernels only)
-        HIPCHK_C(hipMalloc(&h->gacc, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-        HIPCHK_C(hipMemset(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+        HIPCHK_C(hipMalloc(&h->gacc, ((size_t)3 * EH_GSHARDS * h->n_acc + 4) * sizeof(float)));      // (+4: the fused prologue reads five tail floats of every shard whatever T is)
+        HIPCHK_C(hipMemset(h->gacc, 0, ((size_t)3 * EH_GSHARDS * h->n_acc + 4) * sizeof(float)));
     }
     h->slab_rows = lform ? (int)EH_LFORM_ROWS : h->max_blocks;
     HIPCHK_C(hipMalloc(&h->slab, (std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) + 16) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
