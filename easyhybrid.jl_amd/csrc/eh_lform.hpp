@@ -61,9 +61,14 @@ __device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' fr
 // epilogue masks), the LDS tiles are double-buffered (one barrier per step) -- the main loop is loads, LDS traffic and MFMAs with
 // a handful of vector-ALU instructions: on gfx950 an fp32 MFMA does not overlap with the vector ALU, so every
 // address computation or bounds predicate in the loop is time taken from the matrix pipe.
+// Four waves per SIMD (<= 128 registers: accumulators in the VGPR file, no AGPR copies): four workgroups per CU, so that e.g. the
+// 2 048 tiles of the tutorial net's largest forward product are two full rounds of 1 024 resident workgroups, not 2.67 of 768.
+#ifndef EH_GEMM_OCC
+#define EH_GEMM_OCC 4
+#endif
 // BT = 64: 64 x 64 tiles (one MFMA tile per wave) for products too small to fill the chip with 128 x 128 ones.
 template <bool ATR, bool BTR, int EPI, bool VEC = false, int BT = 128>
-__global__ __launch_bounds__(256) void eh_gemm_kernel(const EhGemmArgs g) {
+__global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmArgs g) {
     static_assert(BT == 128 || (BT == 64 && VEC), "64 x 64 tiles exist in the 16-byte-load form only");
     constexpr int BM = BT, BN = BT, BK = 16, LDS_LD = BM + 4, TI = BT / 64, WT = BT / 2, NP = BT / 64, QT = BT / 4, RP = 256 / QT;
     __shared__ __attribute__((aligned(16))) float As[VEC ? 2 : 1][BK][LDS_LD], Bs[VEC ? 2 : 1][BK][LDS_LD];
