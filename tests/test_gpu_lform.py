@@ -75,6 +75,26 @@ def test_other_deep_and_wide_shapes(act, hidden, n_pred):
     _check(spec, ho.init_theta(spec, 9, np.float32), X, f, {"Resp_obs": yv})
 
 
+def test_large_batch_takes_the_128_tile_vector_load_gemms():
+    """B = 16 384 on [8, 512, 256, 4]: every middle product has >= 256 tiles of 128 x 128 and aligned operands -- the 16-byte-load,
+    double-buffered main loop in all three operand layouts (forward NN, delta NT, weight gradient TN); smaller batches run the
+    64 x 64 tiles, unaligned shapes the 4-byte form, the first / last layer's weight gradients the streaming kernel"""
+    rng = np.random.default_rng(15)
+    B = 16384
+    spec = ho.HybridSpec(8, [512, 256], "expo2pool", dict(ho.EXPO2POOL_PARAMS), ["R0a", "ka", "R0b", "kb"], [], ["Resp_obs"], "tanh", True)
+    X = rng.random((8, B)).astype(np.float32)
+    f = {"T": (rng.random(B) * 40 - 10).astype(np.float32)}
+    yv = (1.0 + rng.random(B)).astype(np.float32); yv[rng.random(B) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 4, np.float32)
+    eng = util.load_engine(spec, theta, X, f, {"Resp_obs": yv})
+    _check(spec, theta, X, f, {"Resp_obs": yv}, eng=eng)
+    # same answer from the 4-byte form (EH_GEMM_NOVEC is read once per process: compare against the oracle-checked gradient instead)
+    l1, g1, _ = eng.loss_and_grad(first=0, count=2048)        # 64 x 64 tiles
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, :2048], {"T": f["T"][:2048]}, {"Resp_obs": yv[:2048]})
+    assert abs(l1 - l0) <= TOL * abs(l0) and util.relerr(g1, g0) <= TOL
+    eng.close()
+
+
 def test_two_targets_global_and_fixed_parameters():
     rng = np.random.default_rng(8)
     B = 500
