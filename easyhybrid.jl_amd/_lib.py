@@ -16,7 +16,7 @@ EH_LOSS_PROGRAM = 7
 EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE, EH_ERCCL = 0, -1, -2, -3, -4, -5, -6
 EH_COMM_ID_BYTES = 128
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
-EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT = 0, 1, 2, 3, 4, 5
+EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT, EH_BUF_TCOUNT = 0, 1, 2, 3, 4, 5, 6
 
 ACTIVATIONS = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
 EH_ACT_PER_NET = 5        # MultiNN: net k uses net_activation[k]
@@ -88,6 +88,8 @@ SIGNATURES = {
     "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),
     "eh_dp_grad": (C.c_int32, [_H, C.c_int64, C.c_int64]),
+    "eh_dp_counts": (C.c_int32, [_H, C.c_int64, C.c_int64]),
+    "eh_set_target_shift": (C.c_int32, [_H, C.c_int32, _F, C.c_int64]),
     "eh_set_weight_l2": (C.c_int32, [_H, C.c_float, C.c_int32]),
     "eh_graph_begin": (C.c_int32, [_H]),
     "eh_graph_end": (C.c_int32, [_H, C.POINTER(C.c_int32)]),

@@ -515,11 +515,16 @@ __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, i
 
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
 __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
-                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind) {
+                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, int T) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const float cnt = gradbuf[n_theta + 1];
+    float cnt = gradbuf[n_theta + 1];
     float scale = 0.0f, lossv = 0.0f;
-    eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv);
+    if (T == 1) eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv);
+    else {      // multi-target: the shards used the weights of the global batch (eh_dp_counts): the all-reduced sums are final
+        for (int t = 1; t < T; ++t) cnt += gradbuf[n_theta + 1 + t];
+        scale = cnt > 0.0f ? 1.0f : 0.0f;
+        lossv = cnt > 0.0f ? gradbuf[n_theta] : __builtin_nanf("");
+    }
     if (idx < n_theta && cnt > 0.0f) {
         const float g = gradbuf[idx] * scale;
         float th = theta[idx], mm = m[idx], vv = v[idx];
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
 // and  w_t = 1 / sum (y - mean y)^2  for nseLoss (:79-81) -- all of it a function of the targets alone.  One workgroup per target.
 struct EhShift4 { float c[EH_MAX_TARG]; };
 __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
-                                                       float* inv_n, unsigned loss_t, EhShift4 shift) {
+                                                       float* inv_n, unsigned loss_t, EhShift4 shift, float* raw = nullptr) {
     __shared__ float red[3][256];
     const int t = blockIdx.x;
     float c = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -556,10 +561,20 @@ __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C,
     }
     if (threadIdx.x == 0) {
         const float n = red[0][0];
+        if (raw) { raw[3 * t] = n; raw[3 * t + 1] = red[1][0]; raw[3 * t + 2] = red[2][0]; return; }      // data parallel: this shard's sums (EH_BUF_TCOUNT), all-reduced by the caller
         float w = n > 0.0f ? 1.0f / n : 0.0f;
         if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (red[2][0] - red[1][0] * red[1][0] / n);
         inv_n[t] = w;
     }
+}
+// (data parallel) the all-reduced sums [n_t | sum (y - c) | sum (y - c)^2] of the GLOBAL batch -> the per-target weights; c is common to the ranks (eh_set_target_shift)
+__global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned loss_t, float* inv_n) {
+    const int t = threadIdx.x;
+    if (t >= T) return;
+    const float n = raw[3 * t];
+    float w = n > 0.0f ? 1.0f / n : 0.0f;
+    if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (raw[3 * t + 2] - raw[3 * t + 1] * raw[3 * t + 1] / n);
+    inv_n[t] = w;
 }
 
 // input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample
@@ -715,6 +730,9 @@ struct eh_handle_s {
     float* bn_run = nullptr;        // [2][32] running mean / var
     float* bn_shift = nullptr;      // [32] common shift of the cross-GPU statistics (eh_set_bn_shift)
     float* bn_stat = nullptr;       // [65] sum d | sum d^2 | n of the current step, all-reduced by the host (EH_BUF_BNSTAT)
+    float* tcount = nullptr;        // [EH_MAX_TARG][3] n_t | sum (y - c) | sum (y - c)^2 of the current step's shard, all-reduced by the caller (EH_BUF_TCOUNT)
+    bool dp_weights = false;        // the step being launched takes its per-target weights from the all-reduced sums (no local counting pass)
+    bool tcount_ready = false;      // eh_dp_counts ran for the step eh_dp_grad is about to take
     bool bn_ext = false;            // bn_stat holds the statistics of the step about to run
     bool bn_dp_update = false;
     bool opt_ready = false;
@@ -1319,6 +1337,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->slab_rows = lform ? (int)EH_LFORM_ROWS : h->max_blocks;
     HIPCHK_C(hipMalloc(&h->slab, (std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) + 16) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->tcount, 3 * EH_MAX_TARG * sizeof(float)));
+    HIPCHK_C(hipMemset(h->tcount, 0, 3 * EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, 8 * sizeof(float)));      // per-target 1/n (T > 1), or [1, -, -, -, k0, k1, k2, loss] of a moment-based loss
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
     if (!lform) { if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; } }
@@ -1391,7 +1411,7 @@ int32_t eh_destroy(eh_handle* h) {
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
-    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
@@ -1859,7 +1879,7 @@ static int lform_eval(eh_handle* h, const EhSplit& sp, long long first, long lon
 static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* grid_out, bool bn_update) {
     if (h->lform) return lform_train(h, sp, idx, first, count, grid_out, bn_update);
     const EhNet& net = h->net;
-    if (net.T > 1) {
+    if (net.T > 1 && !h->dp_weights) {
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
         HIPCHK(h, hipGetLastError());
@@ -2444,7 +2464,7 @@ int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
 
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
-    if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: data-parallel seam supports single-target models");
+    if (h->net.T != 1 && !h->tcount_ready) return fail(h, EH_ESTATE, "eh_dp_grad: multi-target model: call eh_dp_counts for this window and all-reduce EH_BUF_TCOUNT first");
     if (h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
     if (h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: the weight_l2 extra loss is not built for the data-parallel seam");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
@@ -2454,7 +2474,45 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     EhSplit& sp = h->split[EH_SPLIT_TRAIN];
     int rc = check_window(h, sp, first, count, "eh_dp_grad");
     if (rc) return rc;
-    return do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
+    if (h->net.T != 1) {      // the weights of the GLOBAL batch from the all-reduced sums; the step kernel then normalises exactly
+        hipLaunchKernelGGL(eh_weights_from_counts_kernel, dim3(1), dim3(64), 0, h->stream, h->tcount, h->net.T, h->net.loss_t, h->inv_n);
+        HIPCHK(h, hipGetLastError());
+        h->dp_weights = true;
+    }
+    rc = do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
+    h->dp_weights = false; h->tcount_ready = false;
+    return rc;
+}
+
+// multi-target models under data parallelism: this shard's per-target sums of the window into EH_BUF_TCOUNT
+// ([n_t | sum (y - c) | sum (y - c)^2] per target, c = the split's target shift: the ranks must share it, eh_set_target_shift).
+// The caller all-reduces the 12 floats; eh_dp_grad turns them into the weights 1 / n_t (mse, mae) or 1 / sum (y - ybar)^2 (nseLoss).
+int32_t eh_dp_counts(eh_handle* h, int64_t first, int64_t count) {
+    if (!h) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    int rc = check_window(h, sp, first, count, "eh_dp_counts");
+    if (rc) return rc;
+    const EhNet& net = h->net;
+    EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
+    HIPCHK(h, hipMemsetAsync(h->tcount, 0, 3 * EH_MAX_TARG * sizeof(float), h->stream));
+    hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, h->perm_valid ? h->perm : nullptr, first, count,
+                       h->inv_n, net.loss_t, sh4, h->tcount);
+    HIPCHK(h, hipGetLastError());
+    h->tcount_ready = true;
+    return EH_OK;
+}
+
+// common shift of the shifted target sums (nseLoss, metrics) -- under data parallelism every rank passes the same vector, e.g. the
+// mean of each target over the global training set; eh_set_data resets it to the shard's own means
+int32_t eh_set_target_shift(eh_handle* h, int32_t split, const float* shift, int64_t n) {
+    if (!h || !shift) return EH_EINVAL;
+    if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_set_target_shift: split %d", split);
+    if (n != h->net.T) return fail(h, EH_EINVAL, "eh_set_target_shift: %lld values for %d targets", (long long)n, h->net.T);
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    for (int t = 0; t < h->net.T; ++t) h->split[split].shift[t] = shift[t];
+    return EH_OK;
 }
 
 int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* buffer_index) {
@@ -2611,7 +2669,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     const int nt = h->net.n_theta;
     hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, TH(h), MM(h), VV(h), sc_in, sc_out, h->opt,
-                       h->loss_hist, h->img, h->net.loss);
+                       h->loss_hist, h->img, h->net.loss, h->net.T);
     HIPCHK(h, hipGetLastError());
     h->sc_sel ^= 1;
     if (loss_out) {
@@ -2678,7 +2736,8 @@ int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
         case EH_BUF_BNSTAT:
             if (!h->bn_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the model has no input BatchNorm");
             buf = h->bn_stat; n = 65; break;
-        default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC or EH_BUF_BNSTAT)", which);
+        case EH_BUF_TCOUNT: buf = h->tcount; n = 3 * EH_MAX_TARG; break;
+        default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT or EH_BUF_TCOUNT)", which);
     }
     HIPCHK(h, hipSetDevice(h->device));
     NCCLCHK(h, g_rccl.AllReduce(buf, buf, n, ncclFloat, ncclSum, h->comm, h->stream));
@@ -2693,11 +2752,15 @@ int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss
         if ((rc = eh_dp_bn_stats(h, first, count))) return rc;
         if ((rc = eh_dp_allreduce(h, EH_BUF_BNSTAT, 0))) return rc;
     }
-    if (h->fused) {
+    if (h->fused && h->net.T == 1) {
         if (loss_out) return fail(h, EH_EINVAL, "eh_dp_train_step: fused_update mode reports no per-step loss (pass NULL)");
         int32_t k = 0;
         if ((rc = eh_dp_fused_step(h, first, count, &k))) return rc;
         return k >= 0 ? eh_dp_allreduce(h, EH_BUF_GACC, k) : EH_OK;
+    }
+    if (h->net.T != 1) {
+        if ((rc = eh_dp_counts(h, first, count))) return rc;
+        if ((rc = eh_dp_allreduce(h, EH_BUF_TCOUNT, 0))) return rc;
     }
     if ((rc = eh_dp_grad(h, first, count))) return rc;
     if ((rc = eh_dp_allreduce(h, EH_BUF_GRAD, 0))) return rc;
@@ -2706,7 +2769,7 @@ int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss
 
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {
     if (!h || !dev_ptr || !n_floats) return EH_EINVAL;
-    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC && which != EH_BUF_BNSTAT) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
+    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC && which != EH_BUF_BNSTAT && which != EH_BUF_TCOUNT) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
     switch (which) {
         case EH_BUF_GRAD: *dev_ptr = h->gradbuf; *n_floats = h->n_acc; return EH_OK;
         case EH_BUF_THETA: *dev_ptr = TH(h); *n_floats = h->net.n_theta; return EH_OK;
@@ -2716,6 +2779,7 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
         case EH_BUF_BNSTAT:
             if (!h->bn_on) return fail(h, EH_ESTATE, "eh_device_buffer: the model has no input BatchNorm");
             *dev_ptr = h->bn_stat; *n_floats = 65; return EH_OK;
+        case EH_BUF_TCOUNT: *dev_ptr = h->tcount; *n_floats = 3 * EH_MAX_TARG; return EH_OK;
         default: return fail(h, EH_EINVAL, "eh_device_buffer: which = %d", which);
     }
 }

@@ -46,6 +46,20 @@ def normalise(buf, n_theta: int, kind: str = "mse"):
     return buf[:n_theta] / n, S / n, n
 
 
+def target_weights(tcount, kinds):
+    """per-target sums [n_t | sum (y-c) | sum (y-c)^2] (T x 3) of the GLOBAL batch (EH_BUF_TCOUNT summed over the ranks) -> the
+    weights w_t the residual terms of target t enter the loss with: 1 / n_t (mse, mae), 1 / sum (y - ybar)^2 (nseLoss).
+    Same arithmetic as eh_weights_from_counts_kernel (csrc/eh_api.hip)."""
+    import numpy as np
+    tc = np.asarray(tcount, np.float64).reshape(-1, 3)
+    kinds = [kinds] * len(tc) if isinstance(kinds, str) else list(kinds)
+    w = np.zeros(len(tc))
+    for t, (n, s1, s2) in enumerate(tc):
+        if n > 0:
+            w[t] = 1.0 / (s2 - s1 * s1 / n) if kinds[t] == "nseLoss" else 1.0 / n
+    return w
+
+
 def bn_moments(stat, shift):
     """[sum (x-c) (32) | sum (x-c)^2 (32) | n] summed over the ranks -> (mean, biased variance) per predictor.
     Same arithmetic as the BatchNorm prologue of the step kernel (csrc/eh_device.hpp)."""
@@ -73,6 +87,7 @@ class DataParallel:
         passes on every rank (no collective call per step at all), otherwise one RCCL all-reduce.
         fused=False: step kernel, deterministic reduction, all-reduce, optimiser kernel."""
         import os
+        import numpy as np
         import torch
         from . import _lib as L
         self.engine, self.group, self.fused = engine, group, fused
@@ -111,6 +126,20 @@ class DataParallel:
             tot = torch.tensor(list(sx) + [float(n)], dtype=torch.float64, device=dev)
             allreduce_partials(tot, group)
             engine.set_bn_shift((tot[:-1] / tot[-1]).cpu().numpy())
+        # the shifted target sums (nseLoss normaliser; per-target weights of multi-target models) are added across ranks: every
+        # rank shifts by the same vector, the mean of each target over the global training set
+        self.multi = int(engine.desc.n_targets) > 1
+        ys = getattr(engine, "y_sum", {}).get(L.EH_SPLIT_TRAIN)
+        if ys is not None:
+            tot = torch.tensor(np.asarray(ys, np.float64).reshape(-1), dtype=torch.float64, device=dev)
+            allreduce_partials(tot, group)
+            tot = tot.cpu().numpy().reshape(-1, 2)
+            engine.set_target_shift(np.where(tot[:, 1] > 0, tot[:, 0] / np.maximum(tot[:, 1], 1), 0.0))
+        elif self.multi:
+            raise RuntimeError("DataParallel with a multi-target model needs the train split uploaded through set_data first")
+        if self.multi:
+            cptr, cn = engine.device_buffer(L.EH_BUF_TCOUNT)
+            self.cbuf = torch.as_tensor(_DevArray(cptr, cn), device=dev)
         if specialize:
             engine.set_option("specialize", 1)
             self.prepare()
@@ -256,6 +285,9 @@ class DataParallel:
             if k >= 0:                                        # k < 0: the kernels exchange the sums themselves (p2p)
                 allreduce_partials(self.gacc[k], self.group)  # 8 shards x (n_theta + 2) raw sums
             return None
+        if self.multi:                                        # per-target normalisers of the GLOBAL batch ahead of the pass (12 floats)
+            self.engine.dp_counts(first, count)
+            allreduce_partials(self.cbuf, self.group)
         self.engine.dp_grad(first, count)
         allreduce_partials(self.buf, self.group)
         return self.engine.dp_apply(want_loss)

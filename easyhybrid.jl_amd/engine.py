@@ -62,6 +62,7 @@ class HybridEngine:
         self.param_names = list(param_names)
         self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
         self.x_sum = {}
+        self.y_sum = {}
         if os.environ.get("EH_MAX_BLOCKS"):               # several ranks sharing one GPU (tests): every kernel must fit beside the others
             self.set_option("max_blocks", int(os.environ["EH_MAX_BLOCKS"]))
 
@@ -100,6 +101,7 @@ class HybridEngine:
         if len(forcings) != self.desc.n_forcings or len(targets) != self.desc.n_targets:
             raise ValueError("number of forcing / target arrays does not match the model")
         self.x_sum[split] = (X.sum(axis=1, dtype=np.float64), N)      # for the common BatchNorm shift under data parallelism
+        self.y_sum[split] = np.array([[np.nansum(np.asarray(t, np.float64)), np.count_nonzero(~np.isnan(t))] for t in targets], np.float64)   # (sum, n valid) per target: common target shift
         xf = np.asfortranarray(X)                       # (P x N) column-major == N records of P
         fs = [np.ascontiguousarray(f, np.float32) for f in forcings]
         ts = [np.ascontiguousarray(t, np.float32) for t in targets]
@@ -286,6 +288,15 @@ class HybridEngine:
     # -- data-parallel seam ----------------------------------------------------------------------
     def dp_grad(self, first: int, count: int):
         self._chk(self._lib.eh_dp_grad(self._h, first, count))
+
+    def dp_counts(self, first: int, count: int):
+        """multi-target models: this shard's per-target sums of the window into EH_BUF_TCOUNT (all-reduce it, then dp_grad)"""
+        self._chk(self._lib.eh_dp_counts(self._h, first, count))
+
+    def set_target_shift(self, shift, split: int = L.EH_SPLIT_TRAIN):
+        """common shift of the shifted target sums (every rank must pass the same vector, e.g. the global mean of each target)"""
+        c = np.ascontiguousarray(shift, np.float32)
+        self._chk(self._lib.eh_set_target_shift(self._h, split, _fptr(c), c.size))
 
     def set_bn_shift(self, shift):
         """common per-predictor shift of the cross-GPU BatchNorm sums (every rank must pass the same vector)"""

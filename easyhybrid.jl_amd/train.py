@@ -323,8 +323,6 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
     from .dp import DataParallel, shard_range
     if not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("train(distributed=True) needs an initialised torch.distributed process group (one rank per GPU)")
-    if len(model.targets) != 1:
-        raise NotImplementedError("distributed training: the data-parallel seam supports single-target models")
     if tc.extra_loss is not None:
         raise NotImplementedError("distributed training: the weight_l2 extra loss is not built for the data-parallel seam")
     if tc.training_loss in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):

@@ -121,7 +121,8 @@ typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LO
                        EH_LOSS_PROGRAM = 7 /* a recorded custom loss, see eh_set_loss_program */ } eh_loss;
 
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
-typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4, EH_BUF_BNSTAT = 5 } eh_buffer;
+typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4, EH_BUF_BNSTAT = 5,
+                         EH_BUF_TCOUNT = 6 /* [EH_MAX_TARG][3] per-target sums of the step's shard (eh_dp_counts) */ } eh_buffer;
 
 typedef struct eh_model_desc {
     int32_t struct_size;                     /* = sizeof(eh_model_desc) */
@@ -283,8 +284,15 @@ int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_ta
  * (host: all_reduce(SUM) over that buffer)
  * eh_dp_apply  : normalise by the global counts and apply the optimiser update (replicated).
  * The mean over the GLOBAL valid count is what the reference computes (src/losses/loss_fn.jl:61-63),
- * so shards exchange sums and counts, never per-shard means.  Single-target models only (T == 1). */
+ * so shards exchange sums and counts, never per-shard means.
+ * Multi-target models (T > 1): every target has its own normaliser, which must be known inside the pass, so a step
+ * starts with  eh_dp_counts(h, first, count)  -> EH_BUF_TCOUNT = [ n_t | sum (y-c) | sum (y-c)^2 ] per target (12 floats),
+ * (host: all_reduce(SUM) over that buffer), then eh_dp_grad (weights 1/n_t, or 1/sum (y-ybar)^2 for nseLoss, of the GLOBAL
+ * batch; EH_BUF_GRAD then holds final sums), all-reduce, eh_dp_apply.  c is the split's target shift: the ranks must share
+ * it (eh_set_target_shift, e.g. the global mean of each target); eh_set_data resets it to the shard's own means. */
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count);
+int32_t eh_dp_counts(eh_handle* h, int64_t first, int64_t count);
+int32_t eh_set_target_shift(eh_handle* h, int32_t split, const float* shift, int64_t n);
 int32_t eh_dp_apply(eh_handle* h, float* loss_out);
 /* per-shard epoch shuffle for the data-parallel calls (the reference shuffles the whole training set,
  * src/data/loaders.jl:6; here every rank permutes its own shard): on != 0 draws a new keyed

@@ -128,3 +128,63 @@ def test_dp_batchnorm_statistics_are_those_of_the_global_batch():
     for p in ps:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-target models: the per-target normalisers of the GLOBAL batch go round before the pass
+# ----------------------------------------------------------------------------------------------
+def _flux_case(N):
+    rng = np.random.default_rng(2)
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(3, [8], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((3, N)); f = {"SW_IN": rng.random(N) * 400, "TA": rng.random(N) * 30}
+    y = {"NEE": 4 + rng.standard_normal(N), "GPP": rng.random(N) * 3}
+    y["NEE"][: N // 2][rng.random(N // 2) < 0.7] = np.nan          # the first shard holds few NEE values
+    y["GPP"][N // 2:][::3] = np.nan
+    return spec, ho.init_theta(spec, 5, np.float64), X, f, y
+
+
+def _mt_worker(rank, world, port, q, kinds):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = 301
+    spec, theta, X, f, y = _flux_case(N)
+    lo, hi = dp.shard_range(N, rank, world)
+    Xs, fs, ys = X[:, lo:hi], {k: v[lo:hi] for k, v in f.items()}, {k: v[lo:hi] for k, v in y.items()}
+    # what DataParallel.__init__ does: a common shift (global mean of each target) ...
+    tot = torch.tensor([[np.nansum(ys[t]), np.count_nonzero(~np.isnan(ys[t]))] for t in spec.targets], dtype=torch.float64)
+    dp.allreduce_partials(tot)
+    c = (tot[:, 0] / tot[:, 1]).numpy()
+    # ... and per step: eh_dp_counts -> all-reduce (12 floats) -> weights of the global batch
+    tc = torch.tensor([[np.count_nonzero(~np.isnan(ys[t])), np.nansum(ys[t] - c[i]), np.nansum((ys[t] - c[i]) ** 2)] for i, t in enumerate(spec.targets)], dtype=torch.float64)
+    dp.allreduce_partials(tc)
+    w = dp.target_weights(tc.numpy(), kinds)
+    # eh_dp_grad: sum over the shard's samples of w_t x (un-normalised per-target terms), the oracle standing in for the kernel
+    part = np.zeros(spec.n_theta + 1)
+    for i, t in enumerate(spec.targets):
+        only = {k: (v if k == t else np.full_like(v, np.nan)) for k, v in ys.items()}
+        n_loc = np.count_nonzero(~np.isnan(ys[t]))
+        if n_loc == 0:
+            continue
+        l, g, _ = ho.loss_and_grad(spec, theta, Xs, fs, only, kind="mae" if kinds[i] == "mae" else "mse")      # local mean of r^2 (|r|): x n_loc = the raw sum
+        part += w[i] * n_loc * np.concatenate([g, [l]])
+    buf = torch.from_numpy(part)
+    dp.allreduce_partials(buf)
+    l0, g0, _ = ho.loss_and_grad(spec, theta, X, f, y, kind=list(kinds))
+    ok = abs(float(buf[-1]) - l0) <= 1e-11 * abs(l0) and float(np.max(np.abs(buf[:-1].numpy() - g0))) <= 1e-11 * np.max(np.abs(g0))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kinds", [("mse", "mse"), ("mae", "nseLoss")])
+def test_multi_target_protocol_counts_then_weighted_sums(kinds):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_mt_worker, args=(r, world, port, q, kinds)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

@@ -55,6 +55,6 @@ def test_two_ranks_recover_from_a_missed_exchange():
 
 
 def test_two_ranks_distributed_train_front_door():
-    # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm
+    # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm, and a two-target model with per-target losses
     lines = _run({"EH_MAX_BLOCKS": "64"}, 29563, tool="train_two_ranks.py")
-    assert len(lines) == 4 and all("results_identical_across_ranks=True" in l for l in lines), lines
+    assert len(lines) == 6 and all("results_identical_across_ranks=True" in l for l in lines), lines      # (single target +- BatchNorm, two targets) x two ranks

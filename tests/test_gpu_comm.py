@@ -72,3 +72,29 @@ def test_batchnorm_statistics_go_through_the_library_collective():
     for a, b in zip(eng.get_bn_state(), ref.get_bn_state()):
         assert np.allclose(a, b, rtol=2e-6, atol=1e-7)
     eng.close(); ref.close()
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_multi_target_model_through_the_library_collective(fused):
+    """eh_dp_train_step on a two-target model: counts -> all-reduce (EH_BUF_TCOUNT) -> gradient sums with the global weights ->
+    all-reduce -> apply; in fused_update mode the seam keeps to that three-kernel path (the weights need the global counts)"""
+    from oracle import hybrid_oracle as ho
+    rng = np.random.default_rng(31)
+    B = 2048
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(4, [16, 8], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((4, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": (5 + rng.standard_normal(B)).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][rng.random(B) < 0.3] = np.nan
+    theta = ho.init_theta(spec, 6, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_training_loss(("nseLoss", "mae"))
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01); ref.set_training_loss(("nseLoss", "mae"))
+    eng.comm_init(HybridEngine.comm_unique_id(), 1, 0)
+    eng.set_option("fused_update", fused)
+    for s in range(4):
+        eng.dp_train_step(s * 512, 512)
+        ref.train_step(s * 512, 512, want_loss=False)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-6
+    eng.comm_destroy()
+    eng.close(); ref.close()

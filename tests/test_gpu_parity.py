@@ -400,6 +400,50 @@ def test_config4_size_eight_virtual_shards_of_65536():
     ref.close(); eng.close()
 
 
+@pytest.mark.parametrize("kinds", ["mse", ("mae", "nseLoss")])
+def test_dp_seam_multi_target_virtual_shards(kinds):
+    """multi-target models under data parallelism: eh_dp_counts -> all-reduce of the 12 per-target sums -> eh_dp_grad with the
+    weights of the GLOBAL batch -> all-reduce -> eh_dp_apply; four "ranks" on the one GPU, sums standing in for the collectives;
+    shards with very different numbers of valid targets, so per-shard normalisers would be visibly wrong"""
+    import torch
+    rng = np.random.default_rng(21)
+    B = 2048
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(4, [16, 8], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((4, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": (5 + rng.standard_normal(B)).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][:512][rng.random(512) < 0.8] = np.nan            # shard 0: few NEE values
+    y["GPP"][1536:] = np.nan                                   # shard 3: no GPP at all
+    theta = ho.init_theta(spec, 6, np.float32)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01); ref.set_training_loss(kinds)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_training_loss(kinds)
+    gptr, gn = eng.device_buffer(eh._lib.EH_BUF_GRAD); cptr, cn = eng.device_buffer(eh._lib.EH_BUF_TCOUNT)
+    gbuf = torch.as_tensor(eh.dp._DevArray(gptr, gn), device="cuda"); cbuf = torch.as_tensor(eh.dp._DevArray(cptr, cn), device="cuda")
+    with pytest.raises(RuntimeError, match="eh_dp_counts"):
+        eng.dp_grad(0, 512)
+    for step in range(3):
+        l_ref = ref.train_step(0, B)
+        cacc = torch.zeros_like(cbuf)
+        for k in range(4):
+            eng.dp_counts(k * 512, 512); eng.synchronize(); cacc += cbuf
+        gacc = torch.zeros_like(gbuf)
+        for k in range(4):
+            eng.dp_counts(k * 512, 512); eng.synchronize()      # "rank" k's own call (arms eh_dp_grad) ...
+            cbuf.copy_(cacc); torch.cuda.synchronize()          # ... and the all-reduced sums in its buffer
+            eng.dp_grad(k * 512, 512); eng.synchronize(); gacc += gbuf
+        gbuf.copy_(gacc); torch.cuda.synchronize()
+        l = eng.dp_apply(want_loss=True)
+        assert l == pytest.approx(l_ref, rel=2e-5), (step, l, l_ref)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 5e-6
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kinds)      # and the first step's loss against the oracle
+    ref.close(); eng.close()
+    chk = util.load_engine(spec, theta, X, f, y); chk.set_training_loss(kinds)
+    l1, g1, _ = chk.loss_and_grad()
+    assert abs(l1 - l0) <= 1e-5 * abs(l0) and util.relerr(g1, g0) <= 1e-5
+    chk.close()
+
+
 def test_dp_seam_and_front_door_with_per_network_activations_and_depths():
     """the reference's MultiNN constructor case (hidden_layers = (a = [16, 8], d = [8]), activation = (a = tanh, d = sigmoid),
     test/test_generic_hybrid_model.jl:346-347) through the data-parallel seam and through `train`: kernels compiled at run time"""

@@ -41,6 +41,29 @@ for bn in (False, True):
     print(f"rank {rank}: input_batchnorm={bn} val mse distributed {v_d:.5f} vs single-process {v_r:.5f}; "
           f"first-epoch {out.val_history[0]['mse']['sum']:.3f}; results_identical_across_ranks={same}", flush=True)
     ok = ok and same and v_d <= 1.25 * v_r + 1e-3 and v_d < 0.5 * out.val_history[0]["mse"]["sum"]
+# a two-target model (flux partitioning: NEE and GPP observed, different gaps): the per-target normalisers of the GLOBAL batch
+# go round before every pass (eh_dp_counts + a 12-float all-reduce), per-target losses
+rng = np.random.default_rng(3)
+n = 16000
+cols = {f"x{i}": rng.standard_normal(n).astype(np.float32) for i in range(4)}
+cols["SW_IN"] = (rng.random(n) * 400).astype(np.float32); cols["TA"] = (rng.random(n) * 30).astype(np.float32)
+gpp = 0.004 * cols["SW_IN"] * (1 + 0.3 * np.tanh(cols["x0"])); reco = (1.5 + 0.5 * np.tanh(cols["x1"])) * 1.6 ** (0.1 * (cols["TA"] - 15))
+cols["GPP"] = (gpp + 0.05 * rng.standard_normal(n)).astype(np.float32); cols["NEE"] = (reco - gpp + 0.05 * rng.standard_normal(n)).astype(np.float32)
+cols["NEE"][rng.random(n) < 0.3] = np.nan; cols["GPP"][:n // 2][rng.random(n // 2) < 0.6] = np.nan      # the first shard sees few GPP values
+model = eh.constructHybridModel([f"x{i}" for i in range(4)], ["SW_IN", "TA"], ["NEE", "GPP"], eh.FluxPartModelQ10,
+                                {"RUE": (0.005, 0.0, 0.02), "Rb": (1.5, 0.0, 6.0), "Q10": (1.6, 1.0, 4.0)}, ["RUE", "Rb"], ["Q10"],
+                                hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+kw = dict(nepochs=6, batchsize=1024, opt=eh.Adam(0.01), loss_types=["mse", "r2"], random_seed=11, training_loss=eh.PerTarget(("mse", "mae")))
+out = eh.train(model, cols, distributed=True, **kw)
+ref = eh.train(model, cols, distributed=False, **kw)
+t = torch.from_numpy(np.concatenate([out.ps, [out.best_loss], out.val_obs_pred["NEE_pred"][:100]]).astype(np.float64))
+tl = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(tl, t)
+same = all(bool(torch.equal(tl[0], q)) for q in tl)
+v_d, v_r = out.val_history[-1]["mse"]["sum"], ref.val_history[-1]["mse"]["sum"]
+print(f"rank {rank}: two targets, PerTarget(mse, mae): val mse distributed {v_d:.5f} vs single-process {v_r:.5f}; "
+      f"first-epoch {out.val_history[0]['mse']['sum']:.3f}; results_identical_across_ranks={same}", flush=True)
+ok = ok and same and v_d <= 1.25 * v_r + 1e-3 and v_d < 0.5 * out.val_history[0]["mse"]["sum"]
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
