@@ -426,6 +426,11 @@ function device_buffer(e::HybridEngine, which::Integer)
     return Ptr{Float32}(p[]), n[]
 end
 dp_grad!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_grad(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)
+"multi-target models under DP: this shard's per-target sums into EH_BUF_TCOUNT (buffer 6; all-reduce its 12 floats, then dp_grad!); dp_train_step! does it itself"
+dp_counts!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_counts(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)
+"common shift of the shifted target sums: every rank passes the same vector (e.g. the global mean of each target) after set_data!"
+set_target_shift!(e::HybridEngine, shift::Vector{Float32}; split = EH_SPLIT_TRAIN) =
+    check(e, @ccall LIB[].eh_set_target_shift(e.h::Ptr{Cvoid}, split::Int32, shift::Ptr{Float32}, length(shift)::Int64)::Int32)
 function dp_apply!(e::HybridEngine)
     loss = Ref{Float32}(NaN32)
     check(e, @ccall LIB[].eh_dp_apply(e.h::Ptr{Cvoid}, loss::Ref{Float32})::Int32)
