@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, i
 
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
 __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
-                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, int T) {
+                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, int T, const float* l2val) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float cnt = gradbuf[n_theta + 1];
     float scale = 0.0f, lossv = 0.0f;
@@ -525,9 +525,11 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
         scale = cnt > 0.0f ? 1.0f : 0.0f;
         lossv = cnt > 0.0f ? gradbuf[n_theta] : __builtin_nanf("");
     }
+    if (l2val && cnt > 0.0f) lossv += *l2val;                  // + lambda * weight_l2 of the (replicated) parameters: agg = sum([loss, extra...]), compute_loss.jl:31-34
     if (idx < n_theta && cnt > 0.0f) {
-        const float g = gradbuf[idx] * scale;
+        float g = gradbuf[idx] * scale;
         float th = theta[idx], mm = m[idx], vv = v[idx];
+        if (l2val && eh_is_weight(im, idx)) g = fmaf(2.0f * im.l2c, th, g);
         eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;
         eh_image_store(im, idx, th);
@@ -1988,7 +1990,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
     const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS;
-    const bool l2 = h->img.l2c != 0.0f;
+    const bool l2 = h->img.l2c != 0.0f && !raw;      // (data-parallel seam: raw sums only -- the extra loss is added once, in eh_dp_apply)
     if (l2) {
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
         HIPCHK(h, hipGetLastError());
@@ -2466,7 +2468,6 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1 && !h->tcount_ready) return fail(h, EH_ESTATE, "eh_dp_grad: multi-target model: call eh_dp_counts for this window and all-reduce EH_BUF_TCOUNT first");
     if (h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
-    if (h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: the weight_l2 extra loss is not built for the data-parallel seam");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     h->bn_dp_update = h->bn_on;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2668,8 +2669,13 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     const int nt = h->net.n_theta;
+    const bool l2 = h->img.l2c != 0.0f;
+    if (l2) {                                                  // the extra loss is a function of the replicated parameters: every rank adds the same term
+        hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
+        HIPCHK(h, hipGetLastError());
+    }
     hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, TH(h), MM(h), VV(h), sc_in, sc_out, h->opt,
-                       h->loss_hist, h->img, h->net.loss, h->net.T);
+                       h->loss_hist, h->img, h->net.loss, h->net.T, l2 ? h->l2val : nullptr);
     HIPCHK(h, hipGetLastError());
     h->sc_sel ^= 1;
     if (loss_out) {

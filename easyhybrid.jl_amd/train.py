@@ -323,8 +323,6 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
     from .dp import DataParallel, shard_range
     if not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("train(distributed=True) needs an initialised torch.distributed process group (one rank per GPU)")
-    if tc.extra_loss is not None:
-        raise NotImplementedError("distributed training: the weight_l2 extra loss is not built for the data-parallel seam")
     if tc.training_loss in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):
         raise NotImplementedError("distributed training: pearson / kge losses need the moments of the global batch before the backward pass (not built)")
     (xtr, ftr, ytr), (xva, fva, yva) = train_split, val_split
@@ -345,6 +343,8 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.set_params(theta); ev.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
+        if tc.extra_loss is not None:                 # a function of the replicated parameters: every rank adds the same term in eh_dp_apply
+            eng.set_weight_l2(tc.extra_loss.lam, tc.extra_loss.normalize)
         drv = DataParallel(eng, fused=tc.fused_update is not False, specialize=bool(tc.specialize))      # ("auto" compiles before the first step here: every rank has to be ready together)
         has_bn = bool(model.config.get("input_batchnorm"))
         first_lt = tc.loss_types[0]
@@ -354,8 +354,13 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
             ev.set_params(eng.get_params())
             if has_bn:
                 ev.set_bn_state(*eng.get_bn_state())
-            return EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
+            snap = EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
                                  _losses(ev, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
+            if tc.extra_loss is not None:
+                v = _weight_l2_value(model, eng.get_params(), tc.extra_loss)
+                for d in (snap.l_train, snap.l_val):
+                    d["extra_loss"] = {"weight_l2": v, "sum": v}
+            return snap
         init = snapshot()
         history = [init]
         best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0

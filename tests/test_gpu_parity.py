@@ -1467,6 +1467,27 @@ def test_weight_l2_extra_loss(normalize, shape):
     eng.close()
 
 
+def test_weight_l2_through_the_data_parallel_seam():
+    """the extra loss is a function of the replicated parameters: the shards exchange raw data sums only, eh_dp_apply adds
+    2 lambda w to the weight gradients and lambda sum w^2 to the loss once (four virtual shards against the plain step)"""
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01); ref.set_weight_l2(0.2, False)
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_weight_l2(0.2, False)
+    ptr, n = eng.device_buffer(eh._lib.EH_BUF_GRAD)
+    buf = torch.as_tensor(eh.dp._DevArray(ptr, n), device="cuda")
+    for step in range(3):
+        l_ref = ref.train_step(0, 2048)
+        acc = torch.zeros_like(buf)
+        for k in range(4):
+            eng.dp_grad(k * 512, 512); eng.synchronize(); acc += buf
+        buf.copy_(acc); torch.cuda.synchronize()
+        l = eng.dp_apply(want_loss=True)
+        assert l == pytest.approx(l_ref, rel=1e-5)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-6
+    ref.close(); eng.close()
+
+
 def test_train_front_door_with_weight_l2_shrinks_the_weights():
     cols = eh.synthetic.make_synth_rbq10(3000, seed=5, nan_frac=0.05)
     cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
