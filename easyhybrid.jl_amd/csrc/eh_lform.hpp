@@ -286,19 +286,6 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) {
     if (a.cs_thin && blockIdx.x == 0 && tid < a.J) a.cs_thin[(long long)z * a.cs_z + tid] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
 }
 
-// out[z * zstride + n] = sum over rows m of chunk z of D(m, n), D(m, n) at D + m*sm + n*sn  (bias gradients: column sums of the deltas)
-__global__ __launch_bounds__(256) void eh_colsum_kernel(const float* D, long long sm, long long sn, int M, int N, int mchunk, float* out, long long zstride) {
-    __shared__ float red[4][64];
-    const int tid = threadIdx.x, nl = tid & 63, q = tid >> 6, n = blockIdx.x * 64 + nl, z = blockIdx.y;
-    const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
-    float s = 0.0f;
-    if (n < N)
-        for (int m = mbeg + q; m < mend; m += 4) s += D[(long long)m * sm + (long long)n * sn];
-    red[q][nl] = s;
-    __syncthreads();
-    if (q == 0 && n < N) out[(long long)z * zstride + n] = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
-}
-
 // The minibatch as the GEMMs want it: Xb [count][P] = the predictors of samples idx[first + i] (or first + i), normalised by the
 // input BatchNorm when the model has one (train mode: the statistics of THIS minibatch from eh_bn_stats_kernel's partial sums, and
 // block 0 advances the running statistics; test mode: the running statistics in `meta`).
