@@ -720,7 +720,7 @@ struct eh_handle_s {
     int p2p_world = 0, p2p_rank = 0;
     unsigned p2p_seq = 0;
     float* p2p_stage = nullptr;
-    unsigned* p2p_ctr = nullptr;    // [0] workgroup counter, [1] error flag, [2] self-test mismatches
+    unsigned* p2p_ctr = nullptr;    // [0] top-level ticket, [1] error flag, [2] self-test mismatches, [32 (1 + g)] group tickets (eh_p2p_publish)
     EhP2P* p2p_dev = nullptr;
     EhP2P p2p_host{};               // the same descriptor, handed to the step kernels by value
     void* p2p_peer[EH_GSHARDS] = {nullptr};
@@ -2559,8 +2559,8 @@ int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out,
     h->p2p_recv = buf;
     HIPCHK(h, hipMalloc(&h->p2p_stage, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK(h, hipMemset(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK(h, hipMalloc(&h->p2p_ctr, 4 * sizeof(unsigned)));
-    HIPCHK(h, hipMemset(h->p2p_ctr, 0, 4 * sizeof(unsigned)));
+    HIPCHK(h, hipMalloc(&h->p2p_ctr, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));      // [0] top ticket, [1] error flag, [2] self-test mismatches, [32 (1 + g)] group tickets
+    HIPCHK(h, hipMemset(h->p2p_ctr, 0, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));
     HIPCHK(h, hipMalloc(&h->p2p_dev, sizeof(EhP2P)));
     HIPCHK(h, hipDeviceSynchronize());        // the memsets ran on the null stream, which the engine's non-blocking stream does not wait for
     memcpy(handle_out, &hd, sizeof hd);

@@ -113,7 +113,7 @@ __device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float
 struct EhP2P {
     unsigned long long* peer_recv[EH_GSHARDS];   // receive buffers of every rank (own one included), mapped into this process
     float* stage;                        // local [3][EH_GSHARDS][n_acc] staging accumulators
-    unsigned* counter;                   // workgroups of the current launch that have finished accumulating
+    unsigned* counter;                   // [0] top-level ticket of the current launch (groups whose workgroups have all finished accumulating); [32 (1 + g)] group g's ticket
     int* err;                            // set when a wait ran into its deadline
     int world, rank;
 };
@@ -492,6 +492,7 @@ __device__ __forceinline__ void eh_ll_finish(const EhP2P* P, A addr, unsigned se
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = ((unsigned)(w[i] >> 32) == seq) ? __uint_as_float((unsigned)w[i]) : 0.0f;
 }
+enum { EH_P2P_GROUPS = 16 };     // first-level ticket counters at counter[32 (1 + g)], g < 16 (one 128-byte line each)
 // called by every thread of every workgroup once its sums are in the staging shards
 __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
     __shared__ unsigned eh_p2p_last;
@@ -499,7 +500,20 @@ __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigne
     // which a __threadfence() would add 256 times per launch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) eh_p2p_last = (atomicAdd(P->counter, 1u) == gridDim.x - 1) ? 1u : 0u;
+    if (tid == 0) {
+        // Two-level ticket: 256 returning atomics on ONE address serialise at the memory side (~13 ns each: the workgroups of a
+        // launch retire within a microsecond of each other, so the last one used to wait out most of the queue).  Sixteen group
+        // counters on lines of their own take at most 16 tickets each; a group's last workgroup takes one of 16 top-level tickets.
+        const unsigned ng = gridDim.x < EH_P2P_GROUPS ? gridDim.x : EH_P2P_GROUPS, gi = blockIdx.x % EH_P2P_GROUPS;
+        const unsigned gsz = (gridDim.x - gi + EH_P2P_GROUPS - 1) / EH_P2P_GROUPS;
+        unsigned* const gc = P->counter + 32 * (1 + gi);
+        unsigned last = 0u;
+        if (atomicAdd(gc, 1u) == gsz - 1) {
+            __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (atomicAdd(P->counter, 1u) == ng - 1) ? 1u : 0u;
+        }
+        eh_p2p_last = last;
+    }
     __syncthreads();
     if (!eh_p2p_last) return;
     const float* st = P->stage + (long long)slot * EH_GSHARDS * n_acc;
