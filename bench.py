@@ -2,7 +2,8 @@
 """bench.py -- headline benchmark of BASELINE.json: training samples/s + ms/step, RbQ10 hybrid
 ([2,16,16,1] MLP -> rb, Q10 global), batch 65 536 per GPU, fp32, synthetic data resident in HBM.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: this script spawns its own N ranks,
+                                                           one process per GPU, BEFORE anything touches a GPU -- spawn_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch: forward + mechanistic model + masked MSE + VJP
@@ -28,6 +29,57 @@ FLOP_PER_SAMPLE = 1824        # 3 x 2 x (2*16 + 16*16 + 16*1)    SURVEY.md secti
 BYTES_PER_SAMPLE = 16         # 4 x (P + F + T) floats; the mask is the NaN in the target, so no +T byte
 PEAK_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBPS = 8000.0
+
+
+def spawn_ranks(nprocs, cmd, env=None, capture=False, timeout=None):
+    """The launcher `python bench.py --gpus N` is its own: start `cmd` N times, one process per rank (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, rendezvous on 127.0.0.1 at a free port), wait for all of them,
+    and stop the others (by their exact PIDs) as soon as one fails -- a rank that died would leave its peers in a barrier.
+    The calling process never initialises a GPU (a process that has must not start programs on the GPU boxes).
+    Returns the largest exit code; capture=True: (code, rank 0's stdout)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(nprocs), LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                EH_BENCH_LAUNCHER="bench.py:spawn_ranks")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL and the peer-to-peer exchange need it on this driver
+    procs = []
+    for r in range(nprocs):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if (capture and r == 0) else None))
+    t0, rc, chunks, reader = time.monotonic(), 0, [], None
+    try:
+        if capture:                                          # a thread drains rank 0's pipe: the wait loop below must keep running
+            import threading
+            reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+            reader.start()
+        live, stopped = list(procs), set()
+        while live:
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                if c != 0 and p.pid not in stopped:          # (a rank this loop stopped reports the signal, not a failure of its own)
+                    rc = max(rc, c if c > 0 else 128 - c)
+                    for q in live:                           # the exact processes started above, nothing by pattern
+                        stopped.add(q.pid)
+                        q.terminate()
+            if timeout is not None and time.monotonic() - t0 > timeout and live:
+                rc = max(rc, 124)
+                for q in live:
+                    stopped.add(q.pid)
+                    q.terminate()
+                timeout = None
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if reader is not None:
+        reader.join(10)
+    return (rc, b"".join(chunks).decode(errors="replace")) if capture else rc
 
 
 def cpu_baseline(batch, seconds=12.0):
@@ -74,6 +126,35 @@ def cpu_baseline(batch, seconds=12.0):
     return out
 
 
+def parity_replay(model, eng_factory, cols, X, B, nsteps=20):
+    """Checker leg (after the timed region, never measured): the same `nsteps` Adam steps on the bench's own un-scaled inputs and
+    initial parameters, on the GPU engine and on the plain-C oracle port, then the loss of the next batch on both.  Ties the
+    headline workload itself -- raw sw_pot ~ 50, i.e. the first layer's tanh saturated -- to the oracle."""
+    from oracle import c_oracle as co
+    from oracle import hybrid_oracle as ho
+    import easyhybrid_jl_amd as eh
+    n = (nsteps + 1) * B
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    theta0 = np.asarray(model.initialparameters(161803), np.float32)
+    f, y = {"ta": cols["ta"][:n]}, {"reco": cols["reco"][:n]}
+    th_ref, _ = co.train_steps(spec, theta0, X[:, :nsteps * B], {"ta": f["ta"][:nsteps * B]}, {"reco": y["reco"][:nsteps * B]}, B, nsteps, nthreads=16)
+    l_ref, _, _ = co.loss_and_grad(spec, th_ref, X[:, nsteps * B:n], {"ta": f["ta"][nsteps * B:]}, {"reco": y["reco"][nsteps * B:]}, nthreads=16)
+    eng = eng_factory()
+    try:
+        eng.set_params(theta0)
+        eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
+        for s in range(nsteps):
+            eng.train_step(s * B, B, want_loss=False)
+        th = eng.get_params()
+        l_gpu, _, _ = eng.loss_and_grad(eh.EH_SPLIT_TRAIN, nsteps * B, B)
+    finally:
+        eng.close()
+    return {"steps": nsteps, "final_loss": l_gpu, "oracle_final_loss": l_ref, "rel_diff": abs(l_gpu - l_ref) / abs(l_ref),
+            "theta_max_abs_diff": float(np.max(np.abs(th - th_ref))),
+            "what": f"{nsteps} Adam steps from initialparameters(161803) on batches 0..{nsteps - 1} of the bench's own (un-scaled) dataset, then the "
+                    f"loss of batch {nsteps}: GPU engine (same kernel and mode as the timed run) vs oracle/eh_oracle.c (fp32, checker only)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,10 +163,14 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mech-stage", action="store_true", help="skip the secondary measurement of the stand-alone mechanistic + VJP kernel")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the secondary measurement of the shuffled epoch (eh_train_epoch)")
     ap.add_argument("--no-specialize", action="store_true",
                     help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing in this process has touched a GPU yet (no torch import, no HIP call).
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world == 1 and not args.no_cpu_baseline:
@@ -97,8 +182,6 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     # EH_BENCH_SHARE_GPU=1 (testing only): all ranks on GPU 0 with gloo carrying the collectives -- the only way to walk
@@ -106,6 +189,8 @@ def main():
     share = os.environ.get("EH_BENCH_SHARE_GPU", "0") == "1"
     if share:
         local = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s) (EH_BENCH_SHARE_GPU=1 walks the multi-rank flow on one GPU: testing only)")
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
@@ -123,83 +208,100 @@ def main():
                                     hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
     cols = make_synth_rbq10(NBATCHES * B, seed=42 + rank)           # each rank: its own shard (weak scaling)
     X = np.stack([cols["sw_pot"], cols["dsw_pot"]]).astype(np.float32)
-    eng = model.engine(local)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    t_up = time.perf_counter()
-    eng.set_data(eh.EH_SPLIT_TRAIN, X, [cols["ta"]], [cols["reco"]])
-    eng.synchronize()
-    t_up = time.perf_counter() - t_up      # one-time host -> HBM upload (interleave on the host + PCIe); never part of `value`
-    eng.set_params(model.initialparameters(161803))                 # same seed on every rank: replicas start equal
-    eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
-    if share:
-        eng.set_option("max_blocks", max(1, 128 // world))          # every rank's kernel has to fit on the shared GPU at once
-    force_dp = os.environ.get("EH_FORCE_DP", "0") == "1"          # exercise the data-parallel seam on one GPU
-    if world > 1 or force_dp:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
-        dp = eh.dp.DataParallel(eng, specialize=not args.no_specialize)
-    else:
-        dp = None
-        # one kernel per step: the optimiser update of step s runs in the prologue of step s+1 and the
-        # partial sums are accumulated with float atomics (opt-in mode)
-        eng.set_option("fused_update", int(os.environ.get("EH_FUSED", "1")))
-        if not args.no_specialize:
-            # the "specialize" option: the step kernel is compiled at run time (hiprtc, ~1 s) with this model's descriptor as a
-            # compile-time constant; one forward over one sample builds it here, ahead of the warm-up
-            eng.set_option("specialize", 1)
-            eng.forward(eh.EH_SPLIT_TRAIN, 0, 1, params=False)
-    jit_kernels, jit_log = eng.jit_status()
-    built = "compiled at run time around the model descriptor (hiprtc)" if jit_kernels else "built ahead of time"
+    t_up = [0.0]
 
-    def run(nsteps, base):
-        for s in range(nsteps):
-            first = ((base + s) % NBATCHES) * B
-            if dp is None:
-                eng.train_step(first, B, want_loss=False)
-            else:
-                dp.step(first, B)
+    def new_engine(single):
+        """a fresh engine holding this rank's shard; single: the one-GPU step mode (one kernel per step on the specialised kernel)"""
+        e = model.engine(local)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        t = time.perf_counter()
+        e.set_data(eh.EH_SPLIT_TRAIN, X, [cols["ta"]], [cols["reco"]])
+        e.synchronize()
+        t_up[0] = time.perf_counter() - t   # one-time host -> HBM upload (interleave on the host + PCIe); never part of `value`
+        e.set_params(model.initialparameters(161803))                # same seed on every rank: replicas start equal
+        e.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
+        if share:
+            e.set_option("max_blocks", max(1, 128 // world))          # every rank's kernel has to fit on the shared GPU at once
+        if single:
+            # one kernel per step: the optimiser update of step s runs in the prologue of step s+1 and the
+            # partial sums are accumulated with float atomics (opt-in mode, see DESIGN.md section 3.3)
+            e.set_option("fused_update", int(os.environ.get("EH_FUSED", "1")))
+            if not args.no_specialize:
+                # the "specialize" option: the step kernel is compiled at run time (hiprtc, ~1 s) with this model's descriptor as a
+                # compile-time constant; one forward over one sample builds it here, ahead of the warm-up
+                e.set_option("specialize", 1)
+                e.forward(eh.EH_SPLIT_TRAIN, 0, 1, params=False)
+        return e
 
-    def fence():
-        eng.synchronize()              # also applies the last step's pending update (fused-update mode)
+    def fence(e):
+        e.synchronize()                # also applies the last step's pending update (fused-update mode)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(stepfn, e):
+        for s in range(args.warmup):
+            stepfn((s % NBATCHES) * B)
+        fence(e)
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            stepfn(((args.warmup + s) % NBATCHES) * B)
+        fence(e)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cpu" if share else "cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    force_dp = os.environ.get("EH_FORCE_DP", "0") == "1"          # exercise the data-parallel seam on one GPU
+    n1_ref = None
+    if world > 1:
+        # the N = 1 figure measured in THIS run, for comparison: every rank runs the one-GPU step mode on its own GPU and shard,
+        # same warm-up and step count, no exchange; the slowest rank's time counts (what weak scaling is measured against)
+        e1 = new_engine(True)
+        dt1 = timed(lambda first: e1.train_step(first, B, want_loss=False), e1)
+        e1.close()
+        n1_ref = {"value": B * args.steps / dt1, "unit": "samples/s", "ms_per_step": 1e3 * dt1 / args.steps,
+                  "what": "one-GPU step mode (no exchange), all ranks at once on their own GPUs, max over ranks; same steps / warm-up"}
+    eng = new_engine(world == 1 and not force_dp)
+    if world > 1 or force_dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        dp = eh.dp.DataParallel(eng, specialize=not args.no_specialize)
+        step = lambda first: dp.step(first, B)
+    else:
+        dp = None
+        step = lambda first: eng.train_step(first, B, want_loss=False)
+    jit_kernels, jit_log = eng.jit_status()
+    built = "compiled at run time around the model descriptor (hiprtc)" if jit_kernels else "built ahead of time"
+
     exchange_cal = None
     if dp is not None and dp.p2p:
         # burn-in of the peer-to-peer exchange (a deadline hit on any rank drops every rank back to the RCCL
         # all-reduce), then time both exchanges for a few hundred steps and keep the faster one
-        run(64, 0)
+        for s in range(64):
+            step((s % NBATCHES) * B)
         if dp.check():
             exchange_cal = dp.calibrate(0, B, 300)
-    run(args.warmup, 0)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cpu" if share else "cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(step, eng)
 
-    # live kernel timing: the same K steps again with HIP events bracketing the fused step kernel
+    # live kernel timing: more steps with HIP events bracketing the fused step kernel
     roof = None
     if rank == 0 or dp is not None:
         # one HIP event pair (on the engine's stream) around every burst of BURST consecutive launches: an event
         # between two back-to-back 13 us kernels would add ~2 us to each, a burst measures the steady-state rate.
+        # At least five bursts whatever --steps says, so that the percentiles below are over several samples.
         # Under data parallelism every rank runs the loop (the step kernels of the peer-to-peer mode wait for each
         # other), with the exchange inside the bracket when it is part of the kernel.
         BURST = 50
-        nprof = max(BURST, min(args.steps, 4000) // BURST * BURST)
+        nprof = max(5 * BURST, min(args.steps, 4000) // BURST * BURST)
         eng.profile_enable(BURST)
-        if dp is None:
-            run(nprof, args.warmup + args.steps)
-        elif dp.p2p:
+        if dp is None or dp.p2p:
             for s in range(nprof):
-                dp.step((s % NBATCHES) * B, B)
+                step((s % NBATCHES) * B)
         else:
             for s in range(nprof):                                 # local part only: no collective inside the bracket
                 if dp.fused:
@@ -211,9 +313,8 @@ def main():
         eng.profile_enable(False)
         n *= BURST
         ms_step = float(per_launch.mean()) if per_launch.size else 0.0
-        ms_red = 0.0
         if dp is not None and dp.p2p:
-            fence()
+            fence(eng)
     if rank == 0:
         if n and ms_step > 0:
             tf = FLOP_PER_SAMPLE * B / (ms_step * 1e-3) / 1e12
@@ -226,18 +327,45 @@ def main():
             except Exception:
                 pass
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train+p2p,K1|PS> (fused update, peer-to-peer exchange)" if (dp is not None and dp.p2p) else
+                    "traffic": traffic, "traffic_kind": "static: read from the committed PMC passes, NOT measured in this run (hardware counters need rocprofv3 around the process)" if traffic is not None else None,
+                    "traffic_source": traffic_src, "kernel": "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train+p2p,K1|PS> (fused update, peer-to-peer exchange)" if (dp is not None and dp.p2p) else
                     "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> (fused update)" if (dp is None or dp.fused) else
                     "eh_step_kernel<NBI=1,NBH=1,NL=2,NT=2,NW=8,tanh,train,K1|PS> + eh_reduce_kernel", "kernel_build": built, "kernel_ms": ms_step, "launches_timed": n,
+                    "bursts_timed": int(per_launch.size),
                     "kernel_ms_p10_p50_p90": [float(np.percentile(per_launch, q)) for q in (10, 50, 90)],
                     "timing": f"HIP events on the engine stream around bursts of {BURST} launches" + (" (step kernel + reduce kernel per launch)" if (dp is not None and not dp.fused) else "")
                               + (" (includes the wait for the peer GPUs' sums: the exchange is part of the kernel)" if (dp is not None and dp.p2p) else ""),
                     "algorithmic": {"flop_per_launch": FLOP_PER_SAMPLE * B, "bytes_per_launch": BYTES_PER_SAMPLE * B},
                     "hbm_achieved_GBps": gbs, "hbm_frac": gbs / PEAK_HBM_GBPS}
-    loss = None
-    if dp is None:
-        loss = eng.train_step(0, B, want_loss=True)
-    fence()
+    devices = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "device": local, "name": props.name, "pid": os.getpid()}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+    fence(eng)
+
+    # the path train() really runs: a shuffled epoch gathers 16-byte records through a device-side permutation
+    # (eh_train_epoch, reference src/data/loaders.jl:1-12 + src/training/epoch.jl:13-33); contiguous epoch beside it
+    epoch = None
+    if rank == 0 and world == 1 and dp is None and not args.no_epoch:
+        try:
+            epoch = {}
+            for name, shuffle in (("contiguous", False), ("shuffled", True)):
+                for k in range(2):
+                    eng.train_epoch(B, seed=11 + k, shuffle=shuffle, want_loss=False)
+                eng.synchronize()
+                reps, t0 = 8, time.perf_counter()
+                for k in range(reps):
+                    eng.train_epoch(B, seed=100 + k, shuffle=shuffle, want_loss=False)
+                eng.synchronize()
+                per = (time.perf_counter() - t0) / (reps * NBATCHES)
+                epoch[name] = {"us_per_step": 1e6 * per, "samples_per_s": B / per, "algorithmic_GBps": BYTES_PER_SAMPLE * B / per / 1e9}
+            epoch["shuffled_over_contiguous"] = epoch["shuffled"]["us_per_step"] / epoch["contiguous"]["us_per_step"]
+            epoch["what"] = (f"eh_train_epoch(batchsize={B}) over the {NBATCHES} resident batches, {reps} epochs, host clock around the calls incl. the "
+                             "permutation kernel; shuffled = every step gathers its 16-byte records through the epoch's device-side permutation")
+        except Exception as e:
+            epoch = {"error": repr(e)}
 
     if rank == 0:
         out = {
@@ -247,18 +375,30 @@ def main():
             "config": {"workload": "RbQ10 hybrid, MLP [2,16,16,1] tanh -> rb (sigmoid-scaled), Q10 global, MSE + Adam(0.01), "
                                    f"batch={B} per GPU, fp32 (BASELINE.json configs[1])",
                        "global_batch": world * B, "resident_batches_per_gpu": NBATCHES, "parallelism": f"dp{world}",
+                       "ranks_seen": (dist.get_world_size() if dist.is_initialized() else 1),
+                       "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "launcher": os.environ.get("EH_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else ("none" if world == 1 else "external")),
+                       "rank_devices": devices,
                        "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
-                                             else "one RCCL all-reduce per step"),
+                                             else "one RCCL all-reduce per step" if not share else "one gloo all-reduce per step (EH_BENCH_SHARE_GPU=1: all ranks on one GPU, testing only)"),
                        "gradient_exchange_calibration_us_per_step": exchange_cal, "step_kernel": built,
                        "step_mode": "one kernel per step (fused_update) on the run-time specialised kernel: what train() runs by default "
                                     "(TrainConfig.fused_update = specialize = 'auto')" if dp is None and not args.no_specialize else "see step_kernel / gradient_exchange"},
             "roofline": roof,
         }
-        out["dataset_upload_ms_once"] = 1e3 * t_up
-        if loss is not None:
-            out["final_loss"] = loss
+        if n1_ref is not None:
+            out["n1_reference"] = n1_ref
+            out["weak_scaling_vs_n1_in_this_run"] = out["value"] / (world * n1_ref["value"])
+        out["dataset_upload_ms_once"] = 1e3 * t_up[0]
+        if epoch is not None:
+            out["epoch"] = epoch
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
+            try:
+                out["parity"] = parity_replay(model, lambda: new_engine(dp is None), cols, X, B)
+                out["final_loss"], out["oracle_final_loss"] = out["parity"]["final_loss"], out["parity"]["oracle_final_loss"]
+            except Exception as e:
+                out["parity"] = {"error": repr(e)}
         if world == 1 and dp is None and not args.no_mech_stage:
             # the HBM-bound stage of the path measured as its own kernel (the fused step is compute / latency
             # bound, so the north_star's HBM yardstick applies to the mechanistic + loss + VJP stage alone): eh_mech_loss_vjp on
@@ -270,7 +410,7 @@ def main():
                 out["hbm_stage"] = bm.measure("rbq10", 1024 * B, 50)      # 1 GiB of planes: four times the 256 MB Infinity Cache
             except Exception as e:      # never lose the headline line over the secondary measurement
                 out["hbm_stage"] = {"error": repr(e)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     eng.close()
     if dist.is_initialized():
         dist.destroy_process_group()

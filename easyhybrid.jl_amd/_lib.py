@@ -79,11 +79,13 @@ SIGNATURES = {
     "eh_set_opt_state": (C.c_int32, [_H, _F, _F, C.c_int64, _F]),
     "eh_comm_unique_id": (C.c_int32, [C.c_void_p, C.c_int64]),
     "eh_comm_init": (C.c_int32, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
+    "eh_comm_init_local": (C.c_int32, [C.POINTER(_H), C.c_int32]),
     "eh_comm_destroy": (C.c_int32, [_H]),
     "eh_comm_group_begin": (C.c_int32, []),
     "eh_comm_group_end": (C.c_int32, []),
     "eh_dp_allreduce": (C.c_int32, [_H, C.c_int32, C.c_int32]),
     "eh_dp_train_step": (C.c_int32, [_H, C.c_int64, C.c_int64, _F]),
+    "eh_dp_train_step_group": (C.c_int32, [C.POINTER(_H), C.c_int32, C.POINTER(C.c_int64), C.c_int64, _F]),
     "eh_train_step": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64, _F]),
     "eh_train_epoch": (C.c_int32, [_H, C.c_int64, C.c_uint64, C.c_int32, _F, C.POINTER(C.c_int64)]),
     "eh_eval": (C.c_int32, [_H, C.c_int32, C.c_int64, C.c_int64, C.POINTER(TargetMetrics), _FP, _FP]),

@@ -748,6 +748,7 @@ struct eh_handle_s {
     int slab_rows = 256;
     ncclComm_t comm = nullptr;      // eh_comm_init: the library's own RCCL communicator (data parallelism without a host-side collective library)
     int comm_world = 0, comm_rank = 0;
+    struct EhLocalGroup* lgroup = nullptr;   // eh_comm_init_local: handles of ONE process exchange through peer-mapped device memory, no RCCL
     EhOpt opt{};
     EhSplit split[2];
     float *slab = nullptr, *gradbuf = nullptr, *inv_n = nullptr, *loss_hist = nullptr;
@@ -841,6 +842,35 @@ static bool rccl_bind(std::string* why) {
         std::string why_;                                                                      \
         if (!rccl_bind(&why_)) return fail(h, EH_ERCCL, "RCCL: %s", why_.c_str());             \
     } while (0)
+
+// ---- local communicator: the handles of ONE process (one host thread issuing to several devices / streams, SURVEY section 8(b)
+// threading row) sum their buffers without RCCL.  The buffers are a few KB: every member's stream waits (events) until all
+// members' producers have run, one small kernel per member then reads ALL members' buffers -- directly, over peer-mapped device
+// memory (xGMI) when they live on different GPUs -- and adds them in rank order, so every replica gets bit-identical sums; a
+// second event round keeps a member from overwriting its buffer while a peer still reads it.
+struct EhLocalGroup {
+    int n = 0;
+    eh_handle* m[EH_GSHARDS] = {nullptr};
+    hipEvent_t ready[EH_GSHARDS] = {nullptr}, done[EH_GSHARDS] = {nullptr};
+    float* sum[EH_GSHARDS] = {nullptr};       // per member, on its device: where its kernel leaves the sums before they replace the buffer
+    size_t cap = 0;                           // floats each of them holds
+};
+struct EhLocalPtrs { const float* p[EH_GSHARDS]; };
+__global__ void __launch_bounds__(256) eh_lgroup_sum_kernel(EhLocalPtrs src, int world, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v[EH_GSHARDS];
+#pragma unroll
+    for (int r = 0; r < EH_GSHARDS; ++r) v[r] = r < world ? __builtin_nontemporal_load(src.p[r] + i) : 0.0f;     // all loads in flight together; rank order below
+    float acc = v[0];
+#pragma unroll
+    for (int r = 1; r < EH_GSHARDS; ++r) if (r < world) acc += v[r];
+    out[i] = acc;
+}
+struct EhLocalReq { eh_handle* h; float* buf; size_t n; };
+static thread_local int g_group_depth = 0;                 // eh_comm_group_begin nesting of this host thread
+static thread_local bool g_group_rccl = false;             // ncclGroupStart was issued for the open bracket
+static thread_local std::vector<EhLocalReq> g_group_reqs;  // all-reduces of local-group members, run at eh_comm_group_end
 
 // ---- fused-update mode: apply the pending gradient so theta / m / v / image are current -----------
 static int flush_pending(eh_handle* h) {
@@ -1409,6 +1439,8 @@ int32_t eh_destroy(eh_handle* h) {
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& e : h->jit) { if (e->worker.joinable()) e->worker.join(); eh_jit_release(&e->k); }
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    if (h->lgroup) (void)eh_comm_destroy(h);
+    (void)hipSetDevice(h->device);
     for (int r = 0; r < EH_GSHARDS; ++r)
         if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
@@ -1804,7 +1836,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     const int rows = (int)std::max<long long>(1, std::min<long long>(EH_LFORM_ROWS, (count + 2047) / 2048));
     const int chunk = std::max(16, (int)(((count + rows - 1) / rows + 15) / 16 * 16));
     *rows_out = rows;
-    if (net.T > 1) {
+    if (net.T > 1 && !h->dp_weights) {        // (data-parallel step: eh_dp_grad has just filled inv_n with the weights of the GLOBAL batch)
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
         HIPCHK(h, hipGetLastError());
@@ -2705,18 +2737,94 @@ int32_t eh_comm_init(eh_handle* h, const void* unique_id, int64_t id_bytes, int3
     if (!h || !unique_id) return EH_EINVAL;
     if (id_bytes < (int64_t)sizeof(ncclUniqueId)) return fail(h, EH_EINVAL, "eh_comm_init: id of %lld bytes, need %zu", (long long)id_bytes, sizeof(ncclUniqueId));
     if (world < 1 || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_comm_init: world %d, rank %d", world, rank);
-    if (h->comm) return fail(h, EH_ESTATE, "eh_comm_init: the handle already has a communicator (eh_comm_destroy first)");
+    if (h->comm || h->lgroup) return fail(h, EH_ESTATE, "eh_comm_init: the handle already has a communicator (eh_comm_destroy first)");
     HIPCHK(h, hipSetDevice(h->device));
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     RCCL_BIND(h);
+    if (g_group_depth > 0 && !g_group_rccl) { NCCLCHK(h, g_rccl.GroupStart()); g_group_rccl = true; }      // the bracket was opened before RCCL was in the process
     NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
     h->comm_world = world; h->comm_rank = rank;
     return EH_OK;
 }
 
+// the largest buffer eh_dp_allreduce can be asked for on this handle
+static size_t lgroup_floats(const eh_handle* h) {
+    size_t n = std::max<size_t>((size_t)h->n_acc, 3 * EH_MAX_TARG);
+    if (h->gacc) n = std::max(n, (size_t)EH_GSHARDS * h->n_acc);
+    return std::max<size_t>(n, 68);
+}
+
+int32_t eh_comm_init_local(eh_handle* const* handles, int32_t n) {
+    if (!handles || n < 1 || n > EH_GSHARDS) return fail(nullptr, EH_EINVAL, "eh_comm_init_local: %d handles (1..%d)", n, EH_GSHARDS);
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return fail(nullptr, EH_EINVAL, "eh_comm_init_local: handle %d is NULL", i);
+        for (int j = 0; j < i; ++j) if (handles[j] == handles[i]) return fail(handles[i], EH_EINVAL, "eh_comm_init_local: handle %d is listed twice", i);
+        if (handles[i]->comm || handles[i]->lgroup) return fail(handles[i], EH_ESTATE, "eh_comm_init_local: handle %d already has a communicator (eh_comm_destroy first)", i);
+        if (handles[i]->net.n_theta != handles[0]->net.n_theta || handles[i]->n_acc != handles[0]->n_acc)
+            return fail(handles[i], EH_EINVAL, "eh_comm_init_local: handle %d is a different model (%d parameters, handle 0 has %d)", i, handles[i]->net.n_theta, handles[0]->net.n_theta);
+    }
+    // every member's kernel reads every other member's buffers: peer access between the distinct devices
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int a = handles[i]->device, b = handles[j]->device;
+            if (a == b) continue;
+            int can = 0;
+            HIPCHK(handles[i], hipDeviceCanAccessPeer(&can, a, b));
+            if (!can) return fail(handles[i], EH_EUNSUPPORTED, "eh_comm_init_local: device %d cannot map the memory of device %d (no peer access): use eh_comm_init (RCCL)", a, b);
+            HIPCHK(handles[i], hipSetDevice(a));
+            hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else if (e != hipSuccess) return fail(handles[i], EH_EHIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", a, b, hipGetErrorString(e));
+        }
+    EhLocalGroup* g = new EhLocalGroup();
+    g->n = n;
+    g->cap = lgroup_floats(handles[0]);
+    auto undo = [&](eh_handle* h, hipError_t e, const char* what) {
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(handles[i]->device);
+            if (g->ready[i]) (void)hipEventDestroy(g->ready[i]);
+            if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+            (void)hipFree(g->sum[i]);
+        }
+        delete g;
+        return fail(h, e == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "eh_comm_init_local: %s: %s", what, hipGetErrorString(e));
+    };
+    for (int i = 0; i < n; ++i) {
+        hipError_t e;
+        if ((e = hipSetDevice(handles[i]->device)) != hipSuccess) return undo(handles[i], e, "hipSetDevice");
+        if ((e = hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming)) != hipSuccess) return undo(handles[i], e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming)) != hipSuccess) return undo(handles[i], e, "hipEventCreate");
+        if ((e = hipMalloc(&g->sum[i], g->cap * sizeof(float))) != hipSuccess) return undo(handles[i], e, "hipMalloc");
+    }
+    for (int i = 0; i < n; ++i) {
+        g->m[i] = handles[i];
+        handles[i]->lgroup = g; handles[i]->comm_world = n; handles[i]->comm_rank = i;
+    }
+    return EH_OK;
+}
+
 int32_t eh_comm_destroy(eh_handle* h) {
     if (!h) return EH_EINVAL;
+    if (h->lgroup) {                            // a local group lives and dies as a whole: every member leaves it
+        EhLocalGroup* g = h->lgroup;
+        for (int i = 0; i < g->n; ++i) {
+            eh_handle* m = g->m[i];
+            (void)hipSetDevice(m->device);
+            (void)hipStreamSynchronize(m->stream);
+        }
+        for (int i = 0; i < g->n; ++i) {
+            eh_handle* m = g->m[i];
+            (void)hipSetDevice(m->device);
+            (void)hipEventDestroy(g->ready[i]); (void)hipEventDestroy(g->done[i]); (void)hipFree(g->sum[i]);
+            m->lgroup = nullptr; m->comm_world = 0; m->comm_rank = 0;
+        }
+        for (size_t k = 0; k < g_group_reqs.size();)
+            if (g_group_reqs[k].h->lgroup == nullptr) g_group_reqs.erase(g_group_reqs.begin() + k); else ++k;
+        delete g;
+        (void)hipSetDevice(h->device);
+        return EH_OK;
+    }
     if (!h->comm) return EH_OK;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2725,12 +2833,76 @@ int32_t eh_comm_destroy(eh_handle* h) {
     return EH_OK;
 }
 
-int32_t eh_comm_group_begin(void) { RCCL_BIND(nullptr); NCCLCHK(nullptr, g_rccl.GroupStart()); return EH_OK; }
-int32_t eh_comm_group_end(void) { RCCL_BIND(nullptr); NCCLCHK(nullptr, g_rccl.GroupEnd()); return EH_OK; }
+// the queued all-reduces of one local group, all members present: two event rounds and one small kernel per member
+static int lgroup_run(EhLocalGroup* g, const std::vector<EhLocalReq>& reqs) {
+    eh_handle* h0 = reqs[0].h;
+    const size_t n = reqs[0].n;
+    const EhLocalReq* by_rank[EH_GSHARDS] = {nullptr};
+    for (const EhLocalReq& r : reqs) {
+        if (by_rank[r.h->comm_rank]) return fail(r.h, EH_ESTATE, "eh_comm_group_end: rank %d of the local group asked for two all-reduces in one bracket", r.h->comm_rank);
+        if (r.n != n) return fail(r.h, EH_ESTATE, "eh_comm_group_end: the members of the local group ask for different buffers (%zu vs %zu floats)", r.n, n);
+        by_rank[r.h->comm_rank] = &r;
+    }
+    for (int i = 0; i < g->n; ++i)
+        if (!by_rank[i]) return fail(h0, EH_ESTATE, "eh_comm_group_end: rank %d of the local group did not call eh_dp_allreduce inside the bracket (every member must)", i);
+    if (n > g->cap) return fail(h0, EH_EINVAL, "eh_comm_group_end: %zu floats, the group's scratch holds %zu", n, g->cap);
+    EhLocalPtrs src;
+    for (int i = 0; i < EH_GSHARDS; ++i) src.p[i] = by_rank[i < g->n ? i : 0]->buf;
+    for (int i = 0; i < g->n; ++i) {           // round 1: every member's buffer is complete
+        eh_handle* m = g->m[i];
+        HIPCHK(m, hipSetDevice(m->device));
+        HIPCHK(m, hipEventRecord(g->ready[i], m->stream));
+    }
+    for (int i = 0; i < g->n; ++i) {
+        eh_handle* m = g->m[i];
+        HIPCHK(m, hipSetDevice(m->device));
+        for (int p = 0; p < g->n; ++p) if (p != i) HIPCHK(m, hipStreamWaitEvent(m->stream, g->ready[p], 0));
+        hipLaunchKernelGGL(eh_lgroup_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, src, g->n, (long long)n, g->sum[i]);
+        HIPCHK(m, hipGetLastError());
+        HIPCHK(m, hipEventRecord(g->done[i], m->stream));
+    }
+    for (int i = 0; i < g->n; ++i) {           // round 2: nobody reads a buffer any more; the sums replace it
+        eh_handle* m = g->m[i];
+        HIPCHK(m, hipSetDevice(m->device));
+        for (int p = 0; p < g->n; ++p) if (p != i) HIPCHK(m, hipStreamWaitEvent(m->stream, g->done[p], 0));
+        HIPCHK(m, hipMemcpyAsync(by_rank[i]->buf, g->sum[i], n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    }
+    return EH_OK;
+}
+
+int32_t eh_comm_group_begin(void) {
+    if (g_group_depth++ == 0) {
+        g_group_rccl = false;
+        g_group_reqs.clear();
+        if (g_rccl.so) { NCCLCHK(nullptr, g_rccl.GroupStart()); g_group_rccl = true; }      // (no RCCL in the process yet: eh_comm_init opens the RCCL bracket itself)
+    }
+    return EH_OK;
+}
+int32_t eh_comm_group_end(void) {
+    if (g_group_depth <= 0) return fail(nullptr, EH_ESTATE, "eh_comm_group_end without eh_comm_group_begin");
+    if (--g_group_depth > 0) return EH_OK;
+    int rc = EH_OK;
+    if (g_group_rccl) {
+        g_group_rccl = false;
+        ncclResult_t r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) rc = fail(nullptr, EH_ERCCL, "ncclGroupEnd: %s", g_rccl.GetErrorString(r));
+    }
+    std::vector<EhLocalReq> reqs;
+    reqs.swap(g_group_reqs);
+    while (!reqs.empty() && rc == EH_OK) {
+        EhLocalGroup* g = reqs[0].h->lgroup;
+        std::vector<EhLocalReq> mine, rest;
+        for (const EhLocalReq& r : reqs) (r.h->lgroup == g ? mine : rest).push_back(r);
+        rc = lgroup_run(g, mine);
+        if (rc != EH_OK) g_create_err = mine[0].h->err.empty() ? g_create_err : mine[0].h->err;
+        reqs.swap(rest);
+    }
+    return rc;
+}
 
 int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
     if (!h) return EH_EINVAL;
-    if (!h->comm) return fail(h, EH_ESTATE, "eh_dp_allreduce: call eh_comm_init first");
+    if (!h->comm && !h->lgroup) return fail(h, EH_ESTATE, "eh_dp_allreduce: call eh_comm_init (or eh_comm_init_local) first");
     float* buf = nullptr;
     size_t n = 0;
     switch (which) {
@@ -2738,12 +2910,19 @@ int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
         case EH_BUF_GACC:
             if (index < 0 || index > 2) return fail(h, EH_EINVAL, "eh_dp_allreduce: accumulator %d (0..2)", index);
             if (h->p2p_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the step kernels exchange their sums themselves (eh_p2p_attach); nothing to reduce");
+            if (!h->gacc) return fail(h, EH_ESTATE, "eh_dp_allreduce: this model has no fused_update accumulators");
             n = (size_t)EH_GSHARDS * h->n_acc; buf = h->gacc + (size_t)index * n; break;
         case EH_BUF_BNSTAT:
             if (!h->bn_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the model has no input BatchNorm");
             buf = h->bn_stat; n = 65; break;
         case EH_BUF_TCOUNT: buf = h->tcount; n = 3 * EH_MAX_TARG; break;
         default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT or EH_BUF_TCOUNT)", which);
+    }
+    if (h->lgroup) {
+        if (h->lgroup->n == 1) return EH_OK;               // a world of one: the sum is the buffer
+        if (g_group_depth <= 0) return fail(h, EH_ESTATE, "eh_dp_allreduce: a local group's members meet at eh_comm_group_end: bracket the calls of all members with eh_comm_group_begin / eh_comm_group_end");
+        g_group_reqs.push_back({h, buf, n});
+        return EH_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));
     NCCLCHK(h, g_rccl.AllReduce(buf, buf, n, ncclFloat, ncclSum, h->comm, h->stream));
@@ -2752,7 +2931,8 @@ int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
 
 int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out) {
     if (!h) return EH_EINVAL;
-    if (!h->comm) return fail(h, EH_ESTATE, "eh_dp_train_step: call eh_comm_init first");
+    if (!h->comm && !h->lgroup) return fail(h, EH_ESTATE, "eh_dp_train_step: call eh_comm_init first");
+    if (h->lgroup && h->lgroup->n > 1) return fail(h, EH_ESTATE, "eh_dp_train_step: the members of a local group step together: eh_dp_train_step_group");
     int rc;
     if (h->bn_on) {
         if ((rc = eh_dp_bn_stats(h, first, count))) return rc;
@@ -2771,6 +2951,46 @@ int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss
     if ((rc = eh_dp_grad(h, first, count))) return rc;
     if ((rc = eh_dp_allreduce(h, EH_BUF_GRAD, 0))) return rc;
     return eh_dp_apply(h, loss_out);
+}
+
+// One host thread, several handles (one per device): a whole data-parallel step of all of them.  Every phase is issued to all
+// members before the exchange that follows it, and every exchange sits in one eh_comm_group_begin / eh_comm_group_end bracket
+// (RCCL communicators: ncclGroupStart / End as RCCL requires of a single thread; local groups: the members meet at the end).
+int32_t eh_dp_train_step_group(eh_handle* const* hs, int32_t n, const int64_t* first, int64_t count, float* loss_out) {
+    if (!hs || !first || n < 1 || n > EH_GSHARDS) return fail(nullptr, EH_EINVAL, "eh_dp_train_step_group: %d handles (1..%d)", n, EH_GSHARDS);
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return fail(nullptr, EH_EINVAL, "eh_dp_train_step_group: handle %d is NULL", i);
+        if (!hs[i]->comm && !hs[i]->lgroup) return fail(hs[i], EH_ESTATE, "eh_dp_train_step_group: handle %d has no communicator (eh_comm_init / eh_comm_init_local)", i);
+        if (hs[i]->fused != hs[0]->fused || hs[i]->net.T != hs[0]->net.T || hs[i]->bn_on != hs[0]->bn_on || hs[i]->p2p_on != hs[0]->p2p_on)
+            return fail(hs[i], EH_EINVAL, "eh_dp_train_step_group: handle %d runs a different step mode than handle 0", i);
+    }
+    int32_t k[EH_GSHARDS] = {0};
+    auto exchange = [&](int which, bool per_handle_index) -> int {
+        int rc = eh_comm_group_begin();
+        if (rc) return rc;
+        for (int i = 0; i < n && !rc; ++i) rc = eh_dp_allreduce(hs[i], which, per_handle_index ? k[i] : 0);
+        const int rc2 = eh_comm_group_end();                // (always closes the bracket)
+        return rc ? rc : rc2;
+    };
+    int rc;
+    eh_handle* h0 = hs[0];
+    if (h0->bn_on) {
+        for (int i = 0; i < n; ++i) if ((rc = eh_dp_bn_stats(hs[i], first[i], count))) return rc;
+        if ((rc = exchange(EH_BUF_BNSTAT, false))) return rc;
+    }
+    if (h0->fused && h0->net.T == 1) {
+        if (loss_out) return fail(h0, EH_EINVAL, "eh_dp_train_step_group: fused_update mode reports no per-step loss (pass NULL)");
+        for (int i = 0; i < n; ++i) if ((rc = eh_dp_fused_step(hs[i], first[i], count, &k[i]))) return rc;
+        return k[0] >= 0 ? exchange(EH_BUF_GACC, true) : EH_OK;
+    }
+    if (h0->net.T != 1) {
+        for (int i = 0; i < n; ++i) if ((rc = eh_dp_counts(hs[i], first[i], count))) return rc;
+        if ((rc = exchange(EH_BUF_TCOUNT, false))) return rc;
+    }
+    for (int i = 0; i < n; ++i) if ((rc = eh_dp_grad(hs[i], first[i], count))) return rc;
+    if ((rc = exchange(EH_BUF_GRAD, false))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = eh_dp_apply(hs[i], i == 0 ? loss_out : nullptr))) return rc;
+    return EH_OK;
 }
 
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {

@@ -355,6 +355,50 @@ class HybridEngine:
     def comm_destroy(self):
         self._chk(self._lib.eh_comm_destroy(self._h))
 
+    @staticmethod
+    def comm_init_local(engines: Sequence["HybridEngine"]):
+        """ONE process driving several engines (one per device): they become a local group whose all-reduces run inside the
+        library without RCCL (include/easyhybrid_hip.h: eh_comm_init_local); rank = position in `engines`."""
+        lib = L.lib()
+        hs = (C.c_void_p * len(engines))(*[e._h.value for e in engines])
+        st = lib.eh_comm_init_local(hs, len(engines))
+        if st != L.EH_OK:
+            msg = lib.eh_last_error(None).decode()
+            for e in engines:
+                m = lib.eh_last_error(e._h).decode()
+                if m:
+                    msg = m
+            _raise(st, msg)
+
+    @staticmethod
+    def comm_group_begin():
+        st = L.lib().eh_comm_group_begin()
+        if st != L.EH_OK:
+            _raise(st, L.lib().eh_last_error(None).decode())
+
+    @staticmethod
+    def comm_group_end():
+        st = L.lib().eh_comm_group_end()
+        if st != L.EH_OK:
+            _raise(st, L.lib().eh_last_error(None).decode())
+
+    @staticmethod
+    def dp_train_step_group(engines: Sequence["HybridEngine"], firsts, count: int, want_loss: bool = False):
+        """a whole data-parallel step of `engines` from this one thread (eh_dp_train_step_group); firsts[i]: engine i's window"""
+        lib = L.lib()
+        hs = (C.c_void_p * len(engines))(*[e._h.value for e in engines])
+        fs = (C.c_int64 * len(engines))(*[int(f) for f in firsts])
+        loss = C.c_float()
+        st = lib.eh_dp_train_step_group(hs, len(engines), fs, count, C.byref(loss) if want_loss else None)
+        if st != L.EH_OK:
+            msg = lib.eh_last_error(None).decode()
+            for e in engines:
+                m = lib.eh_last_error(e._h).decode()
+                if m:
+                    msg = m
+            _raise(st, msg)
+        return float(loss.value) if want_loss else None
+
     def dp_allreduce(self, which: int, index: int = 0):
         self._chk(self._lib.eh_dp_allreduce(self._h, which, index))
 

@@ -472,6 +472,31 @@ dp_allreduce!(e::HybridEngine, which::Integer, index::Integer = 0) = check(e, @c
 dp_train_step!(e::HybridEngine, first::Integer, count::Integer) =
     check(e, @ccall LIB[].eh_dp_train_step(e.h::Ptr{Cvoid}, first::Int64, count::Int64, C_NULL::Ptr{Float32})::Int32)
 
+"""
+ONE Julia process driving several engines (one per device): `comm_init_local!(engines)` makes them a local group whose
+all-reduces run inside the library without RCCL (events + one small kernel per member over peer-mapped memory; rank = position),
+`dp_train_step_group!(engines, firsts, count)` is a whole data-parallel step of all of them from this one task.
+"""
+function comm_init_local!(es::Vector{HybridEngine})
+    hs = Ptr{Cvoid}[e.h for e in es]
+    GC.@preserve hs check(es[1], @ccall LIB[].eh_comm_init_local(hs::Ptr{Ptr{Cvoid}}, length(hs)::Int32)::Int32)
+end
+comm_group_begin() = (st = @ccall LIB[].eh_comm_group_begin()::Int32; st == 0 || error("eh_comm_group_begin: status $st"); nothing)
+comm_group_end() = (st = @ccall LIB[].eh_comm_group_end()::Int32; st == 0 || error("eh_comm_group_end: status $st"); nothing)
+function dp_train_step_group!(es::Vector{HybridEngine}, firsts::Vector{<:Integer}, count::Integer)
+    hs = Ptr{Cvoid}[e.h for e in es]; fs = Int64.(firsts)
+    GC.@preserve hs fs check(es[1], @ccall LIB[].eh_dp_train_step_group(hs::Ptr{Ptr{Cvoid}}, length(hs)::Int32, fs::Ptr{Int64}, count::Int64, C_NULL::Ptr{Float32})::Int32)
+end
+
+"running (mean, var) of the input BatchNorm layer -- the `st.st_nn` part of the model state (`src/models/NNModels.jl:89-105`)"
+function get_bn_state(e::HybridEngine, P::Integer)
+    m = zeros(Float32, P); v = zeros(Float32, P)
+    check(e, @ccall LIB[].eh_get_bn_state(e.h::Ptr{Cvoid}, m::Ptr{Float32}, v::Ptr{Float32}, P::Int64)::Int32)
+    return m, v
+end
+set_bn_state!(e::HybridEngine, m::Vector{Float32}, v::Vector{Float32}) =
+    check(e, @ccall LIB[].eh_set_bn_state(e.h::Ptr{Cvoid}, m::Ptr{Float32}, v::Ptr{Float32}, length(m)::Int64)::Int32)
+
 "input BatchNorm under DP: shard sums into EH_BUF_BNSTAT (all-reduce it before dp_grad! / dp_fused_step!)"
 set_bn_shift!(e::HybridEngine, c::Vector{Float32}) = check(e, @ccall LIB[].eh_set_bn_shift(e.h::Ptr{Cvoid}, c::Ptr{Float32}, length(c)::Int64)::Int32)
 dp_bn_stats!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_bn_stats(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)
@@ -556,6 +581,8 @@ function train!(e::HybridEngine, train_data, val_data; nepochs = 200, batchsize 
     nt, nv = size(xt, 2), size(xv, 2)
     hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types)]
     best_loss = hist_v[1][1].sum; best_ps = get_params(e); best_epoch = 0; counter = 0
+    has_bn = get(e.model.config, :input_batchnorm, false) === true
+    best_bn = has_bn ? get_bn_state(e, length(e.model.predictors)) : nothing                         # the running statistics belong to the epoch's model state
     better = first(loss_types) in (:pearson, :r2, :nse, :kge) ? (>) : (<)        # loss_fn.jl:181-194
     for epoch in 1:nepochs
         train_epoch!(e, batchsize; seed = random_seed + epoch, shuffle = true)   # run_epoch!
@@ -563,12 +590,16 @@ function train!(e::HybridEngine, train_data, val_data; nepochs = 200, batchsize 
         cur = hist_v[end][1].sum
         if better(cur, best_loss)
             best_loss, best_ps, best_epoch, counter = cur, get_params(e), epoch, 0
+            has_bn && (best_bn = get_bn_state(e, length(e.model.predictors)))
         else
             counter += 1
         end
         counter >= patience && break
     end
-    return_model == :best && set_params!(e, best_ps)
+    if return_model == :best
+        set_params!(e, best_ps)
+        has_bn && set_bn_state!(e, best_bn...)
+    end
     return (; ps = get_params(e), train_history = hist_t, val_history = hist_v, best_epoch, best_loss)
 end
 
@@ -605,14 +636,15 @@ _col(data, n::Symbol) = Float32.(collect(data isa AbstractDict ? data[n] : getpr
     prepare_data(model, data) -> ((X, forcings), targets)
 
 `src/data/prepare_data.jl:6-60`: the columns the model names, as Float32 -- predictors as a (P x N) matrix, forcings and targets
-as NamedTuples of vectors; rows with a missing (NaN) predictor or forcing are dropped, missing targets stay NaN (they become the
-mask, `src/training/train.jl:221-232`).
+as NamedTuples of vectors; a row is kept only if its predictors and forcings are complete AND at least one target is present
+(`src/data/prepare_data.jl:44-52`); the remaining missing targets stay NaN (they become the mask, `src/training/train.jl:221-232`).
 """
 function prepare_data(m::SingleNNHybridModel, data)
     X = permutedims(reduce(hcat, [_col(data, p) for p in m.predictors]))
     F = [_col(data, f) for f in m.forcing]; Y = [_col(data, t) for t in m.targets]
     keep = vec(.!any(isnan, X; dims = 1))
     for f in F; keep .&= .!isnan.(f); end
+    isempty(Y) || (keep .&= reduce((a, b) -> a .| b, [.!isnan.(y) for y in Y]))                  # prepare_data.jl:44-52: at least one target present
     return (Matrix{Float32}(X[:, keep]), NamedTuple{Tuple(m.forcing)}(Tuple(f[keep] for f in F))), NamedTuple{Tuple(m.targets)}(Tuple(y[keep] for y in Y))
 end
 
@@ -679,6 +711,8 @@ function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt 
     nt, nv = size(xt, 2), size(xv, 2)
     hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types)]
     best_loss = hist_v[1][1].sum; best_ps = get_params(e); best_epoch = 0; counter = 0
+    has_bn = get(m.config, :input_batchnorm, false) === true
+    best_bn = has_bn ? get_bn_state(e, length(m.predictors)) : nothing                         # the running statistics belong to the epoch's model state
     better = first(loss_types) in (:pearson, :r2, :nse, :kge) ? (>) : (<)                       # loss_fn.jl:181-194
     seed0 = random_seed === nothing ? rand(rng, UInt32) : random_seed
     for epoch in 1:nepochs
@@ -687,12 +721,16 @@ function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt 
         cur = hist_v[end][1].sum
         if better(cur, best_loss)
             best_loss, best_ps, best_epoch, counter = cur, get_params(e), epoch, 0              # early_stopping.jl:16-42
+            has_bn && (best_bn = get_bn_state(e, length(m.predictors)))
         else
             counter += 1
         end
         counter >= patience && break
     end
-    return_model == :best && set_params!(e, best_ps)                                            # best_or_final
+    if return_model == :best                                                                    # best_or_final: parameters AND state of that epoch
+        set_params!(e, best_ps)
+        has_bn && set_bn_state!(e, best_bn...)
+    end
     obs_pred(split, y, n) = n == 0 ? (;) : merge(y, NamedTuple{Tuple(Symbol(t, :_pred) for t in m.targets)}(Tuple(values(forward(e, split, n)))))
     st = (; fixed = NamedTuple{Tuple(m.fixed_param_names)}(Tuple(Float32(m.parameters[f][1]) for f in m.fixed_param_names)))
     return (; train_history = hist_t, val_history = hist_v, train_obs_pred = obs_pred(EH_SPLIT_TRAIN, yt, nt),

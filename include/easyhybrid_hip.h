@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 2      /* 2: eh_train_step takes the minibatch indices; eh_comm_* */
+#define EH_ABI_VERSION 3      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group */
 #define EH_MAX_HIDDEN 8       /* hidden layers: up to 3 run as ONE fused kernel per step, more (or widths above 128) layer by layer (csrc/eh_lform.hpp) */
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
@@ -322,15 +322,30 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
  *   eh_dp_train_step  : the whole data-parallel step of one rank: [eh_dp_bn_stats + all-reduce] + eh_dp_grad + all-reduce +
  *                       eh_dp_apply, or eh_dp_fused_step + all-reduce in fused_update mode (loss_out then must be NULL)
  * A single thread that drives several handles must bracket the calls of one step over all its handles with
- * eh_comm_group_begin / eh_comm_group_end (ncclGroupStart / ncclGroupEnd), as RCCL requires; eh_comm_init likewise. */
+ * eh_comm_group_begin / eh_comm_group_end (ncclGroupStart / ncclGroupEnd), as RCCL requires; eh_comm_init likewise.
+ *
+ * ONE process, one host thread, one handle per device (threading row) needs no RCCL at all:
+ *   eh_comm_init_local     : the n handles (all of this process; rank = position in the list) become a LOCAL group.  Their
+ *                            eh_dp_allreduce calls -- every member's, inside one eh_comm_group_begin / _end bracket -- meet at
+ *                            eh_comm_group_end: each member's stream waits (events) for all members' producers, one small kernel
+ *                            per member reads ALL members' buffers (peer-mapped device memory over xGMI when they sit on
+ *                            different GPUs; EH_EUNSUPPORTED if a pair of devices has no peer access) and adds them in rank
+ *                            order -- bit-identical sums on every replica -- and a second event round guards the write-back.
+ *                            Nothing blocks the host.  eh_comm_destroy on any member dissolves the group.
+ *   eh_dp_train_step_group : a whole data-parallel step of n handles driven by one thread (local group or RCCL communicators):
+ *                            every phase (BatchNorm sums, per-target counts, gradient pass, update) is issued to all handles
+ *                            before the exchange that follows it; first[i] = handle i's window start in its own shard.
+ *                            loss_out (two-kernel mode only) receives the global batch loss. */
 #define EH_COMM_ID_BYTES 128
 int32_t eh_comm_unique_id(void* id_out, int64_t id_bytes);
 int32_t eh_comm_init(eh_handle* h, const void* unique_id, int64_t id_bytes, int32_t world, int32_t rank);
+int32_t eh_comm_init_local(eh_handle* const* handles, int32_t n);
 int32_t eh_comm_destroy(eh_handle* h);
 int32_t eh_comm_group_begin(void);
 int32_t eh_comm_group_end(void);
 int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index);
 int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out);
+int32_t eh_dp_train_step_group(eh_handle* const* handles, int32_t n, const int64_t* first, int64_t count, float* loss_out);
 
 /* One-kernel-per-step variant of the data-parallel seam (needs eh_set_option("fused_update", 1)):
  * eh_dp_fused_step launches the fused step kernel, whose prologue applies the (already all-reduced)

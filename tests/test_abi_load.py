@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(L.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert lib.eh_version() == 2
+    assert lib.eh_version() == 3
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -130,3 +130,91 @@ def test_descriptor_from_model():
     assert (d.param_default[0], d.param_lower[0], d.param_upper[0]) == (3.0, 0.0, 13.0)
     assert (d.n_forcings, d.forcing_index[0], d.n_targets, d.target_output[0]) == (1, 0, 1, 0)
     assert m.n_theta == (2 * 32 + 32) + (32 * 24 + 24) + (24 * 8 + 8) + (8 * 1 + 1) + 1
+
+
+# ---- every @ccall site of the Julia shim against the ctypes signatures (which the tests above pin to the header) -----------------
+def _julia_ccalls():
+    """[(symbol, [argument type strings], return type, line)] of every `@ccall LIB[].eh_*(...)::T` in EasyHybridHIP.jl"""
+    jl = open(os.path.join(ROOT, "easyhybrid.jl_amd", "julia", "EasyHybridHIP", "src", "EasyHybridHIP.jl")).read()
+    out = []
+    for m in re.finditer(r"@ccall LIB\[\]\.(eh_[a-z0-9_]+)\(", jl):
+        i, depth, args, cur = m.end(), 1, [], ""
+        while depth:
+            c = jl[i]
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if c == "," and depth == 1:
+                args.append(cur); cur = ""
+            else:
+                cur += c
+            i += 1
+        if cur.strip():
+            args.append(cur)
+        ret = re.match(r"::([A-Za-z0-9_{}]+)", jl[i + 1:]).group(1)
+        types = []
+        for a in args:
+            d, cut = 0, None
+            for k, c in enumerate(a):                      # the annotation after the last top-level `::`
+                if c in "([{":
+                    d += 1
+                elif c in ")]}":
+                    d -= 1
+                elif d == 0 and a[k:k + 2] == "::":
+                    cut = k
+            assert cut is not None, (m.group(1), a)
+            types.append(a[cut + 2:].strip())
+        out.append((m.group(1), types, ret, jl.count("\n", 0, m.start()) + 1))
+    return out
+
+
+_JL_SCALAR = {"Int32": C.c_int32, "Int64": C.c_int64, "UInt64": C.c_uint64, "Float32": C.c_float, "Float64": C.c_double, "UInt32": C.c_uint32}
+_JL_STRUCT = {"EhModelDesc": L.ModelDesc, "EhTargetMetrics": L.TargetMetrics}
+
+
+def _jl_matches(jt, ct):
+    """does the Julia ccall annotation `jt` describe the C type ctypes calls `ct`?"""
+    if jt in _JL_SCALAR:
+        return ct is _JL_SCALAR[jt]
+    if jt == "Cstring":
+        return ct is C.c_char_p
+    m = re.fullmatch(r"(?:Ptr|Ref)\{(.+)\}", jt)
+    if not m:
+        return False
+    inner = m.group(1)
+    if ct is C.c_void_p:                                   # void*: any pointer
+        return True
+    if ct is C.c_char_p:
+        return inner in ("UInt8", "Cchar")
+    if not hasattr(ct, "_type_") or isinstance(ct._type_, str):
+        return False
+    pointee = ct._type_                                    # POINTER(pointee)
+    if inner in _JL_SCALAR:
+        return pointee is _JL_SCALAR[inner]
+    if inner in _JL_STRUCT:
+        return pointee is _JL_STRUCT[inner]
+    if re.fullmatch(r"Ptr\{.+\}", inner) or inner == "Ptr{Cvoid}":      # array of pointers
+        return pointee is C.c_void_p or (hasattr(pointee, "_type_") and not isinstance(pointee._type_, str) and _jl_matches(inner, pointee))
+    return False
+
+
+def test_every_julia_ccall_matches_the_c_signature():
+    calls = _julia_ccalls()
+    assert len(calls) >= 40, len(calls)
+    seen = set()
+    for name, types, ret, line in calls:
+        assert name in L.SIGNATURES, f"EasyHybridHIP.jl:{line}: @ccall of {name}, which include/easyhybrid_hip.h does not declare"
+        res, argtypes = L.SIGNATURES[name]
+        assert len(types) == len(argtypes), f"EasyHybridHIP.jl:{line}: {name} takes {len(argtypes)} arguments, the @ccall passes {len(types)}"
+        for k, (jt, ct) in enumerate(zip(types, argtypes)):
+            assert _jl_matches(jt, ct), f"EasyHybridHIP.jl:{line}: {name} argument {k}: `{jt}` against {ct}"
+        assert (ret == "Cstring" and res is C.c_char_p) or (ret in _JL_SCALAR and _JL_SCALAR[ret] is res), f"EasyHybridHIP.jl:{line}: {name} returns {res}, @ccall says {ret}"
+        seen.add(name)
+    # the entry points a training run of the shim goes through are all bound
+    for must in ("eh_create", "eh_destroy", "eh_set_data", "eh_set_params", "eh_get_params", "eh_opt_init", "eh_train_step", "eh_train_epoch",
+                 "eh_eval", "eh_forward", "eh_loss_and_grad", "eh_mech_loss_vjp", "eh_comm_init", "eh_comm_init_local", "eh_dp_train_step",
+                 "eh_dp_train_step_group", "eh_get_bn_state", "eh_set_bn_state"):
+        assert must in seen, must

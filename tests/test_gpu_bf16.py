@@ -148,3 +148,89 @@ def test_refusals():
     with pytest.raises(NotImplementedError):
         narrow.set_option("precision", 1)                   # no row-split kernel for 16-wide nets
     narrow.close()
+
+
+# ---- config 5 with its 1e7 samples resident (BASELINE configs[4]: N = 1e7, 32 covariates, 3 forcings) ------------------------------
+N_C5 = 10_000_000
+
+
+def _big_c5(n, seed=5):
+    """make_synth_c5's distributions drawn in float32 directly (3.6e8 values: the float64 detour of the small-case generator
+    would take half a minute and 4 GB); 3 % of the targets missing"""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((32, n), dtype=np.float32)
+    X *= np.float32(0.5)
+    ta = rng.standard_normal(n, dtype=np.float32) * np.float32(10) + np.float32(10)
+    sw = rng.random(n, dtype=np.float32) + np.float32(0.2)
+    vpd = rng.random(n, dtype=np.float32) + np.float32(0.2)
+    e = np.float32(0.1) * (ta - np.float32(15))
+    w = [np.float32(1), sw, vpd]
+    y = np.zeros(n, np.float32)
+    for c in range(3):
+        y += w[c] * (np.float32(1) + np.float32(0.8) * np.tanh(X[3 * c] + np.float32(0.5) * X[3 * c + 1])) * np.power(np.float32(1.6 + 0.4 * c), e)
+    y *= np.float32(1) + np.float32(0.05) * rng.standard_normal(n, dtype=np.float32)
+    y[rng.random(n, dtype=np.float32) < 0.03] = np.nan
+    return X, {"ta": ta, "sw_in": sw, "vpd": vpd}, {"R_soil": y}
+
+
+@pytest.fixture(scope="module")
+def c5_resident():
+    spec = ho.c5_spec()
+    theta = ho.init_theta(spec, 3, np.float32)
+    X, f, y = _big_c5(N_C5)
+    eng = util.load_engine(spec, theta, X, f, y)               # 1.44 GB of 36-float records in HBM
+    yield spec, theta, X, f, y, eng
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16_fwd", "f32"])
+def test_windows_and_gathered_minibatches_at_the_end_of_1e7_resident_samples(c5_resident, precision):
+    """record offsets near the end of a 1.44 GB array (360 M floats: 32-bit element offsets would still hold, 32-bit BYTE offsets
+    would not): the last window, a window straddling nothing but the last records, and minibatches gathered from the last 1 %"""
+    spec, theta, X, f, y, eng = c5_resident
+    eng.set_option("precision", 1 if precision == "bf16_fwd" else 0)
+    sp = ho.c5_spec(precision=precision)
+    ltol, gtol = (2e-5, 5e-5) if precision == "bf16_fwd" else (1e-5, 1e-5)
+    N = N_C5
+
+    def oracle(ix):
+        return ho.loss_and_grad(sp, theta.astype(np.float64), X[:, ix], {k: v[ix] for k, v in f.items()}, {k: v[ix] for k, v in y.items()})
+    for first, count in ((N - 4096, 4096), (N - 1001, 1001), (N // 2 + 3, 2000)):
+        loss, grad, nv = eng.loss_and_grad(eh.EH_SPLIT_TRAIN, first, count)
+        l0, g0, nv0 = oracle(np.arange(first, first + count))
+        assert nv == sum(nv0) and abs(loss - l0) <= ltol * abs(l0) and util.relerr(grad, g0) <= gtol, (first, loss, l0, util.relerr(grad, g0))
+    rng = np.random.default_rng(17)
+    idx = rng.choice(np.arange(N - N // 100, N), 3000, replace=False).astype(np.int32)
+    idx[:3] = (N - 1, N - N // 100, N - 2)                      # the very last record is in
+    loss, grad, nv = eng.loss_and_grad(idx=idx)
+    l0, g0, nv0 = oracle(idx)
+    assert nv == sum(nv0) and abs(loss - l0) <= ltol * abs(l0) and util.relerr(grad, g0) <= gtol
+    with pytest.raises(ValueError):
+        eng.loss_and_grad(eh.EH_SPLIT_TRAIN, N - 100, 101)      # one past the end
+
+
+@pytest.mark.parametrize("precision", ["bf16_fwd", "f32"])
+def test_training_steps_on_full_size_minibatches_from_the_last_percent(c5_resident, precision):
+    """B = 65 536 gathered from the last 1 % (what a shuffled epoch's last steps read), as training steps: the step's loss equals
+    the loss_and_grad of the same indices (HIP vs HIP, bit for bit the same pass), the first step's loss equals the count-weighted
+    sum over oracle-checked eighths, and plain descent moves theta by exactly -lr x that gradient."""
+    spec, theta, X, f, y, eng = c5_resident
+    eng.set_option("precision", 1 if precision == "bf16_fwd" else 0)
+    eng.set_params(theta)
+    sp = ho.c5_spec(precision=precision)
+    N, B = N_C5, 65536
+    rng = np.random.default_rng(23)
+    idx = rng.choice(np.arange(N - N // 100, N), B, replace=False).astype(np.int32)
+    loss, grad, nv = eng.loss_and_grad(idx=idx)
+    acc_l, acc_n = 0.0, 0
+    for q in range(0, B, 8192):
+        ix = idx[q:q + 8192]
+        l0, _, nv0 = ho.loss_and_grad(sp, theta.astype(np.float64), X[:, ix], {k: v[ix] for k, v in f.items()}, {k: v[ix] for k, v in y.items()})
+        acc_l += l0 * sum(nv0); acc_n += sum(nv0)
+    assert nv == acc_n and abs(loss - acc_l / acc_n) <= (2e-5 if precision == "bf16_fwd" else 1e-5) * abs(loss)
+    eng.opt_init("Descent", 0.05)
+    step_loss = eng.train_step(0, B, idx=idx)
+    assert step_loss == pytest.approx(loss, rel=1e-6)
+    moved = (theta.astype(np.float64) - eng.get_params().astype(np.float64)) / 0.05
+    assert util.relerr(moved, grad) <= 1e-5
+    eng.set_params(theta)

@@ -7,6 +7,7 @@ import pytest
 import easyhybrid_jl_amd as eh
 from easyhybrid_jl_amd import _lib as L
 from easyhybrid_jl_amd.engine import HybridEngine
+from oracle import hybrid_oracle as ho
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -98,3 +99,108 @@ def test_multi_target_model_through_the_library_collective(fused):
     assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 3e-6
     eng.comm_destroy()
     eng.close(); ref.close()
+
+
+# ---- ONE process, several handles: the local group (eh_comm_init_local / eh_dp_train_step_group) ---------------------------------
+def _shard_engines(spec, theta, X, f, y, world, opt=("Adam", 0.01)):
+    from easyhybrid_jl_amd import dp
+    N = X.shape[1]
+    engs = []
+    for r in range(world):
+        lo, hi = dp.shard_range(N, r, world)
+        e = util.load_engine(spec, theta, X[:, lo:hi], {k: v[lo:hi] for k, v in f.items()}, {k: v[lo:hi] for k, v in y.items()})
+        e.opt_init(*opt)
+        engs.append(e)
+    return engs
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_handles_of_one_process_train_like_one_engine_on_the_union(world, fused):
+    """two (four) handles on device 0 driven by this one thread, each holding a shard with its own share of missing targets;
+    the library's local collective carries the raw sums.  Against ONE engine stepping on the union of the windows."""
+    B = 4096
+    spec, theta, X, f, y = util.rbq10_case(B, "tanh", True, 0.0)
+    y["reco"][: B // world][::2] = np.nan                      # all the gaps in rank 0's shard: per-shard means would be wrong
+    engs = _shard_engines(spec, theta, X, f, y, world)
+    HybridEngine.comm_init_local(engs)
+    for e in engs:
+        e.set_option("fused_update", fused)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    per = B // world
+    win = per // 4
+    for s in range(6):
+        a = (s % 4) * win
+        HybridEngine.dp_train_step_group(engs, [a] * world, win)
+        idx = np.concatenate([np.arange(r * per + a, r * per + a + win) for r in range(world)]).astype(np.int32)
+        ref.train_step(0, idx.size, want_loss=False, idx=idx)
+    th = [e.get_params() for e in engs]
+    for t in th[1:]:
+        assert np.array_equal(th[0], t), "replicas of a local group must stay bitwise identical"
+    assert np.max(np.abs(th[0] - ref.get_params())) <= 2e-6
+    if not fused:
+        loss = HybridEngine.dp_train_step_group(engs, [0] * world, win, want_loss=True)
+        idx = np.concatenate([np.arange(r * per, r * per + win) for r in range(world)]).astype(np.int32)
+        assert loss == pytest.approx(ref.train_step(0, idx.size, idx=idx), rel=2e-6)
+    engs[1].comm_destroy()                                      # dissolves the whole group
+    with pytest.raises(eh.EngineError):
+        HybridEngine.dp_train_step_group(engs, [0] * world, win)
+    for e in engs:
+        e.close()
+    ref.close()
+
+
+def test_local_group_allreduce_needs_the_bracket_and_every_member():
+    spec, theta, X, f, y = util.rbq10_case(2048, "tanh", True, 0.1)
+    engs = _shard_engines(spec, theta, X, f, y, 2)
+    HybridEngine.comm_init_local(engs)
+    with pytest.raises(eh.EngineError):
+        HybridEngine.comm_init_local(engs)                      # already in a group
+    for e in engs:
+        e.dp_grad(0, 512)
+    with pytest.raises(eh.EngineError):
+        engs[0].dp_allreduce(L.EH_BUF_GRAD)                     # outside a bracket
+    HybridEngine.comm_group_begin()
+    engs[0].dp_allreduce(L.EH_BUF_GRAD)
+    with pytest.raises(eh.EngineError):
+        HybridEngine.comm_group_end()                           # rank 1 never asked
+    HybridEngine.comm_group_begin()
+    for e in engs:
+        e.dp_allreduce(L.EH_BUF_GRAD)
+    HybridEngine.comm_group_end()
+    for e in engs:
+        e.dp_apply()
+    assert np.array_equal(engs[0].get_params(), engs[1].get_params())
+    for e in engs:
+        e.close()
+
+
+@pytest.mark.parametrize("hidden", [(24, 12), (160, 96, 48, 24)])
+def test_multi_target_model_under_the_local_group_fused_and_layerwise_form(hidden):
+    """T = 2 with very different gaps per shard (the per-target weights are those of the GLOBAL batch: eh_dp_counts ahead of the
+    pass), on a fused shape and on a shape only the layer-wise form holds (hidden width > 128: advisor finding of round 2 -- the
+    layer-wise step re-counted per shard and overwrote the global weights)."""
+    rng = np.random.default_rng(8)
+    B, world = 2048, 2
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(6, list(hidden), "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((6, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][: B // 2][rng.random(B // 2) < 0.7] = np.nan      # shard 0 misses most NEE, shard 1 a third of GPP
+    y["GPP"][B // 2:][rng.random(B // 2) < 0.3] = np.nan
+    theta = ho.init_theta(spec, 3, np.float32)
+    engs = _shard_engines(spec, theta, X, f, y, world, opt=("Descent", 0.05))
+    HybridEngine.comm_init_local(engs)
+    # the global shift of the shifted target sums (what DataParallel all-reduces once): the same vector on every member
+    shift = [float(np.nanmean(y[t])) for t in spec.targets]
+    for e in engs:
+        e.set_target_shift(shift)
+    loss = HybridEngine.dp_train_step_group(engs, [0, 0], B // 2, want_loss=True)
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert abs(loss - l0) <= 1e-5 * abs(l0), (loss, l0)
+    step = (theta.astype(np.float64) - engs[0].get_params().astype(np.float64)) / 0.05          # Descent: theta - lr * grad
+    assert util.relerr(step, g0) <= 2e-5, util.relerr(step, g0)
+    assert np.array_equal(engs[0].get_params(), engs[1].get_params())
+    for e in engs:
+        e.close()

@@ -4,6 +4,7 @@ and variant) through the C ABI against the oracle.  One loss + gradient comparis
 import numpy as np
 import pytest
 
+import easyhybrid_jl_amd as eh
 from oracle import hybrid_oracle as ho
 from tests import util
 
@@ -116,6 +117,43 @@ def test_random_configuration_matches_the_oracle(seed, fastpath):
             assert util.relerr(grad, g0) <= tol, (kind, spec)
         else:
             assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec)
+    eng.close()
+
+
+@pytest.mark.parametrize("fastpath", [False, True])
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EH_FUZZ_N", "60")) // 3))
+def test_random_configuration_at_the_raw_input_scale(seed, fastpath):
+    """the same walk with the predictors left at the scale the reference's synthetic columns have (sw_pot ~ |50 + 20 N(0,1)|,
+    test/test_split_data_train.jl:15-31) instead of O(1): saturated tanh / sigmoid units, large relu / swish / identity ones.
+    sigma-scaled outputs (an un-scaled linear output of magnitude 100 is no physical parameter for any of the models)."""
+    spec, theta, X, f, y, kind, first, B, rng = _case(40000 + seed, fastpath)
+    spec.scale_nn_outputs = True
+    rng2 = np.random.default_rng(50000 + seed)
+    X = np.abs(50.0 + 20.0 * rng2.standard_normal(X.shape)).astype(np.float32)
+    if kind in ("kgeLoss", "pearsonLoss", "nseLoss"):
+        kind = "mse"                                              # (saturated nets predict near-constants: their correlation is noise)
+    sl = slice(first, first + B)
+    yb = {k: v[sl] for k, v in y.items()}
+    eng = util.load_engine(spec, theta, X, f, y)
+    if kind != "mse":
+        eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad(first=first, count=B)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind,
+                                   bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+    assert nv == sum(nv0)
+    if sum(nv0) == 0:
+        assert np.isnan(loss) and not grad.any()
+    else:
+        assert np.isfinite(l0) and loss == pytest.approx(l0, rel=1e-5), (kind, spec)
+        if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
+            assert util.relerr(grad, g0) <= 1e-5, (kind, spec, util.relerr(grad, g0))
+        else:
+            assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec)
+        out = eng.forward(eh.EH_SPLIT_TRAIN, first, B, params=False)
+        ref = ho.forward(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()},
+                         bn_state=ho.bn_init(spec) if spec.input_batchnorm else None, train_mode=False)
+        for t in spec.targets:
+            assert util.relerr(out[t], ref[t]) <= 1e-5, (t, spec)
     eng.close()
 
 
