@@ -2404,7 +2404,14 @@ int32_t eh_graph_begin(eh_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ensure_loss_hist(h, 1);
     if (rc) return rc;
-    if (jit_wanted(h, EH_MODE_TRAIN)) (void)jit_entry(h);       // compile and load now: not inside a stream capture
+    if (jit_wanted(h, EH_MODE_TRAIN)) {
+        // compile and load NOW, synchronously: hiprtc / hipModuleLoadData must not run beside a relaxed capture, and the kernel must
+        // not change in the middle of the recorded sequence ("specialize" = 2 would otherwise hand the build to a worker thread)
+        h->capturing = true;                    // (jit_entry builds in the calling thread while this is set)
+        (void)jit_entry(h);
+        h->capturing = false;
+        for (auto& e : h->jit) if (e->worker.joinable()) e->worker.join();      // a build already in flight: wait for it
+    }
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
     h->capturing = true;
     return EH_OK;

@@ -7,6 +7,7 @@ pieces -> NotImplementedError, call-order / device problems -> RuntimeError).
 from __future__ import annotations
 
 import ctypes as C
+import numbers
 import os
 from typing import Dict, Optional, Sequence
 
@@ -241,8 +242,8 @@ class HybridEngine:
         permutation) that must stay alive until the step has run."""
         loss = C.c_float()
         ip, on_dev = None, 0
-        if isinstance(idx, int):
-            ip, on_dev = C.cast(C.c_void_p(idx), C.POINTER(C.c_int32)), 1
+        if isinstance(idx, numbers.Integral):       # (also numpy integers: np.int64(tensor.data_ptr()) is a pointer, not a one-element index list)
+            ip, on_dev = C.cast(C.c_void_p(int(idx)), C.POINTER(C.c_int32)), 1
         elif idx is not None:
             self._idx_keep = np.ascontiguousarray(idx, np.int32)        # (kept until the next call: the copy is asynchronous)
             ip = self._idx_keep.ctypes.data_as(C.POINTER(C.c_int32))

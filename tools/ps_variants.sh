@@ -6,12 +6,15 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/easyhybrid.jl_amd/csrc
 make -C $CS -j8 >/dev/null
+# the flags of the normal build (incl. -fno-slp-vectorize, the fix these variants were written to find) come from the Makefile: pass
+# e.g. "-fslp-vectorize" as a variant's flags to get the failing build back
+BASE=$(make -C $CS -s --no-print-directory print-cxxflags)
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   out=$ROOT/dbg/$name; mkdir -p $out
   for s in 1_4_2 1_4_3; do
     IFS=_ read a b c <<< "$s"
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS -DEH_NBI=$a -DEH_NBH=$b -DEH_NL=$c -DEH_FAST_PATHS $flags \
+    ( /opt/rocm/bin/hipcc $BASE -DEH_NBI=$a -DEH_NBH=$b -DEH_NL=$c -DEH_FAST_PATHS $flags \
         -c $CS/eh_arch.hip -o $out/eh_arch_$s.o ) &
   done
   wait
