@@ -91,8 +91,11 @@ struct EhMechArgs {
     int use_v;
     float* part;                             // [gridDim.x][EH_MECH_PART] partial sums
     const unsigned* prog;                    // EH_MECH_PROGRAM: the recorded closure (EhStepArgs::prog layout)
+    int tiles;                               // > 0: workgroup b owns the `tiles` consecutive 256 V-sample tiles from b * tiles (a front that moves through memory
+                                             // with the dispatch order); 0: grid-stride trips (a capped grid)
 };
 enum { EH_MECH_PART = 16 };                  // [dL/dpar_j (8) | S_t (4) | pad]
+enum { EH_MECH_MAXROWS = 65536 };            // rows of partials (workgroups of the streaming kernel) at most: 4 MiB
 
 template <int V>
 __global__ __launch_bounds__(256) void eh_count_valid_kernel(EhMechArgs a, int T, unsigned long long* counts) {
@@ -133,6 +136,8 @@ constexpr int eh_mech_np(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_PARAMS : 
 constexpr int eh_mech_nf(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_FORC : m == EH_MECH_FLUXPART ? 2 : m == EH_MECH_RS_COMPONENTS3F ? 3 : 1; }
 constexpr int eh_mech_no(int m) { return (m == EH_MECH_PROGRAM || m == EH_MECH_FLUXPART) ? 3 : 1; }
 
+// (RbQ10: 68 VGPRs, seven waves per SIMD.  Forcing eight -- amdgpu_waves_per_eu(8): 64 VGPRs -- spills two registers, and a kernel
+// with ANY scratch pays for the allocation at every wave launch, which a launch of tens of thousands of short workgroups cannot afford.)
 template <int V, int MECH>
 __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMechArgs a) {
     constexpr int NP = eh_mech_np(MECH), NF = eh_mech_nf(MECH), NO = eh_mech_no(MECH), NTG = NO > 1 ? EH_MAX_TARG : 1;
@@ -154,7 +159,13 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
     for (int j = 0; j < NP; ++j) gp[j] = 0.0f;
 #pragma unroll
     for (int t = 0; t < NTG; ++t) S[t] = 0.0f;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * V; i < a.n; i += (long long)gridDim.x * 256 * V) {
+    const long long i_first = a.tiles > 0 ? ((long long)blockIdx.x * a.tiles * 256 + threadIdx.x) * V : ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+    const long long i_step = a.tiles > 0 ? 256ll * V : (long long)gridDim.x * 256 * V;
+    // (no std::min here: it takes references, and a reference to a member of the by-value kernarg struct makes the compiler copy the
+    // whole struct to scratch -- 200 bytes per lane and 24 VGPRs more, measured)
+    const long long n_all = a.n, tile_end = (long long)(blockIdx.x + 1) * a.tiles * 256 * V;
+    const long long i_end = (a.tiles > 0 && tile_end < n_all) ? tile_end : n_all;
+    for (long long i = i_first; i < i_end; i += i_step) {
         float ov[NP][V], fv[NF][V], yv[NTG][V], dov[NP][V], yh[NTG][V];
         auto ld = [&](const float* p, float (&dst)[V]) {
             if constexpr (V == 4) { const f32x4 v = *(const f32x4*)(p + i); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
@@ -256,24 +267,40 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
     if (threadIdx.x < 12) a.part[(long long)blockIdx.x * EH_MECH_PART + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-// rows of partials -> out[0] = loss, out[1 + j] = d loss / d raw global parameter j (canonical parameter order), fixed order
-__global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part, int nblk, const EhNet net, const float* meta, const EhMechArgs a, float* out) {
-    const int k = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 64 row groups x 16 columns: 64-byte rows, independent loads
-    __shared__ float red[64][EH_MECH_PART];
-    // the rows were written by other XCDs: every load is a trip to memory, so all of a thread's loads (nblk <= 4096: at most
-    // 64) are requested before the first is used -- one latency instead of one per row
-    float v[64];
-#pragma unroll
-    for (int u = 0; u < 64; ++u) v[u] = grp + 64 * u < nblk ? part[(long long)(grp + 64 * u) * EH_MECH_PART + k] : 0.0f;
+// rows of partials -> out[0] = loss, out[1 + j] = d loss / d raw global parameter j (canonical parameter order), fixed order:
+// deterministic.  Up to 2 048 rows: eh_mech_finish_kernel alone (one workgroup, 64 row groups x 16 columns, all of a thread's loads
+// -- rows written on other XCDs, each a trip to memory -- requested before the first add).  More rows: eh_mech_fold_kernel first,
+// whose workgroup g folds rows [g rows_per, (g + 1) rows_per) into row g of a second, <= 64-row table for the finish kernel.  (One
+// launch with a ticket for the last workgroup was measured and lost: 13.6 us at 4 096 rows, 37 us at 65 536 -- the release in front
+// of the ticket writes back an L2 -- against 5.1-5.7 us for the plain one-workgroup kernel; profiles/r03/mech_stage_ab.txt.)
+__device__ __forceinline__ float eh_mech_fold_rows(const float* part, int r0, int r1, float (*red)[EH_MECH_PART]) {
+    const int k = threadIdx.x & 15, grp = threadIdx.x >> 4;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int rb = r0 + grp; rb < r1; rb += 64 * 32) {
+        float v[32];
 #pragma unroll
-    for (int u = 0; u < 64; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+        for (int u = 0; u < 32; ++u) v[u] = rb + 64 * u < r1 ? part[(long long)(rb + 64 * u) * EH_MECH_PART + k] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+    }
     red[grp][k] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     float s = 0.0f;
     if (grp == 0)
         for (int g2 = 0; g2 < 64; ++g2) s += red[g2][k];
-    if (grp != 0) return;
+    return s;                                                    // (threads 0..15 hold column k's sum)
+}
+__global__ __launch_bounds__(1024) void eh_mech_fold_kernel(const float* part, int nblk, int rows_per, float* part2) {
+    __shared__ float red[64][EH_MECH_PART];
+    const int r0 = blockIdx.x * rows_per;
+    const float s = eh_mech_fold_rows(part, r0, min(nblk, r0 + rows_per), red);
+    if (threadIdx.x < EH_MECH_PART) part2[blockIdx.x * EH_MECH_PART + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part, int nblk, const EhNet net, const float* meta, const EhMechArgs a, float* out) {
+    __shared__ float red[64][EH_MECH_PART];
+    const int k = threadIdx.x & 15;
+    const float s = eh_mech_fold_rows(part, 0, nblk, red);
+    if (threadIdx.x >= EH_MECH_PART) return;
     __shared__ float St[EH_MAX_TARG];
     if (k >= 8 && k < 12) {
         const unsigned long long c = a.use_v ? a.counts_v[k - 8] : a.counts[k - 8];
@@ -775,6 +802,8 @@ struct eh_handle_s {
     bool capturing = false;
     GraphRec cap{};
     int max_blocks = 256;
+    int mech_blocks = 0;            // "mech_blocks" option: cap on the streaming kernel's workgroups (0: none -- one workgroup per `mech_tiles` tiles)
+    int mech_tiles = 2;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup
     // scratch for forward / eval outputs
     float* out_buf = nullptr;
     long long out_cap = 0;
@@ -1550,6 +1579,16 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->max_blocks = (int)value;
         return EH_OK;
     }
+    if (!strcmp(name, "mech_blocks")) {      // workgroups of the stand-alone mechanistic stage (eh_mech_loss_vjp): rows of partials the finish kernel folds
+        if (value < 0 || value > EH_MECH_MAXROWS) return fail(h, EH_EINVAL, "mech_blocks must be 0 (no cap) .. %d", (int)EH_MECH_MAXROWS);
+        h->mech_blocks = (int)value;
+        return EH_OK;
+    }
+    if (!strcmp(name, "mech_tiles")) {       // consecutive tiles (1 024 samples each) per workgroup of the stand-alone mechanistic stage
+        if (value < 1 || value > 1024) return fail(h, EH_EINVAL, "mech_tiles must be 1..1024");
+        h->mech_tiles = (int)value;
+        return EH_OK;
+    }
     if (!strcmp(name, "fast_paths")) {       // 0 forces the generic MFMA kernels (A/B testing)
         const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech);
         h->fast_user = value ? (int)value : 0;
@@ -2184,20 +2223,32 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
     for (int f = 0; f < net.F; ++f) { a.frc[f] = forcings_dev[f]; vec = vec && (uintptr_t)forcings_dev[f] % 16 == 0; }
     for (int t = 0; t < net.T; ++t) { a.y[t] = targets_dev[t]; vec = vec && (uintptr_t)targets_dev[t] % 16 == 0; }
     if (net.mech == EH_MECH_PROGRAM) { vec = false; a.prog = h->prog; }        // the interpreter keeps its tape in scratch: one sample per lane
-    const int per = vec ? 1024 : 256;                                      // samples per workgroup and trip
+    const int per = vec ? 1024 : 256;                                      // samples per workgroup and tile
     if (net.n_out == 1 && net.T > 1) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: %d targets on a single-output model", net.T);
-    const int nblk = (int)std::min<int64_t>((count + per - 1) / per, 4096);
-    const size_t need = (size_t)nblk * EH_MECH_PART * sizeof(float) + 64 + EH_MAX_TARG * sizeof(unsigned long long);
-    if (need > h->mech_ws_bytes) {
+    // Many short workgroups, each on its own consecutive tiles: the accesses then move through the arrays as one front, in dispatch
+    // order, which is what the memory system serves best (tools/ubench/stream31.hip: 5.8 TB/s for this 3 : 1 mix, against 4.8-5.3 for
+    // a persistent grid of 1-4 k workgroups striding through it).  Rows of partials: one per workgroup, <= EH_MECH_MAXROWS.
+    const long long ntile = (count + per - 1) / per;
+    int tiles = h->mech_tiles > 0 ? h->mech_tiles : 1;
+    while ((ntile + tiles - 1) / tiles > EH_MECH_MAXROWS) tiles *= 2;
+    int nblk = (int)((ntile + tiles - 1) / tiles);
+    if (h->mech_blocks > 0 && nblk > h->mech_blocks) { nblk = h->mech_blocks; tiles = 0; }      // "mech_blocks" option: a capped, grid-striding launch
+    a.tiles = tiles;
+    const int nfold = nblk <= 2048 ? 0 : std::min(64, (nblk + 511) / 512);      // workgroups of the fold kernel (512 rows and more each)
+    const int rows_per = nfold ? (nblk + nfold - 1) / nfold : 0;
+    const size_t ws_bytes = EH_MAX_TARG * sizeof(unsigned long long) + 64 + 64 + (size_t)(64 + EH_MECH_MAXROWS) * EH_MECH_PART * sizeof(float);
+    if (ws_bytes > h->mech_ws_bytes) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         (void)hipFree(h->mech_ws);
         h->mech_ws = nullptr; h->mech_ws_bytes = 0;
-        HIPCHK(h, hipMalloc(&h->mech_ws, (size_t)4096 * EH_MECH_PART * sizeof(float) + 64 + EH_MAX_TARG * sizeof(unsigned long long)));
-        h->mech_ws_bytes = (size_t)4096 * EH_MECH_PART * sizeof(float) + 64 + EH_MAX_TARG * sizeof(unsigned long long);
+        HIPCHK(h, hipMalloc(&h->mech_ws, ws_bytes));
+        h->mech_ws_bytes = ws_bytes;
     }
+    // [counts (4 x u64) | out: loss + 8 gradients, padded to 32 floats | part2 [64][16] | part [rows][16]]
     unsigned long long* counts = reinterpret_cast<unsigned long long*>(h->mech_ws);
-    float* out = reinterpret_cast<float*>(h->mech_ws + EH_MAX_TARG * sizeof(unsigned long long));        // [loss | 8 gradients]
-    a.part = out + 16;
+    float* out = reinterpret_cast<float*>(h->mech_ws + EH_MAX_TARG * sizeof(unsigned long long));
+    float* part2 = out + 32;
+    a.part = part2 + 64 * EH_MECH_PART;
     a.counts = counts;
     unsigned long long hc[EH_MAX_TARG] = {0, 0, 0, 0};
     if (n_valid_in) {                        // masks are a property of the data set (src/training/train.jl:221-232): the caller may know the counts
@@ -2224,7 +2275,11 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
     }
 #undef EH_MECH_GO
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(eh_mech_finish_kernel, dim3(1), dim3(1024), 0, h->stream, a.part, nblk, net, a.meta, a, out);
+    if (nfold) {
+        hipLaunchKernelGGL(eh_mech_fold_kernel, dim3((unsigned)nfold), dim3(1024), 0, h->stream, a.part, nblk, rows_per, part2);
+        HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(eh_mech_finish_kernel, dim3(1), dim3(1024), 0, h->stream, nfold ? part2 : a.part, nfold ? nfold : nblk, net, a.meta, a, out);
     HIPCHK(h, hipGetLastError());
     if (!loss && !grad_global && !n_valid) return EH_OK;         // asynchronous use: results stay on the device, ordered on the handle's stream
     float ho[9];

@@ -25,7 +25,7 @@ CONFIGS = {
 }
 
 
-def measure(mech="rbq10", batch=1 << 24, steps=50, stagger=0):
+def measure(mech="rbq10", batch=1 << 24, steps=50, stagger=0, blocks=0, tiles=0):
     """-> dict (one JSON line of this tool).  Needs a GPU; creates its own engine and a named torch stream."""
     import torch
     import easyhybrid_jl_amd as eh
@@ -41,6 +41,10 @@ def measure(mech="rbq10", batch=1 << 24, steps=50, stagger=0):
     try:
         eng.set_stream(stream.cuda_stream)
         eng.set_params(model.initialparameters(1))
+        if blocks:
+            eng.set_option("mech_blocks", blocks)      # cap on the streaming kernel's workgroups (then a grid-striding launch)
+        if tiles:
+            eng.set_option("mech_tiles", tiles)        # consecutive 1 024-sample tiles per workgroup (default 1)
         B, K, F, T = batch, len(neural), len(forc), len(targ)
         g = torch.Generator(device="cuda").manual_seed(0)
         nplane = [0]
@@ -86,7 +90,7 @@ def measure(mech="rbq10", batch=1 << 24, steps=50, stagger=0):
         torch.cuda.set_stream(prev)
         eng.close()
     return {"kernel": "eh_mech_vjp_kernel<4, %s> + eh_mech_finish_kernel (one eh_mech_loss_vjp call, counts of valid targets handed in)" % mech,
-            "mech": mech, "batch": B, "stagger_bytes": stagger, "K": K, "F": F, "T": T, "bound": "hbm",
+            "mech": mech, "batch": B, "stagger_bytes": stagger, "mech_blocks": blocks or "default", "mech_tiles": tiles or "default", "K": K, "F": F, "T": T, "bound": "hbm",
             "algorithmic_bytes_per_sample": bytes_alg // B, "ms_per_call": ms_known, "achieved": bytes_alg / ms_known / 1e6, "peak": 8000.0,
             "unit": "GB/s", "frac": bytes_alg / ms_known / 1e6 / 8000, "ms_per_call_with_counting_pass": ms_count,
             "GBps_with_counting_pass": (bytes_alg + 4 * T * B) / ms_count / 1e6, "samples_per_s": B / ms_known * 1e3,
@@ -99,8 +103,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--mech", default="rbq10", choices=sorted(CONFIGS))
     ap.add_argument("--stagger", type=int, default=0, help="shift the start of plane k by k x this many bytes (multiple of 16)")
+    ap.add_argument("--blocks", type=int, default=0, help="workgroups of the streaming kernel (the library's default when 0)")
+    ap.add_argument("--tiles", type=int, default=0, help="consecutive 1 024-sample tiles per workgroup (the library's default when 0)")
     args = ap.parse_args()
-    print(json.dumps(measure(args.mech, args.batch, args.steps, args.stagger)))
+    print(json.dumps(measure(args.mech, args.batch, args.steps, args.stagger, args.blocks, args.tiles)))
 
 
 if __name__ == "__main__":
