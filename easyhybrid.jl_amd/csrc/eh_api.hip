@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part,
 template <bool APPLY, int CW>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
-                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom, const float* l2val) {
+                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom, const float* l2val, unsigned tp_mask) {
     constexpr int NQ = 256 / CW;
     __shared__ float part[NQ][CW + 1];
     __shared__ float wsum[4][EH_MAX_TARG + 3];
@@ -386,6 +386,11 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     float dscale = 1.0f, dloss = 0.0f;
     if (deferred) eh_loss_finish(loss_kind, cnts[EH_MAX_TARG], cnts[0], cnts[EH_MAX_TARG + 1], cnts[EH_MAX_TARG + 2], dscale, dloss);
     if (deferred && mom && cnts[0] > 0.0f) { dscale = 1.0f; dloss = mom[7]; }      // moment-based loss: per-sample weights were exact, value from eh_moment_coef_kernel
+    float tp_loss = 0.0f;                    // multi-target: the targets whose loss came out of the coefficient kernel (the others' terms are in the loss sum)
+    if (!deferred && mom) {
+#pragma unroll
+        for (int t = 0; t < EH_MAX_TARG; ++t) tp_loss += (t < T && ((tp_mask >> t) & 1u)) ? mom[EH_TT * t + 7] : 0.0f;
+    }
     if (q == 0 && idx < n_acc) {
         float tot = 0.0f;
 #pragma unroll
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
                 else eh_image_store(im, idx, th);
             }
         } else if (idx == n_theta) {
-            const float loss = ntot > 0.0f ? (deferred ? dloss : tot) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
+            const float loss = ntot > 0.0f ? (deferred ? dloss : tot + tp_loss) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
             gradbuf[idx] = loss;
             if (loss_slot) *loss_slot = loss;
         } else {
@@ -494,31 +499,47 @@ __global__ __launch_bounds__(256) void eh_p2p_test_kernel(const EhP2P* P, int sl
 // beta = mean(yhat) / mean(y);  dr/du_i = (w_i - mw) / sqrt(Suu_c Sww_c) - r (u_i - mu) / Suu_c,
 // dalpha/du_i = (u_i - mu) / (alpha Sww_c),  dbeta/du_i = 1 / (n mean(y)).
 // stage 0: the centre of yhat for the moment pass proper = its batch mean (sum (yhat - c) is accurate; the squares are not)
-__global__ __launch_bounds__(64) void eh_moment_centre_kernel(const float* slab, int nblk, float shift, float* out) {
+struct EhShift4 { float c[EH_MAX_TARG]; };
+// (one workgroup per target; targets whose loss needs no batch statistics of yhat are left alone)
+__device__ __forceinline__ bool eh_kind_two_pass(unsigned kind, int T) {
+    return (kind >= (unsigned)EH_LOSS_PEARSONLOSS && kind <= (unsigned)EH_LOSS_PBKGELOSS) || (kind == (unsigned)EH_LOSS_RMSE && T > 1);
+}
+__global__ __launch_bounds__(64) void eh_moment_centre_kernel(const float* slab, int nblk, int T, unsigned loss_t, EhShift4 shift, float* tt) {
     __shared__ double tot[EH_EVAL_STATS];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, t = blockIdx.x;
+    if (!eh_kind_two_pass((loss_t >> (4 * t)) & 15u, T)) return;
     if (tid < EH_EVAL_STATS) {
         double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)slab[b * EH_EVAL_STATS + tid];
+        for (int b = 0; b < nblk; ++b) s += (double)slab[(b * T + t) * EH_EVAL_STATS + tid];
         tot[tid] = s;
     }
     __syncthreads();
-    if (tid == 0) out[1] = tot[3] > 0.0 ? (float)((double)shift + tot[4] / tot[3]) : shift;
+    if (tid == 0) tt[EH_TT * t + 1] = tot[3] > 0.0 ? (float)((double)shift.c[t] + tot[4] / tot[3]) : shift.c[t];
 }
-// stage 1: moments with u = yhat - out[1], w = y - shift
-__global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int kind, float shift, float* out) {
+// stage 1: moments with u = yhat - tt[1], w = y - shift  ->  tt[4..6] = k0, k1, k2 ; tt[7] = the target's loss value
+// (rmse, the one loss without batch moments here, takes this form on multi-target models, where its scale 1 / (n rmse) has to be
+// known inside the one streaming pass that serves all targets: d/dyhat_i = (yhat_i - y_i) / (n rmse), loss_fn.jl:58-60)
+__global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int T, unsigned loss_t, EhShift4 shift4, float* tt_all) {
     __shared__ double tot[EH_EVAL_STATS];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int kind = (int)((loss_t >> (4 * t)) & 15u);
+    if (!eh_kind_two_pass((unsigned)kind, T)) return;
+    float* const out = tt_all + EH_TT * t;
+    const float shift = shift4.c[t];
     if (tid < EH_EVAL_STATS) {
         double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)slab[b * EH_EVAL_STATS + tid];
+        for (int b = 0; b < nblk; ++b) s += (double)slab[(b * T + t) * EH_EVAL_STATS + tid];
         tot[tid] = s;
     }
     __syncthreads();
     if (tid != 0) return;
     const double n = tot[3], Sw = tot[1], Sww = tot[2], Su = tot[4], Suu = tot[5], Suw = tot[6], cu = (double)out[1];
-    float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, loss = __builtin_nanf("");
-    if (n > 0.0) {
+    float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, loss = T > 1 ? 0.0f : __builtin_nanf("");      // (a target without a valid sample adds nothing to a multi-target loss)
+    if (n > 0.0 && kind == EH_LOSS_RMSE) {
+        const double rm = sqrt(tot[0] / n), q = rm > 0.0 ? 1.0 / (n * rm) : 0.0;            // d = q (yhat - y) = q (u + cu) - q (w + shift)
+        k1 = (float)q; k2 = (float)-q; k0 = (float)(q * (cu - (double)shift));
+        loss = (float)rm;
+    } else if (n > 0.0) {
         const double mu = Su / n, mw = Sw / n;
         const double Suu_c = Suu - Su * Su / n, Sww_c = Sww - Sw * Sw / n, Suw_c = Suw - Su * Sw / n;
         const double den = sqrt(Suu_c * Sww_c), r = Suw_c / den;
@@ -571,7 +592,6 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
 // Per-target weight of one batch (multi-target models: the normaliser differs per target, so it has to be known before the pass):
 // the residual terms of target t enter the loss as w_t r^2 (w_t |r| for MAE) with  w_t = 1 / n_t  for mse / mae  (loss_fn.jl:61-66)
 // and  w_t = 1 / sum (y - mean y)^2  for nseLoss (:79-81) -- all of it a function of the targets alone.  One workgroup per target.
-struct EhShift4 { float c[EH_MAX_TARG]; };
 __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
                                                        float* inv_n, unsigned loss_t, EhShift4 shift, float* raw = nullptr) {
     __shared__ float red[3][256];
@@ -593,7 +613,7 @@ __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C,
         if (raw) { raw[3 * t] = n; raw[3 * t + 1] = red[1][0]; raw[3 * t + 2] = red[2][0]; return; }      // data parallel: this shard's sums (EH_BUF_TCOUNT), all-reduced by the caller
         float w = n > 0.0f ? 1.0f / n : 0.0f;
         if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (red[2][0] - red[1][0] * red[1][0] / n);
-        inv_n[t] = w;
+        inv_n[EH_TT * t] = w;                 // (the per-target table of EhStepArgs::inv_n, eh_device.hpp)
     }
 }
 // (data parallel) the all-reduced sums [n_t | sum (y - c) | sum (y - c)^2] of the GLOBAL batch -> the per-target weights; c is common to the ranks (eh_set_target_shift)
@@ -603,7 +623,7 @@ __global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned 
     const float n = raw[3 * t];
     float w = n > 0.0f ? 1.0f / n : 0.0f;
     if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (raw[3 * t + 2] - raw[3 * t + 1] * raw[3 * t + 1] / n);
-    inv_n[t] = w;
+    inv_n[EH_TT * t] = w;
 }
 
 // input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample
@@ -767,8 +787,10 @@ struct eh_handle_s {
     bool opt_ready = false;
     // layer-wise execution form (eh_lform.hpp): networks no fused kernel holds
     bool lform = false;
-    int l_nl = 0;                                        // Dense layers (hidden + output)
-    int l_in[EH_MAX_HIDDEN + 1] = {0}, l_out[EH_MAX_HIDDEN + 1] = {0}, l_woff[EH_MAX_HIDDEN + 1] = {0}, l_boff[EH_MAX_HIDDEN + 1] = {0};
+    // one entry per network (SingleNN: one; MultiNN: one single-output network per neural parameter, each on its own predictor rows)
+    struct LNet { int nl = 0, c0 = 0, orow = 0, act = 0; int in[EH_MAX_HIDDEN + 1] = {0}, out[EH_MAX_HIDDEN + 1] = {0}, woff[EH_MAX_HIDDEN + 1] = {0}, boff[EH_MAX_HIDDEN + 1] = {0}; };
+    int l_nnets = 0;                                     // 0: no network at all (no neural parameter)
+    LNet l_net[EH_MAX_NETS];
     float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
     long long l_cap = 0;                                 // samples the workspace holds
     unsigned char* wflag = nullptr;
@@ -900,6 +922,8 @@ struct EhLocalReq { eh_handle* h; float* buf; size_t n; };
 static thread_local int g_group_depth = 0;                 // eh_comm_group_begin nesting of this host thread
 static thread_local bool g_group_rccl = false;             // ncclGroupStart was issued for the open bracket
 static thread_local std::vector<EhLocalReq> g_group_reqs;  // all-reduces of local-group members, run at eh_comm_group_end
+
+static unsigned two_pass_mask(const EhNet& net);
 
 // ---- fused-update mode: apply the pending gradient so theta / m / v / image are current -----------
 static int flush_pending(eh_handle* h) {
@@ -1185,8 +1209,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         if (same) act = d->net_activation[0];          // one activation after all: the kernels built ahead of time
     }
     if (d->n_params != mi.n_par) return fail(nullptr, EH_EINVAL, "eh_create: model %d takes %d parameters, descriptor has %d", d->mech, mi.n_par, d->n_params);
-    if (d->n_predictors < 1) return fail(nullptr, EH_EINVAL, "eh_create: n_predictors must be >= 1");
-    if (d->n_hidden < 1 || d->n_hidden > EH_MAX_HIDDEN) return fail(nullptr, EH_EINVAL, "eh_create: n_hidden must be 1..%d", EH_MAX_HIDDEN);
+    if (d->n_predictors < 0 || d->n_hidden < 0 || d->n_hidden > EH_MAX_HIDDEN) return fail(nullptr, EH_EINVAL, "eh_create: n_predictors %d, n_hidden %d (0..%d)", d->n_predictors, d->n_hidden, EH_MAX_HIDDEN);
     if (d->n_forcings < mi.n_forc || d->n_forcings > EH_MAX_FORC) return fail(nullptr, EH_EINVAL, "eh_create: n_forcings %d (model needs %d, max %d)", d->n_forcings, mi.n_forc, EH_MAX_FORC);
     if (d->n_targets < 1 || d->n_targets > EH_MAX_TARG) return fail(nullptr, EH_EINVAL, "eh_create: n_targets must be 1..%d", EH_MAX_TARG);
     int K = 0, G = 0, maxw = 0;
@@ -1207,7 +1230,16 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     for (int i = 0; i < K; ++i) if (!seenK[i]) return fail(nullptr, EH_EINVAL, "eh_create: neural param_index values must be 0..K-1");
     for (int i = 0; i < G; ++i) if (!seenG[i]) return fail(nullptr, EH_EINVAL, "eh_create: global param_index values must be 0..G-1");
-    if (K < 1) return fail(nullptr, EH_EINVAL, "eh_create: at least one neural parameter is required");
+    // No neural parameter: the reference builds no network at all (`NN = Chain()`, GenericHybridModel.jl:112-125) and its forward
+    // is global / fixed parameters -> M (:376-406).  Here: the layer-wise form with zero Dense layers (mechanistic stage + reduce).
+    const bool no_nn = K == 0;
+    if (no_nn) {
+        if (G < 1) return fail(nullptr, EH_EINVAL, "eh_create: a model with neither neural nor global parameters has nothing to train");
+        if (d->n_hidden != 0 || d->n_nets != 0 || d->input_batchnorm) return fail(nullptr, EH_EINVAL, "eh_create: no neural parameter: n_hidden, n_nets and input_batchnorm must be 0");
+    } else {
+        if (d->n_predictors < 1) return fail(nullptr, EH_EINVAL, "eh_create: n_predictors must be >= 1");
+        if (d->n_hidden < 1) return fail(nullptr, EH_EINVAL, "eh_create: n_hidden must be 1..%d", EH_MAX_HIDDEN);
+    }
     // nets and their block placement (SingleNN = one net with K outputs)
     const int nl = d->n_hidden;
     int n_nets = 1, net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0}, net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}}, tot_w[EH_MAX_HIDDEN] = {0};
@@ -1251,17 +1283,18 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         if (d->target_output[t] < 0 || d->target_output[t] >= mi.n_out) return fail(nullptr, EH_EINVAL, "eh_create: target_output[%d] = %d (model has %d outputs)", t, d->target_output[t], mi.n_out);
     const int nbi = (d->n_predictors + 15) / 16, nbh_raw = (maxw + 15) / 16;
     const int nbh = nbh_raw <= 1 ? 1 : nbh_raw <= 2 ? 2 : nbh_raw <= 4 ? 4 : nbh_raw <= 8 ? 8 : 0;
-    const EhArchInfo* arch = (nbh && K <= 16) ? find_arch(nbi, nbh, d->n_hidden) : nullptr;
-    const EhArchInfo* const wide_arch = (nbh && K <= 16) ? find_wide(nbi, nbh, d->n_hidden) : nullptr;
+    const EhArchInfo* arch = (nbh && K <= 16 && !no_nn) ? find_arch(nbi, nbh, d->n_hidden) : nullptr;
+    const EhArchInfo* const wide_arch = (nbh && K <= 16 && !no_nn) ? find_wide(nbi, nbh, d->n_hidden) : nullptr;
     if (!arch) arch = wide_arch;
     bool lform = false;
-    if (!arch) {
+    if (no_nn) { arch = &g_lform_arch; lform = true; }
+    else if (!arch) {
         // no fused kernel holds this network: run it layer by layer (eh_lform.hpp) where that form is built
-        const bool act_ok = act == EH_ACT_TANH || act == EH_ACT_SIGMOID || act == EH_ACT_RELU || act == EH_ACT_IDENTITY;
-        if (d->n_nets > 0 || !act_ok || K > 16 || (d->input_batchnorm && d->n_predictors > 32))
+        // (every activation, SingleNN and MultiNN alike: the layer-wise form runs each network as its own chain of products)
+        if (K > 16 || (d->input_batchnorm && d->n_predictors > 32))
             return fail(nullptr, EH_EUNSUPPORTED, "eh_create: no kernel for P=%d, hidden max width %d%s, %d hidden layers, K=%d, activation %d (fused kernels: P<=32, K<=16, "
-                        "width<=64 with <=3 layers or width<=128 with <=2; layer-wise form: one network (SingleNN), tanh / sigmoid / relu / identity, K<=16, "
-                        "input BatchNorm with P<=32)", d->n_predictors, maxw, d->n_nets > 0 ? " (nets side by side)" : "", d->n_hidden, K, act);
+                        "width<=64 with <=3 layers or width<=128 with <=2; layer-wise form: K<=16, input BatchNorm with P<=32)",
+                        d->n_predictors, maxw, d->n_nets > 0 ? " (nets side by side)" : "", d->n_hidden, K, act);
         arch = &g_lform_arch;
         lform = true;
     }
@@ -1300,7 +1333,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     int lw_off[EH_MAX_HIDDEN + 1], lb_off[EH_MAX_HIDDEN + 1];     // canonical offsets of net 0 (all there is for SingleNN)
     int off = 0;
-    for (int k = 0; k < n_nets; ++k) {
+    for (int k = 0; k < (no_nn ? 0 : n_nets); ++k) {
         int in = net_P[k];
         for (int l = 0; l <= nl; ++l) {
             const int o = l < nl ? net_w[k][l] : net_K[k];
@@ -1314,13 +1347,20 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     n.g_off = off;
     n.n_theta = off + G;
-    if (lform) {              // Dense layers of the one network: shapes and canonical offsets
-        h->l_nl = nl + 1;
-        int in = d->n_predictors, o2 = 0;
-        for (int l = 0; l <= nl; ++l) {
-            const int o = l < nl ? d->hidden[l] : K;
-            h->l_in[l] = in; h->l_out[l] = o; h->l_woff[l] = o2; h->l_boff[l] = o2 + o * in;
-            o2 += o * in + o; in = o;
+    if (lform && !no_nn) {    // Dense layers of every network: shapes and canonical offsets (no network: l_nnets stays 0)
+        h->l_nnets = n_nets;
+        int o2 = 0, c0 = 0;
+        for (int k = 0; k < n_nets; ++k) {
+            eh_handle_s::LNet& L = h->l_net[k];
+            L.nl = net_d[k] + 1; L.c0 = c0; L.orow = d->n_nets > 0 ? k : 0;
+            L.act = (d->n_nets > 0 && d->activation == EH_ACT_PER_NET) ? d->net_activation[k] : (act == EH_ACT_PER_NET ? d->activation : act);
+            int in = net_P[k];
+            for (int l = 0; l < L.nl; ++l) {
+                const int o = l + 1 < L.nl ? net_w[k][l] : net_K[k];
+                L.in[l] = in; L.out[l] = o; L.woff[l] = o2; L.boff[l] = o2 + o * in;
+                o2 += o * in + o; in = o;
+            }
+            c0 += net_P[k];
         }
     }
     h->act = act; n.scale_nn = d->scale_nn_outputs ? 1 : 0;
@@ -1400,12 +1440,14 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->tcount, 3 * EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMemset(h->tcount, 0, 3 * EH_MAX_TARG * sizeof(float)));
-    HIPCHK_C(hipMalloc(&h->inv_n, 8 * sizeof(float)));      // per-target 1/n (T > 1), or [1, -, -, -, k0, k1, k2, loss] of a moment-based loss
+    HIPCHK_C(hipMalloc(&h->inv_n, EH_TT * EH_MAX_TARG * sizeof(float)));      // the per-target table (EhStepArgs::inv_n): weight, centre of yhat, k0 k1 k2, loss of every target
+    HIPCHK_C(hipMemset(h->inv_n, 0, EH_TT * EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
     if (!lform) { if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; } }
     else {
         std::vector<unsigned char> wf((size_t)n.n_theta, 0);
-        for (int l = 0; l < h->l_nl; ++l) std::fill(wf.begin() + h->l_woff[l], wf.begin() + h->l_boff[l], (unsigned char)1);
+        for (int k = 0; k < h->l_nnets; ++k)
+            for (int l = 0; l < h->l_net[k].nl; ++l) std::fill(wf.begin() + h->l_net[k].woff[l], wf.begin() + h->l_net[k].boff[l], (unsigned char)1);
         HIPCHK_C(hipMalloc(&h->wflag, wf.size()));
         HIPCHK_C(hipMemcpy(h->wflag, wf.data(), wf.size(), hipMemcpyHostToDevice));
     }
@@ -1417,7 +1459,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
             img0[arch->phi_off + EH_IMG_SC + j] = d->param_upper[j] - d->param_lower[j];
         }
         for (int p = 0; p < 32; ++p) { img0[arch->phi_off + EH_IMG_BNM + p] = 0.0f; img0[arch->phi_off + EH_IMG_BNR + p] = d->input_batchnorm ? 1.0f / std::sqrt(1.0f + EH_BN_EPS) : 1.0f; }
-        for (int k = 0; k < n_nets; ++k)                    // identity blocks that carry a shallower net to the output layer
+        for (int k = 0; k < (lform ? 0 : n_nets); ++k)      // identity blocks that carry a shallower net to the output layer (fused envelope only: the layer-wise form runs every net at its own depth)
             for (int l = net_d[k]; l < nl; ++l)
                 for (int i = 0; i < net_w[k][l]; ++i)
                     img0[arch->wh_off + (size_t)(l - 1) * arch->hp * arch->sh + (size_t)(h->net_r0[k][l] + i) * arch->sh + h->net_r0[k][l - 1] + i] = 1.0f;
@@ -1437,7 +1479,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMemset(h->l2val, 0, sizeof(float)));
         {
             int nw = 0;
-            if (lform) for (int l = 0; l < h->l_nl; ++l) nw += h->l_in[l] * h->l_out[l];
+            if (lform) { for (int k = 0; k < h->l_nnets; ++k) for (int l = 0; l < h->l_net[k].nl; ++l) nw += h->l_net[k].in[l] * h->l_net[k].out[l]; }
             else for (const EhEntry& e : enumerate_entries(h)) nw += e.col >= 0 ? 1 : 0;
             h->n_weights = nw;
         }
@@ -1451,7 +1493,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipStreamSynchronize(h->stream));
     }
 #undef HIPCHK_C
-    if (h->act == EH_ACT_PER_NET && !jit_entry(h)) {         // built now, so that a missing run-time compiler is an error of the constructor
+    if (h->act == EH_ACT_PER_NET && !h->lform && !jit_entry(h)) {         // built now, so that a missing run-time compiler is an error of the constructor
         const std::string log = h->jit_log;
         eh_destroy(h);
         return fail(nullptr, EH_EUNSUPPORTED, "eh_create: per-net activations need the run-time compiled kernel, which failed to build: %.600s", log.c_str());
@@ -1541,17 +1583,29 @@ int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
     if (n != h->net.T) return fail(h, EH_EINVAL, "eh_set_target_losses: %d losses for %d targets", n, h->net.T);
     unsigned lt = 0;
     bool same = true;
+    bool any_prog = false, any_two = false;
     for (int t = 0; t < n; ++t) {
-        if (kinds[t] != EH_LOSS_MSE && kinds[t] != EH_LOSS_MAE && kinds[t] != EH_LOSS_NSELOSS && !(n == 1 && kinds[t] == EH_LOSS_RMSE))
-            return fail(h, EH_EUNSUPPORTED, "eh_set_target_losses: loss %d for target %d (per target: mse, mae, nseLoss)", kinds[t], t);
+        if (kinds[t] < EH_LOSS_MSE || kinds[t] > EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_set_target_losses: loss %d for target %d is not implemented on the device", kinds[t], t);
         lt |= (unsigned)kinds[t] << (4 * t);
         same = same && kinds[t] == kinds[0];
+        any_prog = any_prog || kinds[t] == EH_LOSS_PROGRAM;
+        any_two = any_two || (kinds[t] >= EH_LOSS_PEARSONLOSS && kinds[t] <= EH_LOSS_PBKGELOSS) || (kinds[t] == EH_LOSS_RMSE && n > 1);
     }
     if (same) return eh_set_option(h, "training_loss", kinds[0]);
+    if (any_prog && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "eh_set_target_losses: EH_LOSS_PROGRAM: call eh_set_loss_program first");
+    if (any_prog && h->lform) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) has no run-time compiled kernels: a recorded loss function needs a model the fused kernels hold");
+    if (any_two && h->fused) return fail(h, EH_EUNSUPPORTED, "rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step: switch fused_update off first");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
-    h->net.loss = EH_LOSS_MSE;               // (what the single-kind code paths read; the kernels take the per-target kinds from loss_t)
+    // (what the single-kind code paths read -- the run-time compiler's "is there a recorded loss", the deferred normalisation of
+    //  single-target steps; the kernels take every target's kind from loss_t)
+    h->net.loss = any_prog ? EH_LOSS_PROGRAM : EH_LOSS_MSE;
     h->net.loss_t = lt;
+    {   // two-pass losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
+        const int want = h->lform ? 0 : fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech);
+        const int fast = any_two ? 0 : (want & h->fast_user);
+        if (!h->lform && fast != h->fast) { h->fast = fast; return build_maps(h, false); }
+    }
     return EH_OK;
 }
 
@@ -1598,7 +1652,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         return build_maps(h, false);
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
-        if (value && h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "fused_update: pearson / kge training losses take two passes per step");
+        if (value && two_pass_mask(h->net)) return fail(h, EH_EUNSUPPORTED, "fused_update: rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step");
         if (value && h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
@@ -1610,18 +1664,17 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "training_loss")) {
         if (value < EH_LOSS_MSE || value > EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
         if (value == EH_LOSS_PROGRAM && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
-        if (h->net.T != 1 && value != EH_LOSS_MSE && value != EH_LOSS_MAE && value != EH_LOSS_NSELOSS)
-            return fail(h, EH_EUNSUPPORTED, "multi-target models train on mse / mae / nseLoss (per target: eh_set_target_losses); the others need a single-target model");
-        if (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS && h->fused) return fail(h, EH_EUNSUPPORTED, "pearson / kge training losses take two passes per step: switch fused_update off first");
-        if (h->lform && value >= EH_LOSS_PEARSONLOSS) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) implements the one-pass training losses mse / rmse / mae / nseLoss");
+        const bool two = (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS) || (value == EH_LOSS_RMSE && h->net.T > 1);
+        if (two && h->fused) return fail(h, EH_EUNSUPPORTED, "rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step: switch fused_update off first");
+        if (h->lform && value == EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) has no run-time compiled kernels: a recorded loss function needs a model the fused kernels hold");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->net.loss = (int)value;
         h->net.loss_t = 0;
         for (int t = 0; t < h->net.T; ++t) h->net.loss_t |= (unsigned)value << (4 * t);
-        {   // the moment-based losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
+        if (!h->lform) {   // the two-pass losses exist in the generic kernels only (the K == 1 / P <= 4 fast paths stay untouched by them)
             const int want = fast_wanted(h->arch, h->net.K, h->net.P, h->net.T, h->net.mech);
-            const int fast = (value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
+            const int fast = (two || value >= EH_LOSS_PEARSONLOSS) ? 0 : (want & h->fast_user);
             if (fast != h->fast) { h->fast = fast; return build_maps(h, false); }
         }
         return EH_OK;
@@ -1688,7 +1741,7 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
     if (!h) return EH_EINVAL;
     if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_set_data: split %d", split);
     if (n < 0 || n > 0x7fffffffLL) return fail(h, EH_EINVAL, "eh_set_data: n = %lld", (long long)n);
-    if (n > 0 && (!x || !forcings || !targets)) return fail(h, EH_EINVAL, "eh_set_data: null array");
+    if (n > 0 && ((!x && h->net.P > 0) || !forcings || !targets)) return fail(h, EH_EINVAL, "eh_set_data: null array");
     const EhNet& net = h->net;
     HIPCHK(h, hipSetDevice(h->device));
     EhSplit& sp = h->split[split];
@@ -1789,10 +1842,14 @@ static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long
 }
 
 // ---- layer-wise execution form (eh_lform.hpp) ---------------------------------------------------------------------------
-struct EhLWs { float *Xb, *H[EH_MAX_HIDDEN], *D[2], *O, *part; long long ldo; };
+struct EhLWs { float *Xb, *H[EH_MAX_NETS][EH_MAX_HIDDEN], *Z[EH_MAX_NETS][EH_MAX_HIDDEN], *D[2], *O, *part; long long ldo; };
 static long long lform_floats_per_sample(const eh_handle* h) {
     long long w = h->net.P + 16, maxw = 0;
-    for (int l = 0; l + 1 < h->l_nl; ++l) { w += h->l_out[l]; maxw = std::max<long long>(maxw, h->l_out[l]); }
+    for (int k = 0; k < h->l_nnets; ++k)
+        for (int l = 0; l + 1 < h->l_net[k].nl; ++l) {
+            w += h->l_net[k].out[l] * (h->l_net[k].act == EH_ACT_SWISH ? 2 : 1);      // swish keeps the pre-activation too
+            maxw = std::max<long long>(maxw, h->l_net[k].out[l]);
+        }
     return w + 2 * maxw;
 }
 static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
@@ -1807,9 +1864,15 @@ static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
     const long long cap = h->l_cap;
     float* p = h->l_ws;
     long long maxw = 0;
-    for (int l = 0; l + 1 < h->l_nl; ++l) maxw = std::max<long long>(maxw, h->l_out[l]);
     W->Xb = p; p += cap * h->net.P;
-    for (int l = 0; l + 1 < h->l_nl; ++l) { W->H[l] = p; p += cap * h->l_out[l]; }
+    for (int k = 0; k < h->l_nnets; ++k)
+        for (int l = 0; l + 1 < h->l_net[k].nl; ++l) {
+            const long long o = h->l_net[k].out[l];
+            maxw = std::max(maxw, o);
+            W->H[k][l] = p; p += cap * o;
+            W->Z[k][l] = nullptr;
+            if (h->l_net[k].act == EH_ACT_SWISH) { W->Z[k][l] = p; p += cap * o; }
+        }
     W->D[0] = p; p += cap * maxw;
     W->D[1] = p; p += cap * maxw;
     W->O = p; p += cap * 16; W->ldo = cap;
@@ -1845,6 +1908,7 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
 static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool train_mode, bool bn_update, const EhLWs& W) {
     const EhNet& net = h->net;
     const int B = (int)count;
+    if (h->l_nnets == 0) return EH_OK;        // no network (no neural parameter): the mechanistic stage reads the records itself
     EhStepArgs bn{};
     if (train_mode) { if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &bn)) return rc; }
     EhLPrepArgs pa{};
@@ -1854,17 +1918,29 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
     hipLaunchKernelGGL(eh_lform_prep_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa);
     HIPCHK(h, hipGetLastError());
     const float* theta = TH(h);
-    for (int l = 0; l < h->l_nl; ++l) {
-        EhGemmArgs g{};
-        g.A = l == 0 ? W.Xb : W.H[l - 1]; g.lda = h->l_in[l];
-        g.B = theta + h->l_woff[l]; g.ldb = h->l_out[l];                 // canonical (out, in) column-major == [in][out] row-major
-        g.M = B; g.N = h->l_out[l]; g.K = h->l_in[l]; g.kchunk = g.K; g.c_zstride = 0;
-        g.bias = theta + h->l_boff[l]; g.act = h->act;
-        if (l + 1 < h->l_nl) { g.C = W.H[l]; g.ldc = h->l_out[l]; lform_gemm<false, false, EH_GEPI_BIAS_ACT>(h, g, 1); }
-        else { g.C = W.O; g.ldc = W.ldo; lform_gemm<false, false, EH_GEPI_BIAS_T>(h, g, 1); }
-        HIPCHK(h, hipGetLastError());
+    for (int k = 0; k < h->l_nnets; ++k) {
+        const eh_handle_s::LNet& L = h->l_net[k];
+        for (int l = 0; l < L.nl; ++l) {
+            EhGemmArgs g{};
+            g.A = l == 0 ? W.Xb + L.c0 : W.H[k][l - 1]; g.lda = l == 0 ? net.P : L.in[l];      // (a network's predictors: its columns of the minibatch matrix)
+            g.B = theta + L.woff[l]; g.ldb = L.out[l];                   // canonical (out, in) column-major == [in][out] row-major
+            g.M = B; g.N = L.out[l]; g.K = L.in[l]; g.kchunk = g.K; g.c_zstride = 0;
+            g.bias = theta + L.boff[l]; g.act = L.act;
+            if (l + 1 < L.nl) { g.C = W.H[k][l]; g.ldc = L.out[l]; g.Z = W.Z[k][l]; lform_gemm<false, false, EH_GEPI_BIAS_ACT>(h, g, 1); }
+            else { g.C = W.O + (long long)L.orow * W.ldo; g.ldc = W.ldo; lform_gemm<false, false, EH_GEPI_BIAS_T>(h, g, 1); }
+            HIPCHK(h, hipGetLastError());
+        }
     }
     return EH_OK;
+}
+// targets whose training loss takes two forward passes ahead of the training pass (batch statistics of yhat): bit t
+static unsigned two_pass_mask(const EhNet& net) {
+    unsigned m = 0;
+    for (int t = 0; t < net.T; ++t) {
+        const unsigned k = (net.loss_t >> (4 * t)) & 15u;
+        if ((k >= (unsigned)EH_LOSS_PEARSONLOSS && k <= (unsigned)EH_LOSS_PBKGELOSS) || (k == (unsigned)EH_LOSS_RMSE && net.T > 1)) m |= 1u << t;
+    }
+    return m;
 }
 // one training step's gradient sums into `rows` partial slab rows (the contract of the fused step kernels: eh_reduce_kernel follows)
 static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* rows_out, bool bn_update) {
@@ -1887,8 +1963,27 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     if (int rc = lform_forward(h, sp, idx, first, count, true, bn_update, W)) return rc;
     EhStepArgs a{};
     a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
-    a.inv_n = net.T > 1 ? h->inv_n : nullptr;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
+    const unsigned tpm = two_pass_mask(net);
+    if (tpm) {
+        // losses that need batch statistics of yhat (see launch_train_kernel): the NN outputs O stay where the forward left them, so
+        // the two statistics passes are two runs of the mechanistic stage alone (eval form), not two forwards
+        EhStepArgs e = a;
+        e.inv_n = nullptr; e.yld = count;
+        const int egrid = (int)std::min<long long>(256, (count + 255) / 256);
+        EhLMechArgs me{W.O, W.ldo, h->slab};                   // [egrid][EH_EVAL_STATS * T] (the slab is rewritten by the training pass afterwards)
+        EhShift4 s4; for (int t = 0; t < EH_MAX_TARG; ++t) s4.c[t] = sp.shift[t];
+        for (int pass = 0; pass < 2; ++pass) {
+            if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<false, true>), dim3(egrid), dim3(256), 0, h->stream, net, e, me, h->image);
+            else hipLaunchKernelGGL((eh_lform_mech_kernel<false, false>), dim3(egrid), dim3(256), 0, h->stream, net, e, me, h->image);
+            HIPCHK(h, hipGetLastError());
+            if (pass == 0) hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
+            else hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
+            HIPCHK(h, hipGetLastError());
+            e.inv_n = h->inv_n;
+        }
+    }
+    a.inv_n = (net.T > 1 || tpm) ? h->inv_n : nullptr;
     EhLMechArgs m{W.O, W.ldo, W.part};
     const int mgrid = (int)std::min<long long>(2048, (count + 255) / 256);
     if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
@@ -1896,28 +1991,32 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     HIPCHK(h, hipGetLastError());
     hipLaunchKernelGGL(eh_lform_tail_kernel, dim3(1), dim3(256), 0, h->stream, W.part, mgrid, net, h->slab, rows, (long long)h->n_acc);
     HIPCHK(h, hipGetLastError());
-    // backward, from the output layer down; dZ of the output layer = d loss / d O^T, still [K][ldo]
+    // backward, every network from its output layer down; dZ of the output layer = its rows of d loss / d O^T, still [K][ldo]
     const float* theta = TH(h);
-    const float* dZ = W.O;
-    bool dz_t = true;                          // dZ stored transposed ([out][B])
-    int which = 0;
-    for (int l = h->l_nl - 1; l >= 0; --l) {
-        const int in = h->l_in[l], out = h->l_out[l];
-        const float* Hprev = l == 0 ? W.Xb : W.H[l - 1];
-        EhGemmArgs g{};                        // dW_l^T [in x out] = Hprev^T [in x B] * dZ_l [B x out], split over the samples
-        g.A = Hprev; g.lda = in; g.B = dZ; g.ldb = dz_t ? W.ldo : out;
-        g.C = h->slab + h->l_woff[l]; g.ldc = out; g.M = in; g.N = out; g.K = B; g.kchunk = chunk; g.c_zstride = h->n_acc;
-        g.colsum = h->slab + h->l_boff[l];       // db_l = column sums of dZ_l, from the same tiles
-        if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
-        HIPCHK(h, hipGetLastError());
-        if (l > 0) {                           // dZ_{l-1} [B x in] = (dZ_l [B x out] * W_l [out x in]) .* act'(H_{l-1})
-            EhGemmArgs b{};
-            b.A = dZ; b.lda = dz_t ? W.ldo : out; b.B = theta + h->l_woff[l]; b.ldb = out;        // W_l element (k = out, n = in) at n * out + k
-            b.C = W.D[which]; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
-            b.H = Hprev; b.ldh = in; b.act = h->act;
-            if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
+    for (int k = 0; k < h->l_nnets; ++k) {
+        const eh_handle_s::LNet& L = h->l_net[k];
+        const float* dZ = W.O + (long long)L.orow * W.ldo;
+        bool dz_t = true;                      // dZ stored transposed ([out][B])
+        int which = 0;
+        for (int l = L.nl - 1; l >= 0; --l) {
+            const int in = L.in[l], out = L.out[l];
+            const float* Hprev = l == 0 ? W.Xb + L.c0 : W.H[k][l - 1];
+            const long long ldp = l == 0 ? net.P : in;
+            EhGemmArgs g{};                    // dW_l^T [in x out] = Hprev^T [in x B] * dZ_l [B x out], split over the samples
+            g.A = Hprev; g.lda = ldp; g.B = dZ; g.ldb = dz_t ? W.ldo : out;
+            g.C = h->slab + L.woff[l]; g.ldc = out; g.M = in; g.N = out; g.K = B; g.kchunk = chunk; g.c_zstride = h->n_acc;
+            g.colsum = h->slab + L.boff[l];      // db_l = column sums of dZ_l, from the same tiles
+            if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
             HIPCHK(h, hipGetLastError());
-            dZ = W.D[which]; dz_t = false; which ^= 1;
+            if (l > 0) {                       // dZ_{l-1} [B x in] = (dZ_l [B x out] * W_l [out x in]) .* act'(H_{l-1})  (swish: act' from the stored Z_{l-1})
+                EhGemmArgs b{};
+                b.A = dZ; b.lda = dz_t ? W.ldo : out; b.B = theta + L.woff[l]; b.ldb = out;        // W_l element (k = out, n = in) at n * out + k
+                b.C = W.D[which]; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
+                b.H = L.act == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.act;
+                if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
+                HIPCHK(h, hipGetLastError());
+                dZ = W.D[which]; dz_t = false; which ^= 1;
+            }
         }
     }
     return EH_OK;
@@ -1957,7 +2056,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
         HIPCHK(h, hipGetLastError());
     }
-    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS;
+    const bool moment_loss = two_pass_mask(net) != 0;
     if (moment_loss) {
         // forward-only passes (train-mode BatchNorm statistics included): the batch mean of yhat, then the moments of
         // (yhat, y) about the means -> the coefficients of the per-sample d loss / d yhat that the training pass multiplies
@@ -1971,11 +2070,12 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
         const int egrid = count > 0 ? grid_for(h, count) : 1;
         HIPCHK(h, step_launch(h, EH_MODE_EVAL, egrid, &e));       // -> mean of yhat
-        hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, sp.shift[0], h->inv_n);
+        EhShift4 s4; for (int t = 0; t < EH_MAX_TARG; ++t) s4.c[t] = sp.shift[t];
+        hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
         HIPCHK(h, hipGetLastError());
         e.inv_n = h->inv_n;                                                                                               // -> moments about it
         HIPCHK(h, step_launch(h, EH_MODE_EVAL, egrid, &e));
-        hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, net.loss, sp.shift[0], h->inv_n);
+        hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
         HIPCHK(h, hipGetLastError());
     }
     EhStepArgs a{};
@@ -2060,7 +2160,8 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     if (rc) return rc;
     if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
-    const bool moment_loss = net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS;
+    const unsigned tp_mask = two_pass_mask(net);
+    const bool moment_loss = tp_mask != 0;
     const bool l2 = h->img.l2c != 0.0f && !raw;      // (data-parallel seam: raw sums only -- the extra loss is added once, in eh_dp_apply)
     if (l2) {
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
@@ -2073,7 +2174,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
 #define EH_REDUCE_GO(AP, CW_)                                                                                                                       \
     hipLaunchKernelGGL((eh_reduce_kernel<AP, CW_>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
-                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr)
+                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)
     if (apply) {
         if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
@@ -2211,6 +2312,7 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
                          const int64_t* n_valid_in, float* d_o_dev, float* yhat_dev, float* loss, float* grad_global, int64_t* n_valid) {
     if (!h || !o_dev || !forcings_dev || !targets_dev || !d_o_dev) return EH_EINVAL;
     const EhNet& net = h->net;
+    if (net.K == 0) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: the model has no neural parameter (no NN outputs to differentiate by): eh_loss_and_grad / eh_train_step run it whole");
     if (net.loss != EH_LOSS_MSE && net.loss != EH_LOSS_MAE) return fail(h, EH_EUNSUPPORTED, "eh_mech_loss_vjp: training loss %d (built: mse, mae)", net.loss);
     if (count < 1 || ld < count) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: count %lld, ld %lld", (long long)count, (long long)ld);
     for (int f = 0; f < net.F; ++f) if (!forcings_dev[f]) return fail(h, EH_EINVAL, "eh_mech_loss_vjp: forcing %d is null", f);
@@ -2561,7 +2663,7 @@ int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1 && !h->tcount_ready) return fail(h, EH_ESTATE, "eh_dp_grad: multi-target model: call eh_dp_counts for this window and all-reduce EH_BUF_TCOUNT first");
-    if (h->net.loss >= EH_LOSS_PEARSONLOSS && h->net.loss <= EH_LOSS_PBKGELOSS) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: pearson / kge training losses need the moments of the GLOBAL batch first (not built)");
+    if (two_pass_mask(h->net)) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: rmse (multi-target) / pearson / kge training losses need the statistics of the GLOBAL batch's predictions first (not built)");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     h->bn_dp_update = h->bn_on;
     HIPCHK(h, hipSetDevice(h->device));

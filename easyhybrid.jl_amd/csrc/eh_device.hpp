@@ -49,6 +49,17 @@ struct EhNet {
     unsigned loss_t;                 // 4 bits per target: its training loss (eh_loss; PerTarget, src/losses/compute_loss.jl:128-145).  One target: == loss.
 };
 __device__ __forceinline__ bool eh_target_mae(unsigned loss_t, int t) { return ((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_MAE; }
+__device__ __forceinline__ bool eh_target_prog(unsigned loss_t, int t) { return ((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_PROGRAM; }
+// losses whose d loss / d yhat_i needs batch statistics of yhat: pearson / kge / pbkge (loss_fn.jl:75-77,105-174), and rmse where its
+// scale cannot be applied after the pass (multi-target models).  Two forward passes leave, per target, the coefficients of
+// d loss / d yhat_i = k0 + k1 (yhat_i - centre) + k2 (y_i - shift) in the per-target table (eh_moment_coef_kernel).
+__device__ __forceinline__ bool eh_target_two_pass(unsigned loss_t, int t, int T) {
+    const unsigned k = (loss_t >> (4 * t)) & 15u;
+    return (k >= (unsigned)EH_LOSS_PEARSONLOSS && k <= (unsigned)EH_LOSS_PBKGELOSS) || (k == (unsigned)EH_LOSS_RMSE && T > 1);
+}
+// EhStepArgs::inv_n is a table of EH_TT floats per target: [0] weight of the target's residual terms (1 / n_t, 1 / sum (y - ybar)^2)
+// [1] centre of yhat (two-pass losses)  [4] k0  [5] k1  [6] k2  [7] the target's loss value (two-pass losses)
+enum { EH_TT = 8 };
 // Per-layer offsets / widths and the (lower, upper-lower) table travel in the parameter image
 // (EhGeom::PHI_OFF block) instead of the kernarg: they are read from LDS where they are used,
 // which keeps them out of the scalar register file during the tile loop.
@@ -138,7 +149,7 @@ struct EhStepArgs {
     const float* image;   // padded parameter image (EhGeom layout, IMG_FLOATS floats)
     float* slab;          // [gridDim.x][n_acc] per-workgroup partials
     int n_acc;            // train: n_theta + 1 + T ; eval: EH_EVAL_STATS*T
-    const float* inv_n;   // train: per-target 1/n_t (device) or nullptr = deferred normalisation (weight 1)
+    const float* inv_n;   // train: the per-target table ([EH_TT] floats per target, see EH_TT) or nullptr = deferred normalisation (weight 1)
     float* yhat;          // eval (optional): [T][yld] predictions for samples first..first+count
     const int* rmap;      // train: canonical index -> (position | lanes<<24) among the parked accumulators (v2 / v3 workgroup reduction; row-split staging)
     float* pout;          // eval (optional): [n_par][yld] physical parameters per sample
@@ -643,7 +654,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     // (the wave index as a SCALAR: derived from threadIdx it counts as divergent, and every loop / branch on it -- the tile loop
     //  first of all -- would run under an exec mask with saved / restored mask pairs instead of scalar branches)
+#ifdef EH_AB_VECTOR_WAVE_INDEX
+    const int wave = tid >> 6;                               // (diagnostic A/B: the round-1 form)
+#else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     float* const ws = smem + G::IMG_FLOATS + wave * G::WAVE_WS;
     float* const XS = ws + G::XS_OFF;
     float* const HS = ws + G::HS_OFF;
@@ -683,9 +698,12 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         fCol[f] = col == 0xFFu ? -1 : (int)(net.P + col);
         EH_PIN("+v"(fCol[f]));
     }
-    float maeT[EH_MAX_TARG];
+    float maeT[EH_MAX_TARG], twoT[EH_MAX_TARG];
 #pragma unroll
-    for (int t = 0; t < EH_MAX_TARG; ++t) { maeT[t] = eh_target_mae(net.loss_t, t) ? 1.0f : 0.0f; EH_PIN("+v"(maeT[t])); }
+    for (int t = 0; t < EH_MAX_TARG; ++t) {
+        maeT[t] = eh_target_mae(net.loss_t, t) ? 1.0f : 0.0f; twoT[t] = eh_target_two_pass(net.loss_t, t, net.T) ? 1.0f : 0.0f;
+        EH_PIN("+v"(maeT[t]), "+v"(twoT[t]));
+    }
     EH_PIN("+v"(sclOn));
     const int tcol0 = net.P + net.F;
 
@@ -1113,20 +1131,21 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     const bool valid = live && !__builtin_isnan(yobs[t]);
                     const float r = valid ? y - yobs[t] : 0.0f;
                     if constexpr (TRAIN) {
-                        const float w = a.inv_n ? a.inv_n[t] : 1.0f;
+                        const float* const tt = a.inv_n + EH_TT * t;
+                        const float w = a.inv_n ? tt[0] : 1.0f;
                         const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                         float d;
                         if (maeT[t] != 0.0f) { lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
 #ifdef EH_JIT_LOSS
-                        else if (net.loss == EH_LOSS_PROGRAM) {
+                        else if (eh_target_prog(net.loss_t, t)) {
                             float dl;
                             const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
                             lacc += valid ? w * lv : 0.0f;
                             d = valid ? w * dl : 0.0f;
                         }
 #endif
-                        else if ((FAST & 3) == 0 && net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS) {      // pearson / kge losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - c) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
-                            d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
+                        else if ((FAST & 3) == 0 && twoT[t] != 0.0f) {      // two-pass losses (generic kernels only: the host drops the fast paths for them): d loss / d yhat = k0 + k1 (yhat - centre) + k2 (y - c), k from the batch moments (eh_moment_coef_kernel)
+                            d = valid ? fmaf(tt[6], cy, fmaf(tt[5], y - tt[1], tt[4])) : 0.0f;
                         }
                         else { lacc += w * r * r; d = 2.0f * w * r; }
                         dy += tOut[t] == 0 ? d : 0.0f; dyx[0] += tOut[t] == 1 ? d : 0.0f; dyx[1] += tOut[t] == 2 ? d : 0.0f;
@@ -1135,7 +1154,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     } else if (valid) {
                         // (moment pass of the pearson / kge losses: yhat is centred on ITS OWN mean, found by a first pass --
                         // a common centre would cancel catastrophically when the predictions sit far from the targets)
-                        const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[1] : a.shift[t]);
+                        const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[EH_TT * t + 1] : a.shift[t]);
                         est[t][0] += r * r; est[t][1] += cy; est[t][2] += cy * cy; est[t][3] += 1.0f;
                         est[t][4] += ch; est[t][5] += ch * ch; est[t][6] += ch * cy; est[t][7] += fabsf(r);
                     }

@@ -311,7 +311,11 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
         while (at < d.size()) {
             size_t e = d.find(' ', at);
             if (e == std::string::npos) e = d.size();
-            if (e > at) src += "#define " + d.substr(at, e - at) + " 1\n";
+            if (e > at) {                                     // NAME -> #define NAME 1 ; NAME=VALUE -> #define NAME VALUE
+                std::string tok = d.substr(at, e - at);
+                const size_t eq = tok.find('=');
+                src += eq == std::string::npos ? "#define " + tok + " 1\n" : "#define " + tok.substr(0, eq) + " " + tok.substr(eq + 1) + "\n";
+            }
             at = e + 1;
         }
     }
@@ -341,7 +345,15 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
                       (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
         hiprtcAddNameExpression(hp, name[m]);
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17"};      // (the flags of the Makefile: see there for -fno-slp-vectorize)
+    // The flags of the Makefile, with one exception.  -fno-slp-vectorize is there because the SLP vectoriser miscompiled ONE group of
+    // kernels (P <= 4 ReLU on shapes wider than one 16-row block: a loss sum lost in a packed accumulator); it
+    // also costs the narrow nets 4 % -- the headline step 10.14 -> 9.73 us with the vectoriser on, A/B on one lease against the
+    // round-1 library (9.66), profiles/r03/headline_ab.txt.  The one-block shapes (NBH = 1) never showed the bug -- round 1 ran its
+    // whole suite and 3 600 fuzz configurations on them with the vectoriser on -- so their run-time kernels get it back; every
+    // other shape, and everything built ahead of time, stays without.  EH_JIT_SLP=0 / 1 overrides (diagnostics).
+    const char* const slp_env = getenv("EH_JIT_SLP");
+    const bool slp_on = slp_env ? atoi(slp_env) != 0 : (A->nbh == 1 && !A->wide);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", slp_on ? "-fslp-vectorize" : "-fno-slp-vectorize", "-std=c++17"};
     // ---- cached code object?
     std::string cpath;
     {

@@ -31,6 +31,7 @@ struct EhGemmArgs {
     const float* bias;                   // EH_GEPI_BIAS_*: [N]
     const float* H; long long ldh;       // EH_GEPI_DACT: stored activations, same shape as C
     int act;                             // eh_activation of the epilogue
+    float* Z;                            // EH_GEPI_BIAS_ACT, nullable: the pre-activation, same layout as C (swish: act' needs it, the rounded h does not give it back)
     float* colsum;                       // (split-K weight gradients) nullable: colsum[z * c_zstride + n] = sum over the k chunk of B[k][n] -- the bias gradient,
                                          // taken from the B tiles the first row of workgroups stages anyway
 };
@@ -40,11 +41,13 @@ __device__ __forceinline__ float eh_act_rt(int act, float z) {
         case EH_ACT_TANH: return eh_tanh(z);
         case EH_ACT_SIGMOID: return eh_sigmoid(z);
         case EH_ACT_RELU: return fmaxf(z, 0.0f);
+        case EH_ACT_SWISH: return z * eh_sigmoid(z);
         default: return z;
     }
 }
-__device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' from the stored activation
+__device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' from the stored activation (swish: from the stored PRE-activation, EhGemmArgs::Z)
     switch (act) {
+        case EH_ACT_SWISH: { const float sg = eh_sigmoid(h); return sg * (1.0f + h * (1.0f - sg)); }
         case EH_ACT_TANH: return 1.0f - h * h;
         case EH_ACT_SIGMOID: return h * (1.0f - h);
         case EH_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmA
                 const int m = m0 + wm * WT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < g.M && n < g.N) {
                     float v = acc[i][j][r];
-                    if (EPI == EH_GEPI_BIAS_ACT) v = eh_act_rt(g.act, v + bv);
+                    if (EPI == EH_GEPI_BIAS_ACT) { v += bv; if (g.Z) g.Z[(long long)m * g.ldc + n] = v; v = eh_act_rt(g.act, v); }
                     else if (EPI == EH_GEPI_BIAS_T) v += bv;
                     else if (EPI == EH_GEPI_DACT) v *= eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
                     if (EPI == EH_GEPI_BIAS_T) C[(long long)n * g.ldc + m] = v;

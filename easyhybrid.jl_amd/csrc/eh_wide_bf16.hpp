@@ -153,27 +153,28 @@ __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepA
             const bool valid = live && !__builtin_isnan(yobs[t]);
             const float r = valid ? y - yobs[t] : 0.0f;
             if constexpr (TRAIN) {
-                const float w = a.inv_n ? a.inv_n[t] : 1.0f;
+                const float* const tt = a.inv_n + EH_TT * t;
+                const float w = a.inv_n ? tt[0] : 1.0f;
                 const float cy = valid ? yobs[t] - a.shift[t] : 0.0f;
                 float d;
                 if (eh_target_mae(net.loss_t, t)) { A.lacc += w * fabsf(r); d = r > 0.0f ? w : (r < 0.0f ? -w : 0.0f); }
 #ifdef EH_JIT_LOSS
-                else if (net.loss == EH_LOSS_PROGRAM) {
+                else if (eh_target_prog(net.loss_t, t)) {
                     float dl;
                     const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
                     A.lacc += valid ? w * lv : 0.0f;
                     d = valid ? w * dl : 0.0f;
                 }
 #endif
-                else if (net.loss >= EH_LOSS_PEARSONLOSS && net.loss <= EH_LOSS_PBKGELOSS) {      // moment-based losses (see eh_step_kernel)
-                    d = valid ? fmaf(a.inv_n[6], cy, fmaf(a.inv_n[5], y - a.inv_n[1], a.inv_n[4])) : 0.0f;
+                else if (eh_target_two_pass(net.loss_t, t, net.T)) {      // two-pass losses (see eh_step_kernel)
+                    d = valid ? fmaf(tt[6], cy, fmaf(tt[5], y - tt[1], tt[4])) : 0.0f;
                 }
                 else { A.lacc += w * r * r; d = 2.0f * w * r; }
                 dy += ot == 0 ? d : 0.0f; dyx[0] += ot == 1 ? d : 0.0f; dyx[1] += ot == 2 ? d : 0.0f;
                 A.cacc[t] += valid ? 1.0f : 0.0f;
                 A.syacc += cy; A.syyacc += cy * cy;
             } else if (valid) {
-                const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[1] : a.shift[t]);      // see eh_step_kernel
+                const float cy = yobs[t] - a.shift[t], ch = y - (a.inv_n ? a.inv_n[EH_TT * t + 1] : a.shift[t]);      // see eh_step_kernel
                 A.est[t][0] += r * r; A.est[t][1] += cy; A.est[t][2] += cy * cy; A.est[t][3] += 1.0f;
                 A.est[t][4] += ch; A.est[t][5] += ch * ch; A.est[t][6] += ch * cy; A.est[t][7] += fabsf(r);
             }

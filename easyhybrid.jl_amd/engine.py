@@ -189,9 +189,10 @@ class HybridEngine:
 
     def set_training_loss(self, name):
         """TrainConfig.training_loss (src/config/TrainingConfig.jl:64): mse | rmse | mae | nseLoss (one pass) |
-        pearsonLoss | kgeLoss | pbkgeLoss (two passes per step: batch moments first; not in fused_update mode, not data parallel),
-        or a function f(yhat, y) = mean of per-sample terms, which is recorded (program.trace_loss) and compiled into the step
-        kernel at run time."""
+        pearsonLoss | kgeLoss | pbkgeLoss (forward passes for the batch moments first; not in fused_update mode, not data parallel;
+        rmse joins them on multi-target models), or a function f(yhat, y) = mean of per-sample terms, which is recorded
+        (program.trace_loss) and compiled into the step kernel at run time.  Applied to every target like the reference does
+        (src/losses/compute_loss.jl:115-126); PerTarget((l_1, ..., l_T)) / a list gives each target its own (:128-145)."""
         if isinstance(name, PerTarget):
             name = list(name.losses)
         if isinstance(name, (list, tuple)) and name and callable(name[0]):
@@ -200,26 +201,35 @@ class HybridEngine:
             args = next((tuple(r) for r in rest if isinstance(r, (tuple, list))), ())
             kwargs = next((dict(r) for r in rest if isinstance(r, dict)), {})
             name = (lambda yh, y, _f=f, _a=args, _k=kwargs: _f(yh, y, *_a, **_k))
-        if isinstance(name, (list, tuple)):                      # PerTarget: one loss name per target (compute_loss.jl:128-145)
+        if isinstance(name, (list, tuple)):                      # PerTarget: one loss per target (compute_loss.jl:128-145)
             if len(name) != len(self.target_names):
                 raise AssertionError("Length of targets and PerTarget losses tuple must match")
+            fns = [n for n in name if callable(n)]
+            if any(f is not fns[0] for f in fns):
+                raise NotImplementedError("PerTarget: one recorded loss function per model (the step kernel is compiled around a single one)")
             for n in name:
-                if n not in L.TRAINING_LOSSES:
+                if not callable(n) and n not in L.TRAINING_LOSSES:
                     raise NotImplementedError(f"training loss {n!r} is not implemented on the device (have {sorted(L.TRAINING_LOSSES)})")
-            kinds = (C.c_int32 * len(name))(*[L.TRAINING_LOSSES[n] for n in name])
+            if fns:
+                self._set_loss_program(fns[0])
+            kinds = (C.c_int32 * len(name))(*[L.EH_LOSS_PROGRAM if callable(n) else L.TRAINING_LOSSES[n] for n in name])
             self._chk(self._lib.eh_set_target_losses(self._h, kinds, len(name)))
             return
         if callable(name):
-            from .program import trace_loss
-            pg = trace_loss(name)
-            words = (C.c_uint32 * len(pg.code))(*pg.words())
-            consts = (C.c_float * max(1, len(pg.consts)))(*pg.consts)
-            self._chk(self._lib.eh_set_loss_program(self._h, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
+            self._set_loss_program(name)
             self.set_option("training_loss", L.EH_LOSS_PROGRAM)
             return
         if name not in L.TRAINING_LOSSES:
             raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
         self.set_option("training_loss", L.TRAINING_LOSSES[name])
+
+    def _set_loss_program(self, fn):
+        """record f(yhat, y) = mean of per-sample terms (program.trace_loss) and hand it to the library (eh_set_loss_program)"""
+        from .program import trace_loss
+        pg = trace_loss(fn)
+        words = (C.c_uint32 * len(pg.code))(*pg.words())
+        consts = (C.c_float * max(1, len(pg.consts)))(*pg.consts)
+        self._chk(self._lib.eh_set_loss_program(self._h, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
 
     def set_weight_l2(self, lam: float, normalize: bool = False):
         """extra_loss = lam * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91); lam = 0 switches it off"""

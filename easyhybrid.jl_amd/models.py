@@ -219,6 +219,8 @@ class SingleNNHybridModel:
 
     @property
     def nets(self) -> List[List[Tuple[int, int]]]:
+        if not self.NN and self.NNs is None:
+            return []                  # no neural parameter: `NN = Chain()` (GenericHybridModel.jl:112-125), theta holds the raw globals only
         return [self.NN] if self.NNs is None else [self.NNs[k] for k in self.neural_param_names]
 
     @property
@@ -288,7 +290,7 @@ class SingleNNHybridModel:
         d.device = device
         d.n_predictors = len(self.predictors)
         hl = self.hidden_layers
-        if not 1 <= len(hl) <= L.EH_MAX_HIDDEN:
+        if not (1 if self.NN else 0) <= len(hl) <= L.EH_MAX_HIDDEN:
             raise NotImplementedError(f"{len(hl)} hidden layers (device kernels: 1..{L.EH_MAX_HIDDEN})")
         d.n_hidden = len(hl)
         for k, w in enumerate(hl):
@@ -433,8 +435,12 @@ def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[s
         raise AssertionError("neural_param_names ⊆ param_names")                      # GenericHybridModel.jl:110
     predictors, forcing, targets = list(predictors), list(forcing), list(targets)
     neural_param_names, global_param_names = list(neural_param_names), list(global_param_names)
-    if len(predictors) == 0 or len(neural_param_names) == 0:
-        raise NotImplementedError("models without a neural network (empty predictors / neural_param_names) are not built")
+    no_nn = len(predictors) == 0 or len(neural_param_names) == 0          # "if empty predictors do not construct NN" (GenericHybridModel.jl:112-125)
+    if no_nn and neural_param_names:
+        # the reference builds `NN = Chain()` here and its forward then fails on the missing NN outputs; said up front instead
+        raise ValueError("neural_param_names given but no predictors: a neural parameter needs a network input")
+    if no_nn and not global_param_names:
+        raise ValueError("a model with neither neural nor global parameters has nothing to train")
     for p in ms.params:
         if p not in all_names:
             raise ValueError(f"mechanistic model {ms.name} needs parameter {p!r}; the table has {all_names}")
@@ -451,7 +457,9 @@ def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[s
         raise NotImplementedError("hidden_layers given as a Lux Chain is not supported; pass the widths")
     act = _act_name(activation)
     dims = [len(predictors)] + [int(h) for h in hidden_layers] + [len(neural_param_names)]
-    NN = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+    NN = [] if no_nn else [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+    if no_nn:
+        input_batchnorm = False                                  # (nothing to normalise: the predictors feed no network)
     fixed = [n for n in all_names if n not in neural_param_names and n not in global_param_names]    # :127
     config = dict(hidden_layers=list(hidden_layers), activation=act, scale_nn_outputs=scale_nn_outputs,
                   input_batchnorm=input_batchnorm, start_from_default=start_from_default, **kwargs)

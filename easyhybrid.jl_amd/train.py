@@ -161,6 +161,8 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
     per_target = tl.losses if isinstance(tl, PerTarget) else (tl if isinstance(tl, (list, tuple)) and tl and not callable(tl[0]) else None)
     if per_target is not None:                                   # PerTarget((l_1, ..., l_T)), compute_loss.jl:128-145
         for lt in per_target:
+            if callable(lt):                                     # a function: recorded and compiled into the step kernel
+                continue
             check_training_loss(lt)
             if lt not in L.TRAINING_LOSSES:
                 raise NotImplementedError(f"training_loss {lt!r}: the device implements {sorted(L.TRAINING_LOSSES)}")
@@ -212,7 +214,8 @@ def prepare_data(model: SingleNNHybridModel, data, drop_missing_rows: bool = Tru
             some_target |= ~np.isnan(arr[c])
         keep = ~miss & some_target
         arr = {c: v[keep] for c, v in arr.items()}
-    X = np.stack([arr[p] for p in model.predictors]).astype(np.float32)
+    nkept = len(next(iter(arr.values())))
+    X = np.stack([arr[p] for p in model.predictors]).astype(np.float32) if model.predictors else np.zeros((0, nkept), np.float32)   # (no predictors: a model without a network)
     return (X, {f: arr[f].astype(np.float32) for f in model.forcing}), {t: arr[t].astype(np.float32) for t in model.targets}
 
 

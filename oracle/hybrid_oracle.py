@@ -403,6 +403,8 @@ class HybridSpec:
     def net_list(self) -> List[Tuple[List[int], List[Tuple[int, int]]]]:
         """[(predictor rows, [(out, in) per Dense layer])] -- one entry for SingleNN, one per neural parameter for MultiNN"""
         if self.nets is None:
+            if not self.neural:
+                return []              # no neural parameter: the reference builds no network (`NN = Chain()`, GenericHybridModel.jl:112-125)
             return [(list(range(self.n_pred)), self.layer_dims)]
         out = []
         for rows, hidden in self.nets:
@@ -542,7 +544,7 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
             zs.append(z); hs.append(h)
         tapes.append((Ws, zs, hs))
         outs.append(h)
-    o = np.concatenate(outs, axis=0)                                   # (K, B)
+    o = np.concatenate(outs, axis=0) if outs else np.zeros((0, X.shape[1]), dt)      # (K, B)
     # k3: optional sigmoid scaling of NN outputs
     nn = {}
     for k, n in enumerate(spec.neural):

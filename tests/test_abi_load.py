@@ -96,7 +96,7 @@ def test_create_rejects_bad_descriptors_before_touching_a_device():
     d.struct_size = 4
     assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL
     d = _model().to_desc()
-    d.hidden[0] = 512; d.activation = 3               # EH_ACT_SWISH, wider than the fused kernels: the layer-wise form has no swish
+    d.hidden[0] = 512; d.input_batchnorm = 1; d.n_predictors = 40      # wider than the fused kernels, and an input BatchNorm over more predictors than the normalisation block holds
     assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EUNSUPPORTED and b"no kernel for" in lib.eh_last_error(None)
     d = _model().to_desc()
     d.param_kind[0] = L.PAR_FIXED                         # no neural parameter left

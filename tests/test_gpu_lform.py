@@ -169,12 +169,87 @@ def test_train_front_door_on_the_tutorial_network():
 
 
 def test_refusals():
-    spec = ho.rbq10_spec(TUTORIAL, "swish", True)
-    with pytest.raises(NotImplementedError, match="layer-wise"):
-        util.model_from_spec(spec).engine()
     eng = util.model_from_spec(ho.rbq10_spec((256, 256), "tanh", True)).engine()
     with pytest.raises(NotImplementedError):
         eng.set_option("fused_update", 1)
     with pytest.raises(NotImplementedError):
-        eng.set_training_loss("kgeLoss")
+        eng.set_training_loss(lambda yh, y: np.mean(np.abs(yh - y) ** 1.5))      # a recorded loss needs a run-time compiled (fused) kernel
+    eng.close()
+
+
+# ---- what the layer-wise form did not hold in round 2: swish, MultiNNHybridModel, the moment losses ----------------------------------
+@pytest.mark.parametrize("hidden", [TUTORIAL, (200, 40), (96, 80, 64, 48)])
+def test_swish_networks(hidden):
+    """swish (README.md:186) on networks no fused kernel holds: act' needs the PRE-activation, which the layer-wise form now keeps next
+    to the activation for swish layers"""
+    B = 700
+    spec, theta, X, f, y = util.rbq10_case(B, "swish", True, 0.1, hidden=hidden)
+    _check(spec, theta, X, f, y)
+    if hidden == TUTORIAL:
+        return
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    batches = [(0, 350), (350, 350)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=2e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 2e-5) >= 0.999
+    out = eng.forward(eh.EH_SPLIT_TRAIN)
+    assert util.relerr(out["reco"], ho.forward(spec, eng.get_params().astype(np.float64), X, f)["reco"]) <= TOL
+    eng.close()
+
+
+MULTI = [
+    # (nets: (predictor rows, hidden widths) per neural parameter, activations or None, globals)
+    ([([0, 1], [160, 40]), ([2, 3, 4], [96, 24])], None, ["Q10"]),                                  # wider than any fused envelope
+    ([([0], [40, 30, 20, 10]), ([1, 2], [24, 24, 24, 24])], None, []),                              # four hidden layers
+    ([([0, 1], [140, 30]), ([2], [20]), ([3, 4, 5], [64, 64, 16])], ["tanh", "swish", "relu"], ["Q10_het", "Q10_root", "Q10_myc"]),   # depths 2 / 1 / 3, own activations
+]
+
+
+@pytest.mark.parametrize("case", range(len(MULTI)))
+def test_multinn_models(case):
+    """MultiNNHybridModel (src/models/GenericHybridModel.jl:142-206,458-530) beyond the block-diagonal envelope of the fused
+    kernels: every network runs as its own chain of products on its own predictor columns"""
+    nets, acts, glob = MULTI[case]
+    rng = np.random.default_rng(20 + case)
+    B = 900
+    if len(nets) == 2:
+        pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+        neural = ["RUE", "Rb"]
+        spec = ho.HybridSpec(max(max(r) for r, _ in nets) + 1, [], "fluxpart", pars, neural, glob, ["NEE", "GPP"], "sigmoid", True, nets=nets, net_activations=acts)
+        f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+        y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+        y["NEE"][rng.random(B) < 0.2] = np.nan
+    else:
+        neural = ["Rb_het", "Rb_root", "Rb_myc"]
+        spec = ho.HybridSpec(6, [], "rs_components", dict(ho.RS6_PARAMS), neural, glob, ["R_soil"], "tanh", True, nets=nets, net_activations=acts)
+        f = {"ta": (10 + 10 * rng.standard_normal(B)).astype(np.float32)}
+        y = {"R_soil": (rng.random(B) * 5 + 0.5).astype(np.float32)}
+        y["R_soil"][rng.random(B) < 0.1] = np.nan
+    X = rng.standard_normal((spec.n_pred, B)).astype(np.float32)
+    theta = ho.init_theta(spec, 5, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    _check(spec, theta, X, f, y, eng=eng)
+    idx = rng.permutation(B)[:333].astype(np.int32)
+    _check(spec, theta, X, f, y, eng=eng, idx=idx)
+    eng.opt_init("Adam", 0.01)
+    batches = [(0, 450), (450, 450)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=2e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 2e-5) >= 0.998
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["kgeLoss", "pearsonLoss", "pbkgeLoss"])
+def test_moment_losses(kind):
+    spec, theta, X, f, y = util.rbq10_case(1500, "tanh", True, 0.1, hidden=(192, 64, 32, 16))
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind)
+    assert nv == sum(nv0) and abs(loss - l0) <= 1e-4 * abs(l0) and util.relerr(grad, g0) <= 1e-4, (loss, l0, util.relerr(grad, g0))
     eng.close()

@@ -1612,3 +1612,58 @@ def test_hipgraph_capture_as_the_first_use_of_a_specialised_engine():
             ref.train_step(i * 512, 512, want_loss=False)
     assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 1e-6
     eng.close(); ref.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# models without a network: every parameter global or fixed (the reference builds `NN = Chain()` and its forward goes
+# global / fixed parameters -> M, src/models/GenericHybridModel.jl:112-125,376-406)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("glob,n_pred", [(["rb", "Q10"], 0), (["Q10"], 0), (["rb"], 2)])
+def test_model_without_a_network(glob, n_pred):
+    B = 3000
+    spec = ho.HybridSpec(n_pred, [], "rbq10", dict(ho.RBQ10_PARAMS), [], list(glob), ["reco"], "tanh", False)
+    assert spec.n_theta == len(glob)
+    X0, f, y = ho.make_synth_rbq10(B, 9, 0.15)
+    X = X0[:n_pred]                                            # predictors may be listed: without a neural parameter nothing reads them
+    theta = (ho.init_theta(spec, 1, np.float32) + np.float32(0.3)).astype(np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    assert eng.n_theta == len(glob)
+    _check_grad(spec, theta, X, f, y, eng=eng)
+    _check_grad(spec, theta, X, f, y, eng=eng, first=17, count=1234)
+    idx = np.random.default_rng(4).permutation(B)[:700].astype(np.int32)
+    _check_grad(spec, theta, X, f, y, eng=eng, idx=idx)
+    out = eng.forward(eh.EH_SPLIT_TRAIN)
+    ref = ho.forward(spec, theta.astype(np.float64), X, f)
+    assert util.relerr(out["reco"], ref["reco"]) <= TOL
+    for p in ("rb", "Q10"):
+        assert util.relerr(out["parameters"][p], np.broadcast_to(ref["parameters"][p], (B,))) <= TOL
+    m, _ = eng.eval(eh.EH_SPLIT_TRAIN)
+    ev, _ = ho.evaluate(spec, theta.astype(np.float64), X, f, y, ("mse", "r2"))
+    assert m[0]["mse"] == pytest.approx(ev["mse"]["reco"], rel=2e-5) and m[0]["r2"] == pytest.approx(ev["r2"]["reco"], abs=2e-5)
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 500, 500) for i in range(6)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=2e-5)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 2e-5
+    mean_loss, nsteps = eng.train_epoch(512, seed=3, shuffle=True)
+    assert nsteps == 6 and np.isfinite(mean_loss)
+    eng.close()
+
+
+def test_model_without_a_network_through_the_front_door():
+    cols = __import__("easyhybrid_jl_amd.synthetic", fromlist=["x"]).make_synth_rbq10(4000, seed=1)
+    # (start_from_default = false: the table's defaults ARE the values the series was made with)
+    model = eh.constructHybridModel([], ["ta"], ["reco"], eh.RbQ10, {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}, [], ["rb", "Q10"], start_from_default=False)
+    assert model.NN == [] and model.n_theta == 2 and model.fixed_param_names == []
+    res = eh.train(model, cols, nepochs=60, batchsize=500, opt=eh.Adam(0.05), random_seed=1)
+    # the synthetic series was made with rb ~ 3 (+- a covariate term of mean zero) and Q10 = 2: two global constants recover them
+    assert res.val_history[-1]["mse"]["reco"] < res.val_history[0]["mse"]["reco"]
+    from easyhybrid_jl_amd.models import scale_single_param
+    _, raw = model.unpack(res.ps)
+    q10, rb = (float(scale_single_param(n, raw[n], model.parameters)[0]) for n in ("Q10", "rb"))
+    assert abs(q10 - 2.0) < 0.15 and abs(rb - 3.0) < 0.3, (q10, rb)
+    with pytest.raises(ValueError):
+        eh.constructHybridModel([], ["ta"], ["reco"], eh.RbQ10, {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}, ["rb"], ["Q10"])      # a neural parameter without predictors
+    with pytest.raises(ValueError):
+        eh.constructHybridModel([], ["ta"], ["reco"], eh.RbQ10, {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}, [], [])               # nothing to train

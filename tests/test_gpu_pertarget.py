@@ -52,8 +52,10 @@ def test_train_front_door_with_per_target_losses():
     assert len(out.val_history) == 4 and np.isfinite(out.best_loss)
     with pytest.raises(AssertionError):
         eh.train(model, cols, nepochs=1, batchsize=200, training_loss=eh.PerTarget(("mae",)), random_seed=1)
+    out = eh.train(model, cols, nepochs=2, batchsize=200, training_loss=eh.PerTarget(("kgeLoss", "rmse")), random_seed=1)      # two-pass losses per target
+    assert len(out.val_history) == 3 and np.isfinite(out.best_loss)
     with pytest.raises(NotImplementedError):
-        eh.train(model, cols, nepochs=1, batchsize=200, training_loss=eh.PerTarget(("kgeLoss", "mse")), random_seed=1)
+        eh.train(model, cols, nepochs=1, batchsize=200, training_loss=eh.PerTarget(("kgeLoss", "no_such_loss")), random_seed=1)
 
 
 def test_tuple_forms_of_a_custom_training_loss():
@@ -69,4 +71,73 @@ def test_tuple_forms_of_a_custom_training_loss():
         eng.set_training_loss(form)
         loss, grad, _ = eng.loss_and_grad()
         assert abs(loss - l0) <= 1e-5 * abs(l0) and util.relerr(grad, g0) <= 2e-5
+        eng.close()
+
+
+# ---- losses that need batch statistics of the predictions, per target on multi-target models: rmse (its scale 1 / (n rmse) has to be
+# known inside the one pass that serves all targets) and the moment losses pearsonLoss / kgeLoss / pbkgeLoss.  The reference applies
+# whatever training_loss it is given to every target (src/losses/compute_loss.jl:115-145, loss_fn.jl:58-174). ----------------------------
+@pytest.mark.parametrize("hidden", [(16, 16), (48, 48), (128, 96), (160, 96, 48, 24)])      # per-wave, per-wave 64-wide family, row-split, layer-wise
+@pytest.mark.parametrize("kinds", [("rmse", "rmse"), ("rmse", "mae"), ("mse", "rmse"), ("kgeLoss", "mse"), ("pearsonLoss", "nseLoss"), ("pbkgeLoss", "rmse"), ("kgeLoss", "kgeLoss")])
+def test_two_pass_losses_per_target(hidden, kinds):
+    spec, theta, X, f, y = _flux_case(hidden)
+    # (targets the model can correlate with: a correlation of noise is ill-conditioned, tests/test_gpu_fuzz.py)
+    ref = ho.forward(spec, (theta + np.float32(0.05) * np.random.default_rng(5).standard_normal(theta.size).astype(np.float32)).astype(np.float64), X, f)
+    rng = np.random.default_rng(6)
+    for t in spec.targets:
+        m = np.isnan(y[t])
+        y[t] = (ref[t] * 0.8 + 0.3 + 0.2 * np.std(ref[t]) * rng.standard_normal(X.shape[1])).astype(np.float32)
+        y[t][m] = np.nan
+    moment = any(k in ("kgeLoss", "pearsonLoss", "pbkgeLoss") for k in kinds)
+    tol = 1e-4 if moment else 1e-5                           # (differences of moments amplify fp32 rounding: DESIGN section 3.4)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(eh.PerTarget(kinds) if kinds[0] != kinds[1] else kinds[0])
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kinds)
+    assert nv == sum(nv0) and abs(loss - l0) <= tol * abs(l0) and util.relerr(grad, g0) <= tol, (loss, l0, util.relerr(grad, g0))
+    idx = np.random.default_rng(2).permutation(X.shape[1])[:500].astype(np.int32)
+    loss, grad, nv = eng.loss_and_grad(idx=idx)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, idx], {k: v[idx] for k, v in f.items()}, {k: v[idx] for k, v in y.items()}, kind=kinds)
+    assert nv == sum(nv0) and abs(loss - l0) <= tol * abs(l0) and util.relerr(grad, g0) <= tol
+    eng.opt_init("Descent", 0.02)
+    batches = [(0, 300), (300, 300), (600, 300)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th = theta.astype(np.float32).copy()
+    for (a, n), lg in zip(batches, losses):
+        sl = slice(a, a + n)
+        l_, g_, _ = ho.loss_and_grad(spec, th.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}, kind=kinds)
+        assert abs(lg - l_) <= 5 * tol * abs(l_)
+        th = (th - np.float32(0.02) * g_.astype(np.float32)).astype(np.float32)
+    assert np.max(np.abs(eng.get_params() - th)) <= 20 * tol * max(1.0, float(np.max(np.abs(th))))
+    with pytest.raises(NotImplementedError):
+        eng.set_option("fused_update", 1)                    # forward passes ahead of the step: no one-kernel mode
+    eng.close()
+
+
+def test_one_target_without_a_valid_sample_adds_nothing():
+    spec, theta, X, f, y = _flux_case((16, 16), B=400)
+    y["GPP"][:] = np.nan
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(eh.PerTarget(("mse", "rmse")))
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=("mse", "rmse"))
+    assert nv == sum(nv0) and abs(loss - l0) <= 1e-5 * abs(l0) and util.relerr(grad, g0) <= 1e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden", [(16, 16), (128, 96)])
+def test_recorded_loss_function_on_a_multi_target_model(hidden):
+    """training_loss::Function is applied to every target (loss_fn.jl:92-94 through compute_loss.jl:115-126); PerTarget mixes it with
+    the named losses"""
+    def logcosh(yh, y):
+        r = yh - y
+        return np.mean(np.log(np.cosh(r)))
+    spec, theta, X, f, y = _flux_case(hidden)
+    name = util.register_loss("logcosh_mt", logcosh) and "logcosh_mt"
+    for spec_kinds, dev in (((name, name), logcosh), ((name, "mse"), eh.PerTarget((logcosh, "mse"))), (("mae", name), [("mae"), logcosh])):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_training_loss(dev)
+        loss, grad, nv = eng.loss_and_grad()
+        l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=spec_kinds)
+        assert nv == sum(nv0) and abs(loss - l0) <= 1e-5 * abs(l0) and util.relerr(grad, g0) <= 2e-5, (spec_kinds, loss, l0, util.relerr(grad, g0))
         eng.close()

@@ -273,3 +273,19 @@ def test_per_target_losses_vjp_matches_finite_differences():
             assert (lp - lm) / 2e-6 == pytest.approx(g0[i], rel=2e-5, abs=1e-8)
     with pytest.raises(AssertionError):
         ho.loss_and_grad(spec, theta, X, f, y, kind=("mse",))
+
+
+def test_model_without_a_network_gradient_matches_finite_differences():
+    """no neural parameter: `NN = Chain()` in the reference (src/models/GenericHybridModel.jl:112-125), theta = the raw globals"""
+    spec = ho.HybridSpec(0, [], "rbq10", dict(ho.RBQ10_PARAMS), [], ["rb", "Q10"], ["reco"], "tanh", False)
+    assert spec.n_theta == 2 and spec.net_list == []
+    X0, f, y = ho.make_synth_rbq10(400, 9, 0.15)
+    X = X0[:0]
+    th = ho.init_theta(spec, 1, np.float64) + 0.3
+    l, g, nv = ho.loss_and_grad(spec, th, X, f, y)
+    eps = 1e-6
+    fd = [(ho.loss_and_grad(spec, th + eps * e, X, f, y)[0] - ho.loss_and_grad(spec, th - eps * e, X, f, y)[0]) / (2 * eps) for e in np.eye(2)]
+    assert np.allclose(g, fd, rtol=1e-6)
+    # at the defaults (raw = inv_sigmoid of the mid-range default) the model is rb = 3, Q10 = 2 for every sample
+    out = ho.forward(spec, ho.init_theta(spec, 1, np.float64), X, f)
+    assert np.allclose(out["reco"], 3.0 * 2.0 ** (0.1 * (f["ta"].astype(np.float64) - 15.0)))
