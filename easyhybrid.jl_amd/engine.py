@@ -193,9 +193,10 @@ class HybridEngine:
         rmse joins them on multi-target models), or a function f(yhat, y) = mean of per-sample terms, which is recorded
         (program.trace_loss) and compiled into the step kernel at run time.  Applied to every target like the reference does
         (src/losses/compute_loss.jl:115-126); PerTarget((l_1, ..., l_T)) / a list gives each target its own (:128-145)."""
-        if isinstance(name, PerTarget):
+        per_target = isinstance(name, PerTarget)
+        if per_target:
             name = list(name.losses)
-        if isinstance(name, (list, tuple)) and name and callable(name[0]):
+        if not per_target and isinstance(name, (list, tuple)) and name and callable(name[0]):
             # (f, args) / (f, kwargs) / (f, args, kwargs)  (src/losses/loss_fn.jl:92-107): f(yhat, y, args...; kwargs...)
             f, rest = name[0], list(name[1:])
             args = next((tuple(r) for r in rest if isinstance(r, (tuple, list))), ())

@@ -280,7 +280,7 @@ class SingleNNHybridModel:
                 layers.append((W, b))
             nets.append(layers)
         glob = {g: theta[off + j:off + j + 1] for j, g in enumerate(self.global_param_names)}
-        return (nets[0] if self.NNs is None else dict(zip(self.neural_param_names, nets))), glob
+        return ((nets[0] if nets else []) if self.NNs is None else dict(zip(self.neural_param_names, nets))), glob
 
     # -- C descriptor ----------------------------------------------------------------------------
     def to_desc(self, device: int = 0) -> L.ModelDesc:

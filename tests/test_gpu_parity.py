@@ -675,8 +675,8 @@ def test_error_paths_on_device():
     with pytest.raises(NotImplementedError):
         eng.opt_init("Lion")
     eng.close()
-    wide = ho.rbq10_spec((256, 16), "swish")              # no fused kernel is that wide, and the layer-wise form has no swish
-    with pytest.raises(NotImplementedError, match="no kernel for"):
+    wide = ho.HybridSpec(40, [256, 16], "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "tanh", True, input_batchnorm=True)
+    with pytest.raises(NotImplementedError, match="no kernel for"):      # no fused kernel is that wide, and the normalisation block of the layer-wise form holds 32 predictors
         util.model_from_spec(wide).engine()
 
 
@@ -1112,8 +1112,7 @@ def test_fused_update_mode_on_a_multi_target_model(kinds):
 def test_width_128_three_layers_runs_layer_by_layer():
     # (refused in round 1: no fused kernel holds three 128-wide layers; since round 2 such shapes take the layer-wise form, tests/test_gpu_lform.py)
     _check_grad(*util.rbq10_case(400, "tanh", True, 0.1, hidden=(128, 128, 128)))
-    with pytest.raises(NotImplementedError, match="layer-wise"):
-        util.model_from_spec(ho.rbq10_spec((128, 128, 128), "swish")).engine()      # ... which has no swish: still refused, loudly
+    _check_grad(*util.rbq10_case(400, "swish", True, 0.1, hidden=(128, 128, 128)))      # (swish there since round 3: the pre-activations are kept)
 
 
 def test_width_128_grid_independence_full_batch():
@@ -1410,7 +1409,7 @@ def test_moment_based_training_losses(kind, shape):
     assert np.allclose(losses, l_ref, rtol=5e-4)
     assert np.max(np.abs(eng.get_params() - th_ref)) <= 2e-4 * max(1.0, float(np.max(np.abs(th_ref))))
     if shape != "wide":
-        with pytest.raises(NotImplementedError, match="two passes"):
+        with pytest.raises(NotImplementedError, match="forward passes"):
             eng.set_option("fused_update", 1)
     eng.close()
 
