@@ -1895,6 +1895,16 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
         hipLaunchKernelGGL(eh_thin_gemm_kernel, dim3((unsigned)((t.ncols + 63) / 64), (unsigned)nz), dim3(256), 0, h->stream, t);
         return;
     }
+    if (!novec && nz == 1 && g.kchunk >= g.K) {          // products with a degenerate dimension: streaming kernels (eh_lform.hpp)
+        const long long tot = (long long)g.M * g.N;
+        const unsigned sg = (unsigned)std::max<long long>(1, std::min<long long>(2048, (tot + 255) / 256));
+        if (EPI == EH_GEPI_BIAS_ACT && !ATR && !BTR && g.K <= 8) { hipLaunchKernelGGL(eh_thin_fwd_k_kernel, dim3(sg), dim3(256), 0, h->stream, g); return; }
+        if (EPI == EH_GEPI_BIAS_T && !ATR && !BTR && g.N <= 16 && g.M <= 16384) {
+            hipLaunchKernelGGL(eh_thin_fwd_n_kernel, dim3((unsigned)std::max(1, std::min(1024, (g.M + 3) / 4))), dim3(256), 0, h->stream, g);
+            return;
+        }
+        if (EPI == EH_GEPI_DACT && ATR && BTR && g.K <= 16) { hipLaunchKernelGGL(eh_thin_dact_kernel, dim3(sg), dim3(256), 0, h->stream, g); return; }
+    }
     const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz);
     const bool vec = !novec && eh_gemm_vec_ok(g, ATR, BTR);
     if (vec && (long long)grid.x * grid.y * grid.z < 256) {      // fewer 128 x 128 tiles than CUs: 64 x 64 ones (four times the workgroups, a quarter of the work each)
@@ -2170,17 +2180,21 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     }
     static const int cw_env = getenv("EH_REDUCE_CW") ? atoi(getenv("EH_REDUCE_CW")) : 0;      // (A/B switch of the measurement tools)
     const bool big = cw_env ? cw_env == 64 : h->n_acc >= 8192;          // enough columns to fill the chip with 64-column blocks
-    const int rgrid = big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
+    // layer-wise form: few slab rows (<= 32) under very many columns (the tutorial net: 700 k): one column per thread -- with 64-column
+    // blocks 3 of 4 threads had no row to read and the per-block part (counts, barriers) ran 11 k times: 29.6 us of a 250 us step at
+    // B = 64 (tools/lform_trace.sh)
+    const bool tall = cw_env ? cw_env == 256 : (h->lform && grid <= 32 && h->n_acc >= 16384);
+    const int rgrid = tall ? (h->n_acc + 255) / 256 : big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
 #define EH_REDUCE_GO(AP, CW_)                                                                                                                       \
     hipLaunchKernelGGL((eh_reduce_kernel<AP, CW_>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
                        TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)
     if (apply) {
-        if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
+        if (tall) EH_REDUCE_GO(true, 256); else if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
     } else {
-        if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
+        if (tall) EH_REDUCE_GO(false, 256); else if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
     }
 #undef EH_REDUCE_GO
     HIPCHK(h, hipGetLastError());

@@ -243,6 +243,12 @@ __device__ __forceinline__ float eh_dact(float s) {
 __device__ __forceinline__ int eh_row_act(int, int) { return EH_ACT_IDENTITY; }
 #endif
 template <int ACT> struct EhStoresZ { static constexpr bool value = ACT == EH_ACT_SWISH || ACT == EH_ACT_PER_NET; };
+// A value that goes to LDS straight from an MFMA accumulator (the pre-activations the swish / per-net kernels keep) may sit in an AGPR;
+// two such stores merged into one ds_write2_b32 whose other data operand is a VGPR is an instruction some ROCm compilers then refuse
+// ("Illegal instruction detected: both data operands should be VGPR or AGPR" -- the hiprtc PyTorch bundles, on the per-net-activation
+// kernels, found by the fuzz in round 3; the system compiler of ROCm 7.2 builds the same source).  Pinning the value to a VGPR costs
+// at most the v_accvgpr_read the store would need on older parts anyway.
+__device__ __forceinline__ float eh_vgpr(float v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float eh_act_id(int id, float z) {
     switch (id) {
         case EH_ACT_TANH: return eh_tanh(z);
@@ -989,7 +995,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 h[m][t] = hv4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = EhStoresZ<ACT>::value ? z4[r] : hv4[r];
+                    if (TRAIN && (NL > 1 || !K1 || !KEEPH)) HS[(16 * m + 4 * g + r) * SR + 16 * t + c] = EhStoresZ<ACT>::value ? eh_vgpr(z4[r]) : hv4[r];
                 if constexpr (KEEPH) hs[0][m][t] = h[m][t];
             }
         }
@@ -1035,7 +1041,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     h[m][t] = hv4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)      // the last layer's image is only read back for act' / dWo when those do not have it in registers
-                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = EhStoresZ<ACT>::value ? z4[r] : hv4[r];
+                        if (TRAIN && (l < NL - 1 || !K1 || !KEEPH)) Hl[(16 * m + 4 * g + r) * SR + 16 * t + c] = EhStoresZ<ACT>::value ? eh_vgpr(z4[r]) : hv4[r];
                     if constexpr (KEEPH) hs[l < NHS ? l : 0][m < NHM ? m : 0][t < NHT ? t : 0] = h[m][t];
                 }
         }

@@ -294,6 +294,12 @@ static std::string eh_jit_rowact_source(const eh_model_desc& d) {
     return s;
 }
 
+// A build that does not get through the compiler is tried again more conservatively: level 1 without the SLP vectoriser (where the
+// first attempt had it), level 2 at -O1.  Seen with the hiprtc / comgr that PyTorch bundles (ROCm 7.0) on the per-net-activation
+// row-split kernels: "Illegal instruction detected: both data operands should be VGPR or AGPR" (a merged ds_write2_b32 with one
+// operand in an accumulator register) at -O2 / -O3; the system compiler of ROCm 7.2 builds the same source.  A slower kernel beats
+// none: these models have no kernel built ahead of time.
+static thread_local int g_jit_level = 0;
 bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
                   const EhLossProg* loss, EhJitKernel* out, std::string* log) {
     const EhVariant& V = A->var[variant];
@@ -352,8 +358,20 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     // whole suite and 3 600 fuzz configurations on them with the vectoriser on -- so their run-time kernels get it back; every
     // other shape, and everything built ahead of time, stays without.  EH_JIT_SLP=0 / 1 overrides (diagnostics).
     const char* const slp_env = getenv("EH_JIT_SLP");
-    const bool slp_on = slp_env ? atoi(slp_env) != 0 : (A->nbh == 1 && !A->wide);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", slp_on ? "-fslp-vectorize" : "-fno-slp-vectorize", "-std=c++17"};
+    const bool slp_on = g_jit_level == 0 && (slp_env ? atoi(slp_env) != 0 : (A->nbh == 1 && !A->wide));
+    std::vector<std::string> extra;                  // EH_JIT_EXTRA_OPTS="-mllvm -foo ..." (diagnostics): appended to the compile options
+    if (const char* xo = getenv("EH_JIT_EXTRA_OPTS")) {
+        std::string x = xo;
+        size_t at = 0;
+        while (at < x.size()) {
+            size_t e = x.find(' ', at);
+            if (e == std::string::npos) e = x.size();
+            if (e > at) extra.push_back(x.substr(at, e - at));
+            at = e + 1;
+        }
+    }
+    std::vector<const char*> opts = {"--offload-arch=gfx950", g_jit_level >= 2 ? "-O1" : "-O3", slp_on ? "-fslp-vectorize" : "-fno-slp-vectorize", "-std=c++17"};
+    for (const std::string& x : extra) opts.push_back(x.c_str());
     // ---- cached code object?
     std::string cpath;
     {
@@ -376,15 +394,30 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     std::vector<std::string> lowered;
     std::vector<char> code;
     bool from_cache = !cpath.empty() && cache_load(cpath, nmode, &lowered, &code);
+    if (getenv("EH_JIT_TRACE")) {          // diagnostics: what exactly is being compiled
+        fprintf(stderr, "eh_jit: %s | slp %d | %s | cache %s%s\n", name[0], (int)slp_on, cpath.c_str(), from_cache ? "hit" : "miss", g_jit_level ? " | retry" : "");
+        const size_t at = src.find("#define EH_SPEC_NET");
+        if (at != std::string::npos) fprintf(stderr, "eh_jit: %s\n", src.substr(at, src.find('\n', at) - at).c_str());
+    }
     if (!from_cache) {
         lowered.clear();
-        const hiprtcResult rc = hiprtcCompileProgram(hp, (int)(sizeof opts / sizeof opts[0]), opts);
+        const hiprtcResult rc = hiprtcCompileProgram(hp, (int)opts.size(), opts.data());
         size_t ls = 0;
         hiprtcGetProgramLogSize(hp, &ls);
         if (ls > 1) { log->resize(ls); hiprtcGetProgramLog(hp, &(*log)[0]); }
         if (rc != HIPRTC_SUCCESS) {
             *log = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + *log;
             hiprtcDestroyProgram(&hp);
+            const int next = (g_jit_level == 0 && slp_on) ? 1 : (g_jit_level < 2 ? 2 : 3);
+            if (next <= 2) {
+                const std::string first = log->substr(0, 240);
+                const int saved = g_jit_level;
+                g_jit_level = next;
+                const bool ok2 = eh_jit_build(d, A, variant, act, fast, spec, with_p2p, loss, out, log);
+                g_jit_level = saved;
+                if (ok2 && log->empty()) *log = std::string(next == 1 ? "(compiled with -fno-slp-vectorize" : "(compiled at -O1") + " after the first build failed: " + first + ")";
+                return ok2;
+            }
             return false;
         }
         size_t cs = 0;

@@ -122,27 +122,78 @@ __global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmA
             }
         };
         const int nsteps = (kend - kbeg) / BK;
-        if (nsteps > 0) { gload(); lstore(0); }
-        __syncthreads();
-        for (int st = 0; st < nsteps; ++st) {
-            const int cur = st & 1;
-            if (st + 1 < nsteps) gload();             // in flight behind this step's MFMAs
-            if (do_cs_v) {
-#pragma unroll
-                for (int kk = 0; kk < BK; ++kk) cs_v += Bs[cur][kk][tid];
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < BK; k2 += 2) {
-                float av[TI], bv[TI];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) { av[i] = As[cur][k2 + lh][wm * WT + 32 * i + l32]; bv[i] = Bs[cur][k2 + lh][wn * WT + 32 * i + l32]; }
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
-            if (st + 1 < nsteps) lstore(cur ^ 1);     // the other buffer: its readers passed the barrier that ended the previous step
+        // (one MFMA chain of a 64 x 64 step is ~0.25 us, a global load 1-2 us: with one tile in flight the K loop of a small-batch
+        //  product -- one or two workgroups per CU, nothing else to hide behind -- ran at one memory latency per step, 17.5 us for the
+        //  tutorial net's 1 024-deep forward product at B = 64 (tools/lform_trace.sh).  64 x 64 tiles keep DEPTH = 4 tiles in flight in
+        //  registers; the 128 x 128 ones, whose accumulators fill the register budget and whose products fill the chip, keep one.)
+        constexpr int DEPTH = BT == 64 ? 4 : 1;
+        if constexpr (DEPTH == 1) {
+            if (nsteps > 0) { gload(); lstore(0); }
             __syncthreads();
+            for (int st = 0; st < nsteps; ++st) {
+                const int cur = st & 1;
+                if (st + 1 < nsteps) gload();             // in flight behind this step's MFMAs
+                if (do_cs_v) {
+#pragma unroll
+                    for (int kk = 0; kk < BK; ++kk) cs_v += Bs[cur][kk][tid];
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < BK; k2 += 2) {
+                    float av[TI], bv[TI];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) { av[i] = As[cur][k2 + lh][wm * WT + 32 * i + l32]; bv[i] = Bs[cur][k2 + lh][wn * WT + 32 * i + l32]; }
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+                if (st + 1 < nsteps) lstore(cur ^ 1);     // the other buffer: its readers passed the barrier that ended the previous step
+                __syncthreads();
+            }
+        } else {
+            // slot d of the ring holds tile s with s % DEPTH == d: requested DEPTH steps before it is parked in LDS
+            f32x4 qa[DEPTH][NP], qb[DEPTH][NP];
+            auto gload_to = [&](int d) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { qa[d][j] = *(const f32x4*)pa[j]; qb[d][j] = *(const f32x4*)pb[j]; pa[j] += sa; pb[j] += sb; }
+            };
+            auto lstore_from = [&](int buf, int d) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) { ra[j] = qa[d][j]; rb[j] = qb[d][j]; }
+                lstore(buf);
+            };
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+                if (d < nsteps) gload_to(d);
+            if (nsteps > 0) lstore_from(0, 0);
+            __syncthreads();
+#pragma unroll 1
+            for (int st0 = 0; st0 < nsteps; st0 += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int st = st0 + d;
+                    if (st < nsteps) {
+                        const int cur = d & 1;                                  // (DEPTH is even: st & 1 == d & 1)
+                        if (st + DEPTH < nsteps) gload_to(d);                  // slot d was parked at the end of the previous step
+                        if (do_cs_v) {
+#pragma unroll
+                            for (int kk = 0; kk < BK; ++kk) cs_v += Bs[cur][kk][tid];
+                        }
+#pragma unroll
+                        for (int k2 = 0; k2 < BK; k2 += 2) {
+                            float av[TI], bv[TI];
+#pragma unroll
+                            for (int i = 0; i < TI; ++i) { av[i] = As[cur][k2 + lh][wm * WT + 32 * i + l32]; bv[i] = Bs[cur][k2 + lh][wn * WT + 32 * i + l32]; }
+#pragma unroll
+                            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                                for (int j = 0; j < TI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        }
+                        if (st + 1 < nsteps) lstore_from(cur ^ 1, (d + 1) % DEPTH);
+                        __syncthreads();
+                    }
+                }
+            }
         }
     }
     const bool do_cs = do_cs_v;
@@ -287,6 +338,55 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) {
         if (a.cs_wide) a.cs_wide[(long long)z * a.cs_z + col] = (red[0][cl][8] + red[1][cl][8]) + (red[2][cl][8] + red[3][cl][8]);
     }
     if (a.cs_thin && blockIdx.x == 0 && tid < a.J) a.cs_thin[(long long)z * a.cs_z + tid] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
+}
+
+// Products with a degenerate dimension, as streaming kernels (a 128 x 128 MFMA tile spends 94 % and more of such a product on padding;
+// at the tutorial's batch of 64 the three of them -- first layer (2 predictors), output layer (1 output) and its delta -- took
+// 16 + 14 + 13 us of a 250 us step, tools/lform_trace.sh):
+//   eh_thin_fwd_k_kernel : C[m][n] = act(sum_{k < K <= 8} A[m][k] B[k][n] + bias[n])          (first layer: few predictors; optional Z)
+//   eh_thin_fwd_n_kernel : C[n][m] = sum_k A[m][k] B[k][n] + bias[n],  N <= 16                 (output layer, transposed output)
+//   eh_thin_dact_kernel  : C[m][n] = (sum_{k < K <= 16} A[k][m] B[n][k]) * act'(H[m][n])        (delta below the output layer; A = dO^T [K][lda])
+// Same sums in the same k order as the tiled kernel (a k-ordered fmaf chain per output).
+__global__ __launch_bounds__(256) void eh_thin_fwd_k_kernel(const EhGemmArgs g) {
+    const long long tot = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int m = (int)(e / g.N), n = (int)(e - (long long)m * g.N);
+        float v = 0.0f;
+        for (int k = 0; k < g.K; ++k) v = fmaf(g.A[(long long)m * g.lda + k], g.B[(long long)k * g.ldb + n], v);
+        v += g.bias[n];
+        if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
+        g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
+    }
+}
+__global__ __launch_bounds__(256) void eh_thin_fwd_n_kernel(const EhGemmArgs g) {
+    // one wave per row m: lanes over k, all N (<= 16) outputs per lane, wave sums -- every load of A is a contiguous run
+    const int lane = threadIdx.x & 63, wave = (int)(((long long)blockIdx.x * 256 + threadIdx.x) >> 6), nwave = (int)(((long long)gridDim.x * 256) >> 6);
+    for (int m = wave; m < g.M; m += nwave) {
+        float acc[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc[n] = 0.0f;
+        for (int k = lane; k < g.K; k += 64) {
+            const float a = g.A[(long long)m * g.lda + k];
+#pragma unroll
+            for (int n = 0; n < 16; ++n)
+                if (n < g.N) acc[n] = fmaf(a, g.B[(long long)k * g.ldb + n], acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n)
+            if (n < g.N) {
+                const float sum = eh_wave_sum(acc[n]);
+                if (lane == 0) g.C[(long long)n * g.ldc + m] = sum + g.bias[n];
+            }
+    }
+}
+__global__ __launch_bounds__(256) void eh_thin_dact_kernel(const EhGemmArgs g) {
+    const long long tot = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int m = (int)(e / g.N), n = (int)(e - (long long)m * g.N);
+        float v = 0.0f;
+        for (int k = 0; k < g.K; ++k) v = fmaf(g.A[(long long)k * g.lda + m], g.B[(long long)n * g.ldb + k], v);
+        g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
+    }
 }
 
 // The minibatch as the GEMMs want it: Xb [count][P] = the predictors of samples idx[first + i] (or first + i), normalised by the

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
                 for (int t = 0; t < NT; ++t) {
                     const f32x4 z4 = acc[mm][t], hv4 = (EhStoresZ<ACT>::value && TRAIN) ? z4 : eh_act4_rows<ACT>(z4, 0, 16 * (m0 + mm) + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) HS[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = hv4[r];
+                    for (int r = 0; r < 4; ++r) HS[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = (EhStoresZ<ACT>::value && TRAIN) ? eh_vgpr(hv4[r]) : hv4[r];      // (eh_vgpr: see there)
                 }
         }
         eh_lds_barrier();
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
                 for (int t = 0; t < NT; ++t) {
                     const f32x4 z4 = acc[mm][t], hv4 = (EhStoresZ<ACT>::value && TRAIN) ? z4 : eh_act4_rows<ACT>(z4, l, 16 * (m0 + mm) + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Hl[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = hv4[r];
+                    for (int r = 0; r < 4; ++r) Hl[(16 * (m0 + mm) + 4 * g + r) * SR + 16 * t + c] = (EhStoresZ<ACT>::value && TRAIN) ? eh_vgpr(hv4[r]) : hv4[r];
                 }
             eh_lds_barrier();
         }
