@@ -792,6 +792,7 @@ struct eh_handle_s {
     struct LNet { int nl = 0, c0 = 0, orow = 0, act = 0; int in[EH_MAX_HIDDEN + 1] = {0}, out[EH_MAX_HIDDEN + 1] = {0}, woff[EH_MAX_HIDDEN + 1] = {0}, boff[EH_MAX_HIDDEN + 1] = {0}; };
     int l_nnets = 0;                                     // 0: no network at all (no neural parameter)
     LNet l_net[EH_MAX_NETS];
+    float* l_split = nullptr; size_t l_split_cap = 0;    // split-K partial products of the small-batch GEMMs
     float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
     long long l_cap = 0;                                 // samples the workspace holds
     unsigned char* wflag = nullptr;
@@ -1519,7 +1520,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->wflag);
+    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1904,6 +1905,31 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
             return;
         }
         if (EPI == EH_GEPI_DACT && ATR && BTR && g.K <= 16) { hipLaunchKernelGGL(eh_thin_dact_kernel, dim3(sg), dim3(256), 0, h->stream, g); return; }
+    }
+    if constexpr (EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_DACT) {
+        // few rows, deep k: split-K into partial products + a combine pass (eh_splitk_combine_kernel)
+        static const bool nosplit = getenv("EH_GEMM_NOSPLIT") != nullptr;
+        if (!novec && !nosplit && nz == 1 && g.M <= 256 && g.K >= 128 && g.kchunk >= g.K && eh_gemm_vec_ok(g, ATR, BTR)) {
+            int kc = std::max(32, ((g.K + 15) / 16 + 15) / 16 * 16);          // ~16 parts, whole 16-deep steps
+            const int ns = (g.K + kc - 1) / kc;
+            const size_t need = (size_t)ns * g.M * g.N;
+            if (ns > 1) {
+                if (need > h->l_split_cap) {
+                    if (hipStreamSynchronize(h->stream) == hipSuccess) { (void)hipFree(h->l_split); h->l_split = nullptr; h->l_split_cap = 0; }
+                    if (hipMalloc(&h->l_split, need * sizeof(float)) == hipSuccess) h->l_split_cap = need; else (void)hipGetLastError();
+                }
+                if (need <= h->l_split_cap) {
+                    EhGemmArgs p = g;
+                    p.C = h->l_split; p.ldc = g.N; p.c_zstride = (long long)g.M * g.N; p.kchunk = kc; p.colsum = nullptr; p.bias = nullptr; p.H = nullptr; p.Z = nullptr;
+                    const dim3 g64((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)ns);
+                    hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EH_GEPI_STORE, true, 64>), g64, dim3(256), 0, h->stream, p);
+                    const long long tot = (long long)g.M * g.N;
+                    hipLaunchKernelGGL(eh_splitk_combine_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream,
+                                       h->l_split, ns, (int)EPI, g);
+                    return;
+                }
+            }
+        }
     }
     const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz);
     const bool vec = !novec && eh_gemm_vec_ok(g, ATR, BTR);

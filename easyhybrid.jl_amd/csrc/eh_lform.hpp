@@ -389,6 +389,26 @@ __global__ __launch_bounds__(256) void eh_thin_dact_kernel(const EhGemmArgs g) {
     }
 }
 
+// Split-K for products with few rows (small minibatches): M <= 256 rows give one or four 64 x 64 tiles per 64 output columns -- 8-16
+// workgroups on 256 CUs, each a dependent chain of eight MFMAs per 16-deep step, 17 us for a 1 024-deep product -- so the k range is
+// split over blockIdx.z into partial products (plain stores, [z][M][N]) and this pass adds them in z order (deterministic) and applies
+// the epilogue the tiled kernel would have: bias + activation (+ the pre-activation for swish), or act' of the stored activation.
+__global__ __launch_bounds__(256) void eh_splitk_combine_kernel(const float* part, int nz, int epi, const EhGemmArgs g) {
+    const long long tot = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int m = (int)(e / g.N), n = (int)(e - (long long)m * g.N);
+        float v = 0.0f;
+        for (int z = 0; z < nz; ++z) v += part[(long long)z * tot + e];
+        if (epi == EH_GEPI_BIAS_ACT) {
+            v += g.bias[n];
+            if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
+            g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
+        } else {
+            g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
+        }
+    }
+}
+
 // The minibatch as the GEMMs want it: Xb [count][P] = the predictors of samples idx[first + i] (or first + i), normalised by the
 // input BatchNorm when the model has one (train mode: the statistics of THIS minibatch from eh_bn_stats_kernel's partial sums, and
 // block 0 advances the running statistics; test mode: the running statistics in `meta`).
