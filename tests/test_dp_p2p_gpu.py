@@ -58,3 +58,25 @@ def test_two_ranks_distributed_train_front_door():
     # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm, and a two-target model with per-target losses
     lines = _run({"EH_MAX_BLOCKS": "64"}, 29563, tool="train_two_ranks.py")
     assert len(lines) == 6 and all("results_identical_across_ranks=True" in l for l in lines), lines      # (single target +- BatchNorm, two targets) x two ranks
+
+
+def test_bench_gpus_2_launches_its_own_ranks_and_prints_a_self_describing_line():
+    """`python bench.py --gpus 2` with no launcher: the script spawns its two ranks itself, before anything touches
+    a GPU; on this one-GPU box both ranks share device 0 (EH_BENCH_SHARE_GPU=1: gloo carries the collectives, the numbers are
+    meaningless), which walks the whole multi-rank flow -- N = 1 reference, exchange negotiation and calibration, timed region, line."""
+    import json
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU; run this file first (or alone)")
+    env = dict(os.environ, EH_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["ranks_seen"] == 2 and cfg["launcher"] == "bench.py:spawn_ranks" and cfg["parallelism"] == "dp2" and cfg["global_batch"] == 2 * 65536
+    assert [d["rank"] for d in cfg["rank_devices"]] == [0, 1]
+    assert "gradient_exchange" in cfg and line["n1_reference"]["value"] > 0 and 0 < line["weak_scaling_vs_n1_in_this_run"] < 2
+    assert line["roofline"]["bursts_timed"] >= 5
