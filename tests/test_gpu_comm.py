@@ -204,3 +204,32 @@ def test_multi_target_model_under_the_local_group_fused_and_layerwise_form(hidde
     assert np.array_equal(engs[0].get_params(), engs[1].get_params())
     for e in engs:
         e.close()
+
+
+def test_local_group_with_input_batchnorm_uses_the_statistics_of_the_global_minibatch():
+    """input BatchNorm under the local group: the members' shifted sums are exchanged ahead of the pass (EH_BUF_BNSTAT), so every replica
+    normalises with the mean / variance of the whole minibatch as one Lux BatchNorm would (src/models/NNModels.jl:97-105) and advances
+    the same running statistics"""
+    B, world = 2048, 2
+    spec, theta, X, f, y = util.rbq10_case(B, "tanh", True, 0.1)
+    spec.input_batchnorm = True
+    X = (X * np.float32(3.0) + np.float32(1.5)).astype(np.float32)
+    engs = _shard_engines(spec, theta, X, f, y, world)
+    shift = X.mean(axis=1).astype(np.float32)                      # the common shift of the sums (any vector, the same on every member)
+    for e in engs:
+        e.set_bn_shift(shift)
+    HybridEngine.comm_init_local(engs)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    per = B // world
+    for s in range(4):
+        a = (s % 2) * (per // 2)
+        HybridEngine.dp_train_step_group(engs, [a] * world, per // 2)
+        idx = np.concatenate([np.arange(r * per + a, r * per + a + per // 2) for r in range(world)]).astype(np.int32)
+        ref.train_step(0, idx.size, want_loss=False, idx=idx)
+    assert np.array_equal(engs[0].get_params(), engs[1].get_params())
+    assert np.max(np.abs(engs[0].get_params() - ref.get_params())) <= 3e-6
+    (m0, v0), (mr, vr) = engs[0].get_bn_state(), ref.get_bn_state()
+    assert np.allclose(m0, mr, rtol=2e-6, atol=2e-6) and np.allclose(v0, vr, rtol=2e-5)
+    for e in engs:
+        e.close()
+    ref.close()

@@ -253,3 +253,18 @@ def test_moment_losses(kind):
     l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kind)
     assert nv == sum(nv0) and abs(loss - l0) <= 1e-4 * abs(l0) and util.relerr(grad, g0) <= 1e-4, (loss, l0, util.relerr(grad, g0))
     eng.close()
+
+
+@pytest.mark.parametrize("B", [1, 7, 64, 200, 256, 257])
+@pytest.mark.parametrize("hidden", [(256, 128, 144), (300, 130), (512, 64, 32, 16)])
+def test_small_minibatches_take_the_split_k_and_streaming_kernels(B, hidden):
+    """M <= 256 rows: products with K >= 128 (a multiple of 16, aligned operands) are split over k into partial products plus a combine
+    pass; products with a degenerate dimension are streaming kernels; the others stay on the tiled kernel.  Every batch size around the
+    boundaries, against the fp64 oracle; and the bits must not depend on which way a product went beyond the summation order (1e-5)."""
+    spec, theta, X, f, y = util.rbq10_case(max(B, 8), "tanh", True, 0.1 if B > 8 else 0.0, hidden=hidden)
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad(eh.EH_SPLIT_TRAIN, 0, B)
+    sl = slice(0, B)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()})
+    assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
+    eng.close()

@@ -1666,3 +1666,24 @@ def test_model_without_a_network_through_the_front_door():
         eh.constructHybridModel([], ["ta"], ["reco"], eh.RbQ10, {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}, ["rb"], ["Q10"])      # a neural parameter without predictors
     with pytest.raises(ValueError):
         eh.constructHybridModel([], ["ta"], ["reco"], eh.RbQ10, {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}, [], [])               # nothing to train
+
+
+def test_model_without_a_network_two_targets_and_per_target_losses():
+    """FluxPart (NEE, GPP) with RUE, Rb and Q10 all global: three raw parameters, two targets with their own gaps, each target its own
+    loss -- rmse on a multi-target model takes the two forward passes (here: two runs of the mechanistic stage)"""
+    rng = np.random.default_rng(12)
+    B = 2500
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(0, [], "fluxpart", pars, [], ["RUE", "Rb", "Q10"], ["NEE", "GPP"], "tanh", False)
+    X = np.zeros((0, B), np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 30).astype(np.float32)}
+    y["NEE"][rng.random(B) < 0.3] = np.nan; y["GPP"][rng.random(B) < 0.1] = np.nan
+    theta = (ho.init_theta(spec, 1, np.float32) + np.float32(0.2)).astype(np.float32)
+    for kinds in (("mse", "mse"), ("mae", "rmse"), ("rmse", "nseLoss")):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_training_loss(eh.PerTarget(kinds) if kinds[0] != kinds[1] else kinds[0])
+        loss, grad, nv = eng.loss_and_grad()
+        l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kinds)
+        assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (kinds, loss, l0, util.relerr(grad, g0))
+        eng.close()
