@@ -115,7 +115,8 @@ class TrainConfig:
     #   specialize   "auto" (default): step kernels compiled at run time (hiprtc) with this model's descriptor as a compile-time
     #                constant, in a background thread -- training starts on the kernels built ahead of time and switches when the
     #                compiled one is ready (about a second; instant from the disk cache).  True: compile before the first step.
-    #                False: only the kernels built ahead of time.
+    #                False: only the kernels built ahead of time.  The two binaries agree to ~1e-6, not bit for bit, and "auto"
+    #                switches at a timing-dependent step: bit-for-bit reproducible runs use True or False with fused_update = False.
     #   fused_update "auto" (default): one kernel per step where the model allows it (single target, per-wave kernel family, no
     #                weight_l2 / moment-based loss) -- the optimiser update of a step runs in the prologue of the next one and the
     #                partial sums meet through float atomics, so results are reproducible to ~1e-7, not bitwise.  False: the
