@@ -111,6 +111,7 @@ SIGNATURES = {
     "eh_profile_samples": (C.c_int32, [_H, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
     "eh_jit_status": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_char_p, C.c_int64]),
     "eh_set_loss_program": (C.c_int32, [_H, C.POINTER(C.c_uint32), C.c_int32, _F, C.c_int32, C.c_int32]),
+    "eh_set_target_loss_program": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, _F, C.c_int32, C.c_int32]),
     "eh_debug_stamps": (C.c_int32, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "eh_set_option": (C.c_int32, [_H, C.c_char_p, C.c_int64]),
     "eh_set_target_losses": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_int32]),

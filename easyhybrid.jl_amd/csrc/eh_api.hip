@@ -1553,10 +1553,11 @@ int32_t eh_synchronize(eh_handle* h) {
     return EH_OK;
 }
 
-int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot) {
+// target < 0: the program of every target that has none of its own; 0 <= target < T: that target's own
+static int set_loss_program(eh_handle* h, int target, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot, const char* who) {
     if (!h || !code || (n_const > 0 && !consts)) return EH_EINVAL;
-    if (n_instr < 1 || n_instr > EH_MAX_PROG) return fail(h, EH_EUNSUPPORTED, "eh_set_loss_program: %d instructions (1..%d)", n_instr, EH_MAX_PROG);
-    if (n_const < 0 || n_const > EH_MAX_PROG_CONST) return fail(h, EH_EUNSUPPORTED, "eh_set_loss_program: %d constants (0..%d)", n_const, EH_MAX_PROG_CONST);
+    if (n_instr < 1 || n_instr > EH_MAX_PROG) return fail(h, EH_EUNSUPPORTED, "%s: %d instructions (1..%d)", who, n_instr, EH_MAX_PROG);
+    if (n_const < 0 || n_const > EH_MAX_PROG_CONST) return fail(h, EH_EUNSUPPORTED, "%s: %d constants (0..%d)", who, n_const, EH_MAX_PROG_CONST);
     auto slot_ok = [&](unsigned sl, int upto) {
         if (sl < EH_PROG_SLOT_CONST) return sl < 2u;                                   // yhat, y
         if (sl < EH_PROG_SLOT_INSTR) return (int)sl - EH_PROG_SLOT_CONST < n_const;
@@ -1564,20 +1565,30 @@ int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr,
     };
     for (int i = 0; i < n_instr; ++i) {
         const unsigned w = code[i], op = w & 255u;
-        if (op >= EH_OP_COUNT) return fail(h, EH_EUNSUPPORTED, "eh_set_loss_program: instruction %d has unknown opcode %u", i, op);
+        if (op >= EH_OP_COUNT) return fail(h, EH_EUNSUPPORTED, "%s: instruction %d has unknown opcode %u", who, i, op);
         const int nop = (op == EH_OP_SELECT) ? 3 : (op == EH_OP_NEG || op == EH_OP_EXP || op == EH_OP_LOG || op == EH_OP_SQRT || op == EH_OP_TANH ||
                                                     op == EH_OP_SIGMOID || op == EH_OP_ABS || op == EH_OP_SIN || op == EH_OP_COS) ? 1 : 2;
         const unsigned sl[3] = {(w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
         for (int k = 0; k < 3; ++k)
-            if (k < nop ? !slot_ok(sl[k], i) : sl[k] != 0u) return fail(h, EH_EINVAL, "eh_set_loss_program: instruction %d, operand %d names slot %u (undefined at that point, or a non-zero unused operand)", i, k, sl[k]);
+            if (k < nop ? !slot_ok(sl[k], i) : sl[k] != 0u) return fail(h, EH_EINVAL, "%s: instruction %d, operand %d names slot %u (undefined at that point, or a non-zero unused operand)", who, i, k, sl[k]);
     }
-    if (out_slot < 0 || !slot_ok((unsigned)out_slot, n_instr)) return fail(h, EH_EINVAL, "eh_set_loss_program: output slot %d", out_slot);
+    if (out_slot < 0 || !slot_ok((unsigned)out_slot, n_instr)) return fail(h, EH_EINVAL, "%s: output slot %d", who, out_slot);
     if (h->net.loss == EH_LOSS_PROGRAM) { HIPCHK(h, hipSetDevice(h->device)); FLUSH(h); }
-    h->loss_prog.code.assign(code, code + n_instr);
-    h->loss_prog.consts.assign(consts, consts + n_const);
-    h->loss_prog.out = out_slot;
+    EhLossProg1& lp = target < 0 ? static_cast<EhLossProg1&>(h->loss_prog) : h->loss_prog.per[target];
+    lp.code.assign(code, code + n_instr);
+    lp.consts.assign(consts, consts + n_const);
+    lp.out = out_slot;
     h->loss_prog.gen++;
     return EH_OK;
+}
+int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot) {
+    if (h) for (int t = 0; t < EH_MAX_TARG; ++t) h->loss_prog.per[t] = EhLossProg1();        // one function for all targets again
+    return set_loss_program(h, -1, code, n_instr, consts, n_const, out_slot, "eh_set_loss_program");
+}
+int32_t eh_set_target_loss_program(eh_handle* h, int32_t target, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot) {
+    if (!h) return EH_EINVAL;
+    if (target < 0 || target >= h->net.T) return fail(h, EH_EINVAL, "eh_set_target_loss_program: target %d of %d", target, h->net.T);
+    return set_loss_program(h, target, code, n_instr, consts, n_const, out_slot, "eh_set_target_loss_program");
 }
 
 int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
@@ -1591,10 +1602,10 @@ int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
         lt |= (unsigned)kinds[t] << (4 * t);
         same = same && kinds[t] == kinds[0];
         any_prog = any_prog || kinds[t] == EH_LOSS_PROGRAM;
+        if (kinds[t] == EH_LOSS_PROGRAM && !h->loss_prog.has(t)) return fail(h, EH_ESTATE, "eh_set_target_losses: target %d: EH_LOSS_PROGRAM without a program (eh_set_loss_program / eh_set_target_loss_program first)", t);
         any_two = any_two || (kinds[t] >= EH_LOSS_PEARSONLOSS && kinds[t] <= EH_LOSS_PBKGELOSS) || (kinds[t] == EH_LOSS_RMSE && n > 1);
     }
     if (same) return eh_set_option(h, "training_loss", kinds[0]);
-    if (any_prog && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "eh_set_target_losses: EH_LOSS_PROGRAM: call eh_set_loss_program first");
     if (any_prog && h->lform) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) has no run-time compiled kernels: a recorded loss function needs a model the fused kernels hold");
     if (any_two && h->fused) return fail(h, EH_EUNSUPPORTED, "rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step: switch fused_update off first");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1665,7 +1676,9 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "training_loss")) {
         if (value < EH_LOSS_MSE || value > EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "training_loss %lld is not implemented on the device", (long long)value);
-        if (value == EH_LOSS_PROGRAM && h->loss_prog.code.empty()) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
+        if (value == EH_LOSS_PROGRAM)
+            for (int t = 0; t < h->net.T; ++t)
+                if (!h->loss_prog.has(t)) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
         const bool two = (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS) || (value == EH_LOSS_RMSE && h->net.T > 1);
         if (two && h->fused) return fail(h, EH_EUNSUPPORTED, "rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step: switch fused_update off first");
         if (h->lform && value == EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) has no run-time compiled kernels: a recorded loss function needs a model the fused kernels hold");

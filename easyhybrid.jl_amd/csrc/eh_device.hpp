@@ -1145,7 +1145,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #ifdef EH_JIT_LOSS
                         else if (eh_target_prog(net.loss_t, t)) {
                             float dl;
-                            const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
+                            const float lv = eh_jit_loss(t, y, valid ? yobs[t] : y, dl);
                             lacc += valid ? w * lv : 0.0f;
                             d = valid ? w * dl : 0.0f;
                         }

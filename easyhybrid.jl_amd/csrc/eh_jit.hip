@@ -149,7 +149,7 @@ std::string const_decls(const float* c, int n) {
 }
 }   // namespace
 
-std::string eh_jit_loss_source(const EhLossProg& lp) {
+static std::string eh_jit_loss_one(const EhLossProg1& lp, const char* fname) {
     const int n = (int)lp.code.size();
     auto val = [](unsigned sl) -> std::string {
         char b[32];
@@ -167,7 +167,7 @@ std::string eh_jit_loss_source(const EhLossProg& lp) {
         return b;
     };
     char b[160];
-    std::string s = "__device__ __forceinline__ float eh_jit_loss(float yhat, float yobs, float& dl) {\n" + const_decls(lp.consts.data(), (int)lp.consts.size());
+    std::string s = std::string("__device__ __forceinline__ float ") + fname + "(float yhat, float yobs, float& dl) {\n" + const_decls(lp.consts.data(), (int)lp.consts.size());
     snprintf(b, sizeof b, "    float t[%d], at[%d] = {}, ayh = 0.0f, ac = 0.0f;\n", n, n);
     s += b;
     for (int i = 0; i < n; ++i) { snprintf(b, sizeof b, "    t[%d] = ", i); s += b + fwd_expr(lp.code[i], val) + ";\n"; }
@@ -177,6 +177,19 @@ std::string eh_jit_loss_source(const EhLossProg& lp) {
         s += b + rev_stmts(lp.code[i], val, adj) + " (void)r; }\n";
     }
     s += "    dl = ayh; (void)ac;\n    return " + val((unsigned)lp.out) + ";\n}\n";
+    return s;
+}
+// one function per target that has a program (its own, or the common one), and the dispatcher the kernels call with the (unrolled,
+// hence compile-time) target index
+std::string eh_jit_loss_source(const EhLossProg& lp) {
+    std::string s;
+    char b[96];
+    for (int t = 0; t < 4; ++t)
+        if (lp.has(t)) { snprintf(b, sizeof b, "eh_jit_loss_%d", t); s += eh_jit_loss_one(lp.of(t), b); }
+    s += "__device__ __forceinline__ float eh_jit_loss(int target, float yhat, float yobs, float& dl) {\n    switch (target) {\n";
+    for (int t = 0; t < 4; ++t)
+        if (lp.has(t)) { snprintf(b, sizeof b, "        case %d: return eh_jit_loss_%d(yhat, yobs, dl);\n", t, t); s += b; }
+    s += "        default: dl = 0.0f; return 0.0f;\n    }\n}\n";
     return s;
 }
 

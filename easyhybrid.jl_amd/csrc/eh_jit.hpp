@@ -17,13 +17,18 @@ struct EhJitKernel {
 };
 
 // a recorded custom training loss (eh_set_loss_program): value slot 0 = yhat, 1 = y
-struct EhLossProg {
+struct EhLossProg1 {
     std::vector<unsigned> code;
     std::vector<float> consts;
     int out = 0;
-    int gen = 0;          // bumped by every eh_set_loss_program: part of the cache key of the compiled kernels
 };
-// the generated eh_jit_loss.inc: float eh_jit_loss(float yhat, float yobs, float& dl)
+struct EhLossProg : EhLossProg1 {          // the program every target without one of its own uses (eh_set_loss_program) ...
+    EhLossProg1 per[4];                    // ... and the targets' own (eh_set_target_loss_program; PerTarget((f, g)), compute_loss.jl:128-145)
+    int gen = 0;          // bumped by every eh_set_*loss_program: part of the cache key of the compiled kernels
+    const EhLossProg1& of(int t) const { return per[t].code.empty() ? static_cast<const EhLossProg1&>(*this) : per[t]; }
+    bool has(int t) const { return !of(t).code.empty(); }
+};
+// the generated eh_jit_loss.inc: float eh_jit_loss(int target, float yhat, float yobs, float& dl)
 std::string eh_jit_loss_source(const EhLossProg& lp);
 // the generated eh_jit_mech.inc (EhJitTape, eh_jit_fwd, eh_jit_rev) for a validated descriptor
 std::string eh_jit_mech_source(const eh_model_desc& d);

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
 #ifdef EH_JIT_LOSS
                         else if (eh_target_prog(net.loss_t, t)) {
                             float dl;
-                            const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
+                            const float lv = eh_jit_loss(t, y, valid ? yobs[t] : y, dl);
                             lacc += valid ? w * lv : 0.0f;
                             d = valid ? w * dl : 0.0f;
                         }

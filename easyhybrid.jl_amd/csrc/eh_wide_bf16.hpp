@@ -161,7 +161,7 @@ __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepA
 #ifdef EH_JIT_LOSS
                 else if (eh_target_prog(net.loss_t, t)) {
                     float dl;
-                    const float lv = eh_jit_loss(y, valid ? yobs[t] : y, dl);
+                    const float lv = eh_jit_loss(t, y, valid ? yobs[t] : y, dl);
                     A.lacc += valid ? w * lv : 0.0f;
                     d = valid ? w * dl : 0.0f;
                 }

@@ -205,14 +205,20 @@ class HybridEngine:
         if isinstance(name, (list, tuple)):                      # PerTarget: one loss per target (compute_loss.jl:128-145)
             if len(name) != len(self.target_names):
                 raise AssertionError("Length of targets and PerTarget losses tuple must match")
-            fns = [n for n in name if callable(n)]
-            if any(f is not fns[0] for f in fns):
-                raise NotImplementedError("PerTarget: one recorded loss function per model (the step kernel is compiled around a single one)")
+            def bind(n):                                         # (f, args) / (f, kwargs) / (f, args, kwargs) per target, loss_fn.jl:92-107
+                if isinstance(n, (list, tuple)) and n and callable(n[0]):
+                    f_, rest = n[0], list(n[1:])
+                    a_ = next((tuple(r) for r in rest if isinstance(r, (tuple, list))), ())
+                    k_ = next((dict(r) for r in rest if isinstance(r, dict)), {})
+                    return lambda yh, y, _f=f_, _a=a_, _k=k_: _f(yh, y, *_a, **_k)
+                return n
+            name = [bind(n) for n in name]
             for n in name:
                 if not callable(n) and n not in L.TRAINING_LOSSES:
                     raise NotImplementedError(f"training loss {n!r} is not implemented on the device (have {sorted(L.TRAINING_LOSSES)})")
-            if fns:
-                self._set_loss_program(fns[0])
+            for t, n in enumerate(name):
+                if callable(n):
+                    self._set_loss_program(n, target=t)          # every function its own program
             kinds = (C.c_int32 * len(name))(*[L.EH_LOSS_PROGRAM if callable(n) else L.TRAINING_LOSSES[n] for n in name])
             self._chk(self._lib.eh_set_target_losses(self._h, kinds, len(name)))
             return
@@ -224,13 +230,17 @@ class HybridEngine:
             raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
         self.set_option("training_loss", L.TRAINING_LOSSES[name])
 
-    def _set_loss_program(self, fn):
-        """record f(yhat, y) = mean of per-sample terms (program.trace_loss) and hand it to the library (eh_set_loss_program)"""
+    def _set_loss_program(self, fn, target=None):
+        """record f(yhat, y) = mean of per-sample terms (program.trace_loss) and hand it to the library: for every target
+        (eh_set_loss_program) or for one (eh_set_target_loss_program)"""
         from .program import trace_loss
         pg = trace_loss(fn)
         words = (C.c_uint32 * len(pg.code))(*pg.words())
         consts = (C.c_float * max(1, len(pg.consts)))(*pg.consts)
-        self._chk(self._lib.eh_set_loss_program(self._h, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
+        if target is None:
+            self._chk(self._lib.eh_set_loss_program(self._h, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
+        else:
+            self._chk(self._lib.eh_set_target_loss_program(self._h, int(target), words, len(pg.code), consts, len(pg.consts), pg.out[0]))
 
     def set_weight_l2(self, lam: float, normalize: bool = False):
         """extra_loss = lam * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91); lam = 0 switches it off"""

@@ -197,16 +197,38 @@ _UFUNCS = {
 }
 
 class MeanOf:
-    """np.mean(<traced per-sample value>): the only reduction a recorded training loss may end in."""
+    """np.mean(<traced per-sample value>): the only reduction a recorded training loss may end in.  What is linear in the mean stays
+    a mean -- `w * mean(l)`, `mean(l) / c`, `mean(l) + c`, `mean(a) + mean(b)` (the reference's own test scales one:
+    test/test_compute_loss.jl:36-47) -- anything else applied to it (sqrt, powers, a ratio of means) is refused."""
     def __init__(self, sym: "Sym"):
         self.sym = sym
 
     def _no(self, *a, **k):
-        raise NotImplementedError("a recorded training loss has the form mean(l(yhat, y)): nothing can be applied to the mean "
+        raise NotImplementedError("a recorded training loss has the form mean(l(yhat, y)): nothing but scaling / shifting can be applied to the mean "
                                   "(sqrt(mean(...)) etc. are the built-in rmse / nseLoss / kgeLoss)")
-    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __pow__ = __rpow__ = __neg__ = __abs__ = _no
 
-    def __array_ufunc__(self, *a, **k):
+    @staticmethod
+    def _num(x):
+        return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
+
+    def __mul__(self, c): return MeanOf(self.sym * float(c)) if self._num(c) else self._no()
+    __rmul__ = __mul__
+    def __truediv__(self, c): return MeanOf(self.sym / float(c)) if self._num(c) else self._no()
+    def __neg__(self): return MeanOf(-self.sym)
+    def __add__(self, o): return MeanOf(self.sym + (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or isinstance(o, MeanOf)) else self._no()
+    __radd__ = __add__
+    def __sub__(self, o): return MeanOf(self.sym - (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or isinstance(o, MeanOf)) else self._no()
+    def __rsub__(self, o): return MeanOf(float(o) - self.sym) if self._num(o) else self._no()
+    __rtruediv__ = __pow__ = __rpow__ = __abs__ = _no
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **k):
+        if method == "__call__" and not k and ufunc.__name__ in ("multiply", "add", "subtract", "true_divide", "divide", "negative") and len(inputs) <= 2:
+            a = inputs[0]; b = inputs[1] if len(inputs) > 1 else None
+            if ufunc.__name__ == "negative": return -self
+            if ufunc.__name__ == "multiply": return (a if isinstance(a, MeanOf) else b) * (b if isinstance(a, MeanOf) else a)
+            if ufunc.__name__ == "add": return (a if isinstance(a, MeanOf) else b) + (b if isinstance(a, MeanOf) else a)
+            if ufunc.__name__ == "subtract": return a - b if isinstance(a, MeanOf) else b.__rsub__(a)
+            if isinstance(a, MeanOf): return a / b
         self._no()
 
 

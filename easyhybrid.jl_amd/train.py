@@ -162,7 +162,7 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
     per_target = tl.losses if isinstance(tl, PerTarget) else (tl if isinstance(tl, (list, tuple)) and tl and not callable(tl[0]) else None)
     if per_target is not None:                                   # PerTarget((l_1, ..., l_T)), compute_loss.jl:128-145
         for lt in per_target:
-            if callable(lt):                                     # a function: recorded and compiled into the step kernel
+            if callable(lt) or (isinstance(lt, (list, tuple)) and lt and callable(lt[0])):      # a function, or (f, args) / (f, kwargs): recorded and compiled into the step kernel
                 continue
             check_training_loss(lt)
             if lt not in L.TRAINING_LOSSES:

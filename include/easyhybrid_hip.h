@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 3      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group */
+#define EH_ABI_VERSION 3      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group, eh_set_target_loss_program */
 #define EH_MAX_HIDDEN 8       /* hidden layers: up to 3 run as ONE fused kernel per step, more (or widths above 128) layer by layer (csrc/eh_lform.hpp) */
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
@@ -402,6 +402,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value);
  * eh_set_option(h, "training_loss", EH_LOSS_PROGRAM).  It exists only in kernels compiled at run time (hiprtc): without them
  * the training calls fail with EH_EUNSUPPORTED -- there is no interpreted or CPU form. */
 int32_t eh_set_loss_program(eh_handle* h, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot);
+/* the same for ONE target of a multi-target model (PerTarget((f, g)) with different functions, src/losses/compute_loss.jl:128-145;
+ * the reference's own test: test/test_compute_loss.jl:56-62): target t then uses this program where its kind is EH_LOSS_PROGRAM,
+ * the others the common one of eh_set_loss_program (which also clears the per-target ones). */
+int32_t eh_set_target_loss_program(eh_handle* h, int32_t target, const uint32_t* code, int32_t n_instr, const float* consts, int32_t n_const, int32_t out_slot);
 
 /* loss_spec = PerTarget((l_1, ..., l_T)) (src/losses/compute_loss.jl:128-145): target t is trained on its own loss, the total is
  * their sum (agg = sum).  Built per target: EH_LOSS_MSE, EH_LOSS_MAE, EH_LOSS_NSELOSS -- the losses whose per-sample weight is a

@@ -141,3 +141,34 @@ def test_recorded_loss_function_on_a_multi_target_model(hidden):
         l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=spec_kinds)
         assert nv == sum(nv0) and abs(loss - l0) <= 1e-5 * abs(l0) and util.relerr(grad, g0) <= 2e-5, (spec_kinds, loss, l0, util.relerr(grad, g0))
         eng.close()
+
+
+def test_per_target_custom_losses_as_in_the_reference_test():
+    """test/test_compute_loss.jl:44-62 on the device: PerTarget((:mse, custom_loss)) = mse(target 1) + custom(target 2), and
+    PerTarget(((weighted_loss, (0.5,)), (scaled_loss, (scale = 2.0,)))) = 0.5 mse(target 1) + 2 mse(target 2) -- two DIFFERENT
+    functions, each recorded into its own program (eh_set_target_loss_program)"""
+    def custom_loss(yh, y):
+        return np.mean((yh - y) ** 2)
+
+    def weighted_loss(yh, y, w):
+        return w * np.mean((yh - y) ** 2)
+
+    def scaled_loss(yh, y, scale=1.0):
+        return scale * np.mean((yh - y) ** 2)
+    spec, theta, X, f, y = _flux_case((16, 16))
+    eng = util.load_engine(spec, theta, X, f, y)
+    # the per-target mse values from the oracle: l_1, l_2 with loss = l_1 + l_2
+    l_sum, g_sum, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=("mse", "mse"))
+    ynan = dict(y); ynan["GPP"] = np.full_like(y["GPP"], np.nan)
+    l1, g1, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, ynan, kind=("mse", "mse"))          # target 1 alone
+    l2, g2 = l_sum - l1, g_sum - g1
+    eng.set_training_loss(eh.PerTarget(("mse", custom_loss)))
+    loss, grad, _ = eng.loss_and_grad()
+    assert abs(loss - (l1 + l2)) <= 1e-5 * abs(l1 + l2) and util.relerr(grad, g1 + g2) <= 2e-5
+    eng.set_training_loss(eh.PerTarget(((weighted_loss, (0.5,)), (scaled_loss, {"scale": 2.0}))))
+    loss, grad, _ = eng.loss_and_grad()
+    want_l, want_g = 0.5 * l1 + 2.0 * l2, 0.5 * g1 + 2.0 * g2
+    assert abs(loss - want_l) <= 1e-5 * abs(want_l) and util.relerr(grad, want_g) <= 2e-5, (loss, want_l, util.relerr(grad, want_g))
+    with pytest.raises(AssertionError):
+        eng.set_training_loss(eh.PerTarget(("mse",)))             # mismatched number of losses and targets
+    eng.close()

@@ -163,8 +163,16 @@ def test_custom_loss_program_value_and_derivative(name):
 
 
 def test_a_loss_that_is_not_a_mean_of_per_sample_terms_is_refused():
-    with pytest.raises(NotImplementedError, match="nothing can be applied to the mean"):
+    with pytest.raises(NotImplementedError, match="nothing but scaling / shifting can be applied to the mean"):
         P.trace_loss(lambda yh, y: np.sqrt(np.mean((yh - y) ** 2)))
+    with pytest.raises(NotImplementedError, match="nothing but scaling"):
+        P.trace_loss(lambda yh, y: np.mean((yh - y) ** 2) / np.mean(y * y))
+    # what is linear in the mean stays a mean (the reference's own test scales one: test/test_compute_loss.jl:36-47)
+    a = P.trace_loss(lambda yh, y: 0.5 * np.mean((yh - y) ** 2))
+    b = P.trace_loss(lambda yh, y: np.mean((yh - y) ** 2 * 0.5))
+    assert a.code == b.code and a.consts == b.consts
+    c = P.trace_loss(lambda yh, y: np.mean(np.abs(yh - y)) / 4 + np.mean((yh - y) ** 2) - 1.0)
+    assert len(c.code) >= 5
     with pytest.raises(NotImplementedError, match="only elementwise"):
         P.trace_loss(lambda yh, y: np.sum((yh - y) ** 2))
     with pytest.raises(TypeError):
