@@ -1091,7 +1091,7 @@ static hipError_t lform_prepare(void) { return hipSuccess; }
 static hipError_t lform_launch(int, int, int, int, hipStream_t, const EhNet*, const EhStepArgs*) { return hipErrorNotSupported; }
 static const EhArchInfo g_lform_arch = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, /*phi_off*/ 0, /*img_floats*/ EH_IMG_META, /*has_fast*/ 0, /*nvar*/ 1,
                                         {{4, 4, 0, 1 << 30, &lform_prepare, &lform_launch, 1, 0}, {}, {}, {}}, /*wide*/ 1};
-enum { EH_LFORM_ROWS = 32 };      // partial slabs of the weight gradients (split over the samples of a minibatch)
+enum { EH_LFORM_ROWS = 64 };      // partial slabs of the weight gradients (split over the samples of a minibatch)
 
 static bool arch_fits(const EhArchInfo* A, int need) {
     for (int vi = 0; vi < A->nvar; ++vi)
@@ -1998,7 +1998,10 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     EhLWs W;
     if (int rc = lform_workspace(h, std::max<long long>(count, 1), &W)) return rc;
     const int B = (int)count;
-    const int rows = (int)std::max<long long>(1, std::min<long long>(EH_LFORM_ROWS, (count + 2047) / 2048));
+    // slab rows = sample chunks the weight-gradient products are split over (their only source of parallelism beyond the tiles of the
+    // weight matrix itself): >= EH_LFORM_CHUNK samples each, at most EH_LFORM_ROWS of them
+    static const long long lchunk = getenv("EH_LFORM_CHUNK") ? std::max(64, atoi(getenv("EH_LFORM_CHUNK"))) : 128;
+    const int rows = (int)std::max<long long>(1, std::min<long long>(EH_LFORM_ROWS, (count + lchunk - 1) / lchunk));
     const int chunk = std::max(16, (int)(((count + rows - 1) / rows + 15) / 16 * 16));
     *rows_out = rows;
     if (net.T > 1 && !h->dp_weights) {        // (data-parallel step: eh_dp_grad has just filled inv_n with the weights of the GLOBAL batch)
@@ -2222,7 +2225,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     // layer-wise form: few slab rows (<= 32) under very many columns (the tutorial net: 700 k): one column per thread -- with 64-column
     // blocks 3 of 4 threads had no row to read and the per-block part (counts, barriers) ran 11 k times: 29.6 us of a 250 us step at
     // B = 64 (tools/lform_trace.sh)
-    const bool tall = cw_env ? cw_env == 256 : (h->lform && grid <= 32 && h->n_acc >= 16384);
+    const bool tall = cw_env ? cw_env == 256 : (h->lform && grid <= (int)EH_LFORM_ROWS && h->n_acc >= 16384);
     const int rgrid = tall ? (h->n_acc + 255) / 256 : big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
