@@ -1922,6 +1922,18 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
     if constexpr (EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_DACT) {
         // few rows, deep k: split-K into partial products + a combine pass (eh_splitk_combine_kernel)
         static const bool nosplit = getenv("EH_GEMM_NOSPLIT") != nullptr;
+        static const bool nofew = getenv("EH_GEMM_NOFEWROWS") != nullptr;
+        static const int fewmax = getenv("EH_GEMM_FEWROWS_MAX") ? atoi(getenv("EH_GEMM_FEWROWS_MAX")) : 256;
+        if constexpr (!ATR) {
+            // ... or, without the combine pass, one 16 x 16 tile per workgroup with the k range split over its waves (eh_fewrows_gemm_kernel)
+            if (!novec && !nofew && nz == 1 && g.M <= fewmax && g.K >= 64 && g.kchunk >= g.K && eh_gemm_vec_ok(g, ATR, BTR)) {
+                EhGemmArgs p = g;
+                p.kchunk = std::max(16, ((g.K + 15) / 16 + 15) / 16 * 16);         // <= 16 slices of whole 16-deep groups
+                const int nw = (g.K + p.kchunk - 1) / p.kchunk;
+                hipLaunchKernelGGL((eh_fewrows_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nw), 0, h->stream, p);
+                return;
+            }
+        }
         if (!novec && !nosplit && nz == 1 && g.M <= 256 && g.K >= 128 && g.kchunk >= g.K && eh_gemm_vec_ok(g, ATR, BTR)) {
             int kc = std::max(32, ((g.K + 15) / 16 + 15) / 16 * 16);          // ~16 parts, whole 16-deep steps
             const int ns = (g.K + kc - 1) / kc;

@@ -409,6 +409,63 @@ __global__ __launch_bounds__(256) void eh_splitk_combine_kernel(const float* par
     }
 }
 
+// Products with few rows and a deep k without the combine pass: one 16 x 16 output tile per workgroup, the k range split over its
+// (up to 16) waves.  A wave's operands go straight from global memory into registers, 64 k per round with every load of the round in
+// flight at once (v_mfma_f32_16x16x4_f32: lane (r, q) supplies A[m0 + r][k] and B[k][n0 + r] for k = kb + 4 q + i in step i of a
+// 16-deep group -- any partition of the k range into fours is a valid one as long as both operands use the same); the waves'
+// partial tiles are added in wave order through LDS (deterministic), then the epilogue of the tiled kernel.  A is [m][k] (!ATR).
+// g.kchunk = the k slice of one wave (a multiple of 16); blockDim.x = 64 * number of slices.
+typedef float f32x4_lf __attribute__((ext_vector_type(4)));
+template <bool BTR, int EPI>
+__global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs g) {
+    static_assert(EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_DACT, "epilogues of the small-batch products");
+    __shared__ float red[16][256];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = (int)(blockDim.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int kbeg = wave * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nc = min(n0 + r, g.N - 1);
+    const float* const pa = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * q;
+    const float* const pb = BTR ? g.B + (long long)nc * g.ldb + 4 * q : g.B + (long long)(4 * q) * g.ldb + nc;
+    f32x4_lf acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        f32x4_lf a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kb = k0 + 16 * u;
+            const bool ok = kb < kend;
+            a[u] = ok ? *(const f32x4_lf*)(pa + kb) : f32x4_lf{0.0f, 0.0f, 0.0f, 0.0f};
+            if (BTR) b[u] = ok ? *(const f32x4_lf*)(pb + kb) : f32x4_lf{0.0f, 0.0f, 0.0f, 0.0f};
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[u][i] = ok ? pb[(long long)(kb + i) * g.ldb] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][i], acc, 0, 0, 0);
+    }
+    // C/D layout of the 16x16 MFMA: lane -> column (lane & 15); register i -> row 4 (lane >> 4) + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][(4 * q + i) * 16 + r] = acc[i];
+    __syncthreads();
+    if (tid < 256) {
+        float v = 0.0f;
+        for (int w = 0; w < nw; ++w) v += red[w][tid];
+        const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+        if (m < g.M && n < g.N) {
+            if (EPI == EH_GEPI_BIAS_ACT) {
+                v += g.bias[n];
+                if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
+                g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
+            } else {
+                g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
+            }
+        }
+    }
+}
+
 // The minibatch as the GEMMs want it: Xb [count][P] = the predictors of samples idx[first + i] (or first + i), normalised by the
 // input BatchNorm when the model has one (train mode: the statistics of THIS minibatch from eh_bn_stats_kernel's partial sums, and
 // block 0 advances the running statistics; test mode: the running statistics in `meta`).
