@@ -793,6 +793,7 @@ struct eh_handle_s {
     int l_nnets = 0;                                     // 0: no network at all (no neural parameter)
     LNet l_net[EH_MAX_NETS];
     float* l_split = nullptr; size_t l_split_cap = 0;    // split-K partial products of the small-batch GEMMs
+    float* l_dk = nullptr; size_t l_dk_cap = 0;          // every layer's delta of a small-batch step (the weight gradients then run as one grouped launch)
     float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
     long long l_cap = 0;                                 // samples the workspace holds
     unsigned char* wflag = nullptr;
@@ -1520,7 +1521,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->wflag);
+    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1894,20 +1895,29 @@ static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
     W->part = p;
     return EH_OK;
 }
+static const bool g_gemm_novec = getenv("EH_GEMM_NOVEC") != nullptr;      // (A/B switch of the measurement tools)
+// a weight gradient (A transposed, plain store) with a thin side runs as a streaming kernel (eh_thin_gemm_kernel): its arguments
+static bool lform_thin_args(const EhGemmArgs& g, bool btr, EhThinArgs* out) {
+    if (g_gemm_novec || !(g.M <= 8 || g.N <= 8) || (g.M <= 8 ? btr : !btr)) return false;
+    EhThinArgs t{};
+    t.K = g.K; t.kchunk = g.kchunk; t.C = g.C; t.c_z = g.c_zstride; t.cs_z = g.c_zstride;
+    if (g.M <= 8) {          // few inputs: wide = B (dZ [B x out]), thin = A (the layer's input [B x in])
+        t.wide = g.B; t.ldw = g.ldb; t.ncols = g.N; t.thin = g.A; t.tsb = g.lda; t.tsj = 1; t.J = g.M; t.c_col = 1; t.c_j = g.ldc; t.cs_wide = g.colsum;
+    } else {                 // few outputs, dO stored [K][ldo]: wide = A (the layer's input [B x in]), thin = B
+        t.wide = g.A; t.ldw = g.lda; t.ncols = g.M; t.thin = g.B; t.tsb = 1; t.tsj = g.ldb; t.J = g.N; t.c_col = g.ldc; t.c_j = 1; t.cs_thin = g.colsum;
+    }
+    *out = t;
+    return true;
+}
 template <bool ATR, bool BTR, int EPI>
 static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
-    static const bool novec = getenv("EH_GEMM_NOVEC") != nullptr;      // (A/B switch of the measurement tools)
-    if (EPI == EH_GEPI_STORE && ATR && !novec && (g.M <= 8 || g.N <= 8) && (g.M <= 8 ? !BTR : BTR)) {
-        // a weight gradient with a thin side: streaming kernel (eh_thin_gemm_kernel)
-        EhThinArgs t{};
-        t.K = g.K; t.kchunk = g.kchunk; t.C = g.C; t.c_z = g.c_zstride; t.cs_z = g.c_zstride;
-        if (g.M <= 8) {          // few inputs: wide = B (dZ [B x out]), thin = A (the layer's input [B x in])
-            t.wide = g.B; t.ldw = g.ldb; t.ncols = g.N; t.thin = g.A; t.tsb = g.lda; t.tsj = 1; t.J = g.M; t.c_col = 1; t.c_j = g.ldc; t.cs_wide = g.colsum;
-        } else {                 // few outputs, dO stored [K][ldo]: wide = A (the layer's input [B x in]), thin = B
-            t.wide = g.A; t.ldw = g.lda; t.ncols = g.M; t.thin = g.B; t.tsb = 1; t.tsj = g.ldb; t.J = g.N; t.c_col = g.ldc; t.c_j = 1; t.cs_thin = g.colsum;
+    const bool novec = g_gemm_novec;
+    if constexpr (EPI == EH_GEPI_STORE && ATR) {
+        EhThinArgs t;
+        if (lform_thin_args(g, BTR, &t)) {
+            hipLaunchKernelGGL(eh_thin_gemm_kernel, dim3((unsigned)((t.ncols + 63) / 64), (unsigned)nz), dim3(256), 0, h->stream, t);
+            return;
         }
-        hipLaunchKernelGGL(eh_thin_gemm_kernel, dim3((unsigned)((t.ncols + 63) / 64), (unsigned)nz), dim3(256), 0, h->stream, t);
-        return;
     }
     if (!novec && nz == 1 && g.kchunk >= g.K) {          // products with a degenerate dimension: streaming kernels (eh_lform.hpp)
         const long long tot = (long long)g.M * g.N;
@@ -1923,7 +1933,7 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
         // few rows, deep k: split-K into partial products + a combine pass (eh_splitk_combine_kernel)
         static const bool nosplit = getenv("EH_GEMM_NOSPLIT") != nullptr;
         static const bool nofew = getenv("EH_GEMM_NOFEWROWS") != nullptr;
-        static const int fewmax = getenv("EH_GEMM_FEWROWS_MAX") ? atoi(getenv("EH_GEMM_FEWROWS_MAX")) : 256;
+        static const int fewmax = getenv("EH_GEMM_FEWROWS_MAX") ? atoi(getenv("EH_GEMM_FEWROWS_MAX")) : 1024;
         if constexpr (!ATR) {
             // ... or, without the combine pass, one 16 x 16 tile per workgroup with the k range split over its waves (eh_fewrows_gemm_kernel)
             if (!novec && !nofew && nz == 1 && g.M <= fewmax && g.K >= 64 && g.kchunk >= g.K && eh_gemm_vec_ok(g, ATR, BTR)) {
@@ -1972,10 +1982,14 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
     const int B = (int)count;
     if (h->l_nnets == 0) return EH_OK;        // no network (no neural parameter): the mechanistic stage reads the records itself
     EhStepArgs bn{};
-    if (train_mode) { if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &bn)) return rc; }
+    // (small minibatches: the prep kernel takes the batch statistics itself -- one dependent launch fewer)
+    static const bool nofuse = getenv("EH_LFORM_NOFUSE") != nullptr;
+    const bool bn_self = train_mode && h->bn_on && !h->bn_ext && count > 0 && count <= 256 && !nofuse;
+    if (train_mode && !bn_self) { if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &bn)) return rc; }
     EhLPrepArgs pa{};
     pa.recs = sp.recs; pa.C = h->C; pa.P = net.P; pa.idx = idx; pa.first = first; pa.count = B; pa.Xb = W.Xb; pa.meta = h->image;
     pa.bn_part = bn.bn_part; pa.bn_nblk = bn.bn_nblk; pa.bn_c = bn.bn_c; pa.bn_n = bn.bn_n; pa.bn_update = bn.bn_update; pa.bn_run = h->bn_run;
+    if (bn_self) { pa.bn_self = 1; pa.bn_update = bn_update ? 1 : 0; }
     const long long tot = (long long)B * net.P;
     hipLaunchKernelGGL(eh_lform_prep_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa);
     HIPCHK(h, hipGetLastError());
@@ -2049,15 +2063,44 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         }
     }
     a.inv_n = (net.T > 1 || tpm) ? h->inv_n : nullptr;
-    EhLMechArgs m{W.O, W.ldo, W.part};
+    EhLMechArgs m{W.O, W.ldo, W.part, nullptr, 0, 0};
     const int mgrid = (int)std::min<long long>(2048, (count + 255) / 256);
+    static const bool nofuse = getenv("EH_LFORM_NOFUSE") != nullptr;
+    if (mgrid == 1 && !nofuse) { m.slab = h->slab; m.nrows = rows; m.n_acc = (long long)h->n_acc; }      // one workgroup: it writes the slab's tail columns itself
     if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
     else hipLaunchKernelGGL((eh_lform_mech_kernel<true, false>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(eh_lform_tail_kernel, dim3(1), dim3(256), 0, h->stream, W.part, mgrid, net, h->slab, rows, (long long)h->n_acc);
-    HIPCHK(h, hipGetLastError());
+    if (!m.slab) {
+        hipLaunchKernelGGL(eh_lform_tail_kernel, dim3(1), dim3(256), 0, h->stream, W.part, mgrid, net, h->slab, rows, (long long)h->n_acc);
+        HIPCHK(h, hipGetLastError());
+    }
     // backward, every network from its output layer down; dZ of the output layer = its rows of d loss / d O^T, still [K][ldo]
     const float* theta = TH(h);
+    // Small minibatches: every layer's delta is kept (l_dk), the chain of delta products runs first and the weight gradients -- a
+    // handful of tiles each, 4-6 us per dependent launch -- follow as ONE grouped launch of the tiled ones and one of the thin ones.
+    static const long long lgroup_max = getenv("EH_LFORM_GROUP_MAX") ? atoll(getenv("EH_LFORM_GROUP_MAX")) : 1024;
+    bool grouped = count <= lgroup_max && h->l_nnets > 0;
+    long long dk_floats = 0;
+    if (grouped) {
+        for (int k = 0; k < h->l_nnets; ++k)
+            for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += (long long)lgroup_max * h->l_net[k].out[l];
+        if ((size_t)dk_floats > h->l_dk_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->l_dk); h->l_dk = nullptr; h->l_dk_cap = 0;
+            if (hipMalloc(&h->l_dk, (size_t)dk_floats * sizeof(float)) == hipSuccess) h->l_dk_cap = (size_t)dk_floats;
+            else { (void)hipGetLastError(); grouped = false; }
+        }
+    }
+    EhGemmGroup GG{}; EhThinGroup TG{};
+    auto flush_tiled = [&]() {
+        if (GG.n > 0) hipLaunchKernelGGL((eh_gemm_group_kernel<true, false, EH_GEPI_STORE, true, 64>), dim3((unsigned)GG.t0[GG.n]), dim3(256), 0, h->stream, GG);
+        GG.n = 0;
+    };
+    auto flush_thin = [&]() {
+        if (TG.n > 0) hipLaunchKernelGGL(eh_thin_gemm_group_kernel, dim3((unsigned)TG.t0[TG.n]), dim3(256), 0, h->stream, TG);
+        TG.n = 0;
+    };
+    float* dkp = h->l_dk;
     for (int k = 0; k < h->l_nnets; ++k) {
         const eh_handle_s::LNet& L = h->l_net[k];
         const float* dZ = W.O + (long long)L.orow * W.ldo;
@@ -2071,19 +2114,35 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
             g.A = Hprev; g.lda = ldp; g.B = dZ; g.ldb = dz_t ? W.ldo : out;
             g.C = h->slab + L.woff[l]; g.ldc = out; g.M = in; g.N = out; g.K = B; g.kchunk = chunk; g.c_zstride = h->n_acc;
             g.colsum = h->slab + L.boff[l];      // db_l = column sums of dZ_l, from the same tiles
-            if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
-            HIPCHK(h, hipGetLastError());
+            EhThinArgs ta;
+            if (grouped && lform_thin_args(g, dz_t, &ta)) {
+                if (TG.n == EH_GEMM_GROUP) { flush_thin(); HIPCHK(h, hipGetLastError()); }
+                const int gx = (ta.ncols + 63) / 64;
+                TG.a[TG.n] = ta; TG.gx[TG.n] = gx; TG.t0[TG.n + 1] = TG.t0[TG.n] + gx * rows; ++TG.n;
+            } else if (grouped && !dz_t && eh_gemm_vec_ok(g, true, false)) {
+                if (GG.n == EH_GEMM_GROUP) { flush_tiled(); HIPCHK(h, hipGetLastError()); }
+                const int gx = (g.N + 63) / 64, gy = (g.M + 63) / 64;
+                GG.g[GG.n] = g; GG.gx[GG.n] = gx; GG.gy[GG.n] = gy; GG.t0[GG.n + 1] = GG.t0[GG.n] + gx * gy * rows; ++GG.n;
+            } else {
+                // (in grouped mode too: dZ_l stays where it is until the step ends)
+                if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
+                HIPCHK(h, hipGetLastError());
+            }
             if (l > 0) {                       // dZ_{l-1} [B x in] = (dZ_l [B x out] * W_l [out x in]) .* act'(H_{l-1})  (swish: act' from the stored Z_{l-1})
                 EhGemmArgs b{};
                 b.A = dZ; b.lda = dz_t ? W.ldo : out; b.B = theta + L.woff[l]; b.ldb = out;        // W_l element (k = out, n = in) at n * out + k
-                b.C = W.D[which]; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
+                float* const dnext = grouped ? dkp : W.D[which];
+                if (grouped) dkp += (long long)lgroup_max * in;
+                b.C = dnext; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
                 b.H = L.act == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.act;
                 if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
                 HIPCHK(h, hipGetLastError());
-                dZ = W.D[which]; dz_t = false; which ^= 1;
+                dZ = dnext; dz_t = false; which ^= 1;
             }
         }
     }
+    flush_thin(); HIPCHK(h, hipGetLastError());
+    flush_tiled(); HIPCHK(h, hipGetLastError());
     return EH_OK;
 }
 // forward + metric sums of samples [first, first+count) in chunks; per-workgroup rows of EH_EVAL_STATS * T sums land in the slab

@@ -70,15 +70,15 @@ __device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' fr
 #define EH_GEMM_OCC 4
 #endif
 // BT = 64: 64 x 64 tiles (one MFMA tile per wave) for products too small to fill the chip with 128 x 128 ones.
-template <bool ATR, bool BTR, int EPI, bool VEC = false, int BT = 128>
-__global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmArgs g) {
+template <bool ATR, bool BTR, int EPI, bool VEC, int BT>
+__device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, const int by, const int bz) {
     static_assert(BT == 128 || (BT == 64 && VEC), "64 x 64 tiles exist in the 16-byte-load form only");
     constexpr int BM = BT, BN = BT, BK = 16, LDS_LD = BM + 4, TI = BT / 64, WT = BT / 2, NP = BT / 64, QT = BT / 4, RP = 256 / QT;
     __shared__ __attribute__((aligned(16))) float As[VEC ? 2 : 1][BK][LDS_LD], Bs[VEC ? 2 : 1][BK][LDS_LD];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = (int)blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     f32x16 acc[TI][TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmA
         for (int j = 0; j < TI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const bool do_cs_v = EPI == EH_GEPI_STORE && g.colsum != nullptr && blockIdx.y == 0 && tid < BN;
+    const bool do_cs_v = EPI == EH_GEPI_STORE && g.colsum != nullptr && by == 0 && tid < BN;
     float cs_v = 0.0f;
     if constexpr (VEC) {
         // NP (= BT / 64) 16-byte pieces of each tile per thread and step
@@ -243,9 +243,9 @@ __global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmA
         }
     }
     }
-    if (do_cs && n0 + tid < g.N) g.colsum[(long long)blockIdx.z * g.c_zstride + n0 + tid] = cs;
+    if (do_cs && n0 + tid < g.N) g.colsum[(long long)bz * g.c_zstride + n0 + tid] = cs;
     // C/D layout of the 32x32 MFMA: lane -> column (lane & 31); register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* const C = g.C + (long long)blockIdx.z * g.c_zstride;
+    float* const C = g.C + (long long)bz * g.c_zstride;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -265,6 +265,24 @@ __global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmA
                 }
             }
         }
+}
+
+template <bool ATR, bool BTR, int EPI, bool VEC = false, int BT = 128>
+__global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_kernel(const EhGemmArgs g) {
+    eh_gemm_tile<ATR, BTR, EPI, VEC, BT>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several independent products in one launch (the weight gradients of every layer of a small-batch step, once every delta is there:
+// each of them alone is a handful of tiles, one dependent launch of 4-6 us each): workgroup -> product by its first-tile table.
+enum { EH_GEMM_GROUP = 8 };
+struct EhGemmGroup { EhGemmArgs g[EH_GEMM_GROUP]; int t0[EH_GEMM_GROUP + 1]; int gx[EH_GEMM_GROUP], gy[EH_GEMM_GROUP]; int n; };
+template <bool ATR, bool BTR, int EPI, bool VEC, int BT>
+__global__ __launch_bounds__(256, EH_GEMM_OCC) void eh_gemm_group_kernel(const EhGemmGroup G) {
+    int i = 0;
+    while (i + 1 < G.n && (int)blockIdx.x >= G.t0[i + 1]) ++i;
+    const int t = (int)blockIdx.x - G.t0[i], gx = G.gx[i], gy = G.gy[i];
+    const EhGemmArgs g = G.g[i];
+    eh_gemm_tile<ATR, BTR, EPI, VEC, BT>(g, t % gx, (t / gx) % gy, t / (gx * gy));
 }
 
 // may this product run the 16-byte-load form of eh_gemm_kernel?
@@ -288,12 +306,12 @@ struct EhThinArgs {
     float* C; long long c_col, c_j, c_z;
     float* cs_wide; float* cs_thin; long long cs_z;
 };
-__global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) {
+__device__ __forceinline__ void eh_thin_gemm_tile(const EhThinArgs& a, const int bx, const int by) {
     constexpr int SB = 512, U = 8;              // samples staged per round; wide loads in flight per thread
     __shared__ float sT[8][SB];                 // the thin operand of the round, [j][sample]: every lane of a wave reads the same word (broadcast)
     __shared__ float red[4][64][10];
     __shared__ float redt[4][8];
-    const int tid = threadIdx.x, cl = tid & 63, q = tid >> 6, col = blockIdx.x * 64 + cl, z = blockIdx.y;
+    const int tid = threadIdx.x, cl = tid & 63, q = tid >> 6, col = bx * 64 + cl, z = by;
     const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
     const bool live = col < a.ncols;
     float acc[8], cst[8], csw = 0.0f;
@@ -337,7 +355,17 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) {
             if (j < a.J) a.C[(long long)z * a.c_z + (long long)col * a.c_col + (long long)j * a.c_j] = (red[0][cl][j] + red[1][cl][j]) + (red[2][cl][j] + red[3][cl][j]);
         if (a.cs_wide) a.cs_wide[(long long)z * a.cs_z + col] = (red[0][cl][8] + red[1][cl][8]) + (red[2][cl][8] + red[3][cl][8]);
     }
-    if (a.cs_thin && blockIdx.x == 0 && tid < a.J) a.cs_thin[(long long)z * a.cs_z + tid] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
+    if (a.cs_thin && bx == 0 && tid < a.J) a.cs_thin[(long long)z * a.cs_z + tid] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
+}
+__global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) { eh_thin_gemm_tile(a, (int)blockIdx.x, (int)blockIdx.y); }
+// (several of them in one launch, as eh_gemm_group_kernel)
+struct EhThinGroup { EhThinArgs a[EH_GEMM_GROUP]; int t0[EH_GEMM_GROUP + 1]; int gx[EH_GEMM_GROUP]; int n; };
+__global__ __launch_bounds__(256) void eh_thin_gemm_group_kernel(const EhThinGroup G) {
+    int i = 0;
+    while (i + 1 < G.n && (int)blockIdx.x >= G.t0[i + 1]) ++i;
+    const int t = (int)blockIdx.x - G.t0[i], gx = G.gx[i];
+    const EhThinArgs a = G.a[i];
+    eh_thin_gemm_tile(a, t % gx, t / gx);
 }
 
 // Products with a degenerate dimension, as streaming kernels (a 128 x 128 MFMA tile spends 94 % and more of such a product on padding;
@@ -475,16 +503,36 @@ struct EhLPrepArgs {
     float* Xb;
     float* meta;              // the handle's EH_IMG_* block (global memory)
     const float* bn_part; int bn_nblk; const float* bn_c; const float* bn_n; int bn_update; float* bn_run;
+    int bn_self;              // train-mode statistics of a small minibatch taken here (every workgroup the same sums in the same order) -- no eh_bn_stats_kernel
 };
 __global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a) {
-    __shared__ float mu[32], rs[32];
+    __shared__ float mu[32], rs[32], sred[8][64];
     const int tid = threadIdx.x;
+    if (a.bn_self) {
+        // thread (g = tid / 32, p = tid % 32): samples g, g + 8, ... of predictor p, shifted by the batch's first sample against cancellation
+        const int p = tid & 31, grp = tid >> 5;
+        const long long n0 = a.idx ? (long long)a.idx[a.first] : a.first;
+        float s1 = 0.0f, s2 = 0.0f;
+        if (p < a.P) {
+            const float c0 = a.recs[n0 * a.C + p];
+#pragma unroll 8
+            for (int i = grp; i < a.count; i += 8) {
+                const long long n = a.idx ? (long long)a.idx[a.first + i] : a.first + i;
+                const float d = a.recs[n * a.C + p] - c0;
+                s1 += d; s2 += d * d;
+            }
+        }
+        sred[grp][p] = s1; sred[grp][32 + p] = s2;
+        __syncthreads();
+    }
     if (tid < 32) {
         float m = a.meta[EH_IMG_BNM + tid], r = a.meta[EH_IMG_BNR + tid];
-        if (a.bn_part && tid < a.P) {
+        if ((a.bn_part || a.bn_self) && tid < a.P) {
             float s1 = 0.0f, s2 = 0.0f;
-            for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
-            const float cnt = a.bn_n ? *a.bn_n : (float)a.count, c0 = a.bn_c[tid];
+            if (a.bn_self) { for (int b = 0; b < 8; ++b) { s1 += sred[b][tid]; s2 += sred[b][32 + tid]; } }
+            else for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
+            const long long nf = a.idx ? (long long)a.idx[a.first] : a.first;
+            const float cnt = a.bn_n ? *a.bn_n : (float)a.count, c0 = a.bn_self ? a.recs[nf * a.C + tid] : a.bn_c[tid];
             const float d = s1 / cnt, var = fmaxf(s2 / cnt - d * d, 0.0f);
             m = c0 + d; r = 1.0f / sqrtf(var + EH_BN_EPS);
             if (a.bn_update && blockIdx.x == 0) {
@@ -513,7 +561,27 @@ __global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a)
 struct EhLMechArgs {
     float* O; long long ldo;
     float* part;              // [gridDim][EH_LMECH_PART] (train) / [gridDim][EH_EVAL_STATS * T] (eval)
+    float* slab; int nrows; long long n_acc;      // (train, ONE workgroup) non-null: the work of eh_lform_tail_kernel done here
 };
+// the sums of the mechanistic stage -> the tail columns of the slab rows (row 0: the sums; the others: cleared)
+__device__ __forceinline__ void eh_lform_tail_write(const float* tot, const EhNet& net, float* slab, int nrows, long long n_acc, int tid) {
+    const int ntail = net.G + 1 + net.T + 2;
+    for (int e = tid; e < nrows * ntail; e += 256) {
+        const int row = e / ntail, c = e % ntail;
+        float v = 0.0f;
+        if (row == 0) {
+            if (c < net.G) {
+#pragma unroll
+                for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                    if (j < net.n_par && ((net.par_kind >> (2 * j)) & 3u) == EH_PAR_GLOBAL && (int)((net.par_idx >> (4 * j)) & 15u) == c) v = tot[j];
+            } else if (c == net.G) v = tot[8];
+            else if (c <= net.G + net.T) v = tot[9 + (c - net.G - 1)];
+            else v = tot[13 + (c - net.G - 1 - net.T)];
+        }
+        slab[(long long)row * n_acc + net.g_off + c] = v;
+    }
+}
+
 enum { EH_LMECH_PART = 16 };
 template <bool TRAIN, bool PROG>
 __global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, const EhStepArgs a, const EhLMechArgs m, const float* meta_g) {
@@ -580,6 +648,14 @@ __global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, con
     }
     __syncthreads();
     const int nout = TRAIN ? EH_LMECH_PART : EH_EVAL_STATS * net.T;
+    if constexpr (TRAIN) {
+        if (m.slab) {             // one workgroup: its sums ARE the totals
+            if (tid < EH_LMECH_PART) red[0][tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            __syncthreads();
+            eh_lform_tail_write(red[0], net, m.slab, m.nrows, m.n_acc, tid);
+            return;
+        }
+    }
     if (tid < nout) m.part[(long long)blockIdx.x * nout + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
@@ -598,19 +674,5 @@ __global__ __launch_bounds__(256) void eh_lform_tail_kernel(const float* part, i
         tot[tid] = t;
     }
     __syncthreads();
-    const int ntail = net.G + 1 + net.T + 2;
-    for (int e = tid; e < nrows * ntail; e += 256) {
-        const int row = e / ntail, c = e % ntail;
-        float v = 0.0f;
-        if (row == 0) {
-            if (c < net.G) {
-#pragma unroll
-                for (int j = 0; j < EH_MAX_PARAMS; ++j)
-                    if (j < net.n_par && ((net.par_kind >> (2 * j)) & 3u) == EH_PAR_GLOBAL && (int)((net.par_idx >> (4 * j)) & 15u) == c) v = tot[j];
-            } else if (c == net.G) v = tot[8];
-            else if (c <= net.G + net.T) v = tot[9 + (c - net.G - 1)];
-            else v = tot[13 + (c - net.G - 1 - net.T)];
-        }
-        slab[(long long)row * n_acc + net.g_off + c] = v;
-    }
+    eh_lform_tail_write(tot, net, slab, nrows, n_acc, tid);
 }

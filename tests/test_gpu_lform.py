@@ -154,7 +154,9 @@ def test_weight_l2_and_data_parallel_seam():
         eng.dp_grad(k * 512, 512); eng.synchronize(); acc += buf
     buf.copy_(acc); torch.cuda.synchronize()
     assert eng.dp_apply(want_loss=True) == pytest.approx(l_ref, rel=1e-5)
-    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 5e-6
+    # (the 512-sample shards and the 2 048-sample step run different product kernels -- other summation orders -- and the first Adam step
+    #  is lr * g / (|g| + eps): a gradient entry near zero turns 1e-8 of rounding into 1e-5 of the 0.01 step)
+    assert np.max(np.abs(eng.get_params() - ref.get_params())) <= 2e-5
     eng.close(); ref.close()
 
 
