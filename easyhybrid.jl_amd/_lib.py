@@ -93,6 +93,7 @@ SIGNATURES = {
     "eh_dp_counts": (C.c_int32, [_H, C.c_int64, C.c_int64]),
     "eh_set_target_shift": (C.c_int32, [_H, C.c_int32, _F, C.c_int64]),
     "eh_set_weight_l2": (C.c_int32, [_H, C.c_float, C.c_int32]),
+    "eh_set_weight_l2_coef": (C.c_int32, [_H, C.POINTER(C.c_float), C.c_int64]),
     "eh_graph_begin": (C.c_int32, [_H]),
     "eh_graph_end": (C.c_int32, [_H, C.POINTER(C.c_int32)]),
     "eh_graph_launch": (C.c_int32, [_H, C.c_int32]),

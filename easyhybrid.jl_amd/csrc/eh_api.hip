@@ -39,20 +39,31 @@ struct EhImg {
     float l2c;
     int b_off;
     const unsigned char* wflag;   // layer-wise form (no image, imap == nullptr): 1 at the canonical positions of Dense weights
+    // several weight_l2 terms (one per network of a MultiNNHybridModel, each with its own lambda / normalisation, or the biases:
+    // extract_weights.jl:64 `l2_Rb = lambda * weight_l2(ps.Rb; normalize = true)`): one coefficient per canonical entry,
+    // extra loss = sum_i l2w[i] theta_i^2 (eh_set_weight_l2_coef); nullptr: the one-lambda form above
+    const float* l2w;
+    int n_theta;
 };
 __device__ __forceinline__ bool eh_is_weight(const EhImg& im, int idx) { return idx < im.g_off && (im.imap ? im.imap[idx] < im.b_off : im.wflag[idx] != 0); }
+// d(extra loss) / d theta_idx = 2 * this * theta_idx
+__device__ __forceinline__ float eh_l2_coef(const EhImg& im, int idx) { return im.l2w ? im.l2w[idx] : (eh_is_weight(im, idx) ? im.l2c : 0.0f); }
 
-// l2c * sum of squared Dense weights of the CURRENT parameters (before the optimiser kernel touches them)
+// the extra loss of the CURRENT parameters (before the optimiser kernel touches them): l2c * sum of squared Dense weights, or sum_i l2w[i] theta_i^2
 __global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, EhImg im, float* out) {
     __shared__ float red[4];
     float s = 0.0f;
-    for (int i = threadIdx.x; i < im.g_off; i += 256)
-        if (eh_is_weight(im, i)) { const float w = theta[i]; s += w * w; }
+    if (im.l2w) {
+        for (int i = threadIdx.x; i < im.n_theta; i += 256) { const float w = theta[i]; s = fmaf(im.l2w[i] * w, w, s); }
+    } else {
+        for (int i = threadIdx.x; i < im.g_off; i += 256)
+            if (eh_is_weight(im, i)) { const float w = theta[i]; s += w * w; }
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) *out = im.l2c * ((red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) *out = (im.l2w ? 1.0f : im.l2c) * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float th) {
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
         const float scale = deferred ? dscale : 1.0f;
         if (idx < n_theta) {
             float g = tot * scale;
-            if (l2val && ntot > 0.0f && eh_is_weight(im, idx)) g = fmaf(2.0f * im.l2c, th, g);      // + d/dw (l2c * sum w^2)
+            if (l2val && ntot > 0.0f) { const float c2 = eh_l2_coef(im, idx); if (c2 != 0.0f) g = fmaf(2.0f * c2, th, g); }      // + d/dw (l2c * sum w^2)
             gradbuf[idx] = g;
             if (APPLY && ntot > 0.0f) {
                 eh_opt_update(o, g, bt1, bt2, th, mm, vv);
@@ -578,7 +589,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
     if (idx < n_theta && cnt > 0.0f) {
         float g = gradbuf[idx] * scale;
         float th = theta[idx], mm = m[idx], vv = v[idx];
-        if (l2val && eh_is_weight(im, idx)) g = fmaf(2.0f * im.l2c, th, g);
+        if (l2val) { const float c2 = eh_l2_coef(im, idx); if (c2 != 0.0f) g = fmaf(2.0f * c2, th, g); }
         eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;
         eh_image_store(im, idx, th);
@@ -821,6 +832,7 @@ struct eh_handle_s {
     EhLossProg loss_prog;           // eh_set_loss_program (EH_LOSS_PROGRAM)
     std::string jit_log;
     float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
+    float* l2w = nullptr;           // eh_set_weight_l2_coef: one coefficient per canonical entry (device)
     int n_weights = 0;
     struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
     std::vector<GraphRec> graphs;         // eh_graph_*: captured step sequences + the rotation state they start (and must end) in
@@ -1477,7 +1489,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMemcpy(h->image, img0.data(), img0.size() * sizeof(float), hipMemcpyHostToDevice));
         EhImg& im = h->img;
         im.image = h->image; im.imap = h->imap; im.g_off = n.g_off; im.phi_off = arch->phi_off;
-        im.l2c = 0.0f; im.b_off = arch->b_off; im.wflag = h->wflag;
+        im.l2c = 0.0f; im.l2w = nullptr; im.n_theta = n.n_theta; im.b_off = arch->b_off; im.wflag = h->wflag;
         HIPCHK_C(hipMalloc(&h->l2val, sizeof(float)));
         HIPCHK_C(hipMemset(h->l2val, 0, sizeof(float)));
         {
@@ -1520,7 +1532,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
-    (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->l2w); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
@@ -1667,7 +1679,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "fused_update")) {     // 1: one kernel per step (float-atomic accumulation, not bitwise reproducible)
         if (value && two_pass_mask(h->net)) return fail(h, EH_EUNSUPPORTED, "fused_update: rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step");
-        if (value && h->img.l2c != 0.0f) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
+        if (value && (h->img.l2c != 0.0f || h->img.l2w)) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
         HIPCHK(h, hipSetDevice(h->device));
@@ -2286,7 +2298,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
     const unsigned tp_mask = two_pass_mask(net);
     const bool moment_loss = tp_mask != 0;
-    const bool l2 = h->img.l2c != 0.0f && !raw;      // (data-parallel seam: raw sums only -- the extra loss is added once, in eh_dp_apply)
+    const bool l2 = (h->img.l2c != 0.0f || h->img.l2w) && !raw;      // (data-parallel seam: raw sums only -- the extra loss is added once, in eh_dp_apply)
     if (l2) {
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
         HIPCHK(h, hipGetLastError());
@@ -2774,6 +2786,27 @@ int32_t eh_set_weight_l2(eh_handle* h, float lambda, int32_t normalize) {
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     h->img.l2c = (normalize && h->n_weights > 0) ? lambda / (float)h->n_weights : lambda;
+    h->img.l2w = nullptr;
+    return EH_OK;
+}
+
+int32_t eh_set_weight_l2_coef(eh_handle* h, const float* coef, int64_t n) {
+    if (!h) return EH_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    if (!coef || n == 0) { h->img.l2w = nullptr; h->img.l2c = 0.0f; return EH_OK; }
+    if (n != h->net.n_theta) return fail(h, EH_EINVAL, "eh_set_weight_l2_coef: %lld coefficients for %d parameters", (long long)n, h->net.n_theta);
+    bool any = false;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(coef[i] >= 0.0f) || std::isinf(coef[i])) return fail(h, EH_EINVAL, "eh_set_weight_l2_coef: coefficient %lld = %g", (long long)i, (double)coef[i]);
+        any = any || coef[i] != 0.0f;
+    }
+    if (any && h->fused) return fail(h, EH_EUNSUPPORTED, "eh_set_weight_l2_coef: not built for the fused_update mode: switch it off first");
+    if (!any) { h->img.l2w = nullptr; h->img.l2c = 0.0f; return EH_OK; }
+    if (!h->l2w) HIPCHK(h, hipMalloc(&h->l2w, (size_t)n * sizeof(float)));
+    HIPCHK(h, hipMemcpyAsync(h->l2w, coef, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // (the caller's array may go away)
+    h->img.l2w = h->l2w; h->img.l2c = 0.0f; h->img.n_theta = h->net.n_theta;
     return EH_OK;
 }
 
@@ -2993,7 +3026,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
     const int nt = h->net.n_theta;
-    const bool l2 = h->img.l2c != 0.0f;
+    const bool l2 = h->img.l2c != 0.0f || h->img.l2w;
     if (l2) {                                                  // the extra loss is a function of the replicated parameters: every rank adds the same term
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
         HIPCHK(h, hipGetLastError());

@@ -246,6 +246,15 @@ class HybridEngine:
         """extra_loss = lam * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91); lam = 0 switches it off"""
         self._chk(self._lib.eh_set_weight_l2(self._h, float(lam), int(bool(normalize))))
 
+    def set_weight_l2_coef(self, coef):
+        """extra loss = sum_i coef[i] * theta_i^2 -- several weight_l2 terms folded into one coefficient per flat-theta entry
+        (HybridModel.l2_coefficients); None / all zero switches it off"""
+        if coef is None:
+            self._chk(self._lib.eh_set_weight_l2_coef(self._h, None, 0))
+            return
+        c = np.ascontiguousarray(coef, np.float32)
+        self._chk(self._lib.eh_set_weight_l2_coef(self._h, c.ctypes.data_as(C.POINTER(C.c_float)), c.size))
+
     def get_opt_state(self):
         m = np.empty(self.n_theta, np.float32)
         v = np.empty(self.n_theta, np.float32)

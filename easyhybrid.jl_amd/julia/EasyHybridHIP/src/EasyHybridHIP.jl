@@ -14,7 +14,7 @@ module EasyHybridHIP
 using Libdl
 using Random
 
-export PerTarget, set_training_loss!, constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
+export PerTarget, set_training_loss!, set_weight_l2!, set_weight_l2_coef!, constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
     Adam, AdamW, RMSProp, Descent, RbQ10, Expo_resp_model,
     LinearHM, Expo2Pool, Rs_components, Rs_components3F, FluxPartModelQ10
 
@@ -408,6 +408,28 @@ function set_training_loss!(e::HybridEngine, spec)
 end
 set_option!(e::HybridEngine, name::Symbol, value::Integer) =
     check(e, @ccall LIB[].eh_set_option(e.h::Ptr{Cvoid}, String(name)::Cstring, value::Int64)::Int32)
+
+"""
+    set_weight_l2!(e, λ; normalize = false)
+
+`extra_loss = (ŷ, ps) -> (; l2 = λ * weight_l2(ps; normalize))` (`src/utils/extract_weights.jl:69-91`, added through `agg = sum`,
+`src/losses/compute_loss.jl:31-34`); `λ = 0` switches it off.
+"""
+set_weight_l2!(e::HybridEngine, λ::Real; normalize::Bool = false) =
+    check(e, @ccall LIB[].eh_set_weight_l2(e.h::Ptr{Cvoid}, Float32(λ)::Float32, Int32(normalize)::Int32)::Int32)
+
+"""
+    set_weight_l2_coef!(e, coef)
+
+Several `weight_l2` terms as one coefficient per flat-θ entry: extra loss `Σᵢ coef[i] θᵢ²` — e.g. the reference's own example
+`(; l2_Rb = λ * weight_l2(ps.Rb; normalize = true),)` (`src/utils/extract_weights.jl:64`) is `λ / length(weights of net Rb)` at the
+entries of that network's `weight` leaves and zero elsewhere (`l2_coefficients`).  `nothing` switches the extra loss off.
+"""
+function set_weight_l2_coef!(e::HybridEngine, coef::Union{Nothing, AbstractVector{<:Real}})
+    coef === nothing && return check(e, @ccall LIB[].eh_set_weight_l2_coef(e.h::Ptr{Cvoid}, C_NULL::Ptr{Float32}, 0::Int64)::Int32)
+    c = Vector{Float32}(coef)
+    GC.@preserve c check(e, @ccall LIB[].eh_set_weight_l2_coef(e.h::Ptr{Cvoid}, c::Ptr{Float32}, length(c)::Int64)::Int32)
+end
 
 "(kernel pairs compiled at run time and in use, compiler / failure log) -- 0 with a log = the kernels built ahead of time run instead"
 function jit_status(e::HybridEngine)

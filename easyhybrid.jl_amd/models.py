@@ -269,6 +269,33 @@ class SingleNNHybridModel:
                 off += o * i + o
         return m
 
+    def l2_mask(self, net=None, key: str = "weight") -> np.ndarray:
+        """the flat-theta positions weight_l2(ps or ps.<net>; key) walks (extract_weights.jl:69-91): the leaves named `key`
+        (:weight or :bias) of every network, or of the network predicting `net` (a MultiNNHybridModel's `ps.<net>`)"""
+        if key not in ("weight", "bias"):
+            raise ValueError(f"weight_l2: key = {key!r} (Dense layers have :weight and :bias leaves)")
+        names = [None] if self.NNs is None else list(self.neural_param_names)
+        if net is not None and net not in names:
+            raise KeyError(f"weight_l2: no network named {net!r} (networks: {[n for n in names if n is not None]})")
+        m = np.zeros(self.n_theta, bool)
+        off = 0
+        for name, dims in zip(names, self.nets):
+            for o, i in dims:
+                if net is None or net == name:
+                    if key == "weight": m[off:off + o * i] = True
+                    else: m[off + o * i:off + o * i + o] = True
+                off += o * i + o
+        return m
+
+    def l2_coefficients(self, terms) -> np.ndarray:
+        """terms [WeightL2...] -> one coefficient per flat-theta entry: sum of the terms == sum_i coef[i] * theta_i^2 (eh_set_weight_l2_coef)"""
+        c = np.zeros(self.n_theta, np.float64)
+        for t in terms:
+            m = self.l2_mask(t.net, t.key)
+            n = int(m.sum())
+            c[m] += float(t.lam) / (n if t.normalize and n > 0 else 1)
+        return c.astype(np.float32)
+
     def unpack(self, theta: np.ndarray):
         """flat theta -> (ps = [(weight (out,in), bias)...], {global: raw})"""
         off, nets = 0, []

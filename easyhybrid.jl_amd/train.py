@@ -86,10 +86,54 @@ def check_training_loss(loss_type):                              # loss_fn.jl:19
 
 @dataclass
 class WeightL2:
-    """extra_loss = (yhat, ps) -> (; weight_l2 = lam * weight_l2(ps; normalize)) (src/utils/extract_weights.jl:69-91): the one
-    extra_loss the device knows -- any other closure cannot run inside the kernel."""
+    """One term of extra_loss = (yhat, ps) -> (; name = lam * weight_l2(ps; key, normalize), ...) (src/utils/extract_weights.jl:
+    64-91) -- the extra losses the device knows: functions of the parameters that are sums of squares of Dense leaves.
+    net: the network of a MultiNNHybridModel the walk starts at (`weight_l2(ps.Rb; ...)`, the reference's own example), None =
+    the whole tree; key: "weight" (default) or "bias".  TrainConfig.extra_loss takes one term, a list of terms or a dict
+    name -> term (the NamedTuple the closure returns).  Closures of yhat cannot run inside the kernel."""
     lam: float
     normalize: bool = False
+    net: Optional[str] = None
+    key: str = "weight"
+    name: Optional[str] = None
+
+    def label(self) -> str:
+        return self.name or ("weight_l2" if self.net is None and self.key == "weight" else f"l2_{self.net or self.key}")
+
+
+def _extra_terms(extra_loss) -> List[WeightL2]:
+    """TrainConfig.extra_loss -> its terms ([] for None); anything else is refused"""
+    if extra_loss is None:
+        return []
+    if isinstance(extra_loss, WeightL2):
+        return [extra_loss]
+    if isinstance(extra_loss, dict) and extra_loss and all(isinstance(v, WeightL2) for v in extra_loss.values()):
+        return [WeightL2(v.lam, v.normalize, v.net, v.key, str(k)) for k, v in extra_loss.items()]
+    if isinstance(extra_loss, (list, tuple)) and extra_loss and all(isinstance(v, WeightL2) for v in extra_loss):
+        terms = list(extra_loss)
+        if len({t.label() for t in terms}) != len(terms):
+            raise ValueError("extra_loss: two terms with the same name (a NamedTuple has distinct fields): give them `name`s")
+        return terms
+    raise NotImplementedError("extra_loss: an arbitrary closure cannot run on the device; WeightL2 terms (one, a list or a dict of them) are built")
+
+
+def _apply_extra_loss(eng, model, terms: List[WeightL2]):
+    if len(terms) == 1 and terms[0].net is None and terms[0].key == "weight":
+        eng.set_weight_l2(terms[0].lam, terms[0].normalize)
+    elif terms:
+        eng.set_weight_l2_coef(model.l2_coefficients(terms))
+
+
+def _extra_loss_values(model, theta, terms: List[WeightL2]) -> Dict[str, float]:
+    """the extra losses of flat parameters `theta` (host side, for the history; compute_loss.jl:39-44: each entry and their agg)"""
+    th = np.asarray(theta, np.float64)
+    out = {}
+    for t in terms:
+        m = model.l2_mask(t.net, t.key)
+        sq = float(np.sum(th[m] * th[m]))
+        out[t.label()] = float(t.lam) * (sq / max(1, int(m.sum())) if t.normalize else sq)
+    out["sum"] = float(sum(out.values()))
+    return out
 
 
 @dataclass
@@ -101,7 +145,7 @@ class TrainConfig:
     training_loss: Any = "mse"           # a name, or a function f(yhat, y) -> np.mean(per-sample terms) (loss_fn.jl: training_loss::Function)
     loss_types: List[str] = field(default_factory=lambda: ["mse", "r2"])
     agg: str = "sum"
-    extra_loss: Any = None               # TrainingConfig.jl:74; None or WeightL2(lam, normalize)
+    extra_loss: Any = None               # TrainingConfig.jl:74; None, a WeightL2 term, or a list / dict (name -> term) of them
     train_from: Any = None
     random_seed: Optional[int] = 161803
     return_model: str = "best"
@@ -174,8 +218,7 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
                                       "or a function f(yhat, y) = mean of per-sample terms")
     if cfg.agg != "sum":
         raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
-    if cfg.extra_loss is not None and not isinstance(cfg.extra_loss, WeightL2):
-        raise NotImplementedError("extra_loss: an arbitrary closure cannot run on the device; WeightL2(lam, normalize) is built")
+    _extra_terms(cfg.extra_loss)          # (refuses what the device cannot run)
     for lt in cfg.loss_types:
         if lt not in _DEVICE_METRICS:
             raise NotImplementedError(f"loss type {lt!r} is not computed by the eval kernel (have {sorted(_DEVICE_METRICS)})")
@@ -297,14 +340,6 @@ def _losses(engine, split, targets, loss_types):
     return out
 
 
-def _weight_l2_value(model, theta, spec: WeightL2) -> float:
-    """lam * weight_l2(ps; normalize) of flat parameters `theta` (host side, for the history)"""
-    m = model.weight_mask()
-    w = np.asarray(theta, np.float64)[m]
-    s = float(np.sum(w * w))
-    return float(spec.lam) * (s / max(1, int(m.sum())) if spec.normalize else s)
-
-
 def _want_distributed(tc: TrainConfig) -> bool:
     if tc.distributed is not None:
         return bool(tc.distributed)
@@ -347,8 +382,8 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.set_params(theta); ev.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
-        if tc.extra_loss is not None:                 # a function of the replicated parameters: every rank adds the same term in eh_dp_apply
-            eng.set_weight_l2(tc.extra_loss.lam, tc.extra_loss.normalize)
+        xterms = _extra_terms(tc.extra_loss)          # functions of the replicated parameters: every rank adds the same terms in eh_dp_apply
+        _apply_extra_loss(eng, model, xterms)
         drv = DataParallel(eng, fused=tc.fused_update is not False, specialize=bool(tc.specialize))      # ("auto" compiles before the first step here: every rank has to be ready together)
         has_bn = bool(model.config.get("input_batchnorm"))
         first_lt = tc.loss_types[0]
@@ -360,10 +395,10 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
                 ev.set_bn_state(*eng.get_bn_state())
             snap = EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
                                  _losses(ev, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
-            if tc.extra_loss is not None:
-                v = _weight_l2_value(model, eng.get_params(), tc.extra_loss)
+            if xterms:
+                xv = _extra_loss_values(model, eng.get_params(), xterms)
                 for d in (snap.l_train, snap.l_val):
-                    d["extra_loss"] = {"weight_l2": v, "sum": v}
+                    d["extra_loss"] = dict(xv)
             return snap
         init = snapshot()
         history = [init]
@@ -449,18 +484,18 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         eng.set_params(theta)
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
-        if tc.extra_loss is not None:
-            eng.set_weight_l2(tc.extra_loss.lam, tc.extra_loss.normalize)
+        xterms = _extra_terms(tc.extra_loss)
+        _apply_extra_loss(eng, model, xterms)
         _apply_step_mode(eng, tc)
         first_lt = tc.loss_types[0]
 
         def snapshot():
             snap = EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
                                  _losses(eng, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
-            if tc.extra_loss is not None:                # compute_loss.jl:39-44: eval mode reports the extra losses next to the metrics
-                v = _weight_l2_value(model, eng.get_params(), tc.extra_loss)
+            if xterms:                                   # compute_loss.jl:39-44: eval mode reports the extra losses next to the metrics
+                xv = _extra_loss_values(model, eng.get_params(), xterms)
                 for d in (snap.l_train, snap.l_val):
-                    d["extra_loss"] = {"weight_l2": v, "sum": v}
+                    d["extra_loss"] = dict(xv)
             return snap
         init = snapshot()
         history = [init]

@@ -261,6 +261,15 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
  * Other extra_loss closures cannot run on the device. */
 int32_t eh_set_weight_l2(eh_handle* h, float lambda, int32_t normalize);
 
+/* The same extra loss with one coefficient per canonical parameter entry: extra loss = sum_i coef[i] * theta_i^2, gradient
+ * 2 coef[i] theta_i.  This is what several weight_l2 terms come to -- one per network of a MultiNNHybridModel with its own
+ * lambda and normalisation (the reference's own example, src/utils/extract_weights.jl:64:
+ * `extra_loss = (yhat, ps) -> (; l2_Rb = lambda * weight_l2(ps.Rb; normalize = true),)`), or `key = :bias` -- the host side
+ * adds lambda (or lambda / #entries of the term) at the entries each term covers.  coef: host array of n = n_theta floats,
+ * >= 0; NULL or all zero switches the extra loss off; replaces whatever eh_set_weight_l2 had set (and vice versa).
+ * (ABI 3, added in the same round as the other version-3 entry points.) */
+int32_t eh_set_weight_l2_coef(eh_handle* h, const float* coef, int64_t n);
+
 /* hipGraph capture of a sequence of steps: between eh_graph_begin and eh_graph_end the calls
  * eh_train_step(..., loss_out = NULL) / eh_dp_fused_step are recorded, not run; eh_graph_launch replays the
  * recorded sequence (same windows, same buffers).  The calls advance the engine's rotation state

@@ -637,6 +637,29 @@ def weight_l2(spec: HybridSpec, theta, lam, normalize=False):
     return c * np.sum(th[m] * th[m]), g
 
 
+def weight_l2_terms(spec: HybridSpec, theta, terms):
+    """several extra-loss terms, each lam * weight_l2(ps or ps.<net>; key, normalize) (src/utils/extract_weights.jl:64-91: the
+    walk collects the leaves named `key` -- :weight or :bias -- below the node it is given: the whole tree, or one network of a
+    MultiNNHybridModel).  terms: [(lam, normalize, net index or None, "weight" | "bias")].  Returns ([values], gradient)."""
+    th = np.asarray(theta)
+    g = np.zeros_like(th)
+    vals = []
+    for lam, normalize, net, key in terms:
+        m = np.zeros(spec.n_theta, bool)
+        off = 0
+        for k, (_, dims) in enumerate(spec.net_list):
+            for o, i in dims:
+                if net is None or net == k:
+                    if key == "weight": m[off:off + o * i] = True
+                    else: m[off + o * i:off + o * i + o] = True
+                off += o * i + o
+        n = int(m.sum())
+        c = th.dtype.type(lam) / (th.dtype.type(n) if normalize and n > 0 else th.dtype.type(1))
+        g[m] += 2 * c * th[m]
+        vals.append(c * np.sum(th[m] * th[m]))
+    return vals, g
+
+
 def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None):
     """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
@@ -740,7 +763,11 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         gnets.append(gWs)
     grad = pack(spec, gnets, graw, dt)
     if l2 is not None and sum(nvalid) > 0:            # extra_loss through agg = sum (compute_loss.jl:31-34)
-        lv, lg = weight_l2(spec, np.asarray(theta, dt), *l2)
+        if isinstance(l2, list):                      # several terms: agg([loss_value, extra_loss_value...])
+            lvs, lg = weight_l2_terms(spec, np.asarray(theta, dt), l2)
+            lv = sum(lvs)
+        else:
+            lv, lg = weight_l2(spec, np.asarray(theta, dt), *l2)
         loss, grad = loss + lv, grad + lg
     return loss, grad, nvalid
 

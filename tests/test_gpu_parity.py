@@ -1466,6 +1466,83 @@ def test_weight_l2_extra_loss(normalize, shape):
     eng.close()
 
 
+@pytest.mark.parametrize("shape", ["multinn", "multinn_lform", "single"])
+def test_weight_l2_terms_per_network(shape):
+    """several extra-loss terms -- the reference's own example `l2_Rb = lambda * weight_l2(ps.Rb; normalize = true)`
+    (src/utils/extract_weights.jl:64), one per network with its own lambda, and a bias term -- as one coefficient per entry
+    (eh_set_weight_l2_coef) against the oracle's term-by-term walk: loss, gradient, an Adam trajectory"""
+    rng = np.random.default_rng(5)
+    if shape == "single":
+        spec, theta, X, f, y = util.rbq10_case(900, "tanh", True, 0.1)
+        oterms = [(0.4, True, None, "weight"), (0.05, False, None, "bias")]
+        terms = [eh.WeightL2(0.4, normalize=True, name="w"), eh.WeightL2(0.05, key="bias")]
+    else:
+        hid = [[8, 8], [16, 8]] if shape == "multinn" else [[160, 8], [16, 8, 8, 8]]
+        spec = ho.HybridSpec(4, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=[([0, 1], hid[0]), ([2, 3], hid[1])])
+        X = rng.standard_normal((4, 900)).astype(np.float32)
+        f = {"ta": rng.uniform(0, 30, 900).astype(np.float32)}
+        y = {"reco": rng.uniform(1, 9, 900).astype(np.float32)}
+        theta = ho.init_theta(spec, 6, np.float32)
+        nrb = int(sum(o * i for o, i in spec.net_list[0][1]))
+        oterms = [(0.04 * nrb, True, 0, "weight"), (0.11, False, 1, "weight"), (0.2, False, 0, "bias")]
+        terms = {"l2_rb": eh.WeightL2(0.04 * nrb, normalize=True, net="rb"), "l2_Q10": eh.WeightL2(0.11, net="Q10"), "b_rb": eh.WeightL2(0.2, net="rb", key="bias")}
+    model = util.model_from_spec(spec)
+    from easyhybrid_jl_amd.train import _extra_terms
+    coef = model.l2_coefficients(_extra_terms(terms))
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_weight_l2_coef(coef)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, l2=oterms)
+    lp, gp, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert util.relerr(g0, gp) > 2e-4                         # the terms are not negligible in this test
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.opt_init("Adam", 0.003)
+    batches = [(i * 300, 300) for i in range(3)] * 2
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, lr=0.003, dtype=np.float32, l2=oterms)
+    assert np.allclose(losses, l_ref, rtol=1e-4)
+    assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    # the one-lambda form replaces the coefficients, and the other way round; NULL switches the extra loss off
+    eng.set_params(theta)
+    eng.set_weight_l2(0.37, False)
+    l1, g1, _ = eng.loss_and_grad()
+    l10, g10, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, l2=(0.37, False))
+    assert l1 == pytest.approx(l10, rel=TOL) and util.relerr(g1, g10) <= TOL
+    eng.set_weight_l2_coef(coef)
+    l2_, g2, _ = eng.loss_and_grad()
+    assert l2_ == pytest.approx(l0, rel=TOL) and util.relerr(g2, g0) <= TOL
+    eng.set_weight_l2_coef(None)
+    l3, g3, _ = eng.loss_and_grad()
+    assert l3 == pytest.approx(lp, rel=TOL) and util.relerr(g3, gp) <= TOL
+    with pytest.raises(ValueError):
+        eng.set_weight_l2_coef(coef[:-1])
+    with pytest.raises(ValueError):
+        eng.set_weight_l2_coef(-coef)
+    eng.close()
+
+
+def test_train_front_door_with_per_network_weight_l2_terms():
+    """TrainConfig.extra_loss as the NamedTuple of terms the reference's closure returns: each entry and their sum in the history
+    (compute_loss.jl:39-44), the penalised network's weights shrink, the other one's do not"""
+    rng = np.random.default_rng(2)
+    n = 3000
+    cols = {"a": rng.standard_normal(n).astype(np.float32), "b": rng.standard_normal(n).astype(np.float32), "c": rng.standard_normal(n).astype(np.float32),
+            "ta": rng.uniform(0, 30, n).astype(np.float32)}
+    cols["reco"] = ((1.5 + np.tanh(cols["a"])) * (1.8 ** (0.1 * (cols["ta"] - 15.0)))).astype(np.float32)
+    pars = dict(eh.synthetic.RBQ10_PARAMS)
+    model = eh.constructHybridModel({"rb": ["a", "b"], "Q10": ["c"]}, ["ta"], ["reco"], eh.RbQ10, pars, [], hidden_layers={"rb": [16, 16], "Q10": [8]},
+                                    activation="tanh", scale_nn_outputs=True)
+    kw = dict(nepochs=8, batchsize=256, opt=eh.Adam(0.01), random_seed=3)
+    plain = eh.train(model, cols, **kw)
+    reg = eh.train(model, cols, extra_loss={"l2_rb": eh.WeightL2(0.1, net="rb"), "l2_Q10": eh.WeightL2(1e-6, net="Q10", normalize=True)}, **kw)
+    mrb, mq = model.l2_mask("rb"), model.l2_mask("Q10")
+    assert np.sum(reg.ps[mrb] ** 2) < 0.7 * np.sum(plain.ps[mrb] ** 2)
+    last = reg.val_history[-1]["extra_loss"]
+    assert set(last) == {"l2_rb", "l2_Q10", "sum"} and last["sum"] == pytest.approx(last["l2_rb"] + last["l2_Q10"])
+    assert last["l2_rb"] == pytest.approx(0.1 * float(np.sum(reg.ps[mrb].astype(np.float64) ** 2)), rel=0.3)
+    assert last["l2_Q10"] == pytest.approx(1e-6 * float(np.mean(reg.ps[mq].astype(np.float64) ** 2)), rel=0.3)
+
+
 def test_weight_l2_through_the_data_parallel_seam():
     """the extra loss is a function of the replicated parameters: the shards exchange raw data sums only, eh_dp_apply adds
     2 lambda w to the weight gradients and lambda sum w^2 to the loss once (four virtual shards against the plain step)"""

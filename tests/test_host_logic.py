@@ -135,3 +135,30 @@ def test_multinn_per_network_activations():
     with pytest.raises(NotImplementedError):
         eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, PARAMS, [],
                                 hidden_layers={"rb": [16], "Q10": [8]}, activation={"rb": "relu", "Q10": "gelu"})
+
+
+def test_weight_l2_terms_fold_into_one_coefficient_per_entry():
+    """extra_loss = (yhat, ps) -> (; l2_rb = a * weight_l2(ps.rb; normalize = true), l2_all = b * weight_l2(ps), bias = c * weight_l2(ps; key = :bias))
+    (src/utils/extract_weights.jl:64-91): what the mirror hands to eh_set_weight_l2_coef against the oracle's term-by-term walk"""
+    from oracle import hybrid_oracle as ho
+    from tests import util
+    from easyhybrid_jl_amd.train import _extra_terms, _extra_loss_values
+    spec = ho.HybridSpec(4, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=[([0, 1], [8, 8]), ([2, 3], [16, 8])])
+    model = util.model_from_spec(spec)
+    theta = ho.init_theta(spec, 6, np.float64)
+    terms = _extra_terms({"l2_rb": eh.WeightL2(0.3, normalize=True, net="rb"), "l2_all": eh.WeightL2(0.02), "bias": eh.WeightL2(0.1, key="bias", net="Q10")})
+    coef = model.l2_coefficients(terms).astype(np.float64)
+    vals, grad = ho.weight_l2_terms(spec, theta, [(0.3, True, 0, "weight"), (0.02, False, None, "weight"), (0.1, False, 1, "bias")])
+    assert np.sum(coef * theta * theta) == pytest.approx(sum(vals), rel=1e-6)
+    assert np.allclose(2 * coef * theta, grad, rtol=1e-6, atol=1e-12)
+    hv = _extra_loss_values(model, theta, terms)
+    assert [hv["l2_rb"], hv["l2_all"], hv["bias"]] == pytest.approx(vals, rel=1e-12) and hv["sum"] == pytest.approx(sum(vals), rel=1e-12)
+    # the single whole-tree term is weight_mask's
+    assert np.array_equal(model.l2_mask(), model.weight_mask()) and np.array_equal(model.l2_mask(), ho.weight_mask(spec))
+    assert not np.any(model.l2_mask(key="bias") & model.weight_mask())
+    with pytest.raises(KeyError):
+        model.l2_mask(net="nope")
+    with pytest.raises(NotImplementedError, match="extra_loss"):
+        _extra_terms(lambda yhat, ps: 0.0)
+    with pytest.raises(ValueError, match="same name"):
+        _extra_terms([eh.WeightL2(0.1), eh.WeightL2(0.2)])
