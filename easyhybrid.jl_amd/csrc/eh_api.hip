@@ -328,38 +328,70 @@ __global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part,
 // image in place.  Block = CW columns x 256/CW row groups (CW = 16 for small models: many blocks; CW = 64 for
 // big gradients: 256-byte runs per slab row); every load of a thread is independent, so
 // the whole slab read costs about one L2 round trip.  gradbuf = [grad | loss | counts].
-template <bool APPLY, int CW>
+template <bool APPLY, int CW, int NC = 1>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
                                                         float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom, const float* l2val, unsigned tp_mask) {
+    // NC > 1 (layer-wise form: hundreds of thousands of columns under a few rows): NC columns per thread, CW apart -- a quarter of the
+    // workgroups, so a quarter of the per-workgroup part (counts, barriers), and NC times the loads in flight per thread
     constexpr int NQ = 256 / CW;
+    static_assert(NC == 1 || NQ == 1, "several columns per thread: one row group");
     __shared__ float part[NQ][CW + 1];
     __shared__ float wsum[4][EH_MAX_TARG + 3];
     const int tid = threadIdx.x, p = tid % CW, q = tid / CW;
-    const int idx = blockIdx.x * CW + p;
-    // optimiser inputs are independent of the slab: request them first so they arrive together
-    float th = 0.0f, mm = 0.0f, vv = 0.0f, bt1 = 0.0f, bt2 = 0.0f;
-    int mp = -1;
-    if (APPLY && q == 0 && idx < n_theta) { th = theta[idx]; mm = m[idx]; vv = v[idx]; bt1 = sc_in[0]; bt2 = sc_in[1]; if (idx < im.g_off && im.imap) mp = im.imap[idx]; }
-    if (!APPLY && l2val && q == 0 && idx < n_theta) th = theta[idx];
+    const int idx0 = blockIdx.x * (CW * NC) + p;
+    // optimiser inputs are independent of the slab: request them first so they arrive together (only the state the rule keeps:
+    // RMSProp has no first moment, Descent none at all)
+    const bool use_m = o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW, use_v = use_m || o.rule == EH_OPT_RMSPROP;
+    float th[NC], mm[NC], vv[NC], bt1 = 0.0f, bt2 = 0.0f;
+    int mp[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int idx = idx0 + CW * j;
+        th[j] = 0.0f; mm[j] = 0.0f; vv[j] = 0.0f; mp[j] = -1;
+        if (APPLY && q == 0 && idx < n_theta) {
+            th[j] = theta[idx];
+            if (use_m) mm[j] = m[idx];
+            if (use_v) vv[j] = v[idx];
+            if (idx < im.g_off && im.imap) mp[j] = im.imap[idx];
+        }
+        if (!APPLY && l2val && q == 0 && idx < n_theta) th[j] = theta[idx];
+    }
+    if (APPLY && q == 0) { bt1 = sc_in[0]; bt2 = sc_in[1]; }
     // (all of a thread's rows in flight at once: the step is one memory round trip, not nblk / NQ / 16 of them)
-    float s = 0.0f;
-    if (idx < n_acc) {
-        const float* col = slab + (size_t)q * n_acc + idx;
+    float s[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) s[j] = 0.0f;
+    if (idx0 < n_acc) {
+        constexpr int U = 32 / NC;
+        const float* col[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) col[j] = slab + (size_t)q * n_acc + min(idx0 + CW * j, n_acc - 1);       // (columns past the end: clamped, dropped below)
         const size_t rstride = (size_t)NQ * n_acc;
         int r = q;
-        for (; r + 31 * NQ < nblk; r += 32 * NQ) {
-            float t[32];
+        for (; r + (U - 1) * NQ < nblk; r += U * NQ) {
+            float t[U][NC];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) t[u] = col[u * rstride];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int u = 0; u < 32; ++u) s += t[u];
-            col += 32 * rstride;
+                for (int j = 0; j < NC; ++j) t[u][j] = col[j][u * rstride];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) s[j] += t[u][j];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) col[j] += U * rstride;
         }
-#pragma unroll 16
-        for (; r < nblk; r += NQ) { s += *col; col += rstride; }
+#pragma unroll 4
+        for (; r < nblk; r += NQ) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { s[j] += *col[j]; col[j] += rstride; }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (idx0 + CW * j >= n_acc) s[j] = 0.0f;
     }
-    part[q][p] = s;
+    if constexpr (NC == 1) part[q][p] = s[0];
     // valid counts: every block needs them (nblk <= 256: one row per thread)
     // wsum columns: [0..3] n_valid per target, [4] S, [5] Sy, [6] Syy
     // (a row's scalars [S | n_t ... | Sy | Syy] are 3 + T consecutive floats behind the gradient: two wide loads per row -- one
@@ -403,27 +435,35 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t) tp_loss += (t < T && ((tp_mask >> t) & 1u)) ? mom[EH_TT * t + 7] : 0.0f;
     }
-    if (q == 0 && idx < n_acc) {
-        float tot = 0.0f;
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) tot += part[k][p];
-        const float scale = deferred ? dscale : 1.0f;
-        if (idx < n_theta) {
-            float g = tot * scale;
-            if (l2val && ntot > 0.0f) { const float c2 = eh_l2_coef(im, idx); if (c2 != 0.0f) g = fmaf(2.0f * c2, th, g); }      // + d/dw (l2c * sum w^2)
-            gradbuf[idx] = g;
-            if (APPLY && ntot > 0.0f) {
-                eh_opt_update(o, g, bt1, bt2, th, mm, vv);
-                theta[idx] = th; m[idx] = mm; v[idx] = vv;
-                if (idx < im.g_off) { if (mp >= 0) im.image[mp] = th; }
-                else eh_image_store(im, idx, th);
+    for (int j = 0; j < NC; ++j) {
+        const int idx = idx0 + CW * j;
+        if (q == 0 && idx < n_acc) {
+            float tot = 0.0f;
+            if constexpr (NC == 1) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) tot += part[k][p];
+            } else tot = s[j];
+            const float scale = deferred ? dscale : 1.0f;
+            if (idx < n_theta) {
+                float g = tot * scale;
+                if (l2val && ntot > 0.0f) { const float c2 = eh_l2_coef(im, idx); if (c2 != 0.0f) g = fmaf(2.0f * c2, th[j], g); }      // + d/dw (l2c * sum w^2)
+                gradbuf[idx] = g;
+                if (APPLY && ntot > 0.0f) {
+                    eh_opt_update(o, g, bt1, bt2, th[j], mm[j], vv[j]);
+                    theta[idx] = th[j];
+                    if (use_m) m[idx] = mm[j];
+                    if (use_v) v[idx] = vv[j];
+                    if (idx < im.g_off) { if (mp[j] >= 0) im.image[mp[j]] = th[j]; }
+                    else eh_image_store(im, idx, th[j]);
+                }
+            } else if (idx == n_theta) {
+                const float loss = ntot > 0.0f ? (deferred ? dloss : tot + tp_loss) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
+                gradbuf[idx] = loss;
+                if (loss_slot) *loss_slot = loss;
+            } else {
+                gradbuf[idx] = tot;
             }
-        } else if (idx == n_theta) {
-            const float loss = ntot > 0.0f ? (deferred ? dloss : tot + tp_loss) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
-            gradbuf[idx] = loss;
-            if (loss_slot) *loss_slot = loss;
-        } else {
-            gradbuf[idx] = tot;
         }
     }
     if (APPLY && blockIdx.x == 0 && tid == 0) {
@@ -1980,7 +2020,8 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
     }
     const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)nz);
     const bool vec = !novec && eh_gemm_vec_ok(g, ATR, BTR);
-    if (vec && (long long)grid.x * grid.y * grid.z < 256) {      // fewer 128 x 128 tiles than CUs: 64 x 64 ones (four times the workgroups, a quarter of the work each)
+    static const long long t128_min = getenv("EH_GEMM_T128_MIN") ? atoll(getenv("EH_GEMM_T128_MIN")) : 2048;
+    if (vec && (long long)grid.x * grid.y * grid.z < t128_min) {      // fewer 128 x 128 tiles than CUs: 64 x 64 ones (four times the workgroups, a quarter of the work each)
         const dim3 grid64((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)nz);
         hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, true, 64>), grid64, dim3(256), 0, h->stream, g);
         return;
@@ -2090,7 +2131,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     const float* theta = TH(h);
     // Small minibatches: every layer's delta is kept (l_dk), the chain of delta products runs first and the weight gradients -- a
     // handful of tiles each, 4-6 us per dependent launch -- follow as ONE grouped launch of the tiled ones and one of the thin ones.
-    static const long long lgroup_max = getenv("EH_LFORM_GROUP_MAX") ? atoll(getenv("EH_LFORM_GROUP_MAX")) : 1024;
+    static const long long lgroup_max = getenv("EH_LFORM_GROUP_MAX") ? atoll(getenv("EH_LFORM_GROUP_MAX")) : 4096;
     bool grouped = count <= lgroup_max && h->l_nnets > 0;
     long long dk_floats = 0;
     if (grouped) {
@@ -2309,17 +2350,19 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     // blocks 3 of 4 threads had no row to read and the per-block part (counts, barriers) ran 11 k times: 29.6 us of a 250 us step at
     // B = 64 (tools/lform_trace.sh)
     const bool tall = cw_env ? cw_env == 256 : (h->lform && grid <= (int)EH_LFORM_ROWS && h->n_acc >= 16384);
-    const int rgrid = tall ? (h->n_acc + 255) / 256 : big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
+    static const bool nc1 = getenv("EH_REDUCE_NC1") != nullptr;
+    const bool tall4 = tall && !nc1;                                   // four columns per thread
+    const int rgrid = tall4 ? (h->n_acc + 1023) / 1024 : tall ? (h->n_acc + 255) / 256 : big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
     float* sc_in = h->sc + 2 * h->sc_sel;
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
-#define EH_REDUCE_GO(AP, CW_)                                                                                                                       \
-    hipLaunchKernelGGL((eh_reduce_kernel<AP, CW_>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
+#define EH_REDUCE_GO(AP, ...)                                                                                                                       \
+    hipLaunchKernelGGL((eh_reduce_kernel<AP, __VA_ARGS__>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
                        TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)
     if (apply) {
-        if (tall) EH_REDUCE_GO(true, 256); else if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
+        if (tall4) EH_REDUCE_GO(true, 256, 4); else if (tall) EH_REDUCE_GO(true, 256); else if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
     } else {
-        if (tall) EH_REDUCE_GO(false, 256); else if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
+        if (tall4) EH_REDUCE_GO(false, 256, 4); else if (tall) EH_REDUCE_GO(false, 256); else if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
     }
 #undef EH_REDUCE_GO
     HIPCHK(h, hipGetLastError());
