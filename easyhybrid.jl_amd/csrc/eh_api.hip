@@ -1992,7 +1992,9 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
                 EhGemmArgs p = g;
                 p.kchunk = std::max(16, ((g.K + 15) / 16 + 15) / 16 * 16);         // <= 16 slices of whole 16-deep groups
                 const int nw = (g.K + p.kchunk - 1) / p.kchunk;
-                hipLaunchKernelGGL((eh_fewrows_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nw), 0, h->stream, p);
+                static const int few32 = getenv("EH_GEMM_FEW32_MIN") ? atoi(getenv("EH_GEMM_FEW32_MIN")) : 512;       // rows from which the 32 x 32 tile runs
+                if (g.M >= few32) hipLaunchKernelGGL((eh_fewrows32_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 31) / 32)), dim3(64u * (unsigned)nw), 0, h->stream, p);
+                else hipLaunchKernelGGL((eh_fewrows_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nw), 0, h->stream, p);
                 return;
             }
         }

@@ -494,6 +494,62 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
     }
 }
 
+// The same with a 32 x 32 output tile per workgroup (v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[m0 + r][k] and B[k][n0 + r] for
+// k = kb + 4 h + i in step i of an 8-deep group): a quarter of the workgroups and half the operand traffic per product -- from a
+// few hundred rows on, the 16 x 16 form is thousands of workgroups that each live one memory latency (16 us for a 1 024 x 1 024 x 512
+// product, tools/lform_trace.sh).  64 KB of LDS for the waves' partial tiles.
+template <bool BTR, int EPI>
+__global__ __launch_bounds__(1024) void eh_fewrows32_gemm_kernel(const EhGemmArgs g) {
+    static_assert(EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_DACT, "epilogues of the small-batch products");
+    __shared__ float red[16][1024];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = (int)(blockDim.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kbeg = wave * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nc = min(n0 + r, g.N - 1);
+    const float* const pa = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * hh;
+    const float* const pb = BTR ? g.B + (long long)nc * g.ldb + 4 * hh : g.B + (long long)(4 * hh) * g.ldb + nc;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        f32x4_lf a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kb = k0 + 8 * u;
+            const bool ok = kb < kend;
+            a[u] = ok ? *(const f32x4_lf*)(pa + kb) : f32x4_lf{0.0f, 0.0f, 0.0f, 0.0f};
+            if (BTR) b[u] = ok ? *(const f32x4_lf*)(pb + kb) : f32x4_lf{0.0f, 0.0f, 0.0f, 0.0f};
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[u][i] = ok ? pb[(long long)(kb + i) * g.ldb] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][i], acc, 0, 0, 0);
+    }
+    // C/D layout of the 32x32 MFMA: lane -> column (lane & 31); register i -> row (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][((i & 3) + 8 * (i >> 2) + 4 * hh) * 32 + r] = acc[i];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += (int)blockDim.x) {
+        float v = 0.0f;
+        for (int w = 0; w < nw; ++w) v += red[w][e];
+        const int m = m0 + (e >> 5), n = n0 + (e & 31);
+        if (m < g.M && n < g.N) {
+            if (EPI == EH_GEPI_BIAS_ACT) {
+                v += g.bias[n];
+                if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
+                g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
+            } else {
+                g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
+            }
+        }
+    }
+}
+
 // The minibatch as the GEMMs want it: Xb [count][P] = the predictors of samples idx[first + i] (or first + i), normalised by the
 // input BatchNorm when the model has one (train mode: the statistics of THIS minibatch from eh_bn_stats_kernel's partial sums, and
 // block 0 advances the running statistics; test mode: the running statistics in `meta`).

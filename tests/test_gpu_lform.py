@@ -246,6 +246,33 @@ def test_multinn_models(case):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [100, 511, 512, 1000, 1024, 1025])
+def test_few_rows_products_and_grouped_weight_gradients(B):
+    """Up to 1 024 rows the forward / delta products with an aligned k >= 64 run one output tile per workgroup with k split over its
+    waves (16 x 16 tiles below 512 rows, 32 x 32 from there on; output widths that are not multiples of the tile: 80, 144), and up to
+    4 096 rows every layer's delta is kept and the weight gradients follow as grouped launches -- here nine tiled ones (more than one
+    group holds) and six thin ones; every boundary against the fp64 oracle, contiguous and gathered."""
+    nets = [([0, 1], [64, 64, 64, 32]), ([2, 3], [64, 64, 64, 32]), ([4, 5], [128, 144, 80, 16])]
+    rng = np.random.default_rng(40 + B)
+    spec = ho.HybridSpec(6, [], "rs_components", dict(ho.RS6_PARAMS), ["Rb_het", "Rb_root", "Rb_myc"], ["Q10_het", "Q10_root", "Q10_myc"], ["R_soil"], "tanh", True,
+                         nets=nets, net_activations=["tanh", "sigmoid", "swish"])
+    n = B + 300
+    X = rng.standard_normal((6, n)).astype(np.float32)
+    f = {"ta": (10 + 10 * rng.standard_normal(n)).astype(np.float32)}
+    y = {"R_soil": (rng.random(n) * 5 + 0.5).astype(np.float32)}
+    y["R_soil"][rng.random(n) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 5, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    sl = slice(100, 100 + B)
+    loss, grad, nv = eng.loss_and_grad(eh.EH_SPLIT_TRAIN, 100, B)
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()})
+    assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
+    assert util.elem_relerr(grad, g0, 1e-3) <= 5e-4
+    idx = rng.permutation(n)[:B].astype(np.int32)
+    _check(spec, theta, X, f, y, eng=eng, idx=idx)
+    eng.close()
+
+
 @pytest.mark.parametrize("kind", ["kgeLoss", "pearsonLoss", "pbkgeLoss"])
 def test_moment_losses(kind):
     spec, theta, X, f, y = util.rbq10_case(1500, "tanh", True, 0.1, hidden=(192, 64, 32, 16))
