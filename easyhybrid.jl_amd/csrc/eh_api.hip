@@ -2139,7 +2139,8 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     if (grouped) {
         for (int k = 0; k < h->l_nnets; ++k)
             for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += (long long)lgroup_max * h->l_net[k].out[l];
-        if ((size_t)dk_floats > h->l_dk_cap) {
+        if (dk_floats > (1ll << 28)) grouped = false;          // (more than 1 GiB of kept deltas: layer by layer as at large batches)
+        else if ((size_t)dk_floats > h->l_dk_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
             (void)hipFree(h->l_dk); h->l_dk = nullptr; h->l_dk_cap = 0;
             if (hipMalloc(&h->l_dk, (size_t)dk_floats * sizeof(float)) == hipSuccess) h->l_dk_cap = (size_t)dk_floats;

@@ -218,3 +218,87 @@ def test_random_configuration_trains_and_predicts_like_the_oracle(seed, fastpath
     for t in spec.targets:
         assert util.relerr(out[t], ref[t]) <= 3e-5, (t, spec)
     eng.close()
+
+
+def _lform_case(seed):
+    """networks only the layer-wise form holds (a width above 128 or more than three hidden layers; MultiNN models whose networks do
+    not fit side by side), batch sizes on both sides of every switch of its small- and mid-batch paths (16 / 32-row tiles at 512, the
+    few-rows products up to 1 024, grouped weight gradients up to 4 096, one-workgroup mechanistic stage up to 256)"""
+    rng = np.random.default_rng(700000 + seed)
+    mech = rng.choice(list(TABLES))
+    mm = ho.MECH[mech][0]
+    names = list(mm.params)
+    kinds = rng.integers(0, 3, len(names))
+    if not (kinds == 0).any():
+        kinds[rng.integers(len(names))] = 0
+    neural = [n for n, k in zip(names, kinds) if k == 0]
+    glob = [n for n, k in zip(names, kinds) if k == 1]
+    rng.shuffle(neural); rng.shuffle(glob)
+    menu = [16, 32, 48, 64, 80, 96, 128, 144, 160, 192, 256, 320, 30, 129, 10]      # mostly whole 16-deep k groups (the aligned kernels), some not
+    def widths(force):
+        while True:
+            nl = int(rng.integers(1, 7))
+            w = [int(rng.choice(menu)) for _ in range(nl)]
+            if not force or nl > 3 or max(w) > 128:
+                return w
+    P = int(rng.integers(1, 13))
+    act = str(rng.choice(["tanh", "sigmoid", "relu", "swish", "identity"]))
+    ntarg = int(rng.integers(1, len(mm.outputs) + 1))
+    targets = [str(t) for t in rng.permutation(list(mm.outputs))[:ntarg]]
+    nets, net_acts, hidden = None, None, widths(True)
+    bn = bool(rng.random() < 0.3)
+    if len(neural) >= 2 and rng.random() < 0.4:
+        K = len(neural)
+        P = max(P, K)
+        cuts = np.sort(rng.choice(np.arange(1, P), K - 1, replace=False))
+        rows = np.split(rng.permutation(P), cuts)
+        nets = [([int(r) for r in rw], widths(k == 0)) for k, rw in enumerate(rows)]
+        if rng.random() < 0.5:
+            net_acts = [str(a) for a in rng.choice(["tanh", "sigmoid", "relu", "swish", "identity"], K)]
+        bn = False
+    spec = ho.HybridSpec(P, hidden, mech, TABLES[mech], neural, glob, targets, act, True, input_batchnorm=bn, nets=nets, net_activations=net_acts)
+    B = int(rng.choice([1, 15, 16, 17, 64, 255, 256, 257, 500, 511, 512, 513, 1000, 1024, 1025, 2047, 4096, 4097, 5000]))
+    N = B + int(rng.integers(0, 300))
+    X = (rng.standard_normal((P, N)) * rng.uniform(0.2, 1.5) + (rng.uniform(-3, 3) if bn else 0.0)).astype(np.float32)
+    f = {k: rng.uniform(*FORCING_RANGE[k], N).astype(np.float32) for k in mm.forcings}
+    y = {}
+    for t in targets:
+        v = rng.uniform(0.5, 6, N).astype(np.float32)
+        v[rng.random(N) < rng.choice([0.0, 0.1, 0.6])] = np.nan
+        y[t] = v
+    kind = "mse" if ntarg > 1 else str(rng.choice(["mse", "mse", "mse", "rmse", "mae", "nseLoss"]))
+    gather = bool(rng.random() < 0.3)
+    return spec, ho.init_theta(spec, seed, np.float32), X, f, y, kind, B, N, gather, rng
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EH_FUZZ_N", "60")) // 2))
+def test_random_layerwise_configuration_matches_the_oracle(seed):
+    spec, theta, X, f, y, kind, B, N, gather, rng = _lform_case(seed)
+    if gather:
+        idx = rng.permutation(N)[:B].astype(np.int32)
+        kw = {"idx": idx}
+    else:
+        first = int(rng.integers(0, N - B + 1))
+        idx = np.arange(first, first + B)
+        kw = {"first": first, "count": B}
+    yb = {k: v[idx] for k, v in y.items()}
+    if kind == "nseLoss" and sum(int((~np.isnan(v)).sum()) for v in yb.values()) < 3:
+        kind = "mse"
+    eng = util.load_engine(spec, theta, X, f, y)
+    if kind != "mse":
+        eng.set_training_loss(kind)
+    loss, grad, nv = eng.loss_and_grad(**kw)
+    Xo = X
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), Xo[:, idx], {k: v[idx] for k, v in f.items()}, yb, kind=kind,
+                                   bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+    assert nv == sum(nv0)
+    if sum(nv0) == 0:
+        assert np.isnan(loss) and not grad.any()
+    else:
+        yscale = float(np.nanmax(np.abs(np.concatenate(list(yb.values())))))
+        assert loss == pytest.approx(l0, rel=1e-5, abs=1e-5 * yscale * (yscale if kind == "mse" else 1.0) if kind in ("mse", "mae", "rmse") else None), (kind, spec, B)
+        if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
+            assert util.relerr(grad, g0) <= 1e-5, (kind, spec, B, util.relerr(grad, g0))
+        else:
+            assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec, B)
+    eng.close()
