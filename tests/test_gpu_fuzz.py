@@ -298,7 +298,13 @@ def test_random_layerwise_configuration_matches_the_oracle(seed):
         yscale = float(np.nanmax(np.abs(np.concatenate(list(yb.values())))))
         assert loss == pytest.approx(l0, rel=1e-5, abs=1e-5 * yscale * (yscale if kind == "mse" else 1.0) if kind in ("mse", "mae", "rmse") else None), (kind, spec, B)
         if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
-            assert util.relerr(grad, g0) <= 1e-5, (kind, spec, B, util.relerr(grad, g0))
+            err = util.relerr(grad, g0)
+            if err > 1e-5:
+                # six sigmoid layers in front of an mae loss: is it the arithmetic or the kernels?  The bar where fp32 itself cannot hold
+                # 1e-5 is what the oracle loses when IT runs in fp32 (seed 859 of 1 500: device 9.9e-5, fp32 oracle 1.3e-4)
+                _, g32, _ = ho.loss_and_grad(spec, theta.astype(np.float32), X[:, idx], {k: v[idx] for k, v in f.items()}, yb, kind=kind, dtype=np.float32,
+                                             bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+                assert err <= max(1e-5, 2.0 * util.relerr(g32, g0)), (kind, spec, B, err, util.relerr(g32, g0))
         else:
             assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec, B)
     eng.close()
