@@ -880,7 +880,7 @@ struct eh_handle_s {
     GraphRec cap{};
     int max_blocks = 256;
     int mech_blocks = 0;            // "mech_blocks" option: cap on the streaming kernel's workgroups (0: none -- one workgroup per `mech_tiles` tiles)
-    int mech_tiles = 2;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup
+    int mech_tiles = 0;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup (0: by model -- 2, multi-output models 8)
     // scratch for forward / eval outputs
     float* out_buf = nullptr;
     long long out_cap = 0;
@@ -2517,7 +2517,9 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
     // order, which is what the memory system serves best (tools/ubench/stream31.hip: 5.8 TB/s for this 3 : 1 mix, against 4.8-5.3 for
     // a persistent grid of 1-4 k workgroups striding through it).  Rows of partials: one per workgroup, <= EH_MECH_MAXROWS.
     const long long ntile = (count + per - 1) / per;
-    int tiles = h->mech_tiles > 0 ? h->mech_tiles : 1;
+    // (default: two tiles per workgroup; models with several outputs -- twice the streams, more registers per lane, fewer resident waves --
+    //  eight: FluxPart 0.59 -> 0.63 of the roof per call, RbQ10 best at two, Expo2Pool indifferent; tools/bench_mech.py --tiles)
+    int tiles = h->mech_tiles > 0 ? h->mech_tiles : (net.n_out > 1 ? 8 : 2);
     while ((ntile + tiles - 1) / tiles > EH_MECH_MAXROWS) tiles *= 2;
     int nblk = (int)((ntile + tiles - 1) / tiles);
     if (h->mech_blocks > 0 && nblk > h->mech_blocks) { nblk = h->mech_blocks; tiles = 0; }      // "mech_blocks" option: a capped, grid-striding launch
