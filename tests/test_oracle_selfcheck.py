@@ -289,3 +289,23 @@ def test_model_without_a_network_gradient_matches_finite_differences():
     # at the defaults (raw = inv_sigmoid of the mid-range default) the model is rb = 3, Q10 = 2 for every sample
     out = ho.forward(spec, ho.init_theta(spec, 1, np.float64), X, f)
     assert np.allclose(out["reco"], 3.0 * 2.0 ** (0.1 * (f["ta"].astype(np.float64) - 15.0)))
+
+
+def test_weight_l2_terms_gradient_matches_finite_differences():
+    """several extra-loss terms (src/utils/extract_weights.jl:64-91: per network, weights or biases, normalised or not): the oracle's
+    gradient against central differences of its own value, and the single whole-tree term against weight_l2"""
+    spec = ho.HybridSpec(4, [1], "rbq10", dict(ho.RBQ10_PARAMS), ["rb", "Q10"], [], ["reco"], "tanh", True, nets=[([0, 1], [5, 3]), ([2, 3], [4])])
+    theta = ho.init_theta(spec, 3, np.float64)
+    terms = [(0.3, True, 0, "weight"), (0.7, False, 1, "weight"), (0.2, False, None, "bias"), (0.05, True, None, "weight")]
+    vals, g = ho.weight_l2_terms(spec, theta, terms)
+    fd = np.zeros_like(theta)
+    for i in range(theta.size):
+        e = np.zeros_like(theta); e[i] = 1e-6
+        fd[i] = (sum(ho.weight_l2_terms(spec, theta + e, terms)[0]) - sum(ho.weight_l2_terms(spec, theta - e, terms)[0])) / 2e-6
+    assert np.allclose(g, fd, rtol=1e-7, atol=1e-9)
+    v1, g1 = ho.weight_l2(spec, theta, 0.4, True)
+    vt, gt = ho.weight_l2_terms(spec, theta, [(0.4, True, None, "weight")])
+    assert vt[0] == pytest.approx(v1, rel=1e-14) and np.allclose(gt, g1, rtol=1e-14)
+    # the mean of the squared weights of ONE network: test/test_extract_weights.jl's relation, per network
+    m = np.zeros(spec.n_theta, bool); m[:5 * 2] = True; m[5 * 2 + 5:5 * 2 + 5 + 3 * 5] = True; m[5 * 2 + 5 + 3 * 5 + 3:5 * 2 + 5 + 3 * 5 + 3 + 3] = True
+    assert vals[0] == pytest.approx(0.3 * np.mean(theta[m] ** 2), rel=1e-12)
