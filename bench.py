@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mech-stage", action="store_true", help="skip the secondary measurement of the stand-alone mechanistic + VJP kernel")
     ap.add_argument("--no-epoch", action="store_true", help="skip the secondary measurement of the shuffled epoch (eh_train_epoch)")
+    ap.add_argument("--no-layerwise", action="store_true", help="skip the secondary measurement of the reference's GPU tutorial network (layer-wise form)")
     ap.add_argument("--no-specialize", action="store_true",
                     help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
     args = ap.parse_args()
@@ -410,6 +411,18 @@ def main():
                 out["hbm_stage"] = bm.measure("rbq10", 1024 * B, 50)      # 1 GiB of planes: four times the 256 MB Infinity Cache
             except Exception as e:      # never lose the headline line over the secondary measurement
                 out["hbm_stage"] = {"error": repr(e)}
+        if world == 1 and dp is None and not args.no_layerwise:
+            # the other kernel family of the path: networks no fused kernel holds run layer by layer -- the
+            # reference's own GPU tutorial network (docs/literate/tutorials/synthetic_respiration_gpu.jl:79-103: [1024, 512, 256, 128, 64],
+            # sigmoid, input BatchNorm, RMSProp) at the tutorial's batch of 64 and at the headline batch.  A secondary figure.
+            try:
+                import importlib.util
+                spec_ = importlib.util.spec_from_file_location("eh_bench_lform", os.path.join(ROOT, "tools", "bench_lform.py"))
+                bl = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bl)
+                out["layerwise"] = {"what": "eh_train_step on the reference's GPU tutorial network, fp32, steady state", "bound": "mfma", "peak_TFLOPs": 157.3,
+                                    "runs": [bl.measure(64, local), bl.measure(B, local)]}
+            except Exception as e:
+                out["layerwise"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     eng.close()
     if dist.is_initialized():

@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 prof() { tag=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- "$@" > $OUT/$tag.json 2> $OUT/$tag.err; }
 pmc() { tag=$1; ctr=$2; shift 2; timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$tag -- "$@" > /dev/null 2> $OUT/pmc_$tag.err; }
-B="--no-cpu-baseline --no-mech-stage --no-epoch"
+B="--no-cpu-baseline --no-mech-stage --no-epoch --no-layerwise"
 # headline
 prof bench python3 $ROOT/bench.py --steps 2000 --warmup 200 $B
 pmc bench_fetch FETCH_SIZE python3 $ROOT/bench.py --steps 200 --warmup 20 $B
