@@ -49,6 +49,7 @@ cd $ROOT
   timeout -k 10 300 python3 tools/bench_config.py c1 --steps 2000 --specialize 1
 } > $OUT/bench_config_all.jsonl 2> $OUT/bench_config_all.err
 timeout -k 10 300 python3 tools/bench_lform.py > $OUT/bench_lform.jsonl 2>&1
+for b in 64 1024 4096; do bash tools/lform_trace.sh gpurun_out/prof_r03/lform_trace $b > $OUT/lform_trace_B$b.txt 2>&1; done
 hipcc --offload-arch=gfx950 -O3 -w tools/ubench/stream31.hip -o /tmp/ubench_stream31 && timeout -k 5 120 /tmp/ubench_stream31 > $OUT/ubench_stream31.txt 2>&1
 python3 - "$OUT" > $OUT/pmc_summary.txt <<'PY'
 import csv, glob, sys, collections, os
