@@ -2197,6 +2197,12 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
             }
         }
     }
+    static const bool nodwmerge = getenv("EH_LFORM_NODWMERGE") != nullptr;
+    if (TG.n > 0 && GG.n > 0 && !nodwmerge) {       // what is left of both groups: one launch
+        hipLaunchKernelGGL(eh_dw_group_kernel, dim3((unsigned)(TG.t0[TG.n] + GG.t0[GG.n])), dim3(256), 0, h->stream, GG, TG);
+        TG.n = 0; GG.n = 0;
+        HIPCHK(h, hipGetLastError());
+    }
     flush_thin(); HIPCHK(h, hipGetLastError());
     flush_tiled(); HIPCHK(h, hipGetLastError());
     return EH_OK;

@@ -368,6 +368,26 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_group_kernel(const EhThinGro
     eh_thin_gemm_tile(a, t % gx, t / gx);
 }
 
+// Both groups of a small-batch step's weight gradients -- the tiled ones and the thin ones -- as ONE launch: the first workgroups run
+// the thin products, the others the tiles (one dependent launch fewer; the two bodies' LDS side by side, 44 KB).
+__global__ __launch_bounds__(256) void eh_dw_group_kernel(const EhGemmGroup G, const EhThinGroup T) {
+    const int nthin = T.t0[T.n];
+    if ((int)blockIdx.x < nthin) {
+        int i = 0;
+        while (i + 1 < T.n && (int)blockIdx.x >= T.t0[i + 1]) ++i;
+        const int t = (int)blockIdx.x - T.t0[i], gx = T.gx[i];
+        const EhThinArgs a = T.a[i];
+        eh_thin_gemm_tile(a, t % gx, t / gx);
+    } else {
+        const int b = (int)blockIdx.x - nthin;
+        int i = 0;
+        while (i + 1 < G.n && b >= G.t0[i + 1]) ++i;
+        const int t = b - G.t0[i], gx = G.gx[i], gy = G.gy[i];
+        const EhGemmArgs g = G.g[i];
+        eh_gemm_tile<true, false, EH_GEPI_STORE, true, 64>(g, t % gx, (t / gx) % gy, t / (gx * gy));
+    }
+}
+
 // Products with a degenerate dimension, as streaming kernels (a 128 x 128 MFMA tile spends 94 % and more of such a product on padding;
 // at the tutorial's batch of 64 the three of them -- first layer (2 predictors), output layer (1 output) and its delta -- took
 // 16 + 14 + 13 us of a 250 us step, tools/lform_trace.sh):

@@ -117,7 +117,13 @@ def test_random_configuration_matches_the_oracle(seed, fastpath):
         yscale = float(np.nanmax(np.abs(np.concatenate(list(yb.values())))))
         assert loss == pytest.approx(l0, rel=tol, abs=tol * yscale * (yscale if kind == "mse" else 1.0) if kind in ("mse", "mae", "rmse") else None), (kind, spec)
         if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):         # (a loss the parameters cannot move has a gradient of pure rounding noise)
-            assert util.relerr(grad, g0) <= tol, (kind, spec)
+            err = util.relerr(grad, g0)
+            if err > tol:
+                # the arithmetic or the kernels?  Where the oracle itself, run in fp32, cannot hold the bar, the bar is twice what it loses
+                # (seed 2753 of 5 000: pearsonLoss of 31 samples behind a two-unit relu layer -- device 3.0e-3, fp32 oracle 6.9e-2)
+                _, g32, _ = ho.loss_and_grad(spec, theta.astype(np.float32), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind, dtype=np.float32,
+                                             bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+                assert err <= max(tol, 2.0 * util.relerr(g32, g0)), (kind, spec, err, util.relerr(g32, g0))
         else:
             assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec)
     eng.close()
