@@ -2046,12 +2046,27 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
     pa.bn_part = bn.bn_part; pa.bn_nblk = bn.bn_nblk; pa.bn_c = bn.bn_c; pa.bn_n = bn.bn_n; pa.bn_update = bn.bn_update; pa.bn_run = h->bn_run;
     if (bn_self) { pa.bn_self = 1; pa.bn_update = bn_update ? 1 : 0; }
     const long long tot = (long long)B * net.P;
-    hipLaunchKernelGGL(eh_lform_prep_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa);
-    HIPCHK(h, hipGetLastError());
     const float* theta = TH(h);
+    // the first network's first layer rides along when it is one of the few-predictor products (K <= 8, hidden layer behind it)
+    bool fused0 = false;
+    {
+        const eh_handle_s::LNet& L0 = h->l_net[0];
+        if (!nofuse && !g_gemm_novec && L0.nl >= 2 && L0.in[0] <= 8) {
+            EhGemmArgs g{};
+            g.A = nullptr; g.lda = net.P; g.B = theta + L0.woff[0]; g.ldb = L0.out[0];
+            g.M = B; g.N = L0.out[0]; g.K = L0.in[0]; g.kchunk = g.K; g.bias = theta + L0.boff[0]; g.act = L0.act;
+            g.C = W.H[0][0]; g.ldc = L0.out[0]; g.Z = W.Z[0][0];
+            const long long totc = (long long)g.M * g.N;
+            hipLaunchKernelGGL((eh_lform_prep_kernel<true>), dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (std::max(tot, totc) + 255) / 256))), dim3(256), 0, h->stream, pa, g, L0.c0);
+            fused0 = true;
+        }
+    }
+    if (!fused0) hipLaunchKernelGGL((eh_lform_prep_kernel<false>), dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa, EhGemmArgs{}, 0);
+    HIPCHK(h, hipGetLastError());
     for (int k = 0; k < h->l_nnets; ++k) {
         const eh_handle_s::LNet& L = h->l_net[k];
         for (int l = 0; l < L.nl; ++l) {
+            if (fused0 && k == 0 && l == 0) continue;
             EhGemmArgs g{};
             g.A = l == 0 ? W.Xb + L.c0 : W.H[k][l - 1]; g.lda = l == 0 ? net.P : L.in[l];      // (a network's predictors: its columns of the minibatch matrix)
             g.B = theta + L.woff[l]; g.ldb = L.out[l];                   // canonical (out, in) column-major == [in][out] row-major

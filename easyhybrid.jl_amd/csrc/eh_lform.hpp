@@ -581,7 +581,11 @@ struct EhLPrepArgs {
     const float* bn_part; int bn_nblk; const float* bn_c; const float* bn_n; int bn_update; float* bn_run;
     int bn_self;              // train-mode statistics of a small minibatch taken here (every workgroup the same sums in the same order) -- no eh_bn_stats_kernel
 };
-__global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a) {
+// FWDK: the first Dense layer of a network with few predictors (eh_thin_fwd_k_kernel's product, K <= 8) in the same launch -- its
+// inputs are the values this kernel writes to Xb, taken from the records by the same expression (other workgroups write the rows this
+// one would need): g.A is not read, the network's predictors are columns c0 .. c0 + K - 1 of the minibatch matrix.
+template <bool FWDK>
+__global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a, const EhGemmArgs g, const int c0) {
     __shared__ float mu[32], rs[32], sred[8][64];
     const int tid = threadIdx.x;
     if (a.bn_self) {
@@ -628,6 +632,22 @@ __global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a)
         const long long n = a.idx ? (long long)a.idx[a.first + i] : a.first + i;
         const float x = a.recs[n * a.C + p];
         a.Xb[e] = p < 32 ? (x - mu[p]) * rs[p] : x;        // (the normalisation block holds 32 predictors; wider inputs come without input BatchNorm)
+    }
+    if constexpr (FWDK) {
+        const long long totc = (long long)g.M * g.N;
+        for (long long e = (long long)blockIdx.x * 256 + tid; e < totc; e += (long long)gridDim.x * 256) {
+            const int m = (int)(e / g.N), n = (int)(e - (long long)m * g.N);
+            const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m;
+            float v = 0.0f;
+            for (int k = 0; k < g.K; ++k) {
+                const int p = c0 + k;
+                const float x = a.recs[ng * a.C + p];
+                v = fmaf(p < 32 ? (x - mu[p]) * rs[p] : x, g.B[(long long)k * g.ldb + n], v);
+            }
+            v += g.bias[n];
+            if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
+            g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
+        }
     }
 }
 
