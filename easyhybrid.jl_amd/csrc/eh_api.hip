@@ -328,45 +328,88 @@ __global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part,
 // image in place.  Block = CW columns x 256/CW row groups (CW = 16 for small models: many blocks; CW = 64 for
 // big gradients: 256-byte runs per slab row); every load of a thread is independent, so
 // the whole slab read costs about one L2 round trip.  gradbuf = [grad | loss | counts].
-template <bool APPLY, int CW, int NC = 1>
+template <bool APPLY, int CW, int NC = 1, bool VEC = false>
 __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
                                                         float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
                                                         float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom, const float* l2val, unsigned tp_mask) {
-    // NC > 1 (layer-wise form: hundreds of thousands of columns under a few rows): NC columns per thread, CW apart -- a quarter of the
-    // workgroups, so a quarter of the per-workgroup part (counts, barriers), and NC times the loads in flight per thread
+    // NC > 1 (layer-wise form: hundreds of thousands of columns under a few rows): NC columns per thread -- a quarter of the
+    // workgroups, so a quarter of the per-workgroup part (counts, barriers), and NC times the loads in flight per thread.
+    // VEC (NC == 4): the thread's columns are four CONSECUTIVE ones, moved as 16-byte pieces wherever all four are parameters (slab
+    // rows are only 4-byte aligned: n_acc is any number -- global memory takes unaligned 16-byte accesses); otherwise CW apart.
     constexpr int NQ = 256 / CW;
     static_assert(NC == 1 || NQ == 1, "several columns per thread: one row group");
+    static_assert(!VEC || NC == 4, "16-byte pieces");
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
     __shared__ float part[NQ][CW + 1];
     __shared__ float wsum[4][EH_MAX_TARG + 3];
     const int tid = threadIdx.x, p = tid % CW, q = tid / CW;
-    const int idx0 = blockIdx.x * (CW * NC) + p;
+    constexpr int CS = VEC ? 1 : CW;                       // distance between a thread's columns
+    const int idx0 = VEC ? (blockIdx.x * CW + p) * NC : blockIdx.x * (CW * NC) + p;
+    const bool full = VEC && idx0 + NC - 1 < n_theta;     // all of the thread's columns are parameters: the 16-byte path
     // optimiser inputs are independent of the slab: request them first so they arrive together (only the state the rule keeps:
     // RMSProp has no first moment, Descent none at all)
     const bool use_m = o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW, use_v = use_m || o.rule == EH_OPT_RMSPROP;
     float th[NC], mm[NC], vv[NC], bt1 = 0.0f, bt2 = 0.0f;
     int mp[NC];
 #pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const int idx = idx0 + CW * j;
-        th[j] = 0.0f; mm[j] = 0.0f; vv[j] = 0.0f; mp[j] = -1;
-        if (APPLY && q == 0 && idx < n_theta) {
-            th[j] = theta[idx];
-            if (use_m) mm[j] = m[idx];
-            if (use_v) vv[j] = v[idx];
-            if (idx < im.g_off && im.imap) mp[j] = im.imap[idx];
+    for (int j = 0; j < NC; ++j) { th[j] = 0.0f; mm[j] = 0.0f; vv[j] = 0.0f; mp[j] = -1; }
+    if (VEC && full) {
+        if constexpr (VEC) {
+            if (APPLY || l2val) { const f32x4u t4 = *reinterpret_cast<const f32x4u*>(theta + idx0); th[0] = t4[0]; th[1] = t4[1]; th[2] = t4[2]; th[3] = t4[3]; }
+            if (APPLY && use_m) { const f32x4u t4 = *reinterpret_cast<const f32x4u*>(m + idx0); mm[0] = t4[0]; mm[1] = t4[1]; mm[2] = t4[2]; mm[3] = t4[3]; }
+            if (APPLY && use_v) { const f32x4u t4 = *reinterpret_cast<const f32x4u*>(v + idx0); vv[0] = t4[0]; vv[1] = t4[1]; vv[2] = t4[2]; vv[3] = t4[3]; }
+            if (APPLY && im.imap) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j)
+                    if (idx0 + j < im.g_off) mp[j] = im.imap[idx0 + j];
+            }
         }
-        if (!APPLY && l2val && q == 0 && idx < n_theta) th[j] = theta[idx];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int idx = idx0 + CS * j;
+            if (APPLY && q == 0 && idx < n_theta) {
+                th[j] = theta[idx];
+                if (use_m) mm[j] = m[idx];
+                if (use_v) vv[j] = v[idx];
+                if (idx < im.g_off && im.imap) mp[j] = im.imap[idx];
+            }
+            if (!APPLY && l2val && q == 0 && idx < n_theta) th[j] = theta[idx];
+        }
     }
     if (APPLY && q == 0) { bt1 = sc_in[0]; bt2 = sc_in[1]; }
     // (all of a thread's rows in flight at once: the step is one memory round trip, not nblk / NQ / 16 of them)
     float s[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) s[j] = 0.0f;
-    if (idx0 < n_acc) {
+    if (VEC && full) {
+        if constexpr (VEC) {
+            constexpr int U = 8;
+            const float* col = slab + idx0;
+            int r = 0;
+            for (; r + U - 1 < nblk; r += U) {
+                f32x4u t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = *reinterpret_cast<const f32x4u*>(col + (size_t)u * n_acc);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) s[j] += t[u][j];
+                col += (size_t)U * n_acc;
+            }
+            for (; r < nblk; ++r) {
+                const f32x4u t4 = *reinterpret_cast<const f32x4u*>(col);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) s[j] += t4[j];
+                col += n_acc;
+            }
+        }
+    } else if (idx0 < n_acc) {
         constexpr int U = 32 / NC;
         const float* col[NC];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) col[j] = slab + (size_t)q * n_acc + min(idx0 + CW * j, n_acc - 1);       // (columns past the end: clamped, dropped below)
+        for (int j = 0; j < NC; ++j) col[j] = slab + (size_t)q * n_acc + min(idx0 + CS * j, n_acc - 1);       // (columns past the end: clamped, dropped below)
         const size_t rstride = (size_t)NQ * n_acc;
         int r = q;
         for (; r + (U - 1) * NQ < nblk; r += U * NQ) {
@@ -389,7 +432,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int j = 0; j < NC; ++j)
-            if (idx0 + CW * j >= n_acc) s[j] = 0.0f;
+            if (idx0 + CS * j >= n_acc) s[j] = 0.0f;
     }
     if constexpr (NC == 1) part[q][p] = s[0];
     // valid counts: every block needs them (nblk <= 256: one row per thread)
@@ -400,8 +443,6 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
     float cs[EH_MAX_TARG + 3];
 #pragma unroll
     for (int t = 0; t < EH_MAX_TARG + 3; ++t) cs[t] = 0.0f;
-    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
     for (int r = tid; r < nblk; r += 256) {
         const float* const row = slab + (size_t)r * n_acc + n_theta;
         const f32x4u lo = *reinterpret_cast<const f32x4u*>(row);
@@ -435,9 +476,33 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t) tp_loss += (t < T && ((tp_mask >> t) & 1u)) ? mom[EH_TT * t + 7] : 0.0f;
     }
+    if (VEC && full) {
+        if constexpr (VEC) {
+            const float scale = deferred ? dscale : 1.0f;
+            f32x4u g4;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                float g = s[j] * scale;
+                if (l2val && ntot > 0.0f) { const float c2 = eh_l2_coef(im, idx0 + j); if (c2 != 0.0f) g = fmaf(2.0f * c2, th[j], g); }
+                g4[j] = g;
+                if (APPLY && ntot > 0.0f) eh_opt_update(o, g, bt1, bt2, th[j], mm[j], vv[j]);
+            }
+            *reinterpret_cast<f32x4u*>(gradbuf + idx0) = g4;
+            if (APPLY && ntot > 0.0f) {
+                *reinterpret_cast<f32x4u*>(theta + idx0) = f32x4u{th[0], th[1], th[2], th[3]};
+                if (use_m) *reinterpret_cast<f32x4u*>(m + idx0) = f32x4u{mm[0], mm[1], mm[2], mm[3]};
+                if (use_v) *reinterpret_cast<f32x4u*>(v + idx0) = f32x4u{vv[0], vv[1], vv[2], vv[3]};
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    if (idx0 + j < im.g_off) { if (mp[j] >= 0) im.image[mp[j]] = th[j]; }
+                    else eh_image_store(im, idx0 + j, th[j]);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        const int idx = idx0 + CW * j;
+        const int idx = idx0 + CS * j;
         if (q == 0 && idx < n_acc) {
             float tot = 0.0f;
             if constexpr (NC == 1) {
@@ -465,6 +530,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
                 gradbuf[idx] = tot;
             }
         }
+    }
     }
     if (APPLY && blockIdx.x == 0 && tid == 0) {
         sc_out[0] = ntot > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
@@ -2383,10 +2449,10 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     hipLaunchKernelGGL((eh_reduce_kernel<AP, __VA_ARGS__>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
                        TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)
     if (apply) {
-        if (tall4) EH_REDUCE_GO(true, 256, 4); else if (tall) EH_REDUCE_GO(true, 256); else if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
+        if (tall4) EH_REDUCE_GO(true, 256, 4, true); else if (tall) EH_REDUCE_GO(true, 256); else if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
     } else {
-        if (tall4) EH_REDUCE_GO(false, 256, 4); else if (tall) EH_REDUCE_GO(false, 256); else if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
+        if (tall4) EH_REDUCE_GO(false, 256, 4, true); else if (tall) EH_REDUCE_GO(false, 256); else if (big) EH_REDUCE_GO(false, 64); else EH_REDUCE_GO(false, 16);
     }
 #undef EH_REDUCE_GO
     HIPCHK(h, hipGetLastError());
