@@ -142,6 +142,11 @@ def parity_replay(model, eng_factory, cols, X, B, nsteps=20):
     eng = eng_factory()
     try:
         eng.set_params(theta0)
+        # where the 1e-5 bar of the north_star applies: ONE loss + gradient on the headline batch itself, against the fp64 oracle
+        l1, g1, _ = eng.loss_and_grad(eh.EH_SPLIT_TRAIN, 0, B)
+        l64, g64, _ = ho.loss_and_grad(spec, theta0.astype(np.float64), X[:, :B], {"ta": f["ta"][:B]}, {"reco": y["reco"][:B]})
+        step0 = {"loss_rel_diff": abs(l1 - l64) / abs(l64), "grad_relerr": float(np.max(np.abs(g1 - g64)) / np.max(np.abs(g64))),
+                 "what": "loss and gradient of batch 0 at the initial parameters, GPU engine vs oracle/hybrid_oracle.py in fp64 (bar: 1e-5)"}
         eng.opt_init("Adam", 0.01, 0.9, 0.999, 1e-8)
         for s in range(nsteps):
             eng.train_step(s * B, B, want_loss=False)
@@ -150,9 +155,13 @@ def parity_replay(model, eng_factory, cols, X, B, nsteps=20):
     finally:
         eng.close()
     return {"steps": nsteps, "final_loss": l_gpu, "oracle_final_loss": l_ref, "rel_diff": abs(l_gpu - l_ref) / abs(l_ref),
-            "theta_max_abs_diff": float(np.max(np.abs(th - th_ref))),
+            "theta_max_abs_diff": float(np.max(np.abs(th - th_ref))), "theta_frac_within_1e-3": float(np.mean(np.abs(th - th_ref) <= 1e-3)),
+            "step0": step0,
             "what": f"{nsteps} Adam steps from initialparameters(161803) on batches 0..{nsteps - 1} of the bench's own (un-scaled) dataset, then the "
-                    f"loss of batch {nsteps}: GPU engine (same kernel and mode as the timed run) vs oracle/eh_oracle.c (fp32, checker only)"}
+                    f"loss of batch {nsteps}: GPU engine (same kernel and mode as the timed run) vs oracle/eh_oracle.c (fp32, checker only).  Two fp32 "
+                    "trajectories: Adam's first steps are lr * sign-like, so a gradient entry near zero (saturated first-layer units at this input scale) "
+                    "turns rounding into a full step for that parameter -- the loss agrees to ~1e-4, single entries of theta may not; the one-step "
+                    "comparison `step0` is the parity statement"}
 
 
 def main():
