@@ -910,6 +910,7 @@ struct eh_handle_s {
     int l_nnets = 0;                                     // 0: no network at all (no neural parameter)
     LNet l_net[EH_MAX_NETS];
     float* l_split = nullptr; size_t l_split_cap = 0;    // split-K partial products of the small-batch GEMMs
+    unsigned* l_lprog = nullptr; int l_lprog_gen = -1;  // the recorded loss programs as the layer-wise form interprets them (device copy, generation it was made from)
     float* l_dk = nullptr; size_t l_dk_cap = 0;          // every layer's delta of a small-batch step (the weight gradients then run as one grouped launch)
     float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
     long long l_cap = 0;                                 // samples the workspace holds
@@ -1639,7 +1640,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->l2w); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->wflag);
+    (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->l_lprog); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1725,7 +1726,6 @@ int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
         any_two = any_two || (kinds[t] >= EH_LOSS_PEARSONLOSS && kinds[t] <= EH_LOSS_PBKGELOSS) || (kinds[t] == EH_LOSS_RMSE && n > 1);
     }
     if (same) return eh_set_option(h, "training_loss", kinds[0]);
-    if (any_prog && h->lform) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) has no run-time compiled kernels: a recorded loss function needs a model the fused kernels hold");
     if (any_two && h->fused) return fail(h, EH_EUNSUPPORTED, "rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step: switch fused_update off first");
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
@@ -1800,7 +1800,6 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
                 if (!h->loss_prog.has(t)) return fail(h, EH_ESTATE, "training_loss EH_LOSS_PROGRAM: call eh_set_loss_program first");
         const bool two = (value >= EH_LOSS_PEARSONLOSS && value <= EH_LOSS_PBKGELOSS) || (value == EH_LOSS_RMSE && h->net.T > 1);
         if (two && h->fused) return fail(h, EH_EUNSUPPORTED, "rmse (on a multi-target model) / pearson / kge training losses take forward passes ahead of the step: switch fused_update off first");
-        if (h->lform && value == EH_LOSS_PROGRAM) return fail(h, EH_EUNSUPPORTED, "the layer-wise form (wide / deep networks) has no run-time compiled kernels: a recorded loss function needs a model the fused kernels hold");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->net.loss = (int)value;
@@ -2199,11 +2198,36 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         }
     }
     a.inv_n = (net.T > 1 || tpm) ? h->inv_n : nullptr;
+    // recorded loss functions: no kernel is compiled at run time in this form -- the mechanistic kernel interprets their tapes
+    bool lprog = false;
+    for (int t = 0; t < net.T; ++t) lprog = lprog || ((net.loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_PROGRAM;
+    if (lprog) {
+        if (h->l_lprog_gen != h->loss_prog.gen) {
+            std::vector<unsigned> img((size_t)EH_MAX_TARG * EH_LPROG_WORDS, 0u);
+            for (int t = 0; t < net.T; ++t) {
+                if (!h->loss_prog.has(t)) continue;
+                const EhLossProg1& lp = h->loss_prog.of(t);
+                unsigned* q = img.data() + (size_t)t * EH_LPROG_WORDS;
+                q[0] = (unsigned)lp.code.size(); q[1] = 1u; q[2] = (unsigned)lp.out;
+                for (size_t k = 0; k < lp.consts.size() && k < (size_t)EH_MAX_PROG_CONST; ++k) memcpy(&q[8 + k], &lp.consts[k], sizeof(float));
+                for (size_t i = 0; i < lp.code.size() && i < (size_t)EH_MAX_PROG; ++i) q[24 + i] = lp.code[i];
+            }
+            if (!h->l_lprog) HIPCHK(h, hipMalloc(&h->l_lprog, img.size() * sizeof(unsigned)));
+            HIPCHK(h, hipStreamSynchronize(h->stream));          // (steps in flight read the old programs)
+            HIPCHK(h, hipMemcpy(h->l_lprog, img.data(), img.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+            h->l_lprog_gen = h->loss_prog.gen;
+        }
+        a.lprog = h->l_lprog;
+    }
     EhLMechArgs m{W.O, W.ldo, W.part, nullptr, 0, 0};
     const int mgrid = (int)std::min<long long>(2048, (count + 255) / 256);
     static const bool nofuse = getenv("EH_LFORM_NOFUSE") != nullptr;
     if (mgrid == 1 && !nofuse) { m.slab = h->slab; m.nrows = rows; m.n_acc = (long long)h->n_acc; }      // one workgroup: it writes the slab's tail columns itself
-    if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+    if (lprog) {
+        if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+        else hipLaunchKernelGGL((eh_lform_mech_kernel<true, false, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
+    }
+    else if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
     else hipLaunchKernelGGL((eh_lform_mech_kernel<true, false>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
     HIPCHK(h, hipGetLastError());
     if (!m.slab) {

@@ -171,7 +171,10 @@ struct EhStepArgs {
     EhP2P p2pv;           // EH_MODE_TRAIN_P2P: the same descriptor by value -- the kernels read it from the kernarg segment
                           // instead of chasing `p2p` (one dependent memory round trip less in front of the exchange)
     const unsigned* prog; // EH_MECH_PROGRAM kernels only: [0] length, [1] outputs, [2..4] output slots, [8..23] constants, [24..] code
+    const unsigned* lprog; // recorded training losses where no kernel is compiled at run time (the layer-wise form): one program per target,
+                           // EH_LPROG_WORDS apart, in the same layout -- slot 0 = yhat, slot 1 = y, [2] = the slot of l(yhat, y); interpreted
 };
+enum { EH_LPROG_WORDS = 24 + EH_MAX_PROG };
 
 #define EH_BN_EPS 1e-5f
 #define EH_BN_MOMENTUM 0.1f

@@ -679,7 +679,7 @@ __device__ __forceinline__ void eh_lform_tail_write(const float* tot, const EhNe
 }
 
 enum { EH_LMECH_PART = 16 };
-template <bool TRAIN, bool PROG>
+template <bool TRAIN, bool PROG, bool LPROG = false>
 __global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, const EhStepArgs a, const EhLMechArgs m, const float* meta_g) {
     constexpr int SR = 64;
     __shared__ float OSs[4][16 * SR], SGs[4][16 * SR], RSs[4][(EH_MAX_FORC + EH_MAX_TARG) * SR], metas[EH_IMG_META], red[4][32];
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, con
             }
             OS[k * SR + lane] = pv; SG[k * SR + lane] = sv;
         }
-        eh_mech_stage_lane<TRAIN, PROG>(net, a, lane, live, n_loc, SR, RS, OS, SG, metas, MA);      // (every access of a lane is to its own column: no cross-lane traffic)
+        eh_mech_stage_lane<TRAIN, PROG, LPROG>(net, a, lane, live, n_loc, SR, RS, OS, SG, metas, MA);      // (every access of a lane is to its own column: no cross-lane traffic)
         if constexpr (TRAIN) {
             if (live)
                 for (int k = 0; k < net.K; ++k) m.O[(long long)k * m.ldo + n_loc] = OS[k * SR + lane];

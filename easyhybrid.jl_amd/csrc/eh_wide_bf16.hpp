@@ -106,7 +106,7 @@ struct EhMechAcc {
 // Mechanistic model + masked loss + its pullback for ONE sample per lane (the caller's wave 0, lane = sample of the tile):
 // physical parameters in OS[row k][lane] with d parameter / d NN output in SG, forcings / targets in RS -> (train) d loss / d NN
 // output back into OS, sums into `acc`; (eval) predictions / parameters written out.  Same arithmetic as stage 5 of eh_wide_kernel.
-template <bool TRAIN, bool PROG, class NET>
+template <bool TRAIN, bool PROG, bool LPROG = false, class NET>
 __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepArgs& a, int lane, bool live, int n_loc, int SR, const float* RS,
                                                    float* OS, const float* SG, const float* meta, EhMechAcc& A) {
     auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
@@ -164,6 +164,27 @@ __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepA
                     const float lv = eh_jit_loss(t, y, valid ? yobs[t] : y, dl);
                     A.lacc += valid ? w * lv : 0.0f;
                     d = valid ? w * dl : 0.0f;
+                }
+#else
+                else if (LPROG && eh_target_prog(net.loss_t, t)) {
+                    // a recorded loss function where no kernel is compiled around it (the layer-wise form): its tape interpreted, forward
+                    // then the reverse sweep from d l / d l = 1 -- the arithmetic eh_jit_loss would have been generated from
+                    if constexpr (LPROG) {
+                        const unsigned* const lp = a.lprog + t * EH_LPROG_WORDS;
+                        float lpar[EH_MAX_PARAMS], lfrc[EH_MAX_FORC], lval[EH_PROG_SLOTS], ladj[EH_PROG_SLOTS];
+#pragma unroll
+                        for (int j = 0; j < EH_MAX_PARAMS; ++j) lpar[j] = 0.0f;
+#pragma unroll
+                        for (int f = 0; f < EH_MAX_FORC; ++f) lfrc[f] = 0.0f;
+                        lpar[0] = y; lpar[1] = valid ? yobs[t] : y;
+                        eh_prog_forward(lp, lpar, lfrc, lval);
+                        const int nslot = EH_PROG_SLOT_INSTR + (int)lp[0];
+                        for (int i = 0; i < nslot; ++i) ladj[i] = 0.0f;
+                        ladj[lp[2]] = 1.0f;
+                        eh_prog_reverse(lp, lval, ladj);
+                        A.lacc += valid ? w * lval[lp[2]] : 0.0f;
+                        d = valid ? w * ladj[0] : 0.0f;
+                    } else d = 0.0f;
                 }
 #endif
                 else if (eh_target_two_pass(net.loss_t, t, net.T)) {      // two-pass losses (see eh_step_kernel)

@@ -174,9 +174,75 @@ def test_refusals():
     eng = util.model_from_spec(ho.rbq10_spec((256, 256), "tanh", True)).engine()
     with pytest.raises(NotImplementedError):
         eng.set_option("fused_update", 1)
-    with pytest.raises(NotImplementedError):
-        eng.set_training_loss(lambda yh, y: np.mean(np.abs(yh - y) ** 1.5))      # a recorded loss needs a run-time compiled (fused) kernel
     eng.close()
+
+
+def _huber(yh, y, delta=0.7):
+    r = np.abs(yh - y)
+    return np.mean(np.where(r <= delta, 0.5 * r * r, delta * (r - 0.5 * delta)))
+
+
+@pytest.mark.parametrize("B", [64, 700, 3000])
+def test_recorded_loss_function_on_a_network_the_fused_kernels_do_not_hold(B):
+    """training_loss::Function (src/losses/loss_fn.jl:92-107) on the tutorial network's kind: no kernel is compiled at run time in the
+    layer-wise form, the mechanistic kernel interprets the recorded tape (forward, then the reverse sweep from d l / d l = 1) -- loss and
+    gradient against the oracle running the function itself, an Adam trajectory, and the named loss coming back afterwards"""
+    spec, theta, X, f, y = util.rbq10_case(B, "sigmoid", True, 0.1, hidden=(160, 64, 32, 16))
+    util.register_loss("huber_lform", _huber)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(_huber)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind="huber_lform")
+    lm, gm, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert abs(l0 - lm) > 1e-3 * abs(lm)                       # (not mse in disguise)
+    assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
+    eng.opt_init("Adam", 0.01)
+    n2 = B // 2
+    batches = [(0, n2), (n2, B - n2)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32, kind="huber_lform")
+    assert np.allclose(losses, l_ref, rtol=2e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 2e-5) >= 0.999
+    eng.set_params(theta)
+    eng.set_training_loss("mse")
+    l1, g1, _ = eng.loss_and_grad()
+    assert abs(l1 - lm) <= TOL * abs(lm) and util.relerr(g1, gm) <= TOL
+    eng.close()
+
+
+def test_train_front_door_with_a_recorded_loss_on_a_deep_network():
+    cols = eh.synthetic.make_synth_rbq10(1500, seed=4, nan_frac=0.05)
+    cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[160, 64, 32, 16], activation="sigmoid", scale_nn_outputs=True)
+    out = eh.train(model, cols, nepochs=4, batchsize=128, opt=eh.Adam(0.003), training_loss=_huber, loss_types=["mse", "mae"], random_seed=7, keep_history=True)
+    assert all(np.isfinite(h["mse"]["sum"]) for h in out.val_history)
+    assert out.val_history[-1]["mae"]["sum"] < out.val_history[0]["mae"]["sum"]
+
+
+def test_recorded_losses_per_target_in_the_layer_wise_form():
+    """PerTarget((f, :mse)) and PerTarget((:mae, f)) on a two-target model that runs layer by layer (compute_loss.jl:128-145)"""
+    def pseudo_huber(yh, y):
+        r = yh - y
+        return np.mean(np.sqrt(1.0 + r * r) - 1.0)
+    rng = np.random.default_rng(8)
+    B = 500
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(6, [160, 96, 48, 24], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((6, B)).astype(np.float32)
+    f = {"SW_IN": (rng.random(B) * 400).astype(np.float32), "TA": (rng.random(B) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(B).astype(np.float32), "GPP": (rng.random(B) * 3).astype(np.float32)}
+    y["NEE"][rng.random(B) < 0.2] = np.nan; y["GPP"][rng.random(B) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 3, np.float32)
+    name = util.register_loss("pseudo_huber_lform", pseudo_huber) and "pseudo_huber_lform"
+    for kinds, dev in (((name, name), pseudo_huber), ((name, "mse"), eh.PerTarget((pseudo_huber, "mse"))), (("mae", name), eh.PerTarget(("mae", pseudo_huber)))):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_training_loss(dev)
+        loss, grad, nv = eng.loss_and_grad()
+        l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kinds)
+        assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= 2e-5, (kinds, loss, l0, util.relerr(grad, g0))
+        eng.close()
 
 
 # ---- what the layer-wise form did not hold in round 2: swish, MultiNNHybridModel, the moment losses ----------------------------------
