@@ -1985,9 +1985,20 @@ static long long lform_floats_per_sample(const eh_handle* h) {
         }
     return w + 2 * maxw;
 }
+// an allocation would be needed while a graph is being recorded: drop the recording (the engine stays usable) and say what to do
+static int lform_alloc_in_capture(eh_handle* h, const char* what) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(h->stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    h->capturing = false;
+    return fail(h, EH_ESTATE, "%s: the layer-wise form sizes this buffer at the first step that needs it -- run one step of this batch size (and training loss) "
+                              "before eh_graph_begin, then record; the recording was dropped", what);
+}
 static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
     const long long cap_need = (count + 127) / 128 * 128;
     if (cap_need > h->l_cap) {
+        if (h->capturing) return lform_alloc_in_capture(h, "workspace");
         HIPCHK(h, hipStreamSynchronize(h->stream));
         (void)hipFree(h->l_ws);
         h->l_ws = nullptr; h->l_cap = 0;
@@ -2068,7 +2079,7 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
             const int ns = (g.K + kc - 1) / kc;
             const size_t need = (size_t)ns * g.M * g.N;
             if (ns > 1) {
-                if (need > h->l_split_cap) {
+                if (need > h->l_split_cap && !h->capturing) {      // (while a graph is being recorded: no allocation -- the tiled kernel below runs instead)
                     if (hipStreamSynchronize(h->stream) == hipSuccess) { (void)hipFree(h->l_split); h->l_split = nullptr; h->l_split_cap = 0; }
                     if (hipMalloc(&h->l_split, need * sizeof(float)) == hipSuccess) h->l_split_cap = need; else (void)hipGetLastError();
                 }
@@ -2203,6 +2214,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     for (int t = 0; t < net.T; ++t) lprog = lprog || ((net.loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_PROGRAM;
     if (lprog) {
         if (h->l_lprog_gen != h->loss_prog.gen) {
+            if (h->capturing) return lform_alloc_in_capture(h, "recorded loss programs");
             std::vector<unsigned> img((size_t)EH_MAX_TARG * EH_LPROG_WORDS, 0u);
             for (int t = 0; t < net.T; ++t) {
                 if (!h->loss_prog.has(t)) continue;
@@ -2246,6 +2258,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
             for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += (long long)lgroup_max * h->l_net[k].out[l];
         if (dk_floats > (1ll << 28)) grouped = false;          // (more than 1 GiB of kept deltas: layer by layer as at large batches)
         else if ((size_t)dk_floats > h->l_dk_cap) {
+            if (h->capturing) return lform_alloc_in_capture(h, "kept deltas");
             HIPCHK(h, hipStreamSynchronize(h->stream));
             (void)hipFree(h->l_dk); h->l_dk = nullptr; h->l_dk_cap = 0;
             if (hipMalloc(&h->l_dk, (size_t)dk_floats * sizeof(float)) == hipSuccess) h->l_dk_cap = (size_t)dk_floats;

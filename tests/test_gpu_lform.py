@@ -177,6 +177,29 @@ def test_refusals():
     eng.close()
 
 
+def test_graph_capture_needs_a_warm_up_step_and_says_so():
+    """hipGraph capture (eh_graph_begin / _end / _launch) of steps of a layer-wise model: the form sizes its buffers at the first step of
+    a batch size, which cannot happen inside a recording -- a clear error, the recording dropped, the engine still usable; after one
+    warm-up step the same recording works and replays to the same parameters as eager steps"""
+    spec, theta, X, f, y = util.rbq10_case(1024, "tanh", True, 0.1, hidden=(160, 64, 32, 16))
+    eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
+    eng.graph_begin()
+    with pytest.raises(eh.EngineError, match="before eh_graph_begin"):
+        eng.train_step(0, 256, want_loss=False)
+    eng.train_step(0, 256, want_loss=False)                       # (eager: sizes the buffers; the engine survived the dropped recording)
+    eng.set_params(theta); eng.opt_init("Adam", 0.01)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
+    eng.graph_begin()
+    for s_ in range(4):
+        eng.train_step(s_ * 256, 256, want_loss=False)
+    g = eng.graph_end()
+    eng.graph_launch(g); eng.synchronize()
+    for s_ in range(4):
+        ref.train_step(s_ * 256, 256, want_loss=False)
+    assert np.array_equal(eng.get_params(), ref.get_params())
+    eng.close(); ref.close()
+
+
 def _huber(yh, y, delta=0.7):
     r = np.abs(yh - y)
     return np.mean(np.where(r <= delta, 0.5 * r * r, delta * (r - 0.5 * delta)))
