@@ -857,7 +857,8 @@ struct eh_handle_s {
     int variant = 0, act = 0, fast = 0;
     float* image = nullptr;
     int* imap = nullptr;
-    int* rmap = nullptr;            // v2 reduction map for the current fast-path flags
+    int* rmap = nullptr;            // reduction map for the current kernel family / variant / fast-path flags (v3: the inverse map)
+    size_t rmap_cap = 0;
     // block placement of every net inside the padded (block-diagonal) MLP
     int n_nets = 1;                                     // 1 for SingleNN
     int net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0};
@@ -1166,7 +1167,24 @@ static int build_maps(eh_handle* h, bool with_imap) {
         if (!h->imap) HIPCHK(h, hipMalloc(&h->imap, imap.size() * sizeof(int)));
         HIPCHK(h, hipMemcpy(h->imap, imap.data(), imap.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    if (!h->rmap) HIPCHK(h, hipMalloc(&h->rmap, rmap.size() * sizeof(int)));
+    // the per-wave kernel's v3 reduction gathers in accumulator order: it wants the INVERSE map, word of a parked accumulator -> canonical
+    // index (-1: padding, structural zeros, the columns of a row sum but the first), then the 16 tail words
+    const size_t emap_n = (size_t)L.na * 256 + 16;
+    if (!A->wide && !v2) {
+        std::vector<int> emap(emap_n, -1);
+        for (int e = 0; e < h->n_acc; ++e) {
+            const int pos = rmap[(size_t)e] & 0xFFFFFF;
+            if (pos >= 0 && (size_t)pos < emap_n) emap[(size_t)pos] = e;
+        }
+        rmap.swap(emap);
+    }
+    if (rmap.size() > h->rmap_cap) {           // (the kernel family / variant / fast-path options change the layout, and with it the size)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->rmap); h->rmap = nullptr; h->rmap_cap = 0;
+        const size_t want = std::max(rmap.size(), std::max((size_t)h->n_acc, emap_n));
+        HIPCHK(h, hipMalloc(&h->rmap, want * sizeof(int)));
+        h->rmap_cap = want;
+    }
     HIPCHK(h, hipMemcpy(h->rmap, rmap.data(), rmap.size() * sizeof(int), hipMemcpyHostToDevice));
     return EH_OK;
 }

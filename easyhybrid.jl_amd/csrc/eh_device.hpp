@@ -1517,15 +1517,12 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     constexpr bool REDV3 = TRAIN && !REDV2 && KH >= 1;
     if constexpr (REDV3) {
         constexpr int NR = (AL.na + KH - 1) / KH;
-        // every map entry this thread will need, requested before anything else: one global round trip for the whole epilogue
-        constexpr int MAXACC = G::IP * HP + (NL - 1) * HP * HP + 16 * HP + NL * HP + 16 + EH_MAX_PARAMS + 1 + EH_MAX_TARG + 2;
-        constexpr int NE = (MAXACC + NTHR - 1) / NTHR;
-        int code[NE];
-#pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int e = tid + u * NTHR;
-            code[u] = e < a.n_acc ? (u == 0 ? f_rcode : a.rmap[e]) : -1;
-        }
+        // The gather runs in ACCUMULATOR order: in the round that holds accumulators [rd KH, rd KH + KH) thread t sums word t of each of
+        // them over the waves and stores it at its canonical index, which the host-built inverse map gives (a.rmap holds, for the shapes
+        // of this branch, emap[k * 256 + word] = canonical index or -1, then 16 tail words: eh_api.hip build_maps).  (Walking the elements
+        // in canonical order instead, every thread had to look at all of its ~20 elements in every one of the NR rounds -- 14 k of config
+        // 3's 238 k cycles, tools/stamps_c3.py.)  Same additions in the same order as before: bit-identical sums.
+        constexpr int NU = (KH * 256 + NTHR - 1) / NTHR;       // words of a round per thread: word (tid + u NTHR) of the round's KH x 256
         float tailv[16];
 #pragma unroll
         for (int j = 0; j < EH_MAX_PARAMS; ++j) tailv[j] = (j < net.n_par) ? eh_wave_sum(gacc[j]) * meta[EH_IMG_DPHI + j] : 0.0f;
@@ -1572,6 +1569,13 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         for (int rd = 0; rd < NR; ++rd) {
             __syncthreads();                       // the wave workspaces are dead / the previous round has been gathered
             if (rd == 0) EH_STAMP(14);
+            int dst[NU], dtail = -1;               // (requested ahead of the parking stores and the barrier)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int wd = tid + u * NTHR;     // accumulator rd KH + wd / 256 of the kernel, its word wd % 256
+                dst[u] = (wd < KH * 256 && rd * KH + wd / 256 < AL.na) ? a.rmap[rd * KH * 256 + wd] : -1;
+            }
+            if (rd == NR - 1 && tid < 16) dtail = a.rmap[AL.na * 256 + tid];
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk)
                 if (rd * KH + kk < AL.na) *(f32x4*)&R[kk * 256 + c * 16 + g * 4] = vals[rd * KH + kk];
@@ -1585,28 +1589,28 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             __syncthreads();
             if (rd == 0) EH_STAMP(9);
             {
-                // branch-free reads (an element of another round reads word 0 and drops it): the LDS requests of all of a
-                // thread's elements are in flight together instead of one round trip per element
-                float sumv[NE];
+                float sumv[NU], sumt = 0.0f;
 #pragma unroll
-                for (int u = 0; u < NE; ++u) {
-                    const int pos = code[u] & 0xFFFFFF, k = pos >> 8, in = pos & 255;
-                    const bool mine = code[u] >= 0 && (k == AL.na ? rd == NR - 1 : k / KH == rd);
-                    const int base = mine ? (k == AL.na ? KH * 256 + in : (k - rd * KH) * 256 + in) : 0;
+                for (int u = 0; u < NU; ++u) {
+                    const int wd = min(tid + u * NTHR, KH * 256 - 1);
                     float sum = 0.0f;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) sum += R0[w * G::WAVE_WS + base];
+                    for (int w = 0; w < NW; ++w) sum += R0[w * G::WAVE_WS + wd];
                     sumv[u] = sum;
                 }
+                if (rd == NR - 1 && tid < 16) {
 #pragma unroll
-                for (int u = 0; u < NE; ++u) {
-                    const int e = tid + u * NTHR;
-                    const int k = (code[u] & 0xFFFFFF) >> 8;
-                    const bool mine = code[u] >= 0 && (k == AL.na ? rd == NR - 1 : k / KH == rd);
-                    if (mine) {
-                        if (gsh) atomicAdd(&gsh[e], sumv[u]);
-                        else out[e] = sumv[u];
+                    for (int w = 0; w < NW; ++w) sumt += R0[w * G::WAVE_WS + KH * 256 + tid];
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (dst[u] >= 0) {
+                        if (gsh) atomicAdd(&gsh[dst[u]], sumv[u]);
+                        else out[dst[u]] = sumv[u];
                     }
+                if (dtail >= 0) {
+                    if (gsh) atomicAdd(&gsh[dtail], sumt);
+                    else out[dtail] = sumt;
                 }
             }
         }
