@@ -31,7 +31,20 @@ PEAK_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 PEAK_HBM_GBPS = 8000.0
 
 
+EX_RENDEZVOUS = 75            # a rank could not join the rendezvous (the port was taken between the probe and rank 0's bind): retried once
+
+
 def spawn_ranks(nprocs, cmd, env=None, capture=False, timeout=None):
+    """spawn_ranks_once, and once more on a fresh port when a rank reports that the rendezvous itself failed (exit code
+    EX_RENDEZVOUS): the free port is found by bind(0) / close, so another job on the box can take it before rank 0 binds."""
+    out = spawn_ranks_once(nprocs, cmd, env=env, capture=capture, timeout=timeout)
+    if (out[0] if capture else out) == EX_RENDEZVOUS:
+        print("bench.py: the rendezvous failed (port taken?); one more try on a fresh port", file=sys.stderr, flush=True)
+        out = spawn_ranks_once(nprocs, cmd, env=env, capture=capture, timeout=timeout)
+    return out
+
+
+def spawn_ranks_once(nprocs, cmd, env=None, capture=False, timeout=None):
     """The launcher `python bench.py --gpus N` is its own: start `cmd` N times, one process per rank (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, rendezvous on 127.0.0.1 at a free port), wait for all of them,
     and stop the others (by their exact PIDs) as soon as one fails -- a rank that died would leave its peers in a barrier.
@@ -205,10 +218,14 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        try:
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        except Exception as e:                              # nothing has run yet: the launcher may try again on another port
+            print(f"bench.py rank {rank}: rendezvous failed: {e!r}", file=sys.stderr, flush=True)
+            sys.exit(EX_RENDEZVOUS if os.environ.get("EH_BENCH_LAUNCHER") else 1)
 
     import easyhybrid_jl_amd as eh
     from easyhybrid_jl_amd.synthetic import RBQ10_PARAMS, make_synth_rbq10

@@ -103,6 +103,8 @@ SIGNATURES = {
     "eh_p2p_attach": (C.c_int32, [_H, C.c_void_p, C.c_int64]),
     "eh_p2p_selftest": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_int32)]),
     "eh_p2p_disable": (C.c_int32, [_H]),
+    "eh_p2p_init_local": (C.c_int32, [C.POINTER(_H), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "eh_p2p_check_local": (C.c_int32, [C.POINTER(_H), C.c_int32, C.POINTER(C.c_int32)]),
     "eh_set_bn_shift": (C.c_int32, [_H, _F, C.c_int64]),
     "eh_dp_bn_stats": (C.c_int32, [_H, C.c_int64, C.c_int64]),
     "eh_dp_fused_step": (C.c_int32, [_H, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),

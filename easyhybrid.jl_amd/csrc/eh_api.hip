@@ -1,11 +1,9 @@
-// C ABI of libeasyhybrid_hip.so (declared in include/easyhybrid_hip.h) and the small kernels around
-// the fused step kernel: partial-slab reduction + optimiser update, valid counts, epoch
-// permutation, record packing.  Everything here runs on one HIP stream per handle; there is no CPU
-// compute path.
+// C ABI of libeasyhybrid_hip.so (declared in include/easyhybrid_hip.h): model, data, parameters, forward / eval, the training
+// step and epoch, the optimiser, graphs, the data-parallel seam eh_dp_*.  The small kernels live in eh_kernels.hpp, the handle in
+// eh_internal.hpp, the library's own collectives (eh_comm_*, eh_p2p_*) in eh_comm.hip.  Everything here runs on one HIP stream
+// per handle; there is no CPU compute path.
 #include <hip/hip_runtime.h>
 #include <chrono>
-#include <rccl/rccl.h>      // types only: the library is bound at run time, by the first eh_comm_* call (see EhRccl)
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -19,954 +17,14 @@
 #include <thread>
 #include <vector>
 
-#include "eh_arch.hpp"
-#include "eh_jit.hpp"
+#include "eh_internal.hpp"
+#include "eh_kernels.hpp"
 #include "eh_wide.hpp"
 #include "eh_lform.hpp"
 
-// --------------------------------------------------------------------------------------------
-// small kernels
-// --------------------------------------------------------------------------------------------
-// Where the optimiser mirrors theta into the padded parameter image the step kernel stages.
-struct EhImg {
-    float* image;
-    const int* imap;     // canonical index -> image offset (-1 for the raw globals)
-    int g_off, phi_off;
-    int glob_par[EH_MAX_PARAMS];   // global g -> canonical mech parameter j
-    float glo[EH_MAX_PARAMS], ghi[EH_MAX_PARAMS];
-    // extra loss lambda * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91): l2c = lambda or lambda / #weights;
-    // the Dense weight matrices are the canonical entries whose image offset lies below the bias block
-    float l2c;
-    int b_off;
-    const unsigned char* wflag;   // layer-wise form (no image, imap == nullptr): 1 at the canonical positions of Dense weights
-    // several weight_l2 terms (one per network of a MultiNNHybridModel, each with its own lambda / normalisation, or the biases:
-    // extract_weights.jl:64 `l2_Rb = lambda * weight_l2(ps.Rb; normalize = true)`): one coefficient per canonical entry,
-    // extra loss = sum_i l2w[i] theta_i^2 (eh_set_weight_l2_coef); nullptr: the one-lambda form above
-    const float* l2w;
-    int n_theta;
-};
-__device__ __forceinline__ bool eh_is_weight(const EhImg& im, int idx) { return idx < im.g_off && (im.imap ? im.imap[idx] < im.b_off : im.wflag[idx] != 0); }
-// d(extra loss) / d theta_idx = 2 * this * theta_idx
-__device__ __forceinline__ float eh_l2_coef(const EhImg& im, int idx) { return im.l2w ? im.l2w[idx] : (eh_is_weight(im, idx) ? im.l2c : 0.0f); }
+std::string g_create_err;
 
-// the extra loss of the CURRENT parameters (before the optimiser kernel touches them): l2c * sum of squared Dense weights, or sum_i l2w[i] theta_i^2
-__global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, EhImg im, float* out) {
-    __shared__ float red[4];
-    float s = 0.0f;
-    if (im.l2w) {
-        for (int i = threadIdx.x; i < im.n_theta; i += 256) { const float w = theta[i]; s = fmaf(im.l2w[i] * w, w, s); }
-    } else {
-        for (int i = threadIdx.x; i < im.g_off; i += 256)
-            if (eh_is_weight(im, i)) { const float w = theta[i]; s += w * w; }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = (im.l2w ? 1.0f : im.l2c) * ((red[0] + red[1]) + (red[2] + red[3]));
-}
-
-__device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float th) {
-    if (idx < im.g_off) {
-        if (im.imap) im.image[im.imap[idx]] = th;      // (layer-wise form: the kernels read the canonical theta itself)
-    } else {   // raw global -> physical value and sigmoid slope (GenericHybridModel.jl:348-352)
-        const int g = idx - im.g_off, j = im.glob_par[g];
-        const float s = 1.0f / (1.0f + expf(-th));
-        im.image[im.phi_off + EH_IMG_PHI + j] = im.glo[g] + (im.ghi[g] - im.glo[g]) * s;
-        im.image[im.phi_off + EH_IMG_DPHI + j] = (im.ghi[g] - im.glo[g]) * s * (1.0f - s);
-    }
-}
-
-__global__ void eh_image_kernel(const float* theta, int n_theta, EhImg im) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n_theta) eh_image_store(im, idx, theta[idx]);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Mechanistic stage on its own (eh_mech_loss_vjp): o = NN outputs of an MLP that lives OUTSIDE this library -> physical
-// parameters (sigma-scaling) -> M(par, forcings) -> masked MSE summed over the targets -> d loss / d o and the gradient of
-// the raw global parameters.  Pure streaming: 4 (K + F + T) bytes read and 4 K written per sample, ~20-60 flop -- the one
-// stage of the path that the HBM roof bounds.  Every lane owns V consecutive samples (V = 4: 16-byte
-// loads and stores, a wave covers 1 KiB runs of every array); sums leave a workgroup once, as one row of partials.
-// ---------------------------------------------------------------------------------------------------------------------
-struct EhMechArgs {
-    const float* o;                          // [K][ld] NN outputs (raw)
-    const float* frc[EH_MAX_FORC];           // the F forcing arrays in eh_set_data order
-    const float* y[EH_MAX_TARG];             // the T target arrays (NaN = missing)
-    float* d_o;                              // [K][ld] d loss / d o
-    float* yhat;                             // [T][ld] or nullptr
-    long long n, ld;
-    const float* meta;                       // parameter image, PHI block (values / d value d raw of the global and fixed parameters, lo, hi - lo)
-    const unsigned long long* counts;        // valid samples per target (whole call), counted on the device ...
-    unsigned long long counts_v[EH_MAX_TARG];   // ... or handed in by the caller (use_v)
-    int use_v;
-    float* part;                             // [gridDim.x][EH_MECH_PART] partial sums
-    const unsigned* prog;                    // EH_MECH_PROGRAM: the recorded closure (EhStepArgs::prog layout)
-    int tiles;                               // > 0: workgroup b owns the `tiles` consecutive 256 V-sample tiles from b * tiles (a front that moves through memory
-                                             // with the dispatch order); 0: grid-stride trips (a capped grid)
-};
-enum { EH_MECH_PART = 16 };                  // [dL/dpar_j (8) | S_t (4) | pad]
-enum { EH_MECH_MAXROWS = 65536 };            // rows of partials (workgroups of the streaming kernel) at most: 4 MiB
-
-template <int V>
-__global__ __launch_bounds__(256) void eh_count_valid_kernel(EhMechArgs a, int T, unsigned long long* counts) {
-    unsigned c[EH_MAX_TARG] = {0, 0, 0, 0};
-    const long long stride = (long long)gridDim.x * 256 * V;
-    for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * V; i0 < a.n; i0 += 4 * stride)
-#pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t)
-            if (t < T) {
-                if constexpr (V == 4) {
-                    f32x4 v[4];                                  // four trips requested before the first is examined
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = i0 + u * stride < a.n ? *(const f32x4*)(a.y[t] + i0 + u * stride) : f32x4{0, 0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u * stride < a.n) c[t] += !__builtin_isnan(v[u][0]) + !__builtin_isnan(v[u][1]) + !__builtin_isnan(v[u][2]) + !__builtin_isnan(v[u][3]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u * stride < a.n) c[t] += !__builtin_isnan(a.y[t][i0 + u * stride]);
-                }
-            }
-    __shared__ unsigned sh[4][EH_MAX_TARG];
-#pragma unroll
-    for (int t = 0; t < EH_MAX_TARG; ++t) {
-        unsigned v = c[t];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][t] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < T) atomicAdd(&counts[threadIdx.x], (unsigned long long)(sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
-}
-
-// (parameters, forcings, outputs) of a registry model: compile-time array sizes, so that a two-parameter model keeps a dozen
-// values per sample in registers, not the 8 + 4 + 4 of the largest one (occupancy is what a streaming kernel lives on)
-// (EH_MECH_PROGRAM, a recorded closure run by the interpreter of eh_device.hpp: the limits of the program format)
-constexpr int eh_mech_np(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_PARAMS : m == EH_MECH_EXPO2POOL ? 4 : (m == EH_MECH_RS_COMPONENTS || m == EH_MECH_RS_COMPONENTS3F) ? 6 : m == EH_MECH_FLUXPART ? 3 : 2; }
-constexpr int eh_mech_nf(int m) { return m == EH_MECH_PROGRAM ? EH_MAX_FORC : m == EH_MECH_FLUXPART ? 2 : m == EH_MECH_RS_COMPONENTS3F ? 3 : 1; }
-constexpr int eh_mech_no(int m) { return (m == EH_MECH_PROGRAM || m == EH_MECH_FLUXPART) ? 3 : 1; }
-
-// (RbQ10: 68 VGPRs, seven waves per SIMD.  Forcing eight -- amdgpu_waves_per_eu(8): 64 VGPRs -- spills two registers, and a kernel
-// with ANY scratch pays for the allocation at every wave launch, which a launch of tens of thousands of short workgroups cannot afford.)
-template <int V, int MECH>
-__global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMechArgs a) {
-    constexpr int NP = eh_mech_np(MECH), NF = eh_mech_nf(MECH), NO = eh_mech_no(MECH), NTG = NO > 1 ? EH_MAX_TARG : 1;
-    float cpar[NP], lo[NP], sc[NP], w[NTG];
-    int row[NP];                                                 // NN output row of a neural parameter, -1 otherwise
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        cpar[j] = a.meta[EH_IMG_PHI + j]; lo[j] = a.meta[EH_IMG_LO + j]; sc[j] = a.meta[EH_IMG_SC + j];
-        row[j] = (((net.par_kind >> (2 * j)) & 3u) == EH_PAR_NEURAL) ? (int)((net.par_idx >> (4 * j)) & 15u) : -1;
-    }
-#pragma unroll
-    for (int t = 0; t < NTG; ++t) {
-        const unsigned long long c = a.use_v ? a.counts_v[t] : a.counts[t];
-        w[t] = (t < net.T && c > 0) ? 1.0f / (float)c : 0.0f;
-    }
-    float gp[NP], S[NTG];
-    const bool mae = net.loss == EH_LOSS_MAE;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) gp[j] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < NTG; ++t) S[t] = 0.0f;
-    const long long i_first = a.tiles > 0 ? ((long long)blockIdx.x * a.tiles * 256 + threadIdx.x) * V : ((long long)blockIdx.x * 256 + threadIdx.x) * V;
-    const long long i_step = a.tiles > 0 ? 256ll * V : (long long)gridDim.x * 256 * V;
-    // (no std::min here: it takes references, and a reference to a member of the by-value kernarg struct makes the compiler copy the
-    // whole struct to scratch -- 200 bytes per lane and 24 VGPRs more, measured)
-    const long long n_all = a.n, tile_end = (long long)(blockIdx.x + 1) * a.tiles * 256 * V;
-    const long long i_end = (a.tiles > 0 && tile_end < n_all) ? tile_end : n_all;
-    for (long long i = i_first; i < i_end; i += i_step) {
-        float ov[NP][V], fv[NF][V], yv[NTG][V], dov[NP][V], yh[NTG][V];
-        auto ld = [&](const float* p, float (&dst)[V]) {
-            if constexpr (V == 4) { const f32x4 v = *(const f32x4*)(p + i); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
-            else dst[0] = p[i];
-        };
-        auto st = [&](float* p, const float (&src)[V]) {
-            if constexpr (V == 4) *(f32x4*)(p + i) = f32x4{src[0], src[1], src[2], src[3]};
-            else p[i] = src[0];
-        };
-        // every load of the tile is requested before the first use
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            if (row[j] >= 0) ld(a.o + (long long)row[j] * a.ld, ov[j]);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const unsigned col = (net.forc_col >> (8 * f)) & 255u;
-            if (col != 255u) ld(a.frc[col], fv[f]);
-            else
-#pragma unroll
-                for (int e = 0; e < V; ++e) fv[f][e] = 0.0f;
-        }
-#pragma unroll
-        for (int t = 0; t < NTG; ++t)
-            if (t < net.T) ld(a.y[t], yv[t]);
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            float par[EH_MAX_PARAMS], sg[NP], dydp[EH_MAX_PARAMS], frc[EH_MAX_FORC];
-#pragma unroll
-            for (int j = NP; j < EH_MAX_PARAMS; ++j) { par[j] = 0.0f; dydp[j] = 0.0f; }
-#pragma unroll
-            for (int f = NF; f < EH_MAX_FORC; ++f) frc[f] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                par[j] = cpar[j]; sg[j] = 0.0f; dydp[j] = 0.0f;
-                if (row[j] >= 0) {
-                    if (net.scale_nn) { const float s = eh_sigmoid(ov[j][e]); par[j] = fmaf(sc[j], s, lo[j]); sg[j] = sc[j] * s * (1.0f - s); }
-                    else { par[j] = ov[j][e]; sg[j] = 1.0f; }
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < NF; ++f) frc[f] = fv[f][e];
-            float yx[2] = {0.0f, 0.0f}, Jx[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-            constexpr bool PROG = MECH == EH_MECH_PROGRAM;
-            float pval[PROG ? EH_PROG_SLOTS : 1], y0;
-            if constexpr (PROG) {
-                eh_prog_forward(a.prog, par, frc, pval);
-                y0 = pval[a.prog[2]];
-                if (net.n_out > 1) yx[0] = pval[a.prog[3]];
-                if (net.n_out > 2) yx[1] = pval[a.prog[4]];
-            } else {
-                y0 = eh_mech_eval(MECH, par, frc, dydp);
-                if constexpr (NO > 1) eh_mech_extra(MECH, par, frc, yx, Jx);
-            }
-            float dy = 0.0f, dyx[2] = {0.0f, 0.0f};
-#pragma unroll
-            for (int t = 0; t < NTG; ++t)
-                if (t < net.T) {
-                    const int oi = NO > 1 ? (int)((net.targ_out >> (2 * t)) & 3u) : 0;
-                    const float y = oi == 0 ? y0 : (oi == 1 ? yx[0] : yx[1]);
-                    yh[t][e] = y;
-                    const float r = __builtin_isnan(yv[t][e]) ? 0.0f : y - yv[t][e];
-                    float d;
-                    if (mae) { S[t] += fabsf(r); d = r > 0.0f ? w[t] : (r < 0.0f ? -w[t] : 0.0f); }      // mean |r| (loss_fn.jl:64-66)
-                    else { S[t] = fmaf(r, r, S[t]); d = 2.0f * w[t] * r; }                              // mean r^2 (loss_fn.jl:61-63)
-                    dy += oi == 0 ? d : 0.0f; dyx[0] += oi == 1 ? d : 0.0f; dyx[1] += oi == 2 ? d : 0.0f;
-                }
-            float padj[PROG ? EH_PROG_SLOTS : 1];
-            if constexpr (PROG) {                                // reverse sweep over the tape (what Zygote derives from the closure)
-                const int nslot = EH_PROG_SLOT_INSTR + (int)a.prog[0];
-                for (int q = 0; q < nslot; ++q) padj[q] = 0.0f;
-                padj[a.prog[2]] += dy;
-                if (net.n_out > 1) padj[a.prog[3]] += dyx[0];
-                if (net.n_out > 2) padj[a.prog[4]] += dyx[1];
-                eh_prog_reverse(a.prog, pval, padj);
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                float dp = PROG ? padj[PROG ? j : 0] : dy * dydp[j];
-                if (!PROG && NO > 1 && j < 3) dp += dyx[0] * Jx[0][j] + dyx[1] * Jx[1][j];
-                gp[j] += row[j] >= 0 ? 0.0f : dp;
-                dov[j][e] = dp * sg[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            if (row[j] >= 0) st(a.d_o + (long long)row[j] * a.ld, dov[j]);
-        if (a.yhat)
-#pragma unroll
-            for (int t = 0; t < NTG; ++t)
-                if (t < net.T) st(a.yhat + (long long)t * a.ld, yh[t]);
-    }
-    __shared__ float sh[4][EH_MECH_PART];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        const float v = eh_wave_sum(k < 8 ? (k < NP ? gp[k < NP ? k : 0] : 0.0f) : (k - 8 < NTG ? S[k - 8 < NTG ? k - 8 : 0] : 0.0f));
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 12) a.part[(long long)blockIdx.x * EH_MECH_PART + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-}
-
-// rows of partials -> out[0] = loss, out[1 + j] = d loss / d raw global parameter j (canonical parameter order), fixed order:
-// deterministic.  Up to 2 048 rows: eh_mech_finish_kernel alone (one workgroup, 64 row groups x 16 columns, all of a thread's loads
-// -- rows written on other XCDs, each a trip to memory -- requested before the first add).  More rows: eh_mech_fold_kernel first,
-// whose workgroup g folds rows [g rows_per, (g + 1) rows_per) into row g of a second, <= 64-row table for the finish kernel.  (One
-// launch with a ticket for the last workgroup was measured and lost: 13.6 us at 4 096 rows, 37 us at 65 536 -- the release in front
-// of the ticket writes back an L2 -- against 5.1-5.7 us for the plain one-workgroup kernel; profiles/r03/mech_stage_ab.txt.)
-__device__ __forceinline__ float eh_mech_fold_rows(const float* part, int r0, int r1, float (*red)[EH_MECH_PART]) {
-    const int k = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (int rb = r0 + grp; rb < r1; rb += 64 * 32) {
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = rb + 64 * u < r1 ? part[(long long)(rb + 64 * u) * EH_MECH_PART + k] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < 32; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
-    }
-    red[grp][k] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    float s = 0.0f;
-    if (grp == 0)
-        for (int g2 = 0; g2 < 64; ++g2) s += red[g2][k];
-    return s;                                                    // (threads 0..15 hold column k's sum)
-}
-__global__ __launch_bounds__(1024) void eh_mech_fold_kernel(const float* part, int nblk, int rows_per, float* part2) {
-    __shared__ float red[64][EH_MECH_PART];
-    const int r0 = blockIdx.x * rows_per;
-    const float s = eh_mech_fold_rows(part, r0, min(nblk, r0 + rows_per), red);
-    if (threadIdx.x < EH_MECH_PART) part2[blockIdx.x * EH_MECH_PART + threadIdx.x] = s;
-}
-__global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part, int nblk, const EhNet net, const float* meta, const EhMechArgs a, float* out) {
-    __shared__ float red[64][EH_MECH_PART];
-    const int k = threadIdx.x & 15;
-    const float s = eh_mech_fold_rows(part, 0, nblk, red);
-    if (threadIdx.x >= EH_MECH_PART) return;
-    __shared__ float St[EH_MAX_TARG];
-    if (k >= 8 && k < 12) {
-        const unsigned long long c = a.use_v ? a.counts_v[k - 8] : a.counts[k - 8];
-        St[k - 8] = (k - 8 < net.T && c > 0) ? s / (float)c : 0.0f;
-    }
-    else if (k < 8) out[1 + k] = (k < net.n_par && ((net.par_kind >> (2 * k)) & 3u) == EH_PAR_GLOBAL) ? s * meta[EH_IMG_DPHI + k] : 0.0f;
-    EH_WAVE_SYNC();                                              // (the 16 threads left are lanes of one wave)
-    if (k == 0) out[0] = (St[0] + St[1]) + (St[2] + St[3]);
-}
-
-// Sum the per-workgroup partials of the step kernel (fixed order: deterministic), normalise by the
-// valid count when the step ran with deferred normalisation, and (APPLY) update theta and its
-// image in place.  Block = CW columns x 256/CW row groups (CW = 16 for small models: many blocks; CW = 64 for
-// big gradients: 256-byte runs per slab row); every load of a thread is independent, so
-// the whole slab read costs about one L2 round trip.  gradbuf = [grad | loss | counts].
-template <bool APPLY, int CW, int NC = 1, bool VEC = false>
-__global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict__ slab, int nblk, int n_acc, int n_theta, int T, int deferred,
-                                                        float* __restrict__ gradbuf, float* theta, float* m, float* v, const float* sc_in,
-                                                        float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, const float* mom, const float* l2val, unsigned tp_mask) {
-    // NC > 1 (layer-wise form: hundreds of thousands of columns under a few rows): NC columns per thread -- a quarter of the
-    // workgroups, so a quarter of the per-workgroup part (counts, barriers), and NC times the loads in flight per thread.
-    // VEC (NC == 4): the thread's columns are four CONSECUTIVE ones, moved as 16-byte pieces wherever all four are parameters (slab
-    // rows are only 4-byte aligned: n_acc is any number -- global memory takes unaligned 16-byte accesses); otherwise CW apart.
-    constexpr int NQ = 256 / CW;
-    static_assert(NC == 1 || NQ == 1, "several columns per thread: one row group");
-    static_assert(!VEC || NC == 4, "16-byte pieces");
-    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
-    __shared__ float part[NQ][CW + 1];
-    __shared__ float wsum[4][EH_MAX_TARG + 3];
-    const int tid = threadIdx.x, p = tid % CW, q = tid / CW;
-    constexpr int CS = VEC ? 1 : CW;                       // distance between a thread's columns
-    const int idx0 = VEC ? (blockIdx.x * CW + p) * NC : blockIdx.x * (CW * NC) + p;
-    const bool full = VEC && idx0 + NC - 1 < n_theta;     // all of the thread's columns are parameters: the 16-byte path
-    // optimiser inputs are independent of the slab: request them first so they arrive together (only the state the rule keeps:
-    // RMSProp has no first moment, Descent none at all)
-    const bool use_m = o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW, use_v = use_m || o.rule == EH_OPT_RMSPROP;
-    float th[NC], mm[NC], vv[NC], bt1 = 0.0f, bt2 = 0.0f;
-    int mp[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) { th[j] = 0.0f; mm[j] = 0.0f; vv[j] = 0.0f; mp[j] = -1; }
-    if (VEC && full) {
-        if constexpr (VEC) {
-            if (APPLY || l2val) { const f32x4u t4 = *reinterpret_cast<const f32x4u*>(theta + idx0); th[0] = t4[0]; th[1] = t4[1]; th[2] = t4[2]; th[3] = t4[3]; }
-            if (APPLY && use_m) { const f32x4u t4 = *reinterpret_cast<const f32x4u*>(m + idx0); mm[0] = t4[0]; mm[1] = t4[1]; mm[2] = t4[2]; mm[3] = t4[3]; }
-            if (APPLY && use_v) { const f32x4u t4 = *reinterpret_cast<const f32x4u*>(v + idx0); vv[0] = t4[0]; vv[1] = t4[1]; vv[2] = t4[2]; vv[3] = t4[3]; }
-            if (APPLY && im.imap) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j)
-                    if (idx0 + j < im.g_off) mp[j] = im.imap[idx0 + j];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            const int idx = idx0 + CS * j;
-            if (APPLY && q == 0 && idx < n_theta) {
-                th[j] = theta[idx];
-                if (use_m) mm[j] = m[idx];
-                if (use_v) vv[j] = v[idx];
-                if (idx < im.g_off && im.imap) mp[j] = im.imap[idx];
-            }
-            if (!APPLY && l2val && q == 0 && idx < n_theta) th[j] = theta[idx];
-        }
-    }
-    if (APPLY && q == 0) { bt1 = sc_in[0]; bt2 = sc_in[1]; }
-    // (all of a thread's rows in flight at once: the step is one memory round trip, not nblk / NQ / 16 of them)
-    float s[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) s[j] = 0.0f;
-    if (VEC && full) {
-        if constexpr (VEC) {
-            constexpr int U = 8;
-            const float* col = slab + idx0;
-            int r = 0;
-            for (; r + U - 1 < nblk; r += U) {
-                f32x4u t[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) t[u] = *reinterpret_cast<const f32x4u*>(col + (size_t)u * n_acc);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) s[j] += t[u][j];
-                col += (size_t)U * n_acc;
-            }
-            for (; r < nblk; ++r) {
-                const f32x4u t4 = *reinterpret_cast<const f32x4u*>(col);
-#pragma unroll
-                for (int j = 0; j < NC; ++j) s[j] += t4[j];
-                col += n_acc;
-            }
-        }
-    } else if (idx0 < n_acc) {
-        constexpr int U = 32 / NC;
-        const float* col[NC];
-#pragma unroll
-        for (int j = 0; j < NC; ++j) col[j] = slab + (size_t)q * n_acc + min(idx0 + CS * j, n_acc - 1);       // (columns past the end: clamped, dropped below)
-        const size_t rstride = (size_t)NQ * n_acc;
-        int r = q;
-        for (; r + (U - 1) * NQ < nblk; r += U * NQ) {
-            float t[U][NC];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int j = 0; j < NC; ++j) t[u][j] = col[j][u * rstride];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int j = 0; j < NC; ++j) s[j] += t[u][j];
-#pragma unroll
-            for (int j = 0; j < NC; ++j) col[j] += U * rstride;
-        }
-#pragma unroll 4
-        for (; r < nblk; r += NQ) {
-#pragma unroll
-            for (int j = 0; j < NC; ++j) { s[j] += *col[j]; col[j] += rstride; }
-        }
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            if (idx0 + CS * j >= n_acc) s[j] = 0.0f;
-    }
-    if constexpr (NC == 1) part[q][p] = s[0];
-    // valid counts: every block needs them (nblk <= 256: one row per thread)
-    // wsum columns: [0..3] n_valid per target, [4] S, [5] Sy, [6] Syy
-    // (a row's scalars [S | n_t ... | Sy | Syy] are 3 + T consecutive floats behind the gradient: two wide loads per row -- one
-    //  instruction per column made every workgroup walk 7 x 256 cache lines and cost 2-3 us of a launch, tools/ubench/reduce.hip;
-    //  4-byte aligned only, and up to 3 floats past a row's end when T < 4: the slab is allocated with that much slack)
-    float cs[EH_MAX_TARG + 3];
-#pragma unroll
-    for (int t = 0; t < EH_MAX_TARG + 3; ++t) cs[t] = 0.0f;
-    for (int r = tid; r < nblk; r += 256) {
-        const float* const row = slab + (size_t)r * n_acc + n_theta;
-        const f32x4u lo = *reinterpret_cast<const f32x4u*>(row);
-        const f32x3u hi = *reinterpret_cast<const f32x3u*>(row + 4);
-        const float f[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
-#pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) cs[t] += t < T ? f[1 + t] : 0.0f;
-        cs[EH_MAX_TARG] += f[0];
-#pragma unroll
-        for (int t = 1; t <= EH_MAX_TARG; ++t)
-            if (t == T) { cs[EH_MAX_TARG + 1] += f[1 + t]; cs[EH_MAX_TARG + 2] += f[2 + t]; }
-    }
-#pragma unroll
-    for (int t = 0; t < EH_MAX_TARG + 3; ++t) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cs[t] += __shfl_xor(cs[t], off, 64);
-        if ((tid & 63) == 0) wsum[tid >> 6][t] = cs[t];
-    }
-    __syncthreads();
-    float cnts[EH_MAX_TARG + 3], ntot = 0.0f;
-#pragma unroll
-    for (int t = 0; t < EH_MAX_TARG + 3; ++t) {
-        cnts[t] = (wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]);
-        if (t < EH_MAX_TARG) ntot += cnts[t];
-    }
-    float dscale = 1.0f, dloss = 0.0f;
-    if (deferred) eh_loss_finish(loss_kind, cnts[EH_MAX_TARG], cnts[0], cnts[EH_MAX_TARG + 1], cnts[EH_MAX_TARG + 2], dscale, dloss);
-    if (deferred && mom && cnts[0] > 0.0f) { dscale = 1.0f; dloss = mom[7]; }      // moment-based loss: per-sample weights were exact, value from eh_moment_coef_kernel
-    float tp_loss = 0.0f;                    // multi-target: the targets whose loss came out of the coefficient kernel (the others' terms are in the loss sum)
-    if (!deferred && mom) {
-#pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) tp_loss += (t < T && ((tp_mask >> t) & 1u)) ? mom[EH_TT * t + 7] : 0.0f;
-    }
-    if (VEC && full) {
-        if constexpr (VEC) {
-            const float scale = deferred ? dscale : 1.0f;
-            f32x4u g4;
-#pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                float g = s[j] * scale;
-                if (l2val && ntot > 0.0f) { const float c2 = eh_l2_coef(im, idx0 + j); if (c2 != 0.0f) g = fmaf(2.0f * c2, th[j], g); }
-                g4[j] = g;
-                if (APPLY && ntot > 0.0f) eh_opt_update(o, g, bt1, bt2, th[j], mm[j], vv[j]);
-            }
-            *reinterpret_cast<f32x4u*>(gradbuf + idx0) = g4;
-            if (APPLY && ntot > 0.0f) {
-                *reinterpret_cast<f32x4u*>(theta + idx0) = f32x4u{th[0], th[1], th[2], th[3]};
-                if (use_m) *reinterpret_cast<f32x4u*>(m + idx0) = f32x4u{mm[0], mm[1], mm[2], mm[3]};
-                if (use_v) *reinterpret_cast<f32x4u*>(v + idx0) = f32x4u{vv[0], vv[1], vv[2], vv[3]};
-#pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    if (idx0 + j < im.g_off) { if (mp[j] >= 0) im.image[mp[j]] = th[j]; }
-                    else eh_image_store(im, idx0 + j, th[j]);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const int idx = idx0 + CS * j;
-        if (q == 0 && idx < n_acc) {
-            float tot = 0.0f;
-            if constexpr (NC == 1) {
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) tot += part[k][p];
-            } else tot = s[j];
-            const float scale = deferred ? dscale : 1.0f;
-            if (idx < n_theta) {
-                float g = tot * scale;
-                if (l2val && ntot > 0.0f) { const float c2 = eh_l2_coef(im, idx); if (c2 != 0.0f) g = fmaf(2.0f * c2, th[j], g); }      // + d/dw (l2c * sum w^2)
-                gradbuf[idx] = g;
-                if (APPLY && ntot > 0.0f) {
-                    eh_opt_update(o, g, bt1, bt2, th[j], mm[j], vv[j]);
-                    theta[idx] = th[j];
-                    if (use_m) m[idx] = mm[j];
-                    if (use_v) v[idx] = vv[j];
-                    if (idx < im.g_off) { if (mp[j] >= 0) im.image[mp[j]] = th[j]; }
-                    else eh_image_store(im, idx, th[j]);
-                }
-            } else if (idx == n_theta) {
-                const float loss = ntot > 0.0f ? (deferred ? dloss : tot + tp_loss) + (l2val ? *l2val : 0.0f) : __builtin_nanf("");      // agg = sum([loss, extra...]), compute_loss.jl:31-34
-                gradbuf[idx] = loss;
-                if (loss_slot) *loss_slot = loss;
-            } else {
-                gradbuf[idx] = tot;
-            }
-        }
-    }
-    }
-    if (APPLY && blockIdx.x == 0 && tid == 0) {
-        sc_out[0] = ntot > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
-        sc_out[1] = ntot > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
-    }
-}
-
-// fused-update mode: apply the still-pending gradient (sharded accumulator g_prev) in place
-__global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev, int n_acc, int n_theta, float* theta, float* m, float* v,
-                                                             const float* sc_in, float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind,
-                                                             const EhP2P* p2p, int slot, unsigned seq, int T) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    float cnt = 0.0f, sse = 0.0f, sy = 0.0f, syy = 0.0f, gs_p2p = 0.0f;
-    if (p2p) {       // every rank's sums of the last step, straight from the receive shards (see EhP2P)
-        auto ad = [&](int i) -> const unsigned long long* {
-            const int sh = i / 5, k = i % 5;
-            if (sh >= p2p->world || (k == 4 && idx >= n_theta)) return nullptr;
-            const unsigned long long* base = p2p->peer_recv[p2p->rank] + ((long long)slot * EH_GSHARDS + sh) * n_acc;
-            return k < 4 ? base + n_theta + k : base + idx;
-        };
-        unsigned long long w[5 * EH_GSHARDS];
-        float got[5 * EH_GSHARDS];
-        eh_ll_issue(ad, seq, w);
-        eh_ll_finish(p2p, ad, seq, w, got);
-#pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) { sse += got[5 * sh]; cnt += got[5 * sh + 1]; sy += got[5 * sh + 2]; syy += got[5 * sh + 3]; gs_p2p += got[5 * sh + 4]; }
-    } else {
-#pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) {
-            const float* gp = g_prev + sh * n_acc + n_theta;
-            sse += gp[0];
-            if (T == 1) { cnt += gp[1]; sy += gp[2]; syy += gp[3]; }
-            else for (int t = 0; t < T; ++t) cnt += gp[1 + t];
-        }
-    }
-    float inv = 0.0f, lossv = 0.0f;
-    if (T == 1) eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
-    else { inv = cnt > 0.0f ? 1.0f : 0.0f; lossv = cnt > 0.0f ? sse : __builtin_nanf(""); }      // multi-target: the step used exact per-target weights
-    if (idx < n_theta && cnt > 0.0f) {
-        float gs = gs_p2p;
-        if (!p2p) {
-#pragma unroll
-            for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * n_acc + idx];
-        }
-        float th = theta[idx], mm = m[idx], vv = v[idx];
-        eh_opt_update(o, gs * inv, sc_in[0], sc_in[1], th, mm, vv);
-        theta[idx] = th; m[idx] = mm; v[idx] = vv;
-    }
-    if (idx < n_theta) eh_image_store(im, idx, theta[idx]);
-    if (idx == 0) {
-        sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
-        sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
-        if (loss_slot) *loss_slot = lossv;
-    }
-}
-
-// eh_p2p_selftest: one exchange round of the EhP2P protocol with a known vector per rank
-__device__ __forceinline__ float eh_p2p_test_value(int rank, int i, unsigned seq) { return (float)((rank + 1) * 1000 + (i % 97) + (int)(seq & 255u)); }
-__global__ __launch_bounds__(256) void eh_p2p_test_kernel(const EhP2P* P, int slot, unsigned seq, int n_acc, int* bad) {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n_acc; i += 256) {
-        const unsigned long long w = eh_ll_pack(eh_p2p_test_value(P->rank, i, seq), seq);
-        for (int r = 0; r < P->world; ++r)
-            __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    for (int i = tid; i < n_acc; i += 256) {
-        auto ad = [&](int r) -> const unsigned long long* {
-            return r < P->world ? P->peer_recv[P->rank] + ((long long)slot * EH_GSHARDS + r) * n_acc + i : nullptr;
-        };
-        unsigned long long w[EH_GSHARDS];
-        float got[EH_GSHARDS];
-        eh_ll_issue(ad, seq, w);
-        eh_ll_finish(P, ad, seq, w, got, 5ull * EH_P2P_DEADLINE_TICKS / 2);        // 5 s: at start-up the ranks may be a while apart
-        float sum = 0.0f, want = 0.0f;
-        for (int r = 0; r < P->world; ++r) { sum += got[r]; want += eh_p2p_test_value(r, i, seq); }
-        if (sum != want) atomicAdd(bad, 1);
-    }
-}
-
-// Moment-based training losses (pearsonLoss, kgeLoss, pbkgeLoss; src/losses/loss_fn.jl:75-77,105-174): from the batch
-// moments the forward-only pass left in the slab ([blocks][EH_EVAL_STATS], shifted by c) to the loss value and the
-// coefficients of  d loss / d yhat_i = k0 + k1 (yhat_i - cu) + k2 (y_i - c).  out = [1, cu, -, -, k0, k1, k2, loss].
-// With u = yhat - cu (cu = batch mean of yhat, from a first forward pass), w = y - c:  r = Suw_c / sqrt(Suu_c Sww_c),  alpha = sqrt(Suu_c / Sww_c) (the n-1 of std cancels),
-// beta = mean(yhat) / mean(y);  dr/du_i = (w_i - mw) / sqrt(Suu_c Sww_c) - r (u_i - mu) / Suu_c,
-// dalpha/du_i = (u_i - mu) / (alpha Sww_c),  dbeta/du_i = 1 / (n mean(y)).
-// stage 0: the centre of yhat for the moment pass proper = its batch mean (sum (yhat - c) is accurate; the squares are not)
-struct EhShift4 { float c[EH_MAX_TARG]; };
-// (one workgroup per target; targets whose loss needs no batch statistics of yhat are left alone)
-__device__ __forceinline__ bool eh_kind_two_pass(unsigned kind, int T) {
-    return (kind >= (unsigned)EH_LOSS_PEARSONLOSS && kind <= (unsigned)EH_LOSS_PBKGELOSS) || (kind == (unsigned)EH_LOSS_RMSE && T > 1);
-}
-__global__ __launch_bounds__(64) void eh_moment_centre_kernel(const float* slab, int nblk, int T, unsigned loss_t, EhShift4 shift, float* tt) {
-    __shared__ double tot[EH_EVAL_STATS];
-    const int tid = threadIdx.x, t = blockIdx.x;
-    if (!eh_kind_two_pass((loss_t >> (4 * t)) & 15u, T)) return;
-    if (tid < EH_EVAL_STATS) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)slab[(b * T + t) * EH_EVAL_STATS + tid];
-        tot[tid] = s;
-    }
-    __syncthreads();
-    if (tid == 0) tt[EH_TT * t + 1] = tot[3] > 0.0 ? (float)((double)shift.c[t] + tot[4] / tot[3]) : shift.c[t];
-}
-// stage 1: moments with u = yhat - tt[1], w = y - shift  ->  tt[4..6] = k0, k1, k2 ; tt[7] = the target's loss value
-// (rmse, the one loss without batch moments here, takes this form on multi-target models, where its scale 1 / (n rmse) has to be
-// known inside the one streaming pass that serves all targets: d/dyhat_i = (yhat_i - y_i) / (n rmse), loss_fn.jl:58-60)
-__global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int T, unsigned loss_t, EhShift4 shift4, float* tt_all) {
-    __shared__ double tot[EH_EVAL_STATS];
-    const int tid = threadIdx.x, t = blockIdx.x;
-    const int kind = (int)((loss_t >> (4 * t)) & 15u);
-    if (!eh_kind_two_pass((unsigned)kind, T)) return;
-    float* const out = tt_all + EH_TT * t;
-    const float shift = shift4.c[t];
-    if (tid < EH_EVAL_STATS) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)slab[(b * T + t) * EH_EVAL_STATS + tid];
-        tot[tid] = s;
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    const double n = tot[3], Sw = tot[1], Sww = tot[2], Su = tot[4], Suu = tot[5], Suw = tot[6], cu = (double)out[1];
-    float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, loss = T > 1 ? 0.0f : __builtin_nanf("");      // (a target without a valid sample adds nothing to a multi-target loss)
-    if (n > 0.0 && kind == EH_LOSS_RMSE) {
-        const double rm = sqrt(tot[0] / n), q = rm > 0.0 ? 1.0 / (n * rm) : 0.0;            // d = q (yhat - y) = q (u + cu) - q (w + shift)
-        k1 = (float)q; k2 = (float)-q; k0 = (float)(q * (cu - (double)shift));
-        loss = (float)rm;
-    } else if (n > 0.0) {
-        const double mu = Su / n, mw = Sw / n;
-        const double Suu_c = Suu - Su * Su / n, Sww_c = Sww - Sw * Sw / n, Suw_c = Suw - Su * Sw / n;
-        const double den = sqrt(Suu_c * Sww_c), r = Suw_c / den;
-        // dr = a_u (u_i - mu) + a_w (w_i - mw)
-        const double a_u = -r / Suu_c, a_w = 1.0 / den;
-        double g_r, g_a = 0.0, g_b = 0.0, L;
-        if (kind == EH_LOSS_PEARSONLOSS) { L = 1.0 - r; g_r = -1.0; }
-        else {
-            const double alpha = sqrt(Suu_c / Sww_c), beta = (cu + mu) / ((double)shift + mw);
-            if (kind == EH_LOSS_KGELOSS) { L = sqrt((r - 1) * (r - 1) + (alpha - 1) * (alpha - 1) + (beta - 1) * (beta - 1)); g_a = (alpha - 1) / L / (alpha * Sww_c); }
-            else L = sqrt((r - 1) * (r - 1) + (beta - 1) * (beta - 1));
-            g_r = (r - 1) / L;
-            g_b = (beta - 1) / L / (n * ((double)shift + mw));
-        }
-        const double qu = g_r * a_u + g_a, qw = g_r * a_w;        // coefficients of (u_i - mu), (w_i - mw)
-        k1 = (float)qu; k2 = (float)qw; k0 = (float)(g_b - qu * mu - qw * mw);
-        loss = (float)L;
-    }
-    out[0] = 1.0f; out[4] = k0; out[5] = k1; out[6] = k2; out[7] = loss;
-}
-
-// data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
-__global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
-                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, int T, const float* l2val) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    float cnt = gradbuf[n_theta + 1];
-    float scale = 0.0f, lossv = 0.0f;
-    if (T == 1) eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv);
-    else {      // multi-target: the shards used the weights of the global batch (eh_dp_counts): the all-reduced sums are final
-        for (int t = 1; t < T; ++t) cnt += gradbuf[n_theta + 1 + t];
-        scale = cnt > 0.0f ? 1.0f : 0.0f;
-        lossv = cnt > 0.0f ? gradbuf[n_theta] : __builtin_nanf("");
-    }
-    if (l2val && cnt > 0.0f) lossv += *l2val;                  // + lambda * weight_l2 of the (replicated) parameters: agg = sum([loss, extra...]), compute_loss.jl:31-34
-    if (idx < n_theta && cnt > 0.0f) {
-        float g = gradbuf[idx] * scale;
-        float th = theta[idx], mm = m[idx], vv = v[idx];
-        if (l2val) { const float c2 = eh_l2_coef(im, idx); if (c2 != 0.0f) g = fmaf(2.0f * c2, th, g); }
-        eh_opt_update(o, g, sc_in[0], sc_in[1], th, mm, vv);
-        theta[idx] = th; m[idx] = mm; v[idx] = vv;
-        eh_image_store(im, idx, th);
-    }
-    if (idx == 0) {
-        sc_out[0] = cnt > 0.0f ? sc_in[0] * o.b1 : sc_in[0];
-        sc_out[1] = cnt > 0.0f ? sc_in[1] * o.b2 : sc_in[1];
-        if (loss_slot) *loss_slot = lossv;
-    }
-}
-
-// Per-target weight of one batch (multi-target models: the normaliser differs per target, so it has to be known before the pass):
-// the residual terms of target t enter the loss as w_t r^2 (w_t |r| for MAE) with  w_t = 1 / n_t  for mse / mae  (loss_fn.jl:61-66)
-// and  w_t = 1 / sum (y - mean y)^2  for nseLoss (:79-81) -- all of it a function of the targets alone.  One workgroup per target.
-__global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
-                                                       float* inv_n, unsigned loss_t, EhShift4 shift, float* raw = nullptr) {
-    __shared__ float red[3][256];
-    const int t = blockIdx.x;
-    float c = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    for (long long i = threadIdx.x; i < count; i += 256) {
-        const long long n = idx ? (long long)idx[first + i] : first + i;
-        const float y = recs[n * C + toff + t];
-        if (!__builtin_isnan(y)) { const float d = y - shift.c[t]; c += 1.0f; s1 += d; s2 += d * d; }
-    }
-    red[0][threadIdx.x] = c; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-        if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; red[2][threadIdx.x] += red[2][threadIdx.x + w]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float n = red[0][0];
-        if (raw) { raw[3 * t] = n; raw[3 * t + 1] = red[1][0]; raw[3 * t + 2] = red[2][0]; return; }      // data parallel: this shard's sums (EH_BUF_TCOUNT), all-reduced by the caller
-        float w = n > 0.0f ? 1.0f / n : 0.0f;
-        if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (red[2][0] - red[1][0] * red[1][0] / n);
-        inv_n[EH_TT * t] = w;                 // (the per-target table of EhStepArgs::inv_n, eh_device.hpp)
-    }
-}
-// (data parallel) the all-reduced sums [n_t | sum (y - c) | sum (y - c)^2] of the GLOBAL batch -> the per-target weights; c is common to the ranks (eh_set_target_shift)
-__global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned loss_t, float* inv_n) {
-    const int t = threadIdx.x;
-    if (t >= T) return;
-    const float n = raw[3 * t];
-    float w = n > 0.0f ? 1.0f / n : 0.0f;
-    if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (raw[3 * t + 2] - raw[3 * t + 1] * raw[3 * t + 1] / n);
-    inv_n[EH_TT * t] = w;
-}
-
-// input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample
-// against cancellation.  part = [gridDim][64] (sum (x-c) | sum (x-c)^2 per predictor) then c[32].
-// cshift != nullptr: shift by that common vector instead (sums of different GPUs must share their shift).
-__global__ __launch_bounds__(1024) void eh_bn_stats_kernel(const float* recs, int C, int P, const int* idx, int first, int count, float* part,
-                                                            const float* cshift) {
-    __shared__ float red[16][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = idx ? idx[first] : first;
-    float s1[32], s2[32];
-#pragma unroll
-    for (int p = 0; p < 32; ++p) { s1[p] = 0.0f; s2[p] = 0.0f; }
-    for (int i = blockIdx.x * 1024 + tid; i < count; i += gridDim.x * 1024) {
-        const int n = idx ? idx[first + i] : first + i;
-        const float* r = recs + (long long)n * C;
-        const float* r0 = cshift ? cshift : recs + (long long)n0 * C;
-#pragma unroll
-        for (int p = 0; p < 32; ++p)
-            if (p < P) { const float d = r[p] - r0[p]; s1[p] += d; s2[p] += d * d; }
-    }
-#pragma unroll
-    for (int p = 0; p < 32; ++p) {
-        if (p < P) {
-            float a = s1[p], b = s2[p];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if (lane == 0) { red[wave][p] = a; red[wave][32 + p] = b; }
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float a = 0.0f;
-        if ((tid & 31) < P)
-            for (int w = 0; w < 16; ++w) a += red[w][tid];
-        part[blockIdx.x * 64 + tid] = a;
-        if (blockIdx.x == 0 && tid < 32) part[gridDim.x * 64 + tid] = tid < P ? (cshift ? cshift[tid] : recs[(long long)n0 * C + tid]) : 0.0f;
-    }
-}
-
-// cross-GPU statistics: fold the workgroup partials of this GPU's shard into stat = [sum d (32) | sum d^2 (32) | n]
-__global__ __launch_bounds__(64) void eh_bn_fold_kernel(const float* part, int nblk, int count, float* stat) {
-    const int tid = threadIdx.x;
-    float a = 0.0f;
-    for (int b = 0; b < nblk; ++b) a += part[b * 64 + tid];
-    stat[tid] = a;
-    if (tid == 0) stat[64] = (float)count;
-}
-
-// keyed bijection of [0, n): 4-round Feistel network on 2*hb bits, cycle-walked into range.
-__host__ __device__ inline uint32_t eh_mix32(uint32_t x, uint32_t k) {
-    x ^= k; x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
-    return x;
-}
-__host__ __device__ inline uint32_t eh_perm32(uint32_t i, uint32_t n, int hb, uint64_t seed) {
-    const uint32_t mask = (1u << hb) - 1u;
-    uint32_t x = i;
-    do {
-        uint32_t L = x >> hb, R = x & mask;
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t k = (uint32_t)(seed >> (16 * (r & 1))) + 0x632BE5ABu * (uint32_t)(r + 1) + (uint32_t)(seed >> 32);
-            const uint32_t t = L ^ (eh_mix32(R, k) & mask);
-            L = R; R = t;
-        }
-        x = (L << hb) | R;
-    } while (x >= n);
-    return x;
-}
-__global__ void eh_perm_kernel(int* idx, uint32_t n, int hb, uint64_t seed) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) idx[i] = (int)eh_perm32(i, n, hb, seed);
-}
-
-// (P x N col-major predictors, F forcing arrays, T target arrays) -> N records of C floats
-struct EhPackArgs {
-    const float* x;
-    const float* forc[EH_MAX_FORC];
-    const float* targ[EH_MAX_TARG];
-};
-__global__ void eh_pack_kernel(EhPackArgs a, float* recs, long long n, int P, int F, int T) {
-    const int C = P + F + T;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * C) return;
-    const long long s = e / C;
-    const int j = (int)(e % C);
-    float v;
-    if (j < P) v = a.x[s * P + j];
-    else if (j < P + F) v = a.forc[j - P][s];
-    else v = a.targ[j - P - F][s];
-    recs[e] = v;
-}
-
-// --------------------------------------------------------------------------------------------
-// handle
-// --------------------------------------------------------------------------------------------
-struct EhSplit {
-    float* recs = nullptr;
-    long long n = 0;
-    float shift[EH_MAX_TARG] = {0, 0, 0, 0};
-};
-
-// kernel selector handed to EhVariant::launch: the fast-path bits, or 4 = the EH_MECH_PROGRAM kernels
-#define KFAST(h) ((h)->net.mech == EH_MECH_PROGRAM ? 4 : (h)->fast)
-#define TH(h) ((h)->thb[(h)->cur])
-#define MM(h) ((h)->mb[(h)->cur])
-#define VV(h) ((h)->vb[(h)->cur])
-
-struct eh_handle_s {
-    eh_model_desc desc;
-    EhNet net;
-    const EhArchInfo* arch = nullptr;
-    const EhArchInfo* arch_alt = nullptr;   // the other kernel family built for this shape ("row_split" option), if any
-    int variant = 0, act = 0, fast = 0;
-    float* image = nullptr;
-    int* imap = nullptr;
-    int* rmap = nullptr;            // reduction map for the current kernel family / variant / fast-path flags (v3: the inverse map)
-    size_t rmap_cap = 0;
-    // block placement of every net inside the padded (block-diagonal) MLP
-    int n_nets = 1;                                     // 1 for SingleNN
-    int net_P[EH_MAX_NETS] = {0}, net_K[EH_MAX_NETS] = {0};
-    int net_w[EH_MAX_NETS][EH_MAX_HIDDEN] = {{0}};      // hidden widths of net k
-    int net_d[EH_MAX_NETS] = {0};                       // hidden layers of net k (layers past them: identity blocks, not in theta)
-    char* mech_ws = nullptr;                            // eh_mech_loss_vjp: [counts | out | partial rows]
-    size_t mech_ws_bytes = 0;
-    int net_c0[EH_MAX_NETS] = {0};                      // first predictor row of net k
-    int net_r0[EH_MAX_NETS][EH_MAX_HIDDEN + 1] = {{0}}; // first row of net k in layer l (l == n_hidden: output row)
-    int tot_w[EH_MAX_HIDDEN] = {0};                     // total (summed) hidden widths
-    EhImg img{};
-    int device = 0;
-    hipStream_t stream = nullptr, own_stream = nullptr;
-    int C = 0, n_acc = 0, n_par = 0;
-    float *thb[2] = {nullptr, nullptr}, *mb[2] = {nullptr, nullptr}, *vb[2] = {nullptr, nullptr};   // parameter sets (fused mode ping-pongs them)
-    float* pset = nullptr;          // backing allocation of thb/mb/vb/sc
-    float* sc = nullptr;            // [2][2] running beta products, ping-pong
-    int cur = 0, sc_sel = 0;
-    // fused-update mode
-    bool fused = false, pending = false;
-    float* gacc = nullptr;          // [3][EH_GSHARDS][n_acc] rotating gradient accumulators
-    // cross-GPU exchange (EhP2P): an uncached, IPC-exported receive buffer of {value, sequence} words next to gacc
-    bool p2p_on = false, p2p_alloc = false;
-    unsigned long long* p2p_recv = nullptr;
-    int p2p_world = 0, p2p_rank = 0;
-    unsigned p2p_seq = 0;
-    float* p2p_stage = nullptr;
-    unsigned* p2p_ctr = nullptr;    // [0] top-level ticket, [1] error flag, [2] self-test mismatches, [32 (1 + g)] group tickets (eh_p2p_publish)
-    EhP2P* p2p_dev = nullptr;
-    EhP2P p2p_host{};               // the same descriptor, handed to the step kernels by value
-    void* p2p_peer[EH_GSHARDS] = {nullptr};
-    long long gstep = 0;
-    float* pending_loss = nullptr;
-    // input BatchNorm
-    bool bn_on = false;
-    float* bn_part = nullptr;       // [32][64] partials + c[32]
-    float* bn_run = nullptr;        // [2][32] running mean / var
-    float* bn_shift = nullptr;      // [32] common shift of the cross-GPU statistics (eh_set_bn_shift)
-    float* bn_stat = nullptr;       // [65] sum d | sum d^2 | n of the current step, all-reduced by the host (EH_BUF_BNSTAT)
-    float* tcount = nullptr;        // [EH_MAX_TARG][3] n_t | sum (y - c) | sum (y - c)^2 of the current step's shard, all-reduced by the caller (EH_BUF_TCOUNT)
-    bool dp_weights = false;        // the step being launched takes its per-target weights from the all-reduced sums (no local counting pass)
-    bool tcount_ready = false;      // eh_dp_counts ran for the step eh_dp_grad is about to take
-    bool bn_ext = false;            // bn_stat holds the statistics of the step about to run
-    bool bn_dp_update = false;
-    bool opt_ready = false;
-    // layer-wise execution form (eh_lform.hpp): networks no fused kernel holds
-    bool lform = false;
-    // one entry per network (SingleNN: one; MultiNN: one single-output network per neural parameter, each on its own predictor rows)
-    struct LNet { int nl = 0, c0 = 0, orow = 0, act = 0; int in[EH_MAX_HIDDEN + 1] = {0}, out[EH_MAX_HIDDEN + 1] = {0}, woff[EH_MAX_HIDDEN + 1] = {0}, boff[EH_MAX_HIDDEN + 1] = {0}; };
-    int l_nnets = 0;                                     // 0: no network at all (no neural parameter)
-    LNet l_net[EH_MAX_NETS];
-    float* l_split = nullptr; size_t l_split_cap = 0;    // split-K partial products of the small-batch GEMMs
-    unsigned* l_lprog = nullptr; int l_lprog_gen = -1;  // the recorded loss programs as the layer-wise form interprets them (device copy, generation it was made from)
-    float* l_dk = nullptr; size_t l_dk_cap = 0;          // every layer's delta of a small-batch step (the weight gradients then run as one grouped launch)
-    float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
-    long long l_cap = 0;                                 // samples the workspace holds
-    unsigned char* wflag = nullptr;
-    int slab_rows = 256;
-    ncclComm_t comm = nullptr;      // eh_comm_init: the library's own RCCL communicator (data parallelism without a host-side collective library)
-    int comm_world = 0, comm_rank = 0;
-    struct EhLocalGroup* lgroup = nullptr;   // eh_comm_init_local: handles of ONE process exchange through peer-mapped device memory, no RCCL
-    EhOpt opt{};
-    EhSplit split[2];
-    float *slab = nullptr, *gradbuf = nullptr, *inv_n = nullptr, *loss_hist = nullptr;
-    long long loss_cap = 0;
-    int* perm = nullptr;
-    long long perm_cap = 0;
-    bool perm_valid = false;
-    int fast_user = 3;              // what the fast_paths option allows (default: all)
-    unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
-    // EH_MECH_PROGRAM: kernels compiled at run time around the program (eh_jit.hpp), one entry per (kernel family, variant) used
-    // state: 0 = being compiled by `worker` ("specialize" = 2: the steps run the kernels built ahead of time meanwhile), 1 = ready, -1 = failed
-    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; std::atomic<int> state{0}; EhJitKernel k; std::thread worker; std::string log; };
-    std::vector<std::unique_ptr<JitEntry>> jit;
-    bool specialize_async = false;  // "specialize" = 2
-    bool jit_on = true;             // "jit" option / EH_JIT=0: 0 = the interpreting kernels built ahead of time
-    bool jit_failed = false;
-    bool specialize = false;        // "specialize" option: every model gets kernels compiled around its descriptor
-    EhLossProg loss_prog;           // eh_set_loss_program (EH_LOSS_PROGRAM)
-    std::string jit_log;
-    float* l2val = nullptr;         // lambda * weight_l2 of the current parameters (device scalar)
-    float* l2w = nullptr;           // eh_set_weight_l2_coef: one coefficient per canonical entry (device)
-    int n_weights = 0;
-    struct GraphRec { hipGraphExec_t exec; bool fused; int gslot, cur, sc_sel; };
-    std::vector<GraphRec> graphs;         // eh_graph_*: captured step sequences + the rotation state they start (and must end) in
-    bool capturing = false;
-    GraphRec cap{};
-    int max_blocks = 256;
-    int mech_blocks = 0;            // "mech_blocks" option: cap on the streaming kernel's workgroups (0: none -- one workgroup per `mech_tiles` tiles)
-    int mech_tiles = 0;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup (0: by model -- 2, multi-output models 8)
-    // scratch for forward / eval outputs
-    float* out_buf = nullptr;
-    long long out_cap = 0;
-    int* idx_buf = nullptr;
-    long long idx_cap = 0;
-    // profiling
-    bool prof = false;
-    int prof_stride = 1;            // events bracket bursts of this many steps (1 = every kernel of every step)
-    long long prof_k = 0;
-    std::vector<hipEvent_t> ev;   // 3 per step: before step kernel, between, after reduce
-    size_t ev_used = 0;
-    unsigned long long* stamps = nullptr;   // diagnostic builds only
-    std::string err;
-};
-
-static std::string g_create_err;
-
-static int fail(eh_handle* h, int code, const char* fmt, ...) {
+int fail(eh_handle* h, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -975,81 +33,11 @@ static int fail(eh_handle* h, int code, const char* fmt, ...) {
     if (h) h->err = buf; else g_create_err = buf;
     return code;
 }
-#define HIPCHK(h, expr)                                                                                   \
-    do {                                                                                                  \
-        hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess) return fail(h, e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-// RCCL is bound with dlopen by the first eh_comm_* call, not linked: a process that never asks for the library's own communicator
-// (every single-GPU user; a host that brings its own collective, like the torch.distributed harness) loads neither RCCL nor
-// the rocm_smi it drags in -- whose static destructors were seen to abort at exit -- and a host that already has an RCCL in the
-// process (torch bundles one) shares that copy instead of getting a second one.
-struct EhRccl {
-    void* so = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)(void) = nullptr;
-    ncclResult_t (*GroupEnd)(void) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
-static EhRccl g_rccl;
-static bool rccl_bind(std::string* why) {
-    if (g_rccl.so) return true;
-    void* so = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-        if ((so = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!so) { *why = std::string("librccl not found: ") + dlerror(); return false; }
-    EhRccl r;
-    r.so = so;
-#define EH_SYM(field, sym) *(void**)(&r.field) = dlsym(so, sym); if (!r.field) { *why = std::string("librccl lacks ") + sym; return false; }
-    EH_SYM(GetUniqueId, "ncclGetUniqueId") EH_SYM(CommInitRank, "ncclCommInitRank") EH_SYM(CommDestroy, "ncclCommDestroy")
-    EH_SYM(AllReduce, "ncclAllReduce") EH_SYM(GroupStart, "ncclGroupStart") EH_SYM(GroupEnd, "ncclGroupEnd") EH_SYM(GetErrorString, "ncclGetErrorString")
-#undef EH_SYM
-    g_rccl = r;                      // (never unloaded)
-    return true;
-}
-#define RCCL_BIND(h)                                                                           \
-    do {                                                                                       \
-        std::string why_;                                                                      \
-        if (!rccl_bind(&why_)) return fail(h, EH_ERCCL, "RCCL: %s", why_.c_str());             \
-    } while (0)
-
-// ---- local communicator: the handles of ONE process (one host thread issuing to several devices / streams, SURVEY section 8(b)
-// threading row) sum their buffers without RCCL.  The buffers are a few KB: every member's stream waits (events) until all
-// members' producers have run, one small kernel per member then reads ALL members' buffers -- directly, over peer-mapped device
-// memory (xGMI) when they live on different GPUs -- and adds them in rank order, so every replica gets bit-identical sums; a
-// second event round keeps a member from overwriting its buffer while a peer still reads it.
-struct EhLocalGroup {
-    int n = 0;
-    eh_handle* m[EH_GSHARDS] = {nullptr};
-    hipEvent_t ready[EH_GSHARDS] = {nullptr}, done[EH_GSHARDS] = {nullptr};
-    float* sum[EH_GSHARDS] = {nullptr};       // per member, on its device: where its kernel leaves the sums before they replace the buffer
-    size_t cap = 0;                           // floats each of them holds
-};
-struct EhLocalPtrs { const float* p[EH_GSHARDS]; };
-__global__ void __launch_bounds__(256) eh_lgroup_sum_kernel(EhLocalPtrs src, int world, long long n, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float v[EH_GSHARDS];
-#pragma unroll
-    for (int r = 0; r < EH_GSHARDS; ++r) v[r] = r < world ? __builtin_nontemporal_load(src.p[r] + i) : 0.0f;     // all loads in flight together; rank order below
-    float acc = v[0];
-#pragma unroll
-    for (int r = 1; r < EH_GSHARDS; ++r) if (r < world) acc += v[r];
-    out[i] = acc;
-}
-struct EhLocalReq { eh_handle* h; float* buf; size_t n; };
-static thread_local int g_group_depth = 0;                 // eh_comm_group_begin nesting of this host thread
-static thread_local bool g_group_rccl = false;             // ncclGroupStart was issued for the open bracket
-static thread_local std::vector<EhLocalReq> g_group_reqs;  // all-reduces of local-group members, run at eh_comm_group_end
 
 static unsigned two_pass_mask(const EhNet& net);
 
 // ---- fused-update mode: apply the pending gradient so theta / m / v / image are current -----------
-static int flush_pending(eh_handle* h) {
+int flush_pending(eh_handle* h) {
     if (!h->pending) return EH_OK;
     const int nt = h->net.n_theta;
     const float* g_prev = h->gacc + (size_t)((h->gstep + 2) % 3) * EH_GSHARDS * h->n_acc;
@@ -1067,12 +55,6 @@ static int flush_pending(eh_handle* h) {
     h->pending_loss = nullptr;
     return EH_OK;
 }
-#define FLUSH(h)                          \
-    do {                                  \
-        int rc_ = flush_pending(h);       \
-        if (rc_) return rc_;              \
-    } while (0)
-
 // Every trainable scalar of the model as (canonical flat index, layer, row, col) in the padded
 // block-diagonal MLP.  col < 0 marks a bias.  SingleNN = one net covering everything.
 struct EhEntry { int canon, l, row, col; };
@@ -1649,12 +631,8 @@ int32_t eh_destroy(eh_handle* h) {
     for (auto e : h->ev) (void)hipEventDestroy(e);
     for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& e : h->jit) { if (e->worker.joinable()) e->worker.join(); eh_jit_release(&e->k); }
-    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
-    if (h->lgroup) (void)eh_comm_destroy(h);
+    eh_comm_release(h);             // communicator / local group / peer-to-peer mappings and buffers (eh_comm.hip)
     (void)hipSetDevice(h->device);
-    for (int r = 0; r < EH_GSHARDS; ++r)
-        if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
-    (void)hipFree(h->p2p_recv); (void)hipFree(h->p2p_stage); (void)hipFree(h->p2p_ctr); (void)hipFree(h->p2p_dev);
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->l2w); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
@@ -3077,109 +2055,6 @@ int32_t eh_dp_fused_step(eh_handle* h, int64_t first, int64_t count, int32_t* bu
     return do_fused_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, nullptr);
 }
 
-// ---- cross-GPU exchange without a collective call (EhP2P, csrc/eh_device.hpp) ----------------------
-static size_t p2p_recv_words(const eh_handle* h) { return (size_t)3 * EH_GSHARDS * h->n_acc; }
-
-int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out, int64_t handle_bytes) {
-    if (!h || !handle_out) return EH_EINVAL;
-    if (handle_bytes < (int64_t)sizeof(hipIpcMemHandle_t)) return fail(h, EH_EINVAL, "eh_p2p_init: handle buffer of %lld bytes, need %zu", (long long)handle_bytes, sizeof(hipIpcMemHandle_t));
-    // (world == 1 is a loopback: the rank publishes to and reads from itself -- measures the cost of the machinery)
-    if (world < 1 || world > EH_GSHARDS || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_p2p_init: world %d (1..%d), rank %d", world, EH_GSHARDS, rank);
-    if (!h->fused) return fail(h, EH_ESTATE, "eh_p2p_init: set the fused_update option first");
-    if (h->net.T != 1) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the peer-to-peer exchange is built for single-target models (use the all-reduce seam)");
-    if (h->net.mech == EH_MECH_PROGRAM) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the program kernels have no cross-GPU variant (use the all-reduce seam)");
-    if (h->act == EH_ACT_PER_NET) return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: the per-net activation kernels have no cross-GPU variant (use the all-reduce seam)");
-    if (h->p2p_on || h->p2p_alloc) return fail(h, EH_ESTATE, "eh_p2p_init: already initialised");
-    HIPCHK(h, hipSetDevice(h->device));
-    FLUSH(h);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    // other GPUs store into the receive buffer: nothing of it may linger in a cache of this one
-    const size_t bytes = p2p_recv_words(h) * sizeof(unsigned long long);
-    unsigned long long* buf = nullptr;
-    hipError_t e = hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void**)&buf, bytes, hipDeviceMallocFinegrained); }
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: no uncached / fine-grained device memory (%s)", hipGetErrorString(e)); }
-    HIPCHK(h, hipMemset(buf, 0, bytes));                  // sequence 0 everywhere: nothing has arrived
-    hipIpcMemHandle_t hd;
-    e = hipIpcGetMemHandle(&hd, buf);
-    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return fail(h, EH_EUNSUPPORTED, "eh_p2p_init: hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
-    h->p2p_recv = buf;
-    HIPCHK(h, hipMalloc(&h->p2p_stage, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK(h, hipMemset(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK(h, hipMalloc(&h->p2p_ctr, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));      // [0] top ticket, [1] error flag, [2] self-test mismatches, [32 (1 + g)] group tickets
-    HIPCHK(h, hipMemset(h->p2p_ctr, 0, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));
-    HIPCHK(h, hipMalloc(&h->p2p_dev, sizeof(EhP2P)));
-    HIPCHK(h, hipDeviceSynchronize());        // the memsets ran on the null stream, which the engine's non-blocking stream does not wait for
-    memcpy(handle_out, &hd, sizeof hd);
-    h->p2p_world = world; h->p2p_rank = rank; h->p2p_alloc = true; h->p2p_seq = 0;
-    return EH_OK;
-}
-
-int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride) {
-    if (!h || !handles) return EH_EINVAL;
-    if (!h->p2p_alloc || h->p2p_on) return fail(h, EH_ESTATE, "eh_p2p_attach: call eh_p2p_init first (once)");
-    if (handle_stride < (int64_t)sizeof(hipIpcMemHandle_t)) return fail(h, EH_EINVAL, "eh_p2p_attach: handle stride %lld", (long long)handle_stride);
-    HIPCHK(h, hipSetDevice(h->device));
-    EhP2P P;
-    memset(&P, 0, sizeof P);
-    for (int r = 0; r < h->p2p_world; ++r) {
-        void* ptr = h->p2p_recv;
-        if (r != h->p2p_rank) {
-            hipIpcMemHandle_t hd;
-            memcpy(&hd, (const char*)handles + (size_t)r * handle_stride, sizeof hd);
-            hipError_t e = hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess);
-            if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, EH_EUNSUPPORTED, "eh_p2p_attach: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e)); }
-        }
-        h->p2p_peer[r] = ptr;
-        P.peer_recv[r] = (unsigned long long*)ptr;
-    }
-    P.stage = h->p2p_stage; P.counter = h->p2p_ctr; P.err = (int*)(h->p2p_ctr + 1);
-    P.world = h->p2p_world; P.rank = h->p2p_rank;
-    HIPCHK(h, hipMemcpy(h->p2p_dev, &P, sizeof P, hipMemcpyHostToDevice));
-    h->p2p_host = P;
-    h->p2p_on = true;
-    return EH_OK;
-}
-
-// `rounds` exchanges of a known vector per rank through the real buffers; EVERY rank must call it at the same point.
-int32_t eh_p2p_selftest(eh_handle* h, int32_t rounds, int32_t* ok) {
-    if (!h || !ok) return EH_EINVAL;
-    *ok = 0;
-    if (!h->p2p_on) return fail(h, EH_ESTATE, "eh_p2p_selftest: call eh_p2p_attach first");
-    if (h->pending) return fail(h, EH_ESTATE, "eh_p2p_selftest: a training step is pending");
-    HIPCHK(h, hipSetDevice(h->device));
-    for (int k = 0; k < rounds; ++k) {
-        hipLaunchKernelGGL(eh_p2p_test_kernel, dim3(1), dim3(256), 0, h->stream, h->p2p_dev, k % 3, ++h->p2p_seq, h->n_acc, (int*)(h->p2p_ctr + 2));
-        HIPCHK(h, hipGetLastError());
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    unsigned c[3] = {0, 0, 0};
-    HIPCHK(h, hipMemcpy(c, h->p2p_ctr, sizeof c, hipMemcpyDeviceToHost));
-    *ok = (c[1] == 0 && c[2] == 0) ? 1 : 0;
-    return EH_OK;
-}
-
-// back to the host-side all-reduce (RCCL) of EH_BUF_GACC
-int32_t eh_p2p_disable(eh_handle* h) {
-    if (!h) return EH_EINVAL;
-    if (!h->p2p_alloc) return EH_OK;
-    HIPCHK(h, hipSetDevice(h->device));
-    FLUSH(h);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int r = 0; r < EH_GSHARDS; ++r) {
-        if (h->p2p_peer[r] && r != h->p2p_rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
-        h->p2p_peer[r] = nullptr;
-    }
-    h->p2p_on = false; h->p2p_alloc = false;
-    (void)hipFree(h->p2p_recv); h->p2p_recv = nullptr;
-    (void)hipFree(h->p2p_stage); h->p2p_stage = nullptr;
-    (void)hipFree(h->p2p_ctr); h->p2p_ctr = nullptr;
-    (void)hipFree(h->p2p_dev); h->p2p_dev = nullptr;
-    HIPCHK(h, hipMemsetAsync(h->gacc, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float), h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return EH_OK;
-}
-
 int32_t eh_set_bn_shift(eh_handle* h, const float* shift, int64_t n) {
     if (!h || !shift) return EH_EINVAL;
     if (!h->bn_on) return fail(h, EH_ESTATE, "eh_set_bn_shift: the model has no input BatchNorm");
@@ -3229,282 +2104,6 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
         HIPCHK(h, hipMemcpyAsync(loss_out, h->loss_hist, sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    return EH_OK;
-}
-
-// ---- the collective inside the library (RCCL) -------------------------------------------------------------------------
-#define NCCLCHK(h, expr)                                                                                     \
-    do {                                                                                                     \
-        ncclResult_t r_ = (expr);                                                                            \
-        if (r_ != ncclSuccess) return fail(h, EH_ERCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
-    } while (0)
-
-int32_t eh_comm_unique_id(void* id_out, int64_t id_bytes) {
-    if (!id_out || id_bytes < (int64_t)sizeof(ncclUniqueId)) return fail(nullptr, EH_EINVAL, "eh_comm_unique_id: buffer of %lld bytes, need %zu", (long long)id_bytes, sizeof(ncclUniqueId));
-    RCCL_BIND(nullptr);
-    ncclUniqueId id;
-    NCCLCHK(nullptr, g_rccl.GetUniqueId(&id));
-    memcpy(id_out, &id, sizeof id);
-    return EH_OK;
-}
-
-int32_t eh_comm_init(eh_handle* h, const void* unique_id, int64_t id_bytes, int32_t world, int32_t rank) {
-    if (!h || !unique_id) return EH_EINVAL;
-    if (id_bytes < (int64_t)sizeof(ncclUniqueId)) return fail(h, EH_EINVAL, "eh_comm_init: id of %lld bytes, need %zu", (long long)id_bytes, sizeof(ncclUniqueId));
-    if (world < 1 || rank < 0 || rank >= world) return fail(h, EH_EINVAL, "eh_comm_init: world %d, rank %d", world, rank);
-    if (h->comm || h->lgroup) return fail(h, EH_ESTATE, "eh_comm_init: the handle already has a communicator (eh_comm_destroy first)");
-    HIPCHK(h, hipSetDevice(h->device));
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof id);
-    RCCL_BIND(h);
-    if (g_group_depth > 0 && !g_group_rccl) { NCCLCHK(h, g_rccl.GroupStart()); g_group_rccl = true; }      // the bracket was opened before RCCL was in the process
-    NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
-    h->comm_world = world; h->comm_rank = rank;
-    return EH_OK;
-}
-
-// the largest buffer eh_dp_allreduce can be asked for on this handle
-static size_t lgroup_floats(const eh_handle* h) {
-    size_t n = std::max<size_t>((size_t)h->n_acc, 3 * EH_MAX_TARG);
-    if (h->gacc) n = std::max(n, (size_t)EH_GSHARDS * h->n_acc);
-    return std::max<size_t>(n, 68);
-}
-
-int32_t eh_comm_init_local(eh_handle* const* handles, int32_t n) {
-    if (!handles || n < 1 || n > EH_GSHARDS) return fail(nullptr, EH_EINVAL, "eh_comm_init_local: %d handles (1..%d)", n, EH_GSHARDS);
-    for (int i = 0; i < n; ++i) {
-        if (!handles[i]) return fail(nullptr, EH_EINVAL, "eh_comm_init_local: handle %d is NULL", i);
-        for (int j = 0; j < i; ++j) if (handles[j] == handles[i]) return fail(handles[i], EH_EINVAL, "eh_comm_init_local: handle %d is listed twice", i);
-        if (handles[i]->comm || handles[i]->lgroup) return fail(handles[i], EH_ESTATE, "eh_comm_init_local: handle %d already has a communicator (eh_comm_destroy first)", i);
-        if (handles[i]->net.n_theta != handles[0]->net.n_theta || handles[i]->n_acc != handles[0]->n_acc)
-            return fail(handles[i], EH_EINVAL, "eh_comm_init_local: handle %d is a different model (%d parameters, handle 0 has %d)", i, handles[i]->net.n_theta, handles[0]->net.n_theta);
-    }
-    // every member's kernel reads every other member's buffers: peer access between the distinct devices
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            const int a = handles[i]->device, b = handles[j]->device;
-            if (a == b) continue;
-            int can = 0;
-            HIPCHK(handles[i], hipDeviceCanAccessPeer(&can, a, b));
-            if (!can) return fail(handles[i], EH_EUNSUPPORTED, "eh_comm_init_local: device %d cannot map the memory of device %d (no peer access): use eh_comm_init (RCCL)", a, b);
-            HIPCHK(handles[i], hipSetDevice(a));
-            hipError_t e = hipDeviceEnablePeerAccess(b, 0);
-            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-            else if (e != hipSuccess) return fail(handles[i], EH_EHIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", a, b, hipGetErrorString(e));
-        }
-    EhLocalGroup* g = new EhLocalGroup();
-    g->n = n;
-    g->cap = lgroup_floats(handles[0]);
-    auto undo = [&](eh_handle* h, hipError_t e, const char* what) {
-        for (int i = 0; i < n; ++i) {
-            (void)hipSetDevice(handles[i]->device);
-            if (g->ready[i]) (void)hipEventDestroy(g->ready[i]);
-            if (g->done[i]) (void)hipEventDestroy(g->done[i]);
-            (void)hipFree(g->sum[i]);
-        }
-        delete g;
-        return fail(h, e == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP, "eh_comm_init_local: %s: %s", what, hipGetErrorString(e));
-    };
-    for (int i = 0; i < n; ++i) {
-        hipError_t e;
-        if ((e = hipSetDevice(handles[i]->device)) != hipSuccess) return undo(handles[i], e, "hipSetDevice");
-        if ((e = hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming)) != hipSuccess) return undo(handles[i], e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming)) != hipSuccess) return undo(handles[i], e, "hipEventCreate");
-        if ((e = hipMalloc(&g->sum[i], g->cap * sizeof(float))) != hipSuccess) return undo(handles[i], e, "hipMalloc");
-    }
-    for (int i = 0; i < n; ++i) {
-        g->m[i] = handles[i];
-        handles[i]->lgroup = g; handles[i]->comm_world = n; handles[i]->comm_rank = i;
-    }
-    return EH_OK;
-}
-
-int32_t eh_comm_destroy(eh_handle* h) {
-    if (!h) return EH_EINVAL;
-    if (h->lgroup) {                            // a local group lives and dies as a whole: every member leaves it
-        EhLocalGroup* g = h->lgroup;
-        for (int i = 0; i < g->n; ++i) {
-            eh_handle* m = g->m[i];
-            (void)hipSetDevice(m->device);
-            (void)hipStreamSynchronize(m->stream);
-        }
-        for (int i = 0; i < g->n; ++i) {
-            eh_handle* m = g->m[i];
-            (void)hipSetDevice(m->device);
-            (void)hipEventDestroy(g->ready[i]); (void)hipEventDestroy(g->done[i]); (void)hipFree(g->sum[i]);
-            m->lgroup = nullptr; m->comm_world = 0; m->comm_rank = 0;
-        }
-        for (size_t k = 0; k < g_group_reqs.size();)
-            if (g_group_reqs[k].h->lgroup == nullptr) g_group_reqs.erase(g_group_reqs.begin() + k); else ++k;
-        delete g;
-        (void)hipSetDevice(h->device);
-        return EH_OK;
-    }
-    if (!h->comm) return EH_OK;
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    NCCLCHK(h, g_rccl.CommDestroy(h->comm));
-    h->comm = nullptr; h->comm_world = 0;
-    return EH_OK;
-}
-
-// the queued all-reduces of one local group, all members present: two event rounds and one small kernel per member
-static int lgroup_run(EhLocalGroup* g, const std::vector<EhLocalReq>& reqs) {
-    eh_handle* h0 = reqs[0].h;
-    const size_t n = reqs[0].n;
-    const EhLocalReq* by_rank[EH_GSHARDS] = {nullptr};
-    for (const EhLocalReq& r : reqs) {
-        if (by_rank[r.h->comm_rank]) return fail(r.h, EH_ESTATE, "eh_comm_group_end: rank %d of the local group asked for two all-reduces in one bracket", r.h->comm_rank);
-        if (r.n != n) return fail(r.h, EH_ESTATE, "eh_comm_group_end: the members of the local group ask for different buffers (%zu vs %zu floats)", r.n, n);
-        by_rank[r.h->comm_rank] = &r;
-    }
-    for (int i = 0; i < g->n; ++i)
-        if (!by_rank[i]) return fail(h0, EH_ESTATE, "eh_comm_group_end: rank %d of the local group did not call eh_dp_allreduce inside the bracket (every member must)", i);
-    if (n > g->cap) return fail(h0, EH_EINVAL, "eh_comm_group_end: %zu floats, the group's scratch holds %zu", n, g->cap);
-    EhLocalPtrs src;
-    for (int i = 0; i < EH_GSHARDS; ++i) src.p[i] = by_rank[i < g->n ? i : 0]->buf;
-    for (int i = 0; i < g->n; ++i) {           // round 1: every member's buffer is complete
-        eh_handle* m = g->m[i];
-        HIPCHK(m, hipSetDevice(m->device));
-        HIPCHK(m, hipEventRecord(g->ready[i], m->stream));
-    }
-    for (int i = 0; i < g->n; ++i) {
-        eh_handle* m = g->m[i];
-        HIPCHK(m, hipSetDevice(m->device));
-        for (int p = 0; p < g->n; ++p) if (p != i) HIPCHK(m, hipStreamWaitEvent(m->stream, g->ready[p], 0));
-        hipLaunchKernelGGL(eh_lgroup_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, src, g->n, (long long)n, g->sum[i]);
-        HIPCHK(m, hipGetLastError());
-        HIPCHK(m, hipEventRecord(g->done[i], m->stream));
-    }
-    for (int i = 0; i < g->n; ++i) {           // round 2: nobody reads a buffer any more; the sums replace it
-        eh_handle* m = g->m[i];
-        HIPCHK(m, hipSetDevice(m->device));
-        for (int p = 0; p < g->n; ++p) if (p != i) HIPCHK(m, hipStreamWaitEvent(m->stream, g->done[p], 0));
-        HIPCHK(m, hipMemcpyAsync(by_rank[i]->buf, g->sum[i], n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-    }
-    return EH_OK;
-}
-
-int32_t eh_comm_group_begin(void) {
-    if (g_group_depth++ == 0) {
-        g_group_rccl = false;
-        g_group_reqs.clear();
-        if (g_rccl.so) { NCCLCHK(nullptr, g_rccl.GroupStart()); g_group_rccl = true; }      // (no RCCL in the process yet: eh_comm_init opens the RCCL bracket itself)
-    }
-    return EH_OK;
-}
-int32_t eh_comm_group_end(void) {
-    if (g_group_depth <= 0) return fail(nullptr, EH_ESTATE, "eh_comm_group_end without eh_comm_group_begin");
-    if (--g_group_depth > 0) return EH_OK;
-    int rc = EH_OK;
-    if (g_group_rccl) {
-        g_group_rccl = false;
-        ncclResult_t r = g_rccl.GroupEnd();
-        if (r != ncclSuccess) rc = fail(nullptr, EH_ERCCL, "ncclGroupEnd: %s", g_rccl.GetErrorString(r));
-    }
-    std::vector<EhLocalReq> reqs;
-    reqs.swap(g_group_reqs);
-    while (!reqs.empty() && rc == EH_OK) {
-        EhLocalGroup* g = reqs[0].h->lgroup;
-        std::vector<EhLocalReq> mine, rest;
-        for (const EhLocalReq& r : reqs) (r.h->lgroup == g ? mine : rest).push_back(r);
-        rc = lgroup_run(g, mine);
-        if (rc != EH_OK) g_create_err = mine[0].h->err.empty() ? g_create_err : mine[0].h->err;
-        reqs.swap(rest);
-    }
-    return rc;
-}
-
-int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
-    if (!h) return EH_EINVAL;
-    if (!h->comm && !h->lgroup) return fail(h, EH_ESTATE, "eh_dp_allreduce: call eh_comm_init (or eh_comm_init_local) first");
-    float* buf = nullptr;
-    size_t n = 0;
-    switch (which) {
-        case EH_BUF_GRAD: buf = h->gradbuf; n = (size_t)h->n_acc; break;
-        case EH_BUF_GACC:
-            if (index < 0 || index > 2) return fail(h, EH_EINVAL, "eh_dp_allreduce: accumulator %d (0..2)", index);
-            if (h->p2p_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the step kernels exchange their sums themselves (eh_p2p_attach); nothing to reduce");
-            if (!h->gacc) return fail(h, EH_ESTATE, "eh_dp_allreduce: this model has no fused_update accumulators");
-            n = (size_t)EH_GSHARDS * h->n_acc; buf = h->gacc + (size_t)index * n; break;
-        case EH_BUF_BNSTAT:
-            if (!h->bn_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the model has no input BatchNorm");
-            buf = h->bn_stat; n = 65; break;
-        case EH_BUF_TCOUNT: buf = h->tcount; n = 3 * EH_MAX_TARG; break;
-        default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT or EH_BUF_TCOUNT)", which);
-    }
-    if (h->lgroup) {
-        if (h->lgroup->n == 1) return EH_OK;               // a world of one: the sum is the buffer
-        if (g_group_depth <= 0) return fail(h, EH_ESTATE, "eh_dp_allreduce: a local group's members meet at eh_comm_group_end: bracket the calls of all members with eh_comm_group_begin / eh_comm_group_end");
-        g_group_reqs.push_back({h, buf, n});
-        return EH_OK;
-    }
-    HIPCHK(h, hipSetDevice(h->device));
-    NCCLCHK(h, g_rccl.AllReduce(buf, buf, n, ncclFloat, ncclSum, h->comm, h->stream));
-    return EH_OK;
-}
-
-int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss_out) {
-    if (!h) return EH_EINVAL;
-    if (!h->comm && !h->lgroup) return fail(h, EH_ESTATE, "eh_dp_train_step: call eh_comm_init first");
-    if (h->lgroup && h->lgroup->n > 1) return fail(h, EH_ESTATE, "eh_dp_train_step: the members of a local group step together: eh_dp_train_step_group");
-    int rc;
-    if (h->bn_on) {
-        if ((rc = eh_dp_bn_stats(h, first, count))) return rc;
-        if ((rc = eh_dp_allreduce(h, EH_BUF_BNSTAT, 0))) return rc;
-    }
-    if (h->fused && h->net.T == 1) {
-        if (loss_out) return fail(h, EH_EINVAL, "eh_dp_train_step: fused_update mode reports no per-step loss (pass NULL)");
-        int32_t k = 0;
-        if ((rc = eh_dp_fused_step(h, first, count, &k))) return rc;
-        return k >= 0 ? eh_dp_allreduce(h, EH_BUF_GACC, k) : EH_OK;
-    }
-    if (h->net.T != 1) {
-        if ((rc = eh_dp_counts(h, first, count))) return rc;
-        if ((rc = eh_dp_allreduce(h, EH_BUF_TCOUNT, 0))) return rc;
-    }
-    if ((rc = eh_dp_grad(h, first, count))) return rc;
-    if ((rc = eh_dp_allreduce(h, EH_BUF_GRAD, 0))) return rc;
-    return eh_dp_apply(h, loss_out);
-}
-
-// One host thread, several handles (one per device): a whole data-parallel step of all of them.  Every phase is issued to all
-// members before the exchange that follows it, and every exchange sits in one eh_comm_group_begin / eh_comm_group_end bracket
-// (RCCL communicators: ncclGroupStart / End as RCCL requires of a single thread; local groups: the members meet at the end).
-int32_t eh_dp_train_step_group(eh_handle* const* hs, int32_t n, const int64_t* first, int64_t count, float* loss_out) {
-    if (!hs || !first || n < 1 || n > EH_GSHARDS) return fail(nullptr, EH_EINVAL, "eh_dp_train_step_group: %d handles (1..%d)", n, EH_GSHARDS);
-    for (int i = 0; i < n; ++i) {
-        if (!hs[i]) return fail(nullptr, EH_EINVAL, "eh_dp_train_step_group: handle %d is NULL", i);
-        if (!hs[i]->comm && !hs[i]->lgroup) return fail(hs[i], EH_ESTATE, "eh_dp_train_step_group: handle %d has no communicator (eh_comm_init / eh_comm_init_local)", i);
-        if (hs[i]->fused != hs[0]->fused || hs[i]->net.T != hs[0]->net.T || hs[i]->bn_on != hs[0]->bn_on || hs[i]->p2p_on != hs[0]->p2p_on)
-            return fail(hs[i], EH_EINVAL, "eh_dp_train_step_group: handle %d runs a different step mode than handle 0", i);
-    }
-    int32_t k[EH_GSHARDS] = {0};
-    auto exchange = [&](int which, bool per_handle_index) -> int {
-        int rc = eh_comm_group_begin();
-        if (rc) return rc;
-        for (int i = 0; i < n && !rc; ++i) rc = eh_dp_allreduce(hs[i], which, per_handle_index ? k[i] : 0);
-        const int rc2 = eh_comm_group_end();                // (always closes the bracket)
-        return rc ? rc : rc2;
-    };
-    int rc;
-    eh_handle* h0 = hs[0];
-    if (h0->bn_on) {
-        for (int i = 0; i < n; ++i) if ((rc = eh_dp_bn_stats(hs[i], first[i], count))) return rc;
-        if ((rc = exchange(EH_BUF_BNSTAT, false))) return rc;
-    }
-    if (h0->fused && h0->net.T == 1) {
-        if (loss_out) return fail(h0, EH_EINVAL, "eh_dp_train_step_group: fused_update mode reports no per-step loss (pass NULL)");
-        for (int i = 0; i < n; ++i) if ((rc = eh_dp_fused_step(hs[i], first[i], count, &k[i]))) return rc;
-        return k[0] >= 0 ? exchange(EH_BUF_GACC, true) : EH_OK;
-    }
-    if (h0->net.T != 1) {
-        for (int i = 0; i < n; ++i) if ((rc = eh_dp_counts(hs[i], first[i], count))) return rc;
-        if ((rc = exchange(EH_BUF_TCOUNT, false))) return rc;
-    }
-    for (int i = 0; i < n; ++i) if ((rc = eh_dp_grad(hs[i], first[i], count))) return rc;
-    if ((rc = exchange(EH_BUF_GRAD, false))) return rc;
-    for (int i = 0; i < n; ++i) if ((rc = eh_dp_apply(hs[i], i == 0 ? loss_out : nullptr))) return rc;
     return EH_OK;
 }
 
@@ -3583,3 +2182,4 @@ int32_t eh_profile_read(eh_handle* h, int64_t* n_launches, double* mean_ms_step_
 }
 
 }   // extern "C"
+

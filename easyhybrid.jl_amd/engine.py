@@ -369,6 +369,36 @@ class HybridEngine:
     def p2p_disable(self):
         self._chk(self._lib.eh_p2p_disable(self._h))
 
+    @staticmethod
+    def _group_call(fn, engines, *args):
+        lib = L.lib()
+        hs = (C.c_void_p * len(engines))(*[e._h.value for e in engines])
+        st = fn(hs, len(engines), *args)
+        if st != L.EH_OK:
+            msg = lib.eh_last_error(None).decode()
+            for e in engines:
+                m = lib.eh_last_error(e._h).decode()
+                if m:
+                    msg = m
+            _raise(st, msg)
+
+    @staticmethod
+    def p2p_init_local(engines: Sequence["HybridEngine"], selftest_rounds: int = 8) -> bool:
+        """ONE process, several engines (one per device, all in fused_update mode): their step kernels exchange the sums
+        themselves through plain pointers to each other's receive buffers -- no IPC, no collective call per step
+        (include/easyhybrid_hip.h: eh_p2p_init_local).  False: the start-up self-test failed, the engines keep all-reducing."""
+        ok = C.c_int32()
+        HybridEngine._group_call(L.lib().eh_p2p_init_local, engines, selftest_rounds, C.byref(ok))
+        return bool(ok.value)
+
+    @staticmethod
+    def p2p_check_local(engines: Sequence["HybridEngine"]) -> bool:
+        """drain every member; False: an exchange ran into its deadline -- every member has left the peer-to-peer exchange and taken
+        member 0's parameters and optimiser state (eh_p2p_check_local)"""
+        ok = C.c_int32()
+        HybridEngine._group_call(L.lib().eh_p2p_check_local, engines, C.byref(ok))
+        return bool(ok.value)
+
     # -- the library's own RCCL communicator (include/easyhybrid_hip.h, eh_comm_*) ---------------------
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -503,6 +503,23 @@ function comm_init_local!(es::Vector{HybridEngine})
     hs = Ptr{Cvoid}[e.h for e in es]
     GC.@preserve hs check(es[1], @ccall LIB[].eh_comm_init_local(hs::Ptr{Ptr{Cvoid}}, length(hs)::Int32)::Int32)
 end
+"""
+The fused step kernels of the engines of ONE Julia process exchange their sums themselves (plain pointers to each other's
+receive buffers, no IPC, no collective call per step).  The engines need `fused_update` on and a communicator for the
+fall-back (`comm_init_local!`).  `p2p_init_local!` returns false when the start-up self-test failed (the engines then keep
+all-reducing); `p2p_check_local!` drains all members and returns false after a missed exchange -- every member has then left the
+exchange and taken member 1's parameters and optimiser state.
+"""
+function p2p_init_local!(es::Vector{HybridEngine}; rounds::Integer = 8)
+    hs = Ptr{Cvoid}[e.h for e in es]; ok = Ref{Int32}(0)
+    GC.@preserve hs check(es[1], @ccall LIB[].eh_p2p_init_local(hs::Ptr{Ptr{Cvoid}}, length(hs)::Int32, rounds::Int32, ok::Ref{Int32})::Int32)
+    return ok[] != 0
+end
+function p2p_check_local!(es::Vector{HybridEngine})
+    hs = Ptr{Cvoid}[e.h for e in es]; ok = Ref{Int32}(0)
+    GC.@preserve hs check(es[1], @ccall LIB[].eh_p2p_check_local(hs::Ptr{Ptr{Cvoid}}, length(hs)::Int32, ok::Ref{Int32})::Int32)
+    return ok[] != 0
+end
 comm_group_begin() = (st = @ccall LIB[].eh_comm_group_begin()::Int32; st == 0 || error("eh_comm_group_begin: status $st"); nothing)
 comm_group_end() = (st = @ccall LIB[].eh_comm_group_end()::Int32; st == 0 || error("eh_comm_group_end: status $st"); nothing)
 function dp_train_step_group!(es::Vector{HybridEngine}, firsts::Vector{<:Integer}, count::Integer)

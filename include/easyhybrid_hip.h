@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define EH_ABI_VERSION 3      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group, eh_set_target_loss_program */
+#define EH_ABI_VERSION 4      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group, eh_set_target_loss_program.
+                               * 4: eh_p2p_init_local, eh_p2p_check_local */
 #define EH_MAX_HIDDEN 8       /* hidden layers: up to 3 run as ONE fused kernel per step, more (or widths above 128) layer by layer (csrc/eh_lform.hpp) */
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
@@ -379,6 +380,19 @@ int32_t eh_p2p_init(eh_handle* h, int32_t world, int32_t rank, void* handle_out,
 int32_t eh_p2p_attach(eh_handle* h, const void* handles, int64_t handle_stride);
 int32_t eh_p2p_selftest(eh_handle* h, int32_t rounds, int32_t* ok);
 int32_t eh_p2p_disable(eh_handle* h);
+/* The same exchange between the handles of ONE process (one host thread, one handle per device -- the Julia host; SURVEY section
+ * 8(b), threading row): no IPC, every member's kernels hold plain device pointers to the others' receive buffers (peer access is
+ * enabled between distinct devices; EH_EUNSUPPORTED where a pair has none).  All members need fused_update on and a communicator
+ * for the fall-back (eh_comm_init_local, or eh_comm_init); steps then go through eh_dp_train_step_group, which issues no
+ * exchange at all while the group is healthy.
+ *   eh_p2p_init_local  : allocate + wire all n members (rank = position) and run the start-up self-test on all of them
+ *                        together; *ok = 0 -> the test failed, everything is released again and the members keep all-reducing
+ *   eh_p2p_check_local : drain every member and read the deadline flags; *healthy = 0 -> an exchange was missed (a member
+ *                        stepped alone, a device stalled > 2 s): every member has left the peer-to-peer exchange and taken
+ *                        member 0's parameters and optimiser state, so the replicas are identical again
+ * eh_p2p_disable on any member dissolves the whole local peer-to-peer group. */
+int32_t eh_p2p_init_local(eh_handle* const* handles, int32_t n, int32_t selftest_rounds, int32_t* ok);
+int32_t eh_p2p_check_local(eh_handle* const* handles, int32_t n, int32_t* healthy);
 
 /* timing aid for bench.py: when enabled, eh_train_step brackets the fused step kernel with HIP
  * events on its stream; eh_profile_read returns the number of launches and their mean duration. */

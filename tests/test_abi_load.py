@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(L.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
-    assert lib.eh_version() == 3
+    assert lib.eh_version() == 4
 
 
 def test_struct_layout_matches_header(tmp_path):

@@ -20,7 +20,7 @@ def _bench():
     return m
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_spawn_ranks_runs_a_gloo_world(world):
     rc, out = _bench().spawn_ranks(world, [sys.executable, WORKER], capture=True, timeout=240)
     assert rc == 0, out
@@ -34,6 +34,14 @@ def test_a_failing_rank_stops_the_others_and_its_code_comes_back():
     t0 = time.monotonic()
     rc = _bench().spawn_ranks(2, [sys.executable, WORKER, "fail"], timeout=120)
     assert rc == 3 and time.monotonic() - t0 < 60
+
+
+def test_a_failed_rendezvous_is_retried_once_on_a_fresh_port(tmp_path):
+    # (advisor, round 3: the free port is found by bind(0) / close and can be taken before rank 0 binds)
+    marker = str(tmp_path / "first_try_done")
+    rc, out = _bench().spawn_ranks(2, [sys.executable, WORKER, "flaky", marker], capture=True, timeout=240)
+    assert rc == 0 and os.path.exists(marker), out
+    assert json.loads(out.strip().splitlines()[-1])["ranks_seen"] == 2
 
 
 def test_importing_bench_does_not_touch_torch_or_the_gpu():

@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env, port, tool="p2p_two_ranks.py"):
+def _run(extra_env, port, tool="p2p_two_ranks.py", nproc=2):
     import torch
     if torch.cuda.is_initialized():
         pytest.skip("this process already initialised the GPU; run this file first (or alone)")
     env = dict(os.environ, **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tools", tool)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in (r.stdout + r.stderr).replace("rank ", "\nrank ").splitlines() if l.startswith("rank ")]
@@ -54,15 +54,47 @@ def test_two_ranks_recover_from_a_missed_exchange():
     assert len(rec) == 2 and all("check() -> False" in l and "identical=True" in l and "finite=True" in l for l in rec), lines
 
 
+def test_four_ranks_peer_to_peer_exchange_and_recovery_from_a_missed_exchange():
+    """the same with four rank processes on the one GPU (the boxes allow at most six processes on the card, so eight RANK PROCESSES
+    cannot be walked here -- the eight-member protocol is walked by the one-process group below): exchange, bitwise-identical
+    replicas, then the forced deadline and the full-state recovery"""
+    lines = _run({"EH_TOOL_FORCE_TIMEOUT": "1"}, 29566, nproc=4)
+    first = [l for l in lines if "max|theta-ref|" in l]
+    assert len(first) == 4 and all("p2p=True" in l and "replicas_identical=True" in l for l in first), lines
+    rec = [l for l in lines if "forced timeout" in l]
+    assert len(rec) == 4 and all("check() -> False" in l and "identical=True" in l and "finite=True" in l for l in rec), lines
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_one_process_peer_to_peer_group_of_eight_handles(world):
+    """eh_p2p_init_local / eh_p2p_check_local: the handles of ONE process (the Julia host's set-up: one thread, one handle per device)
+    exchange through plain pointers; with eight members every slot of the receive buffers is in use (EH_GSHARDS = 8 is the shard
+    count of the float atomics AND the peer-slot count -- the boundary case).  tools/p2p_local_group.py: training equal to one engine
+    on the union, bitwise-identical replicas, the forced missed exchange and its recovery through the local group's all-reduce, the
+    refused self-test."""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU; run this file first (or alone)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_local_group.py"), str(world)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("local group of")]
+    assert r.returncode == 0, "\n".join(lines) + "\n" + (r.stdout + r.stderr)[-1500:]
+    assert len(lines) == 3 and "p2p=True" in lines[0] and "healthy=True" in lines[0] and "replicas_identical=True" in lines[0], lines
+    assert "check -> False" in lines[1] and "identical=True" in lines[1] and "refused=True" in lines[1], lines
+    assert "p2p=False" in lines[2] and "replicas_identical=True" in lines[2], lines
+
+
 def test_two_ranks_distributed_train_front_door():
     # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm, and a two-target model with per-target losses
     lines = _run({"EH_MAX_BLOCKS": "64"}, 29563, tool="train_two_ranks.py")
     assert len(lines) == 6 and all("results_identical_across_ranks=True" in l for l in lines), lines      # (single target +- BatchNorm, two targets) x two ranks
 
 
-def test_bench_gpus_2_launches_its_own_ranks_and_prints_a_self_describing_line():
-    """`python bench.py --gpus 2` with no launcher: the script spawns its two ranks itself, before anything touches
-    a GPU; on this one-GPU box both ranks share device 0 (EH_BENCH_SHARE_GPU=1: gloo carries the collectives, the numbers are
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_gpus_n_launches_its_own_ranks_and_prints_a_self_describing_line(n):
+    """`python bench.py --gpus N` with no launcher: the script spawns its ranks itself, before anything touches
+    a GPU (N = 4 here at most: a GPU box kills a job with more than six processes on the card, so `--gpus 8` on one GPU is not
+    something a test may start; the launcher itself is walked with eight gloo ranks on the CPU in tests/test_bench_launcher.py); on
+    this one-GPU box all ranks share device 0 (EH_BENCH_SHARE_GPU=1: gloo carries the collectives, the numbers are
     meaningless), which walks the whole multi-rank flow -- N = 1 reference, exchange negotiation and calibration, timed region, line."""
     import json
     import torch
@@ -70,13 +102,13 @@ def test_bench_gpus_2_launches_its_own_ranks_and_prints_a_self_describing_line()
         pytest.skip("this process already initialised the GPU; run this file first (or alone)")
     env = dict(os.environ, EH_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == n and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak" and line["value"] > 0
     cfg = line["config"]
-    assert cfg["ranks_seen"] == 2 and cfg["launcher"] == "bench.py:spawn_ranks" and cfg["parallelism"] == "dp2" and cfg["global_batch"] == 2 * 65536
-    assert [d["rank"] for d in cfg["rank_devices"]] == [0, 1]
+    assert cfg["ranks_seen"] == n and cfg["launcher"] == "bench.py:spawn_ranks" and cfg["parallelism"] == f"dp{n}" and cfg["global_batch"] == n * 65536
+    assert [d["rank"] for d in cfg["rank_devices"]] == list(range(n))
     assert "gradient_exchange" in cfg and line["n1_reference"]["value"] > 0 and 0 < line["weak_scaling_vs_n1_in_this_run"] < 2
     assert line["roofline"]["bursts_timed"] >= 5
