@@ -831,18 +831,19 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         for (int vi = 0; vi < h->arch->nvar; ++vi) HIPCHK(h, h->arch->var[vi].prepare());
         return build_maps(h, false);
     }
-    if (!strcmp(name, "precision")) {        // 0 = fp32 end to end (the reference's arithmetic); 1 = bf16 forward products, fp32 accumulate / backward (eh_wide_bf16.hpp)
-        if (value != 0 && value != 1) return fail(h, EH_EINVAL, "precision must be 0 (f32) or 1 (bf16 forward / fp32 accumulate)");
-        const bool now = h->arch->var[h->variant].bf16 != 0;
-        if ((value != 0) == now) return EH_OK;
+    if (!strcmp(name, "precision")) {        // 0 = fp32 end to end (the reference's arithmetic); eh_wide_bf16.hpp: 1 = bf16 forward products, fp32 accumulate, fp32-exact
+                                             // backward; 2 = bf16 operands in both passes (every backward delta rounded once), fp32 accumulate
+        if (value < 0 || value > 2) return fail(h, EH_EINVAL, "precision must be 0 (f32), 1 (bf16 forward / fp32-exact backward) or 2 (bf16 operands in both passes, fp32 accumulate)");
+        const int now = h->arch->var[h->variant].bf16;
+        if ((int)value == now) return EH_OK;
         if (value) {
             if (h->act == EH_ACT_SWISH || h->act == EH_ACT_PER_NET)
-                return fail(h, EH_EUNSUPPORTED, "precision: the bf16-forward kernels keep only the rounded activation (tanh / sigmoid / relu / identity; not swish, not per-net activations)");
+                return fail(h, EH_EUNSUPPORTED, "precision: the bf16 kernels keep only the rounded activation (tanh / sigmoid / relu / identity; not swish, not per-net activations)");
             if (h->fused) return fail(h, EH_EUNSUPPORTED, "precision: switch fused_update off first (the row-split kernels have no such mode)");
             const EhArchInfo* W = h->arch->wide ? h->arch : h->arch_alt;
             int vb = -1;
-            if (W) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16) { vb = vi; break; }
-            if (vb < 0) return fail(h, EH_EUNSUPPORTED, "precision: no bf16-forward kernel is built for this shape (row-split shapes only: hidden width 33..128)");
+            if (W) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16 == (int)value) { vb = vi; break; }
+            if (vb < 0) return fail(h, EH_EUNSUPPORTED, "precision: no bf16 kernel is built for this shape (row-split shapes only: hidden width 33..128)");
             HIPCHK(h, hipSetDevice(h->device));
             FLUSH(h);
             if (W != h->arch) { std::swap(h->arch, h->arch_alt); h->fast = 0; }

@@ -17,7 +17,8 @@ struct EhVariant {
     // fast: bit 0 = single NN output (K == 1), bit 1 = P <= 4; only honoured by shapes built with EH_FAST_PATHS
     hipError_t (*launch)(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
     int tiles;               // macro-tiles a workgroup works on at a time; 0 = nw (one per wave)
-    int bf16;                // 1 = eh_widebf_kernel (eh_wide_bf16.hpp): bf16 forward products, fp32 accumulate / backward ("precision" option)
+    int bf16;                // eh_widebf_kernel (eh_wide_bf16.hpp), the "precision" option: 1 = bf16 forward products, fp32-exact backward (three-term deltas);
+                             // 2 = bf16 operands in both passes (deltas rounded once); 0 = the fp32 kernels
 };
 
 struct EhArchInfo {
@@ -26,7 +27,7 @@ struct EhArchInfo {
     int ip, hp, s0, sh, w0_off, wh_off, wo_off, b_off, phi_off, img_floats;
     int has_fast;            // K1 / small-P kernels compiled for this shape
     int nvar;
-    EhVariant var[4];
+    EhVariant var[6];
     int wide;                // eh_wide_kernel (eh_wide.hpp): the four waves of a workgroup share one tile and split the layers by rows
 };
 

@@ -77,15 +77,15 @@ constexpr int pick_nt_bf() {
     if (sizeof(float) * EhBfGeom<EH_NBI, EH_NBH, EH_NL, 4, NWV>::TOTAL_FLOATS <= EH_LDS_LIMIT) return 4;
     return 2;
 }
-template <int NWV, int NTW = 0>
+template <int NWV, int NTW = 0, int NS = 3>
 struct VarBf {
     static constexpr int NTB = NTW ? NTW : pick_nt_bf<NWV>();
-    using Geom = EhBfGeom<EH_NBI, EH_NBH, EH_NL, NTB, NWV>;
+    using Geom = EhBfGeom<EH_NBI, EH_NBH, EH_NL, NTB, NWV, NS>;
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
     template <int ACT, int MODE>
     static hipError_t prep1() {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_widebf_kernel<EH_NBI, EH_NBH, EH_NL, NTB, NWV, ACT, MODE, false>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_widebf_kernel<EH_NBI, EH_NBH, EH_NL, NTB, NWV, ACT, MODE, false, NS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
     template <int ACT>
@@ -101,7 +101,7 @@ struct VarBf {
         if ((e = prep2<EH_ACT_RELU>()) != hipSuccess) return e;
         return prep2<EH_ACT_IDENTITY>();
     }
-#define EH_GO(MODE) hipLaunchKernelGGL((eh_widebf_kernel<EH_NBI, EH_NBH, EH_NL, NTB, NWV, ACT, MODE, false>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args)
+#define EH_GO(MODE) hipLaunchKernelGGL((eh_widebf_kernel<EH_NBI, EH_NBH, EH_NL, NTB, NWV, ACT, MODE, false, NS>), dim3(grid), dim3(64 * NWV), LDS, stream, *net, *args)
     template <int ACT>
     static void go(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
         if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN); else EH_GO(EH_MODE_EVAL);
@@ -118,7 +118,7 @@ struct VarBf {
         }
         return hipGetLastError();
     }
-    static constexpr EhVariant info() { return EhVariant{NTB, NWV, LDS, 1 << 30, &prepare, &launch, 1, 1}; }
+    static constexpr EhVariant info() { return EhVariant{NTB, NWV, LDS, 1 << 30, &prepare, &launch, 1, NS == 3 ? 1 : 2}; }
 };
 
 using G0 = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT, 4>;
@@ -127,9 +127,9 @@ const EhArchInfo info = {
     G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
     0,
 #if EH_NBH == 8
-    4, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), VarBf<8, 2>::info()},
+    6, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), VarBf<8, 2>::info(), VarBf<8, 0, 1>::info(), VarBf<8, 2, 1>::info()},
 #else
-    2, {Var<4>::info(), VarBf<4>::info(), {}, {}},
+    3, {Var<4>::info(), VarBf<4>::info(), VarBf<4, 0, 1>::info(), {}, {}, {}},
 #endif
     1,
 };

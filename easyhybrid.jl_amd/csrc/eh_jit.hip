@@ -359,7 +359,8 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     const int nmode = (with_p2p && !A->wide && !prog) ? 3 : 2;
     char name[3][160];
     for (int m = 0; m < nmode; ++m) {
-        if (A->wide) snprintf(name[m], sizeof name[m], "%s<%d, %d, %d, %d, %d, %d, %d, %s>", V.bf16 ? "eh_widebf_kernel" : "eh_wide_kernel", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
+        if (A->wide && V.bf16) snprintf(name[m], sizeof name[m], "eh_widebf_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
+        else if (A->wide) snprintf(name[m], sizeof name[m], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
         else snprintf(name[m], sizeof name[m], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m,
                       (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
         hiprtcAddNameExpression(hp, name[m]);

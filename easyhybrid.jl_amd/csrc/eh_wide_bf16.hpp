@@ -55,7 +55,9 @@ __device__ __forceinline__ bf16x8 eh_tr_frag(const __bf16* img, int ld, int row0
     return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
-template <int NBI, int NBH, int NL, int NT, int NWV>
+// NS = bf16 terms a backward delta is carried in: 3 = exact ("bf16_fwd": bf16 forward, fp32-exact backward), 1 = rounded once
+// ("bf16": bf16 operands in both passes, oracle precision = "bf16")
+template <int NBI, int NBH, int NL, int NT, int NWV, int NS = 3>
 struct EhBfGeom {
     using F = EhGeom<NBI, NBH, NL, NT, 1>;                 // the fp32 parameter image in global memory (what the optimiser kernel maintains)
     static_assert(NBH % NWV == 0, "the waves split the feature blocks evenly");
@@ -76,15 +78,16 @@ struct EhBfGeom {
     static constexpr int XB_OFF = IMG_FLOATS;                               // bf16 [MT][S0B] normalised, rounded predictors
     static constexpr int HB_OFF = XB_OFF + MT * S0B / 2;                    // NL x bf16 [MT][SHB] rounded activations
     static constexpr int DOB = 16 + 8;                                      // row stride of the d loss / d NN output planes
-    static constexpr int DZ_OFF = HB_OFF + NL * MT * SHB / 2;               // 3 x bf16 [MT][SHB]: the three terms of the current layer's delta; the fp32 split-K output partials [NPART][16][SR] alias it
-    static constexpr int DO_OFF = DZ_OFF + 3 * MT * SHB / 2;                // 3 x bf16 [MT][DOB]: the three terms of d loss / d NN output
-    static constexpr int OS_OFF = DO_OFF + 3 * MT * DOB / 2;                // fp32 [16][SR] NN outputs -> physical parameters -> d loss / d output
+    static_assert(NS == 1 || NS == 3, "delta terms");
+    static constexpr int DZ_OFF = HB_OFF + NL * MT * SHB / 2;               // NS x bf16 [MT][SHB]: the terms of the current layer's delta; the fp32 split-K output partials [NPART][16][SR] alias it
+    static constexpr int DZ_FLOATS = NS * MT * SHB / 2 > NPART * 16 * SR ? NS * MT * SHB / 2 : NPART * 16 * SR;      // (one plane of a 32-sample tile is smaller than the four output partials)
+    static constexpr int DO_OFF = DZ_OFF + DZ_FLOATS;                       // NS x bf16 [MT][DOB]: the terms of d loss / d NN output
+    static constexpr int OS_OFF = DO_OFF + NS * MT * DOB / 2;               // fp32 [16][SR] NN outputs -> physical parameters -> d loss / d output
     static constexpr int RS_OFF = OS_OFF + 16 * SR;                         // fp32 forcings (rows 0..3), targets (rows 4..7)
     static constexpr int SG_OFF = RS_OFF + (EH_MAX_FORC + EH_MAX_TARG) * SR; // fp32 [16][SR] d parameter / d output
     static constexpr int MAP_FLOATS = SG_OFF + 16 * SR;
     static constexpr int STAGE_FLOATS = NWV * eh_wide_layout(NBI, NBH, NL, NWV).na * 256;      // the end-of-kernel staging of the accumulators overlays the (then dead) map
     static constexpr int TOTAL_FLOATS = MAP_FLOATS > STAGE_FLOATS ? MAP_FLOATS : STAGE_FLOATS;
-    static_assert(NPART * 16 * SR <= 3 * MT * SHB / 2, "the split-K output partials alias the delta planes");
 };
 
 // sums of one wave's mechanistic stage (train: gradient of the global parameters, loss terms; eval: metric sums)
@@ -244,7 +247,7 @@ __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepA
     }
 }
 
-template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false>
+template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false, int NS = 3>
 __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_rt, const EhStepArgs a) {
 #ifdef EH_SPEC_NET
     constexpr EhNet net = {EH_SPEC_NET};        // see eh_step_body
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     const EhNet& net = net_rt;
 #endif
     static_assert(!EhStoresZ<ACT>::value, "the bf16-forward kernel keeps only the rounded activation");
-    using G = EhBfGeom<NBI, NBH, NL, NT, NWV>;
+    using G = EhBfGeom<NBI, NBH, NL, NT, NWV, NS>;
     using F = typename G::F;
     constexpr int MT = G::MT, SR = G::SR, HP = G::HP, IP = G::IP, KP0 = G::KP0, S0B = G::S0B, SHB = G::SHB, MB = NBH / NWV, NTH = 64 * NWV;
     constexpr int NPART = G::NPART, KSH = HP / 32, KS0 = KP0 / 32;
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     float* const BIAS = smem + G::B_OFF;
     __bf16* const XB = reinterpret_cast<__bf16*>(smem + G::XB_OFF);
     __bf16* const HB = reinterpret_cast<__bf16*>(smem + G::HB_OFF);
-    __bf16* const DZP = reinterpret_cast<__bf16*>(smem + G::DZ_OFF);      // [3][MT][SHB]
-    __bf16* const DOP = reinterpret_cast<__bf16*>(smem + G::DO_OFF);      // [3][MT][DOB]
+    __bf16* const DZP = reinterpret_cast<__bf16*>(smem + G::DZ_OFF);      // [NS][MT][SHB]
+    __bf16* const DOP = reinterpret_cast<__bf16*>(smem + G::DO_OFF);      // [NS][MT][DOB]
     float* const OSP = smem + G::DZ_OFF;        // [NPART][16][SR] partial outputs of the split-K output layer (before the deltas exist)
     float* const OS = smem + G::OS_OFF;
     float* const RS = smem + G::RS_OFF;
@@ -443,11 +446,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     constexpr int DOB = G::DOB, PZ = MT * SHB, PO = MT * DOB;      // plane sizes (elements) of the delta / output-delta terms
     // a C/D block of deltas (features 16m+4g .. +3 of sample 16t+c per lane), split into its three bf16 terms, into the delta planes
     auto store_dz = [&](const f32x4& d, int m, int t) {
-        bf16x4 p0, p1, p2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { __bf16 x, y, z; eh_split3(d[r], x, y, z); p0[r] = x; p1[r] = y; p2[r] = z; }
         __bf16* const q = DZP + (16 * t + c) * SHB + 16 * m + 4 * g;
-        *(bf16x4*)q = p0; *(bf16x4*)(q + PZ) = p1; *(bf16x4*)(q + 2 * PZ) = p2;
+        if constexpr (NS == 1) {
+            *(bf16x4*)q = bf16x4{(__bf16)d[0], (__bf16)d[1], (__bf16)d[2], (__bf16)d[3]};
+        } else {
+            bf16x4 p0, p1, p2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { __bf16 x, y, z; eh_split3(d[r], x, y, z); p0[r] = x; p1[r] = y; p2[r] = z; }
+            *(bf16x4*)q = p0; *(bf16x4*)(q + PZ) = p1; *(bf16x4*)(q + 2 * PZ) = p2;
+        }
     };
     // stored (rounded) activations of features 16m+4g .. +3 of sample 16t+c
     auto load_h4 = [&](const __bf16* img, int m, int t) {
@@ -538,9 +545,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
         for (int u = 0; u < NEO; ++u) {
             const int e = tid + u * NTH, k = e & 15, smp = e >> 4;
             if (NEO * NTH == 16 * MT || e < 16 * MT) {
-                __bf16 x, y, z;
-                eh_split3(OS[k * SR + smp], x, y, z);
-                DOP[smp * DOB + k] = x; DOP[PO + smp * DOB + k] = y; DOP[2 * PO + smp * DOB + k] = z;
+                if constexpr (NS == 1) DOP[smp * DOB + k] = (__bf16)OS[k * SR + smp];
+                else {
+                    __bf16 x, y, z;
+                    eh_split3(OS[k * SR + smp], x, y, z);
+                    DOP[smp * DOB + k] = x; DOP[PO + smp * DOB + k] = y; DOP[2 * PO + smp * DOB + k] = z;
+                }
             }
         }
         eh_lds_barrier();
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
             for (int kk = 0; kk < MT / 32; ++kk) {
                 const bf16x8 bfr = eh_tr_frag(Hlast, SHB, 32 * kk, 16 * m, lane);
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NS; ++p)
                     aWo[mm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh_tr_frag(DOP + p * PO, DOB, 32 * kk, 0, lane), bfr, aWo[mm], 0, 0, 0);
             }
             // dH_last[own features][samples] = bf16(Wo)^T dO : k = the 16 (padded) output rows, the upper half of the k-step is zero
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
 #pragma unroll
             for (int t = 0; t < NT; ++t) dh[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NS; ++p)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     bf16x8 bfr = *(const bf16x8*)&DOP[p * PO + (16 * t + c) * DOB + 8 * (g & 1)];
@@ -597,16 +607,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
                 constexpr int NG = NBH < 4 ? NBH : 4;           // column blocks in flight: independent accumulators
 #pragma unroll
                 for (int kk = 0; kk < MT / 32; ++kk) {
-                    bf16x8 afr[3];
+                    bf16x8 afr[NS];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) afr[p] = eh_tr_frag(DZP + p * PZ, SHB, 32 * kk, 16 * (m0 + mm), lane);
+                    for (int p = 0; p < NS; ++p) afr[p] = eh_tr_frag(DZP + p * PZ, SHB, 32 * kk, 16 * (m0 + mm), lane);
 #pragma unroll
                     for (int n0 = 0; n0 < NBH; n0 += NG) {
                         bf16x8 bfr[NG];
 #pragma unroll
                         for (int u = 0; u < NG; ++u) bfr[u] = eh_tr_frag(Hp, SHB, 32 * kk, 16 * (n0 + u), lane);
 #pragma unroll
-                        for (int p = 0; p < 3; ++p)
+                        for (int p = 0; p < NS; ++p)
 #pragma unroll
                             for (int u = 0; u < NG; ++u)
                                 aWh[l - 1][mm][n0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[p], bfr[u], aWh[l - 1][mm][n0 + u], 0, 0, 0);
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
 #pragma unroll
                 for (int mm = 0; mm < MB; ++mm) afr[mm] = eh_tr_frag(W, SHB, 32 * kk, 16 * (m0 + mm), lane);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NS; ++p) {
                     bf16x8 bfr[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) bfr[t] = *(const bf16x8*)&DZP[p * PZ + (16 * t + c) * SHB + 32 * kk + 8 * g];
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
 #pragma unroll
                 for (int n = 0; n < NBI; ++n) bfr[n] = eh_tr_frag(XB, S0B, 32 * kk, 16 * n, lane);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NS; ++p) {
                     const bf16x8 afr = eh_tr_frag(DZP + p * PZ, SHB, 32 * kk, 16 * (m0 + mm), lane);
 #pragma unroll
                     for (int n = 0; n < NBI; ++n) aW0[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n], aW0[mm][n], 0, 0, 0);

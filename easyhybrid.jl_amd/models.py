@@ -370,16 +370,17 @@ class SingleNNHybridModel:
         return d
 
     def engine(self, device: int = 0):
-        """precision = "bf16_fwd" (a build extension, BASELINE.json config 5; the reference is Float32 end to end): Dense products of
-        the forward pass on bf16 operands with fp32 accumulation, fp32 backward (csrc/eh_wide_bf16.hpp)."""
+        """precision (a build extension, BASELINE.json config 5; the reference is Float32 end to end; csrc/eh_wide_bf16.hpp):
+        "bf16_fwd" = Dense products of the forward pass on bf16 operands with fp32 accumulation, fp32-exact backward;
+        "bf16" = bf16 operands in both passes (every backward delta rounded to bf16 once), fp32 accumulation."""
         from .engine import HybridEngine
         eng = HybridEngine(self.to_desc(device), len(self.mechanistic_model.params), self.targets,
                            list(self.mechanistic_model.params))
         prec = self.config.get("precision", "f32")
-        if prec not in ("f32", "bf16_fwd"):
-            raise ValueError(f"precision {prec!r}: 'f32' or 'bf16_fwd'")
-        if prec == "bf16_fwd":
-            eng.set_option("precision", 1)
+        if prec not in ("f32", "bf16_fwd", "bf16"):
+            raise ValueError(f"precision {prec!r}: 'f32', 'bf16_fwd' or 'bf16'")
+        if prec != "f32":
+            eng.set_option("precision", 1 if prec == "bf16_fwd" else 2)
         return eng
 
 

@@ -372,6 +372,15 @@ class HybridSpec:
     # fp32.  What a layer hands on IS the rounded activation, so the backward pass -- fp32 -- is the exact derivative of that
     # function with round() treated as the identity (straight-through): dW = dZ * bf16(h)^T, dH = bf16(W)^T dZ, and act' taken
     # from the stored (rounded) activation, as a mixed-precision framework that keeps bf16 activations does.
+    # "bf16": the usual reading of "bf16 / fp32 accumulate" -- bf16 operands in BOTH passes.  The forward of "bf16_fwd"; in the
+    # backward pass every delta (d loss / d pre-activation of a layer, the NN-output one included) is computed in fp32 and rounded
+    # to bfloat16 before it enters the two Dense products it feeds: dW = bf16(dZ) * bf16(h)^T, dH = bf16(W)^T bf16(dZ), both
+    # accumulated exactly (fp32 on the device).  The bias gradients are sums of the un-rounded fp32 deltas (no product involved).
+    # The deltas are rounded IN THE SCALE THE STEP CARRIES THEM: a one-target model back-propagates the UN-normalised loss (sum of
+    # squared / absolute residuals; the division by n, 2 n rmse or sum (y - ybar)^2 is applied to the finished gradient in fp32 --
+    # n is only known once the pass is over, and under data parallelism only after the all-reduce), so what is rounded is n times the
+    # normalised delta: loss scaling by the batch's own normaliser, independent of how the batch is sharded.  Multi-target models and the
+    # two-pass losses carry exact per-target weights through the pass and round the normalised delta.
     precision: str = "f32"
 
     def act_of(self, k: int) -> str:
@@ -387,9 +396,9 @@ class HybridSpec:
                 raise AssertionError("neural_param_names ⊆ param_names")   # GenericHybridModel.jl:110
         if not self.targets:
             self.targets = [mm.outputs[0]]
-        if self.precision not in ("f32", "bf16_fwd"):
+        if self.precision not in ("f32", "bf16_fwd", "bf16"):
             raise ValueError(f"precision {self.precision}")
-        if self.precision == "bf16_fwd" and any(self.act_of(k) == "swish" for k in range(len(self.neural) if self.nets else 1)):
+        if self.precision != "f32" and any(self.act_of(k) == "swish" for k in range(len(self.neural) if self.nets else 1)):
             raise NotImplementedError("bf16_fwd keeps only the rounded activation: swish needs the pre-activation")
         self.fixed = [n for n in self.parameters if n not in self.neural and n not in self.glob]
 
@@ -530,7 +539,7 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
     # k2: MLP(s): one chain for SingleNN, one single-output chain per neural parameter for MultiNN
     tapes, outs = [], []
     for k_net, ((rows, _), Ws) in enumerate(zip(spec.net_list, nets)):
-        bf = spec.precision == "bf16_fwd"
+        bf = spec.precision in ("bf16_fwd", "bf16")
         h = round_bf16(X[rows]) if bf else X[rows]
         if bf:
             Ws = [(round_bf16(W), b) for W, b in Ws]          # the rounded weights are what forward AND backward multiply by
@@ -675,6 +684,8 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
     kinds = list(kind) if isinstance(kind, (list, tuple)) else [kind] * len(spec.targets)      # PerTarget((l_1, ..., l_T)), compute_loss.jl:128-145
     if len(kinds) != len(spec.targets):
         raise AssertionError("Length of targets and PerTarget losses tuple must match")
+    defer = dt.type(1)           # one-target, one-pass losses: the factor the engine applies AFTER the pass (what "bf16" rounds is delta / defer)
+    dout_un = {}                 # ... and the un-normalised seed d (loss / defer) / d yhat itself, formed the way the engine forms it (no division)
     for t, kind in zip(spec.targets, kinds):
         y = np.asarray(targets[t], dt)
         m = valid_mask(y)
@@ -686,18 +697,22 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
             if kind == "mse":
                 loss = loss + np.sum(r * r) / dt.type(n)
                 d = dt.type(2) * r / dt.type(n)
+                defer = dt.type(1) / dt.type(n); dout_un[t] = dt.type(2) * r
             elif kind == "rmse":
                 rm = np.sqrt(np.sum(r * r) / dt.type(n))
                 loss = loss + rm
                 d = r / (dt.type(n) * rm)
+                defer = dt.type(1) / (dt.type(2) * dt.type(n) * rm); dout_un[t] = dt.type(2) * r
             elif kind == "mae":
                 loss = loss + np.sum(np.abs(r)) / dt.type(n)
                 d = np.sign(r) / dt.type(n)
+                defer = dt.type(1) / dt.type(n); dout_un[t] = np.sign(r).astype(dt)
             elif kind == "nseLoss":
                 yv = y[m]
                 D = np.sum((yv - np.mean(yv)) ** 2)
                 loss = loss + np.sum(r * r) / D
                 d = dt.type(2) * r / D
+                defer = dt.type(1) / D; dout_un[t] = dt.type(2) * r
             elif kind in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):          # loss_fn.jl:75-77,105-174 (Statistics.cor / std, n-1 cancels)
                 yh, yv = res[t][m].astype(dt), y[m]
                 mu_s, mu_o = np.mean(yh), np.mean(yv)
@@ -727,6 +742,8 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
                 value = np.mean(lout["loss"]) if closure is None else dt.type(closure(yh, yv))       # the function itself gives the value
                 loss = loss + value
                 d[m] = lvjp(lpar, {}, lout, laux, {"loss": np.full(n, 1.0 / n, dt)}, dt)["yhat"]
+                defer = dt.type(1) / dt.type(n)
+                du = np.zeros(B, dt); du[m] = lvjp(lpar, {}, lout, laux, {"loss": np.ones(n, dt)}, dt)["yhat"]; dout_un[t] = du
             else:
                 raise ValueError(f"training loss {kind}")
         dout[t] = d
@@ -740,13 +757,25 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         s = _sigmoid(r.reshape(1))[0]
         graw.append(np.sum(dpar[g]) * dt.type(spec.hi(g) - spec.lo(g)) * s * (1 - s))
     # NN outputs
-    do = np.zeros_like(tp["o"])
-    for k, n in enumerate(spec.neural):
-        d = np.broadcast_to(dpar[n], (B,)).astype(dt)
-        if spec.scale_nn_outputs:
-            s = _sigmoid(tp["o"][k])
-            d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
-        do[k] = d
+    def nn_output_grads(dp):
+        do = np.zeros_like(tp["o"])
+        for k, n in enumerate(spec.neural):
+            d = np.broadcast_to(dp[n], (B,)).astype(dt)
+            if spec.scale_nn_outputs:
+                s = _sigmoid(tp["o"][k])
+                d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
+            do[k] = d
+        return do
+    do = nn_output_grads(dpar)
+    # precision = "bf16" rounds the deltas in the scale the step carries them (HybridSpec.precision): un-normalised for a one-target
+    # model with a one-pass loss -- the chain re-run from the un-normalised seed, as the engine forms it, not do / defer
+    bfb = spec.precision == "bf16"
+    deferred = bfb and len(spec.targets) == 1 and spec.targets[0] in dout_un
+    sc = defer if deferred else dt.type(1)
+    if deferred:
+        seeds = {oname: np.zeros(B, dt) for oname in mm.outputs}
+        seeds[spec.targets[0]] = dout_un[spec.targets[0]]
+        do = nn_output_grads(vjp(tp["par"], tp["frc"], tp["out"], tp["aux"], seeds, dt))
     # MLP backward (each net sees the rows of dO that belong to its outputs)
     gnets, k0 = [], 0
     for k_net, (Ws, zs, hs) in enumerate(tp["nets"]):
@@ -754,11 +783,13 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         delta = do[k0:k0 + kout]
         k0 += kout
         gWs = []
+        # bfb: bf16 operands in the backward products too -- the delta (un-normalised where `deferred`) is rounded where it enters them
         for li in reversed(range(len(Ws))):
             W, b = Ws[li]
-            gWs.append((delta @ hs[li].T, delta.sum(axis=1)))
+            dq = round_bf16(delta) if bfb else delta
+            gWs.append(((dq @ hs[li].T) * sc, delta.sum(axis=1) * sc))
             if li > 0:
-                delta = (W.T @ delta) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
+                delta = (W.T @ dq) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
         gWs.reverse()
         gnets.append(gWs)
     grad = pack(spec, gnets, graw, dt)

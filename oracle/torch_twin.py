@@ -52,6 +52,20 @@ class _RoundedAct(torch.autograd.Function):
         return g * d, None
 
 
+class _RoundedGrad(torch.autograd.Function):
+    """spec.precision == "bf16": the identity forward; the gradient passing back through it is rounded to bfloat16.  Placed on the
+    product W h of a Dense layer (ahead of the bias add), it makes both backward products of the layer -- dW = d h^T, dh = W^T d --
+    take the rounded delta, while the bias gradient sums the un-rounded one."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return _round_bf16(g)
+
+
 def _mech(spec, par, frc):
     m = spec.mech
     if m == "rbq10":
@@ -83,7 +97,8 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
         h = (h - h.mean(dim=1, keepdim=True)) / torch.sqrt(h.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
     X0, outs = h, []
     for k_net, (rows, dims) in enumerate(spec.net_list):
-        bf = getattr(spec, "precision", "f32") == "bf16_fwd"
+        bf = getattr(spec, "precision", "f32") in ("bf16_fwd", "bf16")
+        bfb = getattr(spec, "precision", "f32") == "bf16"
         h = _round_bf16(X0[rows]) if bf else X0[rows]
         for li, (o, i) in enumerate(dims):
             W = theta[off:off + o * i].reshape(i, o).T          # column-major (out,in)
@@ -92,7 +107,7 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
             off += o * i
             b = theta[off:off + o]
             off += o
-            z = W @ h + b[:, None]
+            z = (_RoundedGrad.apply(W @ h) if bfb else W @ h) + b[:, None]
             if li == len(dims) - 1: h = z
             elif bf: h = _RoundedAct.apply(z, spec.act_of(k_net))
             else: h = _act(spec.act_of(k_net), z)
@@ -109,7 +124,9 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
     return _mech(spec, par, frc)
 
 
-def loss(spec, theta, X, forcings, targets, kind="mse"):
+def loss(spec, theta, X, forcings, targets, kind="mse", unnormalised=False):
+    """unnormalised (mse on one target only): the SUM of squared residuals -- what the engine back-propagates before it divides the
+    finished gradient by n; matters where the backward pass rounds (precision = "bf16")"""
     out = forward(spec, theta, X, forcings)
     tot = 0
     for t in spec.targets:
@@ -118,7 +135,9 @@ def loss(spec, theta, X, forcings, targets, kind="mse"):
         if int(m.sum()) == 0:
             continue
         a, b = out[t][m], y[m]
-        if kind == "mse":
+        if kind == "mse" and unnormalised:
+            tot = tot + torch.sum((a - b) ** 2)
+        elif kind == "mse":
             tot = tot + torch.mean((a - b) ** 2)                       # loss_fn.jl:61-63
         elif kind == "rmse":
             tot = tot + torch.sqrt(torch.mean((a - b) ** 2))           # :58-60
@@ -133,11 +152,14 @@ def loss(spec, theta, X, forcings, targets, kind="mse"):
 
 def loss_and_grad(spec, theta_np, X, forcings, targets, dtype=torch.float64, kind="mse"):
     theta = torch.tensor(np.asarray(theta_np), dtype=dtype, requires_grad=True)
-    l = loss(spec, theta, X, forcings, targets, kind)
+    # precision = "bf16" on a one-target mse model: the deltas are rounded in the un-normalised scale (oracle/hybrid_oracle.py, HybridSpec.precision)
+    un = getattr(spec, "precision", "f32") == "bf16" and len(spec.targets) == 1 and kind == "mse"
+    l = loss(spec, theta, X, forcings, targets, kind, unnormalised=un)
     if not torch.is_tensor(l):
         return 0.0, np.zeros(theta.numel())
     l.backward()
-    return float(l.detach()), theta.grad.numpy().copy()
+    n = float(np.sum(~np.isnan(np.asarray(targets[spec.targets[0]])))) if un else 1.0
+    return float(l.detach()) / n, theta.grad.numpy().copy() / n
 
 
 def train_step_timed(spec, theta_np, X, forcings, targets, n_steps, lr=0.01, threads=None):

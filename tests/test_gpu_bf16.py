@@ -7,7 +7,14 @@ one rounded operand in 2^-8 / 1e-7 ~ 4e4 lands on the other side of a bf16 round
 (0.4 %).  A sample has 32 + 128 + 128 rounded operands: roughly 1 % of the samples see one flip and their prediction moves by
 ~1e-4 relative; sums over a batch average that out.  Hence: loss within 2e-5, gradient within 5e-5 of its largest entry (both far
 below the 4e-3 quantisation step and the ~1e-2 distance between the bf16 and the fp32 model, which the tests also check), and per
-sample 98 % of the predictions within 1e-5, all within 2e-3."""
+sample 98 % of the predictions within 1e-5, all within 2e-3.
+
+precision = "bf16" (bf16 operands in BOTH passes, every backward delta rounded to bfloat16 once; oracle `HybridSpec.precision =
+"bf16"`): the forward is the same function, so the loss bar stays 2e-5.  The deltas are rounded in the scale the step carries them --
+un-normalised for a one-target model (the division by n comes after the pass) -- and the oracle rounds in that same scale; device
+(fp32) and oracle (fp64) deltas then differ by ~1e-7 relative before rounding, one in ~4e4 rounds the other way, and the gradient
+agrees to 3e-7 .. 6e-7 of its largest entry (measured; bar 2e-5), against 1e-4 .. 1e-3 between the "bf16" and the "bf16_fwd"
+gradients (rounding noise that averages out over the batch), which the tests also check."""
 import numpy as np
 import pytest
 
@@ -18,8 +25,11 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _case(B, act="tanh", hidden=(128, 128), n_pred=32, nan=0.1, seed=11):
-    spec = ho.c5_spec(hidden, act, "bf16_fwd", n_pred)
+GTOL_BF16 = 2e-5        # gradient bar of precision = "bf16" (see the module docstring)
+
+
+def _case(B, act="tanh", hidden=(128, 128), n_pred=32, nan=0.1, seed=11, precision="bf16_fwd"):
+    spec = ho.c5_spec(hidden, act, precision, n_pred)
     X, f, y = ho.make_synth_c5(B, seed, nan, n_pred)
     return spec, ho.init_theta(spec, 3, np.float32), X, f, y
 
@@ -48,6 +58,66 @@ def test_config5_loss_and_gradient_match_the_bf16_oracle(B):
     eng.set_option("precision", 1)
     l2, g2, _ = eng.loss_and_grad()
     assert l2 == loss and np.array_equal(g2, grad)           # deterministic, and the switch goes both ways
+    eng.close()
+
+
+@pytest.mark.parametrize("B", [33, 1000, 4096])
+def test_config5_bf16_operands_in_both_passes_match_the_oracle(B):
+    """precision = "bf16": the same forward as "bf16_fwd" (bit for bit the same loss), the backward products on once-rounded deltas"""
+    spec, theta, X, f, y = _case(B, precision="bf16")
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, l0, g0 = _check(eng, spec, theta, X, f, y, gtol=GTOL_BF16)
+    print(f"bf16 both passes, B = {B}: gradient relerr {util.relerr(grad, g0):.2e}")
+    eng.set_option("precision", 1)                         # the exact-backward mode on the same engine: same loss, a measurably different gradient
+    l1, g1, _ = eng.loss_and_grad()
+    specf = ho.c5_spec(precision="bf16_fwd")
+    _, gf, _ = ho.loss_and_grad(specf, theta.astype(np.float64), X, f, y)
+    assert l1 == loss and util.relerr(g1, gf) <= 5e-5
+    assert util.relerr(grad, g1) > 5e-5, util.relerr(grad, g1)      # (a test that would not notice a kernel that ignored the option)
+    # ... and the oracle sees the same distance between the two modes
+    assert abs(util.relerr(g0, gf) - util.relerr(grad, g1)) <= 0.1 * util.relerr(g0, gf) + GTOL_BF16
+    eng.set_option("precision", 2)
+    l2, g2, _ = eng.loss_and_grad()
+    assert l2 == loss and np.array_equal(g2, grad)           # deterministic, and the switch goes both ways
+    eng.close()
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "identity"])
+def test_other_activations_bf16_both_passes(act):
+    spec, theta, X, f, y = _case(777, act, precision="bf16")
+    eng = util.load_engine(spec, theta, X, f, y)
+    _check(eng, spec, theta, X, f, y, gtol=GTOL_BF16)
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden,n_pred", [((128,), 32), ((100, 70), 20), ((64, 64), 8), ((40, 33, 50), 5)])
+def test_other_shapes_bf16_both_passes(hidden, n_pred):
+    spec, theta, X, f, y = _case(600, "tanh", hidden, n_pred, precision="bf16")
+    eng = util.load_engine(spec, theta, X, f, y)
+    _check(eng, spec, theta, X, f, y, gtol=GTOL_BF16)
+    eng.close()
+
+
+def test_adam_trajectory_bf16_both_passes():
+    """Four Adam steps.  The one-step gradient agrees with the oracle to 5e-7 (above); a trajectory cannot be held to that: the once-
+    rounded deltas give every gradient entry a rounding noise of 1e-4 .. 1e-3 relative that ANY perturbation re-draws -- one Adam
+    sign flip of a near-zero entry in step 1 (|update| = lr whatever the size) moves a weight by 2 lr, every delta of the next step
+    rounds afresh, and the updates differ by ~lr x 1e-3 from then on.  The oracle's own fp32 and fp64 trajectories part the same way
+    (82 % of theta within 2e-5 after these four steps).  Bar: the first step exact up to such flips, afterwards 99 % of theta within
+    4 x lr x 5e-3 and the losses within 2e-3."""
+    spec, theta, X, f, y = _case(2048, nan=0.05, precision="bf16")
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    windows = [(0, 1024), (1024, 1024), (512, 1024), (0, 2048)]
+    l1 = eng.train_step(*windows[0])
+    th1, lr1 = ho.train_steps(spec, theta, X, f, y, windows[:1], dtype=np.float32)
+    d1 = np.abs(eng.get_params() - th1)
+    assert np.mean(d1 <= 1e-6) >= 0.999 and np.max(d1) <= 2.01 * 0.01 and abs(l1 - lr1[0]) <= 2e-5 * abs(lr1[0]), (np.mean(d1 <= 1e-6), np.max(d1))
+    losses = [l1] + [eng.train_step(a, n) for a, n in windows[1:]]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, windows, dtype=np.float32)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 2e-4) >= 0.99 and np.max(d) <= 2.5e-2 * 0.01 * len(windows) * 40, (np.mean(d <= 2e-4), np.max(d))
+    assert np.allclose(losses, l_ref, rtol=2e-3)
     eng.close()
 
 
@@ -183,14 +253,18 @@ def c5_resident():
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16_fwd", "f32"])
+PREC_OPT = {"f32": 0, "bf16_fwd": 1, "bf16": 2}
+PREC_TOL = {"f32": (1e-5, 1e-5), "bf16_fwd": (2e-5, 5e-5), "bf16": (2e-5, GTOL_BF16)}
+
+
+@pytest.mark.parametrize("precision", ["bf16_fwd", "bf16", "f32"])
 def test_windows_and_gathered_minibatches_at_the_end_of_1e7_resident_samples(c5_resident, precision):
     """record offsets near the end of a 1.44 GB array (360 M floats: 32-bit element offsets would still hold, 32-bit BYTE offsets
     would not): the last window, a window straddling nothing but the last records, and minibatches gathered from the last 1 %"""
     spec, theta, X, f, y, eng = c5_resident
-    eng.set_option("precision", 1 if precision == "bf16_fwd" else 0)
+    eng.set_option("precision", PREC_OPT[precision])
     sp = ho.c5_spec(precision=precision)
-    ltol, gtol = (2e-5, 5e-5) if precision == "bf16_fwd" else (1e-5, 1e-5)
+    ltol, gtol = PREC_TOL[precision]
     N = N_C5
 
     def oracle(ix):
@@ -209,13 +283,13 @@ def test_windows_and_gathered_minibatches_at_the_end_of_1e7_resident_samples(c5_
         eng.loss_and_grad(eh.EH_SPLIT_TRAIN, N - 100, 101)      # one past the end
 
 
-@pytest.mark.parametrize("precision", ["bf16_fwd", "f32"])
+@pytest.mark.parametrize("precision", ["bf16_fwd", "bf16", "f32"])
 def test_training_steps_on_full_size_minibatches_from_the_last_percent(c5_resident, precision):
     """B = 65 536 gathered from the last 1 % (what a shuffled epoch's last steps read), as training steps: the step's loss equals
     the loss_and_grad of the same indices (HIP vs HIP, bit for bit the same pass), the first step's loss equals the count-weighted
     sum over oracle-checked eighths, and plain descent moves theta by exactly -lr x that gradient."""
     spec, theta, X, f, y, eng = c5_resident
-    eng.set_option("precision", 1 if precision == "bf16_fwd" else 0)
+    eng.set_option("precision", PREC_OPT[precision])
     eng.set_params(theta)
     sp = ho.c5_spec(precision=precision)
     N, B = N_C5, 65536
@@ -227,7 +301,7 @@ def test_training_steps_on_full_size_minibatches_from_the_last_percent(c5_reside
         ix = idx[q:q + 8192]
         l0, _, nv0 = ho.loss_and_grad(sp, theta.astype(np.float64), X[:, ix], {k: v[ix] for k, v in f.items()}, {k: v[ix] for k, v in y.items()})
         acc_l += l0 * sum(nv0); acc_n += sum(nv0)
-    assert nv == acc_n and abs(loss - acc_l / acc_n) <= (2e-5 if precision == "bf16_fwd" else 1e-5) * abs(loss)
+    assert nv == acc_n and abs(loss - acc_l / acc_n) <= PREC_TOL[precision][0] * abs(loss)
     eng.opt_init("Descent", 0.05)
     step_loss = eng.train_step(0, B, idx=idx)
     assert step_loss == pytest.approx(loss, rel=1e-6)

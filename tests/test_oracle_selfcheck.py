@@ -239,6 +239,27 @@ def test_bf16_forward_vjp_matches_straight_through_autograd(act):
     assert 1e-6 < abs(l32 - l0) / abs(l32) < 5e-2
 
 
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "relu"])
+def test_bf16_both_passes_vjp_matches_autograd_with_rounded_deltas(act):
+    """precision = "bf16" (bf16 operands in both passes): the hand VJP against autograd of the same forward in which the gradient
+    entering each Dense product is rounded to bfloat16 (oracle/torch_twin.py `_RoundedGrad`), the bias gradients un-rounded.  Both
+    sides round the SAME fp64 deltas here, so they agree to rounding of the sums; and the mode differs measurably from bf16_fwd."""
+    spec = ho.c5_spec(hidden=(24, 20), activation=act, n_pred=7, precision="bf16")
+    X, f, y = ho.make_synth_c5(300, 5, 0.1, n_pred=7)
+    theta = ho.init_theta(spec, 2, np.float64)
+    l0, g0, nv = ho.loss_and_grad(spec, theta, X, f, y)
+    l1, g1 = tt.loss_and_grad(spec, theta, X, f, y)
+    assert abs(l0 - l1) <= 1e-12 * abs(l1)
+    # a delta that sits within 1e-16 of a bf16 rounding boundary may round differently on the two sides (different summation order
+    # upstream): rare, and worth one bf16 unit of one delta -- the bar allows for a handful
+    assert np.max(np.abs(g0 - g1)) <= 1e-6 * np.max(np.abs(g1))
+    specf = ho.c5_spec(hidden=(24, 20), activation=act, n_pred=7, precision="bf16_fwd")
+    lf, gf, _ = ho.loss_and_grad(specf, theta, X, f, y)
+    assert lf == l0                                      # same forward
+    rel = np.max(np.abs(gf - g0)) / np.max(np.abs(gf))
+    assert 1e-6 < rel < 2e-2, rel                        # the rounded deltas show at the 1e-3 level
+
+
 def test_bf16_forward_refuses_swish():
     with pytest.raises(NotImplementedError):
         ho.c5_spec(activation="swish")
