@@ -597,6 +597,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         EhImg& im = h->img;
         im.image = h->image; im.imap = h->imap; im.g_off = n.g_off; im.phi_off = arch->phi_off;
         im.l2c = 0.0f; im.l2w = nullptr; im.n_theta = n.n_theta; im.b_off = arch->b_off; im.wflag = h->wflag;
+        im.agg_a = 1.0f; im.l2s = 1.0f;          // agg = sum
         HIPCHK_C(hipMalloc(&h->l2val, sizeof(float)));
         HIPCHK_C(hipMemset(h->l2val, 0, sizeof(float)));
         {
@@ -810,6 +811,20 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "jit")) {              // recorded closures: 1 = kernels compiled at run time around the program (default), 0 = the interpreter
         h->jit_on = value != 0;
+        return EH_OK;
+    }
+    if (!strcmp(name, "agg") || !strcmp(name, "extra_terms")) {
+        // `agg::Function` of the training configuration (src/config/TrainingConfig.jl:76-77): the training loss is
+        // agg([agg(per-target losses), extra loss entries...]) (src/losses/compute_loss.jl:31-34,50-53).  0 = sum (default), 1 = mean;
+        // "extra_terms" = the number of entries the extra loss returns (what eh_set_weight_l2 / eh_set_weight_l2_coef stand for: one
+        // entry, or as many weight_l2 terms as the host folded into the coefficients) -- only `mean` needs it.
+        if (!strcmp(name, "agg")) { if (value != 0 && value != 1) return fail(h, EH_EINVAL, "agg must be 0 (sum) or 1 (mean)"); }
+        else if (value < 0 || value > 64) return fail(h, EH_EINVAL, "extra_terms must be 0..64");
+        HIPCHK(h, hipSetDevice(h->device));
+        FLUSH(h);                                 // (a pending fused update was computed under the old setting)
+        if (!strcmp(name, "agg")) h->agg = (int)value; else h->n_extra = (int)value;
+        h->img.agg_a = h->agg ? 1.0f / ((float)h->net.T * (float)(1 + h->n_extra)) : 1.0f;
+        h->img.l2s = h->agg ? 1.0f / (float)(1 + h->n_extra) : 1.0f;
         return EH_OK;
     }
     if (!strcmp(name, "specialize")) {       // 1 = step kernels compiled at run time with the model descriptor as a compile-time constant;
@@ -1175,7 +1190,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     *rows_out = rows;
     if (net.T > 1 && !h->dp_weights) {        // (data-parallel step: eh_dp_grad has just filled inv_n with the weights of the GLOBAL batch)
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
-        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4, h->img.agg_a);
         HIPCHK(h, hipGetLastError());
     }
     if (count <= 0) {                          // nothing to do: an all-zero partial (the reduce kernel then skips the update)
@@ -1200,7 +1215,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
             else hipLaunchKernelGGL((eh_lform_mech_kernel<false, false>), dim3(egrid), dim3(256), 0, h->stream, net, e, me, h->image);
             HIPCHK(h, hipGetLastError());
             if (pass == 0) hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
-            else hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
+            else hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n, h->img.agg_a);
             HIPCHK(h, hipGetLastError());
             e.inv_n = h->inv_n;
         }
@@ -1354,7 +1369,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     const EhNet& net = h->net;
     if (net.T > 1 && !h->dp_weights) {
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
-        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4);
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4, h->img.agg_a);
         HIPCHK(h, hipGetLastError());
     }
     const bool moment_loss = two_pass_mask(net) != 0;
@@ -1376,7 +1391,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         HIPCHK(h, hipGetLastError());
         e.inv_n = h->inv_n;                                                                                               // -> moments about it
         HIPCHK(h, step_launch(h, EH_MODE_EVAL, egrid, &e));
-        hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n);
+        hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(net.T), dim3(64), 0, h->stream, h->slab, egrid, net.T, net.loss_t, s4, h->inv_n, h->img.agg_a);
         HIPCHK(h, hipGetLastError());
     }
     EhStepArgs a{};
@@ -1412,13 +1427,13 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     if (h->net.T > 1) {      // multi-target: the per-target weights (1 / n_t, 1 / sum (y - ybar)^2) have to be known inside the streaming pass
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
-        hipLaunchKernelGGL(eh_count_kernel, dim3(h->net.T), dim3(256), 0, h->stream, sp.recs, h->C, h->net.P + h->net.F, h->net.T, idx, first, count, h->inv_n, h->net.loss_t, sh4);
+        hipLaunchKernelGGL(eh_count_kernel, dim3(h->net.T), dim3(256), 0, h->stream, sp.recs, h->C, h->net.P + h->net.F, h->net.T, idx, first, count, h->inv_n, h->net.loss_t, sh4, h->img.agg_a);
         HIPCHK(h, hipGetLastError());
         a.inv_n = h->inv_n;
     }
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
-    z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt;
+    z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt; z.agg_a = h->img.agg_a;
     a.p2p = h->p2p_on ? h->p2p_dev : nullptr;
     if (h->p2p_on) a.p2pv = h->p2p_host;
     a.p2p_seq = h->p2p_on ? ++h->p2p_seq : 0u;
@@ -1645,6 +1660,7 @@ int32_t eh_mech_loss_vjp(eh_handle* h, int64_t count, int64_t ld, const float* o
     int nblk = (int)((ntile + tiles - 1) / tiles);
     if (h->mech_blocks > 0 && nblk > h->mech_blocks) { nblk = h->mech_blocks; tiles = 0; }      // "mech_blocks" option: a capped, grid-striding launch
     a.tiles = tiles;
+    a.agg_a = h->img.agg_a;
     const int nfold = nblk <= 2048 ? 0 : std::min(64, (nblk + 511) / 512);      // workgroups of the fold kernel (512 rows and more each)
     const int rows_per = nfold ? (nblk + nfold - 1) / nfold : 0;
     const size_t ws_bytes = EH_MAX_TARG * sizeof(unsigned long long) + 64 + 64 + (size_t)(64 + EH_MECH_MAXROWS) * EH_MECH_PART * sizeof(float);
@@ -2002,7 +2018,7 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     int rc = check_window(h, sp, first, count, "eh_dp_grad");
     if (rc) return rc;
     if (h->net.T != 1) {      // the weights of the GLOBAL batch from the all-reduced sums; the step kernel then normalises exactly
-        hipLaunchKernelGGL(eh_weights_from_counts_kernel, dim3(1), dim3(64), 0, h->stream, h->tcount, h->net.T, h->net.loss_t, h->inv_n);
+        hipLaunchKernelGGL(eh_weights_from_counts_kernel, dim3(1), dim3(64), 0, h->stream, h->tcount, h->net.T, h->net.loss_t, h->inv_n, h->img.agg_a);
         HIPCHK(h, hipGetLastError());
         h->dp_weights = true;
     }
@@ -2024,7 +2040,7 @@ int32_t eh_dp_counts(eh_handle* h, int64_t first, int64_t count) {
     EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
     HIPCHK(h, hipMemsetAsync(h->tcount, 0, 3 * EH_MAX_TARG * sizeof(float), h->stream));
     hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, h->perm_valid ? h->perm : nullptr, first, count,
-                       h->inv_n, net.loss_t, sh4, h->tcount);
+                       h->inv_n, net.loss_t, sh4, h->img.agg_a, h->tcount);
     HIPCHK(h, hipGetLastError());
     h->tcount_ready = true;
     return EH_OK;

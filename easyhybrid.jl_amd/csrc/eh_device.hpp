@@ -91,7 +91,9 @@ __device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1
 // gradient (sum of 2 r dyhat, or of sign(r) dyhat for MAE) into the gradient of the loss
 // (src/losses/loss_fn.jl:58-86).  S = sum r^2 (sum |r| for MAE), n = valid count, Sy / Syy = shifted
 // target sums.  n == 0 -> scale 0, loss NaN: the batch is skipped (src/training/epoch.jl:17-19).
-__device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float Sy, float Syy, float& scale, float& loss) {
+// agg: the factor `agg` puts on the data loss -- 1 for sum, 1 / (T (1 + #extra terms)) for mean (eh_set_option "agg";
+// src/losses/compute_loss.jl:31-34,50-53) -- on the value and on the gradient alike.
+__device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float Sy, float Syy, float& scale, float& loss, float agg = 1.0f) {
     if (!(n > 0.0f)) { scale = 0.0f; loss = __builtin_nanf(""); return; }
     if (kind == EH_LOSS_RMSE) {
         loss = sqrtf(S / n);
@@ -104,6 +106,7 @@ __device__ __forceinline__ void eh_loss_finish(int kind, float S, float n, float
         scale = 1.0f / n;
         loss = S * scale;
     }
+    if (agg != 1.0f) { scale *= agg; loss *= agg; }
 }
 
 #define EH_GSHARDS 8   // gradient accumulators are sharded 8 ways (blockIdx & 7) to spread the float atomics
@@ -139,6 +142,7 @@ struct EhFused {
     int sc_sel;            // same for the beta products
     int pending;
     EhOpt opt;
+    float agg_a;           // factor of `agg` on the data loss (eh_loss_finish); multi-target steps carry it in their per-target weights
 };
 
 struct EhStepArgs {
@@ -867,7 +871,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         float inv = 0.0f, lossv = __builtin_nanf("");
         if (upd) {
             if (a.inv_n) { inv = 1.0f; lossv = f_sse; }      // multi-target: per-target weights from the counting pre-pass, the sums are final
-            else eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv);
+            else eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv, z.agg_a);
         }
         for (int idx = tid; idx < nth; idx += NTHR) {
             float th, mm, vv, gs = 0.0f;

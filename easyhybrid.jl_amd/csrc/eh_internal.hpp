@@ -35,6 +35,10 @@ struct EhImg {
     // extra loss = sum_i l2w[i] theta_i^2 (eh_set_weight_l2_coef); nullptr: the one-lambda form above
     const float* l2w;
     int n_theta;
+    // agg = mean (src/config/TrainingConfig.jl:76-77; compute_loss.jl:31-34,50-53): the training loss is
+    // mean([mean_t(L_t), extra terms...]) = agg_a * sum_t L_t + l2s * sum of the extra terms, agg_a = 1 / (T (1 + E)), l2s = 1 / (1 + E);
+    // agg = sum: both 1
+    float agg_a, l2s;
 };
 
 // --------------------------------------------------------------------------------------------
@@ -125,6 +129,7 @@ struct eh_handle_s {
     ncclComm_t comm = nullptr;      // eh_comm_init: the library's own RCCL communicator (data parallelism without a host-side collective library)
     int comm_world = 0, comm_rank = 0;
     struct EhLocalGroup* lgroup = nullptr;   // eh_comm_init_local: handles of ONE process exchange through peer-mapped device memory, no RCCL
+    int agg = 0, n_extra = 0;       // eh_set_option "agg" (0 = sum, 1 = mean) / "extra_terms" (entries the extra loss returns); img.agg_a / img.l2s follow
     EhOpt opt{};
     EhSplit split[2];
     float *slab = nullptr, *gradbuf = nullptr, *inv_n = nullptr, *loss_hist = nullptr;

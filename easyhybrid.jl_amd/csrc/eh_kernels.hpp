@@ -9,7 +9,7 @@
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool eh_is_weight(const EhImg& im, int idx) { return idx < im.g_off && (im.imap ? im.imap[idx] < im.b_off : im.wflag[idx] != 0); }
 // d(extra loss) / d theta_idx = 2 * this * theta_idx
-__device__ __forceinline__ float eh_l2_coef(const EhImg& im, int idx) { return im.l2w ? im.l2w[idx] : (eh_is_weight(im, idx) ? im.l2c : 0.0f); }
+__device__ __forceinline__ float eh_l2_coef(const EhImg& im, int idx) { return im.l2s * (im.l2w ? im.l2w[idx] : (eh_is_weight(im, idx) ? im.l2c : 0.0f)); }
 
 // the extra loss of the CURRENT parameters (before the optimiser kernel touches them): l2c * sum of squared Dense weights, or sum_i l2w[i] theta_i^2
 __global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, EhImg im, float* out) {
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void eh_weight_l2_kernel(const float* theta, E
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) *out = (im.l2w ? 1.0f : im.l2c) * ((red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) *out = im.l2s * (im.l2w ? 1.0f : im.l2c) * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __device__ __forceinline__ void eh_image_store(const EhImg& im, int idx, float th) {
@@ -65,6 +65,7 @@ struct EhMechArgs {
     int use_v;
     float* part;                             // [gridDim.x][EH_MECH_PART] partial sums
     const unsigned* prog;                    // EH_MECH_PROGRAM: the recorded closure (EhStepArgs::prog layout)
+    float agg_a;                             // factor of `agg` on the data loss (EhImg::agg_a)
     int tiles;                               // > 0: workgroup b owns the `tiles` consecutive 256 V-sample tiles from b * tiles (a front that moves through memory
                                              // with the dispatch order); 0: grid-stride trips (a capped grid)
 };
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void eh_mech_vjp_kernel(const EhNet net, EhMec
 #pragma unroll
     for (int t = 0; t < NTG; ++t) {
         const unsigned long long c = a.use_v ? a.counts_v[t] : a.counts[t];
-        w[t] = (t < net.T && c > 0) ? 1.0f / (float)c : 0.0f;
+        w[t] = (t < net.T && c > 0) ? a.agg_a / (float)c : 0.0f;
     }
     float gp[NP], S[NTG];
     const bool mae = net.loss == EH_LOSS_MAE;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(1024) void eh_mech_finish_kernel(const float* part,
     __shared__ float St[EH_MAX_TARG];
     if (k >= 8 && k < 12) {
         const unsigned long long c = a.use_v ? a.counts_v[k - 8] : a.counts[k - 8];
-        St[k - 8] = (k - 8 < net.T && c > 0) ? s / (float)c : 0.0f;
+        St[k - 8] = (k - 8 < net.T && c > 0) ? a.agg_a * s / (float)c : 0.0f;
     }
     else if (k < 8) out[1 + k] = (k < net.n_par && ((net.par_kind >> (2 * k)) & 3u) == EH_PAR_GLOBAL) ? s * meta[EH_IMG_DPHI + k] : 0.0f;
     EH_WAVE_SYNC();                                              // (the 16 threads left are lanes of one wave)
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void eh_reduce_kernel(const float* __restrict_
         if (t < EH_MAX_TARG) ntot += cnts[t];
     }
     float dscale = 1.0f, dloss = 0.0f;
-    if (deferred) eh_loss_finish(loss_kind, cnts[EH_MAX_TARG], cnts[0], cnts[EH_MAX_TARG + 1], cnts[EH_MAX_TARG + 2], dscale, dloss);
+    if (deferred) eh_loss_finish(loss_kind, cnts[EH_MAX_TARG], cnts[0], cnts[EH_MAX_TARG + 1], cnts[EH_MAX_TARG + 2], dscale, dloss, im.agg_a);
     if (deferred && mom && cnts[0] > 0.0f) { dscale = 1.0f; dloss = mom[7]; }      // moment-based loss: per-sample weights were exact, value from eh_moment_coef_kernel
     float tp_loss = 0.0f;                    // multi-target: the targets whose loss came out of the coefficient kernel (the others' terms are in the loss sum)
     if (!deferred && mom) {
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
         }
     }
     float inv = 0.0f, lossv = 0.0f;
-    if (T == 1) eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv);
+    if (T == 1) eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv, im.agg_a);
     else { inv = cnt > 0.0f ? 1.0f : 0.0f; lossv = cnt > 0.0f ? sse : __builtin_nanf(""); }      // multi-target: the step used exact per-target weights
     if (idx < n_theta && cnt > 0.0f) {
         float gs = gs_p2p;
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(64) void eh_moment_centre_kernel(const float* slab,
 // stage 1: moments with u = yhat - tt[1], w = y - shift  ->  tt[4..6] = k0, k1, k2 ; tt[7] = the target's loss value
 // (rmse, the one loss without batch moments here, takes this form on multi-target models, where its scale 1 / (n rmse) has to be
 // known inside the one streaming pass that serves all targets: d/dyhat_i = (yhat_i - y_i) / (n rmse), loss_fn.jl:58-60)
-__global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int T, unsigned loss_t, EhShift4 shift4, float* tt_all) {
+__global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, int nblk, int T, unsigned loss_t, EhShift4 shift4, float* tt_all, float agg_a) {
     __shared__ double tot[EH_EVAL_STATS];
     const int tid = threadIdx.x, t = blockIdx.x;
     const int kind = (int)((loss_t >> (4 * t)) & 15u);
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, i
         k1 = (float)qu; k2 = (float)qw; k0 = (float)(g_b - qu * mu - qw * mw);
         loss = (float)L;
     }
-    out[0] = 1.0f; out[4] = k0; out[5] = k1; out[6] = k2; out[7] = loss;
+    out[0] = 1.0f; out[4] = k0 * agg_a; out[5] = k1 * agg_a; out[6] = k2 * agg_a; out[7] = loss * agg_a;      // (agg_a: the factor of `agg` on the data loss, EhImg)
 }
 
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float cnt = gradbuf[n_theta + 1];
     float scale = 0.0f, lossv = 0.0f;
-    if (T == 1) eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv);
+    if (T == 1) eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv, im.agg_a);
     else {      // multi-target: the shards used the weights of the global batch (eh_dp_counts): the all-reduced sums are final
         for (int t = 1; t < T; ++t) cnt += gradbuf[n_theta + 1 + t];
         scale = cnt > 0.0f ? 1.0f : 0.0f;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
 // the residual terms of target t enter the loss as w_t r^2 (w_t |r| for MAE) with  w_t = 1 / n_t  for mse / mae  (loss_fn.jl:61-66)
 // and  w_t = 1 / sum (y - mean y)^2  for nseLoss (:79-81) -- all of it a function of the targets alone.  One workgroup per target.
 __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
-                                                       float* inv_n, unsigned loss_t, EhShift4 shift, float* raw = nullptr) {
+                                                       float* inv_n, unsigned loss_t, EhShift4 shift, float agg_a, float* raw = nullptr) {
     __shared__ float red[3][256];
     const int t = blockIdx.x;
     float c = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -671,17 +672,17 @@ __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C,
         if (raw) { raw[3 * t] = n; raw[3 * t + 1] = red[1][0]; raw[3 * t + 2] = red[2][0]; return; }      // data parallel: this shard's sums (EH_BUF_TCOUNT), all-reduced by the caller
         float w = n > 0.0f ? 1.0f / n : 0.0f;
         if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (red[2][0] - red[1][0] * red[1][0] / n);
-        inv_n[EH_TT * t] = w;                 // (the per-target table of EhStepArgs::inv_n, eh_device.hpp)
+        inv_n[EH_TT * t] = w * agg_a;         // (the per-target table of EhStepArgs::inv_n, eh_device.hpp; agg_a: the factor of `agg`, EhImg)
     }
 }
 // (data parallel) the all-reduced sums [n_t | sum (y - c) | sum (y - c)^2] of the GLOBAL batch -> the per-target weights; c is common to the ranks (eh_set_target_shift)
-__global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned loss_t, float* inv_n) {
+__global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned loss_t, float* inv_n, float agg_a) {
     const int t = threadIdx.x;
     if (t >= T) return;
     const float n = raw[3 * t];
     float w = n > 0.0f ? 1.0f / n : 0.0f;
     if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (raw[3 * t + 2] - raw[3 * t + 1] * raw[3 * t + 1] / n);
-    inv_n[EH_TT * t] = w;
+    inv_n[EH_TT * t] = w * agg_a;
 }
 
 // input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample

@@ -246,6 +246,14 @@ class HybridEngine:
         """extra_loss = lam * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91); lam = 0 switches it off"""
         self._chk(self._lib.eh_set_weight_l2(self._h, float(lam), int(bool(normalize))))
 
+    def set_agg(self, agg: str = "sum", n_extra_terms: int = 0):
+        """`agg` of the training configuration (TrainingConfig.jl:76-77): the training loss is agg([agg(per-target losses), extra loss
+        entries...]) (compute_loss.jl:31-34,50-53); "sum" or "mean".  n_extra_terms: the entries the extra loss returns (mean only)."""
+        if agg not in ("sum", "mean"):
+            raise NotImplementedError(f"agg {agg!r}: sum or mean")
+        self.set_option("extra_terms", int(n_extra_terms))
+        self.set_option("agg", 1 if agg == "mean" else 0)
+
     def set_weight_l2_coef(self, coef):
         """extra loss = sum_i coef[i] * theta_i^2 -- several weight_l2 terms folded into one coefficient per flat-theta entry
         (HybridModel.l2_coefficients); None / all zero switches it off"""

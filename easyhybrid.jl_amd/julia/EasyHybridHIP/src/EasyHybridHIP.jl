@@ -14,7 +14,7 @@ module EasyHybridHIP
 using Libdl
 using Random
 
-export PerTarget, set_training_loss!, set_weight_l2!, set_weight_l2_coef!, constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
+export PerTarget, set_training_loss!, set_agg!, set_weight_l2!, set_weight_l2_coef!, constructHybridModel, SingleNNHybridModel, MultiNNHybridModel, HybridModel, train, train!, HybridEngine, prepare_data, split_data, initialparameters,
     Adam, AdamW, RMSProp, Descent, RbQ10, Expo_resp_model,
     LinearHM, Expo2Pool, Rs_components, Rs_components3F, FluxPartModelQ10
 
@@ -408,6 +408,19 @@ function set_training_loss!(e::HybridEngine, spec)
 end
 set_option!(e::HybridEngine, name::Symbol, value::Integer) =
     check(e, @ccall LIB[].eh_set_option(e.h::Ptr{Cvoid}, String(name)::Cstring, value::Int64)::Int32)
+"""
+    set_agg!(e, agg; extra_terms = 0)
+
+`agg::Function` of the training configuration (`src/config/TrainingConfig.jl:76-77`): the training loss is `agg(per-target losses)`
+(`src/losses/compute_loss.jl:50-53`) and, with an extra loss, `agg([that, extra entries...])` (`:31-34`).  `sum` or `mean`
+(`Statistics.mean`); `extra_terms` = the entries the extra loss returns (only `mean` needs it).
+"""
+function set_agg!(e::HybridEngine, agg; extra_terms::Integer = 0)
+    name = Symbol(agg)
+    name in (:sum, :mean) || throw(ArgumentError("agg = $agg: the device implements sum and mean"))
+    set_option!(e, :extra_terms, extra_terms)
+    set_option!(e, :agg, name === :mean ? 1 : 0)
+end
 
 """
     set_weight_l2!(e, λ; normalize = false)
@@ -585,13 +598,13 @@ function mech_loss_vjp!(e::HybridEngine, o, forcings, targets, ∂o; n_valid = n
     return loss[], g[1:length(e.model.global_param_names)], nv[]
 end
 
-function evaluate(e::HybridEngine, split::Integer, n::Integer; loss_types = [:mse, :r2])
+function evaluate(e::HybridEngine, split::Integer, n::Integer; loss_types = [:mse, :r2], agg = sum)
     T = length(e.model.targets)
     m = Vector{EhTargetMetrics}(undef, T)
     check(e, @ccall LIB[].eh_eval(e.h::Ptr{Cvoid}, split::Int32, 0::Int64, n::Int64, m::Ptr{EhTargetMetrics}, C_NULL::Ptr{Ptr{Float32}}, C_NULL::Ptr{Ptr{Float32}})::Int32)
     return NamedTuple{Tuple(loss_types)}(map(loss_types) do lt
         per = [getfield(m[t], lt) for t in 1:T]
-        NamedTuple{(e.model.targets..., :sum)}((per..., sum(per)))
+        NamedTuple{(e.model.targets..., Symbol(agg))}((per..., Symbol(agg) === :mean ? sum(per) / length(per) : sum(per)))      # compute_loss.jl:55-66
     end)
 end
 function forward(e::HybridEngine, split::Integer, n::Integer)
@@ -733,7 +746,7 @@ best_loss)`.  `data`: a DataFrame or a NamedTuple / Dict of equally long columns
 """
 function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt = Adam(0.01f0), patience = typemax(Int),
         loss_types = [:mse, :r2], training_loss = :mse, random_seed = 161803, return_model = :best, split_data_at = 0.8,
-        shuffleobs = false, train_from = nothing, device = 0)
+        shuffleobs = false, train_from = nothing, device = 0, agg = sum)
     nepochs >= 0 || throw(ArgumentError("nepochs must be >= 0"))                               # validate_config, TrainingConfig.jl:162-180
     batchsize >= 1 || throw(ArgumentError("batchsize must be >= 1"))
     training_loss isa Function && throw(ArgumentError("this shim has no tracer for a custom loss function (the Python front door records one: program.trace_loss)"))
@@ -747,17 +760,19 @@ function train(m::SingleNNHybridModel, data; nepochs = 200, batchsize = 64, opt 
     set_data!(e, EH_SPLIT_TRAIN, xt, ft, yt); set_data!(e, EH_SPLIT_VAL, xv, fv, yv)
     opt_init!(e; rule = o.rule, eta = o.eta, beta = o.beta, epsilon = o.epsilon, lambda = o.lambda)
     set_training_loss!(e, training_loss)
+    set_agg!(e, agg)
+    aggn = Symbol(agg)
     nt, nv = size(xt, 2), size(xv, 2)
-    hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types)]
-    best_loss = hist_v[1][1].sum; best_ps = get_params(e); best_epoch = 0; counter = 0
+    hist_t = Any[evaluate(e, EH_SPLIT_TRAIN, nt; loss_types, agg)]; hist_v = Any[evaluate(e, EH_SPLIT_VAL, nv; loss_types, agg)]
+    best_loss = getfield(hist_v[1][1], aggn); best_ps = get_params(e); best_epoch = 0; counter = 0
     has_bn = get(m.config, :input_batchnorm, false) === true
     best_bn = has_bn ? get_bn_state(e, length(m.predictors)) : nothing                         # the running statistics belong to the epoch's model state
     better = first(loss_types) in (:pearson, :r2, :nse, :kge) ? (>) : (<)                       # loss_fn.jl:181-194
     seed0 = random_seed === nothing ? rand(rng, UInt32) : random_seed
     for epoch in 1:nepochs
         train_epoch!(e, batchsize; seed = seed0 + epoch, shuffle = true)
-        push!(hist_t, evaluate(e, EH_SPLIT_TRAIN, nt; loss_types)); push!(hist_v, evaluate(e, EH_SPLIT_VAL, nv; loss_types))
-        cur = hist_v[end][1].sum
+        push!(hist_t, evaluate(e, EH_SPLIT_TRAIN, nt; loss_types, agg)); push!(hist_v, evaluate(e, EH_SPLIT_VAL, nv; loss_types, agg))
+        cur = getfield(hist_v[end][1], aggn)
         if better(cur, best_loss)
             best_loss, best_ps, best_epoch, counter = cur, get_params(e), epoch, 0              # early_stopping.jl:16-42
             has_bn && (best_bn = get_bn_state(e, length(m.predictors)))

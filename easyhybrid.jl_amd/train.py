@@ -117,14 +117,28 @@ def _extra_terms(extra_loss) -> List[WeightL2]:
     raise NotImplementedError("extra_loss: an arbitrary closure cannot run on the device; WeightL2 terms (one, a list or a dict of them) are built")
 
 
-def _apply_extra_loss(eng, model, terms: List[WeightL2]):
+def _apply_extra_loss(eng, model, terms: List[WeightL2], agg: str = "sum"):
+    """the extra loss terms and `agg` (TrainingConfig.jl:76-77): the training loss is agg([agg(per-target losses), extra entries...])
+    (compute_loss.jl:31-34,50-53) -- the engine needs the number of extra entries for agg = mean"""
     if len(terms) == 1 and terms[0].net is None and terms[0].key == "weight":
         eng.set_weight_l2(terms[0].lam, terms[0].normalize)
     elif terms:
         eng.set_weight_l2_coef(model.l2_coefficients(terms))
+    eng.set_agg(agg, len(terms))
 
 
-def _extra_loss_values(model, theta, terms: List[WeightL2]) -> Dict[str, float]:
+def _agg_name(agg) -> str:
+    """TrainConfig.agg -> "sum" / "mean" (the two the device implements); the functions themselves are accepted like the reference's
+    `agg::Function` (sum, np.sum, np.mean, statistics.mean)"""
+    name = agg if isinstance(agg, str) else getattr(agg, "__name__", None)
+    if name in ("sum", "nansum", "fsum"):
+        return "sum"
+    if name in ("mean", "nanmean", "fmean", "average"):
+        return "mean"
+    raise NotImplementedError(f"agg {agg!r}: the device implements sum and mean (TrainingConfig.jl:76-77)")
+
+
+def _extra_loss_values(model, theta, terms: List[WeightL2], agg: str = "sum") -> Dict[str, float]:
     """the extra losses of flat parameters `theta` (host side, for the history; compute_loss.jl:39-44: each entry and their agg)"""
     th = np.asarray(theta, np.float64)
     out = {}
@@ -132,7 +146,8 @@ def _extra_loss_values(model, theta, terms: List[WeightL2]) -> Dict[str, float]:
         m = model.l2_mask(t.net, t.key)
         sq = float(np.sum(th[m] * th[m]))
         out[t.label()] = float(t.lam) * (sq / max(1, int(m.sum())) if t.normalize else sq)
-    out["sum"] = float(sum(out.values()))
+    vals = list(out.values())
+    out[agg] = float(sum(vals) / len(vals)) if (agg == "mean" and vals) else float(sum(vals))      # (; extra_loss_values..., Symbol(agg) => agg(...)), compute_loss.jl:42-44
     return out
 
 
@@ -144,7 +159,7 @@ class TrainConfig:
     patience: int = 2**62
     training_loss: Any = "mse"           # a name, or a function f(yhat, y) -> np.mean(per-sample terms) (loss_fn.jl: training_loss::Function)
     loss_types: List[str] = field(default_factory=lambda: ["mse", "r2"])
-    agg: str = "sum"
+    agg: Any = "sum"                     # TrainingConfig.jl:76-77 `agg::Function`: "sum" / "mean" (or the functions themselves)
     extra_loss: Any = None               # TrainingConfig.jl:74; None, a WeightL2 term, or a list / dict (name -> term) of them
     train_from: Any = None
     random_seed: Optional[int] = 161803
@@ -216,8 +231,7 @@ def validate_config(cfg: TrainConfig):                           # TrainingConfi
         if cfg.training_loss not in L.TRAINING_LOSSES:
             raise NotImplementedError(f"training_loss {cfg.training_loss!r}: the fused kernel implements {sorted(L.TRAINING_LOSSES)} "
                                       "or a function f(yhat, y) = mean of per-sample terms")
-    if cfg.agg != "sum":
-        raise NotImplementedError("agg: the fused kernel implements `sum` over targets (TrainingConfig.jl:77)")
+    _agg_name(cfg.agg)                    # sum or mean
     _extra_terms(cfg.extra_loss)          # (refuses what the device cannot run)
     for lt in cfg.loss_types:
         if lt not in _DEVICE_METRICS:
@@ -327,15 +341,16 @@ class TrainResults:                                                # TrainingCon
     best_loss: float
 
 
-def _losses(engine, split, targets, loss_types):
-    """(mse = (reco = .., sum = ..), r2 = (...)) as nested dicts; compute_loss.jl:55-66."""
+def _losses(engine, split, targets, loss_types, agg="sum"):
+    """(mse = (reco = .., sum = ..), r2 = (...)) as nested dicts, the aggregate under the name of `agg`; compute_loss.jl:55-66."""
     if engine.n_samples[split] == 0:
-        return {lt: {**{t: float("nan") for t in targets}, "sum": float("nan")} for lt in loss_types}
+        return {lt: {**{t: float("nan") for t in targets}, agg: float("nan")} for lt in loss_types}
     metrics, _ = engine.eval(split)
     out = {}
     for lt in loss_types:
         per = {t: metrics[i][lt] for i, t in enumerate(targets)}
-        per["sum"] = float(sum(per[t] for t in targets))
+        tot = float(sum(per[t] for t in targets))
+        per[agg] = tot / len(targets) if agg == "mean" else tot
         out[lt] = per
     return out
 
@@ -383,7 +398,8 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
         xterms = _extra_terms(tc.extra_loss)          # functions of the replicated parameters: every rank adds the same terms in eh_dp_apply
-        _apply_extra_loss(eng, model, xterms)
+        aggn = _agg_name(tc.agg)
+        _apply_extra_loss(eng, model, xterms, aggn)
         drv = DataParallel(eng, fused=tc.fused_update is not False, specialize=bool(tc.specialize))      # ("auto" compiles before the first step here: every rank has to be ready together)
         has_bn = bool(model.config.get("input_batchnorm"))
         first_lt = tc.loss_types[0]
@@ -393,16 +409,16 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
             ev.set_params(eng.get_params())
             if has_bn:
                 ev.set_bn_state(*eng.get_bn_state())
-            snap = EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
-                                 _losses(ev, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
+            snap = EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types, aggn),
+                                 _losses(ev, L.EH_SPLIT_VAL, model.targets, tc.loss_types, aggn))
             if xterms:
-                xv = _extra_loss_values(model, eng.get_params(), xterms)
+                xv = _extra_loss_values(model, eng.get_params(), xterms, aggn)
                 for d in (snap.l_train, snap.l_val):
                     d["extra_loss"] = dict(xv)
             return snap
         init = snapshot()
         history = [init]
-        best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0
+        best_loss, best_ps, best_epoch, counter = init.l_val[first_lt][aggn], theta.copy(), 0, 0
         best_bn = eng.get_bn_state() if has_bn else None            # early_stopping.jl update!: best_ps AND best_st
         seed0 = tc.random_seed if tc.random_seed is not None else 0
         b = -(-tc.batchsize // world)                 # samples per rank per step
@@ -416,7 +432,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
             snap = snapshot()
             if tc.keep_history:
                 history.append(snap)
-            cur = snap.l_val[first_lt]["sum"]
+            cur = snap.l_val[first_lt][aggn]
             if isbetter(cur, best_loss, first_lt):
                 best_loss, best_ps, best_epoch, counter = cur, eng.get_params(), epoch, 0
                 if has_bn:
@@ -485,21 +501,22 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         eng.opt_init(**_opt_args(tc.opt))
         eng.set_training_loss(tc.training_loss)
         xterms = _extra_terms(tc.extra_loss)
-        _apply_extra_loss(eng, model, xterms)
+        aggn = _agg_name(tc.agg)
+        _apply_extra_loss(eng, model, xterms, aggn)
         _apply_step_mode(eng, tc)
         first_lt = tc.loss_types[0]
 
         def snapshot():
-            snap = EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types),
-                                 _losses(eng, L.EH_SPLIT_VAL, model.targets, tc.loss_types))
+            snap = EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types, aggn),
+                                 _losses(eng, L.EH_SPLIT_VAL, model.targets, tc.loss_types, aggn))
             if xterms:                                   # compute_loss.jl:39-44: eval mode reports the extra losses next to the metrics
-                xv = _extra_loss_values(model, eng.get_params(), xterms)
+                xv = _extra_loss_values(model, eng.get_params(), xterms, aggn)
                 for d in (snap.l_train, snap.l_val):
                     d["extra_loss"] = dict(xv)
             return snap
         init = snapshot()
         history = [init]
-        best_loss, best_ps, best_epoch, counter = init.l_val[first_lt]["sum"], theta.copy(), 0, 0
+        best_loss, best_ps, best_epoch, counter = init.l_val[first_lt][aggn], theta.copy(), 0, 0
         has_bn = bool(model.config.get("input_batchnorm"))
         best_bn = eng.get_bn_state() if has_bn else None            # early_stopping.jl update!: best_ps AND best_st
         seed0 = tc.random_seed if tc.random_seed is not None else int(rng.integers(2**31))
@@ -508,7 +525,7 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
             snap = snapshot()                                                                  # evaluate_epoch
             if tc.keep_history:
                 history.append(snap)
-            cur = snap.l_val[first_lt]["sum"]
+            cur = snap.l_val[first_lt][aggn]
             if isbetter(cur, best_loss, first_lt):                                             # early_stopping.jl:16-42
                 best_loss, best_ps, best_epoch, counter = cur, eng.get_params(), epoch, 0
                 if has_bn:

@@ -669,7 +669,7 @@ def weight_l2_terms(spec: HybridSpec, theta, terms):
     return vals, g
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None):
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None, agg="sum"):
     """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
     (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
@@ -793,13 +793,22 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         gWs.reverse()
         gnets.append(gWs)
     grad = pack(spec, gnets, graw, dt)
-    if l2 is not None and sum(nvalid) > 0:            # extra_loss through agg = sum (compute_loss.jl:31-34)
+    # agg (TrainingConfig.jl:76-77): loss = agg(per-target losses) (compute_loss.jl:50-53); with an extra loss
+    # loss = agg([loss, extra entries...]) (compute_loss.jl:31-34).  sum or mean.
+    if agg not in ("sum", "mean"):
+        raise ValueError(f"agg {agg}")
+    if agg == "mean":
+        loss, grad = loss / dt.type(len(spec.targets)), grad / dt.type(len(spec.targets))
+    if l2 is not None and sum(nvalid) > 0:
         if isinstance(l2, list):                      # several terms: agg([loss_value, extra_loss_value...])
             lvs, lg = weight_l2_terms(spec, np.asarray(theta, dt), l2)
-            lv = sum(lvs)
+            lv, n_extra = sum(lvs), len(lvs)
         else:
             lv, lg = weight_l2(spec, np.asarray(theta, dt), *l2)
+            n_extra = 1
         loss, grad = loss + lv, grad + lg
+        if agg == "mean":
+            loss, grad = loss / dt.type(1 + n_extra), grad / dt.type(1 + n_extra)
     return loss, grad, nvalid
 
 
@@ -881,7 +890,7 @@ def adam_step(theta, grad, st, lr=0.01, b1=0.9, b2=0.999, eps=1e-8, weight_decay
 
 
 def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int, int]], lr=0.01, dtype=np.float32, kind="mse",
-                bn_state=None, l2=None):
+                bn_state=None, l2=None, agg="sum"):
     """Run Adam over contiguous batches [(first, count), ...]; all-masked batches are skipped
     (epoch.jl:17-19).  Returns (theta, [loss per batch]); with input_batchnorm `bn_state` (a dict
     from bn_init) is updated in place with the running statistics of every batch that ran."""
@@ -894,7 +903,7 @@ def train_steps(spec, theta0, X, forcings, targets, batches: Sequence[Tuple[int,
         if not any((~np.isnan(v)).any() for v in yb.values()):
             losses.append(float("nan"))          # isemptybatch: the step (and its state update) never runs
             continue
-        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()}, yb, dtype, kind, bn_state, l2)
+        l, g, nv = loss_and_grad(spec, theta, X[:, sl], {k: v[sl] for k, v in forcings.items()}, yb, dtype, kind, bn_state, l2, agg)
         if spec.input_batchnorm and bn_state is not None:
             _, new = batchnorm_input(np.asarray(X[:, sl], np.float64), bn_state, True, np.dtype(np.float64))
             bn_state.update(new)

@@ -9,6 +9,7 @@ spec, theta, X, f, y = tg._rs6_case(int(os.environ.get("EH_P", "32")), hidden, B
 eng = util.load_engine(spec, theta, X, f, y)
 eng.opt_init("Adam", 1e-3)
 if "EH_PRECISION" in os.environ: eng.set_option("precision", int(os.environ["EH_PRECISION"]))
+if "EH_SPECIALIZE" in os.environ: eng.set_option("specialize", int(os.environ["EH_SPECIALIZE"]))      # with EH_JIT_DEFINES=EH_STAMPS: the run-time specialised kernel, stamped
 if "EH_VARIANT" in os.environ: eng.set_option("variant", int(os.environ["EH_VARIANT"]))
 if "EH_ROW_SPLIT" in os.environ: eng.set_option("row_split", int(os.environ["EH_ROW_SPLIT"]))
 buf = (C.c_uint64 * 32)()
