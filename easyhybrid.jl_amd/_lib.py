@@ -16,7 +16,7 @@ EH_LOSS_PROGRAM = 7
 EH_OK, EH_EINVAL, EH_EHIP, EH_ENOMEM, EH_EUNSUPPORTED, EH_ESTATE, EH_ERCCL = 0, -1, -2, -3, -4, -5, -6
 EH_COMM_ID_BYTES = 128
 EH_SPLIT_TRAIN, EH_SPLIT_VAL = 0, 1
-EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT, EH_BUF_TCOUNT = 0, 1, 2, 3, 4, 5, 6
+EH_BUF_GRAD, EH_BUF_THETA, EH_BUF_OPT_M, EH_BUF_OPT_V, EH_BUF_GACC, EH_BUF_BNSTAT, EH_BUF_TCOUNT, EH_BUF_MOMENT = 0, 1, 2, 3, 4, 5, 6, 7
 
 ACTIVATIONS = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
 EH_ACT_PER_NET = 5        # MultiNN: net k uses net_activation[k]
@@ -107,6 +107,7 @@ SIGNATURES = {
     "eh_p2p_check_local": (C.c_int32, [C.POINTER(_H), C.c_int32, C.POINTER(C.c_int32)]),
     "eh_set_bn_shift": (C.c_int32, [_H, _F, C.c_int64]),
     "eh_dp_bn_stats": (C.c_int32, [_H, C.c_int64, C.c_int64]),
+    "eh_dp_moments": (C.c_int32, [_H, C.c_int64, C.c_int64, C.c_int32]),
     "eh_dp_fused_step": (C.c_int32, [_H, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "eh_device_buffer": (C.c_int32, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "eh_profile_enable": (C.c_int32, [_H, C.c_int32]),

@@ -560,6 +560,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     h->slab_rows = lform ? (int)EH_LFORM_ROWS : h->max_blocks;
     HIPCHK_C(hipMalloc(&h->slab, (std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) + 16) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
+    HIPCHK_C(hipMalloc(&h->mombuf, EH_MAX_TARG * EH_EVAL_STATS * sizeof(float)));
+    HIPCHK_C(hipMemset(h->mombuf, 0, EH_MAX_TARG * EH_EVAL_STATS * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->tcount, 3 * EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMemset(h->tcount, 0, 3 * EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMalloc(&h->inv_n, EH_TT * EH_MAX_TARG * sizeof(float)));      // the per-target table (EhStepArgs::inv_n): weight, centre of yhat, k0 k1 k2, loss of every target
@@ -635,7 +637,7 @@ int32_t eh_destroy(eh_handle* h) {
     eh_comm_release(h);             // communicator / local group / peer-to-peer mappings and buffers (eh_comm.hip)
     (void)hipSetDevice(h->device);
     (void)hipFree(h->pset);
-    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
+    (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->mombuf); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->l2w); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->l_lprog); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
@@ -1176,6 +1178,7 @@ static unsigned two_pass_mask(const EhNet& net) {
     }
     return m;
 }
+unsigned eh_two_pass_mask(const eh_handle* h) { return two_pass_mask(h->net); }
 // one training step's gradient sums into `rows` partial slab rows (the contract of the fused step kernels: eh_reduce_kernel follows)
 static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, int* rows_out, bool bn_update) {
     const EhNet& net = h->net;
@@ -1373,7 +1376,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
         HIPCHK(h, hipGetLastError());
     }
     const bool moment_loss = two_pass_mask(net) != 0;
-    if (moment_loss) {
+    if (moment_loss && !h->dp_moments) {      // (data-parallel step: eh_dp_grad has just made the coefficients from the moments of the GLOBAL batch)
         // forward-only passes (train-mode BatchNorm statistics included): the batch mean of yhat, then the moments of
         // (yhat, y) about the means -> the coefficients of the per-sample d loss / d yhat that the training pass multiplies
         // into the VJP
@@ -1496,7 +1499,7 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
 #define EH_REDUCE_GO(AP, ...)                                                                                                                       \
     hipLaunchKernelGGL((eh_reduce_kernel<AP, __VA_ARGS__>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
-                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, moment_loss ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)
+                       TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, (moment_loss && !raw) ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)
     if (apply) {
         if (tall4) EH_REDUCE_GO(true, 256, 4, true); else if (tall) EH_REDUCE_GO(true, 256); else if (big) EH_REDUCE_GO(true, 64); else EH_REDUCE_GO(true, 16);
         h->sc_sel ^= 1;
@@ -2009,7 +2012,8 @@ int32_t eh_dp_shuffle(eh_handle* h, uint64_t seed, int32_t on) {
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     if (!h) return EH_EINVAL;
     if (h->net.T != 1 && !h->tcount_ready) return fail(h, EH_ESTATE, "eh_dp_grad: multi-target model: call eh_dp_counts for this window and all-reduce EH_BUF_TCOUNT first");
-    if (two_pass_mask(h->net)) return fail(h, EH_EUNSUPPORTED, "eh_dp_grad: rmse (multi-target) / pearson / kge training losses need the statistics of the GLOBAL batch's predictions first (not built)");
+    const unsigned tpm_dp = two_pass_mask(h->net);
+    if (tpm_dp && h->mom_stage != 2) return fail(h, EH_ESTATE, "eh_dp_grad: rmse (multi-target) / pearson / kge training losses need the moments of the GLOBAL batch's predictions first: eh_dp_moments stage 0, all-reduce EH_BUF_MOMENT, stage 1, all-reduce");
     if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_grad: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
     h->bn_dp_update = h->bn_on;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2022,8 +2026,14 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
         HIPCHK(h, hipGetLastError());
         h->dp_weights = true;
     }
+    if (tpm_dp) {             // the all-reduced moments about the global centre -> k0 k1 k2 and the loss value of every two-pass target
+        EhShift4 s4; for (int t = 0; t < EH_MAX_TARG; ++t) s4.c[t] = sp.shift[t];
+        hipLaunchKernelGGL(eh_moment_coef_kernel, dim3(h->net.T), dim3(64), 0, h->stream, h->mombuf, 1, h->net.T, h->net.loss_t, s4, h->inv_n, h->img.agg_a);
+        HIPCHK(h, hipGetLastError());
+        h->dp_moments = true;
+    }
     rc = do_step(h, sp, h->perm_valid ? h->perm : nullptr, first, count, false, true, nullptr);
-    h->dp_weights = false; h->tcount_ready = false;
+    h->dp_weights = false; h->tcount_ready = false; h->dp_moments = false; h->mom_stage = 0;
     return rc;
 }
 
@@ -2043,6 +2053,50 @@ int32_t eh_dp_counts(eh_handle* h, int64_t first, int64_t count) {
                        h->inv_n, net.loss_t, sh4, h->img.agg_a, h->tcount);
     HIPCHK(h, hipGetLastError());
     h->tcount_ready = true;
+    return EH_OK;
+}
+
+// Two-pass training losses (pearsonLoss / kgeLoss / pbkgeLoss, rmse on a multi-target model; src/losses/loss_fn.jl:58-60,105-174)
+// under data parallelism: d loss / d yhat_i = k0 + k1 (yhat_i - centre) + k2 (y_i - c) with coefficients made of the moments of the
+// GLOBAL batch, so the shards exchange their moment sums twice ahead of the pass --
+//   stage 0: forward-only pass over the window, this shard's sums about the common shift c into EH_BUF_MOMENT
+//            ([T][EH_EVAL_STATS] floats: S, sum (y-c), sum (y-c)^2, n, sum (yhat-c), ...)          (caller: all-reduce)
+//   stage 1: centre of yhat = c + sum (yhat - c) / n of the global batch; forward-only pass about it, sums into EH_BUF_MOMENT (all-reduce)
+// -- and eh_dp_grad turns the all-reduced moments into the coefficients (same kernel as the single-GPU step) and runs the training
+// pass with them: the sums in EH_BUF_GRAD are final, as for multi-target models.  Fused kernel families only (the layer-wise form
+// keeps its statistics passes inside its own forward).
+int32_t eh_dp_moments(eh_handle* h, int64_t first, int64_t count, int32_t stage) {
+    if (!h) return EH_EINVAL;
+    const EhNet& net = h->net;
+    if (!two_pass_mask(net)) return fail(h, EH_ESTATE, "eh_dp_moments: the training loss needs no batch moments of the predictions");
+    if (h->lform) return fail(h, EH_EUNSUPPORTED, "eh_dp_moments: the layer-wise form has no data-parallel seam for the two-pass training losses");
+    if (stage != 0 && stage != 1) return fail(h, EH_EINVAL, "eh_dp_moments: stage %d (0 or 1)", stage);
+    if (stage == 1 && h->mom_stage != 1) return fail(h, EH_ESTATE, "eh_dp_moments: stage 1 follows stage 0 (and the all-reduce of EH_BUF_MOMENT)");
+    if (h->bn_on && !h->bn_ext) return fail(h, EH_ESTATE, "eh_dp_moments: input BatchNorm needs the global batch statistics: call eh_dp_bn_stats and all-reduce EH_BUF_BNSTAT first");
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    EhSplit& sp = h->split[EH_SPLIT_TRAIN];
+    if (int rc = check_window(h, sp, first, count, "eh_dp_moments")) return rc;
+    const int* idx = h->perm_valid ? h->perm : nullptr;
+    EhStepArgs e{};
+    e.prog = h->prog;
+    e.recs = sp.recs; e.C = h->C; e.idx = idx; e.first = first; e.count = count;
+    e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.stamps = nullptr;
+    e.yld = count;
+    for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
+    if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
+    EhShift4 s4; for (int t = 0; t < EH_MAX_TARG; ++t) s4.c[t] = sp.shift[t];
+    if (stage == 1) {        // the all-reduced sums about the shift -> the centre of yhat of the global batch
+        hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(net.T), dim3(64), 0, h->stream, h->mombuf, 1, net.T, net.loss_t, s4, h->inv_n);
+        HIPCHK(h, hipGetLastError());
+        e.inv_n = h->inv_n;
+    }
+    const int egrid = count > 0 ? grid_for(h, count) : 1;
+    if (count > 0) HIPCHK(h, step_launch(h, EH_MODE_EVAL, egrid, &e));
+    else HIPCHK(h, hipMemsetAsync(h->slab, 0, (size_t)EH_EVAL_STATS * net.T * sizeof(float), h->stream));      // an empty shard window adds nothing
+    hipLaunchKernelGGL(eh_moment_fold_kernel, dim3(1), dim3(64), 0, h->stream, h->slab, egrid, net.T, h->mombuf);
+    HIPCHK(h, hipGetLastError());
+    h->mom_stage = stage + 1;
     return EH_OK;
 }
 
@@ -2114,7 +2168,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
         HIPCHK(h, hipGetLastError());
     }
     hipLaunchKernelGGL(eh_apply_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->gradbuf, nt, TH(h), MM(h), VV(h), sc_in, sc_out, h->opt,
-                       h->loss_hist, h->img, h->net.loss, h->net.T, l2 ? h->l2val : nullptr);
+                       h->loss_hist, h->img, h->net.loss, h->net.T, l2 ? h->l2val : nullptr, two_pass_mask(h->net) ? h->inv_n : nullptr, two_pass_mask(h->net));
     HIPCHK(h, hipGetLastError());
     h->sc_sel ^= 1;
     if (loss_out) {
@@ -2126,7 +2180,7 @@ int32_t eh_dp_apply(eh_handle* h, float* loss_out) {
 
 int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n_floats) {
     if (!h || !dev_ptr || !n_floats) return EH_EINVAL;
-    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC && which != EH_BUF_BNSTAT && which != EH_BUF_TCOUNT) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
+    if (h->fused && which != EH_BUF_GRAD && which != EH_BUF_GACC && which != EH_BUF_BNSTAT && which != EH_BUF_TCOUNT && which != EH_BUF_MOMENT) return fail(h, EH_ESTATE, "eh_device_buffer: parameter buffers ping-pong in fused_update mode; switch it off first");
     switch (which) {
         case EH_BUF_GRAD: *dev_ptr = h->gradbuf; *n_floats = h->n_acc; return EH_OK;
         case EH_BUF_THETA: *dev_ptr = TH(h); *n_floats = h->net.n_theta; return EH_OK;
@@ -2137,6 +2191,7 @@ int32_t eh_device_buffer(eh_handle* h, int32_t which, void** dev_ptr, int64_t* n
             if (!h->bn_on) return fail(h, EH_ESTATE, "eh_device_buffer: the model has no input BatchNorm");
             *dev_ptr = h->bn_stat; *n_floats = 65; return EH_OK;
         case EH_BUF_TCOUNT: *dev_ptr = h->tcount; *n_floats = 3 * EH_MAX_TARG; return EH_OK;
+        case EH_BUF_MOMENT: *dev_ptr = h->mombuf; *n_floats = EH_MAX_TARG * EH_EVAL_STATS; return EH_OK;
         default: return fail(h, EH_EINVAL, "eh_device_buffer: which = %d", which);
     }
 }

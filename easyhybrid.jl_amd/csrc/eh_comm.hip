@@ -523,7 +523,8 @@ int32_t eh_dp_allreduce(eh_handle* h, int32_t which, int32_t index) {
             if (!h->bn_on) return fail(h, EH_ESTATE, "eh_dp_allreduce: the model has no input BatchNorm");
             buf = h->bn_stat; n = 65; break;
         case EH_BUF_TCOUNT: buf = h->tcount; n = 3 * EH_MAX_TARG; break;
-        default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT or EH_BUF_TCOUNT)", which);
+        case EH_BUF_MOMENT: buf = h->mombuf; n = EH_MAX_TARG * EH_EVAL_STATS; break;
+        default: return fail(h, EH_EINVAL, "eh_dp_allreduce: buffer %d (EH_BUF_GRAD, EH_BUF_GACC, EH_BUF_BNSTAT, EH_BUF_TCOUNT or EH_BUF_MOMENT)", which);
     }
     if (h->lgroup) {
         if (h->lgroup->n == 1) return EH_OK;               // a world of one: the sum is the buffer
@@ -550,6 +551,12 @@ int32_t eh_dp_train_step(eh_handle* h, int64_t first, int64_t count, float* loss
         int32_t k = 0;
         if ((rc = eh_dp_fused_step(h, first, count, &k))) return rc;
         return k >= 0 ? eh_dp_allreduce(h, EH_BUF_GACC, k) : EH_OK;
+    }
+    if (eh_two_pass_mask(h)) {           // the moments of the GLOBAL batch's predictions, two small exchanges ahead of the pass (eh_dp_moments)
+        for (int stage = 0; stage < 2; ++stage) {
+            if ((rc = eh_dp_moments(h, first, count, stage))) return rc;
+            if ((rc = eh_dp_allreduce(h, EH_BUF_MOMENT, 0))) return rc;
+        }
     }
     if (h->net.T != 1) {
         if ((rc = eh_dp_counts(h, first, count))) return rc;
@@ -600,6 +607,12 @@ int32_t eh_dp_train_step_group(eh_handle* const* hs, int32_t n, const int64_t* f
         if (loss_out) return fail(h0, EH_EINVAL, "eh_dp_train_step_group: fused_update mode reports no per-step loss (pass NULL)");
         for (int i = 0; i < n; ++i) if ((rc = eh_dp_fused_step(hs[i], first[i], count, &k[i]))) return rc;
         return k[0] >= 0 ? exchange(EH_BUF_GACC, true) : EH_OK;
+    }
+    if (eh_two_pass_mask(h0)) {
+        for (int stage = 0; stage < 2; ++stage) {
+            for (int i = 0; i < n; ++i) if ((rc = eh_dp_moments(hs[i], first[i], count, stage))) return rc;
+            if ((rc = exchange(EH_BUF_MOMENT, false))) return rc;
+        }
     }
     if (h0->net.T != 1) {
         for (int i = 0; i < n; ++i) if ((rc = eh_dp_counts(hs[i], first[i], count))) return rc;

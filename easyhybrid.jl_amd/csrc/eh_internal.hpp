@@ -108,6 +108,9 @@ struct eh_handle_s {
     float* bn_shift = nullptr;      // [32] common shift of the cross-GPU statistics (eh_set_bn_shift)
     float* bn_stat = nullptr;       // [65] sum d | sum d^2 | n of the current step, all-reduced by the host (EH_BUF_BNSTAT)
     float* tcount = nullptr;        // [EH_MAX_TARG][3] n_t | sum (y - c) | sum (y - c)^2 of the current step's shard, all-reduced by the caller (EH_BUF_TCOUNT)
+    float* mombuf = nullptr;        // [EH_MAX_TARG][EH_EVAL_STATS] this shard's moments of (yhat, y) of the current step (eh_dp_moments), all-reduced by the caller (EH_BUF_MOMENT)
+    int mom_stage = 0;              // eh_dp_moments: 0 = none, 1 = the sums about the shift are out, 2 = the sums about the global centre are out
+    bool dp_moments = false;        // the step being launched takes its two-pass coefficients from the all-reduced moments (no local statistics passes)
     bool dp_weights = false;        // the step being launched takes its per-target weights from the all-reduced sums (no local counting pass)
     bool tcount_ready = false;      // eh_dp_counts ran for the step eh_dp_grad is about to take
     bool bn_ext = false;            // bn_stat holds the statistics of the step about to run
@@ -191,6 +194,9 @@ int flush_pending(eh_handle* h);
         int rc_ = flush_pending(h);       \
         if (rc_) return rc_;              \
     } while (0)
+
+// bit t set: target t's training loss needs batch moments of the predictions ahead of the pass (two forward-only passes; eh_api.hip)
+unsigned eh_two_pass_mask(const eh_handle* h);
 
 // eh_destroy's share of eh_comm.hip: leave the communicator / local group, unmap the peers, free the exchange buffers
 void eh_comm_release(eh_handle* h);

@@ -620,17 +620,32 @@ __global__ __launch_bounds__(64) void eh_moment_coef_kernel(const float* slab, i
     out[0] = 1.0f; out[4] = k0 * agg_a; out[5] = k1 * agg_a; out[6] = k2 * agg_a; out[7] = loss * agg_a;      // (agg_a: the factor of `agg` on the data loss, EhImg)
 }
 
+// data parallel, two-pass losses (eh_dp_moments): this shard's per-workgroup moment rows [nblk][T][EH_EVAL_STATS] of a forward-only
+// pass -> one row [T][EH_EVAL_STATS] (EH_BUF_MOMENT), which the caller all-reduces
+__global__ __launch_bounds__(64) void eh_moment_fold_kernel(const float* slab, int nblk, int T, float* out) {
+    const int tid = threadIdx.x;
+    if (tid >= T * EH_EVAL_STATS) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)slab[b * T * EH_EVAL_STATS + tid];
+    out[tid] = (float)s;
+}
+
 // data-parallel tail: gradbuf holds the all-reduced RAW sums [grad | sse | count]
+// mom / tp_mask: the per-target table and the targets with a two-pass loss (their exact in-pass weights came from the all-reduced
+// moments of the GLOBAL batch, eh_dp_moments; their loss values sit in the table)
 __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_theta, float* theta, float* m, float* v, const float* sc_in,
-                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, int T, const float* l2val) {
+                                                       float* sc_out, EhOpt o, float* loss_slot, EhImg im, int loss_kind, int T, const float* l2val,
+                                                       const float* mom, unsigned tp_mask) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float cnt = gradbuf[n_theta + 1];
     float scale = 0.0f, lossv = 0.0f;
-    if (T == 1) eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv, im.agg_a);
+    if (T == 1 && !tp_mask) eh_loss_finish(loss_kind, gradbuf[n_theta], cnt, gradbuf[n_theta + 2], gradbuf[n_theta + 3], scale, lossv, im.agg_a);
     else {      // multi-target: the shards used the weights of the global batch (eh_dp_counts): the all-reduced sums are final
         for (int t = 1; t < T; ++t) cnt += gradbuf[n_theta + 1 + t];
         scale = cnt > 0.0f ? 1.0f : 0.0f;
         lossv = cnt > 0.0f ? gradbuf[n_theta] : __builtin_nanf("");
+        if (mom && cnt > 0.0f)
+            for (int t = 0; t < T; ++t) lossv += ((tp_mask >> t) & 1u) ? mom[EH_TT * t + 7] : 0.0f;
     }
     if (l2val && cnt > 0.0f) lossv += *l2val;                  // + lambda * weight_l2 of the (replicated) parameters: agg = sum([loss, extra...]), compute_loss.jl:31-34
     if (idx < n_theta && cnt > 0.0f) {

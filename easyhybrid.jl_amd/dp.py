@@ -140,6 +140,10 @@ class DataParallel:
         if self.multi:
             cptr, cn = engine.device_buffer(L.EH_BUF_TCOUNT)
             self.cbuf = torch.as_tensor(_DevArray(cptr, cn), device=dev)
+        # two-pass training losses (pearson / kge / pbkge; rmse on a multi-target model): the moments of the GLOBAL batch's predictions
+        # go round twice ahead of the pass (32 floats each: eh_dp_moments)
+        mptr, mn = engine.device_buffer(L.EH_BUF_MOMENT)
+        self.mbuf = torch.as_tensor(_DevArray(mptr, mn), device=dev)
         if specialize:
             engine.set_option("specialize", 1)
             self.prepare()
@@ -285,6 +289,10 @@ class DataParallel:
             if k >= 0:                                        # k < 0: the kernels exchange the sums themselves (p2p)
                 allreduce_partials(self.gacc[k], self.group)  # 8 shards x (n_theta + 2) raw sums
             return None
+        if self.engine.two_pass_loss:                         # moments of the GLOBAL batch's predictions: about the common shift, then about their global mean
+            for stage in (0, 1):
+                self.engine.dp_moments(first, count, stage)
+                allreduce_partials(self.mbuf, self.group)
         if self.multi:                                        # per-target normalisers of the GLOBAL batch ahead of the pass (12 floats)
             self.engine.dp_counts(first, count)
             allreduce_partials(self.cbuf, self.group)

@@ -221,14 +221,17 @@ class HybridEngine:
                     self._set_loss_program(n, target=t)          # every function its own program
             kinds = (C.c_int32 * len(name))(*[L.EH_LOSS_PROGRAM if callable(n) else L.TRAINING_LOSSES[n] for n in name])
             self._chk(self._lib.eh_set_target_losses(self._h, kinds, len(name)))
+            self._loss_kinds = ["program" if callable(n) else n for n in name]
             return
         if callable(name):
             self._set_loss_program(name)
             self.set_option("training_loss", L.EH_LOSS_PROGRAM)
+            self._loss_kinds = ["program"] * len(self.target_names)
             return
         if name not in L.TRAINING_LOSSES:
             raise NotImplementedError(f"training loss {name!r} is not implemented in the fused kernel (have {sorted(L.TRAINING_LOSSES)})")
         self.set_option("training_loss", L.TRAINING_LOSSES[name])
+        self._loss_kinds = [name] * len(self.target_names)
 
     def _set_loss_program(self, fn, target=None):
         """record f(yhat, y) = mean of per-sample terms (program.trace_loss) and hand it to the library: for every target
@@ -331,6 +334,18 @@ class HybridEngine:
     def dp_counts(self, first: int, count: int):
         """multi-target models: this shard's per-target sums of the window into EH_BUF_TCOUNT (all-reduce it, then dp_grad)"""
         self._chk(self._lib.eh_dp_counts(self._h, first, count))
+
+    def dp_moments(self, first: int, count: int, stage: int):
+        """two-pass training losses under data parallelism: this shard's moment sums of the window into EH_BUF_MOMENT -- stage 0 about
+        the common target shift, stage 1 (after the all-reduce) about the global mean of the predictions; all-reduce after each"""
+        self._chk(self._lib.eh_dp_moments(self._h, first, count, stage))
+
+    @property
+    def two_pass_loss(self) -> bool:
+        """the training loss of some target needs batch moments of the predictions ahead of the pass (pearson / kge / pbkge; rmse on a
+        multi-target model)"""
+        kinds = getattr(self, "_loss_kinds", None) or ["mse"] * len(self.target_names)
+        return any(k in ("pearsonLoss", "kgeLoss", "pbkgeLoss") or (k == "rmse" and len(kinds) > 1) for k in kinds)
 
     def set_target_shift(self, shift, split: int = L.EH_SPLIT_TRAIN):
         """common shift of the shifted target sums (every rank must pass the same vector, e.g. the global mean of each target)"""

@@ -549,6 +549,14 @@ end
 set_bn_state!(e::HybridEngine, m::Vector{Float32}, v::Vector{Float32}) =
     check(e, @ccall LIB[].eh_set_bn_state(e.h::Ptr{Cvoid}, m::Ptr{Float32}, v::Ptr{Float32}, length(m)::Int64)::Int32)
 
+"""
+two-pass training losses (pearsonLoss / kgeLoss / pbkgeLoss; rmse on a multi-target model) under DP: the shard's moment sums of the
+window into EH_BUF_MOMENT -- `stage = 0` about the common target shift, `stage = 1` (after the all-reduce) about the global mean of the
+predictions; all-reduce after each, then `dp_grad!` (`eh_dp_train_step` / `dp_train_step_group!` do all of it inside the library)
+"""
+dp_moments!(e::HybridEngine, first::Integer, count::Integer, stage::Integer) =
+    check(e, @ccall LIB[].eh_dp_moments(e.h::Ptr{Cvoid}, first::Int64, count::Int64, stage::Int32)::Int32)
+
 "input BatchNorm under DP: shard sums into EH_BUF_BNSTAT (all-reduce it before dp_grad! / dp_fused_step!)"
 set_bn_shift!(e::HybridEngine, c::Vector{Float32}) = check(e, @ccall LIB[].eh_set_bn_shift(e.h::Ptr{Cvoid}, c::Ptr{Float32}, length(c)::Int64)::Int32)
 dp_bn_stats!(e::HybridEngine, first::Integer, count::Integer) = check(e, @ccall LIB[].eh_dp_bn_stats(e.h::Ptr{Cvoid}, first::Int64, count::Int64)::Int32)

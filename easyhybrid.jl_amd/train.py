@@ -377,8 +377,6 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
     from .dp import DataParallel, shard_range
     if not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("train(distributed=True) needs an initialised torch.distributed process group (one rank per GPU)")
-    if tc.training_loss in ("pearsonLoss", "kgeLoss", "pbkgeLoss"):
-        raise NotImplementedError("distributed training: pearson / kge losses need the moments of the global batch before the backward pass (not built)")
     (xtr, ftr, ytr), (xva, fva, yva) = train_split, val_split
     world, rank = dist.get_world_size(), dist.get_rank()
     device = torch.cuda.current_device()

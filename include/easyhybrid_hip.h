@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define EH_ABI_VERSION 4      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group, eh_set_target_loss_program.
-                               * 4: eh_p2p_init_local, eh_p2p_check_local */
+                               * 4: eh_p2p_init_local, eh_p2p_check_local, eh_dp_moments */
 #define EH_MAX_HIDDEN 8       /* hidden layers: up to 3 run as ONE fused kernel per step, more (or widths above 128) layer by layer (csrc/eh_lform.hpp) */
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
@@ -115,7 +115,7 @@ typedef enum eh_opt_rule { EH_OPT_ADAM = 0, EH_OPT_ADAMW = 1, EH_OPT_RMSPROP = 2
  *   MSE mean(r^2) | RMSE sqrt(mean(r^2)) | MAE mean(|r|) | NSELOSS sum(r^2) / sum((y - mean(y))^2)      -- one pass;
  *   PEARSONLOSS 1 - cor | KGELOSS sqrt((r-1)^2 + (alpha-1)^2 + (beta-1)^2) | PBKGELOSS sqrt((r-1)^2 + (beta-1)^2)
  *   -- two passes: d loss / d yhat_i is affine in (yhat_i, y_i) with coefficients made of the batch moments, so a
- *   forward-only pass collects the moments first (no fused_update mode, no data-parallel seam for these).
+ *   forward-only pass collects the moments first (no fused_update mode; under data parallelism the moments go round first: eh_dp_moments).
  * Selected with eh_set_option(h, "training_loss", k) (TrainConfig.training_loss, src/config/TrainingConfig.jl:64; default MSE) */
 typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LOSS_NSELOSS = 3,
                        EH_LOSS_PEARSONLOSS = 4, EH_LOSS_KGELOSS = 5, EH_LOSS_PBKGELOSS = 6,
@@ -123,7 +123,8 @@ typedef enum eh_loss { EH_LOSS_MSE = 0, EH_LOSS_RMSE = 1, EH_LOSS_MAE = 2, EH_LO
 
 /* buffers a host may address directly on the device (data-parallel all-reduce over RCCL) */
 typedef enum eh_buffer { EH_BUF_GRAD = 0, EH_BUF_THETA = 1, EH_BUF_OPT_M = 2, EH_BUF_OPT_V = 3, EH_BUF_GACC = 4, EH_BUF_BNSTAT = 5,
-                         EH_BUF_TCOUNT = 6 /* [EH_MAX_TARG][3] per-target sums of the step's shard (eh_dp_counts) */ } eh_buffer;
+                         EH_BUF_TCOUNT = 6 /* [EH_MAX_TARG][3] per-target sums of the step's shard (eh_dp_counts) */,
+                         EH_BUF_MOMENT = 7 /* [EH_MAX_TARG][8] moment sums of (yhat, y) of the step's shard (eh_dp_moments) */ } eh_buffer;
 
 typedef struct eh_model_desc {
     int32_t struct_size;                     /* = sizeof(eh_model_desc) */
@@ -302,6 +303,14 @@ int32_t eh_eval(eh_handle* h, int32_t split, int64_t first, int64_t count, eh_ta
  * it (eh_set_target_shift, e.g. the global mean of each target); eh_set_data resets it to the shard's own means. */
 int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count);
 int32_t eh_dp_counts(eh_handle* h, int64_t first, int64_t count);
+/* Two-pass training losses (pearsonLoss / kgeLoss / pbkgeLoss, src/losses/loss_fn.jl:105-174; rmse on a multi-target model, :58-60):
+ * d loss / d yhat_i is affine in (yhat_i, y_i) with coefficients made of the moments of the GLOBAL batch, so a step starts with
+ *   eh_dp_moments(h, first, count, 0) -> this shard's sums about the common target shift in EH_BUF_MOMENT (host: all_reduce(SUM)),
+ *   eh_dp_moments(h, first, count, 1) -> the same about the global mean of yhat (host: all_reduce(SUM) again),
+ * then [eh_dp_counts + all-reduce for a multi-target model,] eh_dp_grad (which turns the all-reduced moments into the coefficients; the
+ * sums in EH_BUF_GRAD are then final), all-reduce, eh_dp_apply.  The shift must be common to the ranks (eh_set_target_shift).  Not
+ * for the layer-wise form (EH_EUNSUPPORTED).  (ABI 4) */
+int32_t eh_dp_moments(eh_handle* h, int64_t first, int64_t count, int32_t stage);
 int32_t eh_set_target_shift(eh_handle* h, int32_t split, const float* shift, int64_t n);
 int32_t eh_dp_apply(eh_handle* h, float* loss_out);
 /* per-shard epoch shuffle for the data-parallel calls (the reference shuffles the whole training set,

@@ -669,6 +669,70 @@ def weight_l2_terms(spec: HybridSpec, theta, terms):
     return vals, g
 
 
+def _backprop(spec, tp, dout, dt, B, dout_un=None, defer=None):
+    """d loss / d mechanistic outputs (`dout`: one (B,) seed per output) -> gradient wrt flat theta: the pullback through the
+    mechanistic model, the sigmoid scaling and the MLP(s).  dout_un / defer: the un-normalised seed and the
+    factor applied after the pass, for precision = "bf16" (HybridSpec.precision)."""
+    dout = dict(dout)
+    dout_un = dout_un or {}
+    defer = dt.type(1) if defer is None else defer
+    mm, _, vjp = MECH[spec.mech]
+    for oname in mm.outputs:
+        dout.setdefault(oname, np.zeros(B, dt))
+    dpar = vjp(tp["par"], tp["frc"], tp["out"], tp["aux"], dout, dt)
+    # globals: sum over samples, chain through the sigmoid scaling
+    graw = []
+    for g, r in zip(spec.glob, tp["raw"]):
+        s = _sigmoid(r.reshape(1))[0]
+        graw.append(np.sum(dpar[g]) * dt.type(spec.hi(g) - spec.lo(g)) * s * (1 - s))
+    # NN outputs
+    def nn_output_grads(dp):
+        do = np.zeros_like(tp["o"])
+        for k, n in enumerate(spec.neural):
+            d = np.broadcast_to(dp[n], (B,)).astype(dt)
+            if spec.scale_nn_outputs:
+                s = _sigmoid(tp["o"][k])
+                d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
+            do[k] = d
+        return do
+    do = nn_output_grads(dpar)
+    # precision = "bf16" rounds the deltas in the scale the step carries them (HybridSpec.precision): un-normalised for a one-target
+    # model with a one-pass loss -- the chain re-run from the un-normalised seed, as the engine forms it, not do / defer
+    bfb = spec.precision == "bf16"
+    deferred = bfb and len(spec.targets) == 1 and spec.targets[0] in dout_un
+    sc = defer if deferred else dt.type(1)
+    if deferred:
+        seeds = {oname: np.zeros(B, dt) for oname in mm.outputs}
+        seeds[spec.targets[0]] = dout_un[spec.targets[0]]
+        do = nn_output_grads(vjp(tp["par"], tp["frc"], tp["out"], tp["aux"], seeds, dt))
+    # MLP backward (each net sees the rows of dO that belong to its outputs)
+    gnets, k0 = [], 0
+    for k_net, (Ws, zs, hs) in enumerate(tp["nets"]):
+        kout = Ws[-1][0].shape[0]
+        delta = do[k0:k0 + kout]
+        k0 += kout
+        gWs = []
+        # bfb: bf16 operands in the backward products too -- the delta (un-normalised where `deferred`) is rounded where it enters them
+        for li in reversed(range(len(Ws))):
+            W, b = Ws[li]
+            dq = round_bf16(delta) if bfb else delta
+            gWs.append(((dq @ hs[li].T) * sc, delta.sum(axis=1) * sc))
+            if li > 0:
+                delta = (W.T @ dq) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
+        gWs.reverse()
+        gnets.append(gWs)
+    return pack(spec, gnets, graw, dt)
+
+
+def vjp_from_output_seed(spec, theta, X, forcings, seeds: Dict[str, np.ndarray], dtype=np.float64, bn_state=None):
+    """sum_i seeds[o][i] * d out_o[i] / d theta for given per-sample seeds on the mechanistic outputs (missing outputs: zero) -- the
+    pullback a data-parallel shard applies once the global batch statistics have fixed d loss / d yhat_i (tests/test_dp_gloo.py), and
+    what an extra loss of the predictions adds to the gradient"""
+    dt = np.dtype(dtype)
+    res = forward(spec, theta, X, forcings, dtype, keep=True, bn_state=bn_state, train_mode=True)
+    return _backprop(spec, res["_tape"], {k: np.asarray(v, dt) for k, v in seeds.items()}, dt, X.shape[1])
+
+
 def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None, agg="sum"):
     """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
@@ -747,52 +811,7 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
             else:
                 raise ValueError(f"training loss {kind}")
         dout[t] = d
-    mm, _, vjp = MECH[spec.mech]
-    for oname in mm.outputs:
-        dout.setdefault(oname, np.zeros(B, dt))
-    dpar = vjp(tp["par"], tp["frc"], tp["out"], tp["aux"], dout, dt)
-    # globals: sum over samples, chain through the sigmoid scaling
-    graw = []
-    for g, r in zip(spec.glob, tp["raw"]):
-        s = _sigmoid(r.reshape(1))[0]
-        graw.append(np.sum(dpar[g]) * dt.type(spec.hi(g) - spec.lo(g)) * s * (1 - s))
-    # NN outputs
-    def nn_output_grads(dp):
-        do = np.zeros_like(tp["o"])
-        for k, n in enumerate(spec.neural):
-            d = np.broadcast_to(dp[n], (B,)).astype(dt)
-            if spec.scale_nn_outputs:
-                s = _sigmoid(tp["o"][k])
-                d = d * dt.type(spec.hi(n) - spec.lo(n)) * s * (1 - s)
-            do[k] = d
-        return do
-    do = nn_output_grads(dpar)
-    # precision = "bf16" rounds the deltas in the scale the step carries them (HybridSpec.precision): un-normalised for a one-target
-    # model with a one-pass loss -- the chain re-run from the un-normalised seed, as the engine forms it, not do / defer
-    bfb = spec.precision == "bf16"
-    deferred = bfb and len(spec.targets) == 1 and spec.targets[0] in dout_un
-    sc = defer if deferred else dt.type(1)
-    if deferred:
-        seeds = {oname: np.zeros(B, dt) for oname in mm.outputs}
-        seeds[spec.targets[0]] = dout_un[spec.targets[0]]
-        do = nn_output_grads(vjp(tp["par"], tp["frc"], tp["out"], tp["aux"], seeds, dt))
-    # MLP backward (each net sees the rows of dO that belong to its outputs)
-    gnets, k0 = [], 0
-    for k_net, (Ws, zs, hs) in enumerate(tp["nets"]):
-        kout = Ws[-1][0].shape[0]
-        delta = do[k0:k0 + kout]
-        k0 += kout
-        gWs = []
-        # bfb: bf16 operands in the backward products too -- the delta (un-normalised where `deferred`) is rounded where it enters them
-        for li in reversed(range(len(Ws))):
-            W, b = Ws[li]
-            dq = round_bf16(delta) if bfb else delta
-            gWs.append(((dq @ hs[li].T) * sc, delta.sum(axis=1) * sc))
-            if li > 0:
-                delta = (W.T @ dq) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
-        gWs.reverse()
-        gnets.append(gWs)
-    grad = pack(spec, gnets, graw, dt)
+    grad = _backprop(spec, tp, dout, dt, B, dout_un, defer)
     # agg (TrainingConfig.jl:76-77): loss = agg(per-target losses) (compute_loss.jl:50-53); with an extra loss
     # loss = agg([loss, extra entries...]) (compute_loss.jl:31-34).  sum or mean.
     if agg not in ("sum", "mean"):

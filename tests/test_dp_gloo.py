@@ -188,3 +188,84 @@ def test_multi_target_protocol_counts_then_weighted_sums(kinds):
     for p in ps:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+# ----------------------------------------------------------------------------------------------
+# two-pass losses: the moments of the GLOBAL batch's predictions go round before the pass (eh_dp_moments)
+# ----------------------------------------------------------------------------------------------
+def _moment_sums(yh, yv, c, centre):
+    """what a shard's forward-only pass leaves per target (csrc/eh_device.hpp EH_EVAL_STATS): [S, sum (y-c), sum (y-c)^2, n,
+    sum (yhat-centre), sum (yhat-centre)^2, sum (yhat-centre)(y-c), sum |r|] over its valid samples"""
+    m = ~np.isnan(yv)
+    u, w, r = yh[m] - centre, yv[m] - c, yh[m] - yv[m]
+    return np.array([np.sum(r * r), w.sum(), (w * w).sum(), m.sum(), u.sum(), (u * u).sum(), (u * w).sum(), np.abs(r).sum()])
+
+
+def _coefficients(kind, tot, c, centre):
+    """the all-reduced moments about (centre, c) -> k0 k1 k2 of d loss / d yhat_i = k0 + k1 (yhat_i - centre) + k2 (y_i - c) and the
+    loss value: the arithmetic of eh_moment_coef_kernel (csrc/eh_kernels.hpp)"""
+    n, Sw, Sww, Su, Suu, Suw = tot[3], tot[1], tot[2], tot[4], tot[5], tot[6]
+    mu, mw = Su / n, Sw / n
+    Suu_c, Sww_c, Suw_c = Suu - Su * Su / n, Sww - Sw * Sw / n, Suw - Su * Sw / n
+    den = np.sqrt(Suu_c * Sww_c); r = Suw_c / den
+    a_u, a_w = -r / Suu_c, 1.0 / den
+    g_a = g_b = 0.0
+    if kind == "pearsonLoss":
+        L, g_r = 1.0 - r, -1.0
+    else:
+        alpha, beta = np.sqrt(Suu_c / Sww_c), (centre + mu) / (c + mw)
+        if kind == "kgeLoss":
+            L = np.sqrt((r - 1) ** 2 + (alpha - 1) ** 2 + (beta - 1) ** 2); g_a = (alpha - 1) / L / (alpha * Sww_c)
+        else:
+            L = np.sqrt((r - 1) ** 2 + (beta - 1) ** 2)
+        g_r = (r - 1) / L
+        g_b = (beta - 1) / L / (n * (c + mw))
+    qu, qw = g_r * a_u + g_a, g_r * a_w
+    return g_b - qu * mu - qw * mw, qu, qw, L
+
+
+def _mom_worker(rank, world, port, q, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = ho.rbq10_spec((16, 16), "tanh", True)
+    N = 301
+    X, f, y = ho.make_synth_rbq10(N, 3, 0.0)
+    X = X / 50
+    y["reco"][:100][::2] = np.nan                                 # all the gaps in rank 0's shard
+    theta = ho.init_theta(spec, 4, np.float64)
+    lo, hi = dp.shard_range(N, rank, world)
+    Xs, fs, ys = X[:, lo:hi], {k: v[lo:hi] for k, v in f.items()}, y["reco"][lo:hi].astype(np.float64)
+    tot = torch.tensor([np.nansum(ys), np.count_nonzero(~np.isnan(ys))], dtype=torch.float64)
+    dp.allreduce_partials(tot)
+    c = float(tot[0] / tot[1])                                    # the common shift (DataParallel.__init__)
+    yh = ho.forward(spec, theta, Xs, fs)["reco"]
+    # eh_dp_moments stage 0 -> all-reduce -> the centre of yhat of the GLOBAL batch; stage 1 -> all-reduce -> coefficients
+    m0 = torch.from_numpy(_moment_sums(yh, ys, c, c)); dp.allreduce_partials(m0)
+    centre = c + float(m0[4] / m0[3])
+    m1 = torch.from_numpy(_moment_sums(yh, ys, c, centre)); dp.allreduce_partials(m1)
+    k0, k1, k2, L = _coefficients(kind, m1.numpy(), c, centre)
+    # eh_dp_grad: this shard's sum of (d loss / d yhat_i) x d yhat_i / d theta -- the oracle's VJP seeded with the per-sample weights
+    valid = ~np.isnan(ys)
+    seed = np.where(valid, k0 + k1 * (yh - centre) + k2 * (np.where(valid, ys, 0.0) - c), 0.0)
+    g = ho.vjp_from_output_seed(spec, theta, Xs, fs, {"reco": seed})
+    buf = torch.from_numpy(g.copy()); dp.allreduce_partials(buf)
+    l0, g0, _ = ho.loss_and_grad(spec, theta, X, f, y, kind=kind)
+    ok = abs(L - l0) <= 1e-10 * abs(l0) and float(np.max(np.abs(buf.numpy() - g0))) <= 1e-9 * np.max(np.abs(g0))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["pearsonLoss", "kgeLoss", "pbkgeLoss"])
+def test_two_pass_protocol_moments_then_coefficients_then_sums(kind):
+    """the exchange eh_dp_moments / eh_dp_grad implement, with the oracle standing in for the kernels: two all-reduces of moment sums,
+    coefficients from the GLOBAL moments on every rank, then the all-reduced gradient sums are those of the whole batch"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_mom_worker, args=(r, world, port, q, kind)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

@@ -84,9 +84,9 @@ def test_one_process_peer_to_peer_group_of_eight_handles(world):
 
 
 def test_two_ranks_distributed_train_front_door():
-    # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm, and a two-target model with per-target losses
+    # train(model, data, distributed=True): shard + per-shard shuffle + replicated evaluation, with and without input BatchNorm, a two-target model with per-target losses, and a two-pass training loss (kgeLoss: the global moments go round ahead of every pass)
     lines = _run({"EH_MAX_BLOCKS": "64"}, 29563, tool="train_two_ranks.py")
-    assert len(lines) == 6 and all("results_identical_across_ranks=True" in l for l in lines), lines      # (single target +- BatchNorm, two targets) x two ranks
+    assert len(lines) == 8 and all("results_identical_across_ranks=True" in l for l in lines), lines      # (single target +- BatchNorm, two targets, kgeLoss) x two ranks
 
 
 @pytest.mark.parametrize("n", [2, 4])

@@ -64,6 +64,21 @@ v_d, v_r = out.val_history[-1]["mse"]["sum"], ref.val_history[-1]["mse"]["sum"]
 print(f"rank {rank}: two targets, PerTarget(mse, mae): val mse distributed {v_d:.5f} vs single-process {v_r:.5f}; "
       f"first-epoch {out.val_history[0]['mse']['sum']:.3f}; results_identical_across_ranks={same}", flush=True)
 ok = ok and same and v_d <= 1.25 * v_r + 1e-3 and v_d < 0.5 * out.val_history[0]["mse"]["sum"]
+# a two-pass training loss (kgeLoss): the moments of the GLOBAL batch's predictions go round twice ahead of every pass (eh_dp_moments)
+cols = eh.synthetic.make_synth_rbq10(12000, seed=9, nan_frac=0.05)
+cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+kw = dict(nepochs=5, batchsize=1024, opt=eh.Adam(0.01), loss_types=["kge", "mse"], training_loss="kgeLoss", random_seed=11)
+out = eh.train(model, cols, distributed=True, **kw)
+ref = eh.train(model, cols, distributed=False, **kw)
+t = torch.from_numpy(np.concatenate([out.ps, [out.best_loss], out.val_obs_pred["reco_pred"][:100]]).astype(np.float64))
+tl = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(tl, t)
+same = all(bool(torch.equal(tl[0], q)) for q in tl)
+k_d, k_r, k_0 = out.val_history[-1]["kge"]["sum"], ref.val_history[-1]["kge"]["sum"], out.val_history[0]["kge"]["sum"]
+print(f"rank {rank}: kgeLoss: val kge distributed {k_d:.4f} vs single-process {k_r:.4f}; first-epoch {k_0:.4f}; results_identical_across_ranks={same}", flush=True)
+ok = ok and same and k_d >= k_r - 0.05 and k_d > k_0 + 0.1
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
