@@ -167,14 +167,22 @@ def parity_replay(model, eng_factory, cols, X, B, nsteps=20):
         l_gpu, _, _ = eng.loss_and_grad(eh.EH_SPLIT_TRAIN, nsteps * B, B)
     finally:
         eng.close()
-    return {"steps": nsteps, "final_loss": l_gpu, "oracle_final_loss": l_ref, "rel_diff": abs(l_gpu - l_ref) / abs(l_ref),
-            "theta_max_abs_diff": float(np.max(np.abs(th - th_ref))), "theta_frac_within_1e-3": float(np.mean(np.abs(th - th_ref) <= 1e-3)),
+    # anchored in fp64: the same steps in the fp64 oracle are what both fp32 trajectories drift from
+    th64, _ = ho.train_steps(spec, theta0.astype(np.float64), X[:, :nsteps * B], {"ta": f["ta"][:nsteps * B]}, {"reco": y["reco"][:nsteps * B]},
+                             [(s * B, B) for s in range(nsteps)], dtype=np.float64)
+    l64, _, _ = ho.loss_and_grad(spec, th64, X[:, nsteps * B:n], {"ta": f["ta"][nsteps * B:]}, {"reco": y["reco"][nsteps * B:]})
+    return {"steps": nsteps, "final_loss": l_gpu, "oracle_final_loss": l_ref, "fp64_final_loss": float(l64),
+            "loss_distance_from_fp64": {"engine": abs(l_gpu - l64) / abs(l64), "c_fp32_port": abs(l_ref - l64) / abs(l64)},
+            "theta_max_distance_from_fp64": {"engine": float(np.max(np.abs(th - th64))), "c_fp32_port": float(np.max(np.abs(th_ref - th64)))},
+            "theta_mean_distance_from_fp64": {"engine": float(np.mean(np.abs(th - th64))), "c_fp32_port": float(np.mean(np.abs(th_ref - th64)))},
+            "rel_diff": abs(l_gpu - l_ref) / abs(l_ref),
             "step0": step0,
             "what": f"{nsteps} Adam steps from initialparameters(161803) on batches 0..{nsteps - 1} of the bench's own (un-scaled) dataset, then the "
-                    f"loss of batch {nsteps}: GPU engine (same kernel and mode as the timed run) vs oracle/eh_oracle.c (fp32, checker only).  Two fp32 "
-                    "trajectories: Adam's first steps are lr * sign-like, so a gradient entry near zero (saturated first-layer units at this input scale) "
-                    "turns rounding into a full step for that parameter -- the loss agrees to ~1e-4, single entries of theta may not; the one-step "
-                    "comparison `step0` is the parity statement"}
+                    f"loss of batch {nsteps}: GPU engine (same kernel and mode as the timed run), oracle/eh_oracle.c (fp32 port, checker only) and the fp64 "
+                    "oracle (oracle/hybrid_oracle.py), whose trajectory is the truth the two fp32 ones drift from -- the `*_distance_from_fp64` pairs say "
+                    "how far each got (Adam's first steps are lr * sign-like, so a gradient entry near zero -- saturated first-layer units at this input "
+                    "scale -- turns rounding into a full step for that parameter: single entries of theta part by up to nsteps * lr on EITHER fp32 side); "
+                    "the one-step comparison `step0` is the 1e-5 parity statement"}
 
 
 def main():

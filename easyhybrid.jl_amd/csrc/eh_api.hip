@@ -255,7 +255,7 @@ static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
         const int act = h->act, device = h->device;
         je->worker = std::thread([je, desc, act, device]() {
             (void)hipSetDevice(device);
-            const bool ok = eh_jit_build(desc, je->arch, je->variant, act, je->fast, &je->net, false, nullptr, &je->k, &je->log);
+            const bool ok = eh_jit_build(desc, je->arch, je->variant, act, je->fast, &je->net, false, nullptr, &je->k, &je->log, /*allow_slp*/ false);
             je->state.store(ok ? 1 : -1, std::memory_order_release);
         });
         return nullptr;
@@ -265,9 +265,72 @@ static eh_handle_s::JitEntry* jit_entry(eh_handle* h) {
     if (!ok) { h->jit_log = je->log; h->jit_failed = true; return nullptr; }
     return je;
 }
+// A kernel compiled at run time that merely REPLACES one built ahead of time (the "specialize" option on a registry model) is checked
+// against it before it takes over: both run the training pass on one window of the step's own data (no update, no state touched),
+// their partial sums are reduced, and loss sum, counts and un-normalised gradient must agree to 1e-5 of the gradient's largest
+// entry.  The two are the same source -- constants folded, dead branches gone -- but different binaries (hiprtc; the SLP vectoriser
+// on for the one-block shapes, which miscompiled a sibling group of kernels in round 2: a loss sum lost in a packed accumulator),
+// and the retry ladder of the build only catches compiler refusals, not silent miscompiles.  On disagreement the handle keeps the
+// kernels built ahead of time and says so in eh_jit_status.  ~100 us, once per compiled kernel.
+static int grid_for(const eh_handle* h, long long count);
+static bool jit_verify(eh_handle* h, eh_handle_s::JitEntry* je, const EhStepArgs* a) {
+    const EhNet& net = h->net;
+    EhStepArgs v = *a;
+    v.fz.gacc = nullptr;                         // the two-kernel form of the pass: one slab row per workgroup, nothing else written
+    v.count = std::min<long long>(a->count, 8192);
+    v.bn_update = 0; v.stamps = nullptr; v.slab = h->slab; v.n_acc = h->n_acc;
+    v.yhat = nullptr; v.pout = nullptr;
+    if (v.count <= 0) return true;
+    const int grid = grid_for(h, v.count);
+    const size_t nb = (size_t)h->n_acc * sizeof(float);
+    float* dev = nullptr;
+    if (hipMalloc(&dev, 2 * nb) != hipSuccess) { (void)hipGetLastError(); return true; }      // (cannot check: not a reason to refuse the kernel)
+    std::vector<float> host(2 * (size_t)h->n_acc);
+    float* sc = h->sc;                           // (read by nothing: APPLY = false)
+    bool launched = true;
+    for (int k = 0; k < 2 && launched; ++k) {
+        hipError_t e = k == 0 ? h->arch->var[h->variant].launch(EH_MODE_TRAIN, h->act, KFAST(h), grid, h->stream, &net, &v)
+                              : eh_jit_launch(&je->k, EH_MODE_TRAIN, grid, h->stream, &net, &v);
+        if (e != hipSuccess) { (void)hipGetLastError(); launched = false; break; }
+        hipLaunchKernelGGL((eh_reduce_kernel<false, 16>), dim3((h->n_acc + 15) / 16), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, 0,
+                           dev + (size_t)k * h->n_acc, TH(h), MM(h), VV(h), sc, sc, h->opt, (float*)nullptr, h->img, net.loss, (const float*)nullptr, (const float*)nullptr, 0u);
+        if (hipGetLastError() != hipSuccess) { launched = false; break; }
+    }
+    bool ok = true;
+    std::string why;
+    if (launched && hipMemcpyAsync(host.data(), dev, 2 * nb, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) {
+        const float* A = host.data(); const float* B = A + h->n_acc;
+        if (getenv("EH_DEBUG_JIT_SKEW")) host[(size_t)h->n_acc + net.n_theta] *= 1.01f;        // tests: the fall-back path without a second compiler run
+        double gmax = 0.0, dmax = 0.0;
+        for (int i = 0; i < net.n_theta; ++i) { gmax = std::max(gmax, (double)fabsf(A[i])); dmax = std::max(dmax, (double)fabsf(A[i] - B[i])); }
+        const double sa = A[net.n_theta], sb = B[net.n_theta];
+        bool counts = true;
+        for (int t = 0; t < net.T; ++t) counts = counts && A[net.n_theta + 1 + t] == B[net.n_theta + 1 + t];
+        const bool loss_ok = (std::isnan(sa) && std::isnan(sb)) || fabs(sa - sb) <= 1e-5 * fabs(sa) + 1e-30;      // (a window without a valid target: NaN on both sides)
+        if (!(dmax <= 1e-5 * gmax + 1e-30) || !loss_ok || !counts || !std::isfinite(gmax)) {
+            ok = false;
+            char b[320];
+            snprintf(b, sizeof b, "the kernel compiled at run time disagrees with the one built ahead of time on %lld samples of this model's data "
+                     "(gradient: max |difference| %.3g against a largest entry of %.3g; loss sum %.9g vs %.9g; valid counts %s): the handle keeps the kernels built ahead of time",
+                     v.count, dmax, gmax, sb, sa, counts ? "equal" : "DIFFERENT");
+            why = b;
+        }
+    } else (void)hipGetLastError();
+    (void)hipFree(dev);
+    if (!ok) { je->state.store(-1); h->jit_failed = true; h->jit_log = why; }
+    return ok;
+}
+
 static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
     if (jit_wanted(h, mode)) {
-        if (eh_handle_s::JitEntry* je = jit_entry(h)) {
+        eh_handle_s::JitEntry* je = jit_entry(h);
+        if (je && !je->verified && mode != EH_MODE_EVAL && !h->capturing && je->spec && h->net.mech != EH_MECH_PROGRAM && h->net.loss != EH_LOSS_PROGRAM &&
+            h->act != EH_ACT_PER_NET && !getenv("EH_JIT_NO_VERIFY")) {
+            bool has_lprog = false;
+            for (int t = 0; t < h->net.T; ++t) has_lprog = has_lprog || ((h->net.loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_PROGRAM;
+            if (has_lprog || jit_verify(h, je, a)) je->verified = true; else je = nullptr;
+        }
+        if (je) {
             const hipError_t e = eh_jit_launch(&je->k, mode, grid, h->stream, &h->net, a);
             if (e == hipSuccess) return e;
             (void)hipGetLastError();

@@ -144,7 +144,8 @@ struct eh_handle_s {
     unsigned* prog = nullptr;       // EH_MECH_PROGRAM: device copy of the program (EhStepArgs::prog layout)
     // EH_MECH_PROGRAM: kernels compiled at run time around the program (eh_jit.hpp), one entry per (kernel family, variant) used
     // state: 0 = being compiled by `worker` ("specialize" = 2: the steps run the kernels built ahead of time meanwhile), 1 = ready, -1 = failed
-    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; std::atomic<int> state{0}; EhJitKernel k; std::thread worker; std::string log; };
+    // verified: the kernel has been run next to the one built ahead of time on one window of the user's data and agreed (jit_verify, eh_api.hip)
+    struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; std::atomic<int> state{0}; EhJitKernel k; std::thread worker; std::string log; bool verified = false; };
     std::vector<std::unique_ptr<JitEntry>> jit;
     bool specialize_async = false;  // "specialize" = 2
     bool jit_on = true;             // "jit" option / EH_JIT=0: 0 = the interpreting kernels built ahead of time

@@ -314,7 +314,7 @@ static std::string eh_jit_rowact_source(const eh_model_desc& d) {
 // none: these models have no kernel built ahead of time.
 static thread_local int g_jit_level = 0;
 bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
-                  const EhLossProg* loss, EhJitKernel* out, std::string* log) {
+                  const EhLossProg* loss, EhJitKernel* out, std::string* log, bool allow_slp) {
     const EhVariant& V = A->var[variant];
     const bool prog = d.mech == EH_MECH_PROGRAM;
     const std::string mech = prog ? eh_jit_mech_source(d) : std::string();
@@ -372,7 +372,9 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     // whole suite and 3 600 fuzz configurations on them with the vectoriser on -- so their run-time kernels get it back; every
     // other shape, and everything built ahead of time, stays without.  EH_JIT_SLP=0 / 1 overrides (diagnostics).
     const char* const slp_env = getenv("EH_JIT_SLP");
-    const bool slp_on = g_jit_level == 0 && (slp_env ? atoi(slp_env) != 0 : (A->nbh == 1 && !A->wide));
+    // (allow_slp = false -- the background build of "specialize" = 2, whose kernel takes over from the one built ahead of time at a
+    //  timing-dependent step: same flags as that one, so the trajectory does not depend on when the switch happens; advisor, round 3)
+    const bool slp_on = g_jit_level == 0 && allow_slp && (slp_env ? atoi(slp_env) != 0 : (A->nbh == 1 && !A->wide));
     std::vector<std::string> extra;                  // EH_JIT_EXTRA_OPTS="-mllvm -foo ..." (diagnostics): appended to the compile options
     if (const char* xo = getenv("EH_JIT_EXTRA_OPTS")) {
         std::string x = xo;
@@ -427,7 +429,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
                 const std::string first = log->substr(0, 240);
                 const int saved = g_jit_level;
                 g_jit_level = next;
-                const bool ok2 = eh_jit_build(d, A, variant, act, fast, spec, with_p2p, loss, out, log);
+                const bool ok2 = eh_jit_build(d, A, variant, act, fast, spec, with_p2p, loss, out, log, allow_slp);
                 g_jit_level = saved;
                 if (ok2 && log->empty()) *log = std::string(next == 1 ? "(compiled with -fno-slp-vectorize" : "(compiled at -O1") + " after the first build failed: " + first + ")";
                 return ok2;

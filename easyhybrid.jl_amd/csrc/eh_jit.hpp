@@ -34,7 +34,9 @@ std::string eh_jit_loss_source(const EhLossProg& lp);
 std::string eh_jit_mech_source(const eh_model_desc& d);
 // Compiles the train + eval (+ cross-GPU train) kernels of (arch, variant, activation, fast-path flags); false + log on failure.
 // `spec` (optional) bakes the model descriptor into the kernels as a compile-time constant.
+// allow_slp = false: never the SLP vectoriser (the flags of the kernels built ahead of time: a kernel that REPLACES one of those in the
+// middle of a run -- "specialize" = 2 -- must give the same bits)
 bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int act, int fast, const EhNet* spec, bool with_p2p,
-                  const EhLossProg* loss, EhJitKernel* out, std::string* log);
+                  const EhLossProg* loss, EhJitKernel* out, std::string* log, bool allow_slp = true);
 hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
 void eh_jit_release(EhJitKernel* k);

@@ -13,6 +13,7 @@ The per-minibatch work (`run_epoch!`, src/training/epoch.jl:13-33) and the per-e
 from __future__ import annotations
 
 import copy
+import time
 from dataclasses import dataclass, field, replace
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -172,10 +173,11 @@ class TrainConfig:
     distributed: Optional[bool] = None
     # not in the reference -- how the device runs the step (DESIGN.md sections 3.8 and 6):
     #   specialize   "auto" (default): step kernels compiled at run time (hiprtc) with this model's descriptor as a compile-time
-    #                constant, in a background thread -- training starts on the kernels built ahead of time and switches when the
-    #                compiled one is ready (about a second; instant from the disk cache).  True: compile before the first step.
-    #                False: only the kernels built ahead of time.  The two binaries agree to ~1e-6, not bit for bit, and "auto"
-    #                switches at a timing-dependent step: bit-for-bit reproducible runs use True or False with fused_update = False.
+    #                constant -- before the first step when `random_seed` is set (a reproducible run: about a second the first time, instant
+    #                from the disk cache), in a background thread otherwise (training starts on the kernels built ahead of time and
+    #                switches when the compiled one is ready; the two binaries agree to ~1e-6, not bit for bit).  True: compile before the
+    #                first step.  False: only the kernels built ahead of time.  Every compiled kernel is checked against the one built
+    #                ahead of time on the first batch before it takes over (eh_jit_status says when it was refused).
     #   fused_update "auto" (default): one kernel per step where the model allows it (single target, per-wave kernel family, no
     #                weight_l2 / moment-based loss) -- the optimiser update of a step runs in the prologue of the next one and the
     #                partial sums meet through float atomics, so results are reproducible to ~1e-7, not bitwise.  False: the
@@ -183,6 +185,9 @@ class TrainConfig:
     # Both defaults are what bench.py measures.
     specialize: Any = "auto"
     fused_update: Any = "auto"
+    # not in the reference: True = TrainResults.timing splits the wall-clock of the epoch loop into training steps / evaluation passes /
+    # host bookkeeping (one extra device synchronisation per epoch, after the steps, so that the split is clean: bench.py `train_e2e`)
+    timing: bool = False
 
 
 @dataclass
@@ -204,7 +209,10 @@ def _apply_step_mode(eng, tc: "TrainConfig"):
         except (NotImplementedError, RuntimeError):
             if tc.fused_update is True:
                 raise
-    eng.set_option("specialize", 2 if tc.specialize == "auto" else int(bool(tc.specialize)))
+    # "auto": a run that asked for reproducibility (random_seed set -- the default, TrainingConfig.jl:86) compiles BEFORE the first step
+    # (about a second the first time, instant from the disk cache): the background build would switch binaries at a timing-dependent step,
+    # and the two agree to ~1e-6, not bit for bit (advisor, round 3).  Without a seed the build runs in the background.
+    eng.set_option("specialize", (1 if tc.random_seed is not None else 2) if tc.specialize == "auto" else int(bool(tc.specialize)))
 
 
 def validate_config(cfg: TrainConfig):                           # TrainingConfig.jl:162-185
@@ -339,6 +347,7 @@ class TrainResults:                                                # TrainingCon
     st: dict
     best_epoch: int
     best_loss: float
+    timing: Optional[dict] = None      # TrainConfig.timing: seconds of the epoch loop by part
 
 
 def _losses(engine, split, targets, loss_types, agg="sum"):
@@ -518,9 +527,18 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         has_bn = bool(model.config.get("input_batchnorm"))
         best_bn = eng.get_bn_state() if has_bn else None            # early_stopping.jl update!: best_ps AND best_st
         seed0 = tc.random_seed if tc.random_seed is not None else int(rng.integers(2**31))
+        tm = {"steps_s": 0.0, "eval_s": 0.0, "host_s": 0.0, "epochs": 0} if tc.timing else None
+        t_loop = time.perf_counter()
         for epoch in range(1, tc.nepochs + 1):
+            t0 = time.perf_counter()
             eng.train_epoch(tc.batchsize, seed=seed0 + epoch, shuffle=True, want_loss=False)      # run_epoch!
+            if tm is not None:
+                eng.synchronize()
+                t1 = time.perf_counter()
             snap = snapshot()                                                                  # evaluate_epoch
+            if tm is not None:
+                t2 = time.perf_counter()
+                tm["steps_s"] += t1 - t0; tm["eval_s"] += t2 - t1; tm["epochs"] += 1
             if tc.keep_history:
                 history.append(snap)
             cur = snap.l_val[first_lt][aggn]
@@ -534,6 +552,10 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
                 counter += 1
             if counter >= tc.patience:
                 break
+        if tm is not None:
+            eng.synchronize()
+            tm["loop_s"] = time.perf_counter() - t_loop
+            tm["host_s"] = tm["loop_s"] - tm["steps_s"] - tm["eval_s"]
         ps = best_ps if tc.return_model == "best" else eng.get_params()                        # best_or_final
         bn_out = (best_bn if tc.return_model == "best" else eng.get_bn_state()) if has_bn else None
         eng.set_params(ps)
@@ -554,7 +576,7 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         if has_bn:
             st["st_nn"] = {"running_mean": bn_out[0], "running_var": bn_out[1]}      # Lux BatchNorm state of the returned model (best_or_final)
         return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
-                            ps, st, best_epoch, best_loss)
+                            ps, st, best_epoch, best_loss, tm)
     finally:
         if own:
             eng.close()

@@ -131,6 +131,54 @@ def test_random_configuration_matches_the_oracle(seed, fastpath):
     eng.close()
 
 
+def _one_block_seeds(n, fastpath):
+    """the first n fuzz seeds whose model runs on a one-block shape of the per-wave family (every hidden width <= 16, side-by-side nets
+    included): the shapes whose run-time compiled kernels get the SLP vectoriser (csrc/eh_jit.hip)"""
+    out, seed = [], 0
+    while len(out) < n and seed < 20000:
+        spec = _case(seed, fastpath)[0]
+        widths = [sum(h[l] if l < len(h) else h[-1] for _, h in spec.nets) for l in range(max(len(h) for _, h in spec.nets))] if spec.nets else list(spec.hidden)
+        if max(widths) <= 16:
+            out.append(seed)
+        seed += 1
+    return out
+
+
+@pytest.mark.parametrize("fastpath,seed", [(fp, s) for fp in (False, True) for s in _one_block_seeds(30, fp)])
+def test_one_block_shapes_on_run_time_specialised_kernels(seed, fastpath):
+    """the run-time kernels of the one-block shapes (NBH = 1) are built with the SLP vectoriser ON -- the pass that
+    miscompiled a sibling group of kernels in round 2 -- so a slice of the fuzz runs on them in every suite run: 60 configurations
+    with "specialize" = 1, loss and gradient against the oracle, and the library's own cross-check against the kernel built ahead of
+    time (jit_verify) must have passed (the kernel is in use, nothing in the log)."""
+    spec, theta, X, f, y, kind, first, B, rng = _case(seed, fastpath)
+    sl = slice(first, first + B)
+    yb = {k: v[sl] for k, v in y.items()}
+    if kind in ("kgeLoss", "pearsonLoss", "nseLoss"):
+        kind = "mse"                                              # (tiny batches: their statistics are the first test's business)
+    eng = util.load_engine(spec, theta, X, f, y)
+    if kind != "mse":
+        eng.set_training_loss(kind)
+    eng.set_option("specialize", 1)
+    loss, grad, nv = eng.loss_and_grad(first=first, count=B)
+    njit, jlog = eng.jit_status()
+    assert njit >= 1 and "disagrees" not in jlog, jlog[:400]
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind,
+                                   bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+    assert nv == sum(nv0)
+    if sum(nv0) == 0:
+        assert np.isnan(loss) and not grad.any()
+    else:
+        yscale = float(np.nanmax(np.abs(np.concatenate(list(yb.values())))))
+        assert loss == pytest.approx(l0, rel=1e-5, abs=1e-5 * yscale * (yscale if kind == "mse" else 1.0)), (kind, spec)
+        if np.max(np.abs(g0)) > 1e-7 * max(1.0, abs(l0)):
+            err = util.relerr(grad, g0)
+            if err > 1e-5:
+                _, g32, _ = ho.loss_and_grad(spec, theta.astype(np.float32), X[:, sl], {k: v[sl] for k, v in f.items()}, yb, kind=kind, dtype=np.float32,
+                                             bn_state=ho.bn_init(spec) if spec.input_batchnorm else None)
+                assert err <= max(1e-5, 4.0 * util.relerr(g32, g0)), (kind, spec, err, util.relerr(g32, g0))
+    eng.close()
+
+
 @pytest.mark.parametrize("fastpath", [False, True])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EH_FUZZ_N", "60")) // 3))
 def test_random_configuration_at_the_raw_input_scale(seed, fastpath):

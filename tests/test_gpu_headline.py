@@ -82,11 +82,23 @@ def test_twenty_adam_steps_on_the_bench_inputs_follow_the_c_oracle(bench_case, f
     # (Adam's steps are sign-like while the moments are young: a rounding-level difference in a near-zero gradient entry moves
     # that parameter by up to lr per step; such entries do not move the loss)
     d = np.abs(th - th_ref)
-    assert np.mean(d <= 2e-5) >= 0.97 and d.max() <= nsteps * 0.01 * 1.01, (float(np.mean(d <= 2e-5)), float(d.max()))
-    assert abs(l_gpu - l_ref) <= 1e-4 * abs(l_ref), (l_gpu, l_ref)
+    assert np.mean(d <= 2e-5) >= 0.999 and d.max() <= 1e-4, (float(np.mean(d <= 2e-5)), float(d.max()))
+    assert abs(l_gpu - l_ref) <= 1e-5 * abs(l_ref), (l_gpu, l_ref)
     # and the fp64 oracle agrees on the loss of the next batch at the parameters the GPU reached
     l64, _, _ = ho.loss_and_grad(spec, th.astype(np.float64), *_slice(X, f, y, nsteps * B, B))
     assert abs(l_gpu - l64) <= 1e-5 * abs(l64)
+    # Anchored in fp64: the same 20 steps in the fp64 oracle are the truth both fp32 trajectories drift from;
+    # the engine must not drift further from it than twice what the plain-C fp32 port (the reference's arithmetic) does
+    th64, _ = ho.train_steps(spec, theta.astype(np.float64), Xs, fs, ys, [(s * B, B) for s in range(nsteps)], dtype=np.float64)
+    l64t, _, _ = ho.loss_and_grad(spec, th64, *_slice(X, f, y, nsteps * B, B))
+    d_gpu, d_c = np.abs(th - th64), np.abs(th_ref - th64)
+    print(f"fused {fused} specialize {specialize}: |theta - theta_fp64|: engine max {d_gpu.max():.3e} mean {d_gpu.mean():.3e}; C fp32 port max {d_c.max():.3e} mean {d_c.mean():.3e}; "
+          f"loss distance engine {abs(l_gpu - l64t) / abs(l64t):.2e}, C port {abs(l_ref - l64t) / abs(l64t):.2e}")
+    # (measured, round 4: engine max 6.3e-6 / mean 1.5e-7 against the C port's 1.0e-6 / 1.1e-7 -- before the device tanh returned
+    #  exactly +-1 beyond x^2 = 66 like NNlib.tanh_fast it was 3.8e-2 / 4.5e-4.  The slack on the maximum is 1e-3 of what ONE sign-like
+    #  Adam step moves a parameter: float-atomic accumulation order in the one-kernel mode, fast reciprocals)
+    assert d_gpu.max() <= 2.0 * d_c.max() + 1e-5 and d_gpu.mean() <= 2.0 * d_c.mean() + 1e-7, (d_gpu.max(), d_c.max(), d_gpu.mean(), d_c.mean())
+    assert abs(l_gpu - l64t) <= 2.0 * abs(l_ref - l64t) + 1e-5 * abs(l64t), (l_gpu, l_ref, l64t)
 
 
 def test_shuffled_epoch_on_the_bench_inputs_visits_every_sample_once(bench_case):
@@ -125,3 +137,63 @@ def test_run_time_specialised_kernel_agrees_with_the_one_built_ahead_of_time(ben
     (l0, g0, ls0, t0), (l1, g1, ls1, t1), (l2, g2, ls2, t2) = res
     assert abs(l0 - l1) <= 1e-6 * abs(l0) and util.relerr(g1, g0) <= 1e-6 and np.allclose(ls0, ls1, rtol=1e-6) and np.max(np.abs(t0 - t1)) <= 1e-6
     assert l1 == l2 and np.array_equal(g1, g2) and ls1 == ls2 and np.array_equal(t1, t2)      # the same binary twice: bit for bit
+
+
+def test_a_run_time_kernel_that_disagrees_is_not_used(bench_case, monkeypatch):
+    """the library runs every kernel it compiled at run time next to the one built ahead of time on one window of the step's own data
+    before it lets it take over (jit_verify, csrc/eh_api.hip).  Here the run-time build is made WRONG on purpose
+    (EH_JIT_DEFINES=EH_TEST_SKEW: its tanh is 0.1 % off -- a binary that compiles, launches and computes something else, what a
+    silent miscompile looks like): the handle must keep the kernels built ahead of time, say so in eh_jit_status, and train exactly
+    like a handle that never asked for a run-time kernel."""
+    model, spec, theta, X, f, y = bench_case
+    n = 4 * 4096
+    ref = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 0)
+    ref.opt_init("Adam", 0.01)
+    monkeypatch.setenv("EH_JIT_DEFINES", "EH_TEST_SKEW")
+    eng = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 1)
+    eng.opt_init("Adam", 0.01)
+    la = [ref.train_step(s * 4096, 4096) for s in range(4)]
+    lb = [eng.train_step(s * 4096, 4096) for s in range(4)]
+    njit, jlog = eng.jit_status()
+    assert njit == 0 and "disagrees with the one built ahead of time" in jlog, (njit, jlog[:300])
+    assert la == lb and np.array_equal(ref.get_params(), eng.get_params())
+    eng.close()
+    # without the check the skewed kernel WOULD have been used (the hook really builds a different kernel)
+    monkeypatch.setenv("EH_JIT_NO_VERIFY", "1")
+    bad = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 1)
+    bad.opt_init("Adam", 0.01)
+    lc = [bad.train_step(s * 4096, 4096) for s in range(4)]
+    assert bad.jit_status()[0] >= 1 and abs(lc[0] - la[0]) > 1e-5 * abs(la[0])
+    bad.close(); ref.close()
+
+
+def test_the_background_build_switches_within_rounding_and_seeded_training_is_reproducible(bench_case):
+    """"specialize" = 2: the steps start on the kernels built ahead of time and switch to the run-time specialised one whenever its
+    background build is done -- a timing-dependent step.  That build takes the flags of the kernels built ahead of time (no SLP
+    vectoriser), but it is still another binary (constants folded: other multiply-add pairings), so a trajectory with the switch in
+    the middle agrees with one without to rounding (1e-6 over six Adam steps), not bit for bit.  Which is why train() compiles BEFORE
+    the first step whenever a random_seed is set (advisor, round 3): two seeded runs of the default configuration are bit-identical."""
+    import time
+    model, spec, theta, X, f, y = bench_case
+    n = 8 * 4096
+    res = []
+    for specialize in (0, 2):
+        eng = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 0)
+        eng.set_option("specialize", specialize)
+        eng.opt_init("Adam", 0.01)
+        losses = [eng.train_step(s * 4096, 4096) for s in range(3)]          # (specialize = 2: these run the kernels built ahead of time while the build goes on)
+        if specialize:
+            t0 = time.time()
+            while eng.jit_status()[0] == 0 and time.time() - t0 < 120:       # ... wait for the build, then the next step switches
+                time.sleep(0.2)
+                eng.loss_and_grad(eh.EH_SPLIT_TRAIN, 0, 64)
+            assert eng.jit_status()[0] >= 1, eng.jit_status()[1][:300]
+        losses += [eng.train_step(s * 4096, 4096) for s in range(3, 6)]
+        res.append((losses, eng.get_params()))
+        eng.close()
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-6) and np.max(np.abs(res[0][1] - res[1][1])) <= 1e-6
+    cols = make_synth_rbq10(20000, seed=5, nan_frac=0.05)
+    cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    kw = dict(nepochs=3, batchsize=512, opt=eh.Adam(0.01), random_seed=11, fused_update=False)
+    a, b = eh.train(model, cols, **kw), eh.train(model, cols, **kw)
+    assert np.array_equal(a.ps, b.ps) and a.best_loss == b.best_loss and a.val_history == b.val_history
