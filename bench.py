@@ -136,7 +136,65 @@ def cpu_baseline(batch, seconds=12.0):
                         "sample": f"8 steps of batch {batch}, torch {torch.__version__} CPU eager autograd + torch.optim.Adam (oracle/torch_twin.py), best of 8 / 32 / 64 threads"}
     except Exception as e:
         out["eager"] = {"error": repr(e)}
+    # the primary figure is the FASTER of the two ports; the other one stays beside it
+    if "value" in out.get("eager", {}) and out["eager"]["value"] > out["value"]:
+        c_port = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step")}
+        eager = out.pop("eager")
+        out.update(eager)
+        out["c_port"] = c_port
+        out["which"] = "PyTorch-CPU eager (the faster of the two CPU ports on this host); the plain-C OpenMP port under c_port"
+    else:
+        out["which"] = "plain-C OpenMP port (the faster of the two CPU ports on this host); PyTorch-CPU eager under eager"
+    # BASELINE.json configs[0]: "batch = 1024, CPU reference path" (B = 1 024 and 65 536, >= 50 steps, median / p10 / p90)
+    try:
+        out["c1_batch_1024"] = cpu_baseline_c1(spec, theta, X, f, y, avail)
+    except Exception as e:
+        out["c1_batch_1024"] = {"error": repr(e)}
     return out
+
+
+def cpu_baseline_c1(spec, theta, X, f, y, avail, batch=1024, nsteps=60):
+    """configs[0] on the host cores: `nsteps` single Adam steps of batch 1 024 per port, per-step wall time -> median / p10 / p90"""
+    from oracle import c_oracle as co
+    res = {"batch": batch, "steps": nsteps}
+
+    def stats(ts):
+        ts = np.sort(np.asarray(ts))
+        return {"median_ms": 1e3 * float(np.median(ts)), "p10_ms": 1e3 * float(ts[int(0.1 * (len(ts) - 1))]), "p90_ms": 1e3 * float(ts[int(0.9 * (len(ts) - 1))]),
+                "samples_per_s_at_median": batch / float(np.median(ts))}
+    best = None
+    for nt in sorted({min(avail, k) for k in (1, 4, 8, 16, 32)}):            # (1 024 samples: few threads win)
+        for _ in range(5):
+            co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt)
+        ts = []
+        for _ in range(nsteps):
+            t0 = time.perf_counter(); co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt); ts.append(time.perf_counter() - t0)
+        st = stats(ts)
+        if best is None or st["median_ms"] < best[1]["median_ms"]:
+            best = (nt, st)
+    res["c_port"] = {**best[1], "cores": best[0], "kind": "port", "what": "plain-C oracle port, one Adam step per call (fastest thread count of 1 / 4 / 8 / 16 / 32)"}
+    try:
+        import torch
+        from oracle import torch_twin as tt
+        Xb = torch.as_tensor(X[:, :batch]); fb = {k: torch.as_tensor(v[:batch]) for k, v in f.items()}; yb = {k: torch.as_tensor(v[:batch]) for k, v in y.items()}
+        beste = None
+        for nt in sorted({min(avail, k) for k in (1, 4, 8)}):
+            torch.set_num_threads(nt)
+            th = torch.tensor(np.asarray(theta, np.float32), requires_grad=True)
+            opt = torch.optim.Adam([th], lr=0.01)
+            ts = []
+            for i in range(nsteps + 5):
+                t0 = time.perf_counter()
+                opt.zero_grad(); tt.loss(spec, th, Xb, fb, yb).backward(); opt.step()
+                if i >= 5:
+                    ts.append(time.perf_counter() - t0)
+            st = stats(ts)
+            if beste is None or st["median_ms"] < beste[1]["median_ms"]:
+                beste = (nt, st)
+        res["eager"] = {**beste[1], "cores": beste[0], "kind": "port", "what": f"torch {torch.__version__} CPU eager autograd + Adam (fastest of 1 / 4 / 8 threads)"}
+    except Exception as e:
+        res["eager"] = {"error": repr(e)}
+    return res
 
 
 def parity_replay(model, eng_factory, cols, X, B, nsteps=20):
@@ -195,6 +253,7 @@ def main():
     ap.add_argument("--no-mech-stage", action="store_true", help="skip the secondary measurement of the stand-alone mechanistic + VJP kernel")
     ap.add_argument("--no-epoch", action="store_true", help="skip the secondary measurement of the shuffled epoch (eh_train_epoch)")
     ap.add_argument("--no-layerwise", action="store_true", help="skip the secondary measurement of the reference's GPU tutorial network (layer-wise form)")
+    ap.add_argument("--no-train-e2e", action="store_true", help="skip the secondary end-to-end measurement of eh.train(...) (tools/bench_train_e2e.py)")
     ap.add_argument("--no-specialize", action="store_true",
                     help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
     args = ap.parse_args()
@@ -457,6 +516,16 @@ def main():
                                     "runs": [bl.measure(64, local), bl.measure(B, local)]}
             except Exception as e:
                 out["layerwise"] = {"error": repr(e)}
+        if world == 1 and dp is None and not args.no_train_e2e:
+            # what a user runs: eh.train(...) end to end on the reference tutorial's two models and on the headline data set, split into
+            # steps / evaluation / host, next to the same work in PyTorch-CPU eager; and the evaluation kernel's own roofline entry
+            try:
+                import importlib.util
+                spec_ = importlib.util.spec_from_file_location("eh_bench_e2e", os.path.join(ROOT, "tools", "bench_train_e2e.py"))
+                be = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(be)
+                out["train_e2e"] = be.measure(local)
+            except Exception as e:
+                out["train_e2e"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     eng.close()
     if dist.is_initialized():

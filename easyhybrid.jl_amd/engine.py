@@ -102,7 +102,7 @@ class HybridEngine:
         if len(forcings) != self.desc.n_forcings or len(targets) != self.desc.n_targets:
             raise ValueError("number of forcing / target arrays does not match the model")
         self.x_sum[split] = (X.sum(axis=1, dtype=np.float64), N)      # for the common BatchNorm shift under data parallelism
-        self.y_sum[split] = np.array([[np.nansum(np.asarray(t, np.float64)), np.count_nonzero(~np.isnan(t))] for t in targets], np.float64)   # (sum, n valid) per target: common target shift
+        self.y_sum[split] = np.array([[np.nansum(t, dtype=np.float64), np.count_nonzero(~np.isnan(t))] for t in targets], np.float64)   # (sum, n valid) per target: common target shift
         xf = np.asfortranarray(X)                       # (P x N) column-major == N records of P
         fs = [np.ascontiguousarray(f, np.float32) for f in forcings]
         ts = [np.ascontiguousarray(t, np.float32) for t in targets]

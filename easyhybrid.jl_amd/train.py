@@ -268,7 +268,9 @@ def prepare_data(model: SingleNNHybridModel, data, drop_missing_rows: bool = Tru
     for c in need:
         if c not in cols:
             raise KeyError(f"column {c!r} missing from data")
-    arr = {c: np.asarray(cols[c], np.float64) for c in need}
+    # (float32 / float64 columns stay what they are -- the device data are Float32 like the reference's, prepare_data.jl:58-60 -- anything
+    #  else goes through float64; no copy is made where none is needed: at 4 M rows the copies ARE the cost of this function)
+    arr = {c: (a if (a := np.asarray(cols[c])).dtype in (np.float32, np.float64) else a.astype(np.float64)) for c in need}
     n = len(next(iter(arr.values())))
     if drop_missing_rows:
         predforce = [c for c in need if c not in model.targets]
@@ -279,10 +281,16 @@ def prepare_data(model: SingleNNHybridModel, data, drop_missing_rows: bool = Tru
         for c in model.targets:
             some_target |= ~np.isnan(arr[c])
         keep = ~miss & some_target
-        arr = {c: v[keep] for c, v in arr.items()}
+        if not keep.all():
+            arr = {c: v[keep] for c, v in arr.items()}
     nkept = len(next(iter(arr.values())))
-    X = np.stack([arr[p] for p in model.predictors]).astype(np.float32) if model.predictors else np.zeros((0, nkept), np.float32)   # (no predictors: a model without a network)
-    return (X, {f: arr[f].astype(np.float32) for f in model.forcing}), {t: arr[t].astype(np.float32) for t in model.targets}
+    if model.predictors:
+        X = np.empty((len(model.predictors), nkept), np.float32)
+        for i, p_ in enumerate(model.predictors):
+            X[i] = arr[p_]                                        # (one pass per column, cast on the way)
+    else:
+        X = np.zeros((0, nkept), np.float32)                      # (no predictors: a model without a network)
+    return (X, {f: arr[f].astype(np.float32, copy=False) for f in model.forcing}), {t: arr[t].astype(np.float32, copy=False) for t in model.targets}
 
 
 def split_data(data, model, cfg: DataConfig = DataConfig(), rng: Optional[np.random.Generator] = None):
@@ -312,9 +320,12 @@ def split_data(data, model, cfg: DataConfig = DataConfig(), rng: Optional[np.ran
             raise AssertionError(f"No samples assigned to validation fold {cfg.val_fold}.")
         tr = np.setdiff1d(np.arange(n), va)
     else:
-        idx = (rng or np.random.default_rng()).permutation(n) if cfg.shuffleobs else np.arange(n)
         k = int(np.clip(round(cfg.split_data_at * n), 0, n))           # MLUtils.splitobs(at = ...)
-        tr, va = idx[:k], idx[k:]
+        if cfg.shuffleobs:
+            idx = (rng or np.random.default_rng()).permutation(n)
+            tr, va = idx[:k], idx[k:]
+        else:
+            tr, va = slice(0, k), slice(k, n)                           # contiguous halves: views, no gather
 
     def take(ix):
         return (np.ascontiguousarray(X[:, ix]), {k: v[ix] for k, v in forc.items()}), {k: v[ix] for k, v in targ.items()}
