@@ -255,7 +255,8 @@ def main():
     ap.add_argument("--no-layerwise", action="store_true", help="skip the secondary measurement of the reference's GPU tutorial network (layer-wise form)")
     ap.add_argument("--no-train-e2e", action="store_true", help="skip the secondary end-to-end measurement of eh.train(...) (tools/bench_train_e2e.py)")
     ap.add_argument("--no-specialize", action="store_true",
-                    help="run the step kernels built ahead of time instead of the ones compiled at run time around the model descriptor")
+                    help="never compile a step kernel at run time (the headline descriptor has a kernel specialised ahead of time, csrc/eh_spec.hip, and runs it "
+                         "either way; EH_NO_AOT_SPEC=1 takes that one away: then this flag picks the generic kernels over the hiprtc-built ones)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -324,7 +325,7 @@ def main():
                 # the "specialize" option: the step kernel is compiled at run time (hiprtc, ~1 s) with this model's descriptor as a
                 # compile-time constant; one forward over one sample builds it here, ahead of the warm-up
                 e.set_option("specialize", 1)
-                e.forward(eh.EH_SPLIT_TRAIN, 0, 1, params=False)
+            e.forward(eh.EH_SPLIT_TRAIN, 0, 1, params=False)          # (builds / picks the step kernels here, ahead of the warm-up; eh_jit_status then says which)
         return e
 
     def fence(e):
@@ -370,7 +371,8 @@ def main():
         dp = None
         step = lambda first: eng.train_step(first, B, want_loss=False)
     jit_kernels, jit_log = eng.jit_status()
-    built = "compiled at run time around the model descriptor (hiprtc)" if jit_kernels else "built ahead of time"
+    built = ("specialised for this model descriptor AHEAD of time (csrc/eh_spec.hip: no run-time compiler involved)" if jit_log.startswith("ahead-of-time")
+             else "compiled at run time around the model descriptor (hiprtc)" if jit_kernels else "generic kernel built ahead of time")
 
     exchange_cal = None
     if dp is not None and dp.p2p:
@@ -476,8 +478,8 @@ def main():
                        "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
                                              else "one RCCL all-reduce per step" if not share else "one gloo all-reduce per step (EH_BENCH_SHARE_GPU=1: all ranks on one GPU, testing only)"),
                        "gradient_exchange_calibration_us_per_step": exchange_cal, "step_kernel": built,
-                       "step_mode": "one kernel per step (fused_update) on the run-time specialised kernel: what train() runs by default "
-                                    "(TrainConfig.fused_update = specialize = 'auto')" if dp is None and not args.no_specialize else "see step_kernel / gradient_exchange"},
+                       "step_mode": "one kernel per step (fused_update) on the kernel specialised for this descriptor (see step_kernel): what train() runs by "
+                                    "default (TrainConfig.fused_update = specialize = 'auto')" if dp is None else "see step_kernel / gradient_exchange"},
             "roofline": roof,
         }
         if n1_ref is not None:

@@ -321,7 +321,37 @@ static bool jit_verify(eh_handle* h, eh_handle_s::JitEntry* je, const EhStepArgs
     return ok;
 }
 
+// the kernel specialised AHEAD OF TIME for this handle's descriptor, if it is one of the canonical ones (eh_spec.hip); nullptr otherwise
+static const EhSpecKernel* spec_lookup(const eh_handle* h) {
+    static const EhSpecKernel* const list[] = {
+#define EH_SPEC_ITEM(k) eh_spec_##k(),
+        EH_SPEC_LIST(EH_SPEC_ITEM)
+#undef EH_SPEC_ITEM
+    };
+    static bool prepared[sizeof list / sizeof list[0]] = {};
+    if (!h->aot_spec || h->lform || h->act == EH_ACT_PER_NET) return nullptr;
+    const EhArchInfo* A = h->arch;
+    const EhVariant& V = A->var[h->variant];
+    const int kf = KFAST(h);
+    for (size_t i = 0; i < sizeof list / sizeof list[0]; ++i) {
+        const EhSpecKernel* k = list[i];
+        if (k->wide != (A->wide != 0) || k->bf16 != V.bf16 || k->nbi != A->nbi || k->nbh != A->nbh || k->nl != A->nl || k->nt != V.nt || k->nw != V.nw ||
+            k->act != h->act || k->fast != kf || memcmp(&k->net, &h->net, sizeof(EhNet)) != 0) continue;
+        if (!prepared[i]) {
+            if (k->prepare() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            prepared[i] = true;
+        }
+        return k;
+    }
+    return nullptr;
+}
+
 static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
+    if (const EhSpecKernel* sk = spec_lookup(h)) {
+        const hipError_t e = sk->launch(mode, grid, h->stream, &h->net, a);
+        if (e == hipSuccess) { h->spec_used = sk; return e; }
+        (void)hipGetLastError();                 // (a mode the specialised unit does not hold: the paths below)
+    }
     if (jit_wanted(h, mode)) {
         eh_handle_s::JitEntry* je = jit_entry(h);
         if (je && !je->verified && mode != EH_MODE_EVAL && !h->capturing && je->spec && h->net.mech != EH_MECH_PROGRAM && h->net.loss != EH_LOSS_PROGRAM &&
@@ -589,6 +619,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
     if (const char* ej = getenv("EH_JIT")) h->jit_on = atoi(ej) != 0;
     if (const char* es = getenv("EH_SPECIALIZE")) h->specialize = atoi(es) != 0;      // (test runs: the whole suite on specialised kernels)
+    if (getenv("EH_NO_AOT_SPEC")) h->aot_spec = false;                                // (A/B: the generic / run-time compiled kernels for a canonical descriptor)
     if (d->mech == EH_MECH_PROGRAM) {
         std::vector<unsigned> pb(EH_PROG_HDR + EH_MAX_PROG, 0u);
         pb[0] = (unsigned)d->prog_len; pb[1] = (unsigned)d->prog_n_out;
@@ -807,10 +838,13 @@ int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_
     if (!h || !n_compiled) return EH_EINVAL;
     int n = 0;
     for (auto& e : h->jit) n += e->state.load(std::memory_order_acquire) > 0 ? 1 : 0;
+    // a canonical descriptor runs the kernel specialised AHEAD of time (eh_spec.hip): counted like a compiled pair, the log says which it is
+    std::string msg = h->jit_log;
+    if (h->spec_used && h->aot_spec) { n += 1; msg = std::string("ahead-of-time: ") + h->spec_used->what + (msg.empty() ? "" : "; ") + msg; }
     *n_compiled = n;
     if (log && log_bytes > 0) {
-        const size_t m = std::min((size_t)log_bytes - 1, h->jit_log.size());
-        memcpy(log, h->jit_log.data(), m);
+        const size_t m = std::min((size_t)log_bytes - 1, msg.size());
+        memcpy(log, msg.data(), m);
         log[m] = 0;
     }
     return EH_OK;
@@ -890,6 +924,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         if (!strcmp(name, "agg")) h->agg = (int)value; else h->n_extra = (int)value;
         h->img.agg_a = h->agg ? 1.0f / ((float)h->net.T * (float)(1 + h->n_extra)) : 1.0f;
         h->img.l2s = h->agg ? 1.0f / (float)(1 + h->n_extra) : 1.0f;
+        return EH_OK;
+    }
+    if (!strcmp(name, "aot_spec")) {         // 0 = never the kernels specialised ahead of time for the canonical descriptors (eh_spec.hip): tests of the other paths, A/B
+        h->aot_spec = value != 0;
         return EH_OK;
     }
     if (!strcmp(name, "specialize")) {       // 1 = step kernels compiled at run time with the model descriptor as a compile-time constant;

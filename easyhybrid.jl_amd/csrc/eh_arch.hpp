@@ -31,6 +31,22 @@ struct EhArchInfo {
     int wide;                // eh_wide_kernel (eh_wide.hpp): the four waves of a workgroup share one tile and split the layers by rows
 };
 
+// A step kernel with ONE model descriptor baked in at build time (eh_spec.hip, one translation unit per canonical descriptor: the
+// BASELINE.json configurations): what the "specialize" option compiles at run time, without a run-time compiler.  A handle whose
+// descriptor, kernel family, variant, activation and fast-path flags match runs it instead of the generic kernel.
+struct EhSpecKernel {
+    EhNet net;
+    int wide, bf16, nbi, nbh, nl, nt, nw, act, fast;
+    size_t lds_bytes;
+    const char* what;
+    hipError_t (*prepare)(void);
+    hipError_t (*launch)(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
+};
+#define EH_SPEC_LIST(X) X(0) X(1) X(2) X(3) X(4)
+#define EH_SPEC_DECL(k) extern "C" const EhSpecKernel* eh_spec_##k(void);
+EH_SPEC_LIST(EH_SPEC_DECL)
+#undef EH_SPEC_DECL
+
 constexpr size_t EH_LDS_LIMIT = 160 * 1024;
 
 template <int NBI, int NBH, int NL>

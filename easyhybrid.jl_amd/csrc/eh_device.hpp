@@ -1664,7 +1664,17 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 }
 
 // one training step (or one forward / eval pass) per launch
+// (EH_SPEC_NS: a translation unit that bakes ONE model descriptor into its kernels ahead of time -- eh_spec.hip -- puts them in a
+//  namespace of its own: the same template arguments name a different kernel there than in the generic translation units)
+#ifdef EH_SPEC_NS
+namespace EH_SPEC_NS {
+#endif
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
     eh_step_body<NBI, NBH, NL, NT, NW, ACT, MODE, FAST>(net, a);
 }
+#ifdef EH_SPEC_NS
+}   // namespace EH_SPEC_NS
+using namespace EH_SPEC_NS;
+#endif
+

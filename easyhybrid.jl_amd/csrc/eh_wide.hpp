@@ -44,6 +44,11 @@ struct EhWideGeom : EhGeom<NBI, NBH, NL, NT, 1> {
 // make every barrier wait for the next tile's records (global loads issued a tile ahead on purpose).
 __device__ __forceinline__ void eh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (EH_SPEC_NS: a translation unit that bakes ONE model descriptor into its kernels ahead of time -- eh_spec.hip -- puts them in a
+//  namespace of its own: the same template arguments name a different kernel there than in the generic translation units)
+#ifdef EH_SPEC_NS
+namespace EH_SPEC_NS {
+#endif
 template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false>
 __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt, const EhStepArgs a) {
 #ifdef EH_SPEC_NET
@@ -667,3 +672,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
     }
     EH_STAMP(12);
 }
+#ifdef EH_SPEC_NS
+}   // namespace EH_SPEC_NS
+using namespace EH_SPEC_NS;
+#endif

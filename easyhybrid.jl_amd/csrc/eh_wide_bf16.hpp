@@ -247,6 +247,11 @@ __device__ __forceinline__ void eh_mech_stage_lane(const NET& net, const EhStepA
     }
 }
 
+// (EH_SPEC_NS: a translation unit that bakes ONE model descriptor into its kernels ahead of time -- eh_spec.hip -- puts them in a
+//  namespace of its own: the same template arguments name a different kernel there than in the generic translation units)
+#ifdef EH_SPEC_NS
+namespace EH_SPEC_NS {
+#endif
 template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false, int NS = 3>
 __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_rt, const EhStepArgs a) {
 #ifdef EH_SPEC_NET
@@ -753,3 +758,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     }
     EH_STAMP(12);
 }
+#ifdef EH_SPEC_NS
+}   // namespace EH_SPEC_NS
+using namespace EH_SPEC_NS;
+#endif

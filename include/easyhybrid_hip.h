@@ -423,6 +423,8 @@ int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
  * 0 = the interpreting kernels built ahead of time),
  * "specialize" (1 = every model's step kernels compiled at run time (hiprtc, ~1 s, cached on disk) with the descriptor as a compile-time
  * constant; 2 = the same in a background thread -- steps run the kernels built ahead of time until the compiled one is ready),
+ * "aot_spec" (default 1: a handle whose descriptor is a canonical one -- the BASELINE.json configurations -- runs the kernel specialised for it
+ * at BUILD time, csrc/eh_spec.hip, whatever "specialize" says; 0 = never: tests and A/B runs of the other kernels),
  * "precision" (0 = fp32 end to end, the reference's arithmetic; 1 = bf16 forward products with fp32 accumulation and an fp32-exact
  * backward pass, BASELINE.json config 5 -- row-split shapes with tanh / sigmoid / relu / identity only; 2 = bf16 operands in BOTH passes: every
  * backward delta is rounded to bfloat16 once, in the scale the step carries it, fp32 accumulation),
@@ -449,9 +451,12 @@ int32_t eh_set_target_loss_program(eh_handle* h, int32_t target, const uint32_t*
  * three are what eh_set_option("training_loss") accepts on a multi-target model. */
 int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n);
 
-/* EH_MECH_PROGRAM: how the recorded closure runs.  *n_compiled = kernel pairs (train + eval) compiled with hiprtc so far and in
- * use; 0 with a non-empty log = the build or a launch was refused and the handle runs the interpreting kernels instead
- * (same results, slower mechanistic stage).  log (optional) receives the compiler / failure message, NUL-terminated. */
+/* Which step kernels the handle runs.  *n_compiled = kernel pairs (train + eval) specialised for this handle's descriptor and in use:
+ * compiled with hiprtc at run time (recorded closures, the "specialize" option), or -- log starts with "ahead-of-time:" -- built into the
+ * library for a canonical descriptor (the BASELINE.json configurations, csrc/eh_spec.hip).  0 with a non-empty log = a build or a launch
+ * was refused, or a compiled kernel disagreed with the one built ahead of time on the first batch (every kernel that merely replaces
+ * a generic one is checked before it takes over), and the handle runs the generic / interpreting kernels instead (same results,
+ * slower).  log (optional) receives the message, NUL-terminated. */
 int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes);
 
 #ifdef __cplusplus

@@ -31,10 +31,14 @@ def bench_case():
 
 
 def _engine(model, theta, X, f, y, specialize):
+    """specialize: 0 = the generic kernels built ahead of time, 1 = compiled at run time around the descriptor (hiprtc), "aot" = the
+    kernel specialised AHEAD of time for this canonical descriptor (csrc/eh_spec.hip: what a handle runs by default)"""
     eng = model.engine(0)
     eng.set_data(eh.EH_SPLIT_TRAIN, X, [f["ta"]], [y["reco"]])
     eng.set_params(theta)
-    if specialize:
+    if specialize != "aot":
+        eng.set_option("aot_spec", 0)
+    if specialize == 1:
         eng.set_option("specialize", 1)
     return eng
 
@@ -44,7 +48,7 @@ def _slice(X, f, y, a, n):
     return X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}
 
 
-@pytest.mark.parametrize("specialize", [0, 1])
+@pytest.mark.parametrize("specialize", [0, 1, "aot"])
 def test_loss_gradient_and_forward_on_the_bench_inputs(bench_case, specialize):
     model, spec, theta, X, f, y = bench_case
     eng = _engine(model, theta, X, f, y, specialize)
@@ -60,10 +64,11 @@ def test_loss_gradient_and_forward_on_the_bench_inputs(bench_case, specialize):
     assert util.relerr(out["reco"], ref["reco"]) <= 1e-5 and util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= 1e-5
     if specialize:
         assert eng.jit_status()[0] >= 1, "the run-time specialised kernel did not build: " + eng.jit_status()[1][:300]
+        assert eng.jit_status()[1].startswith("ahead-of-time") == (specialize == "aot")
     eng.close()
 
 
-@pytest.mark.parametrize("fused,specialize", [(1, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("fused,specialize", [(1, "aot"), (1, 1), (0, 0), (0, 1), (0, "aot")])
 def test_twenty_adam_steps_on_the_bench_inputs_follow_the_c_oracle(bench_case, fused, specialize):
     """bench.py's `parity` object, as a test: 20 steps on batches 0..19, loss of batch 20, parameters"""
     model, spec, theta, X, f, y = bench_case
@@ -107,7 +112,7 @@ def test_shuffled_epoch_on_the_bench_inputs_visits_every_sample_once(bench_case)
     that dropped or repeated records would show -- against the oracle's loss of the whole set"""
     model, spec, theta, X, f, y = bench_case
     n = 8 * B
-    eng = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 0)
+    eng = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, "aot")
     eng.opt_init("Descent", 0.0)
     mean_loss, nsteps = eng.train_epoch(B, seed=161803, shuffle=True)
     l0, _, _ = ho.loss_and_grad(spec, theta.astype(np.float64), *_slice(X, f, y, 0, n))
@@ -178,7 +183,7 @@ def test_the_background_build_switches_within_rounding_and_seeded_training_is_re
     n = 8 * 4096
     res = []
     for specialize in (0, 2):
-        eng = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 0)
+        eng = _engine(model, theta, X[:, :n], {"ta": f["ta"][:n]}, {"reco": y["reco"][:n]}, 0)       # (aot_spec off: the run-time path is under test)
         eng.set_option("specialize", specialize)
         eng.opt_init("Adam", 0.01)
         losses = [eng.train_step(s * 4096, 4096) for s in range(3)]          # (specialize = 2: these run the kernels built ahead of time while the build goes on)
@@ -197,3 +202,41 @@ def test_the_background_build_switches_within_rounding_and_seeded_training_is_re
     kw = dict(nepochs=3, batchsize=512, opt=eh.Adam(0.01), random_seed=11, fused_update=False)
     a, b = eh.train(model, cols, **kw), eh.train(model, cols, **kw)
     assert np.array_equal(a.ps, b.ps) and a.best_loss == b.best_loss and a.val_history == b.val_history
+
+
+def test_canonical_descriptors_run_kernels_specialised_ahead_of_time():
+    """the BASELINE configurations must not depend on a run-time compiler.  Their descriptors are baked into step
+    kernels at build time (csrc/eh_spec.hip, the strings in csrc/Makefile); a handle whose descriptor matches runs them by default --
+    checked here for each (if the EhNet layout or a default ever changes, the lookup would silently miss and this test says so) -- and
+    they give what the generic kernels give (1e-6: another binary of the same source)."""
+    from easyhybrid_jl_amd.synthetic import EXPO2POOL_PARAMS, RS6_PARAMS, make_synth_expo2pool, make_synth_fluxnet32_3f
+    cases = []
+    cols = make_synth_rbq10(4096, seed=1)
+    X = np.stack([cols["sw_pot"], cols["dsw_pot"]]).astype(np.float32) / 50
+    for scale in (True, False):
+        m = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"], hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=scale)
+        cases.append((f"RbQ10 [2,16,16,1] scale_nn_outputs={scale}", m, X, [cols["ta"]], [cols["reco"]]))
+    c3 = make_synth_expo2pool(4096, 1)
+    m3 = eh.constructHybridModel([f"x{i}" for i in range(8)], ["T"], ["Resp_obs"], eh.Expo2Pool, dict(EXPO2POOL_PARAMS), ["R0a", "ka", "R0b", "kb"], [],
+                                 hidden_layers=[64, 64], activation="tanh", scale_nn_outputs=True)
+    cases.append(("config 3 [8,64,64,4]", m3, np.stack([c3[f"x{i}"] for i in range(8)]), [c3["T"]], [c3["Resp_obs"]]))
+    c5 = make_synth_fluxnet32_3f(4096, 1)
+    for prec in ("bf16_fwd", "bf16"):
+        m5 = eh.constructHybridModel([f"x{i}" for i in range(32)], ["ta", "sw_in", "vpd"], ["R_soil"], eh.Rs_components3F, dict(RS6_PARAMS), list(RS6_PARAMS), [],
+                                     hidden_layers=[128, 128], activation="tanh", scale_nn_outputs=True, precision=prec)
+        cases.append((f"config 5 [32,128,128,6] {prec}", m5, np.stack([c5[f"x{i}"] for i in range(32)]), [c5["ta"], c5["sw_in"], c5["vpd"]], [c5["R_soil"]]))
+    for name, model, X_, F_, Y_ in cases:
+        res = []
+        for aot in (1, 0):
+            eng = model.engine(0)
+            eng.set_option("aot_spec", aot)
+            eng.set_data(eh.EH_SPLIT_TRAIN, X_, F_, Y_)
+            eng.set_params(model.initialparameters(3))
+            loss, grad, nv = eng.loss_and_grad()
+            m, _ = eng.eval(eh.EH_SPLIT_TRAIN)
+            n, log = eng.jit_status()
+            assert (n >= 1 and log.startswith("ahead-of-time")) == bool(aot), (name, aot, n, log[:200])
+            res.append((loss, grad, m[0]["mse"]))
+            eng.close()
+        (l1, g1, m1), (l0, g0, m0) = res
+        assert abs(l1 - l0) <= 1e-6 * abs(l0) and util.relerr(g1, g0) <= 1e-6 and abs(m1 - m0) <= 1e-6 * abs(m0), (name, l1, l0, util.relerr(g1, g0))
