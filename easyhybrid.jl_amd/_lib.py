@@ -119,6 +119,7 @@ SIGNATURES = {
     "eh_debug_stamps": (C.c_int32, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "eh_set_option": (C.c_int32, [_H, C.c_char_p, C.c_int64]),
     "eh_set_target_losses": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_int32]),
+    "eh_set_target_roles": (C.c_int32, [_H, C.POINTER(C.c_int32), C.c_int32]),
 }
 
 

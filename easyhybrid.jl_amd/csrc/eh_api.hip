@@ -321,6 +321,15 @@ static bool jit_verify(eh_handle* h, eh_handle_s::JitEntry* je, const EhStepArgs
     return ok;
 }
 
+// agg = mean: the data loss enters with 1 / (T_data (1 + E)), every entry of the extra loss with 1 / (1 + E) (EhImg); targets that stand
+// for entries of the extra loss (eh_set_target_roles) are not data targets
+static void eh_agg_factors(eh_handle* h) {
+    int tdata = 0;
+    for (int t = 0; t < h->net.T; ++t) tdata += ((h->roles >> (2 * t)) & 3u) == 0u ? 1 : 0;
+    h->img.agg_a = h->agg ? 1.0f / ((float)std::max(1, tdata) * (float)(1 + h->n_extra)) : 1.0f;
+    h->img.l2s = h->agg ? 1.0f / (float)(1 + h->n_extra) : 1.0f;
+}
+
 // the kernel specialised AHEAD OF TIME for this handle's descriptor, if it is one of the canonical ones (eh_spec.hip); nullptr otherwise
 static const EhSpecKernel* spec_lookup(const eh_handle* h) {
     static const EhSpecKernel* const list[] = {
@@ -834,6 +843,32 @@ int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n) {
     return EH_OK;
 }
 
+// extra_loss as a function of the predictions (src/losses/compute_loss.jl:31-34; the reference's own test:
+// `extra_loss = (yhat, ps) -> [sum(abs, yhat.var1), sum(abs, yhat.var2)]`, test/test_compute_loss.jl:257-285).  An entry that is the sum
+// or the mean over ALL samples of the batch of a per-sample function f(yhat_o) of one model output is carried as one more TARGET: it
+// observes output o (eh_model_desc::target_output), its data column holds no NaN (the host binding passes zeros), its per-sample loss is the
+// recorded f (eh_set_target_loss_program, kind EH_LOSS_PROGRAM in eh_set_target_losses) -- and this call says so:
+// roles[t] = 0 a data target | 1 an extra-loss entry, mean over all samples | 2 an extra-loss entry, sum over all samples.
+// Such a target takes the extra loss's factor under agg = mean, no 1 / n when it is a sum, and does not count as a data target.
+int32_t eh_set_target_roles(eh_handle* h, const int32_t* roles, int32_t n) {
+    if (!h || !roles) return EH_EINVAL;
+    if (n != h->net.T) return fail(h, EH_EINVAL, "eh_set_target_roles: %d roles for %d targets", n, h->net.T);
+    unsigned r = 0;
+    int ndata = 0;
+    for (int t = 0; t < n; ++t) {
+        if (roles[t] < 0 || roles[t] > 2) return fail(h, EH_EINVAL, "eh_set_target_roles: role %d of target %d (0 data, 1 extra-loss mean, 2 extra-loss sum)", roles[t], t);
+        r |= (unsigned)roles[t] << (2 * t);
+        ndata += roles[t] == 0;
+    }
+    if (ndata == 0) return fail(h, EH_EINVAL, "eh_set_target_roles: at least one data target");
+    if (r != 0 && h->net.T < 2) return fail(h, EH_EINVAL, "eh_set_target_roles: an extra-loss entry is a target of its own");
+    HIPCHK(h, hipSetDevice(h->device));
+    FLUSH(h);
+    h->roles = r;
+    eh_agg_factors(h);
+    return EH_OK;
+}
+
 int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_bytes) {
     if (!h || !n_compiled) return EH_EINVAL;
     int n = 0;
@@ -922,8 +957,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);                                 // (a pending fused update was computed under the old setting)
         if (!strcmp(name, "agg")) h->agg = (int)value; else h->n_extra = (int)value;
-        h->img.agg_a = h->agg ? 1.0f / ((float)h->net.T * (float)(1 + h->n_extra)) : 1.0f;
-        h->img.l2s = h->agg ? 1.0f / (float)(1 + h->n_extra) : 1.0f;
+        eh_agg_factors(h);
         return EH_OK;
     }
     if (!strcmp(name, "aot_spec")) {         // 0 = never the kernels specialised ahead of time for the canonical descriptors (eh_spec.hip): tests of the other paths, A/B
@@ -1335,7 +1369,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     *rows_out = rows;
     if (net.T > 1 && !h->dp_weights) {        // (data-parallel step: eh_dp_grad has just filled inv_n with the weights of the GLOBAL batch)
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
-        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4, h->img.agg_a);
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4, h->img.agg_a, h->roles, h->img.l2s);
         HIPCHK(h, hipGetLastError());
     }
     if (count <= 0) {                          // nothing to do: an all-zero partial (the reduce kernel then skips the update)
@@ -1514,7 +1548,7 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     const EhNet& net = h->net;
     if (net.T > 1 && !h->dp_weights) {
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
-        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4, h->img.agg_a);
+        hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, idx, first, count, h->inv_n, net.loss_t, sh4, h->img.agg_a, h->roles, h->img.l2s);
         HIPCHK(h, hipGetLastError());
     }
     const bool moment_loss = two_pass_mask(net) != 0;
@@ -1572,7 +1606,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     if (h->net.T > 1) {      // multi-target: the per-target weights (1 / n_t, 1 / sum (y - ybar)^2) have to be known inside the streaming pass
         EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
-        hipLaunchKernelGGL(eh_count_kernel, dim3(h->net.T), dim3(256), 0, h->stream, sp.recs, h->C, h->net.P + h->net.F, h->net.T, idx, first, count, h->inv_n, h->net.loss_t, sh4, h->img.agg_a);
+        hipLaunchKernelGGL(eh_count_kernel, dim3(h->net.T), dim3(256), 0, h->stream, sp.recs, h->C, h->net.P + h->net.F, h->net.T, idx, first, count, h->inv_n, h->net.loss_t, sh4, h->img.agg_a, h->roles, h->img.l2s);
         HIPCHK(h, hipGetLastError());
         a.inv_n = h->inv_n;
     }
@@ -2164,7 +2198,7 @@ int32_t eh_dp_grad(eh_handle* h, int64_t first, int64_t count) {
     int rc = check_window(h, sp, first, count, "eh_dp_grad");
     if (rc) return rc;
     if (h->net.T != 1) {      // the weights of the GLOBAL batch from the all-reduced sums; the step kernel then normalises exactly
-        hipLaunchKernelGGL(eh_weights_from_counts_kernel, dim3(1), dim3(64), 0, h->stream, h->tcount, h->net.T, h->net.loss_t, h->inv_n, h->img.agg_a);
+        hipLaunchKernelGGL(eh_weights_from_counts_kernel, dim3(1), dim3(64), 0, h->stream, h->tcount, h->net.T, h->net.loss_t, h->inv_n, h->img.agg_a, h->roles, h->img.l2s);
         HIPCHK(h, hipGetLastError());
         h->dp_weights = true;
     }
@@ -2192,7 +2226,7 @@ int32_t eh_dp_counts(eh_handle* h, int64_t first, int64_t count) {
     EhShift4 sh4; for (int t = 0; t < EH_MAX_TARG; ++t) sh4.c[t] = sp.shift[t];
     HIPCHK(h, hipMemsetAsync(h->tcount, 0, 3 * EH_MAX_TARG * sizeof(float), h->stream));
     hipLaunchKernelGGL(eh_count_kernel, dim3(net.T), dim3(256), 0, h->stream, sp.recs, h->C, net.P + net.F, net.T, h->perm_valid ? h->perm : nullptr, first, count,
-                       h->inv_n, net.loss_t, sh4, h->img.agg_a, h->tcount);
+                       h->inv_n, net.loss_t, sh4, h->img.agg_a, h->roles, h->img.l2s, h->tcount);
     HIPCHK(h, hipGetLastError());
     h->tcount_ready = true;
     return EH_OK;

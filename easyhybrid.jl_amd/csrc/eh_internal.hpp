@@ -132,6 +132,7 @@ struct eh_handle_s {
     ncclComm_t comm = nullptr;      // eh_comm_init: the library's own RCCL communicator (data parallelism without a host-side collective library)
     int comm_world = 0, comm_rank = 0;
     struct EhLocalGroup* lgroup = nullptr;   // eh_comm_init_local: handles of ONE process exchange through peer-mapped device memory, no RCCL
+    unsigned roles = 0;             // eh_set_target_roles: 2 bits per target -- 0 a data target, 1 / 2 an entry of the extra loss (mean / sum over all samples of a recorded function of the prediction)
     int agg = 0, n_extra = 0;       // eh_set_option "agg" (0 = sum, 1 = mean) / "extra_terms" (entries the extra loss returns); img.agg_a / img.l2s follow
     EhOpt opt{};
     EhSplit split[2];

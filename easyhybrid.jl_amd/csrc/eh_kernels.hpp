@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void eh_apply_kernel(float* gradbuf, int n_the
 // the residual terms of target t enter the loss as w_t r^2 (w_t |r| for MAE) with  w_t = 1 / n_t  for mse / mae  (loss_fn.jl:61-66)
 // and  w_t = 1 / sum (y - mean y)^2  for nseLoss (:79-81) -- all of it a function of the targets alone.  One workgroup per target.
 __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C, int toff, int T, const int* idx, long long first, long long count,
-                                                       float* inv_n, unsigned loss_t, EhShift4 shift, float agg_a, float* raw = nullptr) {
+                                                       float* inv_n, unsigned loss_t, EhShift4 shift, float agg_a, unsigned roles, float l2s, float* raw = nullptr) {
     __shared__ float red[3][256];
     const int t = blockIdx.x;
     float c = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -687,17 +687,22 @@ __global__ __launch_bounds__(256) void eh_count_kernel(const float* recs, int C,
         if (raw) { raw[3 * t] = n; raw[3 * t + 1] = red[1][0]; raw[3 * t + 2] = red[2][0]; return; }      // data parallel: this shard's sums (EH_BUF_TCOUNT), all-reduced by the caller
         float w = n > 0.0f ? 1.0f / n : 0.0f;
         if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (red[2][0] - red[1][0] * red[1][0] / n);
-        inv_n[EH_TT * t] = w * agg_a;         // (the per-target table of EhStepArgs::inv_n, eh_device.hpp; agg_a: the factor of `agg`, EhImg)
+        // (the per-target table of EhStepArgs::inv_n, eh_device.hpp; agg_a: the factor of `agg`, EhImg.  A target that stands for an ENTRY OF
+        //  THE EXTRA LOSS -- eh_set_target_roles: a recorded function of the predictions, summed or averaged over all samples -- takes the
+        //  extra loss's factor instead, and no 1 / n when it is a sum)
+        const unsigned role = (roles >> (2 * t)) & 3u;
+        inv_n[EH_TT * t] = role == 0u ? w * agg_a : (role == 2u ? (n > 0.0f ? l2s : 0.0f) : w * l2s);
     }
 }
 // (data parallel) the all-reduced sums [n_t | sum (y - c) | sum (y - c)^2] of the GLOBAL batch -> the per-target weights; c is common to the ranks (eh_set_target_shift)
-__global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned loss_t, float* inv_n, float agg_a) {
+__global__ void eh_weights_from_counts_kernel(const float* raw, int T, unsigned loss_t, float* inv_n, float agg_a, unsigned roles, float l2s) {
     const int t = threadIdx.x;
     if (t >= T) return;
     const float n = raw[3 * t];
     float w = n > 0.0f ? 1.0f / n : 0.0f;
     if (((loss_t >> (4 * t)) & 15u) == (unsigned)EH_LOSS_NSELOSS && n > 0.0f) w = 1.0f / (raw[3 * t + 2] - raw[3 * t + 1] * raw[3 * t + 1] / n);
-    inv_n[EH_TT * t] = w * agg_a;
+    const unsigned role = (roles >> (2 * t)) & 3u;          // (see eh_count_kernel)
+    inv_n[EH_TT * t] = role == 0u ? w * agg_a : (role == 2u ? (n > 0.0f ? l2s : 0.0f) : w * l2s);
 }
 
 // input BatchNorm: per-workgroup partial sums of one minibatch, shifted by the batch's first sample

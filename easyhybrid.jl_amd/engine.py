@@ -47,7 +47,7 @@ class PerTarget:
 class HybridEngine:
     """Device-resident hybrid model: parameters, optimiser state and datasets live in HBM."""
 
-    def __init__(self, desc: L.ModelDesc, n_par: int, target_names: Sequence[str], param_names: Sequence[str]):
+    def __init__(self, desc: L.ModelDesc, n_par: int, target_names: Sequence[str], param_names: Sequence[str], n_pseudo: int = 0):
         self._lib = L.lib()
         self._h = C.c_void_p()
         self.desc = desc
@@ -60,6 +60,11 @@ class HybridEngine:
         self.n_theta = int(n.value)
         self.n_par = n_par
         self.target_names = list(target_names)
+        # entries of an extra loss of the predictions ride on targets of their own behind the data targets (set_extra_entries): the
+        # device sees len(target_names) + n_pseudo targets, the caller only ever the data targets
+        self.n_pseudo = int(n_pseudo)
+        self.n_targets_total = len(self.target_names) + self.n_pseudo
+        self.extra_entries = []
         self.param_names = list(param_names)
         self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
         self.x_sum = {}
@@ -99,8 +104,9 @@ class HybridEngine:
         P, N = X.shape
         if P != self.desc.n_predictors:
             raise ValueError(f"X has {P} predictor rows, model expects {self.desc.n_predictors}")
-        if len(forcings) != self.desc.n_forcings or len(targets) != self.desc.n_targets:
+        if len(forcings) != self.desc.n_forcings or len(targets) != len(self.target_names):
             raise ValueError("number of forcing / target arrays does not match the model")
+        targets = list(targets) + [np.zeros(N, np.float32)] * self.n_pseudo      # an extra-loss entry "observes" every sample (no NaN)
         self.x_sum[split] = (X.sum(axis=1, dtype=np.float64), N)      # for the common BatchNorm shift under data parallelism
         self.y_sum[split] = np.array([[np.nansum(t, dtype=np.float64), np.count_nonzero(~np.isnan(t))] for t in targets], np.float64)   # (sum, n valid) per target: common target shift
         xf = np.asfortranarray(X)                       # (P x N) column-major == N records of P
@@ -133,7 +139,7 @@ class HybridEngine:
 
     # -- forward / eval --------------------------------------------------------------------------
     def _outs(self, count, want_yhat, want_params):
-        ys = [np.empty(count, np.float32) for _ in self.target_names] if want_yhat else None
+        ys = [np.empty(count, np.float32) for _ in range(self.n_targets_total)] if want_yhat else None      # (zip with target_names below: the data targets)
         ps = [np.empty(count, np.float32) for _ in range(self.n_par)] if want_params else None
         yp = (_F * len(ys))(*[_fptr(a) for a in ys]) if ys else None
         pp = (_F * len(ps))(*[_fptr(a) for a in ps]) if ps else None
@@ -150,7 +156,7 @@ class HybridEngine:
 
     def eval(self, split: int, first: int = 0, count: Optional[int] = None, predictions: bool = False):
         count = self.n_samples[split] - first if count is None else count
-        m = (L.TargetMetrics * len(self.target_names))()
+        m = (L.TargetMetrics * self.n_targets_total)()
         ys, _, yp, _ = self._outs(count, predictions, False)
         self._chk(self._lib.eh_eval(self._h, split, first, count, m, yp, None))
         metrics = [{f: getattr(m[t], f) for f, _ in L.TargetMetrics._fields_} for t in range(len(self.target_names))]
@@ -193,9 +199,12 @@ class HybridEngine:
         rmse joins them on multi-target models), or a function f(yhat, y) = mean of per-sample terms, which is recorded
         (program.trace_loss) and compiled into the step kernel at run time.  Applied to every target like the reference does
         (src/losses/compute_loss.jl:115-126); PerTarget((l_1, ..., l_T)) / a list gives each target its own (:128-145)."""
+        self._loss_spec = name
         per_target = isinstance(name, PerTarget)
         if per_target:
             name = list(name.losses)
+        if self.n_pseudo and not (per_target or (isinstance(name, (list, tuple)) and not (name and callable(name[0])))):
+            name, per_target = [name] * len(self.target_names), True      # (extra-loss entries make every model a multi-target one: the per-target path)
         if not per_target and isinstance(name, (list, tuple)) and name and callable(name[0]):
             # (f, args) / (f, kwargs) / (f, args, kwargs)  (src/losses/loss_fn.jl:92-107): f(yhat, y, args...; kwargs...)
             f, rest = name[0], list(name[1:])
@@ -219,8 +228,10 @@ class HybridEngine:
             for t, n in enumerate(name):
                 if callable(n):
                     self._set_loss_program(n, target=t)          # every function its own program
-            kinds = (C.c_int32 * len(name))(*[L.EH_LOSS_PROGRAM if callable(n) else L.TRAINING_LOSSES[n] for n in name])
-            self._chk(self._lib.eh_set_target_losses(self._h, kinds, len(name)))
+            self._put_extra_programs()                           # (a kind EH_LOSS_PROGRAM needs its program in place)
+            codes = [L.EH_LOSS_PROGRAM if callable(n) else L.TRAINING_LOSSES[n] for n in name] + [L.EH_LOSS_PROGRAM] * self.n_pseudo
+            kinds = (C.c_int32 * len(codes))(*codes)
+            self._chk(self._lib.eh_set_target_losses(self._h, kinds, len(codes)))
             self._loss_kinds = ["program" if callable(n) else n for n in name]
             return
         if callable(name):
@@ -244,6 +255,22 @@ class HybridEngine:
             self._chk(self._lib.eh_set_loss_program(self._h, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
         else:
             self._chk(self._lib.eh_set_target_loss_program(self._h, int(target), words, len(pg.code), consts, len(pg.consts), pg.out[0]))
+
+    def set_extra_entries(self, entries):
+        """entries of an extra loss that is a function of the predictions (program.trace_extra_loss: [(name, output, "sum" | "mean",
+        Program)]): entry i rides on device target len(target_names) + i (include/easyhybrid_hip.h: eh_set_target_roles)"""
+        if len(entries) != self.n_pseudo:
+            raise ValueError("the engine was created for a different number of extra-loss entries")
+        self.extra_entries = list(entries)
+        roles = [0] * len(self.target_names) + [2 if e[2] == "sum" else 1 for e in entries]
+        self._chk(self._lib.eh_set_target_roles(self._h, (C.c_int32 * len(roles))(*roles), len(roles)))
+        self.set_training_loss(getattr(self, "_loss_spec", "mse"))
+
+    def _put_extra_programs(self):
+        for i, (_, _, _, pg) in enumerate(self.extra_entries):
+            words = (C.c_uint32 * len(pg.code))(*pg.words())
+            consts = (C.c_float * max(1, len(pg.consts)))(*pg.consts)
+            self._chk(self._lib.eh_set_target_loss_program(self._h, len(self.target_names) + i, words, len(pg.code), consts, len(pg.consts), pg.out[0]))
 
     def set_weight_l2(self, lam: float, normalize: bool = False):
         """extra_loss = lam * weight_l2(ps; normalize) (src/utils/extract_weights.jl:69-91); lam = 0 switches it off"""

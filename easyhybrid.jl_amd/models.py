@@ -310,7 +310,7 @@ class SingleNNHybridModel:
         return ((nets[0] if nets else []) if self.NNs is None else dict(zip(self.neural_param_names, nets))), glob
 
     # -- C descriptor ----------------------------------------------------------------------------
-    def to_desc(self, device: int = 0) -> L.ModelDesc:
+    def to_desc(self, device: int = 0, extra_outputs=()) -> L.ModelDesc:
         ms = self.mechanistic_model
         d = L.ModelDesc()
         d.struct_size = __import__("ctypes").sizeof(L.ModelDesc)
@@ -355,8 +355,13 @@ class SingleNNHybridModel:
         d.n_forcings = len(self.forcing)
         for f, name in enumerate(ms.forcings):
             d.forcing_index[f] = self.forcing.index(name)
-        d.n_targets = len(self.targets)
-        for t, name in enumerate(self.targets):
+        # (extra_outputs: entries of an extra loss that is a function of the predictions ride on targets of their own, behind the data
+        #  targets -- include/easyhybrid_hip.h: eh_set_target_roles; each observes the output its entry reads)
+        all_t = list(self.targets) + list(extra_outputs)
+        if len(all_t) > L.EH_MAX_TARG:
+            raise NotImplementedError(f"{len(self.targets)} targets + {len(extra_outputs)} extra-loss entries of the predictions: the device holds {L.EH_MAX_TARG} in all")
+        d.n_targets = len(all_t)
+        for t, name in enumerate(all_t):
             d.target_output[t] = ms.outputs.index(name)
         if ms.program is not None:
             pg = ms.program
@@ -369,13 +374,19 @@ class SingleNNHybridModel:
                 d.prog_out[i] = o
         return d
 
-    def engine(self, device: int = 0):
+    def engine(self, device: int = 0, extra_fn=None):
         """precision (a build extension, BASELINE.json config 5; the reference is Float32 end to end; csrc/eh_wide_bf16.hpp):
         "bf16_fwd" = Dense products of the forward pass on bf16 operands with fp32 accumulation, fp32-exact backward;
         "bf16" = bf16 operands in both passes (every backward delta rounded to bf16 once), fp32 accumulation."""
         from .engine import HybridEngine
-        eng = HybridEngine(self.to_desc(device), len(self.mechanistic_model.params), self.targets,
-                           list(self.mechanistic_model.params))
+        entries = []
+        if extra_fn is not None:                      # extra_loss(yhat[, ps]) of the predictions: recorded, one more target per entry
+            from .program import trace_extra_loss
+            entries = trace_extra_loss(extra_fn, list(self.targets))
+        eng = HybridEngine(self.to_desc(device, [e[1] for e in entries]), len(self.mechanistic_model.params), self.targets,
+                           list(self.mechanistic_model.params), n_pseudo=len(entries))
+        if entries:
+            eng.set_extra_entries(entries)
         prec = self.config.get("precision", "f32")
         if prec not in ("f32", "bf16_fwd", "bf16"):
             raise ValueError(f"precision {prec!r}: 'f32', 'bf16_fwd' or 'bf16'")

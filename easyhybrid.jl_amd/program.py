@@ -211,14 +211,14 @@ class MeanOf:
     def _num(x):
         return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
 
-    def __mul__(self, c): return MeanOf(self.sym * float(c)) if self._num(c) else self._no()
+    def __mul__(self, c): return type(self)(self.sym * float(c)) if self._num(c) else self._no()
     __rmul__ = __mul__
-    def __truediv__(self, c): return MeanOf(self.sym / float(c)) if self._num(c) else self._no()
-    def __neg__(self): return MeanOf(-self.sym)
-    def __add__(self, o): return MeanOf(self.sym + (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or isinstance(o, MeanOf)) else self._no()
+    def __truediv__(self, c): return type(self)(self.sym / float(c)) if self._num(c) else self._no()
+    def __neg__(self): return type(self)(-self.sym)
+    def __add__(self, o): return type(self)(self.sym + (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or type(o) is type(self)) else self._no()
     __radd__ = __add__
-    def __sub__(self, o): return MeanOf(self.sym - (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or isinstance(o, MeanOf)) else self._no()
-    def __rsub__(self, o): return MeanOf(float(o) - self.sym) if self._num(o) else self._no()
+    def __sub__(self, o): return type(self)(self.sym - (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or type(o) is type(self)) else self._no()
+    def __rsub__(self, o): return type(self)(float(o) - self.sym) if self._num(o) else self._no()
     __rtruediv__ = __pow__ = __rpow__ = __abs__ = _no
 
     def __array_ufunc__(self, ufunc, method, *inputs, **k):
@@ -232,8 +232,19 @@ class MeanOf:
         self._no()
 
 
+class SumOf(MeanOf):
+    """np.sum(<traced per-sample value>): the other reduction an entry of the extra loss may end in (`sum(abs, yhat.var1)`,
+    test/test_compute_loss.jl:259-261).  Same rules as MeanOf: scaling by constants and sums of sums stay a sum; a constant ADDED to a
+    sum is refused (it would be added once per sample)."""
+    def __add__(self, o): return type(self)(self.sym + o.sym) if type(o) is type(self) else self._no()
+    __radd__ = __add__
+    def __sub__(self, o): return type(self)(self.sym - o.sym) if type(o) is type(self) else self._no()
+    def __rsub__(self, o): return self._no()
+
+
 _ARRAY_FUNCS = {
     "mean": lambda x, **kw: MeanOf(x),
+    "sum": lambda x, **kw: SumOf(x),
     "where": lambda cond, a, b: where(cond, a, b),
     "clip": lambda x, lo=None, hi=None, **kw: (x if lo is None else maximum(x, lo)) if hi is None else minimum(x if lo is None else maximum(x, lo), hi),
 }
@@ -380,3 +391,75 @@ def trace_loss(fn: Callable) -> Program:
     if len(consts) > MAX_CONST or len(code) > MAX_PROG:
         raise NotImplementedError(f"the loss has {len(code)} operations / {len(consts)} constants (device limits {MAX_PROG} / {MAX_CONST})")
     return Program(("yhat", "y"), (), ("loss",), tuple(consts), tuple(code), (out,))
+
+
+def trace_extra_loss(fn: Callable, outputs: Sequence[str]):
+    """Record `extra_loss(yhat[, ps])` where it is a function of the PREDICTIONS (src/losses/compute_loss.jl:31-34): `fn` is called
+    once with a dict output name -> traced per-sample value (and, if it takes a second argument, a stand-in for `ps` that refuses to
+    be used: parameter penalties are WeightL2 terms) and must return a list / tuple / dict of entries, each `np.sum(...)` or
+    `np.mean(...)` of an elementwise expression of ONE output -- the reference's own test: `[sum(abs, yhat.var1), sum(abs, yhat.var2)]`
+    (test/test_compute_loss.jl:257-285).  Returns [(name, output name, "sum" | "mean", Program)]; the program has the form of a
+    recorded training loss (value slot 0 = yhat, slot 1 = an unused y) so that the entry can ride on one more target of the model."""
+    import inspect
+    g = _Graph()
+    yh = {o: Sym(g, g.node("par", k)) for k, o in enumerate(outputs)}
+
+    class _NoPs:
+        def __getattr__(self, k): raise NotImplementedError("extra_loss: the recorded form takes the predictions only; penalties on the parameters are WeightL2 terms")
+        __getitem__ = __getattr__
+    try:
+        npar = len([p for p in inspect.signature(fn).parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.default is p.empty])
+    except (TypeError, ValueError):
+        npar = 1
+    res = fn(yh, _NoPs()) if npar >= 2 else fn(yh)
+    if hasattr(res, "_asdict"):
+        res = res._asdict()
+    items = list(res.items()) if isinstance(res, dict) else [(f"extra_{i + 1}", v) for i, v in enumerate(res if isinstance(res, (list, tuple)) else [res])]
+    out = []
+    for name, v in items:
+        if not isinstance(v, MeanOf):
+            raise NotImplementedError(f"extra_loss entry {name!r}: np.sum(...) or np.mean(...) of an elementwise expression of one prediction (got {type(v).__name__})")
+        root = _fold(g, v.sym.nid, {})
+        deps, seen, stack = set(), set(), [root]
+        while stack:
+            nid = stack.pop()
+            if nid in seen:
+                continue
+            seen.add(nid)
+            n = g.nodes[nid]
+            if n[0] == "par":
+                deps.add(n[1])
+            elif n[0] not in ("const", "frc"):
+                stack.extend(n[1:])
+        if len(deps) != 1:
+            raise NotImplementedError(f"extra_loss entry {name!r} reads {len(deps)} predictions: an entry rides on ONE output (it becomes a target of its own)")
+        k = deps.pop()
+        consts: List[float] = []
+        code: List[Tuple[int, int, int, int]] = []
+        slot: Dict[int, int] = {}
+
+        def emit(nid: int) -> int:
+            if nid in slot:
+                return slot[nid]
+            n = g.nodes[nid]
+            if n[0] == "par":
+                s_ = SLOT_PAR                               # the one prediction the entry reads = value slot 0 (yhat of a recorded loss)
+            elif n[0] == "const":
+                if n[1] not in consts:
+                    consts.append(n[1])
+                s_ = SLOT_CONST + consts.index(n[1])
+            else:
+                ops = [emit(a) for a in n[1:]] + [0, 0]
+                code.append((OPS[n[0]], ops[0], ops[1], ops[2]))
+                s_ = SLOT_INSTR + len(code) - 1
+            slot[nid] = s_
+            return s_
+        o_ = emit(root)
+        if o_ < SLOT_INSTR:
+            zero = emit(g.const(0.0))
+            code.append((OPS["add"], o_, zero, 0))
+            o_ = SLOT_INSTR + len(code) - 1
+        if len(consts) > MAX_CONST or len(code) > MAX_PROG:
+            raise NotImplementedError(f"extra_loss entry {name!r} has {len(code)} operations / {len(consts)} constants (device limits {MAX_PROG} / {MAX_CONST})")
+        out.append((str(name), outputs[k], "sum" if isinstance(v, SumOf) else "mean", Program(("yhat", "y"), (), ("loss",), tuple(consts), tuple(code), (o_,))))
+    return out

@@ -102,10 +102,29 @@ class WeightL2:
         return self.name or ("weight_l2" if self.net is None and self.key == "weight" else f"l2_{self.net or self.key}")
 
 
+def _extra_fn(extra_loss):
+    """TrainConfig.extra_loss -> the function of the predictions in it (`extra_loss(yhat[, ps])`, compute_loss.jl:31-34), or None.
+    It may stand alone or in a list next to WeightL2 terms; it is recorded (program.trace_extra_loss) when the engine is created."""
+    if callable(extra_loss) and not isinstance(extra_loss, WeightL2):
+        return extra_loss
+    if isinstance(extra_loss, (list, tuple)):
+        fns = [v for v in extra_loss if callable(v) and not isinstance(v, WeightL2)]
+        if len(fns) > 1:
+            raise ValueError("extra_loss: one function of the predictions (it may return several entries)")
+        return fns[0] if fns else None
+    return None
+
+
 def _extra_terms(extra_loss) -> List[WeightL2]:
-    """TrainConfig.extra_loss -> its terms ([] for None); anything else is refused"""
+    """TrainConfig.extra_loss -> its WeightL2 terms ([] for None; a function of the predictions is _extra_fn's); anything else is refused"""
     if extra_loss is None:
         return []
+    if callable(extra_loss) and not isinstance(extra_loss, WeightL2):
+        return []
+    if isinstance(extra_loss, (list, tuple)) and any(callable(v) and not isinstance(v, WeightL2) for v in extra_loss):
+        extra_loss = [v for v in extra_loss if isinstance(v, WeightL2)]
+        if not extra_loss:
+            return []
     if isinstance(extra_loss, WeightL2):
         return [extra_loss]
     if isinstance(extra_loss, dict) and extra_loss and all(isinstance(v, WeightL2) for v in extra_loss.values()):
@@ -115,17 +134,18 @@ def _extra_terms(extra_loss) -> List[WeightL2]:
         if len({t.label() for t in terms}) != len(terms):
             raise ValueError("extra_loss: two terms with the same name (a NamedTuple has distinct fields): give them `name`s")
         return terms
-    raise NotImplementedError("extra_loss: an arbitrary closure cannot run on the device; WeightL2 terms (one, a list or a dict of them) are built")
+    raise NotImplementedError("extra_loss: WeightL2 terms (one, a list or a dict of them) and / or ONE function of the predictions "
+                              "`f(yhat[, ps])` returning np.sum(...) / np.mean(...) entries are built")
 
 
-def _apply_extra_loss(eng, model, terms: List[WeightL2], agg: str = "sum"):
+def _apply_extra_loss(eng, model, terms: List[WeightL2], agg: str = "sum", n_fn_entries: int = 0):
     """the extra loss terms and `agg` (TrainingConfig.jl:76-77): the training loss is agg([agg(per-target losses), extra entries...])
     (compute_loss.jl:31-34,50-53) -- the engine needs the number of extra entries for agg = mean"""
     if len(terms) == 1 and terms[0].net is None and terms[0].key == "weight":
         eng.set_weight_l2(terms[0].lam, terms[0].normalize)
     elif terms:
         eng.set_weight_l2_coef(model.l2_coefficients(terms))
-    eng.set_agg(agg, len(terms))
+    eng.set_agg(agg, len(terms) + n_fn_entries)          # (entries of a function of the predictions ride on targets of their own: engine(extra_fn=...))
 
 
 def _agg_name(agg) -> str:
@@ -139,10 +159,23 @@ def _agg_name(agg) -> str:
     raise NotImplementedError(f"agg {agg!r}: the device implements sum and mean (TrainingConfig.jl:76-77)")
 
 
-def _extra_loss_values(model, theta, terms: List[WeightL2], agg: str = "sum") -> Dict[str, float]:
-    """the extra losses of flat parameters `theta` (host side, for the history; compute_loss.jl:39-44: each entry and their agg)"""
+def _extra_loss_values(model, theta, terms: List[WeightL2], agg: str = "sum", fn=None, preds=None) -> Dict[str, float]:
+    """the extra losses of flat parameters `theta` -- and, fn / preds, of the predictions of one split -- (host side, for the history;
+    compute_loss.jl:39-44: each entry and their agg)"""
     th = np.asarray(theta, np.float64)
     out = {}
+    if fn is not None and preds is not None:
+        import inspect
+        try:
+            two = len([p for p in inspect.signature(fn).parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.default is p.empty]) >= 2
+        except (TypeError, ValueError):
+            two = False
+        res = fn(preds, None) if two else fn(preds)
+        if hasattr(res, "_asdict"):
+            res = res._asdict()
+        items = res.items() if isinstance(res, dict) else [(f"extra_{i + 1}", v) for i, v in enumerate(res if isinstance(res, (list, tuple)) else [res])]
+        for k, v in items:
+            out[str(k)] = float(v)
     for t in terms:
         m = model.l2_mask(t.net, t.key)
         sq = float(np.sum(th[m] * th[m]))
@@ -402,8 +435,9 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
     device = torch.cuda.current_device()
     N = xtr.shape[1]
     lo, hi = shard_range(N, rank, world)
+    xfn = _extra_fn(tc.extra_loss)                    # extra_loss as a function of the predictions: its entries are targets of the TRAINING engine
     ev = model.engine(device)                         # evaluation replica: full splits
-    eng = model.engine(device)                        # training replica: this rank's shard
+    eng = model.engine(device, extra_fn=xfn)          # training replica: this rank's shard
     try:
         ev.set_data(L.EH_SPLIT_TRAIN, xtr, [ftr[f] for f in model.forcing], [ytr[t] for t in model.targets])
         ev.set_data(L.EH_SPLIT_VAL, xva, [fva[f] for f in model.forcing], [yva[t] for t in model.targets])
@@ -417,7 +451,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.set_training_loss(tc.training_loss)
         xterms = _extra_terms(tc.extra_loss)          # functions of the replicated parameters: every rank adds the same terms in eh_dp_apply
         aggn = _agg_name(tc.agg)
-        _apply_extra_loss(eng, model, xterms, aggn)
+        _apply_extra_loss(eng, model, xterms, aggn, eng.n_pseudo)
         drv = DataParallel(eng, fused=tc.fused_update is not False, specialize=bool(tc.specialize))      # ("auto" compiles before the first step here: every rank has to be ready together)
         has_bn = bool(model.config.get("input_batchnorm"))
         first_lt = tc.loss_types[0]
@@ -429,10 +463,10 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
                 ev.set_bn_state(*eng.get_bn_state())
             snap = EpochSnapshot(_losses(ev, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types, aggn),
                                  _losses(ev, L.EH_SPLIT_VAL, model.targets, tc.loss_types, aggn))
-            if xterms:
-                xv = _extra_loss_values(model, eng.get_params(), xterms, aggn)
-                for d in (snap.l_train, snap.l_val):
-                    d["extra_loss"] = dict(xv)
+            if xterms or xfn is not None:
+                for d, split in ((snap.l_train, L.EH_SPLIT_TRAIN), (snap.l_val, L.EH_SPLIT_VAL)):
+                    preds = ev.forward(split, params=False) if (xfn is not None and ev.n_samples[split]) else None
+                    d["extra_loss"] = _extra_loss_values(model, eng.get_params(), xterms, aggn, xfn, preds)
             return snap
         init = snapshot()
         history = [init]
@@ -507,7 +541,10 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
     if _want_distributed(tc):
         return _train_distributed(model, tc, rng, (xtr, ftr, ytr), (xva, fva, yva))
     own = engine is None
-    eng = engine if engine is not None else model.engine(tc.device)
+    xfn = _extra_fn(tc.extra_loss)                    # extra_loss as a function of the predictions (compute_loss.jl:31-34): recorded, its entries ride on targets of their own
+    if xfn is not None and engine is not None and not engine.n_pseudo:
+        raise ValueError("train(engine = ...): an extra_loss of the predictions needs an engine created with it (model.engine(device, extra_fn = f))")
+    eng = engine if engine is not None else model.engine(tc.device, extra_fn=xfn)
     try:
         eng.set_data(L.EH_SPLIT_TRAIN, xtr, [ftr[f] for f in model.forcing], [ytr[t] for t in model.targets])
         eng.set_data(L.EH_SPLIT_VAL, xva, [fva[f] for f in model.forcing], [yva[t] for t in model.targets])
@@ -520,17 +557,17 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         eng.set_training_loss(tc.training_loss)
         xterms = _extra_terms(tc.extra_loss)
         aggn = _agg_name(tc.agg)
-        _apply_extra_loss(eng, model, xterms, aggn)
+        _apply_extra_loss(eng, model, xterms, aggn, eng.n_pseudo)
         _apply_step_mode(eng, tc)
         first_lt = tc.loss_types[0]
 
         def snapshot():
             snap = EpochSnapshot(_losses(eng, L.EH_SPLIT_TRAIN, model.targets, tc.loss_types, aggn),
                                  _losses(eng, L.EH_SPLIT_VAL, model.targets, tc.loss_types, aggn))
-            if xterms:                                   # compute_loss.jl:39-44: eval mode reports the extra losses next to the metrics
-                xv = _extra_loss_values(model, eng.get_params(), xterms, aggn)
-                for d in (snap.l_train, snap.l_val):
-                    d["extra_loss"] = dict(xv)
+            if xterms or xfn is not None:                # compute_loss.jl:39-44: eval mode reports the extra losses next to the metrics
+                for d, split in ((snap.l_train, L.EH_SPLIT_TRAIN), (snap.l_val, L.EH_SPLIT_VAL)):
+                    preds = eng.forward(split, params=False) if (xfn is not None and eng.n_samples[split]) else None
+                    d["extra_loss"] = _extra_loss_values(model, eng.get_params(), xterms, aggn, xfn, preds)
             return snap
         init = snapshot()
         history = [init]

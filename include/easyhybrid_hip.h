@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define EH_ABI_VERSION 4      /* 2: eh_train_step takes the minibatch indices; eh_comm_*.  3: eh_comm_init_local, eh_dp_train_step_group, eh_set_target_loss_program.
-                               * 4: eh_p2p_init_local, eh_p2p_check_local, eh_dp_moments */
+                               * 4: eh_p2p_init_local, eh_p2p_check_local, eh_dp_moments, eh_set_target_roles */
 #define EH_MAX_HIDDEN 8       /* hidden layers: up to 3 run as ONE fused kernel per step, more (or widths above 128) layer by layer (csrc/eh_lform.hpp) */
 #define EH_MAX_PARAMS 8
 #define EH_MAX_FORC 4
@@ -450,6 +450,16 @@ int32_t eh_set_target_loss_program(eh_handle* h, int32_t target, const uint32_t*
  * function of the targets alone (1 / n_t, 1 / n_t, 1 / sum (y - mean y)^2), found by a pre-pass; n must equal n_targets.  The same
  * three are what eh_set_option("training_loss") accepts on a multi-target model. */
 int32_t eh_set_target_losses(eh_handle* h, const int32_t* kinds, int32_t n);
+
+/* extra_loss as a function of the PREDICTIONS (src/losses/compute_loss.jl:31-34; the reference's own test:
+ * `extra_loss = (yhat, ps) -> [sum(abs, yhat.var1), sum(abs, yhat.var2)]`, test/test_compute_loss.jl:257-285).  An entry that is the sum or
+ * the mean over ALL samples of the batch of a per-sample function f(yhat_o) of one model output is carried as one more TARGET of the
+ * descriptor: it observes output o (target_output), its data column holds no NaN (the host binding passes zeros), its per-sample loss is
+ * the recorded f (eh_set_target_loss_program; kind EH_LOSS_PROGRAM in eh_set_target_losses) -- and this call says which targets are such
+ * entries: roles[t] = 0 a data target | 1 an extra-loss entry, mean over all samples | 2 an extra-loss entry, sum over all samples.
+ * An entry takes the extra loss's factor under agg = mean (count it in "extra_terms"), no 1 / n when it is a sum, and is no data target.
+ * n must equal n_targets; at least one data target.  (ABI 4) */
+int32_t eh_set_target_roles(eh_handle* h, const int32_t* roles, int32_t n);
 
 /* Which step kernels the handle runs.  *n_compiled = kernel pairs (train + eval) specialised for this handle's descriptor and in use:
  * compiled with hiprtc at run time (recorded closures, the "specialize" option), or -- log starts with "ahead-of-time:" -- built into the

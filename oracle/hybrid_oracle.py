@@ -733,7 +733,7 @@ def vjp_from_output_seed(spec, theta, X, forcings, seeds: Dict[str, np.ndarray],
     return _backprop(spec, res["_tape"], {k: np.asarray(v, dt) for k, v in seeds.items()}, dt, X.shape[1])
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None, agg="sum"):
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None, agg="sum", extra=None):
     """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
     (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
@@ -811,23 +811,43 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
             else:
                 raise ValueError(f"training loss {kind}")
         dout[t] = d
+    # extra_loss as a function of the PREDICTIONS (compute_loss.jl:31-34; test/test_compute_loss.jl:257-285): entries
+    # (output name, recorded per-sample function registered with loss_program(), "sum" | "mean") over ALL samples of the batch -- their
+    # derivative joins the seed of the output they read, with the factor `agg` puts on an extra entry
+    extra = list(extra or [])
+    n_l2 = 0 if l2 is None else (len(l2) if isinstance(l2, list) else 1)
+    fac_data = dt.type(1) / dt.type(len(spec.targets) * (1 + n_l2 + len(extra))) if agg == "mean" else dt.type(1)
+    fac_extra = dt.type(1) / dt.type(1 + n_l2 + len(extra)) if agg == "mean" else dt.type(1)
+    extra_value = dt.type(0)
+    if extra and sum(nvalid) > 0:
+        mm_ = MECH[spec.mech][0]
+        for oname in mm_.outputs:
+            dout.setdefault(oname, np.zeros(B, dt))
+        for oname, kname, red in extra:
+            pname, closure = CUSTOM_LOSS[kname]
+            _, lfwd, lvjp = MECH[pname]
+            yh = np.broadcast_to(res[oname], (B,)).astype(dt)
+            lpar = {"yhat": yh, "y": np.zeros(B, dt)}
+            lout, laux = lfwd(lpar, {}, dt)
+            w = dt.type(1) if red == "sum" else dt.type(1) / dt.type(B)
+            extra_value = extra_value + w * np.sum(lout["loss"])
+            # (seeded relative to the data loss's factor: the whole gradient is scaled by fac_data below)
+            dout[oname] = dout[oname] + lvjp(lpar, {}, lout, laux, {"loss": np.full(B, w * fac_extra / fac_data, dt)}, dt)["yhat"]
     grad = _backprop(spec, tp, dout, dt, B, dout_un, defer)
     # agg (TrainingConfig.jl:76-77): loss = agg(per-target losses) (compute_loss.jl:50-53); with an extra loss
     # loss = agg([loss, extra entries...]) (compute_loss.jl:31-34).  sum or mean.
     if agg not in ("sum", "mean"):
         raise ValueError(f"agg {agg}")
-    if agg == "mean":
-        loss, grad = loss / dt.type(len(spec.targets)), grad / dt.type(len(spec.targets))
+    loss, grad = loss * fac_data, grad * fac_data
+    if sum(nvalid) > 0:
+        loss = loss + fac_extra * extra_value
     if l2 is not None and sum(nvalid) > 0:
         if isinstance(l2, list):                      # several terms: agg([loss_value, extra_loss_value...])
             lvs, lg = weight_l2_terms(spec, np.asarray(theta, dt), l2)
-            lv, n_extra = sum(lvs), len(lvs)
+            lv = sum(lvs)
         else:
             lv, lg = weight_l2(spec, np.asarray(theta, dt), *l2)
-            n_extra = 1
-        loss, grad = loss + lv, grad + lg
-        if agg == "mean":
-            loss, grad = loss / dt.type(1 + n_extra), grad / dt.type(1 + n_extra)
+        loss, grad = loss + fac_extra * lv, grad + fac_extra * lg
     return loss, grad, nvalid
 
 

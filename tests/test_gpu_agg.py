@@ -159,3 +159,95 @@ def test_train_front_door_with_agg_mean():
     assert out.val_history[-1]["mse"]["mean"] < 0.5 * out.val_history[0]["mse"]["mean"]
     with pytest.raises(NotImplementedError):
         eh.train(model, cols, nepochs=1, batchsize=512, agg=max)
+
+
+# ---- extra_loss as a function of the PREDICTIONS (src/losses/compute_loss.jl:31-34) ----------------------------------------------
+def _extra_case(fn, kinds_red):
+    """registers the entries of `fn` with the oracle (program + closure per entry) -> oracle `extra` list"""
+    from easyhybrid_jl_amd.program import trace_extra_loss
+    ent = trace_extra_loss(fn, ["NEE", "GPP"])
+    extra = []
+    for i, (name, out, red, pg) in enumerate(ent):
+        kname = f"xl_{id(fn)}_{i}"
+        ho.loss_program(kname, pg.as_dict(), None)
+        extra.append((out, kname, red))
+    assert [e[2] for e in extra] == kinds_red
+    return extra
+
+
+@pytest.mark.parametrize("hidden", [(16, 8), (100, 40), (160, 48, 24)])          # per-wave kernel, row-split kernel, layer-wise form
+@pytest.mark.parametrize("agg", ["sum", "mean"])
+def test_extra_loss_of_the_predictions_the_references_own_case(hidden, agg):
+    """`extra_loss_func(yhat, ps) = [sum(abs, yhat.var1), sum(abs, yhat.var2)]` of the reference's test (test/test_compute_loss.jl:
+    257-285): the training loss is agg([main_loss, extra entries...]).  Each entry rides on a target of its own (eh_set_target_roles):
+    loss and gradient against the oracle, whose extra entries are over ALL samples (the masked ones included, as `yhat.var1` is)."""
+    spec, theta, X, f, y = _flux(1400, hidden, 2, seed=12)
+    fn = lambda yhat, ps: [np.sum(np.abs(yhat["NEE"])), np.sum(np.abs(yhat["GPP"]))]
+    extra = _extra_case(fn, ["sum", "sum"])
+    model = util.model_from_spec(spec)
+    eng = model.engine(0, extra_fn=fn)
+    eng.set_data(eh.EH_SPLIT_TRAIN, X, [f["SW_IN"], f["TA"]], [y["NEE"], y["GPP"]])
+    eng.set_params(theta)
+    eng.set_agg(agg, eng.n_pseudo)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, agg=agg, extra=extra)
+    lm, gm, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    res = ho.forward(spec, theta.astype(np.float64), X, f)
+    want = lm + np.sum(np.abs(res["NEE"])) + np.sum(np.abs(res["GPP"]))          # expected_loss = sum([main_loss, extra_loss_vals...])
+    assert (agg != "sum" or l0 == pytest.approx(want, rel=1e-12)) and (agg != "mean" or l0 == pytest.approx((lm / 2 + want - lm) / 3, rel=1e-12))
+    assert loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
+    assert util.relerr(g0, gm) > 1e-2                                # the entries are not negligible here
+    # the caller sees the data targets only
+    m, yh = eng.eval(eh.EH_SPLIT_TRAIN, predictions=True)
+    assert len(m) == 2 and set(yh) == {"NEE", "GPP"} and set(eng.forward(eh.EH_SPLIT_TRAIN, params=False)) == {"NEE", "GPP"}
+    eng.close()
+
+
+def test_extra_loss_mean_entry_next_to_weight_l2_and_a_training_trajectory():
+    """one `mean` entry of one output + a WeightL2 term, mae / mse per target, agg = mean, six Adam steps"""
+    spec, theta, X, f, y = _flux(1800, (24, 12), 2, seed=4)
+    fn = lambda yhat: {"smooth_gpp": 0.3 * np.mean(yhat["GPP"] ** 2)}
+    extra = _extra_case(fn, ["mean"])
+    model = util.model_from_spec(spec)
+    from easyhybrid_jl_amd.train import _apply_extra_loss, _extra_terms
+    eng = model.engine(0, extra_fn=fn)
+    eng.set_data(eh.EH_SPLIT_TRAIN, X, [f["SW_IN"], f["TA"]], [y["NEE"], y["GPP"]])
+    eng.set_params(theta)
+    eng.set_training_loss(eh.PerTarget(("mae", "mse")))
+    _apply_extra_loss(eng, model, _extra_terms(eh.WeightL2(0.02)), "mean", eng.n_pseudo)
+    loss, grad, _ = eng.loss_and_grad()
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=["mae", "mse"], l2=(0.02, False), agg="mean", extra=extra)
+    assert loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    eng.opt_init("Adam", 0.003)
+    batches = [(i * 300, 300) for i in range(6)]
+    losses = [eng.train_step(*b) for b in batches]
+    th_ref = theta.copy(); st = ho.adam_init(theta.size, np.float32); l_ref = []
+    for a, n in batches:
+        sl = slice(a, a + n)
+        l_, g_, _ = ho.loss_and_grad(spec, th_ref, X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}, dtype=np.float32, kind=["mae", "mse"],
+                                     l2=(0.02, False), agg="mean", extra=extra)
+        th_ref = ho.adam_step(th_ref, g_.astype(np.float32), st, 0.003); l_ref.append(float(l_))
+    assert np.allclose(losses, l_ref, rtol=1e-4) and np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5
+    eng.close()
+
+
+def test_train_front_door_with_an_extra_loss_of_the_predictions():
+    """TrainConfig.extra_loss = a function of the predictions (next to a WeightL2 term): recorded when the engine is created; the history
+    reports every entry and their aggregate like the reference's eval mode (compute_loss.jl:39-44); the penalty does what it says"""
+    rng = np.random.default_rng(3)
+    n = 6000
+    cols = {f"x{i}": rng.standard_normal(n).astype(np.float32) for i in range(4)}
+    cols["SW_IN"] = (rng.random(n) * 400).astype(np.float32); cols["TA"] = (rng.random(n) * 30).astype(np.float32)
+    gpp = 0.004 * cols["SW_IN"] * (1 + 0.3 * np.tanh(cols["x0"])); reco = (1.5 + 0.5 * np.tanh(cols["x1"])) * 1.6 ** (0.1 * (cols["TA"] - 15))
+    cols["GPP"] = (gpp + 0.05 * rng.standard_normal(n)).astype(np.float32); cols["NEE"] = (reco - gpp + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    model = eh.constructHybridModel([f"x{i}" for i in range(4)], ["SW_IN", "TA"], ["NEE", "GPP"], eh.FluxPartModelQ10,
+                                    {"RUE": (0.005, 0.0, 0.02), "Rb": (1.5, 0.0, 6.0), "Q10": (1.6, 1.0, 4.0)}, ["RUE", "Rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    kw = dict(nepochs=4, batchsize=512, opt=eh.Adam(0.01), loss_types=["mse", "r2"], random_seed=11, return_model="final")      # (final: the predictions returned are the last epoch's)
+    plain = eh.train(model, cols, **kw)
+    pen = eh.train(model, cols, extra_loss=[eh.WeightL2(1e-4), lambda yhat, ps: {"gpp_size": 5.0 * np.mean(yhat["GPP"] ** 2)}], **kw)
+    last = pen.val_history[-1]["extra_loss"]
+    assert set(last) == {"weight_l2", "gpp_size", "sum"} and last["sum"] == pytest.approx(last["weight_l2"] + last["gpp_size"])
+    assert last["gpp_size"] == pytest.approx(5.0 * float(np.mean(pen.val_obs_pred["GPP_pred"] ** 2)), rel=1e-5)
+    assert np.mean(pen.val_obs_pred["GPP_pred"] ** 2) < 0.8 * np.mean(plain.val_obs_pred["GPP_pred"] ** 2)       # the penalty on the size of GPP shrinks GPP
+    assert set(pen.val_history[-1]["mse"]) == {"NEE", "GPP", "sum"}

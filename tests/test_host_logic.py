@@ -158,7 +158,20 @@ def test_weight_l2_terms_fold_into_one_coefficient_per_entry():
     assert not np.any(model.l2_mask(key="bias") & model.weight_mask())
     with pytest.raises(KeyError):
         model.l2_mask(net="nope")
+    # a function of the predictions is no WeightL2 term: it is recorded when the engine is created (train._extra_fn / program.trace_extra_loss)
+    from easyhybrid_jl_amd.train import _extra_fn
+    fn = lambda yhat, ps: [np.sum(np.abs(yhat["reco"]))]
+    assert _extra_terms(fn) == [] and _extra_fn(fn) is fn and _extra_fn([eh.WeightL2(0.1), fn]) is fn and len(_extra_terms([eh.WeightL2(0.1), fn])) == 1
     with pytest.raises(NotImplementedError, match="extra_loss"):
-        _extra_terms(lambda yhat, ps: 0.0)
+        _extra_terms("l2")
+    from easyhybrid_jl_amd.program import trace_extra_loss
+    ent = trace_extra_loss(lambda yh, ps: {"a": np.sum(np.abs(yh["v1"])), "b": 0.5 * np.mean(yh["v2"] ** 2)}, ["v1", "v2"])
+    assert [(e[0], e[1], e[2]) for e in ent] == [("a", "v1", "sum"), ("b", "v2", "mean")] and ent[0][3].words() == [13]
+    with pytest.raises(NotImplementedError, match="ONE output"):
+        trace_extra_loss(lambda yh: [np.sum(yh["v1"] * yh["v2"])], ["v1", "v2"])
+    with pytest.raises(NotImplementedError):
+        trace_extra_loss(lambda yh: [np.sum(yh["v1"]) + 1.0], ["v1", "v2"])          # a constant added to a sum: once per sample? refused
+    with pytest.raises(NotImplementedError, match="WeightL2"):
+        trace_extra_loss(lambda yh, ps: [np.sum(yh["v1"]) * ps.w], ["v1"])
     with pytest.raises(ValueError, match="same name"):
         _extra_terms([eh.WeightL2(0.1), eh.WeightL2(0.2)])
