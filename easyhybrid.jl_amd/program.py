@@ -305,6 +305,10 @@ def trace(fn: Callable, params: Sequence[str], forcings: Sequence[str], targets:
         raise NotImplementedError(f"{len(outs)} distinct target outputs (device limit {MAX_OUT})")
     some = next(iter(kw.values()))
     memo: Dict[int, int] = {}
+    for t in outs:
+        if isinstance(res[t], MeanOf):
+            raise NotImplementedError(f"output {t!r} of the mechanistic model is a sum / mean over samples: only elementwise operations can be recorded "
+                                      "(a closure that couples samples has no per-sample device form)")
     roots = [_fold(g, some._lift(res[t]).nid, memo) for t in outs]
     # emit what the roots reach, in dependency order
     used_f: List[str] = []
@@ -357,6 +361,9 @@ def trace_loss(fn: Callable) -> Program:
     g = _Graph()
     yhat, y = Sym(g, g.node("par", 0)), Sym(g, g.node("par", 1))
     res = fn(yhat, y)
+    if isinstance(res, SumOf):
+        raise NotImplementedError("numpy.sum in a training loss: only elementwise operations can be recorded, closed by ONE np.mean over the valid samples "
+                                  "(a sum over samples is what an entry of the extra loss may be: program.trace_extra_loss)")
     if isinstance(res, MeanOf):
         res = res.sym
     if not isinstance(res, Sym):
