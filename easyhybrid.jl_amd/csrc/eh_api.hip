@@ -960,6 +960,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         eh_agg_factors(h);
         return EH_OK;
     }
+    if (!strcmp(name, "check_idx")) {        // debug: range-check minibatch indices that live on the DEVICE (eh_train_step, idx_on_device != 0) before every step --
+        h->check_idx = value != 0;           // a small kernel + one synchronisation per step; host indices are always checked
+        return EH_OK;
+    }
     if (!strcmp(name, "aot_spec")) {         // 0 = never the kernels specialised ahead of time for the canonical descriptors (eh_spec.hip): tests of the other paths, A/B
         h->aot_spec = value != 0;
         return EH_OK;
@@ -1444,16 +1448,20 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     static const long long lgroup_max = getenv("EH_LFORM_GROUP_MAX") ? atoll(getenv("EH_LFORM_GROUP_MAX")) : 4096;
     bool grouped = count <= lgroup_max && h->l_nnets > 0;
     long long dk_floats = 0;
+    // (sized by THIS minibatch, rounded up to a power of two -- not by the largest one the path serves: a B = 64 step of a deep, wide
+    //  MultiNN model used to ask for up to the 1 GiB cap; advisor, round 3.  A larger batch later re-grows it, outside a capture.)
+    long long dk_rows = 64;
+    while (dk_rows < count) dk_rows *= 2;
     if (grouped) {
         for (int k = 0; k < h->l_nnets; ++k)
-            for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += (long long)lgroup_max * h->l_net[k].out[l];
-        if (dk_floats > (1ll << 28)) grouped = false;          // (more than 1 GiB of kept deltas: layer by layer as at large batches)
+            for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += dk_rows * h->l_net[k].out[l];
+        if (dk_floats > (1ll << 28)) { grouped = false; h->jit_log = "layer-wise form: kept deltas of this minibatch exceed 1 GiB -- weight gradients run layer by layer (slower small-batch steps)"; }
         else if ((size_t)dk_floats > h->l_dk_cap) {
             if (h->capturing) return lform_alloc_in_capture(h, "kept deltas");
             HIPCHK(h, hipStreamSynchronize(h->stream));
             (void)hipFree(h->l_dk); h->l_dk = nullptr; h->l_dk_cap = 0;
             if (hipMalloc(&h->l_dk, (size_t)dk_floats * sizeof(float)) == hipSuccess) h->l_dk_cap = (size_t)dk_floats;
-            else { (void)hipGetLastError(); grouped = false; }
+            else { (void)hipGetLastError(); grouped = false; h->jit_log = "layer-wise form: no memory for the kept deltas of the grouped small-batch path -- weight gradients run layer by layer (slower small-batch steps)"; }
         }
     }
     EhGemmGroup GG{}; EhThinGroup TG{};
@@ -1497,7 +1505,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
                 EhGemmArgs b{};
                 b.A = dZ; b.lda = dz_t ? W.ldo : out; b.B = theta + L.woff[l]; b.ldb = out;        // W_l element (k = out, n = in) at n * out + k
                 float* const dnext = grouped ? dkp : W.D[which];
-                if (grouped) dkp += (long long)lgroup_max * in;
+                if (grouped) dkp += dk_rows * in;
                 b.C = dnext; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
                 b.H = L.act == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.act;
                 if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
@@ -2019,6 +2027,21 @@ int32_t eh_train_step(eh_handle* h, const int32_t* idx, int32_t idx_on_device, i
         if (!sp.recs || sp.n == 0) return fail(h, EH_ESTATE, "eh_train_step: no data set for this split (call eh_set_data)");
         if (first < 0 || count < 0) return fail(h, EH_EINVAL, "eh_train_step: first %lld, count %lld", (long long)first, (long long)count);
         didx = idx;
+        if (h->check_idx && count > 0) {        // "check_idx" (debug): the entries idx[first .. first + count) of the caller's DEVICE array against the split's size
+            if (h->capturing) return fail(h, EH_ESTATE, "eh_train_step: the check_idx option synchronises: not while a graph is recorded");
+            unsigned* bad = nullptr;
+            HIPCHK(h, hipMalloc(&bad, 2 * sizeof(unsigned)));
+            HIPCHK(h, hipMemsetAsync(bad, 0, sizeof(unsigned), h->stream));
+            HIPCHK(h, hipMemsetAsync(bad + 1, 0xFF, sizeof(unsigned), h->stream));      // (position of the first offender: a minimum)
+            hipLaunchKernelGGL(eh_idx_check_kernel, dim3((unsigned)std::min<long long>(1024, (count + 255) / 256)), dim3(256), 0, h->stream, idx, (long long)first, (long long)count, (long long)sp.n, bad);
+            unsigned res[2] = {0, 0};
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(res, bad, sizeof res, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            (void)hipFree(bad);
+            HIPCHK(h, e);
+            if (res[0]) return fail(h, EH_EINVAL, "eh_train_step: %u of the %lld device-side indices are outside 0..%lld (first offender: idx[%lld])", res[0], (long long)count, (long long)sp.n - 1, (long long)first + (long long)res[1]);
+        }
     } else if ((rc = check_window(h, sp, first, count, "eh_train_step"))) return rc;
     rc = ensure_loss_hist(h, 1);
     if (rc) return rc;

@@ -148,6 +148,7 @@ struct eh_handle_s {
     // verified: the kernel has been run next to the one built ahead of time on one window of the user's data and agreed (jit_verify, eh_api.hip)
     struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; std::atomic<int> state{0}; EhJitKernel k; std::thread worker; std::string log; bool verified = false; };
     std::vector<std::unique_ptr<JitEntry>> jit;
+    bool check_idx = false;         // "check_idx" option: range-check device-side minibatch indices before the step (debug)
     bool aot_spec = true;           // "aot_spec" option / EH_NO_AOT_SPEC: run the kernel specialised ahead of time when the descriptor is a canonical one (eh_spec.hip)
     const struct EhSpecKernel* spec_used = nullptr;      // ... the one the last launch ran (eh_jit_status reports it)
     bool specialize_async = false;  // "specialize" = 2

@@ -771,6 +771,13 @@ __host__ __device__ inline uint32_t eh_perm32(uint32_t i, uint32_t n, int hb, ui
     } while (x >= n);
     return x;
 }
+// "check_idx" option (debug): how many of idx[first .. first + count) lie outside [0, n), and the position of the first one
+__global__ __launch_bounds__(256) void eh_idx_check_kernel(const int* idx, long long first, long long count, long long n, unsigned* bad) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const long long v = idx[first + i];
+        if (v < 0 || v >= n) { atomicAdd(&bad[0], 1u); atomicMin(&bad[1], (unsigned)i); }
+    }
+}
 __global__ void eh_perm_kernel(int* idx, uint32_t n, int hb, uint64_t seed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (int)eh_perm32(i, n, hb, seed);

@@ -423,6 +423,8 @@ int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
  * 0 = the interpreting kernels built ahead of time),
  * "specialize" (1 = every model's step kernels compiled at run time (hiprtc, ~1 s, cached on disk) with the descriptor as a compile-time
  * constant; 2 = the same in a background thread -- steps run the kernels built ahead of time until the compiled one is ready),
+ * "check_idx" (debug: 1 = the minibatch indices eh_train_step is given ON THE DEVICE are range-checked before every step -- a small kernel and
+ * one synchronisation per step; an index outside the split is EH_EINVAL instead of a wild read.  Host indices are always checked),
  * "aot_spec" (default 1: a handle whose descriptor is a canonical one -- the BASELINE.json configurations -- runs the kernel specialised for it
  * at BUILD time, csrc/eh_spec.hip, whatever "specialize" says; 0 = never: tests and A/B runs of the other kernels),
  * "precision" (0 = fp32 end to end, the reference's arithmetic; 1 = bf16 forward products with fp32 accumulation and an fp32-exact

@@ -1764,3 +1764,22 @@ def test_model_without_a_network_two_targets_and_per_target_losses():
         l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=kinds)
         assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (kinds, loss, l0, util.relerr(grad, g0))
         eng.close()
+
+
+def test_device_side_minibatch_indices_can_be_range_checked():
+    """eh_train_step(idx on the device) trusts the caller by default (a whole epoch's permutation uploaded once: no copy, no check);
+    the "check_idx" option (debug) range-checks them before every step: an index past the split is EH_EINVAL, not a wild read"""
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(2000, "tanh", True, 0.0)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    good = torch.randperm(2000, dtype=torch.int32, device="cuda")
+    bad = good.clone(); bad[700] = 2000; bad[900] = -3
+    eng.set_option("check_idx", 1)
+    l0 = eng.train_step(0, 1024, idx=good.cpu().numpy())
+    eng.set_params(theta); eng.opt_init("Adam", 0.01)
+    assert eng.train_step(0, 1024, idx=good.data_ptr()) == pytest.approx(l0, rel=1e-6)
+    with pytest.raises(ValueError, match=r"2 of the 1024 device-side indices.*idx\[700\]"):
+        eng.train_step(0, 1024, idx=bad.data_ptr())
+    eng.train_step(1000, 1000, idx=bad.data_ptr())          # the window past the offenders is fine
+    eng.close()
