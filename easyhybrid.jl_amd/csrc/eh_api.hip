@@ -1588,6 +1588,10 @@ static int launch_train_kernel(eh_handle* h, const EhSplit& sp, const int* idx, 
     a.inv_n = (net.T > 1 || moment_loss) ? h->inv_n : nullptr;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     a.rmap = h->rmap;
+    // one network on a row-split bf16 kernel: the accumulators go to the slab row straight from the registers (canonical order is plain
+    // column-major per layer; eh_wide_bf16.hpp) -- signalled by a null map
+    static const bool no_direct = getenv("EH_NO_DIRECT_STORE") != nullptr;      // (A/B switch of the measurement tools)
+    if (!no_direct && h->arch->wide && h->arch->var[h->variant].bf16 && h->n_nets == 1 && h->desc.n_nets == 0) a.rmap = nullptr;
     a.stamps = h->stamps;
     a.fz.gacc = nullptr;
     if (int rc = bn_prepare(h, sp, idx, first, count, bn_update, &a)) return rc;

@@ -40,6 +40,13 @@ struct EhWideGeom : EhGeom<NBI, NBH, NL, NT, 1> {
     static_assert(NWV * eh_wide_layout(NBI, NBH, NL, NWV).na * 256 <= TOTAL_FLOATS, "the end-of-kernel staging of the accumulators overlays image + workspace");
 };
 
+// the first n (1..4; more: all four) floats of v to p, a 4-byte aligned address in global memory
+__device__ __forceinline__ void eh_store_upto4(float* p, const f32x4& v, int n) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    if (n >= 4) *reinterpret_cast<f32x4u*>(p) = v;
+    else { if (n > 0) p[0] = v[0]; if (n > 1) p[1] = v[1]; if (n > 2) p[2] = v[2]; }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
 // make every barrier wait for the next tile's records (global loads issued a tile ahead on purpose).
 __device__ __forceinline__ void eh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

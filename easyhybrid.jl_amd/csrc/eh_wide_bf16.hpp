@@ -711,6 +711,41 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     float gs[EH_MAX_PARAMS];
 #pragma unroll
     for (int j = 0; j < EH_MAX_PARAMS; ++j) gs[j] = meta[EH_IMG_DPHI + j];
+    if (a.rmap == nullptr) {
+        // ONE network (SingleNN), so the canonical order is plain: layer l's weights column-major (out, in) at w_off[l], its bias behind
+        // them (image meta block).  A C/D accumulator holds rows 4g .. 4g+3 of column c of a 16 x 16 block -- four CONSECUTIVE canonical
+        // entries -- so every lane stores its registers straight to the slab row, 16 bytes at a time: no staging in LDS, no barrier, no
+        // map.  (The staged form below -- 86 KB of map read and 86 KB written through the one 64 B/clk path of the CU, a dependent chain
+        // of load, LDS read and store -- took 9.4 k cycles of a launch on config 5; round 4.)
+        const int* const im = reinterpret_cast<const int*>(meta);
+        int Wd[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) Wd[l] = im[EH_IMG_WIDTH + l];
+#pragma unroll
+        for (int mm = 0; mm < MB; ++mm) {
+            const int row0 = 16 * (m0 + mm) + 4 * g;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int wo = im[EH_IMG_WOFF + l], bo = im[EH_IMG_BOFF + l], nrow = Wd[l] - row0, ncol = l == 0 ? net.P : Wd[l - 1];
+                if (nrow > 0) {
+                    if (l == 0) {
+#pragma unroll
+                        for (int n = 0; n < NBI; ++n)
+                            if (16 * n + c < ncol) eh_store_upto4(out + wo + (16 * n + c) * Wd[0] + row0, aW0[mm][n], nrow);
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NBH; ++n)
+                            if (16 * n + c < ncol) eh_store_upto4(out + wo + (16 * n + c) * Wd[l] + row0, aWh[l > 0 ? l - 1 : 0][mm][n], nrow);
+                    }
+                    if (c == 0) eh_store_upto4(out + bo + row0, aB[l][mm], nrow);
+                }
+            }
+            // output layer: rows = the K outputs (4g .. 4g+3 of this lane), columns = this wave's features of the last hidden layer
+            const int col = 16 * (m0 + mm) + c, nk = net.K - 4 * g;
+            if (col < Wd[NL - 1] && nk > 0) eh_store_upto4(out + im[EH_IMG_WOFF + NL] + col * net.K + 4 * g, aWo[mm], nk);
+        }
+        if (wave == 0 && c == 0 && net.K - 4 * g > 0) eh_store_upto4(out + im[EH_IMG_BOFF + NL] + 4 * g, aBo, net.K - 4 * g);
+    } else {
     __syncthreads();
     float* const st = smem + (long long)wave * WL.na * 256 + lane * 4;
     auto putc = [&](int k, const f32x4& v) { *(f32x4*)&st[k * 256] = v; };
@@ -728,7 +763,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
     }
     putc(WL.kbo, aBo);                                // only wave 0's copy is referenced
     __syncthreads();
-    constexpr int GU = 16;                            // independent map loads in flight per thread (each is an L2 round trip)
+    constexpr int GU = 48;                            // independent map loads in flight per thread (each is an L2 round trip; the accumulators are dead by now: registers to spare.  16 -> 48: 0.5 us of a config 5 step)
     for (int i0 = tid; i0 < net.g_off; i0 += GU * NTH) {
         int pos[GU];
 #pragma unroll
@@ -737,6 +772,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
         for (int u = 0; u < GU; ++u)
             if (i0 + u * NTH < net.g_off) out[i0 + u * NTH] = smem[pos[u]];
     }
+    }       // (staged form)
     if (wave == 0) {
         const float lacc = eh_wave_sum(MA.lacc), syacc = eh_wave_sum(MA.syacc), syyacc = eh_wave_sum(MA.syyacc);
         float cacc[EH_MAX_TARG], gacc[EH_MAX_PARAMS];
