@@ -896,6 +896,11 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->max_blocks = (int)value;
         return EH_OK;
     }
+    if (!strcmp(name, "eval_blocks")) {      // workgroups of the evaluation passes (eh_eval / eh_forward); 0 = the default of the kernel family
+        if (value < 0 || value > 4096) return fail(h, EH_EINVAL, "eval_blocks must be 0 (default) .. 4096");
+        h->eval_blocks = (int)value;
+        return EH_OK;
+    }
     if (!strcmp(name, "mech_blocks")) {      // workgroups of the stand-alone mechanistic stage (eh_mech_loss_vjp): rows of partials the finish kernel folds
         if (value < 0 || value > EH_MECH_MAXROWS) return fail(h, EH_EINVAL, "mech_blocks must be 0 (no cap) .. %d", (int)EH_MECH_MAXROWS);
         h->mech_blocks = (int)value;
@@ -1147,6 +1152,20 @@ static int grid_for(const eh_handle* h, long long count) {
     const long long mt = 16LL * v.nt;
     const long long ntiles = (count + mt - 1) / mt;
     return (int)std::max<long long>(1, std::min<long long>((ntiles + (v.tiles ? v.tiles : v.nw) - 1) / (v.tiles ? v.tiles : v.nw), h->max_blocks));
+}
+
+// The evaluation passes hold no gradient accumulators: the per-wave kernels need a quarter to a half of the registers of their training
+// form (headline shape: 60 against 128 VGPRs), so several workgroups fit a CU, and a forward over a whole split is a long chain of
+// dependent per-tile latencies that more resident waves hide.  The row-split kernels fill a CU's LDS with one workgroup: no gain, and every
+// extra workgroup pays the image prologue again.  The metric rows (EH_EVAL_STATS * T floats per workgroup) fit the slab's 4 MB floor.
+static int eval_grid_for(const eh_handle* h, long long count) {
+    const EhVariant& v = h->arch->var[h->variant];
+    const long long mt = 16LL * v.nt, per = v.tiles ? v.tiles : v.nw;
+    const long long ntiles = (count + mt - 1) / mt;
+    int cap = h->max_blocks;
+    if (h->eval_blocks > 0) cap = h->eval_blocks;
+    else if (!h->arch->wide && h->max_blocks == 256) cap = EH_EVAL_BLOCKS;
+    return (int)std::max<long long>(1, std::min<long long>((ntiles + per - 1) / per, cap));
 }
 
 // input BatchNorm: statistics of the minibatch [first, first+count) -> a.bn_* (train-mode kernels only)
@@ -1764,7 +1783,7 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     a.pout = params ? h->out_buf + (yhat ? (long long)net.T * count : 0) : nullptr;
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
-    int grid = count > 0 ? grid_for(h, count) : 1;
+    int grid = count > 0 ? (h->lform ? grid_for(h, count) : eval_grid_for(h, count)) : 1;
     if (h->lform) { if ((rc = lform_eval(h, sp, first, count, a.yhat, a.pout, &grid))) return rc; }
     else HIPCHK(h, step_launch(h, EH_MODE_EVAL, grid, &a));
     std::vector<float> part((size_t)grid * a.n_acc);

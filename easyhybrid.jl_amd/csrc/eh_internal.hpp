@@ -44,6 +44,8 @@ struct EhImg {
 // --------------------------------------------------------------------------------------------
 // handle
 // --------------------------------------------------------------------------------------------
+constexpr int EH_EVAL_BLOCKS = 1024;      // evaluation passes of the per-wave kernels: up to four workgroups per CU (eval_grid_for, eh_api.hip)
+
 struct EhSplit {
     float* recs = nullptr;
     long long n = 0;
@@ -165,6 +167,7 @@ struct eh_handle_s {
     bool capturing = false;
     GraphRec cap{};
     int max_blocks = 256;
+    int eval_blocks = 0;            // "eval_blocks" option: workgroups of eh_eval / eh_forward (0 = per kernel family, eval_grid_for)
     int mech_blocks = 0;            // "mech_blocks" option: cap on the streaming kernel's workgroups (0: none -- one workgroup per `mech_tiles` tiles)
     int mech_tiles = 0;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup (0: by model -- 2, multi-output models 8)
     // scratch for forward / eval outputs

@@ -16,6 +16,7 @@ ap.add_argument("--variant", type=int, default=-1)
 ap.add_argument("--specialize", type=int, default=0)
 ap.add_argument("--row-split", type=int, default=0)
 ap.add_argument("--precision", default="", help="c5: bf16_fwd (default: bf16 forward, fp32-exact backward), bf16 (bf16 operands in both passes) or f32")
+ap.add_argument("--epoch", type=int, default=0, help="also time N epochs of eh_train_epoch, contiguous and shuffled (what train() runs: every step gathers its records through the epoch's permutation)")
 ap.add_argument("--n", type=int, default=0, help="resident samples (c5 default: 152 batches ~ 1e7 as BASELINE states; others nbatches * batch)")
 a = ap.parse_args()
 if a.config == "c3":
@@ -63,6 +64,17 @@ if a.config == "c5":
     # the bf16 modes run every product on the bf16 MFMA: priced against its dense peak (2 516 TFLOP/s, MI355X_MICROARCH.md); f32 against the fp32 one
     extra = {"precision": prec, "resident_samples": a.nbatches * B}
 peak, pname = (2516.6, "frac_bf16_peak") if (a.config == "c5" and prec != "f32") else (157.3, "frac_f32_peak")
+if a.epoch:
+    for name, shuffle in (("contiguous", False), ("shuffled", True)):
+        for k in range(2):
+            eng.train_epoch(B, seed=11 + k, shuffle=shuffle, want_loss=False)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.epoch):
+            eng.train_epoch(B, seed=21 + k, shuffle=shuffle, want_loss=False)
+        eng.synchronize()
+        extra["epoch_us_per_step_" + name] = 1e6 * (time.perf_counter() - t0) / (a.epoch * a.nbatches)
+    extra["shuffled_over_contiguous"] = extra["epoch_us_per_step_shuffled"] / extra["epoch_us_per_step_contiguous"]
 print(json.dumps({**extra, "config": a.config, "batch": B, "fused": a.fused, "specialize": a.specialize, "us_per_step": us, "samples_per_s": B / us * 1e6,
                   "algorithmic_TFLOPs": flop * B / us / 1e6, pname: flop * B / us / 1e6 / peak,
                   "algorithmic_GBps": byts * B / us / 1e3, "final_loss": eng.train_step(0, B)}))
