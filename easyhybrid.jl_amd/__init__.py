@@ -6,7 +6,7 @@ the root-level shim module `easyhybrid_jl_amd` (import easyhybrid_jl_amd as eh).
 """
 from . import _lib
 from .engine import EngineError, HybridEngine, PerTarget
-from .models import (Expo2Pool, Expo_resp_model, FluxPartModelQ10, HybridModel, LinearHM, MECH_REGISTRY, MultiNNHybridModel, ParameterContainer, RbQ10,
+from .models import (Chain, Dense, Expo2Pool, Expo_resp_model, FluxPartModelQ10, HybridModel, LinearHM, MECH_REGISTRY, MultiNNHybridModel, ParameterContainer, RbQ10,
                      Rs_components, Rs_components3F, SingleNNHybridModel, build_parameters, constructHybridModel, hard_sigmoid,
                      inv_hard_sigmoid, inv_sigmoid, scale_single_param, scale_single_param_minmax, sigmoid)
 from .train import (Adam, AdamW, DataConfig, Descent, EpochSnapshot, RMSProp, TrainConfig, TrainResults, WeightL2,

@@ -191,6 +191,46 @@ def _act_name(a) -> str:
     return _ACT_ALIASES[name]
 
 
+class Dense:
+    """Lux `Dense(in => out, activation)` as a DESCRIPTION of a layer (no weights): what `hidden_layers = Chain(...)` is made of."""
+
+    def __init__(self, in_dims: int, out_dims: int, activation="identity"):
+        self.in_dims, self.out_dims, self.activation = int(in_dims), int(out_dims), activation
+
+    def __repr__(self):
+        return f"Dense({self.in_dims} => {self.out_dims}, {self.activation if isinstance(self.activation, str) else getattr(self.activation, '__name__', self.activation)})"
+
+
+class Chain:
+    """`hidden_layers::Chain` (NNModels.jl:145-219): the user gives the HIDDEN layers only; the reference wraps them as
+    Dense(in_dim, first_h, activation) -> layers... -> Dense(last_h, out_dim), first_h / last_h read off the chain's own dimensions."""
+
+    def __init__(self, *layers):
+        self.layers = list(layers)
+
+
+def _hidden_widths(hidden_layers, act: str) -> List[int]:
+    """hidden_layers as the vector of widths the device kernels are built around.  A Chain of Dense layers that all use the model's
+    `activation` IS such a vector -- [first_h, out_1, ..., out_n] (NNModels.jl:205-211) -- and is taken; anything else a Lux Chain may
+    hold (other layer types, an activation per layer) has no kernel and is refused with the reason."""
+    if isinstance(hidden_layers, Chain):
+        ls = hidden_layers.layers
+        if not ls:
+            raise ValueError("hidden_layers: an empty Chain has no dimensions (NNModels.jl: 'Could not determine input dimension of hidden_layers Chain.')")
+        for i, l in enumerate(ls):
+            if not isinstance(l, Dense):
+                raise NotImplementedError(f"hidden_layers Chain: layer {i + 1} is {type(l).__name__}; only Dense layers have a device kernel")
+            if _act_name(l.activation) != act:
+                raise NotImplementedError(f"hidden_layers Chain: layer {i + 1} uses {_act_name(l.activation)!r}, the model {act!r}: the fused kernels "
+                                          "apply ONE activation to all hidden layers of a network (per NETWORK activations exist: activation = {...})")
+            if i and l.in_dims != ls[i - 1].out_dims:
+                raise ValueError(f"hidden_layers Chain: layer {i + 1} takes {l.in_dims} inputs, layer {i} gives {ls[i - 1].out_dims}")
+        return [ls[0].in_dims] + [l.out_dims for l in ls]
+    if not isinstance(hidden_layers, (list, tuple)):
+        raise NotImplementedError(f"hidden_layers of type {type(hidden_layers).__name__}: pass the widths or a Chain of Dense layers")
+    return [int(h) for h in hidden_layers]
+
+
 @dataclass
 class SingleNNHybridModel:
     """Field-for-field mirror of the reference struct (GenericHybridModel.jl:44-63); `NN` is the
@@ -418,7 +458,10 @@ def _construct_multi(predictors: Dict[str, Sequence[str]], forcing, targets, mec
             net_acts = None
     else:
         act = _act_name(activation)
-    hl = {k: list(hidden_layers[k]) for k in neural} if isinstance(hidden_layers, dict) else {k: list(hidden_layers) for k in neural}
+    acts_k = dict(zip(neural, net_acts)) if net_acts is not None else {k: act for k in neural}
+    hl = ({k: _hidden_widths(hidden_layers[k], acts_k[k]) for k in neural} if isinstance(hidden_layers, dict)
+          else {k: _hidden_widths(hidden_layers, acts_k[k]) for k in neural})
+    hidden_layers = hl if isinstance(hidden_layers, dict) else next(iter(hl.values()), [])
     if any(len(v) < 1 for v in hl.values()):
         raise NotImplementedError("a network without a hidden layer")
     for p in ms.params:
@@ -492,10 +535,9 @@ def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[s
     for t in targets:
         if t not in ms.outputs:
             raise ValueError(f"target {t!r} is not an output of {ms.name} {ms.outputs}")
-    if not isinstance(hidden_layers, (list, tuple)):
-        raise NotImplementedError("hidden_layers given as a Lux Chain is not supported; pass the widths")
     act = _act_name(activation)
-    dims = [len(predictors)] + [int(h) for h in hidden_layers] + [len(neural_param_names)]
+    hidden_layers = _hidden_widths(hidden_layers, act)
+    dims = [len(predictors)] + hidden_layers + [len(neural_param_names)]
     NN = [] if no_nn else [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
     if no_nn:
         input_batchnorm = False                                  # (nothing to normalise: the predictors feed no network)
