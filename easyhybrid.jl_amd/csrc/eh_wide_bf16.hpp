@@ -307,21 +307,37 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
             epk[k] = dst | (col << 16) | (smp << 24);
         }
     }
+    // (branch-free on purpose: a dead element -- beyond the tile's C columns, the window's end or the last tile -- reads word 0 of the
+    //  window, which exists whenever count > 0, and is replaced by a select; with the loads under per-element conditions the compiler
+    //  built five exec-masked regions with a memory wait each: 1.6 k cycles per tile for this phase, measured with the stamps)
     auto fetch_idx = [&](int tile) {
         if (!a.idx) return;
 #pragma unroll
         for (int k = 0; k < NEL; ++k) {
             const int s_loc = tile * MT + (epk[k] >> 24);
-            nidx[k] = (epk[k] >= 0 && tile < ntiles && s_loc < count) ? a.idx[first + s_loc] : 0;
+            const bool on = epk[k] >= 0 && tile < ntiles && s_loc < count;
+            const int v = a.idx[first + (on ? s_loc : 0)];
+            nidx[k] = on ? v : 0;
         }
     };
     auto fetch = [&](int tile) {      // data of `tile` (its gather indices are already in nidx), then the indices one tile further
+        // (a dead element's word is replaced where it is consumed, one tile later: a select right here and the compiler turns it back
+        //  into a branch around the load)
+        if (!a.idx) {         // a window of consecutive records: one scalar base per tile, the element's constant offset beside it
+            const bool in = tile < ntiles;
+            const float* const tb = a.recs + (long long)(first + (in ? tile : 0) * MT) * C;
 #pragma unroll
-        for (int k = 0; k < NEL; ++k) {
-            const int col = (epk[k] >> 16) & 0xFF, s_loc = tile * MT + (epk[k] >> 24);
-            const bool live = epk[k] >= 0 && tile < ntiles && s_loc < count;
-            const long long src = a.idx ? (long long)nidx[k] * C + col : (long long)(first + tile * MT) * C + (tid + k * NTH);
-            nx[k] = live ? a.recs[src] : (col >= net.P + net.F ? __builtin_nanf("") : 0.0f);
+            for (int k = 0; k < NEL; ++k) {
+                const bool live = epk[k] >= 0 && in && tile * MT + (epk[k] >> 24) < count;
+                nx[k] = tb[live ? tid + k * NTH : 0];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NEL; ++k) {
+                const int col = (epk[k] >> 16) & 0xFF, s_loc = tile * MT + (epk[k] >> 24);
+                const bool live = epk[k] >= 0 && tile < ntiles && s_loc < count;
+                nx[k] = a.recs[live ? (long long)nidx[k] * C + col : 0LL];
+            }
         }
         fetch_idx(tile + (int)gridDim.x);
     };
@@ -473,14 +489,25 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
         const int n_loc = tile * MT + lane;
         const bool live = mechw && (n_loc < count);
         // ---- 1. records -> normalised, rounded predictor image + forcing / target rows; next tile's records in flight
+        {
+            // every element stores twice, once for real and once into a padding word no one reads (XB row 0 column KP0; RS row 0 column MT):
+            // straight-line code, the normalisation constants of all elements read from the image in one LDS round trip
+            float bm[NEL], br[NEL];
 #pragma unroll
-        for (int k = 0; k < NEL; ++k)
-            if (epk[k] >= 0) {
+            for (int k = 0; k < NEL; ++k) {
                 const int col = (epk[k] >> 16) & 0xFF;
-                const float v = nx[k];
-                if (col < net.P) XB[epk[k] & 0xFFFF] = (__bf16)((v - meta[EH_IMG_BNM + col]) * meta[EH_IMG_BNR + col]);
-                else RS[epk[k] & 0xFFFF] = v;
+                const int cm = (epk[k] >= 0 && col < net.P) ? col : 0;
+                bm[k] = meta[EH_IMG_BNM + cm]; br[k] = meta[EH_IMG_BNR + cm];
             }
+#pragma unroll
+            for (int k = 0; k < NEL; ++k) {
+                const int col = (epk[k] >> 16) & 0xFF, dst = epk[k] & 0xFFFF;
+                const bool isx = epk[k] >= 0 && col < net.P, isr = epk[k] >= 0 && col >= net.P;
+                const float v = tile * MT + (epk[k] >> 24) < count ? nx[k] : (col >= net.P + net.F ? __builtin_nanf("") : 0.0f);      // beyond the window's end: no sample
+                XB[isx ? dst : KP0] = (__bf16)((v - bm[k]) * br[k]);
+                RS[isr ? dst : MT] = v;
+            }
+        }
         fetch(tile + (int)gridDim.x);
         eh_lds_barrier();
         EH_STAMP(1);
