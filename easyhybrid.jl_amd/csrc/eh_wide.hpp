@@ -105,21 +105,34 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
             epk[k] = dst | (col << 16) | (smp << 24);
         }
     }
+    // (straight-line code on purpose, as in eh_wide_bf16.hpp: a dead element -- beyond the tile's C columns, the window's end or the last
+    //  tile -- reads word 0 of the window, which exists whenever count > 0, and is replaced where it is consumed, one tile later)
     auto fetch_idx = [&](int tile) {
         if (!a.idx) return;
 #pragma unroll
         for (int k = 0; k < NEL; ++k) {
             const int s_loc = tile * MT + (epk[k] >> 24);
-            nidx[k] = (epk[k] >= 0 && tile < ntiles && s_loc < count) ? a.idx[first + s_loc] : 0;
+            const bool on = epk[k] >= 0 && tile < ntiles && s_loc < count;
+            const int v = a.idx[first + (on ? s_loc : 0)];
+            nidx[k] = on ? v : 0;
         }
     };
     auto fetch = [&](int tile) {      // data of `tile` (its gather indices are already in nidx), then the indices one tile further
+        if (!a.idx) {         // a window of consecutive records: one scalar base per tile, the element's constant offset beside it
+            const bool in = tile < ntiles;
+            const float* const tb = a.recs + (long long)(first + (in ? tile : 0) * MT) * C;
 #pragma unroll
-        for (int k = 0; k < NEL; ++k) {
-            const int col = (epk[k] >> 16) & 0xFF, s_loc = tile * MT + (epk[k] >> 24);
-            const bool live = epk[k] >= 0 && tile < ntiles && s_loc < count;
-            const long long src = a.idx ? (long long)nidx[k] * C + col : (long long)(first + tile * MT) * C + (tid + k * NTH);
-            nx[k] = live ? a.recs[src] : (col >= net.P + net.F ? __builtin_nanf("") : 0.0f);
+            for (int k = 0; k < NEL; ++k) {
+                const bool live = epk[k] >= 0 && in && tile * MT + (epk[k] >> 24) < count;
+                nx[k] = tb[live ? tid + k * NTH : 0];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NEL; ++k) {
+                const int col = (epk[k] >> 16) & 0xFF, s_loc = tile * MT + (epk[k] >> 24);
+                const bool live = epk[k] >= 0 && tile < ntiles && s_loc < count;
+                nx[k] = a.recs[live ? (long long)nidx[k] * C + col : 0LL];
+            }
         }
         fetch_idx(tile + (int)gridDim.x);
     };
@@ -222,14 +235,23 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt
         const int n_loc = tile * MT + lane;
         const bool live = mechw && (n_loc < count);
         // ---- 1. records -> normalised [feature][sample] image + forcing / target rows; next tile's records in flight
+        {
+            // the normalisation constants of all elements in one LDS round trip; an element this thread does not own stores into a padding
+            // word (row 0 of the predictor image, column MT) that no one reads
+            float bm[NEL], br[NEL];
 #pragma unroll
-        for (int k = 0; k < NEL; ++k)
-            if (epk[k] >= 0) {
+            for (int k = 0; k < NEL; ++k) {
                 const int col = (epk[k] >> 16) & 0xFF;
-                float v = nx[k];
-                if (col < net.P) v = (v - meta[EH_IMG_BNM + col]) * meta[EH_IMG_BNR + col];
-                ws[epk[k] & 0xFFFF] = v;
+                const int cm = (epk[k] >= 0 && col < net.P) ? col : 0;
+                bm[k] = meta[EH_IMG_BNM + cm]; br[k] = meta[EH_IMG_BNR + cm];
             }
+#pragma unroll
+            for (int k = 0; k < NEL; ++k) {
+                const int col = (epk[k] >> 16) & 0xFF;
+                const float v = tile * MT + (epk[k] >> 24) < count ? nx[k] : (col >= net.P + net.F ? __builtin_nanf("") : 0.0f);      // beyond the window's end: no sample
+                ws[epk[k] >= 0 ? (epk[k] & 0xFFFF) : G::XS_OFF + MT] = (epk[k] >= 0 && col < net.P) ? (v - bm[k]) * br[k] : v;
+            }
+        }
         fetch(tile + (int)gridDim.x);
         eh_lds_barrier();
         EH_STAMP(1);
