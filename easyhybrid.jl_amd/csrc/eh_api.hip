@@ -896,6 +896,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->max_blocks = (int)value;
         return EH_OK;
     }
+    if (!strcmp(name, "bn_in_kernel")) {     // 0: always launch eh_bn_stats_kernel in front of a step with input BatchNorm (A/B, tests); 1 (default): small minibatches take their statistics inside the step kernel
+        h->bn_no_self = value == 0;
+        return EH_OK;
+    }
     if (!strcmp(name, "eval_blocks")) {      // workgroups of the evaluation passes (eh_eval / eh_forward); 0 = the default of the kernel family
         if (value < 0 || value > 4096) return fail(h, EH_EINVAL, "eval_blocks must be 0 (default) .. 4096");
         h->eval_blocks = (int)value;
@@ -1180,6 +1184,10 @@ static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long
         return EH_OK;
     }
     if (count <= 0) return EH_OK;
+    if (!h->arch->wide && !h->lform && count <= EH_BN_SELF_MAX && !h->bn_no_self) {      // small minibatch, per-wave kernel: the step kernel takes the statistics itself
+        a->bn_nblk = -1; a->bn_update = update ? 1 : 0;
+        return EH_OK;
+    }
     const int nblk = (int)std::max<long long>(1, std::min<long long>(32, (count + 1023) / 1024));
     hipLaunchKernelGGL(eh_bn_stats_kernel, dim3(nblk), dim3(1024), 0, h->stream, sp.recs, h->C, h->net.P, idx, (int)first, (int)count, h->bn_part, nullptr);
     HIPCHK(h, hipGetLastError());

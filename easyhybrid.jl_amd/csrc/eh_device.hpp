@@ -30,6 +30,7 @@
 
 #include "easyhybrid_hip.h"   // public enums and EH_MAX_* limits
 
+#define EH_BN_SELF_MAX 512   // input BatchNorm: minibatches up to this size get their statistics inside the per-wave step kernel (no eh_bn_stats_kernel launch)
 #define EH_EVAL_STATS 8   // per target: S=sum m(yh-y)^2, sum(y-c), sum(y-c)^2, n, sum(yh-c), sum(yh-c)^2, sum(yh-c)(y-c), sum|yh-y|
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -163,7 +164,7 @@ struct EhStepArgs {
     EhFused fz;
     // input BatchNorm, train mode: per-workgroup partial sums of the batch from eh_bn_stats_kernel
     const float* bn_part;   // [bn_nblk][64] (sum (x-c), sum (x-c)^2 per predictor); nullptr = use the image's statistics
-    int bn_nblk;
+    int bn_nblk;            // -1 (with bn_part == nullptr): the step kernel takes the statistics of the minibatch itself (count <= EH_BN_SELF_MAX)
     const float* bn_c;      // [32] the shift c the partial sums were taken around
     const float* bn_n;      // number of samples behind the sums when it is not `count` (cross-GPU statistics), else nullptr
     int bn_update;          // workgroup 0 also updates the running statistics (a real training step)
@@ -849,14 +850,47 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             __syncthreads();                                     // T lives where the X images are about to be cleared
         }
     }
+    // small minibatches (a.bn_nblk == -1, count <= EH_BN_SELF_MAX: the reference's tutorial trains on 64): every workgroup takes the
+    // statistics of the whole minibatch itself -- thread (g, p) sums predictor p over the samples g, g + NTHR / 32, ... about the first
+    // sample's value -- instead of waiting for a launch of eh_bn_stats_kernel in front of the step (a dependent launch costs more than
+    // the step's own work at this size); same sums in every workgroup, so the replicas of the image stay identical
+    const bool bn_self = a.bn_nblk == -1;
+    static_assert((NTHR / 32 + 1) * 64 <= NW * G::WAVE_WS, "the statistics scratch fits the waves' work space");
+    float* const bn_red = smem + G::IMG_FLOATS;                  // [NTHR / 32][64], in the (not yet cleared) X images
+    if (bn_self) {
+        const int p = tid & 31, grp = tid >> 5;
+        float s1 = 0.0f, s2 = 0.0f;
+        if (p < net.P) {
+            const long long n0 = a.idx ? (long long)a.idx[a.first] : a.first;
+            const float c0 = a.recs[n0 * a.C + p];
+#pragma unroll 8
+            for (int i = grp; i < count; i += NTHR / 32) {
+                const long long n = a.idx ? (long long)a.idx[a.first + i] : a.first + i;
+                const float d = a.recs[n * a.C + p] - c0;
+                s1 += d; s2 += d * d;
+            }
+        }
+        bn_red[grp * 64 + p] = s1; bn_red[grp * 64 + 32 + p] = s2;
+        __syncthreads();
+        if (tid < net.P) {
+            s1 = 0.0f; s2 = 0.0f;
+            for (int b = 0; b < NTHR / 32; ++b) { s1 += bn_red[b * 64 + tid]; s2 += bn_red[b * 64 + 32 + tid]; }
+            bn_red[(NTHR / 32) * 64 + tid] = s1; bn_red[(NTHR / 32) * 64 + 32 + tid] = s2;      // parked across the clearing of the X images below
+        }
+        __syncthreads();
+    }
+    float bn_s1 = 0.0f, bn_s2 = 0.0f;
+    if (bn_self && tid < net.P) { bn_s1 = bn_red[(NTHR / 32) * 64 + tid]; bn_s2 = bn_red[(NTHR / 32) * 64 + 32 + tid]; }
+    __syncthreads();
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
     __syncthreads();
-    if (a.bn_part) {
+    if (a.bn_part || bn_self) {
         // input BatchNorm, train mode (Lux BatchNorm, affine = false): statistics of THIS minibatch
         if (tid < net.P) {
-            float s1 = 0.0f, s2 = 0.0f;
-            for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
-            const float m = a.bn_n ? *a.bn_n : (float)count, c0 = a.bn_c[tid];
+            float s1 = bn_s1, s2 = bn_s2;
+            if (!bn_self) for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
+            const float m = a.bn_n ? *a.bn_n : (float)count;
+            const float c0 = bn_self ? a.recs[(a.idx ? (long long)a.idx[a.first] : a.first) * a.C + tid] : a.bn_c[tid];
             const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
             wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
             wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);

@@ -167,6 +167,7 @@ struct eh_handle_s {
     bool capturing = false;
     GraphRec cap{};
     int max_blocks = 256;
+    bool bn_no_self = false;        // "bn_in_kernel" 0
     int eval_blocks = 0;            // "eval_blocks" option: workgroups of eh_eval / eh_forward (0 = per kernel family, eval_grid_for)
     int mech_blocks = 0;            // "mech_blocks" option: cap on the streaming kernel's workgroups (0: none -- one workgroup per `mech_tiles` tiles)
     int mech_tiles = 0;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup (0: by model -- 2, multi-output models 8)

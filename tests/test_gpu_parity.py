@@ -846,6 +846,42 @@ def test_input_batchnorm_training_trajectory_and_running_statistics(fused):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [64, 257, 512, 513])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_input_batchnorm_statistics_inside_the_step_kernel(B, fused):
+    """minibatches of up to 512 samples (the reference's tutorial trains on 64: docs/literate/tutorials/synthetic_respiration_gpu.jl:79-104)
+    take their BatchNorm statistics inside the per-wave step kernel, larger ones from a launch in front of it: both against the oracle, on
+    a window off the start, on gathered indices, through a training trajectory with the running statistics, and against each other"""
+    spec, theta, X, f, y = _bn_case(2100, seed=23)
+    th64 = theta.astype(np.float64)
+    res = []
+    for in_kernel in (1, 0):
+        eng = util.load_engine(spec, theta, X, f, y); eng.set_option("bn_in_kernel", in_kernel)
+        sl = slice(77, 77 + B)
+        l, g, nv = eng.loss_and_grad(first=77, count=B)
+        l0, g0, _ = ho.loss_and_grad(spec, th64, X[:, sl], {"ta": f["ta"][sl]}, {"reco": y["reco"][sl]})
+        assert l == pytest.approx(l0, rel=TOL) and util.relerr(g, g0) <= TOL
+        eng.opt_init("Adam", 0.01); eng.set_option("fused_update", fused)
+        rng = np.random.default_rng(5)
+        ix = [rng.choice(2100, B, replace=False).astype(np.int32) for _ in range(4)]
+        losses = [eng.train_step(0, B, idx=i) for i in ix]
+        cat = np.concatenate(ix)                                         # the oracle steps over the same gathered minibatches, laid end to end
+        st = ho.bn_init(spec)
+        th_ref, l_ref = ho.train_steps(spec, theta, X[:, cat], {"ta": f["ta"][cat]}, {"reco": y["reco"][cat]}, [(k * B, B) for k in range(4)],
+                                       dtype=np.float32, bn_state=st)
+        assert np.allclose(losses, l_ref, rtol=1e-4)
+        assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+        rm, rv = eng.get_bn_state()
+        assert util.relerr(rm, st["mean"]) <= 1e-5 and util.relerr(rv, st["var"]) <= 1e-5
+        eng.synchronize()
+        res.append((l, g, np.array(losses), eng.get_params(), eng.get_bn_state()))
+        eng.close()
+    (l1, g1, ls1, t1, (rm1, rv1)), (l0_, g0_, ls0, t0, (rm0, rv0)) = res
+    assert abs(l1 - l0_) <= 2e-6 * abs(l0_) and util.relerr(g1, g0_) <= 2e-6
+    assert np.allclose(ls1, ls0, rtol=2e-5) and np.max(np.abs(t1 - t0)) <= 2e-5
+    assert util.relerr(rm1, rm0) <= 1e-6 and util.relerr(rv1, rv0) <= 1e-6
+
+
 def test_readme_quickstart_configuration_trains():
     # README.md:185-201: hidden [16,16], sigmoid/tanh, scale_nn_outputs = true, input_batchnorm = true on RAW predictors
     cols = eh.synthetic.make_synth_rbq10(4000, seed=8, nan_frac=0.05)
