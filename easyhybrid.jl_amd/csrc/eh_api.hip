@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -388,6 +389,27 @@ int32_t eh_version(void) { return EH_ABI_VERSION; }
 
 const char* eh_last_error(const eh_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+// Streams of destroyed handles are kept for the next handle on the same device: creating one takes 1.4-1.9 ms and destroying it as long
+// again -- a fifth of a whole train() call on the reference's tutorial data set, which creates and destroys one engine per call.  At most
+// eight per device are kept (more are destroyed); the kept ones live until the process ends.
+static std::mutex g_stream_pool_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+static hipStream_t stream_pool_take(int device) {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+        if (g_stream_pool[i].first == device) { hipStream_t s = g_stream_pool[i].second; g_stream_pool.erase(g_stream_pool.begin() + (long)i); return s; }
+    return nullptr;
+}
+static void stream_pool_give(int device, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        int kept = 0;
+        for (auto& e : g_stream_pool) kept += e.first == device;
+        if (kept < 8 && !getenv("EH_NO_STREAM_POOL")) { g_stream_pool.emplace_back(device, s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     if (!d || !out) return fail(nullptr, EH_EINVAL, "eh_create: null argument");
     *out = nullptr;
@@ -622,10 +644,21 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
             return e_ == hipErrorOutOfMemory ? EH_ENOMEM : EH_EHIP;               \
         }                                                                         \
     } while (0)
+    const bool ctrace = getenv("EH_CREATE_TRACE") != nullptr;          // diagnostics: where eh_create's milliseconds go
+    auto ct0 = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!ctrace) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[eh_create] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - ct0).count());
+        ct0 = t;
+    };
     HIPCHK_C(hipSetDevice(h->device));
-    HIPCHK_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    tick("hipSetDevice");
+    if (!(h->own_stream = stream_pool_take(h->device))) HIPCHK_C(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    tick("stream");
     h->stream = h->own_stream;
     for (int vi = 0; vi < arch->nvar; ++vi) HIPCHK_C(arch->var[vi].prepare());
+    tick("kernel attributes");
     if (const char* ej = getenv("EH_JIT")) h->jit_on = atoi(ej) != 0;
     if (const char* es = getenv("EH_SPECIALIZE")) h->specialize = atoi(es) != 0;      // (test runs: the whole suite on specialised kernels)
     if (getenv("EH_NO_AOT_SPEC")) h->aot_spec = false;                                // (A/B: the generic / run-time compiled kernels for a canonical descriptor)
@@ -660,6 +693,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMalloc(&h->gacc, ((size_t)3 * EH_GSHARDS * h->n_acc + 4) * sizeof(float)));      // (+4: the fused prologue reads five tail floats of every shard whatever T is)
         HIPCHK_C(hipMemset(h->gacc, 0, ((size_t)3 * EH_GSHARDS * h->n_acc + 4) * sizeof(float)));
     }
+    tick("pset / bn / gacc");
     h->slab_rows = lform ? (int)EH_LFORM_ROWS : h->max_blocks;
     HIPCHK_C(hipMalloc(&h->slab, (std::max((size_t)h->slab_rows * std::max(h->n_acc, EH_EVAL_STATS * n.T), (size_t)1 << 20) + 16) * sizeof(float)));      // (>= 4 MB: the evaluation passes park their per-workgroup metric sums here)
     HIPCHK_C(hipMalloc(&h->gradbuf, (size_t)h->n_acc * sizeof(float)));
@@ -670,6 +704,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     HIPCHK_C(hipMalloc(&h->inv_n, EH_TT * EH_MAX_TARG * sizeof(float)));      // the per-target table (EhStepArgs::inv_n): weight, centre of yhat, k0 k1 k2, loss of every target
     HIPCHK_C(hipMemset(h->inv_n, 0, EH_TT * EH_MAX_TARG * sizeof(float)));
     HIPCHK_C(hipMemset(h->gradbuf, 0, (size_t)h->n_acc * sizeof(float)));
+    tick("slab + small buffers");
     if (!lform) { if (int rc = build_maps(h, true)) { g_create_err = h->err; eh_destroy(h); return rc; } }
     else {
         std::vector<unsigned char> wf((size_t)n.n_theta, 0);
@@ -678,6 +713,7 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
         HIPCHK_C(hipMalloc(&h->wflag, wf.size()));
         HIPCHK_C(hipMemcpy(h->wflag, wf.data(), wf.size(), hipMemcpyHostToDevice));
     }
+    tick("maps");
     {   // parameter image (constant parts; theta is mirrored into it by eh_image_kernel / the optimiser)
         std::vector<float> img0((size_t)arch->img_floats, 0.0f);
         for (int j = 0; j < d->n_params; ++j) {
@@ -716,9 +752,12 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
                 const int g = d->param_index[j];
                 im.glob_par[g] = j; im.glo[g] = d->param_lower[j]; im.ghi[g] = d->param_upper[j];
             }
+        tick("image");
         hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, TH(h), (int)nt, h->img);
         HIPCHK_C(hipGetLastError());
+        tick("image kernel launch");
         HIPCHK_C(hipStreamSynchronize(h->stream));
+        tick("synchronize");
     }
 #undef HIPCHK_C
     if (h->act == EH_ACT_PER_NET && !h->lform && !jit_entry(h)) {         // built now, so that a missing run-time compiler is an error of the constructor
@@ -745,7 +784,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->l_lprog); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream) stream_pool_give(h->device, h->own_stream);      // (drained above; the next handle on this device takes it over)
     delete h;
     return EH_OK;
 }
@@ -1036,6 +1075,7 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
     if (!h) return EH_EINVAL;
     if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_set_data: split %d", split);
     if (n < 0 || n > 0x7fffffffLL) return fail(h, EH_EINVAL, "eh_set_data: n = %lld", (long long)n);
+    if (on_device & ~(EH_DATA_ON_DEVICE | EH_DATA_X_PLANES)) return fail(h, EH_EINVAL, "eh_set_data: flags %d", on_device);
     if (n > 0 && ((!x && h->net.P > 0) || !forcings || !targets)) return fail(h, EH_EINVAL, "eh_set_data: null array");
     const EhNet& net = h->net;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1047,13 +1087,15 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
     if (n == 0) return EH_OK;
     const int C = h->C;
     HIPCHK(h, hipMalloc(&sp.recs, (size_t)n * C * sizeof(float)));
+    const bool planes = (on_device & EH_DATA_X_PLANES) != 0;       // x as P arrays of N (row-major P x N: what a NumPy host holds) instead of N records of P
+    on_device &= EH_DATA_ON_DEVICE;
     if (on_device) {
         EhPackArgs pa{};
         pa.x = x;
         for (int f = 0; f < net.F; ++f) pa.forc[f] = forcings[f];
         for (int t = 0; t < net.T; ++t) pa.targ[t] = targets[t];
         const long long tot = (long long)n * C;
-        hipLaunchKernelGGL(eh_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, pa, sp.recs, (long long)n, net.P, net.F, net.T);
+        hipLaunchKernelGGL(eh_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, pa, sp.recs, (long long)n, net.P, net.F, net.T, planes ? 1 : 0);
         HIPCHK(h, hipGetLastError());
         // metric shift: mean of the first valid targets, computed from a small host copy
         std::vector<float> tmp((size_t)std::min<int64_t>(n, 4096));
@@ -1093,7 +1135,8 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
         auto pack = [&](float* dst, int64_t s0, int64_t s1, int64_t base) {
             for (int64_t s = s0; s < s1; ++s) {
                 float* r = dst + (size_t)(s - base) * C;
-                for (int j = 0; j < P; ++j) r[j] = x[(size_t)s * P + j];
+                if (planes) for (int j = 0; j < P; ++j) r[j] = x[(size_t)j * (size_t)n + (size_t)s];
+                else for (int j = 0; j < P; ++j) r[j] = x[(size_t)s * P + j];
                 for (int f = 0; f < F; ++f) r[P + f] = forcings[f][s];
                 for (int t = 0; t < T; ++t) r[P + F + t] = targets[t][s];
             }

@@ -789,14 +789,14 @@ struct EhPackArgs {
     const float* forc[EH_MAX_FORC];
     const float* targ[EH_MAX_TARG];
 };
-__global__ void eh_pack_kernel(EhPackArgs a, float* recs, long long n, int P, int F, int T) {
+__global__ void eh_pack_kernel(EhPackArgs a, float* recs, long long n, int P, int F, int T, int planes) {
     const int C = P + F + T;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * C) return;
     const long long s = e / C;
     const int j = (int)(e % C);
     float v;
-    if (j < P) v = a.x[s * P + j];
+    if (j < P) v = planes ? a.x[(long long)j * n + s] : a.x[s * P + j];
     else if (j < P + F) v = a.forc[j - P][s];
     else v = a.targ[j - P - F][s];
     recs[e] = v;

@@ -44,6 +44,33 @@ class PerTarget:
         self.losses = tuple(losses)
 
 
+class _LazySums(dict):
+    """split -> sums over that split's host arrays, computed at the first read (the arrays are referenced until then or until the split is replaced)"""
+
+    def __init__(self, fn):
+        super().__init__()
+        self._fn, self._src = fn, {}
+
+    def put(self, key, src):
+        self._src[key] = src
+        dict.pop(self, key, None)
+
+    def _materialise(self, key):
+        if key in self._src:
+            dict.__setitem__(self, key, self._fn(*self._src.pop(key)))
+
+    def get(self, key, default=None):
+        self._materialise(key)
+        return dict.get(self, key, default)
+
+    def __getitem__(self, key):
+        self._materialise(key)
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return key in self._src or dict.__contains__(self, key)
+
+
 class HybridEngine:
     """Device-resident hybrid model: parameters, optimiser state and datasets live in HBM."""
 
@@ -67,8 +94,8 @@ class HybridEngine:
         self.extra_entries = []
         self.param_names = list(param_names)
         self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
-        self.x_sum = {}
-        self.y_sum = {}
+        self.x_sum = _LazySums(lambda X, N: (X.sum(axis=1, dtype=np.float64), N))
+        self.y_sum = _LazySums(lambda ts: np.array([[np.nansum(t, dtype=np.float64), np.count_nonzero(~np.isnan(t))] for t in ts], np.float64))   # (sum, n valid) per target
         if os.environ.get("EH_MAX_BLOCKS"):               # several ranks sharing one GPU (tests): every kernel must fit beside the others
             self.set_option("max_blocks", int(os.environ["EH_MAX_BLOCKS"]))
 
@@ -107,9 +134,11 @@ class HybridEngine:
         if len(forcings) != self.desc.n_forcings or len(targets) != len(self.target_names):
             raise ValueError("number of forcing / target arrays does not match the model")
         targets = list(targets) + [np.zeros(N, np.float32)] * self.n_pseudo      # an extra-loss entry "observes" every sample (no NaN)
-        self.x_sum[split] = (X.sum(axis=1, dtype=np.float64), N)      # for the common BatchNorm shift under data parallelism
-        self.y_sum[split] = np.array([[np.nansum(t, dtype=np.float64), np.count_nonzero(~np.isnan(t))] for t in targets], np.float64)   # (sum, n valid) per target: common target shift
-        xf = np.asfortranarray(X)                       # (P x N) column-major == N records of P
+        # sums only the data-parallel driver asks for (common BatchNorm shift, common target shift): taken when they are asked for --
+        # two more passes over 4 M rows are a tenth of a short train() call
+        self.x_sum.put(split, (X, N))
+        self.y_sum.put(split, (list(targets),))
+        xf = np.ascontiguousarray(X)                    # row-major (P, N): handed over as P planes (EH_DATA_X_PLANES) -- no transposed copy of the whole matrix
         fs = [np.ascontiguousarray(f, np.float32) for f in forcings]
         ts = [np.ascontiguousarray(t, np.float32) for t in targets]
         for a in fs + ts:
@@ -117,14 +146,15 @@ class HybridEngine:
                 raise ValueError("forcing / target arrays must have one value per sample")
         fp = (C.c_void_p * max(1, len(fs)))(*[a.ctypes.data for a in fs])
         tp = (C.c_void_p * max(1, len(ts)))(*[a.ctypes.data for a in ts])
-        self._chk(self._lib.eh_set_data(self._h, split, N, C.c_void_p(xf.ctypes.data), fp, tp, 0))
+        self._chk(self._lib.eh_set_data(self._h, split, N, C.c_void_p(xf.ctypes.data), fp, tp, 2))
         self.n_samples[split] = N
 
-    def set_data_device(self, split: int, n: int, x_ptr: int, forcing_ptrs: Sequence[int], target_ptrs: Sequence[int]):
-        """Same as set_data with pointers that already live on the handle's device."""
+    def set_data_device(self, split: int, n: int, x_ptr: int, forcing_ptrs: Sequence[int], target_ptrs: Sequence[int], planes: bool = False):
+        """Same as set_data with pointers that already live on the handle's device; x as the reference holds it -- (P x N) column-major, N
+        records of P -- or, planes = True, as P arrays of N (a row-major (P, N) tensor)."""
         fp = (C.c_void_p * max(1, len(forcing_ptrs)))(*forcing_ptrs)
         tp = (C.c_void_p * max(1, len(target_ptrs)))(*target_ptrs)
-        self._chk(self._lib.eh_set_data(self._h, split, n, C.c_void_p(x_ptr), fp, tp, 1))
+        self._chk(self._lib.eh_set_data(self._h, split, n, C.c_void_p(x_ptr), fp, tp, 1 | (2 if planes else 0)))
         self.n_samples[split] = n
 
     # -- parameters ------------------------------------------------------------------------------

@@ -193,8 +193,11 @@ int32_t eh_synchronize(eh_handle* h);
 /* dataset of one split, made resident in HBM once (replaces the per-batch host->device copies of
  * collect_dim_data, src/training/epoch.jl:1-11).  x: (P x N) column-major exactly as the reference
  * holds it (src/data/prepare_data.jl:6); forcings: F arrays of N; targets: T arrays of N with NaN =
- * missing (valid_mask, src/training/train.jl:221-232).  on_device != 0: the pointers are device
- * pointers on the handle's device. */
+ * missing (valid_mask, src/training/train.jl:221-232).  on_device: flags -- EH_DATA_ON_DEVICE (1): the pointers are device
+ * pointers on the handle's device; EH_DATA_X_PLANES (2): x is given as P arrays of N (a ROW-major P x N matrix, what a NumPy host
+ * holds: no transposed copy on the caller's side). */
+#define EH_DATA_ON_DEVICE 1
+#define EH_DATA_X_PLANES 2
 int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, const float* const* forcings,
                     const float* const* targets, int32_t on_device);
 

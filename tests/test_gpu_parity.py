@@ -663,6 +663,36 @@ def test_set_data_from_device_pointers():
     eng.close()
 
 
+def test_set_data_layouts_agree():
+    """eh_set_data takes the predictors as the reference holds them -- (P x N) column-major = N records of P -- or as P arrays of N
+    (EH_DATA_X_PLANES: what a NumPy host holds), from the host or from the device: four ways in, one data set"""
+    import ctypes as C
+    import torch
+    spec, theta, X, f, y = util.rbq10_case(70001, "tanh", True, 0.1)      # (above 65 536: the host path packs in two threads)
+    outs = []
+    for where, planes in (("host", True), ("host", False), ("device", True), ("device", False)):
+        eng = util.model_from_spec(spec).engine()
+        xh = np.ascontiguousarray(X) if planes else np.ascontiguousarray(X.T)
+        if where == "host":
+            fp = (C.c_void_p * 1)(f["ta"].ctypes.data); tp = (C.c_void_p * 1)(y["reco"].ctypes.data)
+            eng._chk(eng._lib.eh_set_data(eng._h, 0, 70001, C.c_void_p(xh.ctypes.data), fp, tp, 2 if planes else 0))
+            eng.n_samples[0] = 70001
+        else:
+            xd = torch.from_numpy(xh).cuda(); fd = torch.from_numpy(f["ta"]).cuda(); yd = torch.from_numpy(y["reco"]).cuda()
+            eng.set_data_device(0, 70001, xd.data_ptr(), [fd.data_ptr()], [yd.data_ptr()], planes=planes)
+        eng.set_params(theta)
+        outs.append(eng.loss_and_grad())
+        eng.close()
+    l0, g0, n0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert outs[0][0] == pytest.approx(l0, rel=TOL) and util.relerr(outs[0][1], g0) <= TOL
+    for l, g, n in outs[1:]:
+        assert l == outs[0][0] and np.array_equal(g, outs[0][1]) and n == outs[0][2]
+    eng = util.model_from_spec(spec).engine()
+    with pytest.raises(ValueError, match="flags 4"):
+        eng._chk(eng._lib.eh_set_data(eng._h, 0, 10, C.c_void_p(X.ctypes.data), (C.c_void_p * 1)(f["ta"].ctypes.data), (C.c_void_p * 1)(y["reco"].ctypes.data), 4))
+    eng.close()
+
+
 def test_error_paths_on_device():
     spec, theta, X, f, y = util.rbq10_case(64)
     eng = util.model_from_spec(spec).engine()
