@@ -392,6 +392,9 @@ const char* eh_last_error(const eh_handle* h) { return h ? h->err.c_str() : g_cr
 // Streams of destroyed handles are kept for the next handle on the same device: creating one takes 1.4-1.9 ms and destroying it as long
 // again -- a fifth of a whole train() call on the reference's tutorial data set, which creates and destroys one engine per call.  At most
 // eight per device are kept (more are destroyed); the kept ones live until the process ends.
+static std::mutex g_stage_mu;                 // eh_set_data's pinned staging pair (host memory: any device)
+static float* g_stage[2] = {nullptr, nullptr};
+static size_t g_stage_bytes = 0;
 static std::mutex g_stream_pool_mu;
 static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
 static hipStream_t stream_pool_take(int device) {
@@ -1108,7 +1111,7 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
         HIPCHK(h, hipStreamSynchronize(h->stream));
     } else {
         // records interleaved on the host in chunks of <= 1 M samples, through two pinned staging buffers: chunk k is packed (two
-        // threads, each one half) while chunk k - 1 is on its way over PCIe.  (Rounds 1-3: one pageable 67 MB vector, one thread, one
+        // to eight threads, each on its own run of samples) while chunk k - 1 is on its way over PCIe.  (Rounds 1-3: one pageable 67 MB vector, one thread, one
         // blocking copy: 56 ms for the headline data set; the one-time cost a user's train() call pays before its first step.)
         for (int t = 0; t < net.T; ++t) {
             double sum = 0; long long c = 0;
@@ -1116,15 +1119,32 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
             sp.shift[t] = c ? (float)(sum / c) : 0.0f;
         }
         const int64_t CH = std::min<int64_t>(n, (int64_t)1 << 20);
+        // (the two pinned buffers are kept for the next call of the process -- pinning 2 x 16 MB costs as much as the upload they stage;
+        //  a second thread uploading at the same time gets buffers of its own)
         float* stage[2] = {nullptr, nullptr};
         hipEvent_t done[2] = {nullptr, nullptr};
-        bool pinned = hipHostMalloc((void**)&stage[0], (size_t)CH * C * sizeof(float), hipHostMallocDefault) == hipSuccess &&
-                      hipHostMalloc((void**)&stage[1], (size_t)CH * C * sizeof(float), hipHostMallocDefault) == hipSuccess;
+        const size_t stage_bytes = (size_t)CH * C * sizeof(float);
+        std::unique_lock<std::mutex> pool_lk(g_stage_mu, std::try_to_lock);
+        const bool pooled = pool_lk.owns_lock();
+        bool pinned;
+        if (pooled) {
+            if (g_stage_bytes < stage_bytes) {
+                for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; }
+                g_stage_bytes = 0;
+                if (hipHostMalloc((void**)&g_stage[0], stage_bytes, hipHostMallocPortable) == hipSuccess &&          // (portable: the next handle may sit on another device)
+                    hipHostMalloc((void**)&g_stage[1], stage_bytes, hipHostMallocPortable) == hipSuccess) g_stage_bytes = stage_bytes;
+                else { (void)hipGetLastError(); for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; } }
+            }
+            pinned = g_stage_bytes >= stage_bytes;
+            if (pinned) { stage[0] = g_stage[0]; stage[1] = g_stage[1]; }
+        } else {
+            pinned = hipHostMalloc((void**)&stage[0], stage_bytes, hipHostMallocDefault) == hipSuccess &&
+                     hipHostMalloc((void**)&stage[1], stage_bytes, hipHostMallocDefault) == hipSuccess;
+        }
         std::vector<float> pageable;
         if (!pinned) {                                   // (no pinned memory to be had: the plain path)
             (void)hipGetLastError();
-            if (stage[0]) (void)hipHostFree(stage[0]);
-            if (stage[1]) (void)hipHostFree(stage[1]);
+            if (!pooled) { if (stage[0]) (void)hipHostFree(stage[0]); if (stage[1]) (void)hipHostFree(stage[1]); }
             pageable.resize((size_t)CH * C);
             stage[0] = stage[1] = pageable.data();
         } else {
@@ -1148,11 +1168,17 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
             float* const buf = stage[k & 1];
             if (pinned && k >= 2) err = hipEventSynchronize(done[k & 1]);       // the copy that last read this buffer is through
             if (err != hipSuccess) break;
-            if (cnt >= 65536) {
-                const int64_t mid = s0 + cnt / 2;
-                std::thread other([&] { pack(buf, mid, s0 + cnt, s0); });
-                pack(buf, s0, mid, s0);
-                other.join();
+            if (cnt >= 65536) {          // a chunk is interleaved by up to eight threads, each on its own run of samples
+                const unsigned hw = std::thread::hardware_concurrency();
+                const int nthr = (int)std::max<int64_t>(2, std::min<int64_t>({(int64_t)8, (int64_t)(hw ? hw / 2 : 2), cnt / 32768}));
+                const int64_t per = (cnt + nthr - 1) / nthr;
+                std::vector<std::thread> others;
+                for (int w = 1; w < nthr; ++w) {
+                    const int64_t a0 = s0 + w * per, a1 = std::min(s0 + cnt, a0 + per);
+                    if (a0 < a1) others.emplace_back([&, a0, a1] { pack(buf, a0, a1, s0); });
+                }
+                pack(buf, s0, std::min(s0 + cnt, s0 + per), s0);
+                for (auto& t : others) t.join();
             } else pack(buf, s0, s0 + cnt, s0);
             if (pinned) {
                 err = hipMemcpyAsync(sp.recs + (size_t)s0 * C, buf, (size_t)cnt * C * sizeof(float), hipMemcpyHostToDevice, h->stream);
@@ -1160,7 +1186,7 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
             } else err = hipMemcpy(sp.recs + (size_t)s0 * C, buf, (size_t)cnt * C * sizeof(float), hipMemcpyHostToDevice);
         }
         if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
-        if (pinned) { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); (void)hipHostFree(stage[0]); (void)hipHostFree(stage[1]); }
+        if (pinned) { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); if (!pooled) { (void)hipHostFree(stage[0]); (void)hipHostFree(stage[1]); } }
         HIPCHK(h, err);
     }
     sp.n = n;
