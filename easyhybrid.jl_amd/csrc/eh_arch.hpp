@@ -42,7 +42,7 @@ struct EhSpecKernel {
     hipError_t (*prepare)(void);
     hipError_t (*launch)(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
 };
-#define EH_SPEC_LIST(X) X(0) X(1) X(2) X(3) X(4)
+#define EH_SPEC_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define EH_SPEC_DECL(k) extern "C" const EhSpecKernel* eh_spec_##k(void);
 EH_SPEC_LIST(EH_SPEC_DECL)
 #undef EH_SPEC_DECL

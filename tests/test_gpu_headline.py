@@ -216,6 +216,10 @@ def test_canonical_descriptors_run_kernels_specialised_ahead_of_time():
     for scale in (True, False):
         m = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"], hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=scale)
         cases.append((f"RbQ10 [2,16,16,1] scale_nn_outputs={scale}", m, X, [cols["ta"]], [cols["reco"]]))
+    for bn in (False, True):                  # the reference's GPU tutorial / README model: sigmoid, sigma-scaled, input BatchNorm (raw predictors there)
+        m = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"], hidden_layers=[16, 16], activation="sigmoid",
+                                    scale_nn_outputs=True, input_batchnorm=bn)
+        cases.append((f"tutorial RbQ10 [2,16,16,1] sigmoid input_batchnorm={bn}", m, X * (50 if bn else 1), [cols["ta"]], [cols["reco"]]))
     c3 = make_synth_expo2pool(4096, 1)
     m3 = eh.constructHybridModel([f"x{i}" for i in range(8)], ["T"], ["Resp_obs"], eh.Expo2Pool, dict(EXPO2POOL_PARAMS), ["R0a", "ka", "R0b", "kb"], [],
                                  hidden_layers=[64, 64], activation="tanh", scale_nn_outputs=True)
