@@ -357,6 +357,19 @@ static const EhSpecKernel* spec_lookup(const eh_handle* h) {
 }
 
 static hipError_t step_launch(eh_handle* h, int mode, int grid, const EhStepArgs* a) {
+    if (mode == EH_MODE_TRAIN_MULTI) {     // (built ahead of time only -- specialised for the canonical descriptors, generic otherwise; the caller checked: multi_ok)
+        if (const EhSpecKernel* sk = spec_lookup(h)) {
+            if (sk->launch(mode, grid, h->stream, &h->net, a) == hipSuccess) { h->spec_used = sk; return hipSuccess; }
+            (void)hipGetLastError();
+        } else if (jit_wanted(h, EH_MODE_TRAIN)) {      // the kernel compiled at run time, once it has been checked against the generic one (the single-step path does that)
+            eh_handle_s::JitEntry* je = jit_entry(h);
+            if (je && je->verified && je->k.fn[EH_MODE_TRAIN_MULTI]) {
+                if (eh_jit_launch(&je->k, mode, grid, h->stream, &h->net, a) == hipSuccess) return hipSuccess;
+                (void)hipGetLastError();
+            }
+        }
+        return h->arch->var[h->variant].launch(mode, h->act, KFAST(h), grid, h->stream, &h->net, a);
+    }
     if (const EhSpecKernel* sk = spec_lookup(h)) {
         const hipError_t e = sk->launch(mode, grid, h->stream, &h->net, a);
         if (e == hipSuccess) { h->spec_used = sk; return e; }
@@ -940,6 +953,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     }
     if (!strcmp(name, "bn_in_kernel")) {     // 0: always launch eh_bn_stats_kernel in front of a step with input BatchNorm (A/B, tests); 1 (default): small minibatches take their statistics inside the step kernel
         h->bn_no_self = value == 0;
+        return EH_OK;
+    }
+    if (!strcmp(name, "multi_step")) {       // 1 (default): eh_train_epoch runs the steps of small minibatches (one workgroup each) several per launch; 0: one launch per step
+        h->multi_step = value != 0;
         return EH_OK;
     }
     if (!strcmp(name, "eval_blocks")) {      // workgroups of the evaluation passes (eh_eval / eh_forward); 0 = the default of the kernel family
@@ -1738,6 +1755,40 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
     return EH_OK;
 }
 
+// Several fused-update steps in one launch (EH_MODE_TRAIN_MULTI, eh_device.hpp): minibatches one workgroup covers -- the reference's
+// default batch of 64 among them -- with the step-to-step state in LDS.
+static bool multi_ok(const eh_handle* h, long long batch) {
+    if (!h->fused || !h->multi_step || h->lform || h->arch->wide || h->p2p_on || h->prof || h->stamps || h->capturing) return false;
+    if (h->net.T != 1 || h->net.mech == EH_MECH_PROGRAM || h->net.loss == EH_LOSS_PROGRAM || h->act == EH_ACT_PER_NET) return false;
+    if (h->bn_on && (h->bn_ext || h->bn_no_self || batch > EH_BN_SELF_MAX)) return false;
+    if (h->arch->var[h->variant].lds_bytes + sizeof(float) * (size_t)eh_ms_extra_floats(h->net.n_theta, h->n_acc) > EH_LDS_LIMIT) return false;
+    if (grid_for(h, batch) != 1) return false;
+    if (!spec_lookup(h) && jit_wanted(h, EH_MODE_TRAIN)) {      // a model on kernels compiled at run time: its multi-step kernel, or one launch per step
+        eh_handle_s::JitEntry* je = jit_entry(const_cast<eh_handle*>(h));      // (a compiled single-step kernel beats the GENERIC multi-step one: 7.4 against 9.0 us)
+        if (je && (!je->verified || !je->k.fn[EH_MODE_TRAIN_MULTI])) return false;
+    }
+    return true;
+}
+static int do_fused_multi(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long batch, long long end, int nsteps, float* loss_slots) {
+    EhStepArgs a{};
+    a.prog = h->prog;
+    a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = std::min(batch, end - first);
+    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = nullptr;
+    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
+    EhFused& z = a.fz;
+    z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
+    z.gslot = (int)(h->gstep % 3); z.cur = h->cur; z.sc_sel = h->sc_sel; z.pending = h->pending ? 1 : 0; z.opt = h->opt; z.agg_a = h->img.agg_a;
+    a.p2p = nullptr; a.p2p_seq = 0u;
+    if (int rc = bn_prepare(h, sp, idx, first, a.count, true, &a)) return rc;       // (input BatchNorm: statistics inside the kernel, multi_ok made sure)
+    a.ms_nsteps = nsteps; a.ms_batch = (int)batch; a.ms_end = end; a.ms_loss = loss_slots;
+    HIPCHK(h, step_launch(h, EH_MODE_TRAIN_MULTI, 1, &a));
+    if (nsteps & 1) { h->cur ^= 1; h->sc_sel ^= 1; }
+    h->gstep += nsteps;
+    h->pending = true;
+    h->pending_loss = loss_slots + (nsteps - 1);
+    return EH_OK;
+}
+
 static int ensure_events(eh_handle* h, size_t need) {
     while (h->ev.size() < need) {
         hipEvent_t e;
@@ -2247,6 +2298,12 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
     const long long steps = (N + batchsize - 1) / batchsize;
     int rc = ensure_loss_hist(h, steps);
     if (rc) return rc;
+    if (multi_ok(h, batchsize)) {          // one workgroup per step: up to EH_MULTI_MAX steps per launch
+        for (long long s = 0; s < steps; s += EH_MULTI_MAX) {
+            const int n = (int)std::min<long long>(EH_MULTI_MAX, steps - s);
+            if ((rc = do_fused_multi(h, sp, shuffle ? h->perm : nullptr, s * batchsize, batchsize, N, n, h->loss_hist + s))) return rc;
+        }
+    } else
     for (long long s = 0; s < steps; ++s) {
         const long long first = s * batchsize, count = std::min<long long>(batchsize, N - first);
         rc = h->fused ? do_fused_step(h, sp, shuffle ? h->perm : nullptr, first, count, h->loss_hist + s)

@@ -27,16 +27,24 @@ struct Var {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     }
+    template <int ACT, int FAST>
+    static hipError_t prepm() {           // the multi-step kernels keep their step-to-step state behind the work space: whatever LDS a CU has
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, EH_MODE_TRAIN_MULTI, FAST>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EH_LDS_LIMIT);
+    }
     template <int ACT>
     static hipError_t prep2() {
         hipError_t e = prep1<ACT, EH_MODE_TRAIN, 0>();
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 0>();
         if constexpr (HASP2P) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 0>(); }
+        if (e == hipSuccess) e = prepm<ACT, 0>();                     // several steps of one workgroup per launch (small minibatches)
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 4>();      // EH_MECH_PROGRAM kernels (no cross-GPU variant)
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 4>();
 #ifdef EH_FAST_PATHS
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 1>();
+        if (e == hipSuccess) e = prepm<ACT, 1>();
         if constexpr (HASPS) { if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN, 3>(); }
+        if constexpr (HASPS) { if (e == hipSuccess) e = prepm<ACT, 3>(); }
         if (e == hipSuccess) e = prep1<ACT, EH_MODE_EVAL, 1>();
         if constexpr (HASP2P) {
             if (e == hipSuccess) e = prep1<ACT, EH_MODE_TRAIN_P2P, 1>();
@@ -60,6 +68,17 @@ struct Var {
             if (mode == EH_MODE_TRAIN) EH_GO(EH_MODE_TRAIN, 4); else EH_GO(EH_MODE_EVAL, 4);
             return;
         }
+        if (mode == EH_MODE_TRAIN_MULTI) {
+            const size_t lds_ms = LDS + sizeof(float) * (size_t)eh_ms_extra_floats(net->n_theta, args->n_acc);
+#define EH_GOM(FAST) hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, EH_MODE_TRAIN_MULTI, FAST>), dim3(1), dim3(64 * NW), lds_ms, stream, *net, *args)
+#ifdef EH_FAST_PATHS
+            if constexpr (HASPS) { if (fast == 3) { EH_GOM(3); return; } }
+            if (fast & 1) { EH_GOM(1); return; }
+#endif
+            EH_GOM(0);
+#undef EH_GOM
+            return;
+        }
         if (mode == EH_MODE_TRAIN_P2P) {
             if constexpr (HASP2P) {
 #ifdef EH_FAST_PATHS
@@ -81,7 +100,8 @@ struct Var {
     static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
         if (mode == EH_MODE_TRAIN_P2P && !HASP2P) return hipErrorNotSupported;
         if (fast == 3 && !HASPS) return hipErrorNotSupported;
-        if ((fast & 4) && (fast != 4 || mode == EH_MODE_TRAIN_P2P)) return hipErrorNotSupported;
+        if ((fast & 4) && (fast != 4 || mode == EH_MODE_TRAIN_P2P || mode == EH_MODE_TRAIN_MULTI)) return hipErrorNotSupported;
+        if (mode == EH_MODE_TRAIN_MULTI && (grid != 1 || LDS + sizeof(float) * (size_t)eh_ms_extra_floats(net->n_theta, args->n_acc) > EH_LDS_LIMIT)) return hipErrorInvalidValue;
         switch (act) {
             case EH_ACT_TANH: go<EH_ACT_TANH>(mode, fast, grid, stream, net, args); break;
             case EH_ACT_SIGMOID: go<EH_ACT_SIGMOID>(mode, fast, grid, stream, net, args); break;

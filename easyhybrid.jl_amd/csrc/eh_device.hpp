@@ -35,7 +35,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EH_MODE_TRAIN = 0, EH_MODE_EVAL = 1, EH_MODE_TRAIN_P2P = 2 };   // TRAIN_P2P: fused-update step that exchanges its sums with the peer GPUs itself (EhP2P)
+enum { EH_MODE_TRAIN = 0, EH_MODE_EVAL = 1, EH_MODE_TRAIN_P2P = 2, EH_MODE_TRAIN_MULTI = 3 };   // TRAIN_P2P: fused-update step that exchanges its sums with the peer GPUs itself (EhP2P)
 
 struct EhNet {
     int P, K, G, T, F;               // predictors, NN outputs (neural params), global params, targets, forcing columns
@@ -178,6 +178,12 @@ struct EhStepArgs {
     const unsigned* prog; // EH_MECH_PROGRAM kernels only: [0] length, [1] outputs, [2..4] output slots, [8..23] constants, [24..] code
     const unsigned* lprog; // recorded training losses where no kernel is compiled at run time (the layer-wise form): one program per target,
                            // EH_LPROG_WORDS apart, in the same layout -- slot 0 = yhat, slot 1 = y, [2] = the slot of l(yhat, y); interpreted
+    // EH_MODE_TRAIN_MULTI only: ms_nsteps consecutive fused-update steps of ONE workgroup in one launch -- step k trains on the window
+    // [first + k * ms_batch, ...) of at most ms_batch samples that ends at ms_end at the latest; the loss of step k goes to ms_loss[k]
+    int ms_nsteps, ms_batch;
+    int ms_keep;            // set by the multi-step kernel for its steps after the first: the parameter image is already in LDS
+    long long ms_end;
+    float* ms_loss;
 };
 enum { EH_LPROG_WORDS = 24 + EH_MAX_PROG };
 
@@ -817,7 +823,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     if constexpr (P2PM) {
         if (fusedm && a.fz.pending) eh_ll_issue(p2p_addr, a.p2p_seq - 1u, p2p_w);
     }
-    {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
+    if (!a.ms_keep) {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
+        // (ms_keep: a later step of a multi-step launch -- the image is still in LDS from the step before, whose update wrote the new
+        //  parameters into it; its constant part never changes)
         constexpr int NI = (G::IMG_FLOATS / 4 + NTHR - 1) / NTHR, NIB = NI < 16 ? NI : 16;
         for (int e0 = 4 * tid; e0 < G::IMG_FLOATS; e0 += 4 * NTHR * NIB) {
             f32x4 tmp[NIB];
@@ -1705,8 +1713,54 @@ namespace EH_SPEC_NS {
 #endif
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
-    eh_step_body<NBI, NBH, NL, NT, NW, ACT, MODE, FAST>(net, a);
+    if constexpr (MODE == EH_MODE_TRAIN_MULTI) {
+        // Minibatches that ONE workgroup covers -- the reference's default batch of 64 (src/config/TrainingConfig.jl:14) and everything up
+        // to 16 NT NW samples: a step's only consumer is the same workgroup's next step, so the steps of an epoch need neither a kernel
+        // boundary between them nor global memory for what one hands to the next.  One launch runs ms_nsteps fused-update steps with the
+        // step-to-step state -- both parameter sets {theta, m, v}, the beta products, the three rotating gradient accumulators -- in LDS
+        // behind the step body's own work space: the body is the single-step body, unchanged, with its state pointers redirected (its
+        // float atomics become LDS atomics, its parameter re-load an LDS read); global memory sees the state again when the launch ends.
+        // A first version kept the state in global memory with a release / acquire between two steps and was SLOWER than one launch per
+        // step (10.3 against 7.4 us): every dependent round trip of a step is exposed inside one kernel.  (Staging a small data set and the
+        // epoch's permutation in LDS as well was measured: 0.15-0.3 us of a 6 us step; not kept.)  Launched with ONE workgroup.
+        extern __shared__ __attribute__((aligned(16))) float eh_ms_smem[];
+        using G = EhGeom<NBI, NBH, NL, NT, NW>;
+        constexpr int NTHR = 64 * NW;
+#ifdef EH_SPEC_NET
+        constexpr EhNet cnet = {EH_SPEC_NET};
+        const int nth = cnet.n_theta;
+#else
+        const int nth = net.n_theta;
+#endif
+        const int np = 6 * nth + 4, ng = 3 * EH_GSHARDS * a.n_acc + 4;
+        float* const l_pset = eh_ms_smem + G::TOTAL_FLOATS;
+        float* const l_gacc = l_pset + ((np + 3) & ~3);
+        for (int i = threadIdx.x; i < np; i += NTHR) l_pset[i] = a.fz.pset[i];
+        for (int i = threadIdx.x; i < ng; i += NTHR) l_gacc[i] = a.fz.gacc[i];
+        __syncthreads();
+        for (int k = 0; k < a.ms_nsteps; ++k) {
+            EhStepArgs b = a;
+            b.first = a.first + (long long)k * a.ms_batch;
+            const long long left = a.ms_end - b.first;
+            b.count = left < (long long)a.ms_batch ? left : (long long)a.ms_batch;
+            b.fz.pset = l_pset; b.fz.gacc = l_gacc;
+            b.fz.gslot = (a.fz.gslot + k) % 3;
+            b.fz.cur = a.fz.cur ^ (k & 1);
+            b.fz.sc_sel = a.fz.sc_sel ^ (k & 1);
+            b.fz.pending = k ? 1 : a.fz.pending;
+            b.fz.loss_slot = k ? a.ms_loss + (k - 1) : a.fz.loss_slot;       // (a step's prologue finishes the loss of the step before it)
+            b.ms_keep = k > 0;
+            eh_step_body<NBI, NBH, NL, NT, NW, ACT, EH_MODE_TRAIN, FAST>(net, b);
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < np; i += NTHR) a.fz.pset[i] = l_pset[i];
+        for (int i = threadIdx.x; i < ng; i += NTHR) a.fz.gacc[i] = l_gacc[i];
+    } else {
+        eh_step_body<NBI, NBH, NL, NT, NW, ACT, MODE, FAST>(net, a);
+    }
 }
+// LDS floats behind the step body's work space that the multi-step kernel keeps its state in (host side: launch size, eligibility)
+__host__ __device__ inline long long eh_ms_extra_floats(int n_theta, int n_acc) { return (long long)((6 * n_theta + 4 + 3) & ~3) + 3LL * EH_GSHARDS * n_acc + 4; }
 #ifdef EH_SPEC_NS
 }   // namespace EH_SPEC_NS
 using namespace EH_SPEC_NS;

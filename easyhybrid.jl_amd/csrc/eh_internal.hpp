@@ -44,6 +44,7 @@ struct EhImg {
 // --------------------------------------------------------------------------------------------
 // handle
 // --------------------------------------------------------------------------------------------
+constexpr int EH_MULTI_MAX = 256;         // steps per launch of the multi-step kernel (EH_MODE_TRAIN_MULTI): bounds a launch to a millisecond or two
 constexpr int EH_EVAL_BLOCKS = 1024;      // evaluation passes of the per-wave kernels: up to four workgroups per CU (eval_grid_for, eh_api.hip)
 
 struct EhSplit {
@@ -167,6 +168,7 @@ struct eh_handle_s {
     bool capturing = false;
     GraphRec cap{};
     int max_blocks = 256;
+    bool multi_step = true;         // "multi_step" option (eh_train_epoch: several one-workgroup steps per launch)
     bool bn_no_self = false;        // "bn_in_kernel" 0
     int eval_blocks = 0;            // "eval_blocks" option: workgroups of eh_eval / eh_forward (0 = per kernel family, eval_grid_for)
     int mech_blocks = 0;            // "mech_blocks" option: cap on the streaming kernel's workgroups (0: none -- one workgroup per `mech_tiles` tiles)

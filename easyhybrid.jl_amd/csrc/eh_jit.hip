@@ -356,14 +356,20 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     if (rowact) { hnames[nh] = "eh_jit_rowact.inc"; hsrc[nh++] = rsrc.c_str(); }
     hiprtcProgram hp = nullptr;
     if (hiprtcCreateProgram(&hp, src.c_str(), "eh_jit.hip", nh, hsrc, hnames) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
-    const int nmode = (with_p2p && !A->wide && !prog) ? 3 : 2;
-    char name[3][160];
-    for (int m = 0; m < nmode; ++m) {
-        if (A->wide && V.bf16) snprintf(name[m], sizeof name[m], "eh_widebf_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
-        else if (A->wide) snprintf(name[m], sizeof name[m], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
-        else snprintf(name[m], sizeof name[m], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m,
+    // which kernels: train + eval, the cross-GPU train kernel when asked for, and -- per-wave family, registry model with its descriptor
+    // baked in, one target -- the multi-step train kernel (several one-workgroup steps per launch, eh_device.hpp EH_MODE_TRAIN_MULTI)
+    int modes[4], nmode = 0;
+    modes[nmode++] = EH_MODE_TRAIN; modes[nmode++] = EH_MODE_EVAL;
+    if (with_p2p && !A->wide && !prog) modes[nmode++] = EH_MODE_TRAIN_P2P;
+    if (!A->wide && !prog && !loss && !rowact && spec && spec->T == 1 && !(fast & 4)) modes[nmode++] = EH_MODE_TRAIN_MULTI;
+    char name[4][160];
+    for (int i = 0; i < nmode; ++i) {
+        const int m = modes[i];
+        if (A->wide && V.bf16) snprintf(name[i], sizeof name[i], "eh_widebf_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
+        else if (A->wide) snprintf(name[i], sizeof name[i], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
+        else snprintf(name[i], sizeof name[i], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m,
                       (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
-        hiprtcAddNameExpression(hp, name[m]);
+        hiprtcAddNameExpression(hp, name[i]);
     }
     // The flags of the Makefile, with one exception.  -fno-slp-vectorize is there because the SLP vectoriser miscompiled ONE group of
     // kernels (P <= 4 ReLU on shapes wider than one 16-row block: a loss sum lost in a packed accumulator); it
@@ -449,10 +455,12 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
         if (names_ok && !cpath.empty()) cache_store(cpath, lowered, code);
     }
     bool ok = hipModuleLoadData(&out->mod, code.data()) == hipSuccess;
-    for (int m = 0; m < nmode && ok; ++m) {
-        ok = !lowered[m].empty() && hipModuleGetFunction(&out->fn[m], out->mod, lowered[m].c_str()) == hipSuccess;
+    for (int i = 0; i < nmode && ok; ++i) {
+        const int m = modes[i];
+        ok = !lowered[i].empty() && hipModuleGetFunction(&out->fn[m], out->mod, lowered[i].c_str()) == hipSuccess;
         // (raises the dynamic-LDS limit where the runtime wants to be told; a refusal shows up as a failed launch, which the caller handles)
-        if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(out->fn[m]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds_bytes);
+        if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(out->fn[m]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          m == EH_MODE_TRAIN_MULTI ? (int)EH_LDS_LIMIT : (int)V.lds_bytes);
     }
     if (!ok && from_cache) (void)unlink(cpath.c_str());       // a stale or damaged entry: gone, the next build compiles
     (void)hipGetLastError();
@@ -465,11 +473,16 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
 
 hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
     void* params[] = {const_cast<EhNet*>(net), const_cast<EhStepArgs*>(args)};
-    if (mode < 0 || mode > 2 || !k->fn[mode]) return hipErrorNotSupported;
+    if (mode < 0 || mode > 3 || !k->fn[mode]) return hipErrorNotSupported;
+    if (mode == EH_MODE_TRAIN_MULTI) {      // one workgroup; its step-to-step state sits in LDS behind the work space
+        const size_t lds_ms = k->lds_bytes + sizeof(float) * (size_t)eh_ms_extra_floats(net->n_theta, args->n_acc);
+        if (grid != 1 || lds_ms > EH_LDS_LIMIT) return hipErrorInvalidValue;
+        return hipModuleLaunchKernel(k->fn[mode], 1, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)lds_ms, stream, params, nullptr);
+    }
     return hipModuleLaunchKernel(k->fn[mode], (unsigned)grid, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)k->lds_bytes, stream, params, nullptr);
 }
 
 void eh_jit_release(EhJitKernel* k) {
     if (k->mod) (void)hipModuleUnload(k->mod);
-    k->mod = nullptr; k->fn[0] = k->fn[1] = k->fn[2] = nullptr;
+    k->mod = nullptr; k->fn[0] = k->fn[1] = k->fn[2] = k->fn[3] = nullptr;
 }

@@ -11,7 +11,7 @@
 
 struct EhJitKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[3] = {nullptr, nullptr, nullptr};   // EH_MODE_TRAIN, EH_MODE_EVAL, EH_MODE_TRAIN_P2P (when asked for)
+    hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};   // EH_MODE_TRAIN, EH_MODE_EVAL, EH_MODE_TRAIN_P2P (when asked for), EH_MODE_TRAIN_MULTI (per-wave registry models with one target)
     int nw = 0;
     size_t lds_bytes = 0;
 };

@@ -33,6 +33,7 @@ constexpr bool HASP2P = false;
 using Geom = EhGeom<NBI, NBH, NL, NT, NW>;
 #define EH_SPEC_KERNEL(MODE) eh_step_kernel<NBI, NBH, NL, NT, NW, ACT, MODE, ((MODE) == EH_MODE_EVAL ? (FAST & 5) : FAST)>
 constexpr bool HASP2P = (FAST & 4) == 0;
+constexpr bool HASMULTI = (FAST & 4) == 0 && EhNet{EH_SPEC_NET}.T == 1;
 #endif
 constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
 static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
@@ -42,6 +43,7 @@ hipError_t prepare() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&EH_SPEC_KERNEL(EH_MODE_EVAL)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
 #if EH_SPEC_FAMILY == 0
     if constexpr (HASP2P) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&EH_SPEC_KERNEL(EH_MODE_TRAIN_P2P)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); }
+    if constexpr (HASMULTI) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&EH_SPEC_KERNEL(EH_MODE_TRAIN_MULTI)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EH_LDS_LIMIT); }
 #endif
     return e;
 }
@@ -50,6 +52,11 @@ hipError_t launch(int mode, int grid, hipStream_t stream, const EhNet* net, cons
     else if (mode == EH_MODE_EVAL) hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_EVAL)), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
 #if EH_SPEC_FAMILY == 0
     else if (mode == EH_MODE_TRAIN_P2P && HASP2P) hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_TRAIN_P2P)), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
+    else if (mode == EH_MODE_TRAIN_MULTI && HASMULTI) {      // several steps of one workgroup per launch, the state between them in LDS behind the work space
+        const size_t lds_ms = LDS + sizeof(float) * (size_t)eh_ms_extra_floats(net->n_theta, args->n_acc);
+        if (grid != 1 || lds_ms > EH_LDS_LIMIT) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_TRAIN_MULTI)), dim3(1), dim3(64 * NW), lds_ms, stream, *net, *args);
+    }
 #endif
     else return hipErrorNotSupported;
     return hipGetLastError();

@@ -433,6 +433,8 @@ int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
  * "precision" (0 = fp32 end to end, the reference's arithmetic; 1 = bf16 forward products with fp32 accumulation and an fp32-exact
  * backward pass, BASELINE.json config 5 -- row-split shapes with tanh / sigmoid / relu / identity only; 2 = bf16 operands in BOTH passes: every
  * backward delta is rounded to bfloat16 once, in the scale the step carries it, fp32 accumulation),
+ * "multi_step" (1 = default: eh_train_epoch in fused_update mode runs minibatches that one workgroup covers -- e.g. the reference's default
+ * batch of 64 -- several steps per kernel launch, the state between two steps in LDS; 0 = one launch per step),
  * "bn_in_kernel" (1 = default: with input BatchNorm, minibatches of up to 512 samples get their batch statistics inside the per-wave step
  * kernel instead of from a launch in front of it; 0 = always the separate launch),
  * "eval_blocks" (workgroups of eh_eval / eh_forward; 0 = default: the per-wave kernels, which need far fewer registers without gradient

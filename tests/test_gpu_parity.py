@@ -757,6 +757,63 @@ def test_fused_update_skips_all_masked_batch_and_reports_losses():
     eng.close(); ref.close()
 
 
+@pytest.mark.parametrize("kernels", ["generic", "compiled at run time", "specialised ahead of time"])
+@pytest.mark.parametrize("case", ["rbq10", "rbq10_bn", "expo2pool", "relu"])
+def test_epochs_of_small_minibatches_run_several_steps_per_launch(case, kernels):
+    """minibatches that one workgroup covers (the reference's default batch of 64, src/config/TrainingConfig.jl:14) run up to 256
+    fused-update steps per kernel launch with the step-to-step state in LDS (EH_MODE_TRAIN_MULTI): against one launch per step and
+    against the oracle -- partial last batch, missing targets, input BatchNorm with its running statistics, shuffled epochs with
+    evaluation passes in between (the pending update is flushed and picked up again), the optimiser state afterwards"""
+    if case == "expo2pool":
+        spec = ho.expo2pool_spec((16, 16), "tanh", True)
+        rng = np.random.default_rng(3)
+        mm = ho.MECH[spec.mech][0]
+        N = 1000
+        X = rng.standard_normal((spec.n_pred, N)).astype(np.float32)
+        f = {k: (10 + 5 * rng.standard_normal(N)).astype(np.float32) for k in mm.forcings}
+        y = {k: np.abs(rng.standard_normal(N)).astype(np.float32) for k in spec.targets}
+        y[spec.targets[0]][rng.random(N) < 0.1] = np.nan
+        theta = ho.init_theta(spec, 2, np.float32)
+    elif case == "rbq10_bn":
+        spec, theta, X, f, y = _bn_case(1000, seed=5)
+    else:
+        spec, theta, X, f, y = util.rbq10_case(1000, "relu" if case == "relu" else "tanh", True, 0.1, seed=5)
+    B = 64                                                    # 15 full minibatches + one of 40
+    engs = []
+    if kernels == "specialised ahead of time" and case not in ("rbq10", "rbq10_bn"):
+        pytest.skip("no canonical descriptor")                # (csrc/Makefile SPECDEF_*: RbQ10 [2,16,16,1] tanh; input BatchNorm lives in the image, not in the descriptor)
+    for multi in (1, 0):
+        eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01); eng.set_option("fused_update", 1); eng.set_option("multi_step", multi)
+        eng.set_option("aot_spec", int(kernels == "specialised ahead of time")); eng.set_option("specialize", int(kernels == "compiled at run time"))
+        if kernels == "compiled at run time":
+            eng.loss_and_grad(count=64)                        # (builds the kernel and checks it against the generic one: only then does the multi-step form take over)
+        l1, n1 = eng.train_epoch(B, shuffle=False)
+        engs.append((eng, l1, n1, eng.get_params()))
+    (e1, l1, n1, t1), (e0, l0, n0, t0) = engs
+    assert n1 == n0 == 16 and l1 == pytest.approx(l0, rel=2e-6) and np.max(np.abs(t1 - t0)) <= 2e-6
+    if kernels != "generic":
+        nj, log = e1.jit_status()
+        assert nj >= 1 and log.startswith("ahead-of-time") == (kernels == "specialised ahead of time"), (nj, log[:200])
+    st = ho.bn_init(spec) if getattr(spec, "input_batchnorm", False) else None
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, [(i * B, min(B, 1000 - i * B)) for i in range(16)], dtype=np.float32, bn_state=st)
+    assert l1 == pytest.approx(float(np.nanmean(l_ref)), rel=1e-4) and np.max(np.abs(t1 - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+    if st is not None:
+        rm, rv = e1.get_bn_state()
+        assert util.relerr(rm, st["mean"]) <= 1e-5 and util.relerr(rv, st["var"]) <= 1e-5
+    for ep in range(3):                                       # shuffled epochs, an evaluation pass between them
+        for e in (e1, e0):
+            e.train_epoch(B, seed=40 + ep, shuffle=True, want_loss=False)
+        m1, _ = e1.eval(0); m0, _ = e0.eval(0)
+        assert m1[0]["mse"] == pytest.approx(m0[0]["mse"], rel=2e-5)
+    assert np.max(np.abs(e1.get_params() - e0.get_params())) <= 2e-5
+    (m1_, v1_, b1_), (m0_, v0_, b0_) = e1.get_opt_state(), e0.get_opt_state()
+    assert np.max(np.abs(m1_ - m0_)) <= 1e-5 * max(1e-3, float(np.max(np.abs(m0_)))) + 1e-9 and np.allclose(b1_, b0_, rtol=1e-6)
+    e1.set_option("fused_update", 0)                          # leaving the mode: the deterministic path continues from the same state
+    l_a = e1.train_step(0, 64); l_b = e0.train_step(0, 64)
+    assert l_a == pytest.approx(l_b, rel=2e-5)
+    e1.close(); e0.close()
+
+
 def test_data_parallel_driver_world_size_one_nccl():
     # the real DataParallel driver (RCCL through torch.distributed) with a single rank: both the
     # fused one-kernel path and the deterministic three-kernel path must reproduce plain training
