@@ -380,3 +380,43 @@ def test_random_layerwise_configuration_matches_the_oracle(seed):
         else:
             assert np.max(np.abs(grad)) <= 1e-5 * max(1.0, abs(l0)), (kind, spec, B)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EH_FUZZ_N", "60"))))
+def test_random_small_minibatch_epochs_several_steps_per_launch(seed):
+    """eh_train_epoch on minibatches one workgroup covers: several fused-update steps per launch with the state in LDS (EH_MODE_TRAIN_MULTI)
+    against one launch per step -- same arithmetic, only the order in which a workgroup's float atomics meet differs -- over random
+    per-wave configurations with one target: shape, activation, mechanistic model, parameter kinds, scaling, BatchNorm, missing targets,
+    optimiser, minibatch size (incl. sizes that leave a partial last minibatch), shuffled or not"""
+    for sub in range(40):                                  # the next configuration of this seed's stream that the mode serves
+        spec, theta, X, f, y, kind, first, B, rng = _case(7000 + 40 * seed + sub, fastpath=bool(seed % 2))
+        if len(spec.targets) == 1 and spec.nets is None and max(spec.hidden) <= 64 and kind in ("mse", "rmse", "mae", "nseLoss"):
+            break
+    else:
+        pytest.skip("no eligible configuration in this seed's stream")
+    N = X.shape[1]
+    batch = int(rng.choice([1, 5, 16, 32, 33, 64, 100, 128]))
+    opt = [("Adam", 0.01), ("RMSProp", 0.005), ("AdamW", 0.01), ("Descent", 0.01)][int(rng.integers(4))]
+    shuffle = bool(rng.integers(2))
+    out = []
+    for multi in (1, 0):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_training_loss(kind)
+        eng.opt_init(*opt)
+        try:
+            eng.set_option("fused_update", 1)
+        except Exception:
+            eng.close(); pytest.skip("no fused-update mode for this configuration")
+        eng.set_option("multi_step", multi)
+        l0, n0 = eng.train_epoch(batch, seed=seed, shuffle=shuffle)
+        eng.train_epoch(batch, seed=seed + 1, shuffle=shuffle, want_loss=False)
+        out.append((l0, n0, eng.get_params(), eng.forward(0, params=False)[spec.targets[0]]))
+        eng.close()
+    (l1, n1, t1, p1), (l0, n0, t0, p0) = out
+    assert n1 == n0 == -(-N // batch)
+    if not (np.all(np.isfinite(t0)) and np.isfinite(l0)):
+        pytest.skip("the descent diverges for this configuration (one launch per step as well)")
+    scale = max(1.0, float(np.max(np.abs(t0))))
+    assert l1 == pytest.approx(l0, rel=1e-4, abs=1e-6), (spec, kind, batch, opt)
+    assert np.max(np.abs(t1 - t0)) <= 1e-4 * scale, (spec, kind, batch, opt, float(np.max(np.abs(t1 - t0))))
+    assert util.relerr(p1, p0) <= 1e-3
