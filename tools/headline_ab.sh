@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of the headline step on ONE lease: the round-1 final library + bench (a copy under dbg/r01, built from commit a6913d7) against
 # the current tree, alternating, long runs (3 000 steps) and the driver-sized form (20 steps).
+# (needs a built copy of the round-1 tree next to this one, which is NOT tracked: git worktree add dbg/r01 a6913d7 && make -C dbg/r01/easyhybrid.jl_amd/csrc -j8)
+if [ ! -d "$(dirname "$0")/../dbg/r01" ]; then echo "$0: dbg/r01 is missing (a worktree of commit a6913d7, built): see the comment at the top" >&2; exit 2; fi
 set -u
 ROOT=$PWD
 OUT=$ROOT/$1; mkdir -p $OUT

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Which change since round 1 costs the headline step its 0.45 us?  One lease, the current library, the step kernel recompiled at run
 # time with single changes switched back (EH_JIT_DEFINES / EH_JIT_SLP), 3 000-step bench each, two rounds; dbg/r01 alongside.
+# (needs a built copy of the round-1 tree next to this one, which is NOT tracked: git worktree add dbg/r01 a6913d7 && make -C dbg/r01/easyhybrid.jl_amd/csrc -j8)
+if [ ! -d "$(dirname "$0")/../dbg/r01" ]; then echo "$0: dbg/r01 is missing (a worktree of commit a6913d7, built): see the comment at the top" >&2; exit 2; fi
 set -u
 ROOT=$PWD
 OUT=$ROOT/$1; mkdir -p $OUT
