@@ -1758,7 +1758,7 @@ static int do_fused_step(eh_handle* h, const EhSplit& sp, const int* idx, long l
 // Several fused-update steps in one launch (EH_MODE_TRAIN_MULTI, eh_device.hpp): minibatches one workgroup covers -- the reference's
 // default batch of 64 among them -- with the step-to-step state in LDS.
 static bool multi_ok(const eh_handle* h, long long batch) {
-    if (!h->fused || !h->multi_step || h->lform || h->arch->wide || h->p2p_on || h->prof || h->stamps || h->capturing) return false;
+    if (!h->fused || !h->multi_step || h->lform || h->arch->wide || h->p2p_on || h->prof || h->capturing) return false;
     if (h->net.T != 1 || h->net.mech == EH_MECH_PROGRAM || h->net.loss == EH_LOSS_PROGRAM || h->act == EH_ACT_PER_NET) return false;
     if (h->bn_on && (h->bn_ext || h->bn_no_self || batch > EH_BN_SELF_MAX)) return false;
     if (h->arch->var[h->variant].lds_bytes + sizeof(float) * (size_t)eh_ms_extra_floats(h->net.n_theta, h->n_acc) > EH_LDS_LIMIT) return false;
@@ -1773,7 +1773,7 @@ static int do_fused_multi(eh_handle* h, const EhSplit& sp, const int* idx, long 
     EhStepArgs a{};
     a.prog = h->prog;
     a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = std::min(batch, end - first);
-    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = nullptr;
+    a.image = h->image; a.slab = h->slab; a.n_acc = h->n_acc; a.inv_n = nullptr; a.rmap = h->rmap; a.stamps = h->stamps;      // (diagnostic builds: the stamps of the launch's LAST step remain)
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     EhFused& z = a.fz;
     z.gacc = h->gacc; z.pset = h->pset; z.imap = h->imap; z.loss_slot = h->pending_loss;
