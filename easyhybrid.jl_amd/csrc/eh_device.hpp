@@ -1728,22 +1728,24 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         constexpr int NTHR = 64 * NW;
 #ifdef EH_SPEC_NET
         constexpr EhNet cnet = {EH_SPEC_NET};
-        const int nth = cnet.n_theta;
+        const int nth = cnet.n_theta, g_off = cnet.g_off;
 #else
-        const int nth = net.n_theta;
+        const int nth = net.n_theta, g_off = net.g_off;
 #endif
         const int np = 6 * nth + 4, ng = 3 * EH_GSHARDS * a.n_acc + 4;
         float* const l_pset = eh_ms_smem + G::TOTAL_FLOATS;
         float* const l_gacc = l_pset + ((np + 3) & ~3);
+        int* const l_imap = reinterpret_cast<int*>(l_gacc + ((ng + 3) & ~3));      // canonical index -> image offset: read by every step's update (a global round trip per step otherwise)
         for (int i = threadIdx.x; i < np; i += NTHR) l_pset[i] = a.fz.pset[i];
         for (int i = threadIdx.x; i < ng; i += NTHR) l_gacc[i] = a.fz.gacc[i];
+        for (int i = threadIdx.x; i < g_off; i += NTHR) l_imap[i] = a.fz.imap[i];
         __syncthreads();
         for (int k = 0; k < a.ms_nsteps; ++k) {
             EhStepArgs b = a;
             b.first = a.first + (long long)k * a.ms_batch;
             const long long left = a.ms_end - b.first;
             b.count = left < (long long)a.ms_batch ? left : (long long)a.ms_batch;
-            b.fz.pset = l_pset; b.fz.gacc = l_gacc;
+            b.fz.pset = l_pset; b.fz.gacc = l_gacc; b.fz.imap = l_imap;
             b.fz.gslot = (a.fz.gslot + k) % 3;
             b.fz.cur = a.fz.cur ^ (k & 1);
             b.fz.sc_sel = a.fz.sc_sel ^ (k & 1);
@@ -1760,7 +1762,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
     }
 }
 // LDS floats behind the step body's work space that the multi-step kernel keeps its state in (host side: launch size, eligibility)
-__host__ __device__ inline long long eh_ms_extra_floats(int n_theta, int n_acc) { return (long long)((6 * n_theta + 4 + 3) & ~3) + 3LL * EH_GSHARDS * n_acc + 4; }
+__host__ __device__ inline long long eh_ms_extra_floats(int n_theta, int n_acc) { return (long long)((6 * n_theta + 4 + 3) & ~3) + ((3LL * EH_GSHARDS * n_acc + 4 + 3) & ~3LL) + n_theta + 4; }
 #ifdef EH_SPEC_NS
 }   // namespace EH_SPEC_NS
 using namespace EH_SPEC_NS;
