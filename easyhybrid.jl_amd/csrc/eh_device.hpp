@@ -888,8 +888,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         __syncthreads();
     }
     float bn_s1 = 0.0f, bn_s2 = 0.0f;
-    if (bn_self && tid < net.P) { bn_s1 = bn_red[(NTHR / 32) * 64 + tid]; bn_s2 = bn_red[(NTHR / 32) * 64 + 32 + tid]; }
-    __syncthreads();
+    if (bn_self) {          // (uniform; the barrier only where the scratch is in use: the headline step has no BatchNorm and no barrier to spare)
+        if (tid < net.P) { bn_s1 = bn_red[(NTHR / 32) * 64 + tid]; bn_s2 = bn_red[(NTHR / 32) * 64 + 32 + tid]; }
+        __syncthreads();
+    }
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
     __syncthreads();
     if (a.bn_part || bn_self) {
