@@ -1065,8 +1065,12 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
                 return fail(h, EH_EUNSUPPORTED, "precision: the bf16 kernels keep only the rounded activation (tanh / sigmoid / relu / identity; not swish, not per-net activations)");
             if (h->fused) return fail(h, EH_EUNSUPPORTED, "precision: switch fused_update off first (the row-split kernels have no such mode)");
             const EhArchInfo* W = h->arch->wide ? h->arch : h->arch_alt;
+            // one network (the slab row in plain canonical order): the sample-owned training kernel (eh_bf16_sample.hpp); else the row-split one
+            static const bool no_so = getenv("EH_NO_DIRECT_STORE") != nullptr || getenv("EH_NO_SAMPLE_OWNED") != nullptr;      // (A/B switches of the measurement tools)
+            const bool so_ok = !no_so && h->n_nets == 1 && h->desc.n_nets == 0;
             int vb = -1;
-            if (W) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16 == (int)value) { vb = vi; break; }
+            if (W && so_ok) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16 == (int)value && W->var[vi].so) { vb = vi; break; }
+            if (W && vb < 0) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16 == (int)value && !W->var[vi].so) { vb = vi; break; }
             if (vb < 0) return fail(h, EH_EUNSUPPORTED, "precision: no bf16 kernel is built for this shape (row-split shapes only: hidden width 33..128)");
             HIPCHK(h, hipSetDevice(h->device));
             FLUSH(h);
@@ -1083,6 +1087,8 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "variant")) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
         if (h->arch->var[value].bf16 != h->arch->var[h->variant].bf16) return fail(h, EH_EINVAL, "variant %lld belongs to the other precision (set the \"precision\" option)", (long long)value);
+        if (h->arch->var[value].so && (h->n_nets != 1 || h->desc.n_nets != 0 || getenv("EH_NO_DIRECT_STORE")))
+            return fail(h, EH_EUNSUPPORTED, "variant %lld is the sample-owned training kernel: one-network models only", (long long)value);
         h->variant = (int)value;
         HIPCHK(h, hipSetDevice(h->device));      // the reduction map depends on the variant (waves of a row-split workgroup; layout of the parked accumulators)
         return build_maps(h, false);

@@ -19,6 +19,8 @@ struct EhVariant {
     int tiles;               // macro-tiles a workgroup works on at a time; 0 = nw (one per wave)
     int bf16;                // eh_widebf_kernel (eh_wide_bf16.hpp), the "precision" option: 1 = bf16 forward products, fp32-exact backward (three-term deltas);
                              // 2 = bf16 operands in both passes (deltas rounded once); 0 = the fp32 kernels
+    int so;                  // != 0: the TRAIN kernel is the sample-owned eh_bfs_kernel (eh_bf16_sample.hpp; one-network models only, 16 * nw-sample
+                             // tiles: nt == nw); evaluation passes run eh_widebf_kernel with so x 16-sample tiles.  What "precision" selects.
 };
 
 struct EhArchInfo {
@@ -27,7 +29,7 @@ struct EhArchInfo {
     int ip, hp, s0, sh, w0_off, wh_off, wo_off, b_off, phi_off, img_floats;
     int has_fast;            // K1 / small-P kernels compiled for this shape
     int nvar;
-    EhVariant var[6];
+    EhVariant var[8];
     int wide;                // eh_wide_kernel (eh_wide.hpp): the four waves of a workgroup share one tile and split the layers by rows
 };
 
@@ -42,7 +44,7 @@ struct EhSpecKernel {
     hipError_t (*prepare)(void);
     hipError_t (*launch)(int mode, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args);
 };
-#define EH_SPEC_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define EH_SPEC_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
 #define EH_SPEC_DECL(k) extern "C" const EhSpecKernel* eh_spec_##k(void);
 EH_SPEC_LIST(EH_SPEC_DECL)
 #undef EH_SPEC_DECL

@@ -4,6 +4,7 @@
 #include "eh_arch.hpp"
 #include "eh_wide.hpp"
 #include "eh_wide_bf16.hpp"
+#include "eh_bf16_sample.hpp"
 
 #ifndef EH_NBI
 #error "build with -DEH_NBI -DEH_NBH -DEH_NL"
@@ -121,15 +122,54 @@ struct VarBf {
     static constexpr EhVariant info() { return EhVariant{NTB, NWV, LDS, 1 << 30, &prepare, &launch, 1, NS == 3 ? 1 : 2}; }
 };
 
+// the sample-owned training kernel of the bf16 modes (eh_bf16_sample.hpp): what "precision" selects for a one-network model.  Its
+// evaluation passes -- and nothing else: the handle keeps models with a mapped slab row off this variant -- run the row-split kernel.
+template <int NWV, int NS>
+struct VarBfs {
+    using Old = VarBf<NWV, 0, NS>;
+    using Geom = EhBfsGeom<EH_NBI, EH_NBH, EH_NL, NWV, NS>;
+    static constexpr size_t LDS_T = sizeof(float) * Geom::TOTAL_FLOATS;
+    static constexpr size_t LDS = LDS_T > Old::LDS ? LDS_T : Old::LDS;      // (one figure per variant: what a run-time build of its kernels is launched with)
+    static_assert(LDS_T <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
+    template <int ACT>
+    static hipError_t prep1() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&eh_bfs_kernel<EH_NBI, EH_NBH, EH_NL, NWV, ACT, false, NS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_T);
+    }
+    static hipError_t prepare() {
+        hipError_t e;
+        if ((e = Old::prepare()) != hipSuccess) return e;
+        if ((e = prep1<EH_ACT_TANH>()) != hipSuccess) return e;
+        if ((e = prep1<EH_ACT_SIGMOID>()) != hipSuccess) return e;
+        if ((e = prep1<EH_ACT_RELU>()) != hipSuccess) return e;
+        return prep1<EH_ACT_IDENTITY>();
+    }
+#define EH_GO(ACT) hipLaunchKernelGGL((eh_bfs_kernel<EH_NBI, EH_NBH, EH_NL, NWV, ACT, false, NS>), dim3(grid), dim3(64 * NWV), LDS_T, stream, *net, *args)
+    static hipError_t launch(int mode, int act, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
+        if (mode == EH_MODE_EVAL) return Old::launch(mode, act, fast, grid, stream, net, args);
+        if (mode != EH_MODE_TRAIN || (fast & 4) || args->rmap) return hipErrorNotSupported;
+        switch (act) {
+            case EH_ACT_TANH: EH_GO(EH_ACT_TANH); break;
+            case EH_ACT_SIGMOID: EH_GO(EH_ACT_SIGMOID); break;
+            case EH_ACT_RELU: EH_GO(EH_ACT_RELU); break;
+            case EH_ACT_IDENTITY: EH_GO(EH_ACT_IDENTITY); break;
+            default: return hipErrorNotSupported;
+        }
+        return hipGetLastError();
+    }
+#undef EH_GO
+    static constexpr EhVariant info() { return EhVariant{NWV, NWV, LDS, 1 << 30, &prepare, &launch, 1, NS == 3 ? 1 : 2, Old::NTB}; }
+};
+
 using G0 = EhWideGeom<EH_NBI, EH_NBH, EH_NL, NT, 4>;
 const EhArchInfo info = {
     EH_NBI, EH_NBH, EH_NL,
     G0::IP, G0::HP, G0::S0, G0::SH, G0::W0_OFF, G0::WH_OFF, G0::WO_OFF, G0::B_OFF, G0::PHI_OFF, G0::IMG_FLOATS,
     0,
 #if EH_NBH == 8
-    6, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), VarBf<8, 2>::info(), VarBf<8, 0, 1>::info(), VarBf<8, 2, 1>::info()},
+    7, {Var<8>::info(), Var<4>::info(), VarBf<8>::info(), VarBf<8, 2>::info(), VarBf<8, 0, 1>::info(), VarBf<8, 2, 1>::info(), VarBfs<8, 1>::info()},
 #else
-    3, {Var<4>::info(), VarBf<4>::info(), VarBf<4, 0, 1>::info(), {}, {}, {}},
+    4, {Var<4>::info(), VarBf<4>::info(), VarBf<4, 0, 1>::info(), VarBfs<4, 1>::info(), {}, {}, {}, {}},
 #endif
     1,
 };

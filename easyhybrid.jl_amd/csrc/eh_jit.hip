@@ -347,10 +347,10 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
                  spec->n_theta, spec->g_off, spec->scale_nn, spec->mech, spec->n_par, spec->loss, spec->n_out, spec->targ_out, spec->par_kind, spec->par_idx, spec->forc_col, spec->loss_t);
         src += b;
     }
-    src += V.bf16 ? "#include \"eh_wide_bf16.hpp\"\n" : A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
-    const char* hnames[7] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", "eh_wide_bf16.hpp", nullptr, nullptr, nullptr};
-    const char* hsrc[7] = {eh_src_device, eh_src_wide, eh_src_public, eh_src_widebf, nullptr, nullptr, nullptr};
-    int nh = 4;
+    src += V.so ? "#include \"eh_bf16_sample.hpp\"\n" : V.bf16 ? "#include \"eh_wide_bf16.hpp\"\n" : A->wide ? "#include \"eh_wide.hpp\"\n" : "#include \"eh_device.hpp\"\n";
+    const char* hnames[8] = {"eh_device.hpp", "eh_wide.hpp", "easyhybrid_hip.h", "eh_wide_bf16.hpp", "eh_bf16_sample.hpp", nullptr, nullptr, nullptr};
+    const char* hsrc[8] = {eh_src_device, eh_src_wide, eh_src_public, eh_src_widebf, eh_src_bfs, nullptr, nullptr, nullptr};
+    int nh = 5;
     if (prog) { hnames[nh] = "eh_jit_mech.inc"; hsrc[nh++] = mech.c_str(); }
     if (loss) { hnames[nh] = "eh_jit_loss.inc"; hsrc[nh++] = lsrc.c_str(); }
     if (rowact) { hnames[nh] = "eh_jit_rowact.inc"; hsrc[nh++] = rsrc.c_str(); }
@@ -365,7 +365,9 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     char name[4][160];
     for (int i = 0; i < nmode; ++i) {
         const int m = modes[i];
-        if (A->wide && V.bf16) snprintf(name[i], sizeof name[i], "eh_widebf_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
+        if (A->wide && V.so && m == EH_MODE_TRAIN) snprintf(name[i], sizeof name[i], "eh_bfs_kernel<%d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.nw, act, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
+        else if (A->wide && V.so) snprintf(name[i], sizeof name[i], "eh_widebf_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.so, V.nw, act, m, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
+        else if (A->wide && V.bf16) snprintf(name[i], sizeof name[i], "eh_widebf_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false", V.bf16 == 2 ? 1 : 3);
         else if (A->wide) snprintf(name[i], sizeof name[i], "eh_wide_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m, prog ? "true" : "false");
         else snprintf(name[i], sizeof name[i], "eh_step_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", A->nbi, A->nbh, A->nl, V.nt, V.nw, act, m,
                       (m == EH_MODE_EVAL) ? (fast & 5) : fast);       // (the eval kernels exist for FAST 0 / 1 / 4)
@@ -405,7 +407,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
             h = fnv(h, ver, sizeof ver);
             h = fnv(h, src.data(), src.size()); h = fnv(h, mech.data(), mech.size()); h = fnv(h, lsrc.data(), lsrc.size()); h = fnv(h, rsrc.data(), rsrc.size());
             h = fnv(h, eh_src_device, sizeof eh_src_device); h = fnv(h, eh_src_wide, sizeof eh_src_wide); h = fnv(h, eh_src_public, sizeof eh_src_public);
-            h = fnv(h, eh_src_widebf, sizeof eh_src_widebf);
+            h = fnv(h, eh_src_widebf, sizeof eh_src_widebf); h = fnv(h, eh_src_bfs, sizeof eh_src_bfs);
             for (int m = 0; m < nmode; ++m) h = fnv(h, name[m], strlen(name[m]));
             for (const char* o : opts) h = fnv(h, o, strlen(o));
             char fn[64];

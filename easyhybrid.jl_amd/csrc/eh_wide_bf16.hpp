@@ -477,6 +477,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
             *(bf16x4*)q = p0; *(bf16x4*)(q + PZ) = p1; *(bf16x4*)(q + 2 * PZ) = p2;
         }
     };
+    // what a delta block adds to its bias gradient: itself (exact mode), its once-rounded value ("bf16": the operand of the products)
+    auto bias_term = [&](const f32x4& d) {
+        if constexpr (NS == 1) return f32x4{eh_bf2f((__bf16)d[0]), eh_bf2f((__bf16)d[1]), eh_bf2f((__bf16)d[2]), eh_bf2f((__bf16)d[3])};
+        else return d;
+    };
     // stored (rounded) activations of features 16m+4g .. +3 of sample 16t+c
     auto load_h4 = [&](const __bf16* img, int m, int t) {
         const bf16x4 p = *(const bf16x4*)&img[(16 * t + c) * SHB + 16 * m + 4 * g];
@@ -570,6 +575,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
                 f32x4 dO;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dO[r] = OS[(4 * g + r) * SR + 16 * t + c];
+                if constexpr (NS == 1) {          // "bf16": the bias gradient sums the once-rounded delta, the operand of the products (oracle _backprop)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dO[r] = eh_bf2f((__bf16)dO[r]);
+                }
                 aBo += dO;
             }
         }
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
                 const f32x4 hv = load_h4(Hlast, m, t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dh[t][r] * eh_dact_row<ACT>(hv[r], NL - 1, 16 * m + 4 * g + r);
-                aB[NL - 1][mm] += dzr[mm][t];
+                aB[NL - 1][mm] += bias_term(dzr[mm][t]);
             }
         }
         // the split-K partials (aliasing the delta planes) were last read in step 4b: safe to overwrite now
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_widebf_kernel(const EhNet net_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dzr[mm][t][r] = dn[mm][t][r] * eh_dact_row<ACT>(hv[r], l - 1, 16 * (m0 + mm) + 4 * g + r);
                     store_dz(dzr[mm][t], m0 + mm, t);
-                    aB[l - 1][mm] += dzr[mm][t];
+                    aB[l - 1][mm] += bias_term(dzr[mm][t]);
                 }
             eh_lds_barrier();
         }

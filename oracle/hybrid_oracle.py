@@ -375,7 +375,7 @@ class HybridSpec:
     # "bf16": the usual reading of "bf16 / fp32 accumulate" -- bf16 operands in BOTH passes.  The forward of "bf16_fwd"; in the
     # backward pass every delta (d loss / d pre-activation of a layer, the NN-output one included) is computed in fp32 and rounded
     # to bfloat16 before it enters the two Dense products it feeds: dW = bf16(dZ) * bf16(h)^T, dH = bf16(W)^T bf16(dZ), both
-    # accumulated exactly (fp32 on the device).  The bias gradients are sums of the un-rounded fp32 deltas (no product involved).
+    # accumulated exactly (fp32 on the device).  The bias gradients are the row sums of the same rounded deltas (dZ * 1: a product like the others; rounds 2-4 summed the un-rounded deltas).
     # The deltas are rounded IN THE SCALE THE STEP CARRIES THEM: a one-target model back-propagates the UN-normalised loss (sum of
     # squared / absolute residuals; the division by n, 2 n rmse or sum (y - ybar)^2 is applied to the finished gradient in fp32 --
     # n is only known once the pass is over, and under data parallelism only after the all-reduce), so what is rounded is n times the
@@ -716,7 +716,9 @@ def _backprop(spec, tp, dout, dt, B, dout_un=None, defer=None):
         for li in reversed(range(len(Ws))):
             W, b = Ws[li]
             dq = round_bf16(delta) if bfb else delta
-            gWs.append(((dq @ hs[li].T) * sc, delta.sum(axis=1) * sc))
+            # (the bias gradient is the row sum of the SAME operand -- dZ * 1 -- so "bf16" sums the once-rounded delta, as a framework that
+            #  hands a bfloat16 dZ to both reductions does; round 5: the device forms it as a product with a vector of ones)
+            gWs.append(((dq @ hs[li].T) * sc, dq.sum(axis=1) * sc))
             if li > 0:
                 delta = (W.T @ dq) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
         gWs.reverse()

@@ -54,8 +54,8 @@ class _RoundedAct(torch.autograd.Function):
 
 class _RoundedGrad(torch.autograd.Function):
     """spec.precision == "bf16": the identity forward; the gradient passing back through it is rounded to bfloat16.  Placed on the
-    product W h of a Dense layer (ahead of the bias add), it makes both backward products of the layer -- dW = d h^T, dh = W^T d --
-    take the rounded delta, while the bias gradient sums the un-rounded one."""
+    pre-activation W h + b of a Dense layer, it makes everything the layer's delta feeds -- dW = d h^T, dh = W^T d and the bias gradient
+    d 1 -- take the rounded delta."""
 
     @staticmethod
     def forward(ctx, x):
@@ -107,7 +107,7 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
             off += o * i
             b = theta[off:off + o]
             off += o
-            z = (_RoundedGrad.apply(W @ h) if bfb else W @ h) + b[:, None]
+            z = _RoundedGrad.apply(W @ h + b[:, None]) if bfb else W @ h + b[:, None]
             if li == len(dims) - 1: h = z
             elif bf: h = _RoundedAct.apply(z, spec.act_of(k_net))
             else: h = _act(spec.act_of(k_net), z)

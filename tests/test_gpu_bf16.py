@@ -63,7 +63,7 @@ def test_config5_loss_and_gradient_match_the_bf16_oracle(B):
 
 @pytest.mark.parametrize("B", [33, 1000, 4096])
 def test_config5_bf16_operands_in_both_passes_match_the_oracle(B):
-    """precision = "bf16": the same forward as "bf16_fwd" (bit for bit the same loss), the backward products on once-rounded deltas"""
+    """precision = "bf16": the same forward as "bf16_fwd", the backward products (bias sums included) on once-rounded deltas"""
     spec, theta, X, f, y = _case(B, precision="bf16")
     eng = util.load_engine(spec, theta, X, f, y)
     loss, grad, l0, g0 = _check(eng, spec, theta, X, f, y, gtol=GTOL_BF16)
@@ -72,7 +72,9 @@ def test_config5_bf16_operands_in_both_passes_match_the_oracle(B):
     l1, g1, _ = eng.loss_and_grad()
     specf = ho.c5_spec(precision="bf16_fwd")
     _, gf, _ = ho.loss_and_grad(specf, theta.astype(np.float64), X, f, y)
-    assert l1 == loss and util.relerr(g1, gf) <= 5e-5
+    # (the same forward FUNCTION; since round 5 the two modes run different kernels -- "bf16" the sample-owned one, csrc/eh_bf16_sample.hpp --
+    #  so the loss sums agree to the order of summation, not bit for bit)
+    assert abs(l1 - loss) <= 1e-6 * abs(loss) and util.relerr(g1, gf) <= 5e-5
     assert util.relerr(grad, g1) > 5e-5, util.relerr(grad, g1)      # (a test that would not notice a kernel that ignored the option)
     # ... and the oracle sees the same distance between the two modes
     assert abs(util.relerr(g0, gf) - util.relerr(grad, g1)) <= 0.1 * util.relerr(g0, gf) + GTOL_BF16
