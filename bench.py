@@ -96,7 +96,7 @@ def spawn_ranks_once(nprocs, cmd, env=None, capture=False, timeout=None):
 
 
 def cpu_baseline(batch, seconds=12.0):
-    """The CPU oracle (plain-C port, OpenMP over samples) timed on this box's host cores, on a
+    """The CPU oracle (C port in its blocked, vectorised form -- oracle/eh_oracle_fast.c -- OpenMP over sample blocks) timed on this box's host cores, on a
     bounded sample of the same workload: steps of `batch` samples for ~`seconds` of CPU work.  The
     thread count is the best of a short sweep (all cores is not the fastest on a 256-thread host)."""
     from oracle import c_oracle as co
@@ -107,20 +107,21 @@ def cpu_baseline(batch, seconds=12.0):
     theta = ho.init_theta(spec, 1, np.float32)
     best, per = None, None
     for nt in sorted({min(avail, k) for k in (8, 16, 32, 64, 128, 256, avail)}):
-        co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt)          # warm-up (page-in, thread pool)
+        co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt, fast=True)          # warm-up (page-in, thread pool)
         t0 = time.perf_counter()
-        co.train_steps(spec, theta, X, f, y, batch, 2, nthreads=nt)
+        co.train_steps(spec, theta, X, f, y, batch, 2, nthreads=nt, fast=True)
         t = (time.perf_counter() - t0) / 2
         if per is None or t < per:
             best, per = nt, t
     n, chunk, t0 = 0, max(2, min(64, int(1.0 / max(per, 1e-4)))), time.perf_counter()
     while time.perf_counter() - t0 < seconds:              # bounded by wall time, whatever the sweep estimated
-        co.train_steps(spec, theta, X, f, y, batch, chunk, nthreads=best)
+        co.train_steps(spec, theta, X, f, y, batch, chunk, nthreads=best, fast=True)
         n += chunk
     dt = time.perf_counter() - t0
     out = {"value": batch * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
-           "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the plain-C oracle port, "
-                     f"OpenMP over samples on {best} of {avail} host threads (fastest of a short sweep)",
+           "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the C port in its blocked form "
+                     f"(oracle/eh_oracle_fast.c: 16 samples per SIMD block, AVX2, rational tanh, vector exp / log; the scalar checker "
+                     f"oracle/eh_oracle.c is not what is timed), OpenMP over blocks on {best} of {avail} host threads (fastest of a short sweep)",
            "ms_per_step": 1e3 * dt / n}
     # PyTorch-CPU eager autograd + Adam on the same batch -- the structurally closest stand-in for the
     # reference's Lux + Zygote step this box can run (BLAS GEMMs, un-fused broadcasts, tape, boolean-mask gather); ~3 s
@@ -142,9 +143,9 @@ def cpu_baseline(batch, seconds=12.0):
         eager = out.pop("eager")
         out.update(eager)
         out["c_port"] = c_port
-        out["which"] = "PyTorch-CPU eager (the faster of the two CPU ports on this host); the plain-C OpenMP port under c_port"
+        out["which"] = "PyTorch-CPU eager (the faster of the two CPU ports on this host); the blocked C / OpenMP port under c_port"
     else:
-        out["which"] = "plain-C OpenMP port (the faster of the two CPU ports on this host); PyTorch-CPU eager under eager"
+        out["which"] = "blocked C / OpenMP port, oracle/eh_oracle_fast.c (the faster of the two CPU ports on this host); PyTorch-CPU eager under eager"
     # BASELINE.json configs[0]: "batch = 1024, CPU reference path" (B = 1 024 and 65 536, >= 50 steps, median / p10 / p90)
     try:
         out["c1_batch_1024"] = cpu_baseline_c1(spec, theta, X, f, y, avail)
@@ -165,14 +166,14 @@ def cpu_baseline_c1(spec, theta, X, f, y, avail, batch=1024, nsteps=60):
     best = None
     for nt in sorted({min(avail, k) for k in (1, 4, 8, 16, 32)}):            # (1 024 samples: few threads win)
         for _ in range(5):
-            co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt)
+            co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt, fast=True)
         ts = []
         for _ in range(nsteps):
-            t0 = time.perf_counter(); co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt); ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt, fast=True); ts.append(time.perf_counter() - t0)
         st = stats(ts)
         if best is None or st["median_ms"] < best[1]["median_ms"]:
             best = (nt, st)
-    res["c_port"] = {**best[1], "cores": best[0], "kind": "port", "what": "plain-C oracle port, one Adam step per call (fastest thread count of 1 / 4 / 8 / 16 / 32)"}
+    res["c_port"] = {**best[1], "cores": best[0], "kind": "port", "what": "C port, blocked form (oracle/eh_oracle_fast.c), one Adam step per call (fastest thread count of 1 / 4 / 8 / 16 / 32)"}
     try:
         import torch
         from oracle import torch_twin as tt

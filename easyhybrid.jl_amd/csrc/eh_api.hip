@@ -338,7 +338,11 @@ static const EhSpecKernel* spec_lookup(const eh_handle* h) {
         EH_SPEC_LIST(EH_SPEC_ITEM)
 #undef EH_SPEC_ITEM
     };
-    static bool prepared[sizeof list / sizeof list[0]] = {};
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per DEVICE: several handles of one process on different devices
+    // (eh_p2p_init_local, eh_comm_init_local) each need the raised LDS limit (advisor, round 4: a per-process flag left every device but
+    // the first with a kernel that failed to launch on every step and fell back silently)
+    static std::mutex mu;
+    static uint64_t prepared[sizeof list / sizeof list[0]] = {};          // bit d: prepared on device d
     if (!h->aot_spec || h->lform || h->act == EH_ACT_PER_NET) return nullptr;
     const EhArchInfo* A = h->arch;
     const EhVariant& V = A->var[h->variant];
@@ -347,9 +351,13 @@ static const EhSpecKernel* spec_lookup(const eh_handle* h) {
         const EhSpecKernel* k = list[i];
         if (k->wide != (A->wide != 0) || k->bf16 != V.bf16 || k->nbi != A->nbi || k->nbh != A->nbh || k->nl != A->nl || k->nt != V.nt || k->nw != V.nw ||
             k->act != h->act || k->fast != kf || memcmp(&k->net, &h->net, sizeof(EhNet)) != 0) continue;
-        if (!prepared[i]) {
-            if (k->prepare() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            prepared[i] = true;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            const uint64_t bit = 1ull << (h->device & 63);
+            if (!(prepared[i] & bit)) {
+                if (hipSetDevice(h->device) != hipSuccess || k->prepare() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                prepared[i] |= bit;
+            }
         }
         return k;
     }
@@ -1032,6 +1040,10 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->check_idx = value != 0;           // a small kernel + one synchronisation per step; host indices are always checked
         return EH_OK;
     }
+    if (!strcmp(name, "empty_target_nan")) { // a target with no valid sample inside a batch that has some: the gradient is the reference's either way (that target adds
+        h->empty_nan = value != 0;           // nothing); the VALUE is the sum of the other targets (0, default) or the reference's NaN = mean over an empty selection
+        return EH_OK;                        // (1; src/losses/loss_fn.jl:61-63), reported by eh_loss_and_grad -- the seam where the reference's objective is called directly
+    }
     if (!strcmp(name, "aot_spec")) {         // 0 = never the kernels specialised ahead of time for the canonical descriptors (eh_spec.hip): tests of the other paths, A/B
         h->aot_spec = value != 0;
         return EH_OK;
@@ -1171,8 +1183,10 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
             pageable.resize((size_t)CH * C);
             stage[0] = stage[1] = pageable.data();
         } else {
-            HIPCHK(h, hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+            // (an event that cannot be made: the first one is not leaked and a one-off staging pair not kept; advisor, round 4)
+            hipError_t ee = hipEventCreateWithFlags(&done[0], hipEventDisableTiming);
+            if (ee == hipSuccess) { ee = hipEventCreateWithFlags(&done[1], hipEventDisableTiming); if (ee != hipSuccess) (void)hipEventDestroy(done[0]); }
+            if (ee != hipSuccess) { if (!pooled) { (void)hipHostFree(stage[0]); (void)hipHostFree(stage[1]); } HIPCHK(h, ee); }
         }
         const int P = net.P, F = net.F, T = net.T;
         auto pack = [&](float* dst, int64_t s0, int64_t s1, int64_t base) {
@@ -1196,11 +1210,18 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
                 const int nthr = (int)std::max<int64_t>(2, std::min<int64_t>({(int64_t)8, (int64_t)(hw ? hw / 2 : 2), cnt / 32768}));
                 const int64_t per = (cnt + nthr - 1) / nthr;
                 std::vector<std::thread> others;
-                for (int w = 1; w < nthr; ++w) {
-                    const int64_t a0 = s0 + w * per, a1 = std::min(s0 + cnt, a0 + per);
-                    if (a0 < a1) others.emplace_back([&, a0, a1] { pack(buf, a0, a1, s0); });
+                int64_t mine_end = std::min(s0 + cnt, s0 + per);
+                try {                    // (no exception crosses the C ABI: a thread that cannot be started leaves its run of samples to this one)
+                    for (int w = 1; w < nthr; ++w) {
+                        const int64_t a0 = s0 + w * per, a1 = std::min(s0 + cnt, a0 + per);
+                        if (a0 < a1) others.emplace_back([&, a0, a1] { pack(buf, a0, a1, s0); });
+                    }
+                } catch (...) {
+                    for (auto& t : others) t.join();
+                    others.clear();
+                    mine_end = s0 + cnt;         // single-threaded: everything (the threads that did start packed the same values into the same places)
                 }
-                pack(buf, s0, std::min(s0 + cnt, s0 + per), s0);
+                pack(buf, s0, mine_end, s0);
                 for (auto& t : others) t.join();
             } else pack(buf, s0, s0 + cnt, s0);
             if (pinned) {
@@ -1208,7 +1229,9 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
                 if (err == hipSuccess) err = hipEventRecord(done[k & 1], h->stream);
             } else err = hipMemcpy(sp.recs + (size_t)s0 * C, buf, (size_t)cnt * C * sizeof(float), hipMemcpyHostToDevice);
         }
-        if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
+        // always drained before the staging pair is released or handed to the next caller -- also after an error: copies of earlier chunks
+        // may still be reading it (advisor, round 4)
+        { const hipError_t es = hipStreamSynchronize(h->stream); if (err == hipSuccess) err = es; }
         if (pinned) { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); if (!pooled) { (void)hipHostFree(stage[0]); (void)hipHostFree(stage[1]); } }
         HIPCHK(h, err);
     }
@@ -1265,14 +1288,15 @@ static int eval_grid_for(const eh_handle* h, long long count) {
 }
 
 // input BatchNorm: statistics of the minibatch [first, first+count) -> a.bn_* (train-mode kernels only)
-static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool update, EhStepArgs* a) {
+// consume = false: a forward-only pass in front of the step's training pass (eh_dp_moments) -- the global statistics stay for the passes behind it
+static int bn_prepare(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool update, EhStepArgs* a, bool consume = true) {
     a->bn_part = nullptr; a->bn_nblk = 0; a->bn_update = 0; a->bn_run = h->bn_run; a->image_out = h->image;
     a->bn_c = nullptr; a->bn_n = nullptr;
     if (!h->bn_on) return EH_OK;
     if (h->bn_ext) {          // statistics of the GLOBAL batch, summed over the GPUs by the host since eh_dp_bn_stats
         a->bn_part = h->bn_stat; a->bn_nblk = 1; a->bn_c = h->bn_shift; a->bn_n = h->bn_stat + 64;
         a->bn_update = (update || h->bn_dp_update) ? 1 : 0;
-        h->bn_ext = false; h->bn_dp_update = false;
+        if (consume) { h->bn_ext = false; h->bn_dp_update = false; }
         return EH_OK;
     }
     if (count <= 0) return EH_OK;
@@ -2090,7 +2114,14 @@ int32_t eh_loss_and_grad(eh_handle* h, int32_t split, const int32_t* idx, int64_
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int nt = h->net.n_theta;
     if (grad) memcpy(grad, host.data(), (size_t)nt * sizeof(float));
-    if (loss) *loss = host[nt];
+    if (loss) {
+        *loss = host[nt];
+        if (h->empty_nan && h->net.T > 1) {
+            bool some = false, empty = false;
+            for (int t = 0; t < h->net.T; ++t) { some = some || host[nt + 1 + t] > 0.0f; empty = empty || !(host[nt + 1 + t] > 0.0f); }
+            if (some && empty) *loss = std::nanf("");
+        }
+    }
     if (n_valid) {
         double c = 0;
         for (int t = 0; t < h->net.T; ++t) c += host[nt + 1 + t];
@@ -2446,7 +2477,9 @@ int32_t eh_dp_moments(eh_handle* h, int64_t first, int64_t count, int32_t stage)
     e.image = h->image; e.slab = h->slab; e.n_acc = EH_EVAL_STATS * net.T; e.rmap = h->rmap; e.stamps = nullptr;
     e.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) e.shift[t] = sp.shift[t];
-    if (int rc = bn_prepare(h, sp, idx, first, count, false, &e)) return rc;
+    // (the global BatchNorm statistics of eh_dp_bn_stats serve both moment passes AND the training pass behind them: eh_dp_grad /
+    //  eh_dp_fused_step consume them; advisor, round 4: stage 0 used to clear them and every later pass of the step failed)
+    if (int rc = bn_prepare(h, sp, idx, first, count, false, &e, /*consume*/ false)) return rc;
     EhShift4 s4; for (int t = 0; t < EH_MAX_TARG; ++t) s4.c[t] = sp.shift[t];
     if (stage == 1) {        // the all-reduced sums about the shift -> the centre of yhat of the global batch
         hipLaunchKernelGGL(eh_moment_centre_kernel, dim3(net.T), dim3(64), 0, h->stream, h->mombuf, 1, net.T, net.loss_t, s4, h->inv_n);

@@ -144,7 +144,7 @@ static int p2p_alloc(eh_handle* h, int32_t world, int32_t rank, hipIpcMemHandle_
         e = hipIpcGetMemHandle(handle_out, buf);
         if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return fail(h, EH_EUNSUPPORTED, "%s: hipIpcGetMemHandle: %s", who, hipGetErrorString(e)); }
     }
-    h->p2p_recv = buf;
+    h->p2p_recv = buf; h->p2p_local = handle_out == nullptr;      // (known from here on: an error below leaves buffers that the caller's clean-up frees)
     HIPCHK(h, hipMalloc(&h->p2p_stage, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK(h, hipMemset(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->p2p_ctr, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));      // [0] top ticket, [1] error flag, [2] self-test mismatches, [32 (1 + g)] group tickets
@@ -276,7 +276,14 @@ int32_t eh_p2p_init_local(eh_handle* const* handles, int32_t n, int32_t selftest
         if (handles[i]->pending) return fail(handles[i], EH_ESTATE, "eh_p2p_init_local: handle %d has a training step pending (eh_synchronize first)", i);
     }
     if (int rc = eh_enable_peer_access(handles, n, "eh_p2p_init_local")) return rc;
-    auto undo = [&](int rc) { for (int i = 0; i < n; ++i) if (handles[i]->p2p_alloc) { handles[i]->p2p_on = false; (void)p2p_disable_one(handles[i]); } return rc; };
+    // (every member's stream is drained BEFORE any buffer is freed: self-test kernels of the earlier members may still be storing into their
+    //  peers' receive buffers -- as eh_p2p_disable does; advisor, round 4)
+    auto undo = [&](int rc) {
+        for (int i = 0; i < n; ++i) { (void)hipSetDevice(handles[i]->device); (void)hipStreamSynchronize(handles[i]->stream); }
+        for (int i = 0; i < n; ++i) if (handles[i]->p2p_alloc || handles[i]->p2p_recv || handles[i]->p2p_stage || handles[i]->p2p_ctr || handles[i]->p2p_dev) { handles[i]->p2p_on = false; (void)p2p_disable_one(handles[i]); }
+        (void)hipGetLastError();
+        return rc;
+    };
     for (int i = 0; i < n; ++i)
         if (int rc = p2p_alloc(handles[i], n, i, nullptr, "eh_p2p_init_local")) return undo(rc);
     for (int i = 0; i < n; ++i) {

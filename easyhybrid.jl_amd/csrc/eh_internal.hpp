@@ -152,6 +152,7 @@ struct eh_handle_s {
     struct JitEntry { const EhArchInfo* arch; int variant, fast; bool spec, p2p; EhNet net; int loss_gen; std::atomic<int> state{0}; EhJitKernel k; std::thread worker; std::string log; bool verified = false; };
     std::vector<std::unique_ptr<JitEntry>> jit;
     bool check_idx = false;         // "check_idx" option: range-check device-side minibatch indices before the step (debug)
+    bool empty_nan = false;         // "empty_target_nan" option: eh_loss_and_grad reports NaN when a target of a non-empty batch has no valid sample (the reference's value; gradient unchanged)
     bool aot_spec = true;           // "aot_spec" option / EH_NO_AOT_SPEC: run the kernel specialised ahead of time when the descriptor is a canonical one (eh_spec.hip)
     const struct EhSpecKernel* spec_used = nullptr;      // ... the one the last launch ran (eh_jit_status reports it)
     bool specialize_async = false;  // "specialize" = 2

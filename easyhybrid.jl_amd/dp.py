@@ -135,8 +135,11 @@ class DataParallel:
             allreduce_partials(tot, group)
             tot = tot.cpu().numpy().reshape(-1, 2)
             engine.set_target_shift(np.where(tot[:, 1] > 0, tot[:, 0] / np.maximum(tot[:, 1], 1), 0.0))
-        elif self.multi:
-            raise RuntimeError("DataParallel with a multi-target model needs the train split uploaded through set_data first")
+        elif self.multi or engine.two_pass_loss:
+            # (advisor, round 4: a single-target pearson / kge engine fed through set_data_device kept its shard's own shift -- the mean of
+            #  its first 4 096 samples -- and the all-reduced moments then mixed different centres: a silently wrong gradient)
+            raise RuntimeError("DataParallel with a multi-target model or a two-pass training loss (pearson / kge / pbkge) needs the train split "
+                               "uploaded through set_data first: the shifted sums are added across ranks about ONE common shift")
         if self.multi:
             cptr, cn = engine.device_buffer(L.EH_BUF_TCOUNT)
             self.cbuf = torch.as_tensor(_DevArray(cptr, cn), device=dev)

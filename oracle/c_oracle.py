@@ -13,6 +13,7 @@ from . import hybrid_oracle as ho
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libeh_oracle.so")
 SRC = os.path.join(HERE, "eh_oracle.c")
+SRC_FAST = os.path.join(HERE, "eh_oracle_fast.c")
 
 ACT = {"tanh": 0, "sigmoid": 1, "relu": 2, "swish": 3, "identity": 4}
 MECH = {"rbq10": 0, "expo": 1, "linear": 2, "expo2pool": 3, "rs_components": 4}     # single-output models only
@@ -36,11 +37,15 @@ def _gpu_is_up() -> bool:
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(SRC):
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(SRC_FAST)):
         if _gpu_is_up():      # compiling means fork + exec, which a process that has initialised the GPU must not do on the GPU boxes
             raise RuntimeError("oracle/libeh_oracle.so is missing or stale and this process has already initialised the GPU: build it first "
                                "(python -c 'from oracle import c_oracle; c_oracle.build()', __graft_entry__.build(), or the start of a pytest session)")
-        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", SRC, "-o", SO, "-lm"])
+        # the checker (eh_oracle.c) with strict fp32 semantics; the timed blocked form (eh_oracle_fast.c) with the vector math library
+        obj = os.path.join(HERE, "eh_oracle_fast.o")
+        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-ffast-math", "-fPIC", "-c", SRC_FAST, "-o", obj])
+        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", SRC, obj, "-o", SO, "-lm"])
+        os.unlink(obj)
     return SO
 
 
@@ -54,6 +59,8 @@ def lib():
         _lib.eho_n_theta.restype = C.c_long
         _lib.eho_loss_and_grad.restype = C.c_float
         _lib.eho_train_steps.restype = C.c_float
+        _lib.eho_loss_and_grad_fast.restype = C.c_float
+        _lib.eho_train_steps_fast.restype = C.c_float
     return _lib
 
 
@@ -93,24 +100,27 @@ def _pack(spec, X, forcings, targets):
     return Xf, fs, ts
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, nthreads=1):
+def loss_and_grad(spec, theta, X, forcings, targets, nthreads=1, fast=False):
+    """fast: the blocked form bench.py times (eh_oracle_fast.c: 16 samples per SIMD block); else the checker"""
     s = to_c(spec)
     Xf, fs, ts = _pack(spec, X, forcings, targets)
     theta = np.ascontiguousarray(theta, np.float32)
     grad = np.zeros(theta.size, np.float32)
     nv = (C.c_long * 4)()
-    loss = lib().eho_loss_and_grad(C.byref(s), C.c_void_p(theta.ctypes.data), C.c_void_p(Xf.ctypes.data), _ptrs(fs), _ptrs(ts),
+    fn = lib().eho_loss_and_grad_fast if fast else lib().eho_loss_and_grad
+    loss = fn(C.byref(s), C.c_void_p(theta.ctypes.data), C.c_void_p(Xf.ctypes.data), _ptrs(fs), _ptrs(ts),
                                    C.c_long(Xf.shape[1]), C.c_void_p(grad.ctypes.data), nv, C.c_int(nthreads))
     return float(loss), grad, [int(nv[t]) for t in range(len(spec.targets))]
 
 
-def train_steps(spec, theta, X, forcings, targets, batch, nsteps, lr=0.01, nthreads=1):
-    """Adam steps over contiguous batches; returns (theta, last loss).  Timed by bench.py."""
+def train_steps(spec, theta, X, forcings, targets, batch, nsteps, lr=0.01, nthreads=1, fast=False):
+    """Adam steps over contiguous batches; returns (theta, last loss).  Timed by bench.py (fast = True: the blocked form)."""
     s = to_c(spec)
     Xf, fs, ts = _pack(spec, X, forcings, targets)
     theta = np.ascontiguousarray(theta, np.float32).copy()
     m = np.zeros_like(theta); v = np.zeros_like(theta); bt = np.array([0.9, 0.999], np.float32)
-    loss = lib().eho_train_steps(C.byref(s), C.c_void_p(theta.ctypes.data), C.c_void_p(m.ctypes.data), C.c_void_p(v.ctypes.data),
+    fn = lib().eho_train_steps_fast if fast else lib().eho_train_steps
+    loss = fn(C.byref(s), C.c_void_p(theta.ctypes.data), C.c_void_p(m.ctypes.data), C.c_void_p(v.ctypes.data),
                                  C.c_void_p(bt.ctypes.data), C.c_void_p(Xf.ctypes.data), _ptrs(fs), _ptrs(ts), C.c_long(Xf.shape[1]),
                                  C.c_long(batch), C.c_long(nsteps), C.c_float(lr), C.c_int(nthreads))
     return theta, float(loss)

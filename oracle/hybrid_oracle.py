@@ -735,11 +735,17 @@ def vjp_from_output_seed(spec, theta, X, forcings, seeds: Dict[str, np.ndarray],
     return _backprop(spec, res["_tape"], {k: np.asarray(v, dt) for k, v in seeds.items()}, dt, X.shape[1])
 
 
-def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None, agg="sum", extra=None):
+def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse", bn_state=None, l2=None, agg="sum", extra=None, empty_target="zero"):
     """Training loss (`kind` in mse / rmse / mae / nseLoss / pearsonLoss / kgeLoss / pbkgeLoss, loss_fn.jl:58-174; agg=sum over targets)
     and its gradient wrt flat theta: the hand-derived VJP of SURVEY.md section 8(a).  Returns
-    (loss, grad, n_valid per target).  A target with no valid sample contributes 0 (the reference
-    skips all-masked batches, epoch.jl:17-19)."""
+    (loss, grad, n_valid per target).
+
+    A target with NO valid sample inside a batch that has some (another target's): the reference evaluates `mean(abs2, yhat[mask] .- y[mask])` on
+    the empty selection (loss_fn.jl:61-63) -- 0 / 0 = NaN for the VALUE, while the pullback of a mean over an empty selection scatters nothing
+    back: that target adds zero to the GRADIENT and the other targets' terms arrive intact (Zygote: `getindex` adjoint of an empty mask; the
+    step's loss value is discarded by run_epoch!, epoch.jl:20).  So the gradient below IS the reference's; for the value, empty_target = "zero"
+    (the engine's default: the target contributes 0, the sum of the others is reported) or "nan" (the reference's value; the engine's
+    `empty_target_nan` option at the objective seam, eh_loss_and_grad).  Only the batch whose masks are ALL empty is skipped (epoch.jl:17-19,35-37)."""
     dt = np.dtype(dtype)
     res = forward(spec, theta, X, forcings, dtype, keep=True, bn_state=bn_state, train_mode=True)
     tp = res["_tape"]
@@ -758,6 +764,8 @@ def loss_and_grad(spec, theta, X, forcings, targets, dtype=np.float64, kind="mse
         n = int(m.sum())
         nvalid.append(n)
         d = np.zeros(B, dt)
+        if n == 0 and empty_target == "nan":
+            loss = loss + dt.type(np.nan)
         if n > 0:
             r = np.where(m, res[t] - np.where(m, y, 0), 0).astype(dt)
             if kind == "mse":

@@ -251,3 +251,61 @@ def test_train_front_door_with_an_extra_loss_of_the_predictions():
     assert last["gpp_size"] == pytest.approx(5.0 * float(np.mean(pen.val_obs_pred["GPP_pred"] ** 2)), rel=1e-5)
     assert np.mean(pen.val_obs_pred["GPP_pred"] ** 2) < 0.8 * np.mean(plain.val_obs_pred["GPP_pred"] ** 2)       # the penalty on the size of GPP shrinks GPP
     assert set(pen.val_history[-1]["mse"]) == {"NEE", "GPP", "sum"}
+
+
+# ----------------------------------------------------------------------------------------------
+# a target with NO valid sample inside a batch that has some (missing 1): pinned
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hidden", [(16, 8), (100, 40), (160, 48, 24)])          # per-wave kernel, row-split kernel, layer-wise form
+def test_target_without_a_valid_sample_adds_nothing_to_the_gradient(hidden):
+    """The reference takes `mean(abs2, yhat[mask] .- y[mask])` over the empty selection (src/losses/loss_fn.jl:61-63): NaN for the VALUE of
+    compute_loss, nothing for its GRADIENT (the pullback of a mean over an empty selection scatters nothing back), and only the batch whose
+    masks are ALL empty is skipped (src/training/epoch.jl:17-19,35-37).  The engine: the same gradient -- that of the other target alone --,
+    the sum of the other targets as the value by default, the reference's NaN with the `empty_target_nan` option at the objective seam; a
+    training step is a step on the other target's gradient (the reference discards the step's loss value, epoch.jl:20)."""
+    B = 1200
+    spec, theta, X, f, y = _flux(B, hidden, 2)
+    y["GPP"] = np.full(B, np.nan, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert nv0[1] == 0 and nv == nv0[0]
+    assert loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL and np.isfinite(grad).all()
+    # ... which is the one-target problem on NEE
+    spec1 = ho.HybridSpec(spec.n_pred, list(hidden), "fluxpart", dict(spec.parameters), ["RUE", "Rb"], ["Q10"], ["NEE"], "tanh", True)
+    l1, g1, _ = ho.loss_and_grad(spec1, theta.astype(np.float64), X, f, {"NEE": y["NEE"]})
+    assert l0 == pytest.approx(l1, rel=1e-12) and np.allclose(g0, g1, rtol=1e-12, atol=0)
+    # the reference's value on request; the gradient does not change
+    ln, gn, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, empty_target="nan")
+    assert np.isnan(ln) and np.array_equal(gn, g0)
+    eng.set_option("empty_target_nan", 1)
+    l2, g2, _ = eng.loss_and_grad()
+    assert np.isnan(l2) and np.array_equal(g2, grad)
+    eng.set_option("empty_target_nan", 0)
+    # a training step moves along the other target's gradient (Descent: theta - lr g)
+    eng.opt_init("Descent", 0.1)
+    eng.train_step(0, B, want_loss=False)
+    step = (theta.astype(np.float64) - eng.get_params().astype(np.float64)) / 0.1
+    assert util.relerr(step, g0) <= 3e-5
+    eng.close()
+
+
+def test_target_without_a_valid_sample_under_the_data_parallel_seam():
+    """the same batch split over two members of the local group: the GLOBAL count of the empty target is zero, its weight is zero on every
+    member, and the group's step is the one-engine step"""
+    from tests.test_gpu_comm import _shard_engines
+    B = 2048
+    spec, theta, X, f, y = _flux(B, (16, 8), 2)
+    y["GPP"] = np.full(B, np.nan, np.float32)
+    engs = _shard_engines(spec, theta, X, f, y, 2, opt=("Descent", 0.1))
+    shift = [float(np.nanmean(y["NEE"])), 0.0]
+    for e in engs:
+        e.set_target_shift(shift)
+    HybridEngine.comm_init_local(engs)
+    loss = HybridEngine.dp_train_step_group(engs, [0, 0], B // 2, want_loss=True)
+    l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y)
+    assert loss == pytest.approx(l0, rel=1e-4)
+    step = (theta.astype(np.float64) - engs[0].get_params().astype(np.float64)) / 0.1
+    assert util.relerr(step, g0) <= 3e-5 and np.array_equal(engs[0].get_params(), engs[1].get_params())
+    for e in engs:
+        e.close()

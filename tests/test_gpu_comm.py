@@ -209,6 +209,42 @@ def test_multi_target_model_under_the_local_group_fused_and_layerwise_form(hidde
         e.close()
 
 
+@pytest.mark.parametrize("kind", ["kgeLoss", "pearsonLoss"])
+def test_two_pass_loss_with_input_batchnorm_under_the_local_group(kind):
+    """input BatchNorm AND a two-pass training loss under data parallelism (advisor, round 4): the global statistics of eh_dp_bn_stats serve
+    the two forward-only moment passes and the training pass behind them -- stage 0 used to consume them and every later pass of the step
+    returned EH_ESTATE.  Two members against ONE engine stepping on the union of their windows."""
+    world, B = 2, 2048
+    spec, theta, X, f, y = util.rbq10_case(B, "tanh", True, 0.05, hidden=(24, 12))
+    spec.input_batchnorm = True
+    X = (X * np.float32(2.0) + np.float32(0.5)).astype(np.float32)
+    y["reco"][: B // world][::3] = np.nan
+    engs = _shard_engines(spec, theta, X, f, y, world, opt=("Descent", 0.05))
+    tshift = [float(np.nanmean(y[t])) for t in spec.targets]
+    xshift = X.mean(axis=1).astype(np.float32)
+    for e in engs:
+        e.set_training_loss(kind)
+        e.set_target_shift(tshift)
+        e.set_bn_shift(xshift)
+    HybridEngine.comm_init_local(engs)
+    ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Descent", 0.05)
+    ref.set_training_loss(kind)
+    per = B // world
+    for s in range(3):
+        a = (s % 2) * (per // 2)
+        loss = HybridEngine.dp_train_step_group(engs, [a] * world, per // 2, want_loss=True)
+        idx = np.concatenate([np.arange(r * per + a, r * per + a + per // 2) for r in range(world)]).astype(np.int32)
+        lref = ref.train_step(0, idx.size, want_loss=True, idx=idx)
+        assert abs(loss - lref) <= 1e-4 * abs(lref), (s, loss, lref)
+    assert np.array_equal(engs[0].get_params(), engs[1].get_params())
+    assert np.max(np.abs(engs[0].get_params() - ref.get_params())) <= 2e-5
+    (m0, v0), (mr, vr) = engs[0].get_bn_state(), ref.get_bn_state()
+    assert np.allclose(m0, mr, rtol=2e-6, atol=2e-6) and np.allclose(v0, vr, rtol=2e-5)
+    for e in engs:
+        e.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_local_group_with_input_batchnorm_uses_the_statistics_of_the_global_minibatch(world):
     """input BatchNorm under the local group: the members' shifted sums are exchanged ahead of the pass (EH_BUF_BNSTAT), so every replica

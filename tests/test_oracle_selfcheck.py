@@ -172,6 +172,25 @@ def test_c_port_matches_numpy_oracle(act, scale):
     assert np.max(np.abs(g - g0)) <= 2e-6 * np.max(np.abs(g0))
 
 
+@pytest.mark.parametrize("act,scale,B", [("tanh", True, 500), ("sigmoid", False, 333), ("relu", True, 37)])
+def test_blocked_c_port_matches_the_checker_and_the_numpy_oracle(act, scale, B):
+    """oracle/eh_oracle_fast.c -- what bench.py times as `cpu_baseline`: sixteen samples per SIMD block, the rational tanh, vector exp /
+    log -- against the scalar checker and the fp64 oracle (ragged last block, missing targets, several threads)"""
+    spec, th, X, f, y = _case(act, scale, B=B, nan=0.15)
+    l, g, nv = co.loss_and_grad(spec, th.astype(np.float32), X, f, y, nthreads=3, fast=True)
+    lc, gc, nvc = co.loss_and_grad(spec, th.astype(np.float32), X, f, y, nthreads=2)
+    l0, g0, nv0 = ho.loss_and_grad(spec, th, X, f, y)
+    assert nv == nvc == nv0 and l == pytest.approx(l0, rel=1e-5) and l == pytest.approx(lc, rel=1e-5)
+    assert np.max(np.abs(g - g0)) <= 1e-5 * np.max(np.abs(g0)) and np.max(np.abs(g - gc)) <= 1e-5 * np.max(np.abs(gc))
+    th32 = th.astype(np.float32)
+    a, _ = co.train_steps(spec, th32, X, f, y, min(64, B // 2), 4)
+    b, _ = co.train_steps(spec, th32, X, f, y, min(64, B // 2), 4, fast=True)
+    assert np.max(np.abs(a - b)) <= 5e-5
+    yn = {k: np.full_like(v, np.nan) for k, v in y.items()}
+    ln, gn, nvn = co.loss_and_grad(spec, th32, X, f, yn, nthreads=2, fast=True)
+    assert np.isnan(ln) and not gn.any() and nvn == [0]
+
+
 def test_c_port_adam_trajectory():
     spec, th, X, f, y = _case("tanh", True, B=512, nan=0.1)
     th32 = th.astype(np.float32)
