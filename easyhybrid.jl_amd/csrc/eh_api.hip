@@ -1040,6 +1040,17 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         h->check_idx = value != 0;           // a small kernel + one synchronisation per step; host indices are always checked
         return EH_OK;
     }
+    if (!strcmp(name, "p2p_mode")) {         // who publishes a step's sums to the peers (EhP2P::mode, eh_device.hpp): 0 = the step's last workgroup to finish, elected by a
+                                             // two-level ticket; 1 = workgroup 0 of the next kernel on the stream, no election.  EVERY rank switches at the same step.
+        if (value != 0 && value != 1) return fail(h, EH_EINVAL, "p2p_mode must be 0 (election in the step's epilogue) or 1 (publish from the next kernel's prologue)");
+        if (!h->p2p_on) return fail(h, EH_ESTATE, "p2p_mode: no peer-to-peer exchange on this handle (eh_p2p_init / eh_p2p_init_local first)");
+        HIPCHK(h, hipSetDevice(h->device));
+        FLUSH(h);                                // (no step pending across the switch: whoever was to publish it has done so)
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->p2p_host.mode = (int)value;
+        HIPCHK(h, hipMemcpy(h->p2p_dev, &h->p2p_host, sizeof(EhP2P), hipMemcpyHostToDevice));
+        return EH_OK;
+    }
     if (!strcmp(name, "empty_target_nan")) { // a target with no valid sample inside a batch that has some: the gradient is the reference's either way (that target adds
         h->empty_nan = value != 0;           // nothing); the VALUE is the sum of the other targets (0, default) or the reference's NaN = mean over an empty selection
         return EH_OK;                        // (1; src/losses/loss_fn.jl:61-63), reported by eh_loss_and_grad -- the seam where the reference's objective is called directly

@@ -131,6 +131,8 @@ struct EhP2P {
     unsigned* counter;                   // [0] top-level ticket of the current launch (groups whose workgroups have all finished accumulating); [32 (1 + g)] group g's ticket
     int* err;                            // set when a wait ran into its deadline
     int world, rank;
+    int mode;                            // 0: the last workgroup of a step to finish folds and publishes (two-level ticket election); 1: no election --
+                                         // workgroup 0 of the NEXT kernel on the stream (the next step, or the flush) folds and publishes in its prologue
 };
 
 struct EhFused {
@@ -535,6 +537,20 @@ __device__ __forceinline__ void eh_ll_finish(const EhP2P* P, A addr, unsigned se
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = ((unsigned)(w[i] >> 32) == seq) ? __uint_as_float((unsigned)w[i]) : 0.0f;
 }
+// one workgroup: this rank's staging shards of `slot` folded and stored, every element with its arrival stamp, into shard `rank` of every
+// rank's receive buffer (its own included).  Whoever calls it knows that every add into the shards has landed: the last workgroup of the
+// step by ticket (eh_p2p_publish, mode 0), or workgroup 0 of the next kernel on the stream (mode 1: the kernel boundary says so).
+__device__ __forceinline__ void eh_p2p_fold_store(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
+    const float* st = P->stage + (long long)slot * EH_GSHARDS * n_acc;
+    for (int i = tid; i < n_acc; i += nthr) {
+        float v = 0.0f;
+#pragma unroll
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) v += __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w = eh_ll_pack(v, seq);
+        for (int r = 0; r < P->world; ++r)
+            __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 enum { EH_P2P_GROUPS = 16 };     // first-level ticket counters at counter[32 (1 + g)], g < 16 (one 128-byte line each)
 // called by every thread of every workgroup once its sums are in the staging shards
 __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
@@ -559,15 +575,7 @@ __device__ __forceinline__ void eh_p2p_publish(const EhP2P* P, int slot, unsigne
     }
     __syncthreads();
     if (!eh_p2p_last) return;
-    const float* st = P->stage + (long long)slot * EH_GSHARDS * n_acc;
-    for (int i = tid; i < n_acc; i += nthr) {
-        float v = 0.0f;
-#pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) v += __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long w = eh_ll_pack(v, seq);
-        for (int r = 0; r < P->world; ++r)
-            __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    eh_p2p_fold_store(P, slot, seq, n_acc, tid, nthr);
     if (tid == 0) __hip_atomic_store(P->counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -821,6 +829,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     };
     unsigned long long p2p_w[P2P_NW];
     if constexpr (P2PM) {
+        // mode 1: the previous step's kernel is through (stream order), so its adds have all landed -- no ticket, no election: this workgroup
+        // folds the staging shards and publishes them to every rank, then waits for the words like everybody else
+        if (fusedm && a.fz.pending && a.p2pv.mode == 1 && blockIdx.x == 0) eh_p2p_fold_store(&a.p2pv, (a.fz.gslot + 2) % 3, a.p2p_seq - 1u, a.n_acc, tid, NTHR);
         if (fusedm && a.fz.pending) eh_ll_issue(p2p_addr, a.p2p_seq - 1u, p2p_w);
     }
     if (!a.ms_keep) {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
@@ -1565,7 +1576,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             if (gsh) atomicAdd(&gsh[e], sum);
             else out[e] = sum;
         }
-        if constexpr (P2PM) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
+        if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
         EH_STAMP(10);
         return;
     }
@@ -1674,7 +1685,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 }
             }
         }
-        if constexpr (P2PM) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR);
+        if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
         EH_STAMP(10);
         return;
     }

@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
     if (own) { th0 = theta[idx]; mm0 = m[idx]; vv0 = v[idx]; if (idx < im.g_off && im.imap) mp0 = im.imap[idx]; }
     const float sc0 = sc_in[0], sc1 = sc_in[1];
     if (p2p) {       // every rank's sums of the last step, straight from the receive shards (see EhP2P)
+        if (p2p->mode == 1 && blockIdx.x == 0) eh_p2p_fold_store(p2p, slot, seq, n_acc, (int)threadIdx.x, 256);      // (nobody has published the last step yet)
         auto ad = [&](int i) -> const unsigned long long* {
             const int sh = i / 5, k = i % 5;
             if (sh >= p2p->world || (k == 4 && idx >= n_theta)) return nullptr;

@@ -97,6 +97,7 @@ class DataParallel:
         ptr, n = engine.device_buffer(L.EH_BUF_GRAD)
         self.buf = torch.as_tensor(_DevArray(ptr, n), device=dev)
         self.p2p = False
+        self.p2p_mode = 0
         if fused and int(engine.desc.n_targets) > 1:        # the per-target weights need the GLOBAL counts before the pass: eh_dp_counts + three-kernel path
             fused = self.fused = False
         if fused:
@@ -105,10 +106,16 @@ class DataParallel:
             except NotImplementedError:                     # hidden widths above 64: three-kernel path
                 fused = self.fused = False
         if fused:
+            # p2p = "prologue": the peer-to-peer exchange with the sums published by the NEXT kernel's first workgroup instead of the step's
+            # elected last one (engine option "p2p_mode" = 1; csrc/eh_device.hpp EhP2P::mode); True / "auto": the elected form; calibrate()
+            # times both next to the collective and keeps the fastest
+            self.p2p_mode = 1 if p2p == "prologue" else int(os.environ.get("EH_DP_P2P_MODE", "0"))
             if p2p == "auto":
                 p2p = os.environ.get("EH_DP_P2P", "1") != "0"
             if p2p:
                 self.p2p = self._negotiate_p2p()
+                if self.p2p and self.p2p_mode:
+                    engine.set_option("p2p_mode", self.p2p_mode)
             gptr, gn = engine.device_buffer(L.EH_BUF_GACC)      # (after the negotiation: it re-allocates the accumulators)
             self.gacc = [torch.as_tensor(_DevArray(gptr + 4 * k * (gn // 3), gn // 3), device=dev) for k in range(3)]
         # run the engine on torch's current stream so kernels and the collective are ordered
@@ -221,7 +228,7 @@ class DataParallel:
         import torch
         import torch.distributed as dist
         if not self.p2p:
-            return {"p2p_us": None, "collective_us": None, "chosen": "collective"}
+            return {"p2p_us": None, "p2p_prologue_us": None, "collective_us": None, "chosen": "collective"}
 
         def timed():
             # every rank runs the same sequence of collectives whatever happens locally (an exception on one rank
@@ -245,7 +252,14 @@ class DataParallel:
                              device=self._dev if dist.get_backend(self.group) == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             return 1e6 * float(t.item()) / nsteps, ok
-        t_p2p, ok = timed()
+        # three exchanges on this node, same steps each: the peer-to-peer form with the election in the step's epilogue, the one published
+        # from the next kernel's prologue, the collective.  (Every rank switches modes at the same point: between two drained steps.)
+        t_modes, ok = {}, True
+        for mode in (0, 1):
+            dist.barrier(group=self.group)
+            self.engine.set_option("p2p_mode", mode)
+            t_modes[mode], ok1 = timed()
+            ok = ok and ok1
         ok = self._all_agree(ok)
         dist.barrier(group=self.group)
         self.engine.p2p_disable()
@@ -253,12 +267,17 @@ class DataParallel:
         self._refresh_gacc()
         if not ok:
             self.broadcast_state(0)
-            return {"p2p_us": None, "collective_us": None, "chosen": "collective (peer-to-peer exchange failed)"}
+            return {"p2p_us": None, "p2p_prologue_us": None, "collective_us": None, "chosen": "collective (peer-to-peer exchange failed)"}
         t_col, _ = timed()
-        if t_p2p < t_col:
+        best_mode = 0 if t_modes[0] <= t_modes[1] else 1
+        if t_modes[best_mode] < t_col:
             self.p2p = self._negotiate_p2p()
             self._refresh_gacc()
-        return {"p2p_us": t_p2p, "collective_us": t_col, "chosen": "p2p" if self.p2p else "collective"}
+            if self.p2p:
+                self.p2p_mode = best_mode
+                self.engine.set_option("p2p_mode", best_mode)
+        return {"p2p_us": t_modes[0], "p2p_prologue_us": t_modes[1], "collective_us": t_col,
+                "chosen": ("p2p, published from the next prologue" if best_mode else "p2p, elected publisher") if self.p2p else "collective"}
 
     def check(self) -> bool:
         """Collective: drain the engine and make sure no peer-to-peer wait ran into its deadline anywhere.

@@ -11,12 +11,13 @@ from tests import util
 B, N = 65536, 3000
 spec, theta, X, f, y = util.rbq10_case(8 * B, "tanh", True, 0.0)
 out = {}
-for mode in ("plain fused", "p2p loopback", "rccl world=1 fused", "two-kernel", "rccl world=1 two-kernel"):
+for mode in ("plain fused", "p2p loopback", "p2p loopback, published from the next prologue", "rccl world=1 fused", "two-kernel", "rccl world=1 two-kernel"):
     eng = util.load_engine(spec, theta, X, f, y); eng.opt_init("Adam", 0.01)
     fused = "two-kernel" not in mode
     eng.set_option("fused_update", int(fused)); eng.set_option("specialize", 1)
-    if mode == "p2p loopback":
+    if mode.startswith("p2p loopback"):
         hd = eng.p2p_init(1, 0); eng.p2p_attach([hd]); assert eng.p2p_selftest(4)
+        if "prologue" in mode: eng.set_option("p2p_mode", 1)
     if mode.startswith("rccl"):
         eng.comm_init(HybridEngine.comm_unique_id(), 1, 0)
     if mode.startswith("rccl"):
@@ -33,5 +34,6 @@ for mode in ("plain fused", "p2p loopback", "rccl world=1 fused", "two-kernel", 
     out[mode] = 1e6 * (time.perf_counter() - t0) / N
     print(f"{mode}: {out[mode]:.2f} us/step", flush=True)
     eng.close()
-print(f"peer-to-peer machinery (loop-back): +{out['p2p loopback'] - out['plain fused']:.2f} us;  RCCL all-reduce at world 1: "
+print(f"peer-to-peer machinery (loop-back): +{out['p2p loopback'] - out['plain fused']:.2f} us with the election in the step's epilogue, "
+      f"+{out['p2p loopback, published from the next prologue'] - out['plain fused']:.2f} us published from the next kernel's prologue;  RCCL all-reduce at world 1: "
       f"+{out['rccl world=1 fused'] - out['plain fused']:.2f} us (fused), +{out['rccl world=1 two-kernel'] - out['two-kernel']:.2f} us (two-kernel)")

@@ -64,6 +64,10 @@ def identical(engs, state=False):
 ok = True
 engs = shard_engines()
 p2p = HybridEngine.p2p_init_local(engs)
+P2P_MODE = int(os.environ.get("EH_TOOL_P2P_MODE", "0"))      # 1: a step's sums are published by workgroup 0 of the NEXT kernel on the stream (no election)
+if p2p and P2P_MODE:
+    for e in engs:
+        e.set_option("p2p_mode", P2P_MODE)
 ref = util.load_engine(spec, theta, X, f, y); ref.opt_init("Adam", 0.01)
 for s in range(nsteps):
     a = (s % 4) * win
@@ -72,7 +76,7 @@ for s in range(nsteps):
 healthy = HybridEngine.p2p_check_local(engs)
 same, finite = identical(engs)
 err = float(np.max(np.abs(engs[0].get_params() - ref.get_params())))
-print(f"local group of {world}: p2p={p2p} steps={nsteps} healthy={healthy} max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
+print(f"local group of {world}: p2p={p2p} mode={P2P_MODE} steps={nsteps} healthy={healthy} max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
 ok = ok and p2p and healthy and same and finite and err <= 2e-5
 
 # a missed exchange: member 0 steps alone, so the sums it waits for never come (2 s deadline); the check must notice, drop every

@@ -58,7 +58,7 @@ err = float(np.max(np.abs(th - ref.get_params())))
 t = torch.from_numpy(th.copy()); tl = [torch.empty_like(t) for _ in range(world)]
 dist.all_gather(tl, t)
 same = all(bool(torch.equal(tl[0], q)) for q in tl)
-print(f"rank {rank}: p2p={drv.p2p} jit_kernels={eng.jit_status()[0]} steps={nsteps} {1e6 * dt / nsteps:.1f} us/step max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
+print(f"rank {rank}: p2p={drv.p2p} p2p_mode={drv.p2p_mode} jit_kernels={eng.jit_status()[0]} steps={nsteps} {1e6 * dt / nsteps:.1f} us/step max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
 ok = err <= 3e-5 and same
 if os.environ.get("EH_TOOL_FORCE_TIMEOUT") == "1":
     # recovery: rank 0 runs one step more than rank 1, so its exchange never completes and runs into the 2 s deadline; check() must
