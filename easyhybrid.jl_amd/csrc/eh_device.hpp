@@ -540,7 +540,10 @@ __device__ __forceinline__ void eh_ll_finish(const EhP2P* P, A addr, unsigned se
 // one workgroup: this rank's staging shards of `slot` folded and stored, every element with its arrival stamp, into shard `rank` of every
 // rank's receive buffer (its own included).  Whoever calls it knows that every add into the shards has landed: the last workgroup of the
 // step by ticket (eh_p2p_publish, mode 0), or workgroup 0 of the next kernel on the stream (mode 1: the kernel boundary says so).
-__device__ __forceinline__ void eh_p2p_fold_store(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr) {
+// (mode 1 stores to the PEERS only: every workgroup of this rank takes the rank's own sums straight from the staging shards, as the
+//  single-GPU step takes them from its accumulators -- nothing of the rank's own waits for a publication)
+__device__ __forceinline__ void eh_p2p_fold_store(const EhP2P* P, int slot, unsigned seq, int n_acc, int tid, int nthr, bool peers_only = false) {
+    if (peers_only && P->world == 1) return;
     const float* st = P->stage + (long long)slot * EH_GSHARDS * n_acc;
     for (int i = tid; i < n_acc; i += nthr) {
         float v = 0.0f;
@@ -548,7 +551,8 @@ __device__ __forceinline__ void eh_p2p_fold_store(const EhP2P* P, int slot, unsi
         for (int sh = 0; sh < EH_GSHARDS; ++sh) v += __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long w = eh_ll_pack(v, seq);
         for (int r = 0; r < P->world; ++r)
-            __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!peers_only || r != P->rank)
+                __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 enum { EH_P2P_GROUPS = 16 };     // first-level ticket counters at counter[32 (1 + g)], g < 16 (one 128-byte line each)
@@ -786,9 +790,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     if constexpr (TRAIN) f_rcode = (a.rmap && tid < a.n_acc) ? a.rmap[tid] : 0;
     if (fusedm) {
         const EhFused& z = a.fz;
-        const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
+        // (EhP2P mode 1: this rank's own sums of the previous step come from its staging shards, like the single-GPU step's from its accumulators)
+        const bool own_direct = !P2PM || a.p2pv.mode == 1;
+        const float* const g_prev = (P2PM ? a.p2pv.stage : z.gacc) + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * net.n_theta;
-        if (!P2PM && z.pending) {
+        if (own_direct && z.pending) {
 #pragma unroll
             for (int sh = 0; sh < EH_GSHARDS; ++sh) {
                 const float* gp = g_prev + sh * a.n_acc + net.n_theta;
@@ -806,7 +812,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         if (tid < net.n_theta) {
             f_th = pin[tid]; f_m = pin[net.n_theta + tid]; f_v = pin[2 * net.n_theta + tid];
             f_map = tid < net.g_off ? z.imap[tid] : 0;
-            if (!P2PM && z.pending) {
+            if (own_direct && z.pending) {
 #pragma unroll
                 for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += g_prev[sh * a.n_acc + tid];
             }
@@ -824,6 +830,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         const int j = tid + u * NTHR;
         if (j >= a.p2pv.world * p2p_ne) return nullptr;
         const int sh = j / p2p_ne, e = j - sh * p2p_ne;
+        if (a.p2pv.mode == 1 && sh == a.p2pv.rank) return nullptr;          // (own sums: taken from the staging shards above; reads as 0 here)
         const int idx = e < p2p_ne - 4 ? e : net.n_theta + (e - (p2p_ne - 4));
         return a.p2pv.peer_recv[a.p2pv.rank] + ((long long)((a.fz.gslot + 2) % 3) * EH_GSHARDS + sh) * a.n_acc + idx;
     };
@@ -831,7 +838,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     if constexpr (P2PM) {
         // mode 1: the previous step's kernel is through (stream order), so its adds have all landed -- no ticket, no election: this workgroup
         // folds the staging shards and publishes them to every rank, then waits for the words like everybody else
-        if (fusedm && a.fz.pending && a.p2pv.mode == 1 && blockIdx.x == 0) eh_p2p_fold_store(&a.p2pv, (a.fz.gslot + 2) % 3, a.p2p_seq - 1u, a.n_acc, tid, NTHR);
+        if (fusedm && a.fz.pending && a.p2pv.mode == 1 && blockIdx.x == 0) eh_p2p_fold_store(&a.p2pv, (a.fz.gslot + 2) % 3, a.p2p_seq - 1u, a.n_acc, tid, NTHR, true);
         if (fusedm && a.fz.pending) eh_ll_issue(p2p_addr, a.p2p_seq - 1u, p2p_w);
     }
     if (!a.ms_keep) {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
@@ -857,9 +864,20 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             float got[P2P_NW];
             eh_ll_finish(&a.p2pv, p2p_addr, a.p2p_seq - 1u, p2p_w, got);
             float* const T = smem + G::IMG_FLOATS;               // [world][p2p_ne]
+            const bool own_direct_p2p = a.p2pv.mode == 1;
 #pragma unroll
-            for (int u = 0; u < P2P_NW; ++u)
-                if (tid + u * NTHR < a.p2pv.world * p2p_ne) T[tid + u * NTHR] = got[u];
+            for (int u = 0; u < P2P_NW; ++u) {
+                const int j = tid + u * NTHR;
+                if (j < a.p2pv.world * p2p_ne && !(own_direct_p2p && j / p2p_ne == a.p2pv.rank)) T[j] = got[u];
+            }
+            if (own_direct_p2p) {
+                // this rank's own sums (from its staging shards, folded in shard order exactly as the publishing workgroup folds them for the
+                // peers) take their place in the table: the sum below runs in RANK order on every rank, so the replicas stay bitwise identical
+                float* const To = T + a.p2pv.rank * p2p_ne;
+                if (tid < p2p_ne - 4) To[tid] = f_g;
+                if (tid == 0) { To[p2p_ne - 4] = f_sse; To[p2p_ne - 3] = f_cnt; To[p2p_ne - 2] = f_sy; To[p2p_ne - 1] = f_syy; }
+                f_g = 0.0f; f_sse = 0.0f; f_cnt = 0.0f; f_sy = 0.0f; f_syy = 0.0f;
+            }
             __syncthreads();
             for (int sh = 0; sh < a.p2pv.world; ++sh) {
                 const float* Ts = T + sh * p2p_ne;
@@ -950,14 +968,21 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 if (upd) {
                     if constexpr (P2PM) {
                         auto ad = [&](int sh) -> const unsigned long long* {
+                            if (a.p2pv.mode == 1 && sh == a.p2pv.rank) return nullptr;
                             return sh < a.p2pv.world ? a.p2pv.peer_recv[a.p2pv.rank] + ((long long)((z.gslot + 2) % 3) * EH_GSHARDS + sh) * a.n_acc + idx : nullptr;
                         };
+                        float own = 0.0f;
+                        if (a.p2pv.mode == 1) {
+                            const float* const gst = a.p2pv.stage + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
+#pragma unroll
+                            for (int sh = 0; sh < EH_GSHARDS; ++sh) own += gst[sh * a.n_acc + idx];
+                        }
                         unsigned long long w8[EH_GSHARDS];
                         float got[EH_GSHARDS];
                         eh_ll_issue(ad, a.p2p_seq - 1u, w8);
                         eh_ll_finish(&a.p2pv, ad, a.p2p_seq - 1u, w8, got);
 #pragma unroll
-                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += got[sh];
+                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += (a.p2pv.mode == 1 && sh == a.p2pv.rank) ? own : got[sh];      // (rank order on every rank)
                     } else {
 #pragma unroll
                         for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * a.n_acc + idx];

@@ -518,10 +518,22 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
     if (own) { th0 = theta[idx]; mm0 = m[idx]; vv0 = v[idx]; if (idx < im.g_off && im.imap) mp0 = im.imap[idx]; }
     const float sc0 = sc_in[0], sc1 = sc_in[1];
     if (p2p) {       // every rank's sums of the last step, straight from the receive shards (see EhP2P)
-        if (p2p->mode == 1 && blockIdx.x == 0) eh_p2p_fold_store(p2p, slot, seq, n_acc, (int)threadIdx.x, 256);      // (nobody has published the last step yet)
+        // mode 1: nobody has published the last step yet -- block 0 does it for the peers; this rank's own sums come from its staging shards
+        const bool own_direct = p2p->mode == 1;
+        if (own_direct && blockIdx.x == 0) eh_p2p_fold_store(p2p, slot, seq, n_acc, (int)threadIdx.x, 256, true);
+        float ownv[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (own_direct) {
+            const float* const st = p2p->stage + (long long)slot * EH_GSHARDS * n_acc;
+#pragma unroll
+            for (int sh = 0; sh < EH_GSHARDS; ++sh) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ownv[k] += st[sh * n_acc + n_theta + k];
+                if (own) ownv[4] += st[sh * n_acc + idx];
+            }
+        }
         auto ad = [&](int i) -> const unsigned long long* {
             const int sh = i / 5, k = i % 5;
-            if (sh >= p2p->world || (k == 4 && idx >= n_theta)) return nullptr;
+            if (sh >= p2p->world || (k == 4 && idx >= n_theta) || (own_direct && sh == p2p->rank)) return nullptr;
             const unsigned long long* base = p2p->peer_recv[p2p->rank] + ((long long)slot * EH_GSHARDS + sh) * n_acc;
             return k < 4 ? base + n_theta + k : base + idx;
         };
@@ -530,7 +542,11 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
         eh_ll_issue(ad, seq, w);
         eh_ll_finish(p2p, ad, seq, w, got);
 #pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) { sse += got[5 * sh]; cnt += got[5 * sh + 1]; sy += got[5 * sh + 2]; syy += got[5 * sh + 3]; gs_p2p += got[5 * sh + 4]; }
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) {          // (rank order on every rank: bitwise-identical replicas)
+            const bool me = own_direct && sh == p2p->rank;
+            sse += me ? ownv[0] : got[5 * sh]; cnt += me ? ownv[1] : got[5 * sh + 1]; sy += me ? ownv[2] : got[5 * sh + 2];
+            syy += me ? ownv[3] : got[5 * sh + 3]; gs_p2p += me ? ownv[4] : got[5 * sh + 4];
+        }
     } else {
 #pragma unroll
         for (int sh = 0; sh < EH_GSHARDS; ++sh) {
