@@ -1823,10 +1823,12 @@ static int do_fused_multi(eh_handle* h, const EhSplit& sp, const int* idx, long 
     if (int rc = bn_prepare(h, sp, idx, first, a.count, true, &a)) return rc;       // (input BatchNorm: statistics inside the kernel, multi_ok made sure)
     a.ms_nsteps = nsteps; a.ms_batch = (int)batch; a.ms_end = end; a.ms_loss = loss_slots;
     HIPCHK(h, step_launch(h, EH_MODE_TRAIN_MULTI, 1, &a));
-    if (nsteps & 1) { h->cur ^= 1; h->sc_sel ^= 1; }
-    h->gstep += nsteps;
-    h->pending = true;
-    h->pending_loss = loss_slots + (nsteps - 1);
+    // every step of the launch has applied its own update and written its own loss (eh_ms_apply): nothing is pending behind it; the first
+    // step's prologue flipped the parameter set and rotated the accumulator slots once
+    h->cur ^= 1; h->sc_sel ^= 1;
+    h->gstep += 1;
+    h->pending = false;
+    h->pending_loss = nullptr;
     return EH_OK;
 }
 

@@ -184,6 +184,7 @@ struct EhStepArgs {
     // [first + k * ms_batch, ...) of at most ms_batch samples that ends at ms_end at the latest; the loss of step k goes to ms_loss[k]
     int ms_nsteps, ms_batch;
     int ms_keep;            // set by the multi-step kernel for its steps after the first: the parameter image is already in LDS
+    int ms_direct;          // set by the multi-step kernel: ONE workgroup, so the step that produced the gradient applies the optimiser itself (see eh_ms_apply)
     long long ms_end;
     float* ms_loss;
 };
@@ -675,6 +676,47 @@ struct EhGeom {
 //                    mechanistic stage needs no LDS round trip
 //   FAST bit 1 (PS): P <= 4 predictors -> the first layer's weight gradient runs on the vector ALU
 // ------------------------------------------------------------------------------------------
+// Multi-step launch (EH_MODE_TRAIN_MULTI: ONE workgroup): the step that produced the gradient applies the optimiser itself.  `gsum` holds
+// the step's sums (LDS, one writer per element, written just before the call); thread i owns parameter i: theta / m / v of the CURRENT set
+// (the one step 0's prologue wrote, z.cur ^ 1) are updated in place in LDS, the new value goes straight into the LDS parameter image, the
+// loss into the step's own slot, the sums back to zero.  Op for op the arithmetic of the deferred form (the next step's prologue: 8 shards
+// of which 7 are zero, three rotating accumulator sets, LDS atomics, a second parameter set), without what exists to hand sums between
+// workgroups.
+template <class G, class NET>
+__device__ __forceinline__ void eh_ms_apply(const NET& net, const EhStepArgs& a, float* gsum, float* wl, int tid, int nthr) {
+    const EhFused& z = a.fz;
+    const int nth = net.n_theta;
+    __syncthreads();                                   // every sum of the step is in gsum
+    float* const P = z.pset + (z.cur ^ 1) * 3 * nth;
+    float* const sc = z.pset + 6 * nth + 2 * (z.sc_sel ^ 1);
+    const float* const meta = wl + G::PHI_OFF;
+    const float* const tail = gsum + nth;              // [S | n | Sy | Syy] (one target: the multi-step launch takes no other)
+    const float S = tail[0], cnt = tail[1], Sy = tail[2], Syy = tail[3], bt1 = sc[0], bt2 = sc[1];
+    const bool upd = cnt > 0.0f;
+    float inv = 0.0f, lossv = __builtin_nanf("");
+    if (upd) eh_loss_finish(net.loss, S, cnt, Sy, Syy, inv, lossv, z.agg_a);
+    for (int idx = tid; idx < nth; idx += nthr) {
+        float th = P[idx], mm = P[nth + idx], vv = P[2 * nth + idx];
+        if (upd) {
+            eh_opt_update(z.opt, gsum[idx] * inv, bt1, bt2, th, mm, vv);
+            P[idx] = th; P[nth + idx] = mm; P[2 * nth + idx] = vv;
+            if (idx < net.g_off) wl[z.imap[idx]] = th;
+            else {
+                const int j = __float_as_int(meta[EH_IMG_GPAR + idx - net.g_off]);
+                const float sg = 1.0f / (1.0f + expf(-th)), scl = meta[EH_IMG_SC + j];
+                wl[G::PHI_OFF + EH_IMG_PHI + j] = meta[EH_IMG_LO + j] + scl * sg;
+                wl[G::PHI_OFF + EH_IMG_DPHI + j] = scl * sg * (1.0f - sg);
+            }
+        }
+    }
+    __syncthreads();                                   // everybody has read the sums and the beta products
+    for (int e = tid; e < a.n_acc; e += nthr) gsum[e] = 0.0f;
+    if (tid == 0) {
+        if (upd) { sc[0] = bt1 * z.opt.b1; sc[1] = bt2 * z.opt.b2; }
+        if (a.ms_loss) *a.ms_loss = lossv;
+    }
+}
+
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepArgs& a) {
     // Run-time compiled kernels (eh_jit.hip) know the model: the descriptor is a compile-time constant there and the generality
@@ -788,7 +830,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // full memory round trip, between the last barrier and the LDS reads)
     int f_rcode = 0;
     if constexpr (TRAIN) f_rcode = (a.rmap && tid < a.n_acc) ? a.rmap[tid] : 0;
-    if (fusedm) {
+    // (ms_direct && ms_keep: a later step of a multi-step launch -- the step before it has applied its own update and written the new
+    //  parameters into the LDS image: nothing deferred to pick up here)
+    const bool deferred_upd = fusedm && !(a.ms_direct && a.ms_keep);
+    if (deferred_upd) {
         const EhFused& z = a.fz;
         // (EhP2P mode 1: this rank's own sums of the previous step come from its staging shards, like the single-GPU step's from its accumulators)
         const bool own_direct = !P2PM || a.p2pv.mode == 1;
@@ -943,7 +988,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         }
         __syncthreads();
     }
-    if (fusedm) {
+    if (deferred_upd) {
         // fused update: apply the previous step's optimiser update straight into the LDS image
         const EhFused& z = a.fz;
         const int nth = net.n_theta;
@@ -1598,10 +1643,11 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
                 for (int w = 0; w < NW; ++w) sum += R0[w * AL.rw + pos];
             }
-            if (gsh) atomicAdd(&gsh[e], sum);
+            if (gsh) { if (a.ms_direct) gsh[e] = sum; else atomicAdd(&gsh[e], sum); }      // (ms_direct: one workgroup, one writer per element)
             else out[e] = sum;
         }
         if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
+        if constexpr (!P2PM) { if (a.ms_direct) eh_ms_apply<G>(net, a, gsh, wl, tid, NTHR); }
         EH_STAMP(10);
         return;
     }
@@ -1701,16 +1747,17 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     if (dst[u] >= 0) {
-                        if (gsh) atomicAdd(&gsh[dst[u]], sumv[u]);
+                        if (gsh) { if (a.ms_direct) gsh[dst[u]] = sumv[u]; else atomicAdd(&gsh[dst[u]], sumv[u]); }
                         else out[dst[u]] = sumv[u];
                     }
                 if (dtail >= 0) {
-                    if (gsh) atomicAdd(&gsh[dtail], sumt);
+                    if (gsh) { if (a.ms_direct) gsh[dtail] = sumt; else atomicAdd(&gsh[dtail], sumt); }
                     else out[dtail] = sumt;
                 }
             }
         }
         if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
+        if constexpr (!P2PM) { if (a.ms_direct) eh_ms_apply<G>(net, a, gsh, wl, tid, NTHR); }
         EH_STAMP(10);
         return;
     }
@@ -1784,17 +1831,29 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             const long long left = a.ms_end - b.first;
             b.count = left < (long long)a.ms_batch ? left : (long long)a.ms_batch;
             b.fz.pset = l_pset; b.fz.gacc = l_gacc; b.fz.imap = l_imap;
-            b.fz.gslot = (a.fz.gslot + k) % 3;
-            b.fz.cur = a.fz.cur ^ (k & 1);
-            b.fz.sc_sel = a.fz.sc_sel ^ (k & 1);
-            b.fz.pending = k ? 1 : a.fz.pending;
-            b.fz.loss_slot = k ? a.ms_loss + (k - 1) : a.fz.loss_slot;       // (a step's prologue finishes the loss of the step before it)
+            // every step applies its own update in its epilogue (eh_ms_apply): only step 0's prologue has something deferred to pick up (what was
+            // pending before the launch) and flips the parameter set; the accumulator slot is used as a plain array and left zero
+            b.fz.gslot = a.fz.gslot;
+            b.fz.cur = a.fz.cur;
+            b.fz.sc_sel = a.fz.sc_sel;
+            b.fz.pending = k ? 0 : a.fz.pending;
+            b.fz.loss_slot = a.fz.loss_slot;                                 // (step 0's prologue finishes the loss of the step pending before the launch)
+            b.ms_loss = a.ms_loss ? a.ms_loss + k : nullptr;
             b.ms_keep = k > 0;
+            b.ms_direct = 1;
             eh_step_body<NBI, NBH, NL, NT, NW, ACT, EH_MODE_TRAIN, FAST>(net, b);
             __syncthreads();
         }
         for (int i = threadIdx.x; i < np; i += NTHR) a.fz.pset[i] = l_pset[i];
         for (int i = threadIdx.x; i < ng; i += NTHR) a.fz.gacc[i] = l_gacc[i];
+        // nothing is pending behind the launch, so no flush kernel will refresh the GLOBAL parameter image (what the forward / evaluation
+        // kernels stage): the LDS image goes back as it stands -- except its normalisation block, which holds the last minibatch's statistics
+        // here and the running ones there (written by the steps themselves)
+        if (a.image_out)
+            for (int i = threadIdx.x; i < G::IMG_FLOATS; i += NTHR) {
+                const int q = i - (G::PHI_OFF + EH_IMG_BNM);
+                if (q < 0 || q >= 64) a.image_out[i] = eh_ms_smem[i];
+            }
     } else {
         eh_step_body<NBI, NBH, NL, NT, NW, ACT, MODE, FAST>(net, a);
     }
