@@ -682,25 +682,40 @@ struct EhGeom {
 // loss into the step's own slot, the sums back to zero.  Op for op the arithmetic of the deferred form (the next step's prologue: 8 shards
 // of which 7 are zero, three rotating accumulator sets, LDS atomics, a second parameter set), without what exists to hand sums between
 // workgroups.
+typedef __attribute__((address_space(3))) float eh_lds_f;
+typedef __attribute__((address_space(3))) int eh_lds_i;
 template <class G, class NET>
-__device__ __forceinline__ void eh_ms_apply(const NET& net, const EhStepArgs& a, float* gsum, float* wl, int tid, int nthr) {
+__device__ __forceinline__ void eh_ms_apply(const NET& net, const EhStepArgs& a, float* gsum_, float* wl_, int tid, int nthr) {
     const EhFused& z = a.fz;
     const int nth = net.n_theta;
+    // every pointer here is LDS (the multi-step kernel redirected the step's state there): as generic pointers each access would be a FLAT
+    // load / store -- hundreds of cycles apiece, five of them in a dependent chain (measured: 3 k cycles of a 11 k-cycle step)
+    eh_lds_f* const gsum = (eh_lds_f*)gsum_;
+    eh_lds_f* const wl = (eh_lds_f*)wl_;
+    eh_lds_f* const P = (eh_lds_f*)(z.pset + (z.cur ^ 1) * 3 * nth);
+    eh_lds_f* const sc = (eh_lds_f*)(z.pset + 6 * nth + 2 * (z.sc_sel ^ 1));
+    const eh_lds_i* const imap = (const eh_lds_i*)z.imap;
+    const eh_lds_f* const meta = wl + G::PHI_OFF;
+    // (requested before the barrier: none of it is written by the step's epilogue)
+    const int idx0 = tid < nth ? tid : 0;
+    float th0 = P[idx0], mm0 = P[nth + idx0], vv0 = P[2 * nth + idx0];
+    const int mp0 = idx0 < net.g_off ? imap[idx0] : 0;
+    const float bt1 = sc[0], bt2 = sc[1];
     __syncthreads();                                   // every sum of the step is in gsum
-    float* const P = z.pset + (z.cur ^ 1) * 3 * nth;
-    float* const sc = z.pset + 6 * nth + 2 * (z.sc_sel ^ 1);
-    const float* const meta = wl + G::PHI_OFF;
-    const float* const tail = gsum + nth;              // [S | n | Sy | Syy] (one target: the multi-step launch takes no other)
-    const float S = tail[0], cnt = tail[1], Sy = tail[2], Syy = tail[3], bt1 = sc[0], bt2 = sc[1];
+    EH_STAMP_FINE(11);
+    const eh_lds_f* const tail = gsum + nth;           // [S | n | Sy | Syy] (one target: the multi-step launch takes no other)
+    const float S = tail[0], cnt = tail[1], Sy = tail[2], Syy = tail[3];
     const bool upd = cnt > 0.0f;
     float inv = 0.0f, lossv = __builtin_nanf("");
     if (upd) eh_loss_finish(net.loss, S, cnt, Sy, Syy, inv, lossv, z.agg_a);
     for (int idx = tid; idx < nth; idx += nthr) {
-        float th = P[idx], mm = P[nth + idx], vv = P[2 * nth + idx];
+        float th, mm, vv; int mp;
+        if (idx == tid) { th = th0; mm = mm0; vv = vv0; mp = mp0; }
+        else { th = P[idx]; mm = P[nth + idx]; vv = P[2 * nth + idx]; mp = idx < net.g_off ? imap[idx] : 0; }
         if (upd) {
             eh_opt_update(z.opt, gsum[idx] * inv, bt1, bt2, th, mm, vv);
             P[idx] = th; P[nth + idx] = mm; P[2 * nth + idx] = vv;
-            if (idx < net.g_off) wl[z.imap[idx]] = th;
+            if (idx < net.g_off) wl[mp] = th;
             else {
                 const int j = __float_as_int(meta[EH_IMG_GPAR + idx - net.g_off]);
                 const float sg = 1.0f / (1.0f + expf(-th)), scl = meta[EH_IMG_SC + j];
@@ -709,8 +724,8 @@ __device__ __forceinline__ void eh_ms_apply(const NET& net, const EhStepArgs& a,
             }
         }
     }
-    __syncthreads();                                   // everybody has read the sums and the beta products
-    for (int e = tid; e < a.n_acc; e += nthr) gsum[e] = 0.0f;
+    // (no second barrier: the beta products were read before the barrier above, and the sums are overwritten -- plain stores, one writer per
+    //  element -- only behind the next step's barriers; the multi-step kernel zeroes the array once, when the launch ends)
     if (tid == 0) {
         if (upd) { sc[0] = bt1 * z.opt.b1; sc[1] = bt2 * z.opt.b2; }
         if (a.ms_loss) *a.ms_loss = lossv;
@@ -1589,12 +1604,17 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         EH_STAMP(13);
         __syncthreads();                           // the wave workspaces are dead from here on
         EH_STAMP(14);
+        // waves that had no tile (a minibatch smaller than the workgroup's NW tiles: the reference's batch of 64 fills two of eight) hold zeros
+        // everywhere: they park nothing and the gather leaves them out -- the same sums bit for bit (x + 0), a quarter of the LDS traffic
+        const int nlive_ = ntiles - (int)blockIdx.x * NW, nlive = nlive_ < 0 ? 0 : (nlive_ < NW ? nlive_ : NW);
+        const bool parks = wave < nlive;
         float* const R = smem + G::IMG_FLOATS + wave * AL.rw;
         // region[k][g][r][c]: the 16 samples (c) of a row are contiguous, so row sums are four 16-byte reads
         auto put = [&](int k, const f32x4& v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) R[k * 256 + g * 64 + r * 16 + c] = v[r];
         };
+        if (parks) {
 #pragma unroll
         for (int m = 0; m < NBH; ++m) {
             if constexpr (PS) {
@@ -1619,6 +1639,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             for (int k = 0; k < 16; ++k) tv = (lane == k) ? tailv[k] : tv;
             R[AL.na * 256 + lane] = tv;
         }
+        }       // (parks)
         EH_STAMP(12);
         __syncthreads();
         EH_STAMP(9);
@@ -1629,24 +1650,36 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             const int code = e == tid ? f_rcode : a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
             float sum = 0.0f;
             if (nlan == 16) {
-                f32x4 v[NW][4];
+                // (a run-time loop over the live waves -- predicated loads in an unrolled one became a branch around every load)
+                if (nlive == NW) {
+                    f32x4 v[NW][4];
 #pragma unroll
-                for (int w = 0; w < NW; ++w)
+                    for (int w = 0; w < NW; ++w)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[w][i] = *(const f32x4*)&R0[w * AL.rw + pos + 4 * i];
+                        for (int i = 0; i < 4; ++i) v[w][i] = *(const f32x4*)&R0[w * AL.rw + pos + 4 * i];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const f32x4 q = (v[w][0] + v[w][1]) + (v[w][2] + v[w][3]);
-                    sum += (q[0] + q[1]) + (q[2] + q[3]);
+                    for (int w = 0; w < NW; ++w) {
+                        const f32x4 q = (v[w][0] + v[w][1]) + (v[w][2] + v[w][3]);
+                        sum += (q[0] + q[1]) + (q[2] + q[3]);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int w = 0; w < nlive; ++w) {
+                        const float* const Rw = R0 + w * AL.rw + pos;
+                        const f32x4 v0 = *(const f32x4*)&Rw[0], v1 = *(const f32x4*)&Rw[4], v2 = *(const f32x4*)&Rw[8], v3 = *(const f32x4*)&Rw[12];
+                        const f32x4 q = (v0 + v1) + (v2 + v3);
+                        sum += (q[0] + q[1]) + (q[2] + q[3]);
+                    }
                 }
             } else {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sum += R0[w * AL.rw + pos];
+#pragma unroll 1
+                for (int w = 0; w < nlive; ++w) sum += R0[w * AL.rw + pos];
             }
-            if (gsh) { if (a.ms_direct) gsh[e] = sum; else atomicAdd(&gsh[e], sum); }      // (ms_direct: one workgroup, one writer per element)
+            if (gsh) { if (a.ms_direct) ((eh_lds_f*)gsh)[e] = sum; else atomicAdd(&gsh[e], sum); }      // (ms_direct: one workgroup, one writer per element)
             else out[e] = sum;
         }
         if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
+        EH_STAMP_FINE(15);
         if constexpr (!P2PM) { if (a.ms_direct) eh_ms_apply<G>(net, a, gsh, wl, tid, NTHR); }
         EH_STAMP(10);
         return;
@@ -1747,16 +1780,17 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     if (dst[u] >= 0) {
-                        if (gsh) { if (a.ms_direct) gsh[dst[u]] = sumv[u]; else atomicAdd(&gsh[dst[u]], sumv[u]); }
+                        if (gsh) { if (a.ms_direct) ((eh_lds_f*)gsh)[dst[u]] = sumv[u]; else atomicAdd(&gsh[dst[u]], sumv[u]); }
                         else out[dst[u]] = sumv[u];
                     }
                 if (dtail >= 0) {
-                    if (gsh) { if (a.ms_direct) gsh[dtail] = sumt; else atomicAdd(&gsh[dtail], sumt); }
+                    if (gsh) { if (a.ms_direct) ((eh_lds_f*)gsh)[dtail] = sumt; else atomicAdd(&gsh[dtail], sumt); }
                     else out[dtail] = sumt;
                 }
             }
         }
         if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
+        EH_STAMP_FINE(15);
         if constexpr (!P2PM) { if (a.ms_direct) eh_ms_apply<G>(net, a, gsh, wl, tid, NTHR); }
         EH_STAMP(10);
         return;
@@ -1844,6 +1878,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             eh_step_body<NBI, NBH, NL, NT, NW, ACT, EH_MODE_TRAIN, FAST>(net, b);
             __syncthreads();
         }
+        for (int i = threadIdx.x; i < a.n_acc; i += NTHR) l_gacc[(a.fz.gslot * EH_GSHARDS) * a.n_acc + i] = 0.0f;      // (the steps used shard 0 of this slot as a plain array)
+        __syncthreads();
         for (int i = threadIdx.x; i < np; i += NTHR) a.fz.pset[i] = l_pset[i];
         for (int i = threadIdx.x; i < ng; i += NTHR) a.fz.gacc[i] = l_gacc[i];
         // nothing is pending behind the launch, so no flush kernel will refresh the GLOBAL parameter image (what the forward / evaluation
