@@ -1,5 +1,5 @@
 # OPTIONAL, never a dependency, never shipped to the GPU box: for anyone who has Julia >= 1.10 with EasyHybrid.jl's packages
-# installed (the build container has neither), this runs the small golden cases of tests/golden/julia/ (written by
+# installed (the build container has neither), this runs the small golden cases of tests/golden/csv_for_emit_fixtures/ (written by
 # tools/export_case_csv.py from the committed .npz fixtures) through the REAL reference path -- constructHybridModel +
 # Lux + Zygote + Optimisers.Adam -- and prints how far the committed oracle values are from what the reference computes.
 # The oracle's gradients / Adam steps are otherwise "parity unpinned" by the reference's own tests (SURVEY.md section 8c).
@@ -46,6 +46,6 @@ function run_case(dir)
             " theta after one Adam step (abs) ", maximum(abs.(collect(ps1) .- readrow(joinpath(dir, "expect_theta_after_1.csv")))))
 end
 
-root = joinpath(@__DIR__, "..", "tests", "golden", "julia")
+root = joinpath(@__DIR__, "..", "tests", "golden", "csv_for_emit_fixtures")
 println("relative deviation of the committed ORACLE values from the reference path (expected: ~1e-6, fp32 rounding):")
 foreach(run_case, filter(isdir, readdir(root; join = true)))

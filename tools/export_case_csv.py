@@ -1,4 +1,4 @@
-"""Writes the small golden cases (tests/golden/rbq10_*_B12.npz) as plain CSV under tests/golden/julia/<case>/ so that
+"""Writes the small golden cases (tests/golden/rbq10_*_B12.npz) as plain CSV under tests/golden/csv_for_emit_fixtures/<case>/ so that
 tools/emit_fixtures.jl can read them with Julia's standard library alone:  python tools/export_case_csv.py"""
 import glob, json, os, sys
 import numpy as np
@@ -7,7 +7,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "rbq10_*_B12.
     z = np.load(path)
     spec = json.loads(str(z["spec"]))
     name = os.path.basename(path)[:-4]
-    out = os.path.join(ROOT, "tests", "golden", "julia", name)
+    out = os.path.join(ROOT, "tests", "golden", "csv_for_emit_fixtures", name)
     os.makedirs(out, exist_ok=True)
     np.savetxt(os.path.join(out, "theta.csv"), z["theta"][None].astype(np.float64), delimiter=",", fmt="%.9g")
     np.savetxt(os.path.join(out, "X.csv"), z["X"].astype(np.float64), delimiter=",", fmt="%.9g")                   # (P x B), as the reference holds it
