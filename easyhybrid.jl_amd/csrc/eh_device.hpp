@@ -1606,8 +1606,13 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         EH_STAMP(14);
         // waves that had no tile (a minibatch smaller than the workgroup's NW tiles: the reference's batch of 64 fills two of eight) hold zeros
         // everywhere: they park nothing and the gather leaves them out -- the same sums bit for bit (x + 0), a quarter of the LDS traffic
+#ifdef EH_AB_FULL_GATHER       // (diagnostic A/B: the form of rounds 1-4 -- every wave parks, the gather sums all NW)
+        constexpr int nlive = NW;
+        constexpr bool parks = true;
+#else
         const int nlive_ = ntiles - (int)blockIdx.x * NW, nlive = nlive_ < 0 ? 0 : (nlive_ < NW ? nlive_ : NW);
         const bool parks = wave < nlive;
+#endif
         float* const R = smem + G::IMG_FLOATS + wave * AL.rw;
         // region[k][g][r][c]: the 16 samples (c) of a row are contiguous, so row sums are four 16-byte reads
         auto put = [&](int k, const f32x4& v) {
