@@ -360,11 +360,14 @@ __global__ __launch_bounds__(64 * NWV, 1) void eh_bfs_kernel(const EhNet net_rt,
         }
         EH_STAMP(3);
         // ---- output layer (16 padded rows), sigma-scaling into the parameter range ----
+        // (s_setprio 1 / 3 over this short serial stretch -- dependent MFMAs, sigma, the 16-lane mechanistic stage -- measured: 42.3-43.0 us per step
+        //  with it, 43.0 without, inside the lease's noise; not kept)
         {
             f32x4 o = bo;
 #pragma unroll
             for (int kk = 0; kk < KSH; ++kk) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[kk], hb[NL - 1][kk], o, 0, 0, 0);
             const f32x4 klo = *(const f32x4*)&KT[4 * g], ksc = *(const f32x4*)&KT[16 + 4 * g];
+            EH_STAMP_FINE(15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pv = o[r], sv = 1.0f;

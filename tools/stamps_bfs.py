@@ -23,4 +23,6 @@ print(f"last tile: {st[10,0]-st[0,0]} cycles; clock {(st[12,0]-st[0,0])/max(1,(s
 print(f"   prologue (image)           {st[14,0]-st[13,0]:8d} cycles; whole kernel {st[12,0]-st[13,0]} cycles")
 for i, n in enumerate(names):
     print(f"   {n:52s} {st[i+1,0]-st[i,0]:8d} cycles")
+if st[15, 0] > 0:
+    print(f"   (fine) output-layer MFMAs done + sigma table read at +{st[15,0]-st[3,0]} cycles after the hidden forward; sigma + scratch writes + wave sync {st[4,0]-st[15,0]}")
 eng.close()
