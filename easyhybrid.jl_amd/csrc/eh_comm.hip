@@ -145,8 +145,8 @@ static int p2p_alloc(eh_handle* h, int32_t world, int32_t rank, hipIpcMemHandle_
         if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return fail(h, EH_EUNSUPPORTED, "%s: hipIpcGetMemHandle: %s", who, hipGetErrorString(e)); }
     }
     h->p2p_recv = buf; h->p2p_local = handle_out == nullptr;      // (known from here on: an error below leaves buffers that the caller's clean-up frees)
-    HIPCHK(h, hipMalloc(&h->p2p_stage, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
-    HIPCHK(h, hipMemset(h->p2p_stage, 0, (size_t)3 * EH_GSHARDS * h->n_acc * sizeof(float)));
+    HIPCHK(h, hipMalloc(&h->p2p_stage, ((size_t)3 * EH_GSHARDS * h->n_acc + 4) * sizeof(float)));      // (+4: the prologue reads five scalars behind every shard's gradient, whatever T)
+    HIPCHK(h, hipMemset(h->p2p_stage, 0, ((size_t)3 * EH_GSHARDS * h->n_acc + 4) * sizeof(float)));
     HIPCHK(h, hipMalloc(&h->p2p_ctr, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));      // [0] top ticket, [1] error flag, [2] self-test mismatches, [32 (1 + g)] group tickets
     HIPCHK(h, hipMemset(h->p2p_ctr, 0, 32 * (1 + EH_P2P_GROUPS) * sizeof(unsigned)));
     HIPCHK(h, hipMalloc(&h->p2p_dev, sizeof(EhP2P)));

@@ -334,6 +334,18 @@ __device__ __forceinline__ float eh_wave_sum(float v) {
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48)));
 }
+// The eight shards of an accumulator element are folded in ONE order wherever they are folded (step prologue, flush kernel, the
+// workgroup that publishes a rank's sums to its peers): a rank's own value and the value its peers receive must be the same bits.
+// The tree is what three butterfly steps over eight adjacent lanes compute (eh_fold8_lanes).
+__device__ __forceinline__ float eh_fold8(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7) {
+    return ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+}
+__device__ __forceinline__ float eh_fold8_lanes(float v) {   // lanes 8k + sh hold shard sh: every lane of the group gets eh_fold8 of the group
+    v += eh_dpp<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v += eh_dpp<0x4E>(v);    // quad_perm:[2,3,0,1]
+    v += eh_dpp<0x141>(v);   // row_half_mirror (the quads hold their sums in every lane by now)
+    return v;
+}
 __device__ __forceinline__ float eh_pow(float b, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(b)); }   // b > 0
 
 // ------------------------------------------------------------------------------------------
@@ -547,10 +559,11 @@ __device__ __forceinline__ void eh_p2p_fold_store(const EhP2P* P, int slot, unsi
     if (peers_only && P->world == 1) return;
     const float* st = P->stage + (long long)slot * EH_GSHARDS * n_acc;
     for (int i = tid; i < n_acc; i += nthr) {
-        float v = 0.0f;
+        float sv[EH_GSHARDS];
 #pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) v += __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long w = eh_ll_pack(v, seq);
+        for (int sh = 0; sh < EH_GSHARDS; ++sh) sv[sh] = __hip_atomic_load(&st[sh * n_acc + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        static_assert(EH_GSHARDS == 8, "eh_fold8");
+        const unsigned long long w = eh_ll_pack(eh_fold8(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]), seq);
         for (int r = 0; r < P->world; ++r)
             if (!peers_only || r != P->rank)
                 __hip_atomic_store(&P->peer_recv[r][((long long)slot * EH_GSHARDS + P->rank) * n_acc + i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -630,7 +643,7 @@ struct EhGeom {
 };
 
 #ifdef EH_STAMPS
-#define EH_STAMP(i)                                                                      \
+#define EH_STAMP_RAW(i)                                                                  \
     do {                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                               \
         if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                           \
@@ -640,7 +653,16 @@ struct EhGeom {
         __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
 #else
-#define EH_STAMP(i)
+#define EH_STAMP_RAW(i)
+#endif
+// EH_STAMPS_PROLOGUE (with EH_STAMPS): slots 2..7 and 11..15 stamp the parts of the step's prologue instead of the tile loop's segments
+// (tools/stamps_p2p.py)
+#if defined(EH_STAMPS) && defined(EH_STAMPS_PROLOGUE)
+#define EH_STAMP(i) do { if ((i) <= 1 || ((i) >= 8 && (i) <= 10)) EH_STAMP_RAW(i); } while (0)
+#define EH_STAMP_PRO(i) EH_STAMP_RAW(i)
+#else
+#define EH_STAMP(i) EH_STAMP_RAW(i)
+#define EH_STAMP_PRO(i)
 #endif
 #ifdef EH_STAMPS_FINE
 #define EH_STAMP_FINE(i) EH_STAMP(i)
@@ -732,6 +754,12 @@ __device__ __forceinline__ void eh_ms_apply(const NET& net, const EhStepArgs& a,
     }
 }
 
+// (the exchange's scalar sums on their way from the eight threads that fetch them to everybody; static LDS only in the instantiations that exchange)
+template <bool ON>
+__device__ __forceinline__ float* eh_px_table() {
+    if constexpr (ON) { __shared__ __attribute__((aligned(16))) float T[8]; return T; }
+    else return nullptr;
+}
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepArgs& a) {
     // Run-time compiled kernels (eh_jit.hip) know the model: the descriptor is a compile-time constant there and the generality
@@ -848,59 +876,74 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // (ms_direct && ms_keep: a later step of a multi-step launch -- the step before it has applied its own update and written the new
     //  parameters into the LDS image: nothing deferred to pick up here)
     const bool deferred_upd = fusedm && !(a.ms_direct && a.ms_keep);
+    // (the exchange descriptor's fields once, up front, into scalar registers: read where they are used -- inside address lambdas, behind
+    //  branches -- every use was a chain of dependent scalar loads of its own, rank -> peer_recv[rank] -> the word)
+    const int px_mode = P2PM ? a.p2pv.mode : 0, px_rank = P2PM ? a.p2pv.rank : 0, px_world = P2PM ? a.p2pv.world : 1;
+    const unsigned long long* const px_recv = P2PM ? a.p2pv.peer_recv[px_rank] + (long long)((a.fz.gslot + 2) % 3) * EH_GSHARDS * a.n_acc : nullptr;
+    const float* const px_stage = P2PM ? a.p2pv.stage : nullptr;
+    float px_own[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // (EhP2P mode 1: this rank's own sums of the previous step come from its staging shards, like the single-GPU step's from its accumulators)
+    const bool own_direct = deferred_upd && a.fz.pending && (!P2PM || px_mode == 1);
+    float f_sv = 0.0f;      // lane 8 k + sh of every wave: scalar k of shard sh
     if (deferred_upd) {
         const EhFused& z = a.fz;
-        // (EhP2P mode 1: this rank's own sums of the previous step come from its staging shards, like the single-GPU step's from its accumulators)
-        const bool own_direct = !P2PM || a.p2pv.mode == 1;
-        const float* const g_prev = (P2PM ? a.p2pv.stage : z.gacc) + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
+        const float* const g_prev = (P2PM ? px_stage : z.gacc) + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * net.n_theta;
-        if (own_direct && z.pending) {
-#pragma unroll
-            for (int sh = 0; sh < EH_GSHARDS; ++sh) {
-                const float* gp = g_prev + sh * a.n_acc + net.n_theta;
-                // [S | n | Sy | Syy] (one target) or [S | n_t ... | Sy | Syy]: five loads either way and selects, no branch -- a uniform branch
-                // here split the prologue's single memory round trip in two (+1.7 us per headline step on the kernels built ahead of time).
-                // Multi-target steps used exact per-target weights (a.inv_n): only "any valid sample" matters, Sy / Syy are not read.
-                const float g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3], g4 = gp[4];      // (gp[4]: one float of slack behind the last shard)
-                f_sse += g0;
-                f_cnt += g1 + (net.T > 1 ? g2 : 0.0f) + (net.T > 2 ? g3 : 0.0f) + (net.T > 3 ? g4 : 0.0f);
-                f_sy += g2; f_syy += g3;
-            }
-        }
+        // [S | n | Sy | Syy] (one target) or [S | n_t ... | Sy | Syy] behind the gradient in each of the eight shards: FIVE scalars either way
+        // (one float of slack behind the last shard), one load per lane -- lanes 0..39 of every wave -- folded across the lanes once the
+        // loads are back (below, behind the image).  No branch on the target count: a uniform branch here split the prologue's single
+        // memory round trip in two (+1.7 us per headline step on the kernels built ahead of time).  (Every thread used to load all forty
+        // itself: 40 loads + their addresses in each of the workgroup's waves, ~0.6 us of a prologue that is bound by the instructions it issues.)
+        if (own_direct && lane < 40) f_sv = g_prev[(lane & 7) * a.n_acc + net.n_theta + (lane >> 3)];
         const float* const sc_in = z.pset + 6 * net.n_theta + 2 * z.sc_sel;
         f_bt1 = sc_in[0]; f_bt2 = sc_in[1];
         if (tid < net.n_theta) {
             f_th = pin[tid]; f_m = pin[net.n_theta + tid]; f_v = pin[2 * net.n_theta + tid];
             f_map = tid < net.g_off ? z.imap[tid] : 0;
-            if (own_direct && z.pending) {
+            if (own_direct) {
+                float gsv[EH_GSHARDS];
 #pragma unroll
-                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_g += g_prev[sh * a.n_acc + tid];
+                for (int sh = 0; sh < EH_GSHARDS; ++sh) gsv[sh] = g_prev[sh * a.n_acc + tid];
+                f_g = eh_fold8(gsv[0], gsv[1], gsv[2], gsv[3], gsv[4], gsv[5], gsv[6], gsv[7]);
             }
         }
     }
-    // EH_MODE_TRAIN_P2P: the shards of all ranks for the previous step, every 64-bit word with its own arrival stamp.
-    // The workgroup fetches the world x (min(n_theta, NTHR) + 4) words it needs cooperatively -- a handful per thread,
-    // requested here together with the loads above and the image below, examined (and re-read while a peer is late)
-    // once the image is staged -- and parks the values in LDS, from where every thread sums its own element over
-    // the ranks in rank order.
-    constexpr int P2P_NW = P2PM ? (EH_GSHARDS * (NTHR + 4) + NTHR - 1) / NTHR : 1;
-    static_assert(!P2PM || EH_GSHARDS * (NTHR + 4) <= NW * G::WAVE_WS, "the received sums are parked in the (still unused) wave workspaces");
-    const int p2p_ne = (net.n_theta < NTHR ? net.n_theta : NTHR) + 4;
-    auto p2p_addr = [&](int u) -> const unsigned long long* {
-        const int j = tid + u * NTHR;
-        if (j >= a.p2pv.world * p2p_ne) return nullptr;
-        const int sh = j / p2p_ne, e = j - sh * p2p_ne;
-        if (a.p2pv.mode == 1 && sh == a.p2pv.rank) return nullptr;          // (own sums: taken from the staging shards above; reads as 0 here)
-        const int idx = e < p2p_ne - 4 ? e : net.n_theta + (e - (p2p_ne - 4));
-        return a.p2pv.peer_recv[a.p2pv.rank] + ((long long)((a.fz.gslot + 2) % 3) * EH_GSHARDS + sh) * a.n_acc + idx;
+    // EH_MODE_TRAIN_P2P: the sums of all ranks for the previous step, every 64-bit word with its own arrival stamp.  Thread tid asks
+    // for ITS element of every rank's shard (what the single-GPU prologue reads from its eight local shards), the last eight threads
+    // also for one of the five scalars [S | n_1 .. | Sy | Syy] behind the gradient; requested here together with the loads above and
+    // the image below, examined (and re-read while a peer is late) once the image is staged.  Everything is summed in registers, in
+    // RANK order on every rank, so the replicas stay bitwise identical; the scalar sums reach the other threads through 8 floats of LDS.
+    // (A first version dealt the world x (n_theta + 4) words round-robin over the threads and parked all of them in LDS: nine address
+    //  computations per thread whatever the world, a table walk per rank, two barriers.)
+    EH_STAMP_PRO(2);
+    float* const px_T = eh_px_table<P2PM>();
+    const int px_nmain = net.n_theta < NTHR ? net.n_theta : NTHR;
+    // (written out rather than through eh_ll_issue / eh_ll_finish: what depends on the rank count only is a scalar branch per rank, so a
+    //  small world pays for its own ranks and not for eight -- all waves of the workgroup run this code, and the prologue is bound by
+    //  the instructions they issue, not by the memory it waits for)
+    const unsigned px_seq = a.p2p_seq - 1u;
+    const unsigned long long px_none = (unsigned long long)px_seq << 32;      // "arrived, 0.0"
+    unsigned long long px_w[P2PM ? EH_GSHARDS : 1], px_s[P2PM ? EH_GSHARDS : 1];
+    const int px_k = tid - (NTHR - 8);                      // the last eight threads: scalar k of every rank
+    const bool px_sc = px_k >= 0 && px_k < (net.T > 3 ? 5 : 4);
+    auto px_request = [&]() {
+#pragma unroll
+        for (int sh = 0; sh < (P2PM ? EH_GSHARDS : 1); ++sh) {
+            px_w[sh] = px_none; px_s[sh] = px_none;
+            if (sh < px_world && !(px_mode == 1 && sh == px_rank)) {      // (own sums in mode 1: taken from the staging shards above)
+                const unsigned long long* const q = px_recv + (long long)sh * a.n_acc;
+                if (tid < px_nmain) px_w[sh] = __hip_atomic_load(q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (px_sc) px_s[sh] = __hip_atomic_load(q + net.n_theta + px_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     };
-    unsigned long long p2p_w[P2P_NW];
     if constexpr (P2PM) {
         // mode 1: the previous step's kernel is through (stream order), so its adds have all landed -- no ticket, no election: this workgroup
-        // folds the staging shards and publishes them to every rank, then waits for the words like everybody else
-        if (fusedm && a.fz.pending && a.p2pv.mode == 1 && blockIdx.x == 0) eh_p2p_fold_store(&a.p2pv, (a.fz.gslot + 2) % 3, a.p2p_seq - 1u, a.n_acc, tid, NTHR, true);
-        if (fusedm && a.fz.pending) eh_ll_issue(p2p_addr, a.p2p_seq - 1u, p2p_w);
+        // folds the staging shards and publishes them to the peers, then waits for the words like everybody else
+        if (fusedm && a.fz.pending && px_mode == 1 && px_world > 1 && blockIdx.x == 0) eh_p2p_fold_store(&a.p2pv, (a.fz.gslot + 2) % 3, px_seq, a.n_acc, tid, NTHR, true);
+        if (fusedm && a.fz.pending) px_request();
     }
+    EH_STAMP_PRO(3);
     if (!a.ms_keep) {   // all loads first, then the LDS stores: one memory round trip instead of one per 16 bytes
         // (ms_keep: a later step of a multi-step launch -- the image is still in LDS from the step before, whose update wrote the new
         //  parameters into it; its constant part never changes)
@@ -919,34 +962,66 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             }
         }
     }
-    if constexpr (P2PM) {
-        if (fusedm && a.fz.pending) {
-            float got[P2P_NW];
-            eh_ll_finish(&a.p2pv, p2p_addr, a.p2p_seq - 1u, p2p_w, got);
-            float* const T = smem + G::IMG_FLOATS;               // [world][p2p_ne]
-            const bool own_direct_p2p = a.p2pv.mode == 1;
-#pragma unroll
-            for (int u = 0; u < P2P_NW; ++u) {
-                const int j = tid + u * NTHR;
-                if (j < a.p2pv.world * p2p_ne && !(own_direct_p2p && j / p2p_ne == a.p2pv.rank)) T[j] = got[u];
-            }
-            if (own_direct_p2p) {
-                // this rank's own sums (from its staging shards, folded in shard order exactly as the publishing workgroup folds them for the
-                // peers) take their place in the table: the sum below runs in RANK order on every rank, so the replicas stay bitwise identical
-                float* const To = T + a.p2pv.rank * p2p_ne;
-                if (tid < p2p_ne - 4) To[tid] = f_g;
-                if (tid == 0) { To[p2p_ne - 4] = f_sse; To[p2p_ne - 3] = f_cnt; To[p2p_ne - 2] = f_sy; To[p2p_ne - 1] = f_syy; }
-                f_g = 0.0f; f_sse = 0.0f; f_cnt = 0.0f; f_sy = 0.0f; f_syy = 0.0f;
-            }
-            __syncthreads();
-            for (int sh = 0; sh < a.p2pv.world; ++sh) {
-                const float* Ts = T + sh * p2p_ne;
-                f_sse += Ts[p2p_ne - 4]; f_cnt += Ts[p2p_ne - 3]; f_sy += Ts[p2p_ne - 2]; f_syy += Ts[p2p_ne - 1];
-                if (tid < p2p_ne - 4) f_g += Ts[tid];
-            }
-            __syncthreads();                                     // T lives where the X images are about to be cleared
+    if (own_direct) {
+        const int svi = __builtin_bit_cast(int, eh_fold8_lanes(f_sv));
+        const float S0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 0)), S1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 8)),
+                    S2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 16)), S3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 24)),
+                    S4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 32));
+        if constexpr (P2PM) { px_own[0] = S0; px_own[1] = S1; px_own[2] = S2; px_own[3] = S3; px_own[4] = S4; }
+        else {
+            // Multi-target steps used exact per-target weights (a.inv_n): only "any valid sample" matters, Sy / Syy are not read.
+            f_sse = S0; f_cnt = S1 + (net.T > 1 ? S2 : 0.0f) + (net.T > 2 ? S3 : 0.0f) + (net.T > 3 ? S4 : 0.0f); f_sy = S2; f_syy = S3;
         }
     }
+    EH_STAMP_PRO(4);
+    if constexpr (P2PM) {
+        if (fusedm && a.fz.pending) {
+            // every word carries its arrival stamp: re-read while a peer is late; a deadline on the wall clock (eh_ll_finish's) turns a
+            // missing peer into the error flag, words that never arrive read as 0
+            {
+                unsigned long long t0 = 0;
+                bool timing = false;
+                while (true) {
+                    bool all = true;
+#pragma unroll
+                    for (int sh = 0; sh < EH_GSHARDS; ++sh)
+                        if (sh < px_world) all = all && ((unsigned)(px_w[sh] >> 32) == px_seq) && ((unsigned)(px_s[sh] >> 32) == px_seq);
+                    if (all) break;
+                    if (__hip_atomic_load(a.p2pv.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (!timing) { t0 = wall_clock64(); timing = true; }
+                    else if (wall_clock64() - t0 > EH_P2P_DEADLINE_TICKS) { __hip_atomic_store(a.p2pv.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    px_request();
+                }
+            }
+            EH_STAMP_PRO(11);
+            // this thread's element and (the last eight threads) scalar, summed over the ranks in RANK order; mode 1 puts the rank's own sums --
+            // read from its staging shards, folded in shard order as the publishing workgroup folds them for the peers -- in their place
+            const bool own1 = px_mode == 1;
+            const float own_g = f_g;                             // (mode 0: nothing was read from the staging shards, 0)
+            const float own_s = px_k == 0 ? px_own[0] : px_k == 1 ? px_own[1] : px_k == 2 ? px_own[2] : px_k == 3 ? px_own[3] : px_own[4];
+            float fs = 0.0f;
+            f_g = 0.0f;
+#pragma unroll
+            for (int sh = 0; sh < EH_GSHARDS; ++sh)
+                if (sh < px_world) {
+                    const bool own = own1 && sh == px_rank;
+                    f_g += own ? own_g : ((unsigned)(px_w[sh] >> 32) == px_seq) ? __uint_as_float((unsigned)px_w[sh]) : 0.0f;
+                    fs += own ? own_s : ((unsigned)(px_s[sh] >> 32) == px_seq) ? __uint_as_float((unsigned)px_s[sh]) : 0.0f;
+                }
+            if (px_k >= 0) px_T[px_k] = fs;
+            EH_STAMP_PRO(12);
+            __syncthreads();
+            EH_STAMP_PRO(13);
+            {
+                const f32x4 t4 = *(const f32x4*)px_T;
+                f_sse = t4[0];
+                f_cnt = t4[1] + (net.T > 1 ? t4[2] : 0.0f) + (net.T > 2 ? t4[3] : 0.0f) + (net.T > 3 ? px_T[4] : 0.0f);
+                f_sy = t4[2]; f_syy = t4[3];
+            }
+        }
+    }
+    EH_STAMP_PRO(5);
     // small minibatches (a.bn_nblk == -1, count <= EH_BN_SELF_MAX: the reference's tutorial trains on 64): every workgroup takes the
     // statistics of the whole minibatch itself -- thread (g, p) sums predictor p over the samples g, g + NTHR / 32, ... about the first
     // sample's value -- instead of waiting for a launch of eh_bn_stats_kernel in front of the step (a dependent launch costs more than
@@ -1003,13 +1078,14 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         }
         __syncthreads();
     }
+    EH_STAMP_PRO(6);
     if (deferred_upd) {
         // fused update: apply the previous step's optimiser update straight into the LDS image
         const EhFused& z = a.fz;
         const int nth = net.n_theta;
         const float* const g_prev = z.gacc + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
         // the accumulators the NEXT step adds into: the receive buffer itself, or the local staging copy under EhP2P
-        float* const g_zero = (P2PM ? a.p2pv.stage : z.gacc) + ((z.gslot + 1) % 3) * (EH_GSHARDS * a.n_acc);
+        float* const g_zero = (P2PM ? const_cast<float*>(px_stage) : z.gacc) + ((z.gslot + 1) % 3) * (EH_GSHARDS * a.n_acc);
         const float* const pin = z.pset + z.cur * 3 * nth;
         float* const pout = z.pset + (z.cur ^ 1) * 3 * nth;
         const bool upd = z.pending && f_cnt > 0.0f;
@@ -1028,24 +1104,23 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 if (upd) {
                     if constexpr (P2PM) {
                         auto ad = [&](int sh) -> const unsigned long long* {
-                            if (a.p2pv.mode == 1 && sh == a.p2pv.rank) return nullptr;
-                            return sh < a.p2pv.world ? a.p2pv.peer_recv[a.p2pv.rank] + ((long long)((z.gslot + 2) % 3) * EH_GSHARDS + sh) * a.n_acc + idx : nullptr;
+                            if (px_mode == 1 && sh == px_rank) return nullptr;
+                            return sh < px_world ? px_recv + (long long)sh * a.n_acc + idx : nullptr;
                         };
                         float own = 0.0f;
-                        if (a.p2pv.mode == 1) {
-                            const float* const gst = a.p2pv.stage + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
-#pragma unroll
-                            for (int sh = 0; sh < EH_GSHARDS; ++sh) own += gst[sh * a.n_acc + idx];
+                        if (px_mode == 1) {
+                            const float* const gst = px_stage + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc) + idx;
+                            own = eh_fold8(gst[0], gst[a.n_acc], gst[2 * a.n_acc], gst[3 * a.n_acc], gst[4 * a.n_acc], gst[5 * a.n_acc], gst[6 * a.n_acc], gst[7 * a.n_acc]);
                         }
                         unsigned long long w8[EH_GSHARDS];
                         float got[EH_GSHARDS];
                         eh_ll_issue(ad, a.p2p_seq - 1u, w8);
                         eh_ll_finish(&a.p2pv, ad, a.p2p_seq - 1u, w8, got);
 #pragma unroll
-                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += (a.p2pv.mode == 1 && sh == a.p2pv.rank) ? own : got[sh];      // (rank order on every rank)
+                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += (px_mode == 1 && sh == px_rank) ? own : got[sh];      // (rank order on every rank)
                     } else {
-#pragma unroll
-                        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += g_prev[sh * a.n_acc + idx];
+                        const float* const gq = g_prev + idx;
+                        gs = eh_fold8(gq[0], gq[a.n_acc], gq[2 * a.n_acc], gq[3 * a.n_acc], gq[4 * a.n_acc], gq[5 * a.n_acc], gq[6 * a.n_acc], gq[7 * a.n_acc]);
                     }
                 }
             }
@@ -1060,6 +1135,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 wl[G::PHI_OFF + EH_IMG_DPHI + j] = sc * sg * (1.0f - sg);
             }
         }
+        EH_STAMP_PRO(7);
         if (blockIdx.x == 0 && tid == 0) {
             float* const sc_out = z.pset + 6 * nth + 2 * (z.sc_sel ^ 1);
             sc_out[0] = upd ? f_bt1 * z.opt.b1 : f_bt1;
@@ -1650,7 +1726,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         EH_STAMP(9);
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = a.fz.gacc ? (P2PM ? a.p2pv.stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
+        float* const gsh = a.fz.gacc ? (P2PM ? const_cast<float*>(px_stage) : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
         for (int e = tid; e < a.n_acc; e += NTHR) {
             const int code = e == tid ? f_rcode : a.rmap[e], pos = code & 0xFFFFFF, nlan = code >> 24;
             float sum = 0.0f;
@@ -1683,7 +1759,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             if (gsh) { if (a.ms_direct) ((eh_lds_f*)gsh)[e] = sum; else atomicAdd(&gsh[e], sum); }      // (ms_direct: one workgroup, one writer per element)
             else out[e] = sum;
         }
-        if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
+        if constexpr (P2PM) { if (px_mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
         EH_STAMP_FINE(15);
         if constexpr (!P2PM) { if (a.ms_direct) eh_ms_apply<G>(net, a, gsh, wl, tid, NTHR); }
         EH_STAMP(10);
@@ -1744,7 +1820,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         float* const R = smem + G::IMG_FLOATS + wave * G::WAVE_WS;
         const float* const R0 = smem + G::IMG_FLOATS;
         float* const out = a.slab + (long long)blockIdx.x * a.n_acc;
-        float* const gsh = a.fz.gacc ? (P2PM ? a.p2pv.stage : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
+        float* const gsh = a.fz.gacc ? (P2PM ? const_cast<float*>(px_stage) : a.fz.gacc) + (a.fz.gslot * EH_GSHARDS + (blockIdx.x & (EH_GSHARDS - 1))) * a.n_acc : nullptr;
 #pragma unroll
         for (int rd = 0; rd < NR; ++rd) {
             __syncthreads();                       // the wave workspaces are dead / the previous round has been gathered
@@ -1794,7 +1870,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 }
             }
         }
-        if constexpr (P2PM) { if (a.p2pv.mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
+        if constexpr (P2PM) { if (px_mode == 0) eh_p2p_publish(&a.p2pv, a.fz.gslot, a.p2p_seq, a.n_acc, tid, NTHR); }      // (mode 1: the next kernel's workgroup 0 publishes)
         EH_STAMP_FINE(15);
         if constexpr (!P2PM) { if (a.ms_direct) eh_ms_apply<G>(net, a, gsh, wl, tid, NTHR); }
         EH_STAMP(10);
@@ -1832,11 +1908,35 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 // one training step (or one forward / eval pass) per launch
 // (EH_SPEC_NS: a translation unit that bakes ONE model descriptor into its kernels ahead of time -- eh_spec.hip -- puts them in a
 //  namespace of its own: the same template arguments name a different kernel there than in the generic translation units)
+// The kernel arguments (some 760 bytes: twelve 64-byte lines) sit in memory the host wrote a moment ago: the first scalar load of
+// each line misses every cache.  The step bodies read their arguments where they use them -- behind branches, one line after another,
+// each miss a full memory round trip on the critical path of a 10 us kernel.  One load per line up front, all in flight together,
+// and every later read of an argument is a scalar-cache hit.
+template <int BYTES>
+__device__ __forceinline__ void eh_kernarg_warm() {
+#ifndef EH_NO_KERNARG_WARM
+    // (written out: the compiler splits a loop of plain loads over several waits -- and every wait is one of those round trips)
+    static_assert(BYTES > 256 && BYTES <= 768, "four to twelve lines");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d0, d1, d2, d3, d4 = 0u, d5 = 0u, d6 = 0u, d7 = 0u, d8 = 0u, d9 = 0u, d10 = 0u, d11 = 0u;
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
+    if constexpr (BYTES > 256)
+        asm volatile("s_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0"
+                     : "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7) : "s"(ka));
+    if constexpr (BYTES > 512)
+        asm volatile("s_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0"
+                     : "=&s"(d8), "=&s"(d9), "=&s"(d10), "=&s"(d11) : "s"(ka));
+    // (the destinations stay live up to the wait: a register handed out earlier would be overwritten when its load lands)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4), "s"(d5), "s"(d6), "s"(d7), "s"(d8), "s"(d9), "s"(d10), "s"(d11));
+#endif
+}
 #ifdef EH_SPEC_NS
 namespace EH_SPEC_NS {
 #endif
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
+    eh_kernarg_warm<((sizeof(EhNet) + sizeof(EhStepArgs) + 255) & ~255)>();
     if constexpr (MODE == EH_MODE_TRAIN_MULTI) {
         // Minibatches that ONE workgroup covers -- the reference's default batch of 64 (src/config/TrainingConfig.jl:14) and everything up
         // to 16 NT NW samples: a step's only consumer is the same workgroup's next step, so the steps of an epoch need neither a kernel

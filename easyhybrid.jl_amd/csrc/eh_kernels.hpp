@@ -521,32 +521,37 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
         // mode 1: nobody has published the last step yet -- block 0 does it for the peers; this rank's own sums come from its staging shards
         const bool own_direct = p2p->mode == 1;
         if (own_direct && blockIdx.x == 0) eh_p2p_fold_store(p2p, slot, seq, n_acc, (int)threadIdx.x, 256, true);
-        float ownv[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // (five scalars behind the gradient, [S | n_1 .. | Sy | Syy], as the step's prologue reads them; the fifth only where it is a count;
+        //  the own sums folded as the publishing workgroup folds them -- eh_fold8)
+        float ownv[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (own_direct) {
             const float* const st = p2p->stage + (long long)slot * EH_GSHARDS * n_acc;
 #pragma unroll
-            for (int sh = 0; sh < EH_GSHARDS; ++sh) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ownv[k] += st[sh * n_acc + n_theta + k];
-                if (own) ownv[4] += st[sh * n_acc + idx];
+            for (int k = 0; k < 6; ++k) {
+                if (k == 4 && T <= 3) continue;
+                if (k == 5 && !own) continue;
+                const float* q = st + (k < 5 ? n_theta + k : idx);
+                ownv[k] = eh_fold8(q[0], q[n_acc], q[2 * n_acc], q[3 * n_acc], q[4 * n_acc], q[5 * n_acc], q[6 * n_acc], q[7 * n_acc]);
             }
         }
         auto ad = [&](int i) -> const unsigned long long* {
-            const int sh = i / 5, k = i % 5;
-            if (sh >= p2p->world || (k == 4 && idx >= n_theta) || (own_direct && sh == p2p->rank)) return nullptr;
+            const int sh = i / 6, k = i % 6;
+            if (sh >= p2p->world || (k == 5 && idx >= n_theta) || (k == 4 && T <= 3) || (own_direct && sh == p2p->rank)) return nullptr;
             const unsigned long long* base = p2p->peer_recv[p2p->rank] + ((long long)slot * EH_GSHARDS + sh) * n_acc;
-            return k < 4 ? base + n_theta + k : base + idx;
+            return k < 5 ? base + n_theta + k : base + idx;
         };
-        unsigned long long w[5 * EH_GSHARDS];
-        float got[5 * EH_GSHARDS];
+        unsigned long long w[6 * EH_GSHARDS];
+        float got[6 * EH_GSHARDS];
         eh_ll_issue(ad, seq, w);
         eh_ll_finish(p2p, ad, seq, w, got);
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
 #pragma unroll
         for (int sh = 0; sh < EH_GSHARDS; ++sh) {          // (rank order on every rank: bitwise-identical replicas)
             const bool me = own_direct && sh == p2p->rank;
-            sse += me ? ownv[0] : got[5 * sh]; cnt += me ? ownv[1] : got[5 * sh + 1]; sy += me ? ownv[2] : got[5 * sh + 2];
-            syy += me ? ownv[3] : got[5 * sh + 3]; gs_p2p += me ? ownv[4] : got[5 * sh + 4];
+            sse += me ? ownv[0] : got[6 * sh]; s1 += me ? ownv[1] : got[6 * sh + 1]; s2 += me ? ownv[2] : got[6 * sh + 2];
+            s3 += me ? ownv[3] : got[6 * sh + 3]; s4 += me ? ownv[4] : got[6 * sh + 4]; gs_p2p += me ? ownv[5] : got[6 * sh + 5];
         }
+        cnt = s1 + (T > 1 ? s2 : 0.0f) + (T > 2 ? s3 : 0.0f) + (T > 3 ? s4 : 0.0f); sy = s2; syy = s3;
     } else {
 #pragma unroll
         for (int sh = 0; sh < EH_GSHARDS; ++sh) {
