@@ -841,11 +841,20 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     struct { f32x4 x[NX4]; float frc[EH_MAX_FORC]; float y[EH_MAX_TARG]; } nx;
     const int count = (int)a.count, first = (int)a.first;     // N <= 2^31 - 1 (checked by eh_set_data)
     const int ntiles = (count + MT - 1) / MT;
-    auto fetch = [&](int tile) {
+    // (in two halves: a gathered minibatch reads its record THROUGH the epoch's permutation -- a dependent pair of loads.  The step's first
+    //  fetch asks for the index up front and for the record only once everything else the prologue needs is in flight -- state, exchange
+    //  words, parameter image -- so the index's round trip is theirs as well; asked for first, as one piece, the pair put two round trips
+    //  in front of everything else.)
+    int nx_glb = 0;
+    bool nx_live = false;
+    auto fetch_idx = [&](int tile) {
         const int n_loc = tile * MT + lane;
-        const bool live = (tile < ntiles) && (lane < MT) && (n_loc < count);
-        const int n_glb = live ? (a.idx ? a.idx[first + n_loc] : first + n_loc) : 0;
-        const float* const rec = a.recs + (long long)n_glb * a.C;
+        nx_live = (tile < ntiles) && (lane < MT) && (n_loc < count);
+        nx_glb = nx_live ? (a.idx ? a.idx[first + n_loc] : first + n_loc) : 0;
+    };
+    auto fetch_rec = [&]() {
+        const bool live = nx_live;
+        const float* const rec = a.recs + (long long)nx_glb * a.C;
         if ((a.C & 3) == 0) {          // 16-byte-multiple records (RbQ10: exactly one dwordx4 per sample)
 #pragma unroll
             for (int q = 0; q < NX4; ++q) nx.x[q] = (live && 4 * q < net.P) ? *(const f32x4*)(rec + 4 * q) : f32x4{0, 0, 0, 0};
@@ -860,7 +869,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t) nx.y[t] = (tOn[t] != 0.0f && live) ? rec[tcol0 + t] : __builtin_nanf("");
     };
-    fetch((int)blockIdx.x * NW + wave);
+    auto fetch = [&](int tile) { fetch_idx(tile); fetch_rec(); };
+    fetch_idx((int)blockIdx.x * NW + wave);
+    bool rec_pending = a.idx != nullptr;
+    if (!rec_pending) fetch_rec();               // contiguous minibatch: nothing to wait for
 
     EH_STAMP(0);
     // ---- stage the parameter image into LDS (straight copy) ------------------------------------
@@ -885,6 +897,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // (EhP2P mode 1: this rank's own sums of the previous step come from its staging shards, like the single-GPU step's from its accumulators)
     const bool own_direct = deferred_upd && a.fz.pending && (!P2PM || px_mode == 1);
     float f_sv = 0.0f;      // lane 8 k + sh of every wave: scalar k of shard sh
+    float f_gs[EH_GSHARDS] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // this thread's element in the eight shards
     if (deferred_upd) {
         const EhFused& z = a.fz;
         const float* const g_prev = (P2PM ? px_stage : z.gacc) + ((z.gslot + 2) % 3) * (EH_GSHARDS * a.n_acc);
@@ -900,11 +913,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         if (tid < net.n_theta) {
             f_th = pin[tid]; f_m = pin[net.n_theta + tid]; f_v = pin[2 * net.n_theta + tid];
             f_map = tid < net.g_off ? z.imap[tid] : 0;
-            if (own_direct) {
-                float gsv[EH_GSHARDS];
+            if (own_direct) {       // (folded below, behind the image: folded here, the loads' round trip would come before the image's)
 #pragma unroll
-                for (int sh = 0; sh < EH_GSHARDS; ++sh) gsv[sh] = g_prev[sh * a.n_acc + tid];
-                f_g = eh_fold8(gsv[0], gsv[1], gsv[2], gsv[3], gsv[4], gsv[5], gsv[6], gsv[7]);
+                for (int sh = 0; sh < EH_GSHARDS; ++sh) f_gs[sh] = g_prev[sh * a.n_acc + tid];
             }
         }
     }
@@ -955,6 +966,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 const int e = e0 + 4 * NTHR * u;
                 tmp[u] = e < G::IMG_FLOATS ? *(const f32x4*)&a.image[e] : f32x4{0, 0, 0, 0};
             }
+            if (rec_pending) { fetch_rec(); rec_pending = false; }
 #pragma unroll
             for (int u = 0; u < NIB; ++u) {
                 const int e = e0 + 4 * NTHR * u;
@@ -962,7 +974,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             }
         }
     }
+    if (rec_pending) fetch_rec();
     if (own_direct) {
+        f_g = eh_fold8(f_gs[0], f_gs[1], f_gs[2], f_gs[3], f_gs[4], f_gs[5], f_gs[6], f_gs[7]);
         const int svi = __builtin_bit_cast(int, eh_fold8_lanes(f_sv));
         const float S0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 0)), S1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 8)),
                     S2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 16)), S3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(svi, 24)),
@@ -1198,6 +1212,13 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         for (int f = 0; f < EH_MAX_FORC; ++f) frc[f] = nx.frc[f];
 #pragma unroll
         for (int t = 0; t < EH_MAX_TARG; ++t) yobs[t] = nx.y[t];
+#pragma unroll
+        for (int q = 0; q < NX4; ++q) {
+            // (all four components of a fetched quad stay allocated up to here, used or not: the register allocator hands the unused ones of a
+            //  16-byte load to the very next address computation, and a write to the destination of a load in flight waits for the load --
+            //  in the step's prologue that put the record's whole round trip in front of the state loads behind it)
+            asm volatile("" ::"v"(nx.x[q][0]), "v"(nx.x[q][1]), "v"(nx.x[q][2]), "v"(nx.x[q][3]));
+        }
 #pragma unroll
         for (int q = 0; q < NX4; ++q)
 #pragma unroll
