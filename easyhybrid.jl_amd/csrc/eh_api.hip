@@ -805,6 +805,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->mombuf); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->l2w); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
+    if (h->eval_host) (void)hipHostFree(h->eval_host);
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->l_lprog); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
@@ -1955,10 +1956,33 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     a.yld = count;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     int grid = count > 0 ? (h->lform ? grid_for(h, count) : eval_grid_for(h, count)) : 1;
+    // The per-workgroup sums (grid x 8 T floats) go to the host for the final fold in double.  The step kernels store them straight into
+    // pinned, device-visible host memory -- the call is the kernel and one synchronisation; as a copy out of the slab into pageable
+    // memory behind the kernel it was a staged transfer of its own, 25-30 us of a 105 us call over the headline split.
+    const float* part = nullptr;
+    std::vector<float> part_copy;
+    static const bool no_zero_copy = getenv("EH_EVAL_COPY") != nullptr;      // (A/B switch of the measurement tools)
+    if (!h->lform && !no_zero_copy) {
+        const size_t need_host = (size_t)grid * a.n_acc;
+        if (need_host > h->eval_host_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->eval_host) (void)hipHostFree(h->eval_host);
+            h->eval_host = nullptr; h->eval_host_dev = nullptr; h->eval_host_cap = 0;
+            const size_t cap = std::max<size_t>(need_host, (size_t)4096 * EH_EVAL_STATS * EH_MAX_TARG);
+            HIPCHK(h, hipHostMalloc((void**)&h->eval_host, cap * sizeof(float), hipHostMallocMapped));
+            HIPCHK(h, hipHostGetDevicePointer((void**)&h->eval_host_dev, h->eval_host, 0));
+            h->eval_host_cap = cap;
+        }
+        a.slab = h->eval_host_dev;
+        part = h->eval_host;
+    }
     if (h->lform) { if ((rc = lform_eval(h, sp, first, count, a.yhat, a.pout, &grid))) return rc; }
     else HIPCHK(h, step_launch(h, EH_MODE_EVAL, grid, &a));
-    std::vector<float> part((size_t)grid * a.n_acc);
-    HIPCHK(h, hipMemcpyAsync(part.data(), h->slab, part.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (!part) {
+        part_copy.resize((size_t)grid * a.n_acc);
+        HIPCHK(h, hipMemcpyAsync(part_copy.data(), h->slab, part_copy.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        part = part_copy.data();
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (stats) {
         for (int k = 0; k < a.n_acc; ++k) {

@@ -1108,6 +1108,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             if (a.inv_n) { inv = 1.0f; lossv = f_sse; }      // multi-target: per-target weights from the counting pre-pass, the sums are final
             else eh_loss_finish(net.loss, f_sse, f_cnt, f_sy, f_syy, inv, lossv, z.agg_a);
         }
+        // (which workgroup stores an element: its index modulo the largest power of two within the grid -- a mask; the remainder by the grid
+        //  size itself was a 32-bit division in every thread of every workgroup)
+        const unsigned gmask = (1u << (31 - __builtin_clz(gridDim.x))) - 1u;
         for (int idx = tid; idx < nth; idx += NTHR) {
             float th, mm, vv, gs = 0.0f;
             int mp;
@@ -1139,7 +1142,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                 }
             }
             if (upd) eh_opt_update(z.opt, gs * inv, f_bt1, f_bt2, th, mm, vv);
-            if ((unsigned)idx % gridDim.x == blockIdx.x) { pout[idx] = th; pout[nth + idx] = mm; pout[2 * nth + idx] = vv; }   // every workgroup holds the same values: spread the stores
+            if (((unsigned)idx & gmask) == blockIdx.x) { pout[idx] = th; pout[nth + idx] = mm; pout[2 * nth + idx] = vv; }   // every workgroup holds the same values: spread the stores
             if (idx < net.g_off) {
                 wl[mp] = th;
             } else {

@@ -176,6 +176,9 @@ struct eh_handle_s {
     int mech_tiles = 0;             // "mech_tiles" option: consecutive 256 V-sample tiles per workgroup (0: by model -- 2, multi-output models 8)
     // scratch for forward / eval outputs
     float* out_buf = nullptr;
+    float* eval_host = nullptr;          // pinned, device-visible: the evaluation kernels store their per-workgroup sums straight into it
+    float* eval_host_dev = nullptr;
+    size_t eval_host_cap = 0;            // floats
     long long out_cap = 0;
     int* idx_buf = nullptr;
     long long idx_cap = 0;
