@@ -220,6 +220,21 @@ static bool arch_fits(const EhArchInfo* A, int need) {
     return true;
 }
 
+namespace {
+struct EvalHostBuf { float* host; float* dev; size_t cap; int device; };
+std::mutex g_eval_pool_mu;
+std::vector<EvalHostBuf> g_eval_pool;
+}
+// (see eval_host_acquire)
+static void eval_host_release(eh_handle* h) {
+    if (!h->eval_host) return;
+    {
+        std::lock_guard<std::mutex> lk(g_eval_pool_mu);
+        if (g_eval_pool.size() < 8) { g_eval_pool.push_back({h->eval_host, h->eval_host_dev, h->eval_host_cap, h->device}); h->eval_host = nullptr; }
+    }
+    if (h->eval_host) (void)hipHostFree(h->eval_host);
+    h->eval_host = nullptr; h->eval_host_dev = nullptr; h->eval_host_cap = 0;
+}
 // Launches the step kernel of the handle's (family, variant).  A recorded closure, or any model with the "specialize" option,
 // runs a kernel compiled at run time (eh_jit.hpp; built on first use, one per descriptor state; a failed build or launch
 // switches the handle to the kernels built ahead of time for good); everything else runs the table entry.
@@ -805,7 +820,7 @@ int32_t eh_destroy(eh_handle* h) {
     (void)hipFree(h->pset);
     (void)hipFree(h->gacc); (void)hipFree(h->bn_part); (void)hipFree(h->bn_run); (void)hipFree(h->bn_shift); (void)hipFree(h->bn_stat); (void)hipFree(h->tcount); (void)hipFree(h->mombuf); (void)hipFree(h->slab); (void)hipFree(h->gradbuf); (void)hipFree(h->inv_n);
     (void)hipFree(h->prog); (void)hipFree(h->l2val); (void)hipFree(h->l2w); (void)hipFree(h->loss_hist); (void)hipFree(h->perm); (void)hipFree(h->out_buf); (void)hipFree(h->idx_buf);
-    if (h->eval_host) (void)hipHostFree(h->eval_host);
+    eval_host_release(h);
     (void)hipFree(h->mech_ws); (void)hipFree(h->l_ws); (void)hipFree(h->l_split); (void)hipFree(h->l_dk); (void)hipFree(h->l_lprog); (void)hipFree(h->wflag);
     (void)hipFree(h->stamps); (void)hipFree(h->image); (void)hipFree(h->imap); (void)hipFree(h->rmap);
     (void)hipFree(h->split[0].recs); (void)hipFree(h->split[1].recs);
@@ -1932,6 +1947,24 @@ static int stage_host_idx(eh_handle* h, const EhSplit& sp, const int32_t* idx, i
 }
 
 // forward / eval on a window; stats (host, double) per target may be null
+// The pinned buffers the evaluation kernels store their sums into outlive their handles in a small pool: pinning host memory costs
+// some hundred microseconds, and train() creates (and closes) an engine per call -- 10 ms in all for the tutorial's 20 epochs.
+static int eval_host_acquire(eh_handle* h, size_t need) {
+    {
+        std::lock_guard<std::mutex> lk(g_eval_pool_mu);
+        for (size_t i = 0; i < g_eval_pool.size(); ++i)
+            if (g_eval_pool[i].device == h->device && g_eval_pool[i].cap >= need) {
+                h->eval_host = g_eval_pool[i].host; h->eval_host_dev = g_eval_pool[i].dev; h->eval_host_cap = g_eval_pool[i].cap;
+                g_eval_pool.erase(g_eval_pool.begin() + (long)i);
+                return EH_OK;
+            }
+    }
+    const size_t cap = std::max<size_t>(need, (size_t)4096 * EH_EVAL_STATS * EH_MAX_TARG);
+    HIPCHK(h, hipHostMalloc((void**)&h->eval_host, cap * sizeof(float), hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->eval_host_dev, h->eval_host, 0));
+    h->eval_host_cap = cap;
+    return EH_OK;
+}
 static int do_eval(eh_handle* h, int split, long long first, long long count, double* stats, float* const* yhat, float* const* params) {
     const EhNet& net = h->net;
     EhSplit& sp = h->split[split];
@@ -1966,12 +1999,8 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
         const size_t need_host = (size_t)grid * a.n_acc;
         if (need_host > h->eval_host_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (h->eval_host) (void)hipHostFree(h->eval_host);
-            h->eval_host = nullptr; h->eval_host_dev = nullptr; h->eval_host_cap = 0;
-            const size_t cap = std::max<size_t>(need_host, (size_t)4096 * EH_EVAL_STATS * EH_MAX_TARG);
-            HIPCHK(h, hipHostMalloc((void**)&h->eval_host, cap * sizeof(float), hipHostMallocMapped));
-            HIPCHK(h, hipHostGetDevicePointer((void**)&h->eval_host_dev, h->eval_host, 0));
-            h->eval_host_cap = cap;
+            eval_host_release(h);
+            if (int rc2 = eval_host_acquire(h, need_host)) return rc2;
         }
         a.slab = h->eval_host_dev;
         part = h->eval_host;

@@ -885,6 +885,9 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // full memory round trip, between the last barrier and the LDS reads)
     int f_rcode = 0;
     if constexpr (TRAIN) f_rcode = (a.rmap && tid < a.n_acc) ? a.rmap[tid] : 0;
+    // (the running statistics of the input BatchNorm, which the workgroup that updates them would otherwise read where it needs them)
+    float f_rm = 0.0f, f_rv = 0.0f;
+    if ((a.bn_part || a.bn_nblk == -1) && a.bn_update && blockIdx.x == 0 && tid < net.P) { f_rm = a.bn_run[tid]; f_rv = a.bn_run[32 + tid]; }
     // (ms_direct && ms_keep: a later step of a multi-step launch -- the step before it has applied its own update and written the new
     //  parameters into the LDS image: nothing deferred to pick up here)
     const bool deferred_upd = fusedm && !(a.ms_direct && a.ms_keep);
@@ -1043,7 +1046,41 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     const bool bn_self = a.bn_nblk == -1;
     static_assert((NTHR / 32 + 1) * 64 <= NW * G::WAVE_WS, "the statistics scratch fits the waves' work space");
     float* const bn_red = smem + G::IMG_FLOATS;                  // [NTHR / 32][64], in the (not yet cleared) X images
-    if (bn_self) {
+    // One workgroup covering the whole minibatch (the multi-step launches; any single launch of at most 16 NT NW samples): its waves HOLD
+    // the minibatch -- one record per lane, fetched above for the forward pass.  Every wave sums its own lanes about its first sample's
+    // value on the DPP network, {centre, sum, sum of squares, count} per wave and predictor go through LDS, and thread p merges the
+    // waves' sums about wave 0's centre (the pairwise update of a variance: S2 = sum_w [s2_w + 2 (c_w - c) s1_w + n_w (c_w - c)^2]).
+    // The gather below reads the minibatch a second time through the permutation -- index, then record, then the centre's own pair:
+    // dependent round trips that were 1.6 us of a 6.1 us step of the tutorial's model.
+    const bool bn_regs = bn_self && gridDim.x == 1 && ntiles <= NW;
+    static_assert(NW * G::IP * 4 <= NW * G::WAVE_WS, "the per-wave statistics fit the waves' work space");
+    float bn_s1r = 0.0f, bn_s2r = 0.0f, bn_c0 = 0.0f;
+    if (bn_regs) {
+        const float n_w = (float)__popcll(__ballot(nx_live));
+#pragma unroll
+        for (int q = 0; q < NX4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < net.P) {
+                    const float xv = nx.x[q][e];
+                    const float cw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), 0));      // (live lanes are a prefix)
+                    const float d = nx_live ? xv - cw : 0.0f;
+                    const float s1 = eh_wave_sum(d), s2 = eh_wave_sum(d * d);
+                    if (lane == 0) *(f32x4*)&bn_red[(wave * G::IP + 4 * q + e) * 4] = f32x4{cw, s1, s2, n_w};
+                }
+        __syncthreads();
+        if (tid < net.P) {
+            const float c = bn_red[tid * 4];
+            for (int w = 0; w < NW; ++w) {
+                const f32x4 t = *(const f32x4*)&bn_red[(w * G::IP + tid) * 4];
+                const float dc = t[0] - c;
+                bn_s1r += t[1] + t[3] * dc;
+                bn_s2r += t[2] + 2.0f * dc * t[1] + t[3] * dc * dc;
+            }
+            bn_c0 = c;
+        }
+        __syncthreads();                                         // (the table sits where the X images are about to be cleared)
+    } else if (bn_self) {
         const int p = tid & 31, grp = tid >> 5;
         float s1 = 0.0f, s2 = 0.0f;
         if (p < net.P) {
@@ -1065,8 +1102,8 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         }
         __syncthreads();
     }
-    float bn_s1 = 0.0f, bn_s2 = 0.0f;
-    if (bn_self) {          // (uniform; the barrier only where the scratch is in use: the headline step has no BatchNorm and no barrier to spare)
+    float bn_s1 = bn_s1r, bn_s2 = bn_s2r;
+    if (bn_self && !bn_regs) {          // (uniform; the barrier only where the scratch is in use: the headline step has no BatchNorm and no barrier to spare)
         if (tid < net.P) { bn_s1 = bn_red[(NTHR / 32) * 64 + tid]; bn_s2 = bn_red[(NTHR / 32) * 64 + 32 + tid]; }
         __syncthreads();
     }
@@ -1078,13 +1115,13 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             float s1 = bn_s1, s2 = bn_s2;
             if (!bn_self) for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
             const float m = a.bn_n ? *a.bn_n : (float)count;
-            const float c0 = bn_self ? a.recs[(a.idx ? (long long)a.idx[a.first] : a.first) * a.C + tid] : a.bn_c[tid];
+            const float c0 = bn_regs ? bn_c0 : bn_self ? a.recs[(a.idx ? (long long)a.idx[a.first] : a.first) * a.C + tid] : a.bn_c[tid];
             const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
             wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
             wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);
             if (a.bn_update && blockIdx.x == 0) {
-                const float rm = (1.0f - EH_BN_MOMENTUM) * a.bn_run[tid] + EH_BN_MOMENTUM * mu;
-                const float rv = (1.0f - EH_BN_MOMENTUM) * a.bn_run[32 + tid] + EH_BN_MOMENTUM * (m > 1.0f ? m / (m - 1.0f) : 1.0f) * var;
+                const float rm = (1.0f - EH_BN_MOMENTUM) * f_rm + EH_BN_MOMENTUM * mu;
+                const float rv = (1.0f - EH_BN_MOMENTUM) * f_rv + EH_BN_MOMENTUM * (m > 1.0f ? m / (m - 1.0f) : 1.0f) * var;
                 a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
                 a.image_out[G::PHI_OFF + EH_IMG_BNM + tid] = rm;                       // what forward / eval (test mode) will use
                 a.image_out[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);

@@ -1,11 +1,13 @@
 """Diagnostic: phase stamps of the LAST step of a multi-step launch (EH_MODE_TRAIN_MULTI) at batch 64:
-   EH_JIT_DEFINES="EH_STAMPS" EH_SPECIALIZE=1 EH_JIT_CACHE=0 EH_NO_AOT_SPEC=1 python tools/stamps_multistep.py"""
+   EH_JIT_DEFINES="EH_STAMPS" EH_SPECIALIZE=1 EH_JIT_CACHE=0 EH_NO_AOT_SPEC=1 python tools/stamps_multistep.py
+   EH_TOOL_BN=1: the tutorial's model (input BatchNorm + sigmoid) instead of plain tanh"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import easyhybrid_jl_amd as eh
 from easyhybrid_jl_amd.synthetic import RBQ10_PARAMS, make_synth_rbq10
-model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"], hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"], hidden_layers=[16, 16], activation="sigmoid" if os.environ.get("EH_TOOL_BN") else "tanh",
+                                scale_nn_outputs=True, input_batchnorm=bool(os.environ.get("EH_TOOL_BN")))
 cols = make_synth_rbq10(4000, seed=1)
 X = np.stack([cols["sw_pot"], cols["dsw_pot"]]).astype(np.float32)
 eng = model.engine(0)
