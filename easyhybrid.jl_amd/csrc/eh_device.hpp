@@ -187,6 +187,7 @@ struct EhStepArgs {
     int ms_direct;          // set by the multi-step kernel: ONE workgroup, so the step that produced the gradient applies the optimiser itself (see eh_ms_apply)
     long long ms_end;
     float* ms_loss;
+    long long pf_first, pf_count;     // set by the multi-step kernel: the NEXT step's window (pf_count == 0: none) -- its records are fetched behind this step's compute
 };
 enum { EH_LPROG_WORDS = 24 + EH_MAX_PROG };
 
@@ -754,6 +755,12 @@ __device__ __forceinline__ void eh_ms_apply(const NET& net, const EhStepArgs& a,
     }
 }
 
+// one sample record per lane as the step body holds it between the fetch and the forward pass; EhCarry hands the NEXT step's records
+// from one step of a multi-step launch to the following one
+template <int NX4>
+struct EhRec { f32x4 x[NX4]; float frc[EH_MAX_FORC]; float y[EH_MAX_TARG]; };
+template <int NX4>
+struct EhCarry { EhRec<NX4> rec; bool live; bool valid; };
 // (the exchange's scalar sums on their way from the eight threads that fetch them to everybody; static LDS only in the instantiations that exchange)
 template <bool ON>
 __device__ __forceinline__ float* eh_px_table() {
@@ -761,7 +768,7 @@ __device__ __forceinline__ float* eh_px_table() {
     else return nullptr;
 }
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
-__device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepArgs& a) {
+__device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepArgs& a, EhCarry<(EhGeom<NBI, NBH, NL, NT, NW>::IP + 3) / 4>* carry = nullptr) {
     // Run-time compiled kernels (eh_jit.hip) know the model: the descriptor is a compile-time constant there and the generality
     // below -- per-parameter kinds, per-target switches, the mechanistic switch -- folds away.
 #ifdef EH_SPEC_NET
@@ -838,7 +845,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
 
     // one sample record per lane, fetched one macro-tile ahead of its use
     constexpr int NX4 = (G::IP + 3) / 4;
-    struct { f32x4 x[NX4]; float frc[EH_MAX_FORC]; float y[EH_MAX_TARG]; } nx;
+    EhRec<NX4> nx;
     const int count = (int)a.count, first = (int)a.first;     // N <= 2^31 - 1 (checked by eh_set_data)
     const int ntiles = (count + MT - 1) / MT;
     // (in two halves: a gathered minibatch reads its record THROUGH the epoch's permutation -- a dependent pair of loads.  The step's first
@@ -852,27 +859,37 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         nx_live = (tile < ntiles) && (lane < MT) && (n_loc < count);
         nx_glb = nx_live ? (a.idx ? a.idx[first + n_loc] : first + n_loc) : 0;
     };
-    auto fetch_rec = [&]() {
+    auto fetch_rec_into = [&](EhRec<NX4>& dst) {
         const bool live = nx_live;
         const float* const rec = a.recs + (long long)nx_glb * a.C;
         if ((a.C & 3) == 0) {          // 16-byte-multiple records (RbQ10: exactly one dwordx4 per sample)
 #pragma unroll
-            for (int q = 0; q < NX4; ++q) nx.x[q] = (live && 4 * q < net.P) ? *(const f32x4*)(rec + 4 * q) : f32x4{0, 0, 0, 0};
+            for (int q = 0; q < NX4; ++q) dst.x[q] = (live && 4 * q < net.P) ? *(const f32x4*)(rec + 4 * q) : f32x4{0, 0, 0, 0};
         } else {
 #pragma unroll
             for (int q = 0; q < NX4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) nx.x[q][e] = (live && 4 * q + e < net.P) ? rec[4 * q + e] : 0.0f;
+                for (int e = 0; e < 4; ++e) dst.x[q][e] = (live && 4 * q + e < net.P) ? rec[4 * q + e] : 0.0f;
         }
 #pragma unroll
-        for (int f = 0; f < EH_MAX_FORC; ++f) nx.frc[f] = (fCol[f] >= 0 && live) ? rec[fCol[f]] : 0.0f;
+        for (int f = 0; f < EH_MAX_FORC; ++f) dst.frc[f] = (fCol[f] >= 0 && live) ? rec[fCol[f]] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < EH_MAX_TARG; ++t) nx.y[t] = (tOn[t] != 0.0f && live) ? rec[tcol0 + t] : __builtin_nanf("");
+        for (int t = 0; t < EH_MAX_TARG; ++t) dst.y[t] = (tOn[t] != 0.0f && live) ? rec[tcol0 + t] : __builtin_nanf("");
     };
+    auto fetch_rec = [&]() { fetch_rec_into(nx); };
     auto fetch = [&](int tile) { fetch_idx(tile); fetch_rec(); };
-    fetch_idx((int)blockIdx.x * NW + wave);
-    bool rec_pending = a.idx != nullptr;
-    if (!rec_pending) fetch_rec();               // contiguous minibatch: nothing to wait for
+    // (a later step of a multi-step launch: the step before it fetched this step's records behind its own compute -- a gathered record is a
+    //  dependent pair of loads, index then record, and with nothing else to hide behind in a step whose image is already in LDS the pair
+    //  was 0.5 us at the head of a 4.5 us step)
+    const bool carried = carry && carry->valid;
+    bool rec_pending = false;
+    if (carried) { nx = carry->rec; nx_live = carry->live; }
+    else {
+        fetch_idx((int)blockIdx.x * NW + wave);
+        rec_pending = a.idx != nullptr;
+        if (!rec_pending) fetch_rec();               // contiguous minibatch: nothing to wait for
+    }
+    bool pf_issued = false;
 
     EH_STAMP(0);
     // ---- stage the parameter image into LDS (straight copy) ------------------------------------
@@ -1053,8 +1070,22 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // The gather below reads the minibatch a second time through the permutation -- index, then record, then the centre's own pair:
     // dependent round trips that were 1.6 us of a 6.1 us step of the tutorial's model.
     const bool bn_regs = bn_self && gridDim.x == 1 && ntiles <= NW;
+    // thread p < P: sums of (x - c0), (x - c0)^2 over the minibatch -> mean and 1 / std into the LDS image, the running statistics updated
+    auto bn_to_image = [&](float s1, float s2, float c0) {
+        const float m = a.bn_n ? *a.bn_n : (float)count;
+        const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
+        wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
+        wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);
+        if (a.bn_update && blockIdx.x == 0) {
+            const float rm = (1.0f - EH_BN_MOMENTUM) * f_rm + EH_BN_MOMENTUM * mu;
+            const float rv = (1.0f - EH_BN_MOMENTUM) * f_rv + EH_BN_MOMENTUM * (m > 1.0f ? m / (m - 1.0f) : 1.0f) * var;
+            a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
+            a.image_out[G::PHI_OFF + EH_IMG_BNM + tid] = rm;                       // what forward / eval (test mode) will use
+            a.image_out[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
+        }
+    };
     static_assert(NW * G::IP * 4 <= NW * G::WAVE_WS, "the per-wave statistics fit the waves' work space");
-    float bn_s1r = 0.0f, bn_s2r = 0.0f, bn_c0 = 0.0f;
+    float bn_s1r = 0.0f, bn_s2r = 0.0f;
     if (bn_regs) {
         const float n_w = (float)__popcll(__ballot(nx_live));
 #pragma unroll
@@ -1068,17 +1099,20 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
                     const float s1 = eh_wave_sum(d), s2 = eh_wave_sum(d * d);
                     if (lane == 0) *(f32x4*)&bn_red[(wave * G::IP + 4 * q + e) * 4] = f32x4{cw, s1, s2, n_w};
                 }
+        EH_STAMP_PRO(11);
         __syncthreads();
         if (tid < net.P) {
             const float c = bn_red[tid * 4];
-            for (int w = 0; w < NW; ++w) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {       // (unrolled: the eight reads go out together -- one after the other they were a chain of LDS round trips)
                 const f32x4 t = *(const f32x4*)&bn_red[(w * G::IP + tid) * 4];
                 const float dc = t[0] - c;
                 bn_s1r += t[1] + t[3] * dc;
                 bn_s2r += t[2] + 2.0f * dc * t[1] + t[3] * dc * dc;
             }
-            bn_c0 = c;
+            bn_to_image(bn_s1r, bn_s2r, c);      // (here, in front of the barrier the table needs anyway: a block and a barrier of its own further down otherwise)
         }
+        EH_STAMP_PRO(12);
         __syncthreads();                                         // (the table sits where the X images are about to be cleared)
     } else if (bn_self) {
         const int p = tid & 31, grp = tid >> 5;
@@ -1109,23 +1143,14 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     }
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
     __syncthreads();
-    if (a.bn_part || bn_self) {
+    EH_STAMP_PRO(13);
+    if ((a.bn_part || bn_self) && !bn_regs) {
         // input BatchNorm, train mode (Lux BatchNorm, affine = false): statistics of THIS minibatch
         if (tid < net.P) {
             float s1 = bn_s1, s2 = bn_s2;
             if (!bn_self) for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
-            const float m = a.bn_n ? *a.bn_n : (float)count;
-            const float c0 = bn_regs ? bn_c0 : bn_self ? a.recs[(a.idx ? (long long)a.idx[a.first] : a.first) * a.C + tid] : a.bn_c[tid];
-            const float d = s1 / m, var = fmaxf(s2 / m - d * d, 0.0f), mu = c0 + d;
-            wl[G::PHI_OFF + EH_IMG_BNM + tid] = mu;
-            wl[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(var + EH_BN_EPS);
-            if (a.bn_update && blockIdx.x == 0) {
-                const float rm = (1.0f - EH_BN_MOMENTUM) * f_rm + EH_BN_MOMENTUM * mu;
-                const float rv = (1.0f - EH_BN_MOMENTUM) * f_rv + EH_BN_MOMENTUM * (m > 1.0f ? m / (m - 1.0f) : 1.0f) * var;
-                a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
-                a.image_out[G::PHI_OFF + EH_IMG_BNM + tid] = rm;                       // what forward / eval (test mode) will use
-                a.image_out[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
-            }
+            const float c0 = bn_self ? a.recs[(a.idx ? (long long)a.idx[a.first] : a.first) * a.C + tid] : a.bn_c[tid];
+            bn_to_image(s1, s2, c0);
         }
         __syncthreads();
     }
@@ -1265,7 +1290,17 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             for (int e = 0; e < 4; ++e)
                 if (4 * q + e < net.P && lane < MT)      // (x - mean) / std of the input BatchNorm; mean 0, 1/std 1 without it
                     XS[(4 * q + e) * SR + lane] = (nx.x[q][e] - meta[EH_IMG_BNM + 4 * q + e]) * meta[EH_IMG_BNR + 4 * q + e];
-        fetch(tile + (int)gridDim.x * NW);   // next tile's record: in flight behind this tile's compute
+        {
+            const int tnext = tile + (int)gridDim.x * NW;
+            if (carry && tnext >= ntiles) {      // (multi-step launch, this wave's last tile of the step: the index of its sample in the NEXT step's window)
+                if (a.pf_count > 0) {
+                    const int n_nxt = ((int)blockIdx.x * NW + wave) * MT + lane;
+                    nx_live = (lane < MT) && (n_nxt < (int)a.pf_count);
+                    nx_glb = nx_live ? (a.idx ? a.idx[(int)a.pf_first + n_nxt] : (int)a.pf_first + n_nxt) : 0;
+                    pf_issued = true;
+                }
+            } else fetch(tnext);             // next tile's record: in flight behind this tile's compute
+        }
         EH_WAVE_SYNC();
 
         EH_STAMP_FINE(3);
@@ -1719,6 +1754,14 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         EH_WAVE_SYNC();
     }
 
+    // (multi-step launch: the next step's records, straight into what the launch carries from step to step -- their indices were asked for
+    //  when this step's records were consumed and have long arrived; the records have the reduction and the update to arrive behind)
+    if (carry) {
+        carry->valid = a.pf_count > 0;
+        if (pf_issued) fetch_rec_into(carry->rec);
+        else if (carry->valid) carry->rec = nx;                  // (a wave without a sample in this step has none in the next: its zeros)
+        carry->live = nx_live;
+    }
     EH_STAMP(8);
 #ifdef EH_DBG_LACC
     if (a.stamps && blockIdx.x == 0 && lane < 2) reinterpret_cast<float*>(a.stamps)[wave * 2 + lane] = lacc;      // diagnostics: lanes 0 / 1 of every wave, before the wave sums
@@ -2025,11 +2068,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
         for (int i = threadIdx.x; i < ng; i += NTHR) l_gacc[i] = a.fz.gacc[i];
         for (int i = threadIdx.x; i < g_off; i += NTHR) l_imap[i] = a.fz.imap[i];
         __syncthreads();
+        EhCarry<(G::IP + 3) / 4> carry;
+        carry.valid = false; carry.live = false;
         for (int k = 0; k < a.ms_nsteps; ++k) {
             EhStepArgs b = a;
             b.first = a.first + (long long)k * a.ms_batch;
             const long long left = a.ms_end - b.first;
             b.count = left < (long long)a.ms_batch ? left : (long long)a.ms_batch;
+            b.pf_first = b.first + a.ms_batch;
+            b.pf_count = k + 1 < a.ms_nsteps ? (left - a.ms_batch < (long long)a.ms_batch ? left - a.ms_batch : (long long)a.ms_batch) : 0;
+            if (b.pf_count < 0) b.pf_count = 0;
             b.fz.pset = l_pset; b.fz.gacc = l_gacc; b.fz.imap = l_imap;
             // every step applies its own update in its epilogue (eh_ms_apply): only step 0's prologue has something deferred to pick up (what was
             // pending before the launch) and flips the parameter set; the accumulator slot is used as a plain array and left zero
@@ -2041,7 +2089,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const Eh
             b.ms_loss = a.ms_loss ? a.ms_loss + k : nullptr;
             b.ms_keep = k > 0;
             b.ms_direct = 1;
-            eh_step_body<NBI, NBH, NL, NT, NW, ACT, EH_MODE_TRAIN, FAST>(net, b);
+            eh_step_body<NBI, NBH, NL, NT, NW, ACT, EH_MODE_TRAIN, FAST>(net, b, &carry);
             __syncthreads();
         }
         for (int i = threadIdx.x; i < a.n_acc; i += NTHR) l_gacc[(a.fz.gslot * EH_GSHARDS) * a.n_acc + i] = 0.0f;      // (the steps used shard 0 of this slot as a plain array)
