@@ -18,6 +18,8 @@ C5="python3 $ROOT/tools/bench_config.py c5"
 SQ1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM"
 SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 SQ3="SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
+PART=${PART:-all}      # PART=1: traces and counters, PART=2: the un-profiled lines, stamps, primitives, soak (a gpurun call is 20 minutes at most)
+if [ "$PART" != "2" ]; then
 # headline
 prof bench python3 $ROOT/bench.py --steps 2000 --warmup 200 $B
 pmc bench_fetch FETCH_SIZE python3 $ROOT/bench.py --steps 200 --warmup 20 $B
@@ -45,7 +47,9 @@ done
 # what a user runs: eh.train end to end; epochs of one-workgroup minibatches as single and as multi-step launches
 prof train_e2e python3 $ROOT/tools/bench_train_e2e.py
 prof multistep python3 $ROOT/tools/multistep_probe.py
+fi
 cd $ROOT
+if [ "$PART" != "1" ]; then
 timeout -k 10 400 python3 bench.py --steps 3000 --warmup 300 > $OUT/bench_3000steps.json 2> $OUT/bench_3000.err; echo "progress: bench line"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 $B > $OUT/bench_driver_sized_20steps.json 2>/dev/null
 {
@@ -58,11 +62,19 @@ timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 $B > $OUT/bench_driver_
   timeout -k 10 300 python3 tools/bench_config.py c1 --steps 2000
 } > $OUT/bench_config_all.jsonl 2> $OUT/bench_config_all.err; echo "progress: configs"
 timeout -k 10 300 python3 tools/multistep_probe.py > $OUT/multistep_probe.txt 2>&1
-EH_JIT_DEFINES="EH_STAMPS EH_STAMPS_FINE" EH_SPECIALIZE=1 EH_JIT_CACHE=0 EH_NO_AOT_SPEC=1 timeout -k 10 200 python3 tools/stamps_multistep.py > $OUT/stamps_multistep.txt 2>&1
 for p in 2; do EH_NO_AOT_SPEC=1 EH_SPECIALIZE=1 EH_JIT_DEFINES=EH_STAMPS EH_PRECISION=$p timeout -k 10 200 python3 tools/stamps_bfs.py 65536; done > $OUT/stamps_c5_bf16.txt 2>&1
 timeout -k 10 300 python3 tools/dp_primitives.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $OUT/dp_primitives.txt
 for m in 0 1; do EH_TOOL_P2P_MODE=$m timeout -k 10 300 python3 tools/p2p_local_group.py 8; done > $OUT/p2p_local_group_8.txt 2>&1
+EH_JIT_DEFINES="EH_STAMPS EH_STAMPS_PROLOGUE" EH_JIT_CACHE=0 timeout -k 10 300 python3 tools/stamps_p2p.py 2>&1 | grep -v amdgpu.ids > $OUT/stamps_prologue_p2p.txt
+for bn in "" 1; do echo "== input BatchNorm + sigmoid: ${bn:-0}"; EH_TOOL_BN=$bn EH_JIT_DEFINES="EH_STAMPS EH_STAMPS_FINE" EH_SPECIALIZE=1 EH_JIT_CACHE=0 EH_NO_AOT_SPEC=1 timeout -k 10 200 python3 tools/stamps_multistep.py 2>&1 | grep -v amdgpu.ids; done > $OUT/stamps_multistep.txt
+{ echo "== sums stored straight into pinned host memory (default)"; timeout -k 10 300 python3 tools/bench_eval.py --config c2; echo "== EH_EVAL_COPY=1: copied out of the slab behind the kernel (rounds 1-4)"; EH_EVAL_COPY=1 timeout -k 10 300 python3 tools/bench_eval.py --config c2; } > $OUT/eval_zero_copy_ab.txt 2>&1
 echo "progress: primitives"
+for n in 2 4; do
+  EH_DP_P2P_MODE=1 EH_SOAK_STEPS=200000 timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29570 + n)) tools/p2p_two_ranks.py 2>&1 | sed "s/rank /\nrank /g" | grep "^rank "
+  echo "progress: soak $n ranks" >&2
+done > $OUT/p2p_soak_mode1.txt
+fi
+if [ "$PART" != "2" ]; then
 python3 - "$OUT" > $OUT/pmc_summary.txt <<'PY'
 import csv, glob, sys, collections, os
 out = sys.argv[1]
@@ -77,6 +89,7 @@ for d in sorted(glob.glob(out + "/pmc_*")):
     for k, dd in acc.items():
         print(os.path.basename(d), k, {c: (round(sum(v) / len(v), 2), len(v)) for c, v in sorted(dd.items())})
 PY
+fi
 for f in $(find $OUT -name "*kernel_stats.csv"); do cp $f $OUT/$(basename $(dirname $(dirname $f)) | sed s/trace_//)_kernel_stats.csv; done
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*domain_stats.csv" -delete
 find $OUT -name "*.db" -delete; find $OUT -type d -empty -delete

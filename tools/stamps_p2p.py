@@ -26,9 +26,9 @@ for mode in ("plain", "p2p mode 0", "p2p mode 1"):
     if PRO:
         seq = [0, 2, 3, 4, 5, 6, 7, 1]
         lab = ["state loads issued", "exchange words requested", "image staged", "exchange words in, summed over ranks", "statistics + X images cleared", "update applied", "scalars, next shards zeroed, barrier"]
-        if st[11, 0] and st[12, 0] and st[13, 0]:
-            print("   (exchange words in: the wait loop %d cycles, values + table writes + own sum %d, barrier %d, table sum %d)" % (
-                st[11, 0] - st[4, 0], st[12, 0] - st[11, 0], st[13, 0] - st[12, 0], st[5, 0] - st[13, 0]))
+        if mode.startswith("p2p") and st[11, 0] and st[12, 0]:      # (slot 13 belongs to the BatchNorm block's stamps further down)
+            print("   (exchange words in: the wait loop %d cycles, sums over the ranks in registers %d, barrier + the five scalars out of LDS %d)" % (
+                st[11, 0] - st[4, 0], st[12, 0] - st[11, 0], st[5, 0] - st[12, 0]))
         for k in range(len(seq) - 1):
             print(f"   {lab[k]:40s} {st[seq[k+1],0]-st[seq[k],0]:8d} cycles  {(st[seq[k+1],1]-st[seq[k],1])*10:8d} ns", flush=True)
     for i, nme in enumerate(names):
