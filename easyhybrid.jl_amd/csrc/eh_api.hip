@@ -484,11 +484,17 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
     }
     if (d->activation < 0 || d->activation > EH_ACT_PER_NET) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d", d->activation);
     int act = d->activation;
-    if (act == EH_ACT_PER_NET) {             // activation::NamedTuple of the MultiNN constructor (GenericHybridModel.jl:168-176)
-        if (d->n_nets < 1 || d->n_nets > EH_MAX_NETS) return fail(nullptr, EH_EINVAL, "eh_create: per-net activations need the MultiNN form (n_nets = %d)", d->n_nets);
+    if (act == EH_ACT_PER_NET) {
+        // n_nets >= 1: activation::NamedTuple of the MultiNN constructor (GenericHybridModel.jl:168-176), one activation per network;
+        // n_nets == 0: `hidden_layers::Chain` of the single-network constructor (NNModels.jl:145-219: Dense layers that carry activations of
+        // their own), one activation per hidden LAYER.  Both run on kernels compiled at run time around eh_row_act(layer, row).
+        if (d->n_nets < 0 || d->n_nets > EH_MAX_NETS) return fail(nullptr, EH_EINVAL, "eh_create: n_nets = %d (0..%d)", d->n_nets, EH_MAX_NETS);
+        const int na = d->n_nets > 0 ? d->n_nets : d->n_hidden;
+        if (na < 1 || na > EH_MAX_HIDDEN) return fail(nullptr, EH_EINVAL, "eh_create: per-layer activations need 1..%d hidden layers (n_hidden = %d)", EH_MAX_HIDDEN, d->n_hidden);
         bool same = true;
-        for (int k = 0; k < d->n_nets; ++k) {
-            if (d->net_activation[k] < 0 || d->net_activation[k] > EH_ACT_IDENTITY) return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d for net %d", d->net_activation[k], k);
+        for (int k = 0; k < na; ++k) {
+            if (d->net_activation[k] < 0 || d->net_activation[k] > EH_ACT_IDENTITY)
+                return fail(nullptr, EH_EUNSUPPORTED, "eh_create: unknown activation id %d for %s %d", d->net_activation[k], d->n_nets > 0 ? "net" : "hidden layer", k);
             same = same && d->net_activation[k] == d->net_activation[0];
         }
         if (same) act = d->net_activation[0];          // one activation after all: the kernels built ahead of time
@@ -639,6 +645,8 @@ int32_t eh_create(const eh_model_desc* d, eh_handle** out) {
             eh_handle_s::LNet& L = h->l_net[k];
             L.nl = net_d[k] + 1; L.c0 = c0; L.orow = d->n_nets > 0 ? k : 0;
             L.act = (d->n_nets > 0 && d->activation == EH_ACT_PER_NET) ? d->net_activation[k] : (act == EH_ACT_PER_NET ? d->activation : act);
+            for (int l = 0; l <= EH_MAX_HIDDEN; ++l)      // (an activation per hidden layer: the single network of a `hidden_layers::Chain`)
+                L.lact[l] = (d->n_nets == 0 && act == EH_ACT_PER_NET && l < nl) ? d->net_activation[l] : L.act;
             int in = net_P[k];
             for (int l = 0; l < L.nl; ++l) {
                 const int o = l + 1 < L.nl ? net_w[k][l] : net_K[k];
@@ -1344,7 +1352,7 @@ static long long lform_floats_per_sample(const eh_handle* h) {
     long long w = h->net.P + 16, maxw = 0;
     for (int k = 0; k < h->l_nnets; ++k)
         for (int l = 0; l + 1 < h->l_net[k].nl; ++l) {
-            w += h->l_net[k].out[l] * (h->l_net[k].act == EH_ACT_SWISH ? 2 : 1);      // swish keeps the pre-activation too
+            w += h->l_net[k].out[l] * (h->l_net[k].lact[l] == EH_ACT_SWISH ? 2 : 1);      // swish keeps the pre-activation too
             maxw = std::max<long long>(maxw, h->l_net[k].out[l]);
         }
     return w + 2 * maxw;
@@ -1379,7 +1387,7 @@ static int lform_workspace(eh_handle* h, long long count, EhLWs* W) {
             maxw = std::max(maxw, o);
             W->H[k][l] = p; p += cap * o;
             W->Z[k][l] = nullptr;
-            if (h->l_net[k].act == EH_ACT_SWISH) { W->Z[k][l] = p; p += cap * o; }
+            if (h->l_net[k].lact[l] == EH_ACT_SWISH) { W->Z[k][l] = p; p += cap * o; }
         }
     W->D[0] = p; p += cap * maxw;
     W->D[1] = p; p += cap * maxw;
@@ -1494,7 +1502,7 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
         if (!nofuse && !g_gemm_novec && L0.nl >= 2 && L0.in[0] <= 8) {
             EhGemmArgs g{};
             g.A = nullptr; g.lda = net.P; g.B = theta + L0.woff[0]; g.ldb = L0.out[0];
-            g.M = B; g.N = L0.out[0]; g.K = L0.in[0]; g.kchunk = g.K; g.bias = theta + L0.boff[0]; g.act = L0.act;
+            g.M = B; g.N = L0.out[0]; g.K = L0.in[0]; g.kchunk = g.K; g.bias = theta + L0.boff[0]; g.act = L0.lact[0];
             g.C = W.H[0][0]; g.ldc = L0.out[0]; g.Z = W.Z[0][0];
             const long long totc = (long long)g.M * g.N;
             hipLaunchKernelGGL((eh_lform_prep_kernel<true>), dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (std::max(tot, totc) + 255) / 256))), dim3(256), 0, h->stream, pa, g, L0.c0);
@@ -1511,7 +1519,7 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
             g.A = l == 0 ? W.Xb + L.c0 : W.H[k][l - 1]; g.lda = l == 0 ? net.P : L.in[l];      // (a network's predictors: its columns of the minibatch matrix)
             g.B = theta + L.woff[l]; g.ldb = L.out[l];                   // canonical (out, in) column-major == [in][out] row-major
             g.M = B; g.N = L.out[l]; g.K = L.in[l]; g.kchunk = g.K; g.c_zstride = 0;
-            g.bias = theta + L.boff[l]; g.act = L.act;
+            g.bias = theta + L.boff[l]; g.act = L.lact[l];
             if (l + 1 < L.nl) { g.C = W.H[k][l]; g.ldc = L.out[l]; g.Z = W.Z[k][l]; lform_gemm<false, false, EH_GEPI_BIAS_ACT>(h, g, 1); }
             else { g.C = W.O + (long long)L.orow * W.ldo; g.ldc = W.ldo; lform_gemm<false, false, EH_GEPI_BIAS_T>(h, g, 1); }
             HIPCHK(h, hipGetLastError());
@@ -1677,7 +1685,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
                 float* const dnext = grouped ? dkp : W.D[which];
                 if (grouped) dkp += dk_rows * in;
                 b.C = dnext; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
-                b.H = L.act == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.act;
+                b.H = L.lact[l - 1] == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.lact[l - 1];
                 if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
                 HIPCHK(h, hipGetLastError());
                 dZ = dnext; dz_t = false; which ^= 1;

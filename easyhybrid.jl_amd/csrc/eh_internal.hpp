@@ -122,7 +122,7 @@ struct eh_handle_s {
     // layer-wise execution form (eh_lform.hpp): networks no fused kernel holds
     bool lform = false;
     // one entry per network (SingleNN: one; MultiNN: one single-output network per neural parameter, each on its own predictor rows)
-    struct LNet { int nl = 0, c0 = 0, orow = 0, act = 0; int in[EH_MAX_HIDDEN + 1] = {0}, out[EH_MAX_HIDDEN + 1] = {0}, woff[EH_MAX_HIDDEN + 1] = {0}, boff[EH_MAX_HIDDEN + 1] = {0}; };
+    struct LNet { int nl = 0, c0 = 0, orow = 0, act = 0; int lact[EH_MAX_HIDDEN + 1] = {0}; int in[EH_MAX_HIDDEN + 1] = {0}, out[EH_MAX_HIDDEN + 1] = {0}, woff[EH_MAX_HIDDEN + 1] = {0}, boff[EH_MAX_HIDDEN + 1] = {0}; };
     int l_nnets = 0;                                     // 0: no network at all (no neural parameter)
     LNet l_net[EH_MAX_NETS];
     float* l_split = nullptr; size_t l_split_cap = 0;    // split-K partial products of the small-batch GEMMs

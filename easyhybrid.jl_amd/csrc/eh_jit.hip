@@ -293,6 +293,11 @@ static std::string eh_jit_rowact_source(const eh_model_desc& d) {
     for (int l = 0; l < d.n_hidden; ++l) {
         snprintf(b, sizeof b, "    if (l == %d) return", l);
         s += b;
+        if (d.n_nets == 0) {      // one network, an activation per hidden layer (`hidden_layers::Chain`): whatever the row
+            snprintf(b, sizeof b, " %d;\n", d.net_activation[l]);
+            s += b;
+            continue;
+        }
         int r0 = 0;
         for (int k = 0; k < d.n_nets; ++k) {
             r0 += d.net_hidden[k][l];

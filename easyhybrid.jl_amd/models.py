@@ -209,26 +209,33 @@ class Chain:
         self.layers = list(layers)
 
 
-def _hidden_widths(hidden_layers, act: str) -> List[int]:
-    """hidden_layers as the vector of widths the device kernels are built around.  A Chain of Dense layers that all use the model's
-    `activation` IS such a vector -- [first_h, out_1, ..., out_n] (NNModels.jl:205-211) -- and is taken; anything else a Lux Chain may
-    hold (other layer types, an activation per layer) has no kernel and is refused with the reason."""
+def _hidden_widths(hidden_layers, act: str, per_layer: bool = False):
+    """hidden_layers as the vector of widths the device kernels are built around.  A Chain of Dense layers IS such a vector --
+    [first_h, out_1, ..., out_n], the first hidden layer (the one the reference puts in front, Dense(in_dim, first_h, activation)) using
+    the model's `activation` and layer i the one it was written with (NNModels.jl:205-211).  Other layer types have no kernel and are
+    refused with the reason.  per_layer: also return the hidden layers' activations when they are not all the model's (None otherwise);
+    without it such a chain is refused (the MultiNN form: its networks differ by network, not by layer)."""
     if isinstance(hidden_layers, Chain):
         ls = hidden_layers.layers
         if not ls:
             raise ValueError("hidden_layers: an empty Chain has no dimensions (NNModels.jl: 'Could not determine input dimension of hidden_layers Chain.')")
+        acts = [act]
         for i, l in enumerate(ls):
             if not isinstance(l, Dense):
                 raise NotImplementedError(f"hidden_layers Chain: layer {i + 1} is {type(l).__name__}; only Dense layers have a device kernel")
-            if _act_name(l.activation) != act:
-                raise NotImplementedError(f"hidden_layers Chain: layer {i + 1} uses {_act_name(l.activation)!r}, the model {act!r}: the fused kernels "
-                                          "apply ONE activation to all hidden layers of a network (per NETWORK activations exist: activation = {...})")
+            acts.append(_act_name(l.activation))
+            if acts[-1] != act and not per_layer:
+                raise NotImplementedError(f"hidden_layers Chain: layer {i + 1} uses {acts[-1]!r}, the model {act!r}: the networks of a MultiNN model "
+                                          "apply ONE activation to all their hidden layers (per NETWORK activations exist: activation = {...}; "
+                                          "a single network takes an activation per layer)")
             if i and l.in_dims != ls[i - 1].out_dims:
                 raise ValueError(f"hidden_layers Chain: layer {i + 1} takes {l.in_dims} inputs, layer {i} gives {ls[i - 1].out_dims}")
-        return [ls[0].in_dims] + [l.out_dims for l in ls]
+        widths = [ls[0].in_dims] + [l.out_dims for l in ls]
+        return (widths, acts if any(a != act for a in acts) else None) if per_layer else widths
     if not isinstance(hidden_layers, (list, tuple)):
         raise NotImplementedError(f"hidden_layers of type {type(hidden_layers).__name__}: pass the widths or a Chain of Dense layers")
-    return [int(h) for h in hidden_layers]
+    widths = [int(h) for h in hidden_layers]
+    return (widths, None) if per_layer else widths
 
 
 @dataclass
@@ -251,6 +258,7 @@ class SingleNNHybridModel:
     NNs: Optional[Dict[str, List[Tuple[int, int]]]] = None
     predictor_sets: Optional[Dict[str, List[str]]] = None
     net_activations: Optional[List[str]] = None      # MultiNN with activation::NamedTuple: the activation of net k (None = one for all)
+    layer_activations: Optional[List[str]] = None    # single network from `hidden_layers::Chain` whose layers differ: the activation of hidden layer l (None = one for all)
 
     # -- sizes ---------------------------------------------------------------------------------
     @property
@@ -276,7 +284,9 @@ class SingleNNHybridModel:
         """the name, or {network: name} when the networks differ (the reference keeps the NamedTuple in `config`)"""
         return self.config["activation"]
 
-    def activation_of(self, k: int) -> str:
+    def activation_of(self, k: int, layer: Optional[int] = None) -> str:
+        if self.layer_activations is not None and layer is not None:
+            return self.layer_activations[layer]
         return self.config["activation"] if self.net_activations is None else self.net_activations[k]
 
     # -- LuxCore.initialparameters analogue (GenericHybridModel.jl:236-256) ----------------------
@@ -288,7 +298,7 @@ class SingleNNHybridModel:
         parts = []
         for k, net in enumerate(self.nets):
             for li, (o, i) in enumerate(net):
-                gain = _ACT_GAIN[self.activation_of(k)] if li < len(net) - 1 else 1.0
+                gain = _ACT_GAIN[self.activation_of(k, li)] if li < len(net) - 1 else 1.0
                 bw = gain * math.sqrt(3.0 / i)
                 parts.append(rng.uniform(-bw, bw, (o, i)).astype(np.float32).flatten(order="F"))
                 parts.append(rng.uniform(-1 / math.sqrt(i), 1 / math.sqrt(i), o).astype(np.float32))
@@ -376,6 +386,10 @@ class SingleNNHybridModel:
             d.activation = L.EH_ACT_PER_NET
             for k, a in enumerate(self.net_activations):
                 d.net_activation[k] = L.ACTIVATIONS[a]
+        elif self.layer_activations is not None:   # an activation per hidden layer (n_nets = 0): net_activation[l] is layer l's
+            d.activation = L.EH_ACT_PER_NET
+            for l, a in enumerate(self.layer_activations):
+                d.net_activation[l] = L.ACTIVATIONS[a]
         else:
             d.activation = L.ACTIVATIONS[self.activation]
         d.scale_nn_outputs = int(self.scale_nn_outputs)
@@ -536,7 +550,7 @@ def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[s
         if t not in ms.outputs:
             raise ValueError(f"target {t!r} is not an output of {ms.name} {ms.outputs}")
     act = _act_name(activation)
-    hidden_layers = _hidden_widths(hidden_layers, act)
+    hidden_layers, layer_acts = _hidden_widths(hidden_layers, act, per_layer=True)
     dims = [len(predictors)] + hidden_layers + [len(neural_param_names)]
     NN = [] if no_nn else [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
     if no_nn:
@@ -544,5 +558,8 @@ def constructHybridModel(predictors, forcing: Sequence[str], targets: Sequence[s
     fixed = [n for n in all_names if n not in neural_param_names and n not in global_param_names]    # :127
     config = dict(hidden_layers=list(hidden_layers), activation=act, scale_nn_outputs=scale_nn_outputs,
                   input_batchnorm=input_batchnorm, start_from_default=start_from_default, **kwargs)
+    if layer_acts is not None and not no_nn:
+        config["layer_activations"] = list(layer_acts)
     return SingleNNHybridModel(NN, predictors, forcing, targets, ms, parameters, neural_param_names, global_param_names,
-                               fixed, bool(scale_nn_outputs), bool(start_from_default), config)
+                               fixed, bool(scale_nn_outputs), bool(start_from_default), config,
+                               layer_activations=None if no_nn else layer_acts)

@@ -56,8 +56,10 @@ typedef enum eh_status {
 
 /* activation of the hidden Dense layers (src/models/NNModels.jl:225-230; last layer is linear) */
 typedef enum eh_activation { EH_ACT_TANH = 0, EH_ACT_SIGMOID = 1, EH_ACT_RELU = 2, EH_ACT_SWISH = 3, EH_ACT_IDENTITY = 4,
-                             EH_ACT_PER_NET = 5 /* MultiNN only: net k uses net_activation[k] (activation::NamedTuple,
-                                                   GenericHybridModel.jl:168-176); such kernels are compiled at run time */ } eh_activation;
+                             EH_ACT_PER_NET = 5 /* n_nets >= 1: net k uses net_activation[k] (activation::NamedTuple,
+                                                   GenericHybridModel.jl:168-176); n_nets == 0: hidden layer l of the single network uses
+                                                   net_activation[l] (hidden_layers::Chain of Dense layers with activations of their own,
+                                                   src/models/NNModels.jl:145-219); such kernels are compiled at run time */ } eh_activation;
 
 /* registry of mechanistic models (the reference takes an arbitrary Julia closure,
  * src/models/GenericHybridModel.jl:425; a closure cannot run in a kernel, so the engine ships
@@ -154,7 +156,8 @@ typedef struct eh_model_desc {
     int32_t n_nets;
     int32_t net_n_predictors[EH_MAX_NETS];
     int32_t net_hidden[EH_MAX_NETS][EH_MAX_HIDDEN];
-    int32_t net_activation[EH_MAX_NETS];     /* read when activation == EH_ACT_PER_NET: eh_activation of net k (TANH..IDENTITY) */
+    int32_t net_activation[EH_MAX_NETS];     /* read when activation == EH_ACT_PER_NET: eh_activation (TANH..IDENTITY) of net k, or -- n_nets == 0 --
+                                              * of hidden layer l of the single network (EH_MAX_NETS == EH_MAX_HIDDEN) */
     int32_t net_depth[EH_MAX_NETS];          /* hidden layers of net k (hidden_layers::NamedTuple with vectors of different length,
                                               * test/test_generic_hybrid_model.jl:346): 1..n_hidden, 0 = n_hidden; n_hidden is the deepest
                                               * net's.  A shallower net is carried through the remaining layers of the block-diagonal MLP

@@ -365,6 +365,8 @@ class HybridSpec:
     nets: Optional[List[Tuple[List[int], List[int]]]] = None
     # MultiNN with activation::NamedTuple (GenericHybridModel.jl:168-176): the activation of net k; None = `activation` for all
     net_activations: Optional[List[str]] = None
+    # SingleNN built from `hidden_layers::Chain` whose Dense layers carry activations of their own (NNModels.jl:205-211): layer l's; None = `activation`
+    layer_activations: Optional[List[str]] = None
     # "f32": the reference's arithmetic (Float32 end to end, src/data/prepare_data.jl:58-60).
     # "bf16_fwd": BASELINE.json configs[4] "bf16 fwd / fp32 accumulate" (NOT a reference mode; build-defined): every Dense
     # product takes its two operands -- weights and the layer's input (predictors, hidden activations) -- rounded to bfloat16
@@ -383,7 +385,11 @@ class HybridSpec:
     # two-pass losses carry exact per-target weights through the pass and round the normalised delta.
     precision: str = "f32"
 
-    def act_of(self, k: int) -> str:
+    def act_of(self, k: int, layer: Optional[int] = None) -> str:
+        """activation of hidden layer `layer` of net k.  SingleNN with `hidden_layers::Chain` (NNModels.jl:145-219: the reference
+        wraps the user's layers as Dense(in, first_h, activation) -> layers... -> Dense(last_h, out)): every hidden layer its own."""
+        if self.layer_activations is not None and layer is not None:
+            return self.layer_activations[layer]
         return self.activation if self.net_activations is None else self.net_activations[k]
 
     def __post_init__(self):
@@ -547,7 +553,7 @@ def forward(spec: HybridSpec, theta, X, forcings: Dict[str, np.ndarray], dtype=n
         for li, (W, b) in enumerate(Ws):
             z = (W @ h + b[:, None]).astype(dt)
             last = li == len(Ws) - 1
-            h = z if last else act_fwd(spec.act_of(k_net), z).astype(dt)
+            h = z if last else act_fwd(spec.act_of(k_net, li), z).astype(dt)
             if bf and not last:
                 h = round_bf16(h)
             zs.append(z); hs.append(h)
@@ -720,7 +726,7 @@ def _backprop(spec, tp, dout, dt, B, dout_un=None, defer=None):
             #  hands a bfloat16 dZ to both reductions does; round 5: the device forms it as a product with a vector of ones)
             gWs.append(((dq @ hs[li].T) * sc, dq.sum(axis=1) * sc))
             if li > 0:
-                delta = (W.T @ dq) * act_bwd(spec.act_of(k_net), zs[li - 1], hs[li])
+                delta = (W.T @ dq) * act_bwd(spec.act_of(k_net, li - 1), zs[li - 1], hs[li])
         gWs.reverse()
         gnets.append(gWs)
     return pack(spec, gnets, graw, dt)

@@ -109,8 +109,8 @@ def forward(spec: ho.HybridSpec, theta: torch.Tensor, X, forcings):
             off += o
             z = _RoundedGrad.apply(W @ h + b[:, None]) if bfb else W @ h + b[:, None]
             if li == len(dims) - 1: h = z
-            elif bf: h = _RoundedAct.apply(z, spec.act_of(k_net))
-            else: h = _act(spec.act_of(k_net), z)
+            elif bf: h = _RoundedAct.apply(z, spec.act_of(k_net, li))
+            else: h = _act(spec.act_of(k_net, li), z)
         outs.append(h)
     h = torch.cat(outs, dim=0)
     par = {}

@@ -103,10 +103,20 @@ def test_create_rejects_bad_descriptors_before_touching_a_device():
     assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL
     assert lib.eh_create(None, C.byref(h)) == L.EH_EINVAL
     assert lib.eh_destroy(None) == L.EH_OK
-    # per-net activations / depths are MultiNN fields
+    # EH_ACT_PER_NET on a single-network descriptor: net_activation[l] is hidden layer l's (hidden_layers::Chain, NNModels.jl:145-219)
     d = _model().to_desc()
-    d.activation = L.EH_ACT_PER_NET                       # SingleNN descriptor
-    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EINVAL and b"MultiNN" in lib.eh_last_error(None)
+    d.activation = L.EH_ACT_PER_NET
+    d.net_activation[d.n_hidden - 1] = 23
+    assert lib.eh_create(C.byref(d), C.byref(h)) == L.EH_EUNSUPPORTED and b"activation id 23 for hidden layer" in lib.eh_last_error(None)
+    ch = eh.constructHybridModel(["a", "b"], ["ta"], ["reco"], eh.RbQ10, {"rb": (3, 0, 13), "Q10": (2, 1, 4)}, ["rb"], ["Q10"],
+                                 hidden_layers=eh.Chain(eh.Dense(16, 32, "relu"), eh.Dense(32, 8, "sigmoid")), activation="tanh")
+    d = ch.to_desc()
+    assert (d.activation, d.n_nets, d.n_hidden, list(d.hidden[:3]), list(d.net_activation[:3])) == (
+        L.EH_ACT_PER_NET, 0, 3, [16, 32, 8], [L.ACTIVATIONS["tanh"], L.ACTIVATIONS["relu"], L.ACTIVATIONS["sigmoid"]])
+    assert ch.layer_activations == ["tanh", "relu", "sigmoid"] and ch.n_theta == (2 * 16 + 16) + (16 * 32 + 32) + (32 * 8 + 8) + (8 + 1) + 1
+    same = eh.constructHybridModel(["a", "b"], ["ta"], ["reco"], eh.RbQ10, {"rb": (3, 0, 13), "Q10": (2, 1, 4)}, ["rb"], ["Q10"],
+                                   hidden_layers=eh.Chain(eh.Dense(16, 32, "tanh")), activation="tanh")
+    assert same.layer_activations is None and same.to_desc().activation == L.ACTIVATIONS["tanh"]        # one activation after all: the plain descriptor
     mm = eh.constructHybridModel({"rb": ["a"], "Q10": ["b"]}, ["ta"], ["reco"], eh.RbQ10, {"rb": (3, 0, 13), "Q10": (2, 1, 4)}, [],
                                  hidden_layers={"rb": [16], "Q10": [8, 4]}, activation={"rb": "relu", "Q10": "tanh"})
     d = mm.to_desc()

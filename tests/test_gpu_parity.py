@@ -262,6 +262,26 @@ def test_train_front_door_runs_and_improves():
     assert len(out2.train_history) == 1                                        # test_split_data_train.jl:165-166
 
 
+def test_train_front_door_with_a_chain_of_dense_layers():
+    """train() on a model whose hidden layers are given as a Lux-style Chain with activations of their own (NNModels.jl:145-219): the
+    epoch loop on the kernels compiled at run time for it (batch 64: every minibatch is one workgroup's), against the oracle's trajectory
+    on the same shuffled batches via the engine's own epoch call"""
+    cols = eh.synthetic.make_synth_rbq10(3000, seed=4, nan_frac=0.05)
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=eh.Chain(eh.Dense(16, 16, "relu"), eh.Dense(16, 8, "sigmoid")), activation="tanh", scale_nn_outputs=True)
+    assert model.layer_activations == ["tanh", "relu", "sigmoid"]
+    out = eh.train(model, cols, nepochs=5, batchsize=64, opt=eh.Adam(0.01), random_seed=1)
+    assert len(out.val_history) == 6 and out.val_history[-1]["mse"]["sum"] < 0.8 * out.val_history[0]["mse"]["sum"]
+    assert out.ps.size == model.n_theta == (2 * 16 + 16) + (16 * 16 + 16) + (16 * 8 + 8) + (8 + 1) + 1
+    # the trained parameters reproduce the reported validation loss through the oracle's forward with the per-layer activations
+    spec = ho.HybridSpec(2, [16, 16, 8], "rbq10", dict(eh.synthetic.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "tanh", True,
+                         layer_activations=["tanh", "relu", "sigmoid"])
+    yo, yp = out.val_obs_pred["reco"], out.val_obs_pred["reco_pred"]
+    ok = ~np.isnan(yo)
+    assert float(np.mean((yp[ok] - yo[ok]) ** 2)) == pytest.approx(out.best_loss, rel=1e-4)
+    assert spec.n_theta == out.ps.size
+
+
 # ----------------------------------------------------------------------------------------------
 # committed golden fixtures
 # ----------------------------------------------------------------------------------------------
@@ -1010,6 +1030,61 @@ def test_multinn_hybrid_model(nets, glob):
     ref = ho.forward(spec, eng.get_params().astype(np.float64), X, f)
     out = eng.forward(0)
     assert util.relerr(out["reco"], ref["reco"]) <= TOL and util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden,acts,bn", [
+    ([16, 16], ["tanh", "relu"], False),                       # per-wave kernel, the headline's shape
+    ([16, 32, 8], ["tanh", "relu", "sigmoid"], True),          # three layers of different widths, input BatchNorm in front
+    ([24], ["swish"], False),                                  # one hidden layer: the Chain degenerates to the model's activation
+    ([64, 48], ["sigmoid", "swish"], False),                   # 64-wide kernel; swish keeps its pre-activation
+    ([96, 120], ["relu", "tanh"], False),                      # the row-split kernel
+    ([200, 64, 32], ["tanh", "swish", "relu"], False),         # wider than any fused kernel: the layer-wise form
+    ([32, 32, 16, 8], ["sigmoid", "tanh", "identity", "relu"], False),      # four hidden layers: layer-wise
+])
+def test_single_network_with_an_activation_per_layer(hidden, acts, bn):
+    """`hidden_layers::Chain` of Dense layers with activations of their own (NNModels.jl:145-219): the reference puts
+    Dense(in, first_h, activation) in front and Dense(last_h, out) behind them.  The fused kernels that run it are compiled at run
+    time around eh_row_act(layer, row) (descriptor: EH_ACT_PER_NET with n_nets = 0, net_activation[l] = layer l's); the layer-wise
+    form takes the layer's activation per product.  Loss, gradient, forward, metrics and an Adam trajectory against the oracle."""
+    spec = ho.HybridSpec(3, list(hidden), "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], acts[0], True, layer_activations=list(acts))
+    spec.input_batchnorm = bn
+    rng = np.random.default_rng(12)
+    B = 1300
+    X = rng.standard_normal((3, B)).astype(np.float32)
+    f = {"ta": rng.uniform(0, 30, B).astype(np.float32)}
+    yv = rng.uniform(1, 9, B).astype(np.float32); yv[rng.random(B) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 8, np.float32)
+    model = util.model_from_spec(spec)
+    assert model.layer_activations == (list(acts) if len(set(acts)) > 1 else None)
+    eng = util.load_engine(spec, theta, X, f, {"reco": yv})
+    njit, jlog = eng.jit_status()
+    fused = len(hidden) <= 3 and max(hidden) <= 128 and not (len(hidden) == 3 and max(hidden) > 64)
+    if fused and len(set(acts)) > 1:
+        assert njit >= 1, jlog                   # no kernel built ahead of time can run this model
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, {"reco": yv})
+    assert nv == sum(nv0) and loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL
+    if not bn:                                   # (with BatchNorm the forward of a fresh engine is in test mode on initial running statistics)
+        ref = ho.forward(spec, theta.astype(np.float64), X, f)
+        out = eng.forward(0)
+        assert util.relerr(out["reco"], ref["reco"]) <= TOL and util.relerr(out["parameters"]["rb"], ref["parameters"]["rb"]) <= TOL
+        m, _ = eng.eval(0)
+        yy = yv.astype(np.float64)
+        assert m[0]["mse"] == pytest.approx(ho.loss_fn(ref["reco"], yy, ~np.isnan(yy), "mse"), rel=3e-5)
+        eng.opt_init("Adam", 0.01)
+        batches = [(i * 160, 160) for i in range(7)]
+        losses = [eng.train_step(*b) for b in batches]
+        th_ref, l_ref = ho.train_steps(spec, theta, X, f, {"reco": yv}, batches, dtype=np.float32)
+        assert np.allclose(losses, l_ref, rtol=1e-4)
+        assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
+        if fused and max(hidden) <= 64:
+            eng.set_option("fused_update", 1)    # one kernel per step: the same compiled kernel, update in its prologue
+            more = [(i * 100, 100) for i in range(3)]
+            for b in more:
+                eng.train_step(*b, want_loss=False)
+            th_ref, _ = ho.train_steps(spec, theta, X, f, {"reco": yv}, batches + more, dtype=np.float32)
+            assert np.max(np.abs(eng.get_params() - th_ref)) <= 3e-5 * max(1.0, float(np.max(np.abs(th_ref))))
     eng.close()
 
 

@@ -192,8 +192,14 @@ def test_hidden_layers_given_as_a_chain_of_dense_layers():
     mm = eh.constructHybridModel({"rb": ["sw_pot", "dsw_pot"]}, ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["Q10"],
                                  hidden_layers={"rb": eh.Chain(eh.Dense(8, 4, "sigmoid"))}, activation={"rb": "sigmoid"})
     assert mm.config["hidden_layers"] == {"rb": [8, 4]}
+    # a single network takes an activation per layer: [model's, layer 1's, ...]; the gains of the initialisation follow the layers
+    m_mixed = eh.constructHybridModel(*args, hidden_layers=eh.Chain(eh.Dense(16, 16, "relu")), **kw)
+    assert m_mixed.layer_activations == ["tanh", "relu"] and m_mixed.NN == [(16, 2), (16, 16), (1, 16)]
+    assert m_mixed.activation_of(0, 1) == "relu" and m_mixed.config["layer_activations"] == ["tanh", "relu"]
+    # ... the networks of a MultiNN model one per NETWORK
     with pytest.raises(NotImplementedError, match="ONE activation"):
-        eh.constructHybridModel(*args, hidden_layers=eh.Chain(eh.Dense(16, 16, "relu")), **kw)
+        eh.constructHybridModel({"rb": ["sw_pot", "dsw_pot"]}, ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["Q10"],
+                                hidden_layers={"rb": eh.Chain(eh.Dense(8, 4, "relu"))}, activation={"rb": "sigmoid"})
     with pytest.raises(ValueError, match="takes 8 inputs"):
         eh.constructHybridModel(*args, hidden_layers=eh.Chain(eh.Dense(16, 16, "tanh"), eh.Dense(8, 8, "tanh")), **kw)
     with pytest.raises(NotImplementedError, match="only Dense"):

@@ -141,6 +141,37 @@ def test_per_net_activations_vjp(acts):
         assert np.allclose(par[name], lo + (hi - lo) / (1 + np.exp(-h[0])), rtol=1e-12)
 
 
+@pytest.mark.parametrize("acts", [["tanh", "relu", "sigmoid"], ["swish", "tanh", "identity"], ["sigmoid", "swish", "relu"]])
+def test_per_layer_activations_vjp(acts):
+    # SingleNN from `hidden_layers::Chain` whose Dense layers carry activations of their own (NNModels.jl:145-219: the reference wraps
+    # them as Dense(in, first_h, activation) -> layers... -> Dense(last_h, out)): hand VJP against autograd and central differences,
+    # and the forward against the chain evaluated layer by layer
+    spec = ho.HybridSpec(3, [12, 9, 7], "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], acts[0], True, layer_activations=acts)
+    rng = np.random.default_rng(5)
+    B = 70
+    X = rng.standard_normal((3, B)); f = {"ta": rng.uniform(0, 30, B)}
+    y = {"reco": rng.uniform(1, 9, B)}; y["reco"][::6] = np.nan
+    th = ho.init_theta(spec, 8, np.float64)
+    l, g, _ = ho.loss_and_grad(spec, th, X, f, y)
+    l2, g2 = tt.loss_and_grad(spec, th, X, f, y)
+    assert l == pytest.approx(l2, rel=1e-12) and np.max(np.abs(g - g2)) <= 1e-11 * np.max(np.abs(g2))
+    for k in rng.choice(th.size, 25, replace=False):
+        e = np.zeros_like(th); e[k] = 1e-6
+        fd = (ho.compute_loss(spec, th + e, X, f, y) - ho.compute_loss(spec, th - e, X, f, y)) / 2e-6
+        assert fd == pytest.approx(g[k], rel=2e-5, abs=2e-7)
+    nets_w, _ = ho.unpack(spec, th)
+    h = X
+    for li, (W, b) in enumerate(nets_w[0]):
+        z = W @ h + b[:, None]
+        h = z if li == 3 else ho.act_fwd(acts[li], z)
+    lo, hi = spec.lo("rb"), spec.hi("rb")
+    assert np.allclose(ho.forward(spec, th, X, f)["parameters"]["rb"], lo + (hi - lo) / (1 + np.exp(-h[0])), rtol=1e-12)
+    # the same activation everywhere IS the plain model
+    plain = ho.HybridSpec(3, [12, 9, 7], "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "tanh", True)
+    same = ho.HybridSpec(3, [12, 9, 7], "rbq10", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "relu", True, layer_activations=["tanh"] * 3)
+    assert ho.compute_loss(plain, th, X, f, y) == ho.compute_loss(same, th, X, f, y)
+
+
 @pytest.mark.parametrize("mech", ["expo", "linear", "expo2pool", "rs_components"])
 def test_other_mech_models_vjp(mech):
     rng = np.random.default_rng(3)

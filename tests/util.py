@@ -38,9 +38,14 @@ def model_from_spec(spec: ho.HybridSpec):
                                        activation=spec.activation if spec.net_activations is None else dict(zip(spec.neural, spec.net_activations)),
                                        scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False),
                                        precision=getattr(spec, "precision", "f32"))
+    hidden, act = list(spec.hidden), spec.activation
+    if getattr(spec, "layer_activations", None) is not None:      # hidden_layers::Chain: the first hidden layer takes the model's activation, the others their own
+        la = spec.layer_activations
+        act = la[0]
+        hidden = eh.Chain(*[eh.Dense(hidden[i], hidden[i + 1], la[i + 1]) for i in range(len(hidden) - 1)]) if len(hidden) > 1 else hidden
     return eh.constructHybridModel([f"x{i}" for i in range(spec.n_pred)], list(mm.forcings), list(spec.targets),
                                    MECH_NAME[spec.mech], dict(spec.parameters), list(spec.neural), list(spec.glob),
-                                   hidden_layers=list(spec.hidden), activation=spec.activation,
+                                   hidden_layers=hidden, activation=act,
                                    scale_nn_outputs=spec.scale_nn_outputs, input_batchnorm=getattr(spec, "input_batchnorm", False),
                                    precision=getattr(spec, "precision", "f32"))
 
