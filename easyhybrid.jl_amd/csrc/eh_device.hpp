@@ -1142,7 +1142,10 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
         __syncthreads();
     }
     for (int e = lane; e < G::IP * SR; e += 64) XS[e] = 0.0f;   // rows >= P of the X image stay 0
-    __syncthreads();
+    // (the X image is the wave's own: the workgroup barrier here is for what ELSE sits in front of the tile loop -- the parameter image
+    //  staged above by all threads.  A later step of a multi-step launch stages nothing: its image was completed behind a barrier by the
+    //  step before, and the statistics block above ends with a barrier of its own)
+    if (a.ms_keep) EH_WAVE_SYNC(); else __syncthreads();
     EH_STAMP_PRO(13);
     if ((a.bn_part || bn_self) && !bn_regs) {
         // input BatchNorm, train mode (Lux BatchNorm, affine = false): statistics of THIS minibatch
