@@ -73,7 +73,12 @@ struct EhOpt {
 
 // Optimisers.jl rules, fp32 op for op.  bt = {beta1^t, beta2^t} running products (Optimisers keeps
 // them in Float32: 1 - Float32(0.999) != 1e-3, which matters at 1e-5 in the first steps).
+// (no contraction into fused multiply-adds here: "op for op" is what Optimisers.jl's broadcasts do and what the oracle's NumPy does, and
+//  left to the compiler the choice depended on the kernel the rule was inlined into -- Descent's `theta - eta * g` came out as one fma in
+//  the multi-step kernel and as two operations in the single-step one: one ulp per step apart, which plain SGD on single-sample
+//  minibatches amplifies to O(1) within a few hundred steps, tests/test_gpu_fuzz.py seed 296)
 __device__ __forceinline__ void eh_opt_update(const EhOpt& o, float g, float bt1, float bt2, float& th, float& m, float& v) {
+#pragma clang fp contract(off)
     if (o.rule == EH_OPT_ADAM || o.rule == EH_OPT_ADAMW) {
         m = o.b1 * m + (1.0f - o.b1) * g;
         v = o.b2 * v + (1.0f - o.b2) * (g * g);

@@ -420,3 +420,31 @@ def test_random_small_minibatch_epochs_several_steps_per_launch(seed):
     assert l1 == pytest.approx(l0, rel=1e-4, abs=1e-6), (spec, kind, batch, opt)
     assert np.max(np.abs(t1 - t0)) <= 1e-4 * scale, (spec, kind, batch, opt, float(np.max(np.abs(t1 - t0))))
     assert util.relerr(p1, p0) <= 1e-3
+
+
+@pytest.mark.parametrize("opt", [("Descent", 0.01), ("RMSProp", 0.005), ("Adam", 0.01), ("AdamW", 0.01)])
+@pytest.mark.parametrize("batch", [1, 33])
+def test_several_steps_per_launch_are_bit_for_bit_one_launch_per_step(opt, batch):
+    """A minibatch one workgroup covers takes no float atomic that meets another: the multi-step launch and one launch per step run the
+    same operations in the same order, so their trajectories are IDENTICAL -- for every optimiser rule.  Found by the extended fuzz
+    (EH_FUZZ_N=300, seed 296: plain SGD on single-sample minibatches of un-normalised predictors, a chaotic descent): Descent's
+    `theta - eta * g` had been contracted into one fma in the multi-step kernel and not in the single-step one, one ulp per step that
+    the descent amplified to O(1) within a few hundred steps; the optimiser rules are compiled without contraction since
+    (csrc/eh_device.hpp eh_opt_update: "op for op", as Optimisers.jl's broadcasts and the oracle's NumPy)."""
+    spec, theta, X, f, y, kind, first, B, rng = _case(7000 + 40 * 296, fastpath=False)
+    for sub in range(40):
+        spec, theta, X, f, y, kind, first, B, rng = _case(7000 + 40 * 296 + sub, fastpath=False)
+        if len(spec.targets) == 1 and spec.nets is None and max(spec.hidden) <= 64 and kind in ("mse", "rmse", "mae", "nseLoss"):
+            break
+    n = 400
+    X, f, y = X[:, :n], {k: v[:n] for k, v in f.items()}, {k: v[:n] for k, v in y.items()}
+    out = []
+    for multi in (1, 0):
+        eng = util.load_engine(spec, theta, X, f, y)
+        eng.set_training_loss(kind); eng.opt_init(*opt); eng.set_option("fused_update", 1); eng.set_option("multi_step", multi)
+        l0, _ = eng.train_epoch(batch, seed=3, shuffle=True)
+        out.append((l0, eng.get_params()))
+        eng.close()
+    assert np.all(np.isfinite(out[1][1]))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
