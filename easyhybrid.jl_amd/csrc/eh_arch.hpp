@@ -21,6 +21,7 @@ struct EhVariant {
                              // 2 = bf16 operands in both passes (deltas rounded once); 0 = the fp32 kernels
     int so;                  // != 0: the TRAIN kernel is the sample-owned eh_bfs_kernel (eh_bf16_sample.hpp; one-network models only, 16 * nw-sample
                              // tiles: nt == nw); evaluation passes run eh_widebf_kernel with so x 16-sample tiles.  What "precision" selects.
+    size_t lds_eval;         // != 0: dynamic LDS of the variant's forward / evaluation kernels (per-wave family: no hidden images); 0 = lds_bytes
 };
 
 struct EhArchInfo {

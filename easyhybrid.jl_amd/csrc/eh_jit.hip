@@ -475,6 +475,7 @@ bool eh_jit_build(const eh_model_desc& d, const EhArchInfo* A, int variant, int 
     if (!ok) { *log = "hipModuleLoadData / hipModuleGetFunction failed for the compiled program"; eh_jit_release(out); return false; }
     out->nw = V.nw;
     out->lds_bytes = V.lds_bytes;
+    out->lds_eval_bytes = V.lds_eval;
     return true;
 }
 
@@ -486,7 +487,8 @@ hipError_t eh_jit_launch(const EhJitKernel* k, int mode, int grid, hipStream_t s
         if (grid != 1 || lds_ms > EH_LDS_LIMIT) return hipErrorInvalidValue;
         return hipModuleLaunchKernel(k->fn[mode], 1, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)lds_ms, stream, params, nullptr);
     }
-    return hipModuleLaunchKernel(k->fn[mode], (unsigned)grid, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)k->lds_bytes, stream, params, nullptr);
+    const size_t lds = (mode == EH_MODE_EVAL && k->lds_eval_bytes) ? k->lds_eval_bytes : k->lds_bytes;
+    return hipModuleLaunchKernel(k->fn[mode], (unsigned)grid, 1, 1, 64u * (unsigned)k->nw, 1, 1, (unsigned)lds, stream, params, nullptr);
 }
 
 void eh_jit_release(EhJitKernel* k) {

@@ -14,6 +14,7 @@ struct EhJitKernel {
     hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};   // EH_MODE_TRAIN, EH_MODE_EVAL, EH_MODE_TRAIN_P2P (when asked for), EH_MODE_TRAIN_MULTI (per-wave registry models with one target)
     int nw = 0;
     size_t lds_bytes = 0;
+    size_t lds_eval_bytes = 0;      // forward / evaluation kernel (0: lds_bytes)
 };
 
 // a recorded custom training loss (eh_set_loss_program): value slot 0 = yhat, 1 = y

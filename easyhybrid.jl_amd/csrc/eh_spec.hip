@@ -49,6 +49,11 @@ constexpr bool HASP2P = (FAST & 4) == 0;
 constexpr bool HASMULTI = (FAST & 4) == 0 && EhNet{EH_SPEC_NET}.T == 1;
 #endif
 constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
+#if EH_SPEC_FAMILY == 0
+constexpr size_t LDS_EVAL = sizeof(float) * Geom::TOTAL_FLOATS_EVAL;      // (the per-wave forward / evaluation kernels: no hidden images, eh_device.hpp)
+#else
+constexpr size_t LDS_EVAL = LDS;
+#endif
 static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
 
 hipError_t prepare() {
@@ -65,7 +70,7 @@ hipError_t launch(int mode, int grid, hipStream_t stream, const EhNet* net, cons
     if (mode == EH_MODE_TRAIN && args->rmap) return hipErrorNotSupported;      // (the sample-owned kernel writes plain canonical slab rows)
 #endif
     if (mode == EH_MODE_TRAIN) hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_TRAIN)), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
-    else if (mode == EH_MODE_EVAL) hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_EVAL)), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
+    else if (mode == EH_MODE_EVAL) hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_EVAL)), dim3(grid), dim3(64 * NW), LDS_EVAL, stream, *net, *args);
 #if EH_SPEC_FAMILY == 0
     else if (mode == EH_MODE_TRAIN_P2P && HASP2P) hipLaunchKernelGGL((EH_SPEC_KERNEL(EH_MODE_TRAIN_P2P)), dim3(grid), dim3(64 * NW), LDS, stream, *net, *args);
     else if (mode == EH_MODE_TRAIN_MULTI && HASMULTI) {      // several steps of one workgroup per launch, the state between them in LDS behind the work space
