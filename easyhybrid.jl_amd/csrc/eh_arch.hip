@@ -15,6 +15,7 @@ struct Var {
     static constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
     static_assert(LDS <= EH_LDS_LIMIT, "kernel shape does not fit the 160 KiB LDS of a gfx950 CU");
     static constexpr size_t LDS_EVAL = sizeof(float) * Geom::TOTAL_FLOATS_EVAL;      // (forward / evaluation kernels: no hidden images, eh_device.hpp)
+    static constexpr size_t LDS_EVAL_K1 = sizeof(float) * Geom::TOTAL_FLOATS_EVAL_K1;
     static constexpr bool HASPS = true;      // the P <= 4 kernels (FAST = 3) of every shape built with the fast paths
     // the cross-GPU (EH_MODE_TRAIN_P2P) kernels are built for the default variant of a shape only
 #ifdef EH_EXTRA_VARIANTS
@@ -62,7 +63,7 @@ struct Var {
         if ((e = prep2<EH_ACT_SWISH>()) != hipSuccess) return e;
         return prep2<EH_ACT_IDENTITY>();
     }
-#define EH_GO(MODE, FAST) hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>), dim3(grid), dim3(64 * NW), (MODE) == EH_MODE_EVAL ? LDS_EVAL : LDS, stream, *net, *args)
+#define EH_GO(MODE, FAST) hipLaunchKernelGGL((eh_step_kernel<EH_NBI, EH_NBH, EH_NL, NT, NW, ACT, MODE, FAST>), dim3(grid), dim3(64 * NW), (MODE) == EH_MODE_EVAL ? (((FAST) & 1) ? LDS_EVAL_K1 : LDS_EVAL) : LDS, stream, *net, *args)
     template <int ACT>
     static void go(int mode, int fast, int grid, hipStream_t stream, const EhNet* net, const EhStepArgs* args) {
         if (fast & 4) {

@@ -652,6 +652,8 @@ struct EhGeom {
     static constexpr int OS_OFF_EVAL = XS_OFF + IP * SR;
     static constexpr int WS_EVAL = OS_OFF_EVAL + 16 * SR;
     static constexpr int TOTAL_FLOATS_EVAL = IMG_FLOATS + NW * WS_EVAL;
+    static constexpr int WS_EVAL_K1 = IP * SR;                      // single NN output (FAST bit 0): the output stays in a register, no output rows either
+    static constexpr int TOTAL_FLOATS_EVAL_K1 = IMG_FLOATS + NW * WS_EVAL_K1;
 };
 
 #ifdef EH_STAMPS
@@ -807,7 +809,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     constexpr bool EVALM = MODE == EH_MODE_EVAL;
-    float* const ws = smem + G::IMG_FLOATS + wave * (EVALM ? G::WS_EVAL : G::WAVE_WS);
+    float* const ws = smem + G::IMG_FLOATS + wave * (EVALM ? (K1 ? G::WS_EVAL_K1 : G::WS_EVAL) : G::WAVE_WS);
     float* const XS = ws + G::XS_OFF;
     float* const HS = ws + G::HS_OFF;
     float* const OS = ws + (EVALM ? G::OS_OFF_EVAL : G::OS_OFF);
@@ -1073,7 +1075,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
     // sample's value -- instead of waiting for a launch of eh_bn_stats_kernel in front of the step (a dependent launch costs more than
     // the step's own work at this size); same sums in every workgroup, so the replicas of the image stay identical
     const bool bn_self = a.bn_nblk == -1;
-    static_assert((NTHR / 32 + 1) * 64 <= NW * G::WAVE_WS && (NTHR / 32 + 1) * 64 <= NW * G::WS_EVAL, "the statistics scratch fits the waves' work space");
+    static_assert((NTHR / 32 + 1) * 64 <= NW * G::WAVE_WS && (NTHR / 32 + 1) * 64 <= NW * G::WS_EVAL_K1, "the statistics scratch fits the waves' work space");
     float* const bn_red = smem + G::IMG_FLOATS;                  // [NTHR / 32][64], in the (not yet cleared) X images
     // One workgroup covering the whole minibatch (the multi-step launches; any single launch of at most 16 NT NW samples): its waves HOLD
     // the minibatch -- one record per lane, fetched above for the forward pass.  Every wave sums its own lanes about its first sample's
@@ -1096,7 +1098,7 @@ __device__ __forceinline__ void eh_step_body(const EhNet& net_rt, const EhStepAr
             a.image_out[G::PHI_OFF + EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
         }
     };
-    static_assert(NW * G::IP * 4 <= NW * G::WS_EVAL, "the per-wave statistics fit the waves' work space");
+    static_assert(NW * G::IP * 4 <= NW * G::WS_EVAL_K1, "the per-wave statistics fit the waves' work space");
     float bn_s1r = 0.0f, bn_s2r = 0.0f;
     if (bn_regs) {
         const float n_w = (float)__popcll(__ballot(nx_live));

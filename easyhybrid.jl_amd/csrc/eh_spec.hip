@@ -50,7 +50,7 @@ constexpr bool HASMULTI = (FAST & 4) == 0 && EhNet{EH_SPEC_NET}.T == 1;
 #endif
 constexpr size_t LDS = sizeof(float) * Geom::TOTAL_FLOATS;
 #if EH_SPEC_FAMILY == 0
-constexpr size_t LDS_EVAL = sizeof(float) * Geom::TOTAL_FLOATS_EVAL;      // (the per-wave forward / evaluation kernels: no hidden images, eh_device.hpp)
+constexpr size_t LDS_EVAL = sizeof(float) * ((FAST & 1) ? Geom::TOTAL_FLOATS_EVAL_K1 : Geom::TOTAL_FLOATS_EVAL);      // (the per-wave forward / evaluation kernels: no hidden images, eh_device.hpp)
 #else
 constexpr size_t LDS_EVAL = LDS;
 #endif
