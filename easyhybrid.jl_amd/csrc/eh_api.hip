@@ -38,8 +38,26 @@ int fail(eh_handle* h, int code, const char* fmt, ...) {
 static unsigned two_pass_mask(const EhNet& net);
 
 // ---- fused-update mode: apply the pending gradient so theta / m / v / image are current -----------
+static int flush_one(eh_handle* h);
 int flush_pending(eh_handle* h) {
     if (!h->pending) return EH_OK;
+    // Publishing mode 1: a step's sums reach the peers from the NEXT kernel on each rank's stream -- the next step or this flush -- so a
+    // drain is collective: the flush kernel waits for words that only the peers' own next kernels store.  Members of a one-process
+    // local group are drained together here, all launches before anybody synchronises (advisor r05: eh_get_params / eh_eval / a loss
+    // read / eh_set_option on ONE member used to run into the 2 s deadline and apply the step with the peers' sums read as 0).  Rank
+    // processes cannot be reached from here: there every draining call has to be made on all ranks (dp.py).
+    if (h->p2p_on && h->p2p_local && h->p2p_host.mode == 1) {
+        for (int r = 0; r < h->p2p_world; ++r) {
+            eh_handle* g = h->p2p_group[r];
+            if (!g || g == h || !g->pending) continue;
+            HIPCHK(g, hipSetDevice(g->device));
+            if (int rc = flush_one(g)) return rc;
+        }
+        HIPCHK(h, hipSetDevice(h->device));
+    }
+    return flush_one(h);
+}
+static int flush_one(eh_handle* h) {
     const int nt = h->net.n_theta;
     const float* g_prev = h->gacc + (size_t)((h->gstep + 2) % 3) * EH_GSHARDS * h->n_acc;
     float* sc_in = h->sc + 2 * h->sc_sel;
@@ -365,7 +383,7 @@ static const EhSpecKernel* spec_lookup(const eh_handle* h) {
     for (size_t i = 0; i < sizeof list / sizeof list[0]; ++i) {
         const EhSpecKernel* k = list[i];
         if (k->wide != (A->wide != 0) || k->bf16 != V.bf16 || k->nbi != A->nbi || k->nbh != A->nbh || k->nl != A->nl || k->nt != V.nt || k->nw != V.nw ||
-            k->act != h->act || k->fast != kf || memcmp(&k->net, &h->net, sizeof(EhNet)) != 0) continue;
+            k->act != h->act || k->fast != kf || (k->so != 0) != (V.so != 0) || memcmp(&k->net, &h->net, sizeof(EhNet)) != 0) continue;
         {
             std::lock_guard<std::mutex> lk(mu);
             const uint64_t bit = 1ull << (h->device & 63);
@@ -972,6 +990,13 @@ int32_t eh_jit_status(eh_handle* h, int32_t* n_compiled, char* log, int64_t log_
     return EH_OK;
 }
 
+// may this handle train on the sample-owned bf16 kernel (eh_bf16_sample.hpp)?  One network (its slab row is the plain canonical order); the
+// A/B switches of the measurement tools are read once and mean the same to the "precision" and the "variant" option (advisor r05)
+static bool so_allowed(const eh_handle* h) {
+    static const bool no_so = getenv("EH_NO_DIRECT_STORE") != nullptr || getenv("EH_NO_SAMPLE_OWNED") != nullptr;
+    return !no_so && h->n_nets == 1 && h->desc.n_nets == 0;
+}
+
 int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!h || !name) return EH_EINVAL;
     if (h->lform && (!strcmp(name, "fast_paths") || !strcmp(name, "row_split") || !strcmp(name, "variant") || !strcmp(name, "precision"))) {
@@ -1113,8 +1138,7 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
             if (h->fused) return fail(h, EH_EUNSUPPORTED, "precision: switch fused_update off first (the row-split kernels have no such mode)");
             const EhArchInfo* W = h->arch->wide ? h->arch : h->arch_alt;
             // one network (the slab row in plain canonical order): the sample-owned training kernel (eh_bf16_sample.hpp); else the row-split one
-            static const bool no_so = getenv("EH_NO_DIRECT_STORE") != nullptr || getenv("EH_NO_SAMPLE_OWNED") != nullptr;      // (A/B switches of the measurement tools)
-            const bool so_ok = !no_so && h->n_nets == 1 && h->desc.n_nets == 0;
+            const bool so_ok = so_allowed(h);
             int vb = -1;
             if (W && so_ok) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16 == (int)value && W->var[vi].so) { vb = vi; break; }
             if (W && vb < 0) for (int vi = 0; vi < W->nvar; ++vi) if (W->var[vi].bf16 == (int)value && !W->var[vi].so) { vb = vi; break; }
@@ -1134,8 +1158,8 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
     if (!strcmp(name, "variant")) {
         if (value < 0 || value >= h->arch->nvar) return fail(h, EH_EINVAL, "variant must be 0..%d for this shape", h->arch->nvar - 1);
         if (h->arch->var[value].bf16 != h->arch->var[h->variant].bf16) return fail(h, EH_EINVAL, "variant %lld belongs to the other precision (set the \"precision\" option)", (long long)value);
-        if (h->arch->var[value].so && (h->n_nets != 1 || h->desc.n_nets != 0 || getenv("EH_NO_DIRECT_STORE")))
-            return fail(h, EH_EUNSUPPORTED, "variant %lld is the sample-owned training kernel: one-network models only", (long long)value);
+        if (h->arch->var[value].so && !so_allowed(h))
+            return fail(h, EH_EUNSUPPORTED, "variant %lld is the sample-owned training kernel: one-network models only (and not with EH_NO_DIRECT_STORE / EH_NO_SAMPLE_OWNED set)", (long long)value);
         h->variant = (int)value;
         HIPCHK(h, hipSetDevice(h->device));      // the reduction map depends on the variant (waves of a row-split workgroup; layout of the parked accumulators)
         return build_maps(h, false);

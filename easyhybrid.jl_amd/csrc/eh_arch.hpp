@@ -40,6 +40,7 @@ struct EhArchInfo {
 struct EhSpecKernel {
     EhNet net;
     int wide, bf16, nbi, nbh, nl, nt, nw, act, fast;
+    int so;                  // the TRAIN kernel is the sample-owned one (EhVariant::so; family 3 of eh_spec.hip): part of the match, the (nt, nw, bf16) signature alone does not tell the families apart
     size_t lds_bytes;
     const char* what;
     hipError_t (*prepare)(void);

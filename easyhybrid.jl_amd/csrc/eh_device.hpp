@@ -2037,17 +2037,21 @@ template <int BYTES>
 __device__ __forceinline__ void eh_kernarg_warm() {
 #ifndef EH_NO_KERNARG_WARM
     // (written out: the compiler splits a loop of plain loads over several waits -- and every wait is one of those round trips)
-    static_assert(BYTES > 256 && BYTES <= 768, "four to twelve lines");
+    // BYTES = the explicit arguments as they are: only lines that START inside them are touched (advisor r05: rounding up to 256 read up
+    // to 255 bytes past them -- inside the hidden-argument block today, an out-of-segment scalar read if the structs ever end near its end)
+    static_assert(BYTES > 192 && BYTES <= 768, "four to twelve lines");
     const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
     unsigned d0, d1, d2, d3, d4 = 0u, d5 = 0u, d6 = 0u, d7 = 0u, d8 = 0u, d9 = 0u, d10 = 0u, d11 = 0u;
     asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
                  : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
-    if constexpr (BYTES > 256)
-        asm volatile("s_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0"
-                     : "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7) : "s"(ka));
-    if constexpr (BYTES > 512)
-        asm volatile("s_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0"
-                     : "=&s"(d8), "=&s"(d9), "=&s"(d10), "=&s"(d11) : "s"(ka));
+    if constexpr (BYTES > 0x100) asm volatile("s_load_dword %0, %1, 0x100" : "=&s"(d4) : "s"(ka));
+    if constexpr (BYTES > 0x140) asm volatile("s_load_dword %0, %1, 0x140" : "=&s"(d5) : "s"(ka));
+    if constexpr (BYTES > 0x180) asm volatile("s_load_dword %0, %1, 0x180" : "=&s"(d6) : "s"(ka));
+    if constexpr (BYTES > 0x1c0) asm volatile("s_load_dword %0, %1, 0x1c0" : "=&s"(d7) : "s"(ka));
+    if constexpr (BYTES > 0x200) asm volatile("s_load_dword %0, %1, 0x200" : "=&s"(d8) : "s"(ka));
+    if constexpr (BYTES > 0x240) asm volatile("s_load_dword %0, %1, 0x240" : "=&s"(d9) : "s"(ka));
+    if constexpr (BYTES > 0x280) asm volatile("s_load_dword %0, %1, 0x280" : "=&s"(d10) : "s"(ka));
+    if constexpr (BYTES > 0x2c0) asm volatile("s_load_dword %0, %1, 0x2c0" : "=&s"(d11) : "s"(ka));
     // (the destinations stay live up to the wait: a register handed out earlier would be overwritten when its load lands)
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4), "s"(d5), "s"(d6), "s"(d7), "s"(d8), "s"(d9), "s"(d10), "s"(d11));
 #endif
@@ -2057,7 +2061,7 @@ namespace EH_SPEC_NS {
 #endif
 template <int NBI, int NBH, int NL, int NT, int NW, int ACT, int MODE, int FAST>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void eh_step_kernel(const EhNet net, const EhStepArgs a) {
-    eh_kernarg_warm<((sizeof(EhNet) + sizeof(EhStepArgs) + 255) & ~255)>();
+    eh_kernarg_warm<(int)(sizeof(EhNet) + sizeof(EhStepArgs))>();
     if constexpr (MODE == EH_MODE_TRAIN_MULTI) {
         // Minibatches that ONE workgroup covers -- the reference's default batch of 64 (src/config/TrainingConfig.jl:14) and everything up
         // to 16 NT NW samples: a step's only consumer is the same workgroup's next step, so the steps of an epoch need neither a kernel

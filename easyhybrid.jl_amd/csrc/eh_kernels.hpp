@@ -553,22 +553,24 @@ __global__ __launch_bounds__(256) void eh_fused_flush_kernel(const float* g_prev
         }
         cnt = s1 + (T > 1 ? s2 : 0.0f) + (T > 2 ? s3 : 0.0f) + (T > 3 ? s4 : 0.0f); sy = s2; syy = s3;
     } else {
+        // the eight shards of every scalar in the order the step's prologue folds them (eh_fold8): a step applied here and the same step
+        // applied by the next step's prologue are the same bits, so a trajectory does not depend on when the host drains (advisor r05)
+        static_assert(EH_GSHARDS == 8, "eh_fold8");
+        float S[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) {
-            const float* gp = g_prev + sh * n_acc + n_theta;
-            sse += gp[0];
-            if (T == 1) { cnt += gp[1]; sy += gp[2]; syy += gp[3]; }
-            else for (int t = 0; t < T; ++t) cnt += gp[1 + t];
+        for (int k = 0; k < 5; ++k) {
+            if (k == 4 && T <= 3) continue;
+            const float* q = g_prev + n_theta + k;
+            S[k] = eh_fold8(q[0], q[n_acc], q[2 * n_acc], q[3 * n_acc], q[4 * n_acc], q[5 * n_acc], q[6 * n_acc], q[7 * n_acc]);
         }
+        sse = S[0]; cnt = S[1] + (T > 1 ? S[2] : 0.0f) + (T > 2 ? S[3] : 0.0f) + (T > 3 ? S[4] : 0.0f); sy = S[2]; syy = S[3];
     }
     float inv = 0.0f, lossv = 0.0f;
     if (T == 1) eh_loss_finish(loss_kind, sse, cnt, sy, syy, inv, lossv, im.agg_a);
     else { inv = cnt > 0.0f ? 1.0f : 0.0f; lossv = cnt > 0.0f ? sse : __builtin_nanf(""); }      // multi-target: the step used exact per-target weights
     float th = th0;
     if (own && cnt > 0.0f) {
-        float gs = gs_p2p;
-#pragma unroll
-        for (int sh = 0; sh < EH_GSHARDS; ++sh) gs += gsv[sh];
+        const float gs = p2p ? gs_p2p : eh_fold8(gsv[0], gsv[1], gsv[2], gsv[3], gsv[4], gsv[5], gsv[6], gsv[7]);
         float mm = mm0, vv = vv0;
         eh_opt_update(o, gs * inv, sc0, sc1, th, mm, vv);
         theta[idx] = th; m[idx] = mm; v[idx] = vv;

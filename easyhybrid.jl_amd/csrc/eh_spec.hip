@@ -84,7 +84,7 @@ hipError_t launch(int mode, int grid, hipStream_t stream, const EhNet* net, cons
 }
 #define EH_STR_(x) #x
 #define EH_STR(x) EH_STR_(x)
-const EhSpecKernel spec = {EhNet{EH_SPEC_NET}, EH_SPEC_FAMILY != 0, EH_SPEC_FAMILY >= 2 ? (EH_SPEC_NSPLIT == 3 ? 1 : 2) : 0, NBI, NBH, NL, NT, NW, ACT, FAST, LDS,
+const EhSpecKernel spec = {EhNet{EH_SPEC_NET}, EH_SPEC_FAMILY != 0, EH_SPEC_FAMILY >= 2 ? (EH_SPEC_NSPLIT == 3 ? 1 : 2) : 0, NBI, NBH, NL, NT, NW, ACT, FAST, EH_SPEC_FAMILY == 3 ? 1 : 0, LDS,
                            "descriptor " EH_STR(EH_SPEC_ID) " of csrc/Makefile, specialised ahead of time", &prepare, &launch};
 }   // namespace
 

@@ -58,7 +58,7 @@ namespace EH_SPEC_NS {
 #endif
 template <int NBI, int NBH, int NL, int NT, int NWV, int ACT, int MODE, bool PROG = false>
 __global__ __launch_bounds__(64 * NWV, 1) void eh_wide_kernel(const EhNet net_rt, const EhStepArgs a) {
-    eh_kernarg_warm<((sizeof(EhNet) + sizeof(EhStepArgs) + 255) & ~255)>();
+    eh_kernarg_warm<(int)(sizeof(EhNet) + sizeof(EhStepArgs))>();
 #ifdef EH_SPEC_NET
     constexpr EhNet net = {EH_SPEC_NET};        // see eh_step_body
 #else

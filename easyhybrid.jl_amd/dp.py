@@ -85,7 +85,10 @@ class DataParallel:
         prologue of step s+1; `engine.synchronize()` applies the last one).  The exchange is the
         engine's own peer-to-peer store protocol over xGMI when `p2p` is on and its start-up self-test
         passes on every rank (no collective call per step at all), otherwise one RCCL all-reduce.
-        fused=False: step kernel, deterministic reduction, all-reduce, optimiser kernel."""
+        fused=False: step kernel, deterministic reduction, all-reduce, optimiser kernel.
+        p2p="prologue" (publishing mode 1): a step's sums leave this rank from the NEXT kernel on its stream, which then waits for the
+        peers' -- every draining call (`synchronize`, `get_params`, `evaluate`, `forward`, a loss read, `set_option`) is a collective
+        then and has to be made on ALL ranks at the same step; a one-sided drain runs into the 2 s deadline."""
         import os
         import numpy as np
         import torch

@@ -760,6 +760,29 @@ def test_fused_update_mode_matches_two_kernel_mode():
     a.close(); b.close(); c.close()
 
 
+@pytest.mark.parametrize("aot", [0, 1])
+def test_fused_update_trajectory_does_not_depend_on_when_the_host_drains(aot):
+    """advisor r05: a step's eight accumulator shards are folded in ONE order (eh_fold8) by the next step's prologue AND by the flush
+    kernel behind every drain (synchronize, get_params, a loss read): the same steps with a drain after every one and drained once
+    at the end are the same bits.  Minibatches of 2 048 = eight workgroups of the headline kernel, one per shard: every shard is
+    non-zero and takes exactly one add, so the float atomics themselves have no order to differ in."""
+    spec, theta, X, f, y = util.rbq10_case(8 * 2048, "tanh", True, 0.05)
+    out = []
+    for drain in (False, True):
+        e = util.load_engine(spec, theta, X, f, y); e.set_option("aot_spec", aot)
+        e.opt_init("Adam", 0.01); e.set_option("fused_update", 1)
+        for i in range(24):
+            e.train_step((i % 8) * 2048, 2048, want_loss=False)
+            if drain:
+                e.synchronize()
+                if i % 5 == 0: e.get_params()
+        out.append((e.get_params().copy(), [np.asarray(v).copy() for v in e.get_opt_state()]))
+        e.close()
+    (th0, st0), (th1, st1) = out
+    assert np.array_equal(th0, th1)
+    assert all(np.array_equal(u, v) for u, v in zip(st0, st1))
+
+
 def test_fused_update_skips_all_masked_batch_and_reports_losses():
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "rbq10_allmasked_batch.npz"))
     spec = _load_spec(d)
