@@ -1504,7 +1504,8 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
     else hipLaunchKernelGGL((eh_gemm_kernel<ATR, BTR, EPI, false>), grid, dim3(256), 0, h->stream, g);
 }
 // minibatch -> Xb (input BatchNorm applied), forward through every Dense layer; O^T [K][ldo] = the raw NN outputs
-static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool train_mode, bool bn_update, const EhLWs& W) {
+// (lstop >= 0: a one-network model, only its layers below `lstop` run here -- the rest belongs to eh_lform_tailchain_kernel)
+static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long long first, long long count, bool train_mode, bool bn_update, const EhLWs& W, int lstop = -1) {
     const EhNet& net = h->net;
     const int B = (int)count;
     if (h->l_nnets == 0) return EH_OK;        // no network (no neural parameter): the mechanistic stage reads the records itself
@@ -1523,7 +1524,7 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
     bool fused0 = false;
     {
         const eh_handle_s::LNet& L0 = h->l_net[0];
-        if (!nofuse && !g_gemm_novec && L0.nl >= 2 && L0.in[0] <= 8) {
+        if (!nofuse && !g_gemm_novec && L0.nl >= 2 && L0.in[0] <= 8 && lstop != 0) {
             EhGemmArgs g{};
             g.A = nullptr; g.lda = net.P; g.B = theta + L0.woff[0]; g.ldb = L0.out[0];
             g.M = B; g.N = L0.out[0]; g.K = L0.in[0]; g.kchunk = g.K; g.bias = theta + L0.boff[0]; g.act = L0.lact[0];
@@ -1537,7 +1538,7 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
     HIPCHK(h, hipGetLastError());
     for (int k = 0; k < h->l_nnets; ++k) {
         const eh_handle_s::LNet& L = h->l_net[k];
-        for (int l = 0; l < L.nl; ++l) {
+        for (int l = 0; l < (lstop >= 0 ? lstop : L.nl); ++l) {
             if (fused0 && k == 0 && l == 0) continue;
             EhGemmArgs g{};
             g.A = l == 0 ? W.Xb + L.c0 : W.H[k][l - 1]; g.lda = l == 0 ? net.P : L.in[l];      // (a network's predictors: its columns of the minibatch matrix)
@@ -1582,11 +1583,45 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         HIPCHK(h, hipMemsetAsync(h->slab, 0, (size_t)h->n_acc * sizeof(float), h->stream));
         return EH_OK;
     }
-    if (int rc = lform_forward(h, sp, idx, first, count, true, bn_update, W)) return rc;
-    EhStepArgs a{};
-    a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count;
-    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     const unsigned tpm = two_pass_mask(net);
+    // Small minibatches: every layer's delta is kept (l_dk), the chain of delta products runs first and the weight gradients -- a
+    // handful of tiles each, 4-6 us per dependent launch -- follow as ONE grouped launch of the tiled ones and one of the thin ones.
+    static const long long lgroup_max = getenv("EH_LFORM_GROUP_MAX") ? atoll(getenv("EH_LFORM_GROUP_MAX")) : 4096;
+    bool grouped = count <= lgroup_max && h->l_nnets > 0;
+    long long dk_floats = 0;
+    // (sized by THIS minibatch, rounded up to a power of two -- not by the largest one the path serves: a B = 64 step of a deep, wide
+    //  MultiNN model used to ask for up to the 1 GiB cap; advisor, round 3.  A larger batch later re-grows it, outside a capture.)
+    long long dk_rows = 64;
+    while (dk_rows < count) dk_rows *= 2;
+    if (grouped) {
+        for (int k = 0; k < h->l_nnets; ++k)
+            for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += dk_rows * h->l_net[k].out[l];
+        if (dk_floats > (1ll << 28)) { grouped = false; h->jit_log = "layer-wise form: kept deltas of this minibatch exceed 1 GiB -- weight gradients run layer by layer (slower small-batch steps)"; }
+        else if ((size_t)dk_floats > h->l_dk_cap) {
+            if (h->capturing) return lform_alloc_in_capture(h, "kept deltas");
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->l_dk); h->l_dk = nullptr; h->l_dk_cap = 0;
+            if (hipMalloc(&h->l_dk, (size_t)dk_floats * sizeof(float)) == hipSuccess) h->l_dk_cap = (size_t)dk_floats;
+            else { (void)hipGetLastError(); grouped = false; h->jit_log = "layer-wise form: no memory for the kept deltas of the grouped small-batch path -- weight gradients run layer by layer (slower small-batch steps)"; }
+        }
+    }
+    // Few rows, one network: the narrow end of the network -- every layer from `tail_s` on, the mechanistic stage and the deltas back
+    // down to layer tail_s - 1 -- is ONE launch with a workgroup per row (eh_lform_tailchain_kernel, eh_lform.hpp)
+    static const bool notail = getenv("EH_LFORM_NOTAIL") != nullptr;
+    int tail_s = -1;
+    if (!notail && grouped && h->l_nnets == 1 && count <= 256 && !tpm && !g_gemm_novec) {
+        const eh_handle_s::LNet& L = h->l_net[0];
+        long long wsum = 0;
+        for (int l = L.nl - 1; l >= 0; --l) {
+            if (L.in[l] > (int)EH_LTAIL_MAXW || L.out[l] > (int)EH_LTAIL_MAXW || wsum + (long long)L.in[l] * L.out[l] > (96ll << 10)) break;
+            wsum += (long long)L.in[l] * L.out[l];
+            tail_s = l;
+        }
+    }
+    if (int rc = lform_forward(h, sp, idx, first, count, true, bn_update, W, tail_s)) return rc;
+    EhStepArgs a{};
+    a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count; a.stamps = h->stamps;
+    for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     if (tpm) {
         // losses that need batch statistics of yhat (see launch_train_kernel): the NN outputs O stay where the forward left them, so
         // the two statistics passes are two runs of the mechanistic stage alone (eval form), not two forwards
@@ -1632,6 +1667,50 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     const int mgrid = (int)std::min<long long>(2048, (count + 255) / 256);
     static const bool nofuse = getenv("EH_LFORM_NOFUSE") != nullptr;
     if (mgrid == 1 && !nofuse) { m.slab = h->slab; m.nrows = rows; m.n_acc = (long long)h->n_acc; }      // one workgroup: it writes the slab's tail columns itself
+    EhLTailJob tjob{nullptr, 0, nullptr, 0, 0};
+    if (tail_s >= 0) {
+        const eh_handle_s::LNet& L = h->l_net[0];
+        const float* theta = TH(h);
+        EhLTailArgs t{};
+        t.nl = L.nl - tail_s;
+        // dZ_l of the hidden layers where the grouped weight gradients will look for them (the order of the backward loop below: from the top)
+        float* dptr[EH_MAX_HIDDEN + 1] = {nullptr};
+        { float* q = h->l_dk; for (int l = L.nl - 1; l >= 1; --l) { dptr[l - 1] = q; q += dk_rows * L.in[l]; } }
+        int wmax = 4;
+        for (int j = 0; j < t.nl; ++j) {
+            const int l = tail_s + j;
+            EhLTailLayer& T = t.L[j];
+            T.W = theta + L.woff[l]; T.b = theta + L.boff[l]; T.in = L.in[l]; T.out = L.out[l]; T.act = L.lact[l];
+            T.vec = ((reinterpret_cast<unsigned long long>(T.W) & 15ull) == 0 && (T.out & 3) == 0) ? 1 : 0;
+            const bool hidden = l + 1 < L.nl;
+            T.H = hidden ? W.H[0][l] : nullptr; T.Z = hidden ? W.Z[0][l] : nullptr; T.D = hidden ? dptr[l] : nullptr;
+            eh_ltail_geometry(T);
+            if (hidden && T.act == EH_ACT_SWISH) t.any_swish = 1;
+            wmax = std::max(wmax, std::max(T.in, T.out));
+        }
+        (void)wmax;
+        t.wmax = (int)EH_LTAIL_MAXW;        // (rows of EH_LTAIL_MAXW + EH_LTAIL_PAD floats whatever the widths: a product reads on past a row's width into zeros, up to the next power of two)
+        t.Hin = tail_s == 0 ? W.Xb + L.c0 : W.H[0][tail_s - 1]; t.ldin = tail_s == 0 ? net.P : L.in[tail_s];
+        t.act_below = tail_s > 0 ? L.lact[tail_s - 1] : EH_ACT_IDENTITY;
+        t.Zin = (tail_s > 0 && t.act_below == EH_ACT_SWISH) ? W.Z[0][tail_s - 1] : nullptr;
+        if (t.Zin) t.any_swish = 1;
+        t.Dbelow = tail_s > 0 ? dptr[tail_s - 1] : nullptr;
+        t.O = W.O + (long long)L.orow * W.ldo; t.ldo = W.ldo; t.part = W.part;
+        const int R = count <= 64 ? 1 : 4;
+        const int tgrid = (int)((count + R - 1) / R);
+        const size_t lds = eh_ltail_lds_bytes(R, t.nl, t.wmax, t.any_swish != 0);
+        const bool mp = net.mech == EH_MECH_PROGRAM;
+        const void* fn = R == 1 ? (lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, true> : (const void*)&eh_lform_tailchain_kernel<1, false, true>)
+                                         : (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, false> : (const void*)&eh_lform_tailchain_kernel<1, false, false>))
+                                : (lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<4, true, true> : (const void*)&eh_lform_tailchain_kernel<4, false, true>)
+                                         : (mp ? (const void*)&eh_lform_tailchain_kernel<4, true, false> : (const void*)&eh_lform_tailchain_kernel<4, false, false>));
+        if (lds > EH_LDS_LIMIT) return fail(h, EH_EUNSUPPORTED, "layer-wise form: %zu bytes of LDS for the tail chain", lds);
+        bool& prepared = h->l_tail_fn[(R == 4 ? 4 : 0) + (lprog ? 2 : 0) + (mp ? 1 : 0)];      // (per handle = per device)
+        if (!prepared) { HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EH_LDS_LIMIT)); prepared = true; }
+        void* kargs[] = {(void*)&net, (void*)&a, (void*)&t, (void*)&h->image};
+        HIPCHK(h, hipLaunchKernel(fn, dim3((unsigned)tgrid), dim3(EH_LTAIL_THREADS), kargs, lds, h->stream));
+        tjob = EhLTailJob{W.part, tgrid, h->slab, rows, (long long)h->n_acc};
+    } else
     if (lprog) {
         if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
         else hipLaunchKernelGGL((eh_lform_mech_kernel<true, false, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
@@ -1639,33 +1718,12 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     else if (net.mech == EH_MECH_PROGRAM) hipLaunchKernelGGL((eh_lform_mech_kernel<true, true>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
     else hipLaunchKernelGGL((eh_lform_mech_kernel<true, false>), dim3(mgrid), dim3(256), 0, h->stream, net, a, m, h->image);
     HIPCHK(h, hipGetLastError());
-    if (!m.slab) {
+    if (!m.slab && tail_s < 0) {
         hipLaunchKernelGGL(eh_lform_tail_kernel, dim3(1), dim3(256), 0, h->stream, W.part, mgrid, net, h->slab, rows, (long long)h->n_acc);
         HIPCHK(h, hipGetLastError());
     }
     // backward, every network from its output layer down; dZ of the output layer = its rows of d loss / d O^T, still [K][ldo]
     const float* theta = TH(h);
-    // Small minibatches: every layer's delta is kept (l_dk), the chain of delta products runs first and the weight gradients -- a
-    // handful of tiles each, 4-6 us per dependent launch -- follow as ONE grouped launch of the tiled ones and one of the thin ones.
-    static const long long lgroup_max = getenv("EH_LFORM_GROUP_MAX") ? atoll(getenv("EH_LFORM_GROUP_MAX")) : 4096;
-    bool grouped = count <= lgroup_max && h->l_nnets > 0;
-    long long dk_floats = 0;
-    // (sized by THIS minibatch, rounded up to a power of two -- not by the largest one the path serves: a B = 64 step of a deep, wide
-    //  MultiNN model used to ask for up to the 1 GiB cap; advisor, round 3.  A larger batch later re-grows it, outside a capture.)
-    long long dk_rows = 64;
-    while (dk_rows < count) dk_rows *= 2;
-    if (grouped) {
-        for (int k = 0; k < h->l_nnets; ++k)
-            for (int l = 0; l + 1 < h->l_net[k].nl; ++l) dk_floats += dk_rows * h->l_net[k].out[l];
-        if (dk_floats > (1ll << 28)) { grouped = false; h->jit_log = "layer-wise form: kept deltas of this minibatch exceed 1 GiB -- weight gradients run layer by layer (slower small-batch steps)"; }
-        else if ((size_t)dk_floats > h->l_dk_cap) {
-            if (h->capturing) return lform_alloc_in_capture(h, "kept deltas");
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            (void)hipFree(h->l_dk); h->l_dk = nullptr; h->l_dk_cap = 0;
-            if (hipMalloc(&h->l_dk, (size_t)dk_floats * sizeof(float)) == hipSuccess) h->l_dk_cap = (size_t)dk_floats;
-            else { (void)hipGetLastError(); grouped = false; h->jit_log = "layer-wise form: no memory for the kept deltas of the grouped small-batch path -- weight gradients run layer by layer (slower small-batch steps)"; }
-        }
-    }
     EhGemmGroup GG{}; EhThinGroup TG{};
     auto flush_tiled = [&]() {
         if (GG.n > 0) hipLaunchKernelGGL((eh_gemm_group_kernel<true, false, EH_GEPI_STORE, true, 64>), dim3((unsigned)GG.t0[GG.n]), dim3(256), 0, h->stream, GG);
@@ -1708,17 +1766,19 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
                 b.A = dZ; b.lda = dz_t ? W.ldo : out; b.B = theta + L.woff[l]; b.ldb = out;        // W_l element (k = out, n = in) at n * out + k
                 float* const dnext = grouped ? dkp : W.D[which];
                 if (grouped) dkp += dk_rows * in;
-                b.C = dnext; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
-                b.H = L.lact[l - 1] == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.lact[l - 1];
-                if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
-                HIPCHK(h, hipGetLastError());
+                if (!(tail_s >= 0 && l >= tail_s)) {      // (the tail chain has left this delta where the weight gradients look for it)
+                    b.C = dnext; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
+                    b.H = L.lact[l - 1] == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.lact[l - 1];
+                    if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
+                    HIPCHK(h, hipGetLastError());
+                }
                 dZ = dnext; dz_t = false; which ^= 1;
             }
         }
     }
     static const bool nodwmerge = getenv("EH_LFORM_NODWMERGE") != nullptr;
-    if (TG.n > 0 && GG.n > 0 && !nodwmerge) {       // what is left of both groups: one launch
-        hipLaunchKernelGGL(eh_dw_group_kernel, dim3((unsigned)(TG.t0[TG.n] + GG.t0[GG.n])), dim3(256), 0, h->stream, GG, TG);
+    if (tjob.part || (TG.n > 0 && GG.n > 0 && !nodwmerge)) {       // what is left of both groups: one launch (+ the workgroup that sums the tail chain's partial rows)
+        hipLaunchKernelGGL(eh_dw_group_kernel, dim3((unsigned)(TG.t0[TG.n] + GG.t0[GG.n] + (tjob.part ? 1 : 0))), dim3(256), 0, h->stream, GG, TG, tjob, net);
         TG.n = 0; GG.n = 0;
         HIPCHK(h, hipGetLastError());
     }

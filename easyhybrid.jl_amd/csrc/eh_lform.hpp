@@ -370,8 +370,13 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_group_kernel(const EhThinGro
 
 // Both groups of a small-batch step's weight gradients -- the tiled ones and the thin ones -- as ONE launch: the first workgroups run
 // the thin products, the others the tiles (one dependent launch fewer; the two bodies' LDS side by side, 44 KB).
-__global__ __launch_bounds__(256) void eh_dw_group_kernel(const EhGemmGroup G, const EhThinGroup T) {
+// ... and, as one more workgroup behind them, the sums of the mechanistic stage (rows of partial sums -> the tail columns of the slab:
+// eh_lform_tail_sum below, the body of eh_lform_tail_kernel) when the stage ran on several workgroups (eh_lform_tailchain_kernel).
+struct EhLTailJob { const float* part; int nblk; float* slab; int nrows; long long n_acc; };
+__device__ __forceinline__ void eh_lform_tail_sum(const float* part, int nblk, const EhNet& net, float* slab, int nrows, long long n_acc);
+__global__ __launch_bounds__(256) void eh_dw_group_kernel(const EhGemmGroup G, const EhThinGroup T, const EhLTailJob J, const EhNet net) {
     const int nthin = T.t0[T.n];
+    if (J.part && (int)blockIdx.x == (int)gridDim.x - 1) { eh_lform_tail_sum(J.part, J.nblk, net, J.slab, J.nrows, J.n_acc); return; }
     if ((int)blockIdx.x < nthin) {
         int i = 0;
         while (i + 1 < T.n && (int)blockIdx.x >= T.t0[i + 1]) ++i;
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(256) void eh_lform_mech_kernel(const EhNet net, con
 
 // rows of mechanistic-stage sums -> the tail of slab row 0 ([grad of the raw globals | S | n_t | Sy | Syy] in the fused kernels'
 // column order); the same columns of the other slab rows are cleared.  One workgroup.
-__global__ __launch_bounds__(256) void eh_lform_tail_kernel(const float* part, int nblk, const EhNet net, float* slab, int nrows, long long n_acc) {
+__device__ __forceinline__ void eh_lform_tail_sum(const float* part, int nblk, const EhNet& net, float* slab, int nrows, long long n_acc) {
     __shared__ float tot[EH_LMECH_PART], red[16][EH_LMECH_PART];
     const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4;       // 16 row groups x 16 columns, fixed order: deterministic
     float s = 0.0f;
@@ -771,4 +776,495 @@ __global__ __launch_bounds__(256) void eh_lform_tail_kernel(const float* part, i
     }
     __syncthreads();
     eh_lform_tail_write(tot, net, slab, nrows, n_acc, tid);
+}
+__global__ __launch_bounds__(256) void eh_lform_tail_kernel(const float* part, int nblk, const EhNet net, float* slab, int nrows, long long n_acc) {
+    eh_lform_tail_sum(part, nblk, net, slab, nrows, n_acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Few rows (B <= 256), the narrow END of the network as ONE launch: the reference's GPU tutorial net [1024,512,256,128,64] at its own
+// batch of 64 ran 256->128, 128->64, 64->1, the mechanistic stage, and the deltas back down to the 256-wide layer as SEVEN dependent
+// launches of 3.6-6.6 us each -- none of them has work for more than a few CUs, each is a launch boundary plus one or two memory round
+// trips (profiles/r05/train_e2e_kernel_stats.csv).  Forward and delta products of a layer touch one ROW of the minibatch at a time, so
+// the rows are independent all the way: workgroup b runs rows [R b, R b + R) through every layer of the suffix, the mechanistic model +
+// masked loss + its pullback, and the delta chain back to the layer below the suffix, with the activations of its rows in LDS.  Products
+// are row-vector x matrix on the vector ALU (a 16-row MFMA tile would be 1/16 full): the k range of a forward product is split over the
+// workgroup's 1 024 threads (thread = 4 adjacent output columns x one k slice; 16-byte loads of the canonical [in][out] weights, one
+// batch in flight per layer), the slices are added in k order through LDS; a delta product contracts over the contiguous dimension
+// (lane = 4 adjacent columns, a lane group per k row, butterfly sum).  Every sum in a fixed order: deterministic.  What the weight-
+// gradient products (grouped launch, eh_dw_group_kernel) need -- H_l, dZ_l -- goes to global memory on the way.
+// Suffix: every layer from `first` on has in, out <= 256 (EH_LTAIL_MAXW); each workgroup streams its weights from L2 twice.
+enum { EH_LTAIL_MAXL = EH_MAX_HIDDEN + 1, EH_LTAIL_MAXW = 256, EH_LTAIL_THREADS = 512, EH_LTAIL_RED = 4 * EH_LTAIL_THREADS, EH_LTAIL_RED2 = 1024, EH_LTAIL_PAD = 64,
+       EH_LTAIL_FD = 8, EH_LTAIL_BU = 4 };      // weight fragments a thread keeps in flight: rows of its k slice (forward), passes over the k rows (delta)
+struct EhLTailLayer {
+    const float* W; const float* b;      // canonical [in][out] row-major weights, bias [out]
+    float* H; float* Z;                  // (hidden layers) activations [B][out] out; pre-activations out when the layer's activation is swish, else null
+    float* D;                            // (hidden layers) dZ_l [B][out] out
+    int in, out, act, vec;               // vec: W 16-byte aligned and out % 4 == 0
+    // geometry of the two products (eh_ltail_geometry, host): forward thread = (k slice tid >> lg_ng, column group tid & (ng - 1)) with
+    // KS slices of kper rows, partial rows ostr = 1 << lg_ostr apart; delta product: 1 << lg_G lanes per k row
+    int lg_ng, KS, kper, lg_ostr, lg_G, nloop, pad0, pad1;
+};
+struct EhLTailArgs {
+    EhLTailLayer L[EH_LTAIL_MAXL];
+    int nl, wmax, any_swish, act_below;
+    const float* Hin; long long ldin;    // input of L[0]: [B][ldin]
+    const float* Zin;                    // its pre-activation (the layer below is swish), else null
+    float* Dbelow;                       // dZ of the layer below [B][L[0].in]; null: L[0] is the network's first layer
+    float* O; long long ldo;             // this network's rows of O^T [K][ldo]: raw outputs -> d loss / d O
+    float* part;                         // [gridDim][EH_LMECH_PART]
+};
+inline void eh_ltail_geometry(EhLTailLayer& T) {
+    const int CV = T.vec ? 4 : 1;
+    int lg = 0;
+    while ((CV << lg) < T.out) ++lg;                      // ng = 1 << lg column groups
+    T.lg_ng = lg;
+    T.lg_ostr = lg + (T.vec ? 2 : 0);
+    int KS = std::min(std::min((int)EH_LTAIL_THREADS >> lg, T.in), 64);          // (two levels of eight: at most 64 slices)
+    KS = std::max(KS, 1);
+    T.kper = (T.in + KS - 1) / KS;
+    T.KS = (T.in + T.kper - 1) / T.kper;                  // slices that are not empty
+    int lgG = 0;
+    while (4 * (CV << lgG) < T.out && lgG < 6) ++lgG;     // a lane takes up to four pieces (of CV columns) of its k row
+    T.lg_G = lgG;
+    T.nloop = (T.out + (CV << lgG) - 1) / (CV << lgG);    // pieces per lane, <= 4
+    T.pad0 = T.pad1 = 0;
+}
+// every 64-byte line of a large block of kernel arguments requested at once (eh_kernarg_warm's idea, eh_device.hpp, for blocks beyond
+// its twelve lines): the table of layers is read phase by phase, and every cold line is a memory round trip on the critical path
+template <int LINE0, int BYTES, class KA>
+__device__ __forceinline__ void eh_kernarg_warm4(const KA ka) {
+    if constexpr (64 * LINE0 < BYTES) {
+        unsigned d0, d1 = 0u, d2 = 0u, d3 = 0u;
+        asm volatile("s_load_dword %0, %1, %2" : "=&s"(d0) : "s"(ka), "n"(64 * LINE0));
+        if constexpr (64 * (LINE0 + 1) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d1) : "s"(ka), "n"(64 * (LINE0 + 1)));
+        if constexpr (64 * (LINE0 + 2) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d2) : "s"(ka), "n"(64 * (LINE0 + 2)));
+        if constexpr (64 * (LINE0 + 3) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d3) : "s"(ka), "n"(64 * (LINE0 + 3)));
+        eh_kernarg_warm4<LINE0 + 4, BYTES>(ka);
+        // (the destinations stay allocated up to the wait the outermost call ends with: a register handed out earlier would be overwritten when its load lands)
+        asm volatile("" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+template <int BYTES>
+__device__ __forceinline__ void eh_kernarg_warm_big() {
+    static_assert(BYTES <= 4096, "kernel arguments");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    eh_kernarg_warm4<0, BYTES>(ka);
+}
+inline size_t eh_ltail_lds_bytes(int R, int nl, int wmax, bool any_swish) {
+    const size_t WP = (size_t)wmax + EH_LTAIL_PAD;
+    return sizeof(float) * ((size_t)(nl + 1) * R * WP * (any_swish ? 3 : 2) + (size_t)R * (EH_LTAIL_RED + EH_LTAIL_RED2) + 2 * 16 * 64 +
+                            (EH_MAX_FORC + EH_MAX_TARG) * 64 + ((EH_IMG_META + 3) & ~3) + (size_t)nl * wmax);
+}
+// sum over the 1 << lg lanes of a lane group (aligned, lg <= 6), every lane of the group gets it: DPP inside rows of 16, the crossbar for 32 / 64
+__device__ __forceinline__ float eh_group_sum(float v, const int lg) {
+    if (lg >= 1) v += eh_dpp<0xB1>(v);      // quad_perm:[1,0,3,2]
+    if (lg >= 2) v += eh_dpp<0x4E>(v);      // quad_perm:[2,3,0,1]
+    if (lg >= 3) v += eh_dpp<0x141>(v);     // row_half_mirror
+    if (lg >= 4) v += eh_dpp<0x140>(v);     // row_mirror
+    if (lg >= 5) v += __shfl_xor(v, 16, 64);
+    if (lg >= 6) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int R, bool PROG, bool LPROG>
+__global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel(const EhNet net, const EhStepArgs a, const EhLTailArgs t, const float* meta_g) {
+    extern __shared__ __attribute__((aligned(16))) float eh_lt_smem[];
+    constexpr int NTH = EH_LTAIL_THREADS, NWV = NTH / 64, SR = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = t.wmax, WP = W + EH_LTAIL_PAD, nl = t.nl;
+    float* const hb = eh_lt_smem;                                        // [(nl + 1)][R][WP]: hb[0] = the input rows, hb[l + 1] = layer l's activations (last: raw outputs); zero beyond a row's width
+    float* const zb = hb + (size_t)(nl + 1) * R * WP;                    // the same for pre-activations (swish layers only)
+    float* const dd = zb + (t.any_swish ? (size_t)(nl + 1) * R * WP : 0); // [(nl + 1)][R][WP] deltas: dd[j] = d loss / d (input of layer j), dd[nl] = d loss / d (raw outputs); zero beyond a row's width
+    float* const red = dd + (size_t)(nl + 1) * R * WP;                   // [R][EH_LTAIL_RED] k-slice partials
+    float* const red2 = red + (size_t)R * EH_LTAIL_RED;                  // [R][EH_LTAIL_RED2] their sums in groups of eight
+    float* const OS = red2 + (size_t)R * EH_LTAIL_RED2;                  // mechanistic stage: [16][SR] parameters -> d loss / d output
+    float* const SG = OS + 16 * SR;
+    float* const RS = SG + 16 * SR;
+    float* const metas = RS + (EH_MAX_FORC + EH_MAX_TARG) * SR;
+    float* const bb = metas + ((EH_IMG_META + 3) & ~3);                  // [nl][W] biases
+    const int count = (int)a.count, row0 = (int)blockIdx.x * R;
+    // The kernel is a chain of a dozen short phases; what each of them costs is a memory round trip plus the instructions every wave
+    // issues (stamps of the first versions, tools/stamps_lform.py: 27 us = 65 k cycles, 7-12 k per phase -- ONE thread per output adding
+    // 64 k-slice partials from LDS one after the other, butterfly sums issued one at a time, barriers waiting for global stores; then
+    // 22 us: sixteen waves walking through index arithmetic with run-time divisors, a branch per predicated load, the finishing of a
+    // delta product -- cross-lane sums and act' -- done by every lane for every row).  Hence: eight waves; the geometry of every
+    // product comes from the host as shifts; rows in LDS are zero beyond their width, so the last k slice reads on instead of
+    // branching; a lane of a delta product takes up to four pieces of its row, so that a row is eight lanes and its sum three DPP
+    // steps; and the weights of the NEXT product are requested before the sums of the current one are finished, so that a phase
+    // finds them in registers.  Everything that does not depend on the rows is asked for at the start, in one round of requests.
+    EH_STAMP(0);
+    eh_kernarg_warm_big<(int)(sizeof(EhNet) + sizeof(EhStepArgs) + sizeof(EhLTailArgs) + 8)>();
+    EH_STAMP(1);
+    // ---- weight fragments of the two kinds of product --------------------------------------------------------------------------------
+    // forward: thread (ks, g) -- the first FD rows of its k slice, columns n0 .. n0 + 3 (or n0)
+    constexpr int FD = EH_LTAIL_FD, BU = EH_LTAIL_BU;
+    auto fwd_load = [&](const EhLTailLayer& L, f32x4 (&w)[FD]) {
+        const int g = tid & ((1 << L.lg_ng) - 1), ks = tid >> L.lg_ng, n0 = L.vec ? 4 * g : g, k0 = ks * L.kper;
+        if (n0 < L.out && ks < L.KS) {
+#pragma unroll
+            for (int u = 0; u < FD; ++u)
+                if (u < L.kper) {                                         // (the same for every thread: a scalar branch)
+                    const float* const q = L.W + (long long)min(k0 + u, L.in - 1) * L.out + n0;      // (rows past the end: the last row again, times the zeros behind the input)
+                    if (L.vec) w[u] = *(const f32x4*)q; else w[u] = f32x4{*q, 0.0f, 0.0f, 0.0f};
+                }
+        }
+    };
+    // delta product: lane (kr, gl) of wave w -- rows kb + u RP + kr (u < BU, RP = rows of a pass of the workgroup), pieces gl + it G (it < nloop <= 4)
+    auto bwd_load = [&](const EhLTailLayer& L, f32x4 (&w)[BU][4]) {
+        const int lg_G = L.lg_G, rpw = 64 >> lg_G, gl = lane & ((1 << lg_G) - 1), kr = lane >> lg_G, CV = L.vec ? 4 : 1, kb = wave * rpw;
+#pragma unroll
+        for (int u = 0; u < BU; ++u)
+            if (kb + u * NWV * rpw < L.in) {                              // (per wave: scalar)
+                const float* const row = L.W + (long long)min(kb + u * NWV * rpw + kr, L.in - 1) * L.out;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    if (it < L.nloop) {
+                        const float* const q = row + min((gl + (it << lg_G)) * CV, L.out - CV);      // (columns past the end: the last ones again, times the zeros behind the delta)
+                        if (L.vec) w[u][it] = *(const f32x4*)q; else w[u][it] = f32x4{*q, 0.0f, 0.0f, 0.0f};
+                    }
+            }
+    };
+    // this workgroup's rows of the input, the first product's weights, the records: all requested before anything is waited for
+    float xin[R][(EH_LTAIL_MAXW + NTH - 1) / NTH], zin[R][(EH_LTAIL_MAXW + NTH - 1) / NTH];
+    {
+        const int in0 = t.L[0].in;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < (EH_LTAIL_MAXW + NTH - 1) / NTH; ++j) {
+                const int k = tid + j * NTH, row = row0 + r;
+                const bool ok = k < in0 && row < count;
+                xin[r][j] = ok ? t.Hin[(long long)row * t.ldin + k] : 0.0f;
+                zin[r][j] = (ok && t.Zin) ? t.Zin[(long long)row * in0 + k] : 0.0f;
+            }
+    }
+    f32x4 wf[FD];
+    if (nl > 1) fwd_load(t.L[0], wf);
+    // The suffix's weights (one contiguous range of theta: [W | b] layer after layer) were rewritten by the optimiser kernel of the step
+    // before: the first request for a line from this XCD goes past its L2 -- about 3 k cycles, which a fetch one phase ahead does not
+    // cover.  The workgroups of an XCD (blockIdx mod 8 under round-robin dispatch; nothing depends on it) share the range between them:
+    // one load per 64-byte line, summed into a value that is looked at when the kernel ends.  (Every workgroup touching the whole range
+    // was tried first: it doubles the bytes a CU pulls through its 64-byte-per-clock port.)
+    float touch[4];
+    {
+        const float* const w0 = t.L[0].W;
+        const long long wn = (t.L[nl - 1].b + t.L[nl - 1].out) - w0;
+        const int part8 = ((int)blockIdx.x >> 3) & 7;
+        const long long seg = ((wn + 7) / 8 + 15) & ~15ll, s0 = part8 * seg, s1 = min(wn, s0 + seg);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long e = s0 + 16ll * tid + 16ll * NTH * u; touch[u] = w0[e < s1 ? e : 0]; }      // (up to 32 k floats per workgroup, 256 k per XCD)
+    }
+    for (int e = tid; e < (nl + 1) * R * WP * (t.any_swish ? 3 : 2); e += NTH) hb[e] = 0.0f;
+    if (wave == 0) {
+        const int n_loc = row0 + lane;
+        const bool live = lane < R && n_loc < count;
+        const long long n_glb = live ? (a.idx ? (long long)a.idx[a.first + n_loc] : a.first + n_loc) : 0;
+        const float* const rec = a.recs + n_glb * a.C;
+#pragma unroll
+        for (int f = 0; f < EH_MAX_FORC; ++f) RS[f * SR + lane] = (f < net.F && live) ? rec[net.P + f] : 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < EH_MAX_TARG; ++tt) RS[(EH_MAX_FORC + tt) * SR + lane] = (tt < net.T && live) ? rec[net.P + net.F + tt] : __builtin_nanf("");
+    } else if (wave == 1) {
+        for (int e = lane; e < EH_IMG_META; e += 64) metas[e] = meta_g[e];
+    }
+    for (int l = wave; l < nl; l += NWV) {
+        const float* const bp = t.L[l].b; const int out = t.L[l].out;
+        for (int n = lane; n < out; n += 64) bb[l * W + n] = bp[n];
+    }
+    eh_lds_barrier();                                                    // (the zeros are down before the rows go on top of them)
+    {
+        const int in0 = t.L[0].in;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < (EH_LTAIL_MAXW + NTH - 1) / NTH; ++j) {
+                const int k = tid + j * NTH;
+                if (k < in0) { hb[r * WP + k] = xin[r][j]; if (t.Zin) zb[r * WP + k] = zin[r][j]; }
+            }
+    }
+    eh_lds_barrier();
+    EH_STAMP(2);
+    // ---- forward through the suffix ---------------------------------------------------------------------------------------------
+    // (the network's output layer, at most 16 outputs, is not one of these products: it runs with the mechanistic stage below)
+    f32x4 wb[BU][4];
+    for (int l = 0; l + 1 < nl; ++l) {
+        const EhLTailLayer L = t.L[l];
+        const int in = L.in, out = L.out, KS = L.KS, kper = L.kper, lg_ostr = L.lg_ostr, ostr = 1 << lg_ostr;
+        const int g = tid & ((1 << L.lg_ng) - 1), ks = tid >> L.lg_ng, n0 = L.vec ? 4 * g : g;
+        const float* const hin = hb + (size_t)l * R * WP;
+        float acc[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0f; }
+        if (n0 < out && ks < KS) {
+            const int k0 = ks * kper;
+            for (int kb = 0; kb < kper; kb += FD) {                       // (kper is the same for every thread: the branches below are scalar)
+                if (kb > 0) {                                             // a slice of more than FD rows: the later batches are fetched here
+#pragma unroll
+                    for (int u = 0; u < FD; ++u)
+                        if (kb + u < kper) {
+                            const float* const q = L.W + (long long)min(k0 + kb + u, in - 1) * out + n0;
+                            if (L.vec) wf[u] = *(const f32x4*)q; else wf[u] = f32x4{*q, 0.0f, 0.0f, 0.0f};
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < FD; ++u)
+                    if (kb + u < kper) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const float hv = hin[r * WP + k0 + kb + u];
+                            if (L.vec) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(hv, wf[u][c], acc[r][c]);
+                            } else acc[r][0] = fmaf(hv, wf[u][0], acc[r][0]);
+                        }
+                    }
+            }
+        }
+        if (l == 0) EH_STAMP(12);
+        if (ks < KS) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (L.vec) *(f32x4*)&red[r * EH_LTAIL_RED + ks * ostr + n0] = f32x4{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+                else red[r * EH_LTAIL_RED + ks * ostr + n0] = acc[r][0];
+            }
+        }
+        // the next product's weights are on their way while this one's sums are finished
+        if (l + 2 < nl) fwd_load(t.L[l + 1], wf);
+        else if (l > 0 || t.Dbelow) bwd_load(t.L[l], wb);        // (the last of them: the first delta product's, across the output layer and the mechanistic stage)
+        eh_lds_barrier();
+        // the k slices of an output are added in two levels -- groups of eight, then the groups -- both in k order (deterministic), the
+        // first by as many threads as there are groups x outputs
+        const float* src = red;
+        int nsrc = KS, sstr = EH_LTAIL_RED;
+        if (KS > 8) {
+            const int KS1 = (KS + 7) >> 3;
+            for (int e = tid; e < (KS1 << lg_ostr); e += NTH) {
+                const int j = e >> lg_ostr, n = e & (ostr - 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float* const pp = red + r * EH_LTAIL_RED + ((8 * j) << lg_ostr) + n;
+                    float pv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pv[i] = pp[min(i, KS - 1 - 8 * j) << lg_ostr];
+                    float v = pv[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) v += 8 * j + i < KS ? pv[i] : 0.0f;
+                    red2[r * EH_LTAIL_RED2 + e] = v;
+                }
+            }
+            eh_lds_barrier();
+            src = red2; nsrc = KS1; sstr = EH_LTAIL_RED2;
+        }
+        if (l == 0) EH_STAMP(13);
+        const bool last = l + 1 == nl;
+        float* const hout = hb + (size_t)(l + 1) * R * WP;
+        float* const zout = zb + (size_t)(l + 1) * R * WP;
+        for (int n = tid; n < out; n += NTH) {
+            const float bias = bb[l * W + n];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = src[r * sstr + (min(i, nsrc - 1) << lg_ostr) + n];
+                float v = pv[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) v += i < nsrc ? pv[i] : 0.0f;
+                v += bias;
+                if (!last) {
+                    const float hv = eh_act_rt(L.act, v);
+                    hout[r * WP + n] = hv;
+                    if (L.act == EH_ACT_SWISH) zout[r * WP + n] = v;
+                } else hout[r * WP + n] = v;
+            }
+        }
+        if (l == 0) EH_STAMP(14);
+        eh_lds_barrier();
+        EH_STAMP(3 + l);
+    }
+    // ---- the output layer (K <= 16 outputs): an output per wave, lanes over k, the sum on the DPP network -----------------------------
+    {
+        const EhLTailLayer T = t.L[nl - 1];
+        const float* const hin = hb + (size_t)(nl - 1) * R * WP;
+        float* const oraw = hb + (size_t)nl * R * WP;
+        for (int n = wave; n < T.out; n += NWV) {
+            float wv[EH_LTAIL_MAXW / 64];
+#pragma unroll
+            for (int j = 0; j < EH_LTAIL_MAXW / 64; ++j) { const int k = lane + 64 * j; wv[j] = k < T.in ? T.W[(long long)k * T.out + n] : 0.0f; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < EH_LTAIL_MAXW / 64; ++j) sacc = fmaf(hin[r * WP + lane + 64 * j], wv[j], sacc);
+                const float sum = eh_wave_sum(sacc);
+                if (lane == 0) oraw[r * WP + n] = sum + bb[(nl - 1) * W + n];
+            }
+        }
+    }
+    eh_lds_barrier();
+    EH_STAMP(3 + nl - 1);
+    // ---- mechanistic model + masked loss + its pullback: wave 0, lane r = row r of this workgroup ---------------------------------
+    float* const dcur0 = dd + (size_t)nl * R * WP;
+    float* const psum = red;                                             // (the k-slice partials are done with) this workgroup's row of partial sums
+    if (wave == 0) {
+        auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
+        auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
+        const float* const oraw = hb + (size_t)nl * R * WP;
+        const int K = t.L[nl - 1].out;
+        const int n_loc = row0 + lane;
+        const bool live = lane < R && n_loc < count;
+        for (int k = 0; k < 16; ++k) { OS[k * SR + lane] = 0.0f; SG[k * SR + lane] = 1.0f; }
+        for (int k = 0; k < K; ++k) {
+            const float ov = live ? oraw[lane * WP + k] : 0.0f;
+            float pv = ov, sv = 1.0f;
+            if (net.scale_nn) {
+                float lo = 0.0f, sc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                    if (j < net.n_par && pkind(j) == EH_PAR_NEURAL && pidx(j) == k) { lo = metas[EH_IMG_LO + j]; sc = metas[EH_IMG_SC + j]; }
+                const float sgm = eh_sigmoid(ov);
+                pv = fmaf(sc, sgm, lo);
+                sv = sc * sgm * (1.0f - sgm);
+            }
+            OS[k * SR + lane] = pv; SG[k * SR + lane] = sv;
+        }
+        EhMechAcc MA;
+        MA.clear();
+        eh_mech_stage_lane<true, PROG, LPROG>(net, a, lane, live, n_loc, SR, RS, OS, SG, metas, MA);
+        if (lane < R) {
+            for (int k = 0; k < K; ++k) {
+                const float d = live ? OS[k * SR + lane] : 0.0f;
+                dcur0[lane * WP + k] = d;
+            }
+        }
+        float v[EH_LMECH_PART];
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) v[j] = (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) ? MA.gacc[j] * metas[EH_IMG_DPHI + j] : 0.0f;
+        v[8] = MA.lacc;
+#pragma unroll
+        for (int tt = 0; tt < EH_MAX_TARG; ++tt) v[9 + tt] = MA.cacc[tt];
+        v[13] = MA.syacc; v[14] = MA.syyacc; v[15] = 0.0f;
+        // (rows r < R <= 4 are the only lanes with a sample: their sums in lane order, no butterfly over 64 lanes -- one store per column from lane k)
+        float mine = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EH_LMECH_PART; ++k) {
+            float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), 0));
+#pragma unroll
+            for (int r = 1; r < R; ++r) s += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), r));
+            mine = lane == k ? s : mine;
+        }
+        if (lane < EH_LMECH_PART) psum[lane] = mine;
+    }
+    eh_lds_barrier();
+    EH_STAMP(8);
+    // ---- deltas back down: dZ_{l-1}[r][k] = (sum_n dZ_l[r][n] W_l[k][n]) act'(h_{l-1}[r][k]) --------------------------------------
+    if (nl - 1 > 0 || t.Dbelow) {        // across the output layer: a thread per k, its K weights are adjacent
+        const EhLTailLayer T = t.L[nl - 1];
+        const int actp = nl - 1 > 0 ? t.L[nl - 2].act : t.act_below;
+        const float* const hp = (actp == EH_ACT_SWISH ? zb : hb) + (size_t)(nl - 1) * R * WP;
+        float* const dn = dd + (size_t)(nl - 1) * R * WP;
+        for (int k = tid; k < T.in; k += NTH) {
+            float wv[16];
+#pragma unroll
+            for (int n = 0; n < 16; ++n) wv[n] = n < T.out ? T.W[(long long)k * T.out + n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int n = 0; n < 16; ++n) sacc = n < T.out ? fmaf(dcur0[r * WP + n], wv[n], sacc) : sacc;
+                dn[r * WP + k] = sacc * eh_dact_rt(actp, hp[r * WP + k]);
+            }
+        }
+        eh_lds_barrier();
+        EH_STAMP(9);
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        if (l == 0 && !t.Dbelow) break;
+        const EhLTailLayer L = t.L[l];
+        const int in = L.in, out = L.out, CV = L.vec ? 4 : 1, lg_G = L.lg_G;
+        const int actp = l > 0 ? t.L[l - 1].act : t.act_below;
+        const float* const dz = dd + (size_t)(l + 1) * R * WP;
+        float* const dn = dd + (size_t)l * R * WP;
+        const float* const hp = (actp == EH_ACT_SWISH ? zb : hb) + (size_t)l * R * WP;
+        const int rpw = 64 >> lg_G;                                      // k rows per wave and pass
+        const int gl = lane & ((1 << lg_G) - 1), kr = lane >> lg_G;
+        for (int kb = wave * rpw; kb < in; kb += NWV * rpw * BU) {
+            if (kb != wave * rpw) {                                      // more than BU passes: the later rows' weights are fetched here
+                EhLTailLayer Lk = L;
+                Lk.W = L.W + (long long)(kb - wave * rpw) * out; Lk.in = in - (kb - wave * rpw);
+                bwd_load(Lk, wb);
+            }
+            float p[BU][R];
+#pragma unroll
+            for (int u = 0; u < BU; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) p[u][r] = 0.0f;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (it < L.nloop) {
+                    const int n0 = (gl + (it << lg_G)) * CV;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (L.vec) {
+                            const f32x4 d4 = *(const f32x4*)&dz[r * WP + n0];
+#pragma unroll
+                            for (int u = 0; u < BU; ++u)
+                                if (kb + u * NWV * rpw < in) p[u][r] = fmaf(d4[3], wb[u][it][3], fmaf(d4[2], wb[u][it][2], fmaf(d4[1], wb[u][it][1], fmaf(d4[0], wb[u][it][0], p[u][r]))));
+                        } else {
+                            const float d1 = dz[r * WP + n0];
+#pragma unroll
+                            for (int u = 0; u < BU; ++u)
+                                if (kb + u * NWV * rpw < in) p[u][r] = fmaf(d1, wb[u][it][0], p[u][r]);
+                        }
+                    }
+                }
+            if (l == 0) EH_STAMP(6);
+#pragma unroll
+            for (int u = 0; u < BU; ++u)
+                if (kb + u * NWV * rpw < in) {
+                    const int k = kb + u * NWV * rpw + kr;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float sum = eh_group_sum(p[u][r], lg_G);
+                        if (gl == 0 && k < in) dn[r * WP + k] = sum * eh_dact_rt(actp, hp[r * WP + k]);
+                    }
+                }
+        }
+        if (l == 0) EH_STAMP(7);
+        // the next delta product's weights while this one's rows go out
+        if (l - 1 > 0 || (l - 1 == 0 && t.Dbelow)) bwd_load(t.L[l - 1], wb);
+        eh_lds_barrier();
+        EH_STAMP(9 + (nl - 1 - l));
+    }
+    // ---- everything the weight-gradient products need goes out NOW, in one round of stores: a store in the middle of the chain made
+    // the next wait for a prefetched weight a wait for the store's acknowledgement as well (loads and stores share one counter)
+    for (int j = 0; j < nl; ++j) {
+        const EhLTailLayer L = t.L[j];
+        const bool hidden = j + 1 < nl;
+        float* const dst = j > 0 ? t.L[j - 1].D : t.Dbelow;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (row < count) {
+                if (hidden)
+                    for (int n = tid; n < L.out; n += NTH) {
+                        L.H[(long long)row * L.out + n] = hb[((size_t)(j + 1) * R + r) * WP + n];
+                        if (L.Z) L.Z[(long long)row * L.out + n] = zb[((size_t)(j + 1) * R + r) * WP + n];
+                    }
+                if (dst)
+                    for (int k = tid; k < L.in; k += NTH) dst[(long long)row * L.in + k] = dd[((size_t)j * R + r) * WP + k];
+            }
+        }
+    }
+    {
+        const int K = t.L[nl - 1].out;
+        for (int e = tid; e < R * K; e += NTH) {
+            const int r = e / K, k = e - r * K, row = row0 + r;
+            if (row < count) t.O[(long long)k * t.ldo + row] = dd[((size_t)nl * R + r) * WP + k];
+        }
+        if (tid < EH_LMECH_PART) t.part[(long long)blockIdx.x * EH_LMECH_PART + tid] = psum[tid];
+    }
+    if (touch[0] + touch[1] + touch[2] + touch[3] == -1.2345e-30f) t.part[(long long)blockIdx.x * EH_LMECH_PART + EH_LMECH_PART - 1] = 0.0f;      // (keeps the warming loads; column 15 is padding, 0 either way)
+    EH_STAMP(15);
 }

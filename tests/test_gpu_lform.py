@@ -386,3 +386,85 @@ def test_small_minibatches_take_the_split_k_and_streaming_kernels(B, hidden):
     l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()})
     assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
     eng.close()
+
+
+# ---- round 6: few rows -- the narrow end of a one-network model as ONE launch (eh_lform_tailchain_kernel) ---------------------------
+def _expo2pool_case(n_pred, hidden, act, B, seed=5, nan=0.1):
+    rng = np.random.default_rng(seed)
+    spec = ho.HybridSpec(n_pred, list(hidden), "expo2pool", dict(ho.EXPO2POOL_PARAMS), ["R0a", "ka", "R0b", "kb"], [], ["Resp_obs"], act, True)
+    X = rng.random((n_pred, B)).astype(np.float32)
+    f = {"T": (rng.random(B) * 40 - 10).astype(np.float32)}
+    yv = (1.0 + rng.random(B)).astype(np.float32); yv[rng.random(B) < nan] = np.nan
+    return spec, ho.init_theta(spec, 9, np.float32), X, f, {"Resp_obs": yv}
+
+
+@pytest.mark.parametrize("B", [1, 37, 64, 65, 130, 256])
+def test_few_rows_tutorial_network(B):
+    """one row per workgroup up to 64 rows, four from there to 256 (partial last workgroup, a single sample, the largest minibatch the
+    path takes); 257 rows and more run the products launch by launch as before"""
+    _check(*util.rbq10_case(B, "sigmoid", True, 0.1, hidden=TUTORIAL))
+
+
+@pytest.mark.parametrize("act,hidden,n_pred,B", [
+    ("tanh", (40, 30, 20, 10), 8, 64),          # every layer narrow: the whole network is the suffix (its first layer reads the minibatch matrix); out = 30, 10: 4-byte loads
+    ("swish", (96, 80, 64, 48), 8, 200),        # pre-activations kept for act'
+    ("relu", (300, 150), 12, 100),              # 12 -> 300 stays a product of its own (300 > 256); the suffix starts at a layer whose input it reads back
+    ("swish", (512, 200, 36), 5, 50),           # the layer BELOW the suffix is swish: its pre-activation is read for the delta that leaves the chain
+    ("identity", (129,), 3, 64),
+])
+def test_few_rows_other_shapes(act, hidden, n_pred, B):
+    _check(*_expo2pool_case(n_pred, hidden, act, B))
+
+
+def test_few_rows_gathered_minibatch_two_targets_and_training():
+    rng = np.random.default_rng(8)
+    N = 500
+    pars = {"RUE": (0.1, 0.0, 1.0), "Rb": (1.0, 0.0, 6.0), "Q10": (1.5, 1.0, 4.0)}
+    spec = ho.HybridSpec(6, [160, 96, 48, 24], "fluxpart", pars, ["RUE", "Rb"], ["Q10"], ["NEE", "GPP"], "tanh", True)
+    X = rng.standard_normal((6, N)).astype(np.float32)
+    f = {"SW_IN": (rng.random(N) * 400).astype(np.float32), "TA": (rng.random(N) * 30).astype(np.float32)}
+    y = {"NEE": rng.standard_normal(N).astype(np.float32), "GPP": (rng.random(N) * 3).astype(np.float32)}
+    y["NEE"][rng.random(N) < 0.2] = np.nan; y["GPP"][rng.random(N) < 0.1] = np.nan
+    theta = ho.init_theta(spec, 3, np.float32)
+    eng = util.load_engine(spec, theta, X, f, y)
+    for nb in (64, 150):
+        idx = rng.permutation(N)[:nb].astype(np.int32)
+        _check(spec, theta, X, f, y, eng=eng, idx=idx)
+    eng.close()
+    # an Adam trajectory over minibatches of 64 and the epoch driver, the reference's default batch size (src/config/TrainingConfig.jl:14)
+    spec, theta, X, f, y = util.rbq10_case(1024, "tanh", True, 0.1, hidden=(160, 80, 40, 20))
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.opt_init("Adam", 0.01)
+    batches = [(i * 64, 64) for i in range(6)] + [(400, 200)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th_ref, l_ref = ho.train_steps(spec, theta, X, f, y, batches, dtype=np.float32)
+    assert np.allclose(losses, l_ref, rtol=2e-5)
+    d = np.abs(eng.get_params() - th_ref)
+    assert np.mean(d <= 2e-5) >= 0.999 and d.max() <= 8 * 0.01 * 1.01
+    mean_loss, nsteps = eng.train_epoch(64, seed=5, shuffle=True)
+    assert nsteps == 16 and np.isfinite(mean_loss)
+    eng.close()
+
+
+def test_few_rows_recorded_closure_and_recorded_loss():
+    """a recorded mechanistic closure and a recorded loss function at the tutorial's batch size: the chain's mechanistic stage interprets both tapes"""
+    from tests import closures
+    spec, theta, X, f, y = util.rbq10_case(64, "sigmoid", True, 0.1, hidden=(160, 64, 32, 16))
+    util.register_loss("huber_lform", _huber)
+    eng = util.load_engine(spec, theta, X, f, y)
+    eng.set_training_loss(_huber)
+    loss, grad, nv = eng.loss_and_grad()
+    l0, g0, nv0 = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind="huber_lform")
+    assert nv == sum(nv0) and abs(loss - l0) <= TOL * abs(l0) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
+    eng.close()
+    # the three-output flux closure (tests/closures.py) behind a network only the layer-wise form holds, two of its outputs as targets
+    util.register_closure("flux_closure", closures.flux_closure, list(closures.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee", "gpp"])
+    spec = ho.HybridSpec(3, [144, 72, 36, 18], "flux_closure", dict(closures.FLUX_TABLE), ["alpha", "gmax", "rref"], ["e0", "k"], ["nee", "gpp"], "tanh", True)
+    rng = np.random.default_rng(31)
+    B = 100
+    X = rng.uniform(-1, 1, (3, B)).astype(np.float32)
+    f = {"sw": rng.uniform(0, 800, B).astype(np.float32), "ta": rng.uniform(-5, 30, B).astype(np.float32), "vpd": rng.uniform(0, 30, B).astype(np.float32)}
+    truth = ho.forward(spec, ho.init_theta(spec, 33, np.float32).astype(np.float64), X, f)
+    y = {t: (truth[t] * (1.0 + 0.05 * rng.normal(size=B))).astype(np.float32) for t in spec.targets}
+    y["nee"][rng.uniform(size=B) < 0.1] = np.nan
+    _check(spec, ho.init_theta(spec, 32, np.float32), X, f, y)
