@@ -1466,7 +1466,10 @@ static void lform_gemm(eh_handle* h, const EhGemmArgs& g, int nz) {
                 const int nw = (g.K + p.kchunk - 1) / p.kchunk;
                 static const int few32 = getenv("EH_GEMM_FEW32_MIN") ? atoi(getenv("EH_GEMM_FEW32_MIN")) : 512;       // rows from which the 32 x 32 tile runs
                 if (g.M >= few32) hipLaunchKernelGGL((eh_fewrows32_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 31) / 32), (unsigned)((g.M + 31) / 32)), dim3(64u * (unsigned)nw), 0, h->stream, p);
-                else hipLaunchKernelGGL((eh_fewrows_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nw), 0, h->stream, p);
+                else {
+                    hipLaunchKernelGGL((eh_fewrows_gemm_kernel<BTR, EPI>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nw), 0, h->stream, p);
+                    if (p.job_part) h->l_job_done = true;      // (the one product kernel that takes the side job, EhGemmArgs::job_part)
+                }
                 return;
             }
         }
@@ -1620,7 +1623,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     }
     if (int rc = lform_forward(h, sp, idx, first, count, true, bn_update, W, tail_s)) return rc;
     EhStepArgs a{};
-    a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count; a.stamps = h->stamps;
+    a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count; a.stamps = getenv("EH_STAMP_DW") ? nullptr : h->stamps;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];
     if (tpm) {
         // losses that need batch statistics of yhat (see launch_train_kernel): the NN outputs O stay where the forward left them, so
@@ -1725,6 +1728,9 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     // backward, every network from its output layer down; dZ of the output layer = its rows of d loss / d O^T, still [K][ldo]
     const float* theta = TH(h);
     EhGemmGroup GG{}; EhThinGroup TG{};
+    float* tot_job = nullptr;              // where a delta product's side job leaves the sums of the chain's partial rows (only the few-rows product kernel takes the job: l_job_done)
+    h->l_job_done = false;
+    bool all_grouped = true;               // every weight-gradient product of the step sits in GG / TG (none launched on its own, no group flushed early)
     auto flush_tiled = [&]() {
         if (GG.n > 0) hipLaunchKernelGGL((eh_gemm_group_kernel<true, false, EH_GEPI_STORE, true, 64>), dim3((unsigned)GG.t0[GG.n]), dim3(256), 0, h->stream, GG);
         GG.n = 0;
@@ -1749,15 +1755,16 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
             g.colsum = h->slab + L.boff[l];      // db_l = column sums of dZ_l, from the same tiles
             EhThinArgs ta;
             if (grouped && lform_thin_args(g, dz_t, &ta)) {
-                if (TG.n == EH_GEMM_GROUP) { flush_thin(); HIPCHK(h, hipGetLastError()); }
+                if (TG.n == EH_GEMM_GROUP) { flush_thin(); all_grouped = false; HIPCHK(h, hipGetLastError()); }
                 const int gx = (ta.ncols + 63) / 64;
                 TG.a[TG.n] = ta; TG.gx[TG.n] = gx; TG.t0[TG.n + 1] = TG.t0[TG.n] + gx * rows; ++TG.n;
             } else if (grouped && !dz_t && eh_gemm_vec_ok(g, true, false)) {
-                if (GG.n == EH_GEMM_GROUP) { flush_tiled(); HIPCHK(h, hipGetLastError()); }
+                if (GG.n == EH_GEMM_GROUP) { flush_tiled(); all_grouped = false; HIPCHK(h, hipGetLastError()); }
                 const int gx = (g.N + 63) / 64, gy = (g.M + 63) / 64;
                 GG.g[GG.n] = g; GG.gx[GG.n] = gx; GG.gy[GG.n] = gy; GG.t0[GG.n + 1] = GG.t0[GG.n] + gx * gy * rows; ++GG.n;
             } else {
                 // (in grouped mode too: dZ_l stays where it is until the step ends)
+                all_grouped = false;
                 if (dz_t) lform_gemm<true, true, EH_GEPI_STORE>(h, g, rows); else lform_gemm<true, false, EH_GEPI_STORE>(h, g, rows);
                 HIPCHK(h, hipGetLastError());
             }
@@ -1767,6 +1774,10 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
                 float* const dnext = grouped ? dkp : W.D[which];
                 if (grouped) dkp += dk_rows * in;
                 if (!(tail_s >= 0 && l >= tail_s)) {      // (the tail chain has left this delta where the weight gradients look for it)
+                    if (tjob.part && !h->l_job_done && h->l_apply && rows == 1) {      // (its first workgroup also adds up the chain's rows of partial sums: eh_dw_apply_kernel finds them ready)
+                        b.job_part = tjob.part; b.job_nblk = tjob.nblk; b.job_out = W.part + (size_t)2048 * EH_LMECH_PART;
+                        tot_job = b.job_out;
+                    }
                     b.C = dnext; b.ldc = in; b.M = B; b.N = in; b.K = out; b.kchunk = out; b.c_zstride = 0;
                     b.H = L.lact[l - 1] == EH_ACT_SWISH ? W.Z[k][l - 1] : W.H[k][l - 1]; b.ldh = in; b.act = L.lact[l - 1];
                     if (dz_t) lform_gemm<true, true, EH_GEPI_DACT>(h, b, 1); else lform_gemm<false, true, EH_GEPI_DACT>(h, b, 1);
@@ -1777,6 +1788,20 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         }
     }
     static const bool nodwmerge = getenv("EH_LFORM_NODWMERGE") != nullptr;
+    static const bool noapply = getenv("EH_LFORM_NOAPPLY") != nullptr;
+    if (h->l_apply && !noapply && tjob.part && all_grouped && rows == 1) {
+        // one slab row: the products ARE the gradient -- the optimiser runs in their epilogues (eh_dw_apply_kernel), no reduce launch behind them
+        EhLApply ap = *h->l_apply;
+        ap.slab = h->slab; ap.part = tjob.part; ap.nblk = tjob.nblk; ap.tot = h->l_job_done ? tot_job : nullptr;
+        static const bool stamp_dw = getenv("EH_STAMP_DW") != nullptr;      // (diagnostic builds: the stamps of this launch instead of the chain kernel's)
+        ap.stamps = stamp_dw ? h->stamps : nullptr;
+        ap.stamp_wg = stamp_dw ? atoi(getenv("EH_STAMP_DW")) : 0;
+        if (ap.stamp_wg < 0) ap.stamp_wg += TG.t0[TG.n] + GG.t0[GG.n] + 1;
+        hipLaunchKernelGGL(eh_dw_apply_kernel, dim3((unsigned)(TG.t0[TG.n] + GG.t0[GG.n] + 1)), dim3(256), 0, h->stream, GG, TG, net, ap);
+        HIPCHK(h, hipGetLastError());
+        h->l_applied = true;
+        return EH_OK;
+    }
     if (tjob.part || (TG.n > 0 && GG.n > 0 && !nodwmerge)) {       // what is left of both groups: one launch (+ the workgroup that sums the tail chain's partial rows)
         hipLaunchKernelGGL(eh_dw_group_kernel, dim3((unsigned)(TG.t0[TG.n] + GG.t0[GG.n] + (tjob.part ? 1 : 0))), dim3(256), 0, h->stream, GG, TG, tjob, net);
         TG.n = 0; GG.n = 0;
@@ -1961,13 +1986,34 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
         h->prof_k++;
     }
     int grid = 1;
-    int rc = launch_train_kernel(h, sp, idx, first, count, &grid, apply);
-    if (rc) return rc;
-    if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
     const int deferred = (net.T == 1 && !raw) ? 1 : 0;
     const unsigned tp_mask = two_pass_mask(net);
     const bool moment_loss = tp_mask != 0;
     const bool l2 = (h->img.l2c != 0.0f || h->img.l2w) && !raw;      // (data-parallel seam: raw sums only -- the extra loss is added once, in eh_dp_apply)
+    float* sc_in = h->sc + 2 * h->sc_sel;
+    float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
+    // layer-wise form, few rows: the optimiser may run in the epilogue of the grouped weight-gradient launch (lform_train decides; eh_lform.hpp EhLApply)
+    EhLApply lap{};
+    h->l_apply = nullptr; h->l_applied = false;
+    if (h->lform && apply && deferred && !l2 && !moment_loss && net.loss != EH_LOSS_PROGRAM) {
+        lap.theta = TH(h); lap.m = MM(h); lap.v = VV(h); lap.sc_in = sc_in; lap.sc_out = sc_out; lap.o = h->opt; lap.loss_slot = loss_slot; lap.gradbuf = h->gradbuf;
+        lap.im = h->img; lap.loss_kind = h->net.loss; lap.n_theta = net.n_theta; lap.g_off = net.g_off;
+        h->l_apply = &lap;
+    }
+    int rc = launch_train_kernel(h, sp, idx, first, count, &grid, apply);
+    h->l_apply = nullptr;
+    if (rc) return rc;
+    if (prof && !burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+    if (h->l_applied) {                  // theta, the moments, the loss and the beta products are done
+        h->l_applied = false;
+        h->sc_sel ^= 1;
+        if (prof && burst_last) {
+            if (burst) HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+            HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
+            h->ev_used += 3;
+        }
+        return EH_OK;
+    }
     if (l2) {
         hipLaunchKernelGGL(eh_weight_l2_kernel, dim3(1), dim3(256), 0, h->stream, TH(h), h->img, h->l2val);
         HIPCHK(h, hipGetLastError());
@@ -1981,8 +2027,6 @@ static int do_step(eh_handle* h, const EhSplit& sp, const int* idx, long long fi
     static const bool nc1 = getenv("EH_REDUCE_NC1") != nullptr;
     const bool tall4 = tall && !nc1;                                   // four columns per thread
     const int rgrid = tall4 ? (h->n_acc + 1023) / 1024 : tall ? (h->n_acc + 255) / 256 : big ? (h->n_acc + 63) / 64 : (h->n_acc + 15) / 16;
-    float* sc_in = h->sc + 2 * h->sc_sel;
-    float* sc_out = h->sc + 2 * (h->sc_sel ^ 1);
 #define EH_REDUCE_GO(AP, ...)                                                                                                                       \
     hipLaunchKernelGGL((eh_reduce_kernel<AP, __VA_ARGS__>), dim3(rgrid), dim3(256), 0, h->stream, h->slab, grid, h->n_acc, net.n_theta, net.T, deferred, h->gradbuf, \
                        TH(h), MM(h), VV(h), sc_in, sc_out, h->opt, loss_slot, h->img, h->net.loss, (moment_loss && !raw) ? h->inv_n : nullptr, l2 ? h->l2val : nullptr, tp_mask)

@@ -19,7 +19,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EH_GEPI_STORE = 0, EH_GEPI_BIAS_ACT = 1, EH_GEPI_BIAS_T = 2, EH_GEPI_DACT = 3 };
+enum { EH_GEPI_STORE = 0, EH_GEPI_BIAS_ACT = 1, EH_GEPI_BIAS_T = 2, EH_GEPI_DACT = 3, EH_GEPI_APPLY = 4 };
 
 struct EhGemmArgs {
     const float* A; long long lda;       // !ATR: A[m][k] at A + m*lda + k ; ATR: A[k][m] at A + k*lda + m
@@ -34,7 +34,74 @@ struct EhGemmArgs {
     float* Z;                            // EH_GEPI_BIAS_ACT, nullable: the pre-activation, same layout as C (swish: act' needs it, the rounded h does not give it back)
     float* colsum;                       // (split-K weight gradients) nullable: colsum[z * c_zstride + n] = sum over the k chunk of B[k][n] -- the bias gradient,
                                          // taken from the B tiles the first row of workgroups stages anyway
+    // (eh_fewrows_gemm_kernel only) a side job for workgroup (0, 0): the rows of partial sums the mechanistic stage left (few-rows chain
+    // kernel) added up in the order of eh_lform_tail_sum -> job_out[16], so that the launch with the optimiser in its epilogues
+    // (eh_dw_apply_kernel) finds the step's normalisation ready instead of every workgroup adding the rows up again
+    const float* job_part; float* job_out; int job_nblk;
 };
+
+// The optimiser in the epilogue of the weight-gradient products (few rows, ONE slab row: the product IS the gradient, un-normalised):
+// the element that would have gone to the slab goes through the update rule into theta / m / v instead -- no slab row written and read
+// back, no reduce + optimiser launch behind the products (8.6 us of the tutorial net's 59 us step at batch 64).  EhLApply: what the
+// host hands over; EhLApplyS: what a workgroup keeps in LDS once it has the step's normalisation (the sums of the mechanistic stage).
+struct EhLApply {
+    float* slab; float* theta; float* m; float* v;
+    const float* sc_in; float* sc_out;
+    EhOpt o; float* loss_slot; float* gradbuf; EhImg im;
+    int loss_kind, n_theta, g_off;
+    const float* part; int nblk;         // the mechanistic stage's rows of partial sums ...
+    const float* tot;                    // ... or, non-null, their sums [16] (a side job of an earlier launch of the step, EhGemmArgs::job_out)
+    unsigned long long* stamps; int stamp_wg;      // diagnostic builds (-DEH_STAMPS): workgroup stamp_wg stamps its phases
+};
+struct EhLApplyS { float* slab; float* theta; float* m; float* v; EhOpt o; float scale, bt1, bt2; int go, use_m, use_v; unsigned long long* stamps; };
+#ifdef EH_STAMPS
+#define EH_LSTAMP(S, i) do { __builtin_amdgcn_sched_barrier(0); if ((S)->stamps && threadIdx.x == 0) { (S)->stamps[2 * (i)] = __builtin_readcyclecounter(); (S)->stamps[2 * (i) + 1] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EH_LSTAMP(S, i)
+#endif
+// (EhLApplyS lives in LDS and reaches the epilogues through a generic pointer: read through it element by element, every field was a
+//  flat load that had to be repeated behind every global store -- 13 k cycles for sixteen updates.  The epilogues take ONE copy into registers.)
+typedef __attribute__((address_space(1))) float eh_gfloat;      // (pointers that come out of an LDS copy are generic: say that they are global)
+__device__ __forceinline__ void eh_lapply_one(const EhLApplyS& S, const float* cslot, float gsum) {
+    const long long idx = cslot - S.slab;
+    eh_gfloat* const tp = (eh_gfloat*)S.theta; eh_gfloat* const mp = (eh_gfloat*)S.m; eh_gfloat* const vp = (eh_gfloat*)S.v;
+    float th = tp[idx], mm = S.use_m ? mp[idx] : 0.0f, vv = S.use_v ? vp[idx] : 0.0f;
+    eh_opt_update(S.o, gsum * S.scale, S.bt1, S.bt2, th, mm, vv);
+    tp[idx] = th;
+    if (S.use_m) mp[idx] = mm;
+    if (S.use_v) vp[idx] = vv;
+}
+
+// N independent elements through the update rule, the rule looked at ONCE: inside eh_opt_update the rule is a branch per element, and
+// sixteen unrolled copies of it keep the compiler from interleaving the sixteen dependent chains (an IEEE square root and two IEEE
+// divisions each: 7.7 k cycles for the sixteen elements of a thread, one wave per SIMD).  Same arithmetic, op for op: this IS
+// eh_opt_update with the rule hoisted (tests/test_gpu_lform.py trains through both and meets the same oracle trajectory).
+template <int RULE, int N>
+__device__ __forceinline__ void eh_opt_update_n(const EhOpt& o, const float (&g)[N], float bt1, float bt2, float (&th)[N], float (&m)[N], float (&v)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if constexpr (RULE == EH_OPT_ADAM || RULE == EH_OPT_ADAMW) {
+            m[i] = o.b1 * m[i] + (1.0f - o.b1) * g[i];
+            v[i] = o.b2 * v[i] + (1.0f - o.b2) * (g[i] * g[i]);
+            float upd = m[i] / (1.0f - bt1) / (sqrtf(v[i] / (1.0f - bt2)) + o.eps) * o.lr;
+            if constexpr (RULE == EH_OPT_ADAMW) upd += o.lr * o.wd * th[i];
+            th[i] -= upd;
+        } else if constexpr (RULE == EH_OPT_RMSPROP) {
+            v[i] = o.b1 * v[i] + (1.0f - o.b1) * (g[i] * g[i]);
+            th[i] -= g[i] * (o.lr / (sqrtf(v[i]) + o.eps));
+        } else {
+            th[i] -= o.lr * g[i];
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void eh_opt_update_all(const EhOpt& o, const float (&g)[N], float bt1, float bt2, float (&th)[N], float (&m)[N], float (&v)[N]) {
+    if (o.rule == EH_OPT_ADAM) eh_opt_update_n<EH_OPT_ADAM, N>(o, g, bt1, bt2, th, m, v);
+    else if (o.rule == EH_OPT_ADAMW) eh_opt_update_n<EH_OPT_ADAMW, N>(o, g, bt1, bt2, th, m, v);
+    else if (o.rule == EH_OPT_RMSPROP) eh_opt_update_n<EH_OPT_RMSPROP, N>(o, g, bt1, bt2, th, m, v);
+    else eh_opt_update_n<EH_OPT_DESCENT, N>(o, g, bt1, bt2, th, m, v);
+}
 
 __device__ __forceinline__ float eh_act_rt(int act, float z) {
     switch (act) {
@@ -71,7 +138,9 @@ __device__ __forceinline__ float eh_dact_rt(int act, float h) {       // act' fr
 #endif
 // BT = 64: 64 x 64 tiles (one MFMA tile per wave) for products too small to fill the chip with 128 x 128 ones.
 template <bool ATR, bool BTR, int EPI, bool VEC, int BT>
-__device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, const int by, const int bz, const EhLApplyS* const Sp = nullptr) {
+    EhLApplyS S{};
+    if constexpr (EPI == EH_GEPI_APPLY) S = *Sp;
     static_assert(BT == 128 || (BT == 64 && VEC), "64 x 64 tiles exist in the 16-byte-load form only");
     constexpr int BM = BT, BN = BT, BK = 16, LDS_LD = BM + 4, TI = BT / 64, WT = BT / 2, NP = BT / 64, QT = BT / 4, RP = 256 / QT;
     __shared__ __attribute__((aligned(16))) float As[VEC ? 2 : 1][BK][LDS_LD], Bs[VEC ? 2 : 1][BK][LDS_LD];
@@ -86,7 +155,24 @@ __device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, 
         for (int j = 0; j < TI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const bool do_cs_v = EPI == EH_GEPI_STORE && g.colsum != nullptr && by == 0 && tid < BN;
+    // EH_GEPI_APPLY (64 x 64 tiles): the thread's sixteen parameters and their moments are requested NOW -- they do not depend on the product
+    float ap_th[16], ap_m[16], ap_v[16];
+    long long ap_ix[16];
+    if constexpr (EPI == EH_GEPI_APPLY) {
+        static_assert(EPI != EH_GEPI_APPLY || BT == 64, "apply epilogue: one MFMA tile per wave");
+        eh_gfloat* const tp = (eh_gfloat*)S.theta; eh_gfloat* const mp = (eh_gfloat*)S.m; eh_gfloat* const vp = (eh_gfloat*)S.v;
+        const int n = min(n0 + wn * WT + l32, g.N - 1);
+        const float* const Cb = g.C + (long long)bz * g.c_zstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + wm * WT + (r & 3) + 8 * (r >> 2) + 4 * lh, g.M - 1);
+            ap_ix[r] = (Cb + (long long)m * g.ldc + n) - S.slab;
+            ap_th[r] = tp[ap_ix[r]];
+            ap_m[r] = S.use_m ? mp[ap_ix[r]] : 0.0f;
+            ap_v[r] = S.use_v ? vp[ap_ix[r]] : 0.0f;
+        }
+    }
+    const bool do_cs_v = (EPI == EH_GEPI_STORE || EPI == EH_GEPI_APPLY) && g.colsum != nullptr && by == 0 && tid < BN;
     float cs_v = 0.0f;
     if constexpr (VEC) {
         // NP (= BT / 64) 16-byte pieces of each tile per thread and step
@@ -196,6 +282,7 @@ __device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, 
             }
         }
     }
+    if constexpr (EPI == EH_GEPI_APPLY) { EH_LSTAMP(Sp, 2); }
     const bool do_cs = do_cs_v;
     float cs = cs_v;
     if constexpr (!VEC) {
@@ -243,7 +330,10 @@ __device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, 
         }
     }
     }
-    if (do_cs && n0 + tid < g.N) g.colsum[(long long)bz * g.c_zstride + n0 + tid] = cs;
+    if (do_cs && n0 + tid < g.N) {
+        if constexpr (EPI == EH_GEPI_APPLY) { if (S.go) eh_lapply_one(S, g.colsum + n0 + tid, cs); }
+        else g.colsum[(long long)bz * g.c_zstride + n0 + tid] = cs;
+    }
     // C/D layout of the 32x32 MFMA: lane -> column (lane & 31); register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* const C = g.C + (long long)bz * g.c_zstride;
 #pragma unroll
@@ -252,6 +342,31 @@ __device__ __forceinline__ void eh_gemm_tile(const EhGemmArgs& g, const int bx, 
         for (int j = 0; j < TI; ++j) {
             const int n = n0 + wn * WT + 32 * j + l32;
             const float bv = ((EPI == EH_GEPI_BIAS_ACT || EPI == EH_GEPI_BIAS_T) && n < g.N) ? g.bias[n] : 0.0f;
+            if constexpr (EPI == EH_GEPI_APPLY) {
+                // (all of a thread's parameters and moments requested before the first update: one round trip, not sixteen)
+                if (S.go && n < g.N) {
+                    // every update, then the stores -- a store between two updates made the next one wait for the store's acknowledgement
+                    // (loads and stores share one counter and may complete out of order: the compiler waits for zero), sixteen round
+                    // trips in a row: 13 k of the workgroup's 28 k cycles (tools/stamps_lform.py, EH_STAMP_DW)
+                    eh_gfloat* const tp = (eh_gfloat*)S.theta; eh_gfloat* const mp = (eh_gfloat*)S.m; eh_gfloat* const vp = (eh_gfloat*)S.v;
+                    float gg[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gg[r] = acc[i][j][r] * S.scale;
+                    EH_LSTAMP(Sp, 3);
+                    eh_opt_update_all<16>(S.o, gg, S.bt1, S.bt2, ap_th, ap_m, ap_v);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * WT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (m < g.M) {
+                            tp[ap_ix[r]] = ap_th[r];
+                            if (S.use_m) mp[ap_ix[r]] = ap_m[r];
+                            if (S.use_v) vp[ap_ix[r]] = ap_v[r];
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -306,7 +421,10 @@ struct EhThinArgs {
     float* C; long long c_col, c_j, c_z;
     float* cs_wide; float* cs_thin; long long cs_z;
 };
-__device__ __forceinline__ void eh_thin_gemm_tile(const EhThinArgs& a, const int bx, const int by) {
+template <bool APPLY = false>
+__device__ __forceinline__ void eh_thin_gemm_tile(const EhThinArgs& a, const int bx, const int by, const EhLApplyS* const Sp = nullptr) {
+    EhLApplyS S{};
+    if constexpr (APPLY) S = *Sp;
     constexpr int SB = 512, U = 8;              // samples staged per round; wide loads in flight per thread
     __shared__ float sT[8][SB];                 // the thin operand of the round, [j][sample]: every lane of a wave reads the same word (broadcast)
     __shared__ float red[4][64][10];
@@ -349,6 +467,42 @@ __device__ __forceinline__ void eh_thin_gemm_tile(const EhThinArgs& a, const int
         for (int j = 0; j < 8; ++j) redt[q][j] = cst[j];
     }
     __syncthreads();
+    if constexpr (APPLY) {
+        if (S.go) {
+            if (q == 0 && live) {
+                // (all of the thread's parameters and moments requested before the first update, every update before the first store: see eh_gemm_tile)
+                long long ix[9];
+                float th[9], mm[9], vv[9];
+                eh_gfloat* const tp = (eh_gfloat*)S.theta; eh_gfloat* const mp = (eh_gfloat*)S.m; eh_gfloat* const vp = (eh_gfloat*)S.v;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const bool on = j < 8 ? j < a.J : a.cs_wide != nullptr;
+                    const float* const slot = j < 8 ? a.C + (long long)col * a.c_col + (long long)min(j, a.J - 1) * a.c_j : (a.cs_wide ? a.cs_wide + col : a.C);
+                    ix[j] = slot - S.slab;
+                    th[j] = on ? tp[ix[j]] : 0.0f;
+                    mm[j] = (on && S.use_m) ? mp[ix[j]] : 0.0f;
+                    vv[j] = (on && S.use_v) ? vp[ix[j]] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const bool on = j < 8 ? j < a.J : a.cs_wide != nullptr;
+                    if (on) eh_opt_update(S.o, ((red[0][cl][j] + red[1][cl][j]) + (red[2][cl][j] + red[3][cl][j])) * S.scale, S.bt1, S.bt2, th[j], mm[j], vv[j]);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const bool on = j < 8 ? j < a.J : a.cs_wide != nullptr;
+                    if (on) {
+                        tp[ix[j]] = th[j];
+                        if (S.use_m) mp[ix[j]] = mm[j];
+                        if (S.use_v) vp[ix[j]] = vv[j];
+                    }
+                }
+            }
+            if (a.cs_thin && bx == 0 && tid < a.J) eh_lapply_one(S, a.cs_thin + tid, (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]));
+        }
+        return;
+    }
     if (q == 0 && live) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -357,7 +511,7 @@ __device__ __forceinline__ void eh_thin_gemm_tile(const EhThinArgs& a, const int
     }
     if (a.cs_thin && bx == 0 && tid < a.J) a.cs_thin[(long long)z * a.cs_z + tid] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
 }
-__global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) { eh_thin_gemm_tile(a, (int)blockIdx.x, (int)blockIdx.y); }
+__global__ __launch_bounds__(256) void eh_thin_gemm_kernel(const EhThinArgs a) { eh_thin_gemm_tile<false>(a, (int)blockIdx.x, (int)blockIdx.y); }
 // (several of them in one launch, as eh_gemm_group_kernel)
 struct EhThinGroup { EhThinArgs a[EH_GEMM_GROUP]; int t0[EH_GEMM_GROUP + 1]; int gx[EH_GEMM_GROUP]; int n; };
 __global__ __launch_bounds__(256) void eh_thin_gemm_group_kernel(const EhThinGroup G) {
@@ -365,7 +519,7 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_group_kernel(const EhThinGro
     while (i + 1 < G.n && (int)blockIdx.x >= G.t0[i + 1]) ++i;
     const int t = (int)blockIdx.x - G.t0[i], gx = G.gx[i];
     const EhThinArgs a = G.a[i];
-    eh_thin_gemm_tile(a, t % gx, t / gx);
+    eh_thin_gemm_tile<false>(a, t % gx, t / gx);
 }
 
 // Both groups of a small-batch step's weight gradients -- the tiled ones and the thin ones -- as ONE launch: the first workgroups run
@@ -382,7 +536,7 @@ __global__ __launch_bounds__(256) void eh_dw_group_kernel(const EhGemmGroup G, c
         while (i + 1 < T.n && (int)blockIdx.x >= T.t0[i + 1]) ++i;
         const int t = (int)blockIdx.x - T.t0[i], gx = T.gx[i];
         const EhThinArgs a = T.a[i];
-        eh_thin_gemm_tile(a, t % gx, t / gx);
+        eh_thin_gemm_tile<false>(a, t % gx, t / gx);
     } else {
         const int b = (int)blockIdx.x - nthin;
         int i = 0;
@@ -516,6 +670,18 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
                 g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
             }
         }
+    }
+    if (g.job_part && blockIdx.x == 0 && blockIdx.y == 0 && tid < 256) {
+        const int col = tid & 15, grp = tid >> 4;
+        float s = 0.0f;
+        for (int b = grp; b < g.job_nblk; b += 16) s += g.job_part[(long long)b * 16 + col];
+        red[15][tid] = s;                                                // (a thread's own column of the last wave's partials: read above by this thread only)
+    }
+    __syncthreads();
+    if (g.job_part && blockIdx.x == 0 && blockIdx.y == 0 && tid < 16) {
+        float t = 0.0f;
+        for (int q = 0; q < 16; ++q) t += red[15][q * 16 + tid];
+        g.job_out[tid] = t;
     }
 }
 
@@ -1267,4 +1433,87 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel
     }
     if (touch[0] + touch[1] + touch[2] + touch[3] == -1.2345e-30f) t.part[(long long)blockIdx.x * EH_LMECH_PART + EH_LMECH_PART - 1] = 0.0f;      // (keeps the warming loads; column 15 is padding, 0 either way)
     EH_STAMP(15);
+}
+
+
+// The grouped weight-gradient launch of a few-rows step with the optimiser in its epilogues (EhLApply above): every workgroup first takes
+// the step's normalisation from the mechanistic stage's partial rows (the sums in the order of eh_lform_tail_sum), then runs its product
+// and puts its elements through the update rule; the last workgroup updates the global parameters, writes the loss and advances the
+// running beta products -- what eh_lform_tail_kernel + eh_reduce_kernel<APPLY> did in two more launches.  One target, a loss without
+// batch moments, no weight_l2 (the host checks; everything else takes the slab and the reduce kernel as before).
+__global__ __launch_bounds__(256) void eh_dw_apply_kernel(const EhGemmGroup G, const EhThinGroup T, const EhNet net, const EhLApply ap) {
+    __shared__ float tot[EH_LMECH_PART], red[16][EH_LMECH_PART];
+    __shared__ EhLApplyS S;
+    const int tid = threadIdx.x;
+#ifdef EH_STAMPS
+    if (ap.stamps && (int)blockIdx.x == ap.stamp_wg && tid == 0) { ap.stamps[0] = __builtin_readcyclecounter(); ap.stamps[1] = wall_clock64(); }
+#endif
+    if (ap.tot) {
+        if (tid < EH_LMECH_PART) tot[tid] = ap.tot[tid];
+    } else {
+        const int col = tid & 15, grp = tid >> 4;                        // 16 row groups x 16 columns, fixed order: deterministic (eh_lform_tail_sum)
+        float s = 0.0f;
+        for (int b = grp; b < ap.nblk; b += 16) s += ap.part[(long long)b * EH_LMECH_PART + col];
+        red[grp][col] = s;
+        __syncthreads();
+        if (tid < EH_LMECH_PART) {
+            float t = 0.0f;
+            for (int q = 0; q < 16; ++q) t += red[q][tid];
+            tot[tid] = t;
+        }
+    }
+    __syncthreads();
+    float scale, loss;
+    eh_loss_finish(ap.loss_kind, tot[8], tot[9], tot[13], tot[14], scale, loss, ap.im.agg_a);      // [grad of the raw globals (8) | S | n_t (4) | Sy | Syy]
+    const bool go = tot[9] > 0.0f;
+    if (tid == 0) {
+        S.slab = ap.slab; S.theta = ap.theta; S.m = ap.m; S.v = ap.v; S.o = ap.o; S.scale = scale; S.bt1 = ap.sc_in[0]; S.bt2 = ap.sc_in[1];
+        S.go = go ? 1 : 0;
+        S.use_m = (ap.o.rule == EH_OPT_ADAM || ap.o.rule == EH_OPT_ADAMW) ? 1 : 0;
+        S.use_v = (S.use_m || ap.o.rule == EH_OPT_RMSPROP) ? 1 : 0;
+        S.stamps = (int)blockIdx.x == ap.stamp_wg ? ap.stamps : nullptr;
+    }
+    __syncthreads();
+    EH_LSTAMP(&S, 1);
+    const int nthin = T.t0[T.n], ntile = G.t0[G.n];
+    if ((int)blockIdx.x == nthin + ntile) {                              // the global parameters, the loss, the beta products
+        const int ng = net.n_theta - net.g_off;
+        if (tid < ng && go) {
+            float gsum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                if (j < net.n_par && ((net.par_kind >> (2 * j)) & 3u) == EH_PAR_GLOBAL && (int)((net.par_idx >> (4 * j)) & 15u) == tid) gsum = tot[j];
+            const int idx = net.g_off + tid;
+            float th = ap.theta[idx], mm = S.use_m ? ap.m[idx] : 0.0f, vv = S.use_v ? ap.v[idx] : 0.0f;
+            eh_opt_update(ap.o, gsum * scale, S.bt1, S.bt2, th, mm, vv);
+            ap.theta[idx] = th;
+            if (S.use_m) ap.m[idx] = mm;
+            if (S.use_v) ap.v[idx] = vv;
+            eh_image_store(ap.im, idx, th);
+        }
+        if (tid == 0) {
+            ap.sc_out[0] = go ? S.bt1 * ap.o.b1 : S.bt1;
+            ap.sc_out[1] = go ? S.bt2 * ap.o.b2 : S.bt2;
+            ap.gradbuf[net.n_theta] = loss;                             // (what eh_reduce_kernel leaves behind the gradient: loss, count, Sy, Syy -- the gradient itself is not kept)
+            ap.gradbuf[net.n_theta + 1] = tot[9]; ap.gradbuf[net.n_theta + 2] = tot[13]; ap.gradbuf[net.n_theta + 3] = tot[14];
+            if (ap.loss_slot) *ap.loss_slot = loss;
+        }
+        return;
+    }
+    if ((int)blockIdx.x < nthin) {
+        int i = 0;
+        while (i + 1 < T.n && (int)blockIdx.x >= T.t0[i + 1]) ++i;
+        const int t = (int)blockIdx.x - T.t0[i], gx = T.gx[i];
+        const EhThinArgs a = T.a[i];
+        eh_thin_gemm_tile<true>(a, t % gx, t / gx, &S);
+        EH_LSTAMP(&S, 5);
+    } else {
+        const int b = (int)blockIdx.x - nthin;
+        int i = 0;
+        while (i + 1 < G.n && b >= G.t0[i + 1]) ++i;
+        const int t = b - G.t0[i], gx = G.gx[i], gy = G.gy[i];
+        const EhGemmArgs g = G.g[i];
+        eh_gemm_tile<true, false, EH_GEPI_APPLY, true, 64>(g, t % gx, (t / gx) % gy, t / (gx * gy), &S);
+        EH_LSTAMP(&S, 5);
+    }
 }
