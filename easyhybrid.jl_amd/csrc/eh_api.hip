@@ -1044,9 +1044,15 @@ int32_t eh_set_option(eh_handle* h, const char* name, int64_t value) {
         if (value && (h->img.l2c != 0.0f || h->img.l2w)) return fail(h, EH_EUNSUPPORTED, "fused_update: the weight_l2 extra loss is not built for it");
         if (value && h->arch->wide) return fail(h, EH_EUNSUPPORTED, "fused_update is not built for hidden widths above 64");
         if (!value && h->p2p_alloc) return fail(h, EH_ESTATE, "fused_update: eh_p2p_disable first");
+        if (value < 0 || value > 2) return fail(h, EH_EINVAL, "fused_update must be 0, 1 or 2");
         HIPCHK(h, hipSetDevice(h->device));
         FLUSH(h);
         h->fused = value != 0;
+        // 2 = "where it is reproducible": one kernel per step only for minibatches ONE workgroup covers -- its sums meet in one fixed order
+        // (several steps per launch with the state in LDS, or one add per accumulator) -- and the deterministic step + reduce pair for
+        // every larger minibatch, whose workgroups' float atomics land in no fixed order.  What train() asks for when random_seed is set
+        // (the reference's default, src/config/TrainingConfig.jl:85-86: a seeded CPU run IS reproducible).
+        h->fused_det = value == 2;
         return EH_OK;
     }
     if (!strcmp(name, "training_loss")) {
@@ -2435,11 +2441,12 @@ int32_t eh_train_step(eh_handle* h, const int32_t* idx, int32_t idx_on_device, i
     } else if ((rc = check_window(h, sp, first, count, "eh_train_step"))) return rc;
     rc = ensure_loss_hist(h, 1);
     if (rc) return rc;
-    if (h->fused) {
+    if (h->fused && !(h->fused_det && grid_for(h, count) != 1)) {
         rc = do_fused_step(h, sp, didx, first, count, loss_out ? h->loss_hist : nullptr);
         if (rc) return rc;
         if (loss_out) FLUSH(h);
     } else {
+        FLUSH(h);                              // ("fused_update" 2: a one-workgroup step may be pending in front of this larger one)
         rc = do_step(h, sp, didx, first, count, true, false, loss_out ? h->loss_hist : nullptr);
         if (rc) return rc;
     }
@@ -2545,8 +2552,10 @@ int32_t eh_train_epoch(eh_handle* h, int64_t batchsize, uint64_t seed, int32_t s
     } else
     for (long long s = 0; s < steps; ++s) {
         const long long first = s * batchsize, count = std::min<long long>(batchsize, N - first);
-        rc = h->fused ? do_fused_step(h, sp, shuffle ? h->perm : nullptr, first, count, h->loss_hist + s)
-                      : do_step(h, sp, shuffle ? h->perm : nullptr, first, count, true, false, h->loss_hist + s);
+        const bool one_kernel = h->fused && !(h->fused_det && grid_for(h, count) != 1);      // ("fused_update" 2: only where one workgroup covers the minibatch)
+        if (!one_kernel) FLUSH(h);
+        rc = one_kernel ? do_fused_step(h, sp, shuffle ? h->perm : nullptr, first, count, h->loss_hist + s)
+                        : do_step(h, sp, shuffle ? h->perm : nullptr, first, count, true, false, h->loss_hist + s);
         if (rc) return rc;
     }
     if (mean_loss) FLUSH(h);

@@ -88,7 +88,7 @@ struct eh_handle_s {
     float* sc = nullptr;            // [2][2] running beta products, ping-pong
     int cur = 0, sc_sel = 0;
     // fused-update mode
-    bool fused = false, pending = false;
+    bool fused = false, pending = false, fused_det = false;   // fused_det ("fused_update" 2): one kernel per step only where one workgroup covers the minibatch
     float* gacc = nullptr;          // [3][EH_GSHARDS][n_acc] rotating gradient accumulators
     // cross-GPU exchange (EhP2P): an uncached, IPC-exported receive buffer of {value, sequence} words next to gacc
     bool p2p_on = false, p2p_alloc = false;

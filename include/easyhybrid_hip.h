@@ -424,7 +424,8 @@ int32_t eh_profile_samples(eh_handle* h, double* ms, int64_t cap, int64_t* n_out
 int32_t eh_debug_stamps(eh_handle* h, uint64_t* out, int32_t n);
 
 /* tuning knobs (name/value): "max_blocks" (1..256), "variant" (tile shape), "fast_paths" (0 = generic MFMA kernels), "training_loss" (eh_loss),
- * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible), "row_split" (kernel family),
+ * "fused_update" (1 = one kernel per step, float-atomic accumulation: not bitwise reproducible; 2 = one kernel per step only where that IS
+ * reproducible -- minibatches one workgroup covers -- and the deterministic step + reduce pair for larger ones: what a seeded run asks for), "row_split" (kernel family),
  * "jit" (EH_MECH_PROGRAM: 1 = step kernels compiled at run time around the recorded closure (default; also env EH_JIT),
  * 0 = the interpreting kernels built ahead of time),
  * "specialize" (1 = every model's step kernels compiled at run time (hiprtc, ~1 s, cached on disk) with the descriptor as a compile-time

@@ -204,6 +204,24 @@ def test_the_background_build_switches_within_rounding_and_seeded_training_is_re
     assert np.array_equal(a.ps, b.ps) and a.best_loss == b.best_loss and a.val_history == b.val_history
 
 
+@pytest.mark.parametrize("batchsize", [65536, 512, 64])
+def test_seeded_default_train_calls_are_the_same_bits(batchsize):
+    """`random_seed` is set by default, as in the reference (src/config/TrainingConfig.jl:85-86,
+    src/utils/tools.jl:391-395), where a seeded run on the CPU is reproducible.  Two train() calls with every step-mode option left at
+    its default are bit-identical in parameters and history: at batch 65 536 and 512 (more than one workgroup per minibatch: the
+    float-atomic one-kernel step would not be -- fused_update = "auto" resolves to the deterministic step + reduce pair there) and at
+    the reference's default batch of 64 (one workgroup: several steps per launch, sums in one fixed order)."""
+    n = 4 * 65536 if batchsize == 65536 else 20000
+    cols = make_synth_rbq10(n, seed=5, nan_frac=0.05)
+    cols = dict(cols); cols["sw_pot"] = cols["sw_pot"] / 50; cols["dsw_pot"] = cols["dsw_pot"] / 50
+    model = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, dict(RBQ10_PARAMS), ["rb"], ["Q10"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    kw = dict(nepochs=3, batchsize=batchsize, opt=eh.Adam(0.01), random_seed=11)
+    a, b = eh.train(model, cols, **kw), eh.train(model, cols, **kw)
+    assert np.array_equal(a.ps, b.ps) and a.best_loss == b.best_loss and a.val_history == b.val_history
+    assert np.all(np.isfinite(a.ps)) and a.val_history[-1]["mse"]["sum"] < a.val_history[0]["mse"]["sum"]
+
+
 def test_canonical_descriptors_run_kernels_specialised_ahead_of_time():
     """the BASELINE configurations must not depend on a run-time compiler.  Their descriptors are baked into step
     kernels at build time (csrc/eh_spec.hip, the strings in csrc/Makefile); a handle whose descriptor matches runs them by default --
