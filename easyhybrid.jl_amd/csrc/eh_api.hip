@@ -1178,7 +1178,8 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
     if (!h) return EH_EINVAL;
     if (split != EH_SPLIT_TRAIN && split != EH_SPLIT_VAL) return fail(h, EH_EINVAL, "eh_set_data: split %d", split);
     if (n < 0 || n > 0x7fffffffLL) return fail(h, EH_EINVAL, "eh_set_data: n = %lld", (long long)n);
-    if (on_device & ~(EH_DATA_ON_DEVICE | EH_DATA_X_PLANES)) return fail(h, EH_EINVAL, "eh_set_data: flags %d", on_device);
+    if (on_device & ~(EH_DATA_ON_DEVICE | EH_DATA_X_PLANES | EH_DATA_X_ROWS)) return fail(h, EH_EINVAL, "eh_set_data: flags %d", on_device);
+    if ((on_device & EH_DATA_X_ROWS) && (on_device & (EH_DATA_ON_DEVICE | EH_DATA_X_PLANES))) return fail(h, EH_EINVAL, "eh_set_data: EH_DATA_X_ROWS goes with host arrays only, and not with EH_DATA_X_PLANES");
     if (n > 0 && ((!x && h->net.P > 0) || !forcings || !targets)) return fail(h, EH_EINVAL, "eh_set_data: null array");
     const EhNet& net = h->net;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1189,8 +1190,14 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
     if (split == EH_SPLIT_TRAIN) h->perm_valid = false;
     if (n == 0) return EH_OK;
     const int C = h->C;
+    static const bool dbg_t = getenv("EH_DEBUG_SET_DATA") != nullptr;      // (diagnostic: where an upload's wall clock goes)
+    const auto t_a = std::chrono::steady_clock::now();
     HIPCHK(h, hipMalloc(&sp.recs, (size_t)n * C * sizeof(float)));
+    const auto t_b = std::chrono::steady_clock::now();
     const bool planes = (on_device & EH_DATA_X_PLANES) != 0;       // x as P arrays of N (row-major P x N: what a NumPy host holds) instead of N records of P
+    const bool xrows = (on_device & EH_DATA_X_ROWS) != 0;          // x as P POINTERS to arrays of N: the caller's own columns, never stacked into a matrix
+    const float* const* const xr = reinterpret_cast<const float* const*>(x);
+    if (xrows) for (int j = 0; j < net.P; ++j) if (!xr[j]) return fail(h, EH_EINVAL, "eh_set_data: predictor row %d is null", j);
     on_device &= EH_DATA_ON_DEVICE;
     if (on_device) {
         EhPackArgs pa{};
@@ -1253,11 +1260,13 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
             if (ee == hipSuccess) { ee = hipEventCreateWithFlags(&done[1], hipEventDisableTiming); if (ee != hipSuccess) (void)hipEventDestroy(done[0]); }
             if (ee != hipSuccess) { if (!pooled) { (void)hipHostFree(stage[0]); (void)hipHostFree(stage[1]); } HIPCHK(h, ee); }
         }
+        const auto t_c = std::chrono::steady_clock::now();
         const int P = net.P, F = net.F, T = net.T;
         auto pack = [&](float* dst, int64_t s0, int64_t s1, int64_t base) {
             for (int64_t s = s0; s < s1; ++s) {
                 float* r = dst + (size_t)(s - base) * C;
-                if (planes) for (int j = 0; j < P; ++j) r[j] = x[(size_t)j * (size_t)n + (size_t)s];
+                if (xrows) for (int j = 0; j < P; ++j) r[j] = xr[j][s];
+                else if (planes) for (int j = 0; j < P; ++j) r[j] = x[(size_t)j * (size_t)n + (size_t)s];
                 else for (int j = 0; j < P; ++j) r[j] = x[(size_t)s * P + j];
                 for (int f = 0; f < F; ++f) r[P + f] = forcings[f][s];
                 for (int t = 0; t < T; ++t) r[P + F + t] = targets[t][s];
@@ -1268,8 +1277,10 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
         for (int64_t s0 = 0; s0 < n && err == hipSuccess; s0 += CH, ++k) {
             const int64_t cnt = std::min(CH, n - s0);
             float* const buf = stage[k & 1];
+            const auto tq0 = std::chrono::steady_clock::now();
             if (pinned && k >= 2) err = hipEventSynchronize(done[k & 1]);       // the copy that last read this buffer is through
             if (err != hipSuccess) break;
+            const auto tq1 = std::chrono::steady_clock::now();
             if (cnt >= 65536) {          // a chunk is interleaved by up to eight threads, each on its own run of samples
                 const unsigned hw = std::thread::hardware_concurrency();
                 const int nthr = (int)std::max<int64_t>(2, std::min<int64_t>({(int64_t)8, (int64_t)(hw ? hw / 2 : 2), cnt / 32768}));
@@ -1289,14 +1300,25 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
                 pack(buf, s0, mine_end, s0);
                 for (auto& t : others) t.join();
             } else pack(buf, s0, s0 + cnt, s0);
+            const auto tq2 = std::chrono::steady_clock::now();
             if (pinned) {
                 err = hipMemcpyAsync(sp.recs + (size_t)s0 * C, buf, (size_t)cnt * C * sizeof(float), hipMemcpyHostToDevice, h->stream);
                 if (err == hipSuccess) err = hipEventRecord(done[k & 1], h->stream);
+                if (dbg_t) {
+                    auto ms = [](std::chrono::steady_clock::time_point u, std::chrono::steady_clock::time_point v) { return std::chrono::duration<double, std::milli>(v - u).count(); };
+                    fprintf(stderr, "   chunk %d: wait %.2f pack %.2f enqueue %.2f ms\n", k, ms(tq0, tq1), ms(tq1, tq2), ms(tq2, std::chrono::steady_clock::now()));
+                }
             } else err = hipMemcpy(sp.recs + (size_t)s0 * C, buf, (size_t)cnt * C * sizeof(float), hipMemcpyHostToDevice);
         }
         // always drained before the staging pair is released or handed to the next caller -- also after an error: copies of earlier chunks
         // may still be reading it (advisor, round 4)
+        const auto t_d = std::chrono::steady_clock::now();
         { const hipError_t es = hipStreamSynchronize(h->stream); if (err == hipSuccess) err = es; }
+        if (dbg_t) {
+            auto ms = [](std::chrono::steady_clock::time_point u, std::chrono::steady_clock::time_point v) { return std::chrono::duration<double, std::milli>(v - u).count(); };
+            fprintf(stderr, "eh_set_data n=%lld: hipMalloc %.2f ms, staging (pooled %d pinned %d) %.2f ms, pack + enqueue %.2f ms, drain %.2f ms\n", (long long)n, ms(t_a, t_b), (int)pooled, (int)pinned,
+                    ms(t_b, t_c), ms(t_c, t_d), ms(t_d, std::chrono::steady_clock::now()));
+        }
         if (pinned) { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); if (!pooled) { (void)hipHostFree(stage[0]); (void)hipHostFree(stage[1]); } }
         HIPCHK(h, err);
     }
@@ -2107,6 +2129,47 @@ static int eval_host_acquire(eh_handle* h, size_t need) {
     h->eval_host_cap = cap;
     return EH_OK;
 }
+// A large result array to the caller's (pageable) memory: through the pinned staging pair of eh_set_data, chunk k + 1 on its way over
+// PCIe while chunk k is copied out by the CPU.  (hipMemcpy straight into pageable memory pins the destination pages behind the
+// scenes; with 50 MB of predictions per train() call on the headline data set that cost 1-27 ms per call depending on where the
+// allocator had put the arrays -- and whatever the runtime queued to undo it made the NEXT call's first upload chunk wait 15-28 ms
+// (tools/e2e_breakdown2.py).)  Small arrays, or a staging pair that is busy or cannot be had: the plain copy.
+static int copy_out(eh_handle* h, float* dst, const float* src_dev, size_t n) {
+    const size_t bytes = n * sizeof(float);
+    std::unique_lock<std::mutex> lk(g_stage_mu, std::try_to_lock);
+    if (bytes < ((size_t)1 << 20) || !lk.owns_lock()) { HIPCHK(h, hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost)); return EH_OK; }
+    const size_t want = (size_t)8 << 20;                     // 8 MB chunks
+    if (g_stage_bytes < want) {
+        for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; }
+        g_stage_bytes = 0;
+        if (hipHostMalloc((void**)&g_stage[0], want, hipHostMallocPortable) == hipSuccess && hipHostMalloc((void**)&g_stage[1], want, hipHostMallocPortable) == hipSuccess) g_stage_bytes = want;
+        else { (void)hipGetLastError(); for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; } }
+    }
+    if (g_stage_bytes < want) { HIPCHK(h, hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost)); return EH_OK; }
+    const size_t CH = std::min(g_stage_bytes, want) / sizeof(float);
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIPCHK(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    { const hipError_t e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming); if (e != hipSuccess) { (void)hipEventDestroy(ev[0]); HIPCHK(h, e); } }
+    hipError_t err = hipSuccess;
+    const size_t nch = (n + CH - 1) / CH;
+    for (size_t k = 0; k <= nch && err == hipSuccess; ++k) {
+        if (k < nch) {                                       // chunk k: device -> stage[k & 1]
+            const size_t off = k * CH, cnt = std::min(CH, n - off);
+            err = hipMemcpyAsync(g_stage[k & 1], src_dev + off, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+            if (err == hipSuccess) err = hipEventRecord(ev[k & 1], h->stream);
+        }
+        if (k >= 1 && err == hipSuccess) {                   // chunk k - 1: stage -> caller
+            const size_t off = (k - 1) * CH, cnt = std::min(CH, n - off);
+            err = hipEventSynchronize(ev[(k - 1) & 1]);
+            if (err == hipSuccess) memcpy(dst + off, g_stage[(k - 1) & 1], cnt * sizeof(float));
+        }
+    }
+    { const hipError_t es = hipStreamSynchronize(h->stream); if (err == hipSuccess) err = es; }      // (the pair is not handed on with a copy in flight)
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    HIPCHK(h, err);
+    return EH_OK;
+}
+
 static int do_eval(eh_handle* h, int split, long long first, long long count, double* stats, float* const* yhat, float* const* params) {
     const EhNet& net = h->net;
     EhSplit& sp = h->split[split];
@@ -2164,10 +2227,10 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
     }
     if (yhat)
         for (int t = 0; t < net.T; ++t)
-            if (yhat[t]) HIPCHK(h, hipMemcpy(yhat[t], a.yhat + (long long)t * count, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+            if (yhat[t]) { if (int rc2 = copy_out(h, yhat[t], a.yhat + (long long)t * count, (size_t)count)) return rc2; }
     if (params)
         for (int j = 0; j < h->n_par; ++j)
-            if (params[j]) HIPCHK(h, hipMemcpy(params[j], a.pout + (long long)j * count, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+            if (params[j]) { if (int rc2 = copy_out(h, params[j], a.pout + (long long)j * count, (size_t)count)) return rc2; }
     return EH_OK;
 }
 

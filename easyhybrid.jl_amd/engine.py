@@ -94,7 +94,7 @@ class HybridEngine:
         self.extra_entries = []
         self.param_names = list(param_names)
         self.n_samples = {L.EH_SPLIT_TRAIN: 0, L.EH_SPLIT_VAL: 0}
-        self.x_sum = _LazySums(lambda X, N: (X.sum(axis=1, dtype=np.float64), N))
+        self.x_sum = _LazySums(lambda X, N: ((np.array([r.sum(dtype=np.float64) for r in X]) if isinstance(X, list) else X.sum(axis=1, dtype=np.float64)), N))
         self.y_sum = _LazySums(lambda ts: np.array([[np.nansum(t, dtype=np.float64), np.count_nonzero(~np.isnan(t))] for t in ts], np.float64))   # (sum, n valid) per target
         if os.environ.get("EH_MAX_BLOCKS"):               # several ranks sharing one GPU (tests): every kernel must fit beside the others
             self.set_option("max_blocks", int(os.environ["EH_MAX_BLOCKS"]))
@@ -126,9 +126,18 @@ class HybridEngine:
 
     # -- data ------------------------------------------------------------------------------------
     def set_data(self, split: int, X: np.ndarray, forcings: Sequence[np.ndarray], targets: Sequence[np.ndarray]):
-        """X: (P, N) like the reference (features x samples); forcings / targets: lists of (N,)."""
-        X = np.asarray(X, np.float32)
-        P, N = X.shape
+        """X: (P, N) like the reference (features x samples) -- or a list of P arrays of (N,), the caller's own predictor columns, which go
+        to the device without being stacked into a matrix first (EH_DATA_X_ROWS); forcings / targets: lists of (N,)."""
+        rows = None
+        if isinstance(X, (list, tuple)):
+            rows = [np.ascontiguousarray(r, np.float32) for r in X]
+            P, N = len(rows), (len(rows[0]) if rows else len(targets[0]))
+            for r in rows:
+                if r.shape != (N,):
+                    raise ValueError("predictor rows must have one value per sample")
+        else:
+            X = np.asarray(X, np.float32)
+            P, N = X.shape
         if P != self.desc.n_predictors:
             raise ValueError(f"X has {P} predictor rows, model expects {self.desc.n_predictors}")
         if len(forcings) != self.desc.n_forcings or len(targets) != len(self.target_names):
@@ -136,9 +145,9 @@ class HybridEngine:
         targets = list(targets) + [np.zeros(N, np.float32)] * self.n_pseudo      # an extra-loss entry "observes" every sample (no NaN)
         # sums only the data-parallel driver asks for (common BatchNorm shift, common target shift): taken when they are asked for --
         # two more passes over 4 M rows are a tenth of a short train() call
-        self.x_sum.put(split, (X, N))
+        self.x_sum.put(split, (X if rows is None else rows, N))
         self.y_sum.put(split, (list(targets),))
-        xf = np.ascontiguousarray(X)                    # row-major (P, N): handed over as P planes (EH_DATA_X_PLANES) -- no transposed copy of the whole matrix
+        xf = np.ascontiguousarray(X) if rows is None else None      # row-major (P, N): handed over as P planes (EH_DATA_X_PLANES) -- no transposed copy of the whole matrix
         fs = [np.ascontiguousarray(f, np.float32) for f in forcings]
         ts = [np.ascontiguousarray(t, np.float32) for t in targets]
         for a in fs + ts:
@@ -146,7 +155,11 @@ class HybridEngine:
                 raise ValueError("forcing / target arrays must have one value per sample")
         fp = (C.c_void_p * max(1, len(fs)))(*[a.ctypes.data for a in fs])
         tp = (C.c_void_p * max(1, len(ts)))(*[a.ctypes.data for a in ts])
-        self._chk(self._lib.eh_set_data(self._h, split, N, C.c_void_p(xf.ctypes.data), fp, tp, 2))
+        if rows is None:
+            self._chk(self._lib.eh_set_data(self._h, split, N, C.c_void_p(xf.ctypes.data), fp, tp, 2))
+        else:
+            xp = (C.c_void_p * max(1, P))(*[r.ctypes.data for r in rows])
+            self._chk(self._lib.eh_set_data(self._h, split, N, C.cast(xp, C.c_void_p), fp, tp, 4))
         self.n_samples[split] = N
 
     def set_data_device(self, split: int, n: int, x_ptr: int, forcing_ptrs: Sequence[int], target_ptrs: Sequence[int], planes: bool = False):

@@ -13,6 +13,7 @@ The per-minibatch work (`run_epoch!`, src/training/epoch.jl:13-33) and the per-e
 from __future__ import annotations
 
 import copy
+import os
 import time
 from dataclasses import dataclass, field, replace
 from typing import Any, Dict, List, Optional, Sequence
@@ -223,6 +224,11 @@ class TrainConfig:
     # bench.py measures specialize on and fused_update = True at the engine.
     specialize: Any = "auto"
     fused_update: Any = "auto"
+    # not in the reference: "lazy" (default) = the observed-vs-predicted tables and the physical parameters of the returned model
+    # (TrainResults.train_obs_pred / val_obs_pred / train_diffs / val_diffs, train.jl:130-136) are computed when they are first read --
+    # the engine stays resident until then (or until the results are dropped / TrainResults.release()); "eager" = before train() returns,
+    # as the reference does.  Same values either way.  (An engine the caller passed in is never kept: eager.)
+    predictions: str = "lazy"
     # not in the reference: True = TrainResults.timing splits the wall-clock of the epoch loop into training steps / evaluation passes /
     # host bookkeeping (one extra device synchronisation per epoch, after the steps, so that the split is clean: bench.py `train_e2e`)
     timing: bool = False
@@ -333,6 +339,58 @@ def prepare_data(model: SingleNNHybridModel, data, drop_missing_rows: bool = Tru
     return (X, {f: arr[f].astype(np.float32, copy=False) for f in model.forcing}), {t: arr[t].astype(np.float32, copy=False) for t in model.targets}
 
 
+def _no_nan(a) -> bool:
+    """no NaN in `a`, found by ONE reduction pass without a temporary: a NaN anywhere makes the sum NaN (so does inf - inf: then the exact
+    test decides).  np.isnan(a) | ... over 4 M rows allocates and walks a boolean array per column -- a third of a short train() call."""
+    return not bool(np.isnan(np.add.reduce(a))) or not bool(np.isnan(a).any())
+
+
+def _split_columns(model, data, cfg: DataConfig):
+    """The common case of train(model, table; ...) without copying the table: float columns, the contiguous split of MLUtils.splitobs
+    (no shuffleobs / split_by_id / folds), no row to drop (prepare_data.jl:31-63 keeps a row whose predictors and forcings are all there and
+    that has some target) -> (train, val), each ((predictor rows: list of (N,) views), {forcing: view}), {target: view}); None = take the
+    general path (prepare_data + split_data: same result, through copies)."""
+    if isinstance(data, tuple) or cfg.shuffleobs or cfg.split_by_id is not None or cfg.folds is not None or cfg.val_fold is not None:
+        return None
+    cols = _columns(data)
+    need = list(dict.fromkeys(list(model.predictors) + list(model.forcing) + list(model.targets)))
+    arr = {}
+    for c in need:
+        if c not in cols:
+            raise KeyError(f"column {c!r} missing from data")
+        a = np.asarray(cols[c])
+        if a.dtype != np.float32 or a.ndim != 1 or not a.flags.c_contiguous:
+            return None
+        arr[c] = a
+    if not model.predictors:
+        return None
+    n = len(next(iter(arr.values())))
+    if any(len(a) != n for a in arr.values()) or n == 0:
+        return None
+    if n >= (1 << 20) and len(need) > 1:                              # (the reductions release the interpreter lock: one thread per column)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(4, len(need))) as ex:
+            clean = dict(zip(need, ex.map(_no_nan, [arr[c] for c in need])))
+    else:
+        clean = {c: _no_nan(arr[c]) for c in need}
+    if not all(clean[c] for c in need if c not in model.targets):
+        return None                                                   # rows to drop: the general path
+    if len(model.targets) == 1:
+        if not clean[model.targets[0]]:
+            return None                                               # (a row without its only target is dropped)
+    elif not any(clean[t] for t in model.targets):
+        some = np.zeros(n, bool)
+        for t in model.targets:
+            some |= ~np.isnan(arr[t])
+        if not some.all():
+            return None
+    k = int(np.clip(round(cfg.split_data_at * n), 0, n))             # MLUtils.splitobs(at = ...)
+
+    def take(sl):
+        return ([arr[p][sl] for p in model.predictors], {f: arr[f][sl] for f in model.forcing}), {t: arr[t][sl] for t in model.targets}
+    return take(slice(0, k)), take(slice(k, n))
+
+
 def split_data(data, model, cfg: DataConfig = DataConfig(), rng: Optional[np.random.Generator] = None):
     """split_data.jl:8-79 -> (train, val) each ((X, forcings), targets)."""
     raw_cols = _columns(data) if not isinstance(data, tuple) else None
@@ -385,20 +443,84 @@ class EpochSnapshot:                                               # initializat
     y_val: Optional[dict] = None
 
 
-@dataclass
+def _prediction_tables(eng, model, ytr, yva):
+    """(train_obs_pred, val_obs_pred, train_diffs, val_diffs) of the model the engine holds: one forward pass per split (train.jl:130-136)"""
+    def obs_pred(split, y):
+        if eng.n_samples[split] == 0:
+            return {}, None
+        o = eng.forward(split)
+        d = {t: y[t] for t in model.targets}
+        d.update({t + "_pred": o[t] for t in model.targets})
+        return d, o["parameters"]
+    tr_op, tr_diff = obs_pred(L.EH_SPLIT_TRAIN, ytr)
+    va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
+    return tr_op, va_op, tr_diff, va_diff
+
+
+class _PendingPredictions:
+    """The observed-vs-predicted tables and physical parameters of a finished train() call that nobody has looked at yet: the engine --
+    parameters and BatchNorm state of the returned model set, both splits resident -- stays open until the first of the four fields is
+    read (one forward pass per split + the copies to the host, then the engine is closed) or the results are dropped.  On the
+    headline data set the eager copies are 50 MB into freshly mapped host memory: 1-22 ms of a 24-45 ms call, most of its
+    run-to-run spread (tools/e2e_breakdown.py)."""
+
+    def __init__(self, eng, model, ytr, yva):
+        self.eng, self.model, self.ytr, self.yva, self.out = eng, model, ytr, yva, None
+
+    def resolve(self):
+        if self.out is None:
+            try:
+                self.out = _prediction_tables(self.eng, self.model, self.ytr, self.yva)
+            finally:
+                self.release()
+        return self.out
+
+    def release(self):
+        eng, self.eng = self.eng, None
+        if eng is not None:
+            eng.close()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class TrainResults:                                                # TrainingConfig.jl:190-223
-    train_history: list
-    val_history: list
-    epoch_history: list
-    train_obs_pred: dict
-    val_obs_pred: dict
-    train_diffs: Optional[dict]
-    val_diffs: Optional[dict]
-    ps: np.ndarray
-    st: dict
-    best_epoch: int
-    best_loss: float
-    timing: Optional[dict] = None      # TrainConfig.timing: seconds of the epoch loop by part
+    """train_history, val_history, epoch_history, train_obs_pred, val_obs_pred, train_diffs, val_diffs, ps, st, best_epoch, best_loss
+    (+ timing).  The four prediction fields may be pending (TrainConfig.predictions = "lazy", the default for an engine train() made
+    itself): they are computed, exactly as the eager form would have, when first read; `release()` drops them and the device memory."""
+
+    def __init__(self, train_history, val_history, epoch_history, train_obs_pred, val_obs_pred, train_diffs, val_diffs, ps, st, best_epoch, best_loss,
+                 timing=None, pending: Optional[_PendingPredictions] = None):
+        self.train_history, self.val_history, self.epoch_history = train_history, val_history, epoch_history
+        self._pred = (train_obs_pred, val_obs_pred, train_diffs, val_diffs)
+        self._pending = pending
+        self.ps, self.st, self.best_epoch, self.best_loss = ps, st, best_epoch, best_loss
+        self.timing = timing           # TrainConfig.timing: seconds of the call by part
+
+    def _get(self, i):
+        if self._pending is not None:
+            self._pred = self._pending.resolve()
+            self._pending = None
+        return self._pred[i]
+
+    train_obs_pred = property(lambda self: self._get(0))
+    val_obs_pred = property(lambda self: self._get(1))
+    train_diffs = property(lambda self: self._get(2))
+    val_diffs = property(lambda self: self._get(3))
+
+    @property
+    def predictions_pending(self) -> bool:
+        return self._pending is not None
+
+    def release(self):
+        """drop pending predictions (and the engine that would have made them) without computing them"""
+        if self._pending is not None:
+            self._pending.release()
+            self._pending = None
+            self._pred = ({}, {}, None, None)
 
 
 def _losses(engine, split, targets, loss_types, agg="sum"):
@@ -527,6 +649,28 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
         eng.close(); ev.close()
 
 
+_GC_FROZEN = 0
+
+
+def _freeze_gc_once():
+    """The first train() call of a process runs ONE full garbage collection and freezes what survives it (gc.freeze: the interpreter's,
+    NumPy's and -- if it is loaded -- torch's module-level objects, about a million of them).  Without this the cyclic collector's first
+    full pass lands in the middle of the second to fourth call and walks all of them: 40-100 ms of a 17 ms call (tools/e2e_breakdown2.py:
+    the spike sat wherever the allocation count happened to cross the threshold -- engine creation, upload, the first evaluation -- and
+    was the 2 x run-to-run spread of a short train() call that rounds 4 and 5 could not explain).  EH_NO_GC_FREEZE=1 leaves the
+    collector alone."""
+    global _GC_FROZEN
+    import sys
+    state = 2 if "torch" in sys.modules else 1          # (torch imported since the last freeze: its objects are new to the collector -- once more)
+    if _GC_FROZEN >= state or os.environ.get("EH_NO_GC_FREEZE"):
+        return
+    _GC_FROZEN = state
+    import gc
+    if gc.isenabled():
+        gc.collect()
+        gc.freeze()
+
+
 def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[TrainConfig] = None,
           data_cfg: Optional[DataConfig] = None, engine=None, **kwargs) -> Optional[TrainResults]:
     """train(model, data; kwargs...) -> TrainResults (train.jl:211-219 -> _train :95-136).
@@ -541,20 +685,30 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         else:
             raise TypeError(f"train: unknown keyword {k!r}")
     validate_config(tc)
+    _freeze_gc_once()
+    t_call = time.perf_counter()
     rng = np.random.default_rng(tc.random_seed)
-    (xtr, ftr, ytr), (xva, fva, yva) = [(a[0][0], a[0][1], a[1]) for a in split_data(data, model, dc, rng)]
-    if xtr.shape[1] == 0:
+    dist_run = _want_distributed(tc)
+    fast = None if dist_run else _split_columns(model, data, dc)      # the caller's float32 columns as they are: views, no stacked copy (4 M rows: 7 -> 1 ms)
+    (xtr, ftr, ytr), (xva, fva, yva) = [(a[0][0], a[0][1], a[1]) for a in (fast if fast is not None else split_data(data, model, dc, rng))]
+    if (len(xtr[0]) if isinstance(xtr, list) else xtr.shape[1]) == 0:
         return None                                                # train.jl:186 ("returns nothing on empty splits")
-    if _want_distributed(tc):
+    if dist_run:
         return _train_distributed(model, tc, rng, (xtr, ftr, ytr), (xva, fva, yva))
     own = engine is None
     xfn = _extra_fn(tc.extra_loss)                    # extra_loss as a function of the predictions (compute_loss.jl:31-34): recorded, its entries ride on targets of their own
     if xfn is not None and engine is not None and not engine.n_pseudo:
         raise ValueError("train(engine = ...): an extra_loss of the predictions needs an engine created with it (model.engine(device, extra_fn = f))")
+    t_prep = time.perf_counter()
     eng = engine if engine is not None else model.engine(tc.device, extra_fn=xfn)
+    t_eng = time.perf_counter()
+    keep_engine = False
     try:
         eng.set_data(L.EH_SPLIT_TRAIN, xtr, [ftr[f] for f in model.forcing], [ytr[t] for t in model.targets])
         eng.set_data(L.EH_SPLIT_VAL, xva, [fva[f] for f in model.forcing], [yva[t] for t in model.targets])
+        if tc.timing:
+            eng.synchronize()
+        t_up = time.perf_counter()
         if tc.train_from is None:
             theta = model.initialparameters(rng)
         else:
@@ -576,6 +730,7 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
                     preds = eng.forward(split, params=False) if (xfn is not None and eng.n_samples[split]) else None
                     d["extra_loss"] = _extra_loss_values(model, eng.get_params(), xterms, aggn, xfn, preds)
             return snap
+        t_setup = time.perf_counter()
         init = snapshot()
         history = [init]
         best_loss, best_ps, best_epoch, counter = init.l_val[first_lt][aggn], theta.copy(), 0, 0
@@ -583,6 +738,11 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
         best_bn = eng.get_bn_state() if has_bn else None            # early_stopping.jl update!: best_ps AND best_st
         seed0 = tc.random_seed if tc.random_seed is not None else int(rng.integers(2**31))
         tm = {"steps_s": 0.0, "eval_s": 0.0, "host_s": 0.0, "epochs": 0} if tc.timing else None
+        if tm is not None:
+            # outside the epoch loop, part by part: split + cast of the caller's columns | engine creation | interleave +
+            # upload of both splits | parameters, optimiser, options (incl. a run-time compilation that is not in the disk cache) | the
+            # evaluation of epoch 0
+            tm.update(prepare_s=t_prep - t_call, engine_s=t_eng - t_prep, upload_s=t_up - t_eng, setup_s=t_setup - t_up, initial_eval_s=time.perf_counter() - t_setup)
         t_loop = time.perf_counter()
         for epoch in range(1, tc.nepochs + 1):
             t0 = time.perf_counter()
@@ -611,27 +771,30 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
             eng.synchronize()
             tm["loop_s"] = time.perf_counter() - t_loop
             tm["host_s"] = tm["loop_s"] - tm["steps_s"] - tm["eval_s"]
+        t_final = time.perf_counter()
         ps = best_ps if tc.return_model == "best" else eng.get_params()                        # best_or_final
         bn_out = (best_bn if tc.return_model == "best" else eng.get_bn_state()) if has_bn else None
         eng.set_params(ps)
         if has_bn:
             eng.set_bn_state(*bn_out)                                # the predictions below use the state that belongs to `ps`
 
-        def obs_pred(split, y):
-            if eng.n_samples[split] == 0:
-                return {}, None
-            out = eng.forward(split)
-            d = {t: y[t] for t in model.targets}
-            d.update({t + "_pred": out[t] for t in model.targets})
-            return d, out["parameters"]
-        tr_op, tr_diff = obs_pred(L.EH_SPLIT_TRAIN, ytr)
-        va_op, va_diff = obs_pred(L.EH_SPLIT_VAL, yva)
         fixed = {f: np.float32(model.parameters.default(f)) for f in model.fixed_param_names}
         st = {"fixed": fixed}
         if has_bn:
             st["st_nn"] = {"running_mean": bn_out[0], "running_var": bn_out[1]}      # Lux BatchNorm state of the returned model (best_or_final)
-        return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, tr_op, va_op, tr_diff, va_diff,
-                            ps, st, best_epoch, best_loss, tm)
+        if tc.predictions not in ("lazy", "eager"):
+            raise ValueError("predictions must be 'lazy' or 'eager'")
+        if own and tc.predictions == "lazy":
+            pending = _PendingPredictions(eng, model, ytr, yva)
+            keep_engine = True           # (the results own it from here: closed when the predictions are read, released or dropped)
+            preds = (None, None, None, None)
+        else:
+            pending, preds = None, _prediction_tables(eng, model, ytr, yva)
+        if tm is not None:
+            tm["final_predictions_s"] = time.perf_counter() - t_final       # (eager: forward over both splits with the returned parameters + the copies to the host)
+            tm["call_s_before_close"] = time.perf_counter() - t_call
+        return TrainResults([s.l_train for s in history], [s.l_val for s in history], history, *preds,
+                            ps, st, best_epoch, best_loss, tm, pending)
     finally:
-        if own:
+        if own and not keep_engine:
             eng.close()

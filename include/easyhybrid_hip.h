@@ -201,6 +201,8 @@ int32_t eh_synchronize(eh_handle* h);
  * holds: no transposed copy on the caller's side). */
 #define EH_DATA_ON_DEVICE 1
 #define EH_DATA_X_PLANES 2
+#define EH_DATA_X_ROWS 4      /* host arrays only: x is really `const float* const*`, P pointers to arrays of N -- the caller's own predictor columns
+                               * (a DataFrame's), interleaved into the records without ever being stacked into a matrix on the host */
 int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, const float* const* forcings,
                     const float* const* targets, int32_t on_device);
 

@@ -690,10 +690,13 @@ def test_set_data_layouts_agree():
     import torch
     spec, theta, X, f, y = util.rbq10_case(70001, "tanh", True, 0.1)      # (above 65 536: the host path packs in two threads)
     outs = []
-    for where, planes in (("host", True), ("host", False), ("device", True), ("device", False)):
+    for where, planes in (("host", True), ("host", False), ("device", True), ("device", False), ("rows", None)):
         eng = util.model_from_spec(spec).engine()
         xh = np.ascontiguousarray(X) if planes else np.ascontiguousarray(X.T)
-        if where == "host":
+        if where == "rows":          # EH_DATA_X_ROWS: the predictor columns as separate arrays, through the front door (engine.set_data with a list)
+            cols = [X[p].copy() for p in range(X.shape[0])]
+            eng.set_data(0, cols, [f["ta"]], [y["reco"]])
+        elif where == "host":
             fp = (C.c_void_p * 1)(f["ta"].ctypes.data); tp = (C.c_void_p * 1)(y["reco"].ctypes.data)
             eng._chk(eng._lib.eh_set_data(eng._h, 0, 70001, C.c_void_p(xh.ctypes.data), fp, tp, 2 if planes else 0))
             eng.n_samples[0] = 70001
@@ -708,8 +711,10 @@ def test_set_data_layouts_agree():
     for l, g, n in outs[1:]:
         assert l == outs[0][0] and np.array_equal(g, outs[0][1]) and n == outs[0][2]
     eng = util.model_from_spec(spec).engine()
-    with pytest.raises(ValueError, match="flags 4"):
-        eng._chk(eng._lib.eh_set_data(eng._h, 0, 10, C.c_void_p(X.ctypes.data), (C.c_void_p * 1)(f["ta"].ctypes.data), (C.c_void_p * 1)(y["reco"].ctypes.data), 4))
+    with pytest.raises(ValueError, match="flags 8"):
+        eng._chk(eng._lib.eh_set_data(eng._h, 0, 10, C.c_void_p(X.ctypes.data), (C.c_void_p * 1)(f["ta"].ctypes.data), (C.c_void_p * 1)(y["reco"].ctypes.data), 8))
+    with pytest.raises(ValueError, match="EH_DATA_X_ROWS"):          # rows of pointers are host arrays, and not planes at the same time
+        eng._chk(eng._lib.eh_set_data(eng._h, 0, 10, C.c_void_p(X.ctypes.data), (C.c_void_p * 1)(f["ta"].ctypes.data), (C.c_void_p * 1)(y["reco"].ctypes.data), 4 | 2))
     eng.close()
 
 

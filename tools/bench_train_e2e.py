@@ -81,13 +81,31 @@ def _one(eh, name, model, cols, kw, spec, eager_args, threads):
     out = {"workload": name}
     t0 = time.perf_counter(); eh.train(model, cols, **kw); out["first_call_s"] = time.perf_counter() - t0      # pays compilation / caches once, like the tutorial's warm-up
     reps = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter(); res = eh.train(model, cols, **kw); reps.append(time.perf_counter() - t0)
     out["train_call_s"] = float(np.median(reps)); out["train_call_s_runs"] = reps
+    out["train_call_max_over_min"] = max(reps) / min(reps)
+    t0 = time.perf_counter(); n_pred = sum(len(v) for v in res.val_obs_pred.values()) + sum(len(v) for v in res.train_obs_pred.values())
+    out["predictions_first_read_s"] = time.perf_counter() - t0      # TrainConfig.predictions = "lazy" (default): the tables are made when they are read
+    eager = []
+    for _ in range(3):
+        t0 = time.perf_counter(); eh.train(model, cols, predictions="eager", **kw); eager.append(time.perf_counter() - t0)
+    out["train_call_s_eager_predictions"] = float(np.median(eager))
     tm = eh.train(model, cols, timing=True, **kw).timing
     out["epoch_loop_split_s"] = {k: tm[k] for k in ("steps_s", "eval_s", "host_s", "loop_s")}
     out["eval_plus_host_share_of_loop"] = (tm["eval_s"] + tm["host_s"]) / tm["loop_s"]
     out["outside_the_loop_s"] = out["train_call_s"] - tm["loop_s"]          # (timing run: one extra synchronisation per epoch -- the loop itself is a little slower than in the plain call)
+    # ... and what is outside, part by part (TrainConfig.timing): split of the caller's columns | engine | interleave + upload | parameters,
+    # optimiser, options | evaluation of epoch 0 | final predictions (lazy: none) ; the rest of the call is closing the engine
+    out["outside_the_loop_split_s"] = {k: tm[k] for k in ("prepare_s", "engine_s", "upload_s", "setup_s", "initial_eval_s", "final_predictions_s")}
+    # the step mode a seeded run takes by default (fused_update = "auto" with random_seed set: bitwise reproducible) against one kernel per
+    # step everywhere (float-atomic sums; what bench.py's headline line measures at the engine)
+    try:
+        t0 = time.perf_counter(); eh.train(model, cols, fused_update=True, **kw); out["train_call_s_fused_update_true"] = time.perf_counter() - t0
+        tmf = eh.train(model, cols, fused_update=True, timing=True, **kw).timing
+        out["steps_s_fused_update_true"] = tmf["steps_s"]
+    except NotImplementedError:          # (no one-kernel step for this model: the layer-wise form)
+        out["train_call_s_fused_update_true"] = out["steps_s_fused_update_true"] = None
     out["epochs"], out["best_loss"] = tm["epochs"], float(res.best_loss)
     try:
         out["eager_cpu"] = _eager_cpu(spec, cols, *eager_args, threads)
