@@ -95,6 +95,18 @@ def spawn_ranks_once(nprocs, cmd, env=None, capture=False, timeout=None):
     return (rc, b"".join(chunks).decode(errors="replace")) if capture else rc
 
 
+def _cpu_model():
+    try:
+        models = {}
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                m = line.split(":", 1)[1].strip()
+                models[m] = models.get(m, 0) + 1
+        return "; ".join(f"{v} x {k}" for k, v in models.items()) or "unknown"
+    except Exception:
+        return "unknown"
+
+
 def cpu_baseline(batch, seconds=12.0):
     """The CPU oracle (C port in its blocked, vectorised form -- oracle/eh_oracle_fast.c -- OpenMP over sample blocks) timed on this box's host cores, on a
     bounded sample of the same workload: steps of `batch` samples for ~`seconds` of CPU work.  The
@@ -105,12 +117,13 @@ def cpu_baseline(batch, seconds=12.0):
     spec = ho.rbq10_spec((16, 16), "tanh", True)
     X, f, y = ho.make_synth_rbq10(4 * batch, 42)
     theta = ho.init_theta(spec, 1, np.float32)
-    best, per = None, None
+    best, per, sweep = None, None, {}
     for nt in sorted({min(avail, k) for k in (8, 16, 32, 64, 128, 256, avail)}):
         co.train_steps(spec, theta, X, f, y, batch, 1, nthreads=nt, fast=True)          # warm-up (page-in, thread pool)
         t0 = time.perf_counter()
         co.train_steps(spec, theta, X, f, y, batch, 2, nthreads=nt, fast=True)
         t = (time.perf_counter() - t0) / 2
+        sweep[str(nt)] = batch / t                                                       # samples/s at this thread count (two steps: a sweep, not a measurement)
         if per is None or t < per:
             best, per = nt, t
     n, chunk, t0 = 0, max(2, min(64, int(1.0 / max(per, 1e-4)))), time.perf_counter()
@@ -122,7 +135,9 @@ def cpu_baseline(batch, seconds=12.0):
            "sample": f"{n} Adam steps of batch {batch} (RbQ10 [2,16,16,1], fp32) = {dt:.1f} s of the C port in its blocked form "
                      f"(oracle/eh_oracle_fast.c: 16 samples per SIMD block, AVX2, rational tanh, vector exp / log; the scalar checker "
                      f"oracle/eh_oracle.c is not what is timed), OpenMP over blocks on {best} of {avail} host threads (fastest of a short sweep)",
-           "ms_per_step": 1e3 * dt / n}
+           "ms_per_step": 1e3 * dt / n,
+           # "core count and CPU model stated"; and the sweep the thread count came from -- the last entry is ALL host threads
+           "cpu_model": _cpu_model(), "host_threads": avail, "thread_sweep_samples_per_s": sweep, "all_host_threads_samples_per_s": sweep.get(str(avail))}
     # PyTorch-CPU eager autograd + Adam on the same batch -- the structurally closest stand-in for the
     # reference's Lux + Zygote step this box can run (BLAS GEMMs, un-fused broadcasts, tape, boolean-mask gather); ~3 s
     try:
@@ -478,9 +493,11 @@ def main():
                        "rank_devices": devices,
                        "gradient_exchange": ("none (one GPU)" if dp is None else "peer-to-peer stores from the step kernel (eh_p2p_*), no collective call per step" if dp.p2p
                                              else "one RCCL all-reduce per step" if not share else "one gloo all-reduce per step (EH_BENCH_SHARE_GPU=1: all ranks on one GPU, testing only)"),
-                       "gradient_exchange_calibration_us_per_step": exchange_cal, "step_kernel": built,
-                       "step_mode": "one kernel per step (fused_update) on the kernel specialised for this descriptor (see step_kernel): what train() runs by "
-                                    "default (TrainConfig.fused_update = specialize = 'auto')" if dp is None else "see step_kernel / gradient_exchange"},
+                       "gradient_exchange_calibration_us_per_step": exchange_cal,
+                       "gradient_exchange_negotiation": getattr(dp, "p2p_report", None) if dp is not None else None, "step_kernel": built,
+                       "step_mode": "one kernel per step (fused_update = 1: float-atomic sums) on the kernel specialised for this descriptor (see step_kernel): what "
+                                    "train(fused_update = True) or an unseeded train() runs; a seeded train() -- the default, bitwise reproducible -- takes the deterministic "
+                                    "step + reduce pair at this batch size (train_e2e: steps_s against steps_s_fused_update_true)" if dp is None else "see step_kernel / gradient_exchange"},
             "roofline": roof,
         }
         if n1_ref is not None:

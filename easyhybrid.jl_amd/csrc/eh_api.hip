@@ -2210,8 +2210,17 @@ static int do_eval(eh_handle* h, int split, long long first, long long count, do
         a.slab = h->eval_host_dev;
         part = h->eval_host;
     }
+    // (eh_profile_enable: HIP events on the engine's stream around the evaluation kernel too -- the kernel's own time beside the call's,
+    //  which also holds the launch, the synchronisation and the reading of the sums; bench.py eh_eval_roofline)
+    const bool prof_ev = h->prof && h->ev_used + 3 <= 3 * 8192 && ensure_events(h, h->ev_used + 3) == EH_OK;
+    if (prof_ev) HIPCHK(h, hipEventRecord(h->ev[h->ev_used], h->stream));
     if (h->lform) { if ((rc = lform_eval(h, sp, first, count, a.yhat, a.pout, &grid))) return rc; }
     else HIPCHK(h, step_launch(h, EH_MODE_EVAL, grid, &a));
+    if (prof_ev) {
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+        HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
+        h->ev_used += 3;
+    }
     if (!part) {
         part_copy.resize((size_t)grid * a.n_acc);
         HIPCHK(h, hipMemcpyAsync(part_copy.data(), h->slab, part_copy.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -101,6 +101,7 @@ class DataParallel:
         self.buf = torch.as_tensor(_DevArray(ptr, n), device=dev)
         self.p2p = False
         self.p2p_mode = 0
+        self.p2p_report = None                              # set by the negotiation: how far it got on every rank
         if fused and int(engine.desc.n_targets) > 1:        # the per-target weights need the GLOBAL counts before the pass: eh_dp_counts + three-kernel path
             fused = self.fused = False
         if fused:
@@ -180,42 +181,61 @@ class DataParallel:
         return bool(int(t.item()))
 
     def _negotiate_p2p(self) -> bool:
-        """Export / map the receive buffers and run the self-test; every rank ends with the same answer."""
+        """Export / map the receive buffers and run the self-test; every rank ends with the same answer.  `self.p2p_report` says, rank by
+        rank, how far the negotiation got and why it stopped (what bench.py --gpus N prints: on real multi-GPU hardware the first run has
+        to tell which of IPC export, IPC mapping of every peer's buffer, or the store / load self-test over xGMI is the one that failed)."""
         import os
         import torch.distributed as dist
         eng = self.engine
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        info = {"rank": rank, "export": None, "attach": None, "selftest": None, "error": None}
+
+        def done(enabled, stage):
+            infos = [None] * world
+            dist.all_gather_object(infos, info, group=self.group)
+            self.p2p_report = {"enabled": enabled, "stopped_at": None if enabled else stage, "world": world,
+                               "stages": "export = uncached receive buffer + IPC handle; attach = every peer's buffer mapped (world - 1 IPC attachments per rank); "
+                                         "selftest = 8 exchange rounds, every word of every peer checked", "ranks": infos}
+            return enabled
         if world < 2 or world > 8:
+            self.p2p_report = {"enabled": False, "stopped_at": "world size %d (2..8)" % world, "world": world, "ranks": []}
             return False
         try:
             handle = eng.p2p_init(world, rank)
-        except Exception:                                   # no uncached memory / IPC on this system
+            info["export"] = True
+        except Exception as e:                              # no uncached memory / IPC on this system
             handle = None
+            info["export"], info["error"] = False, repr(e)[:200]
         if not self._all_agree(handle is not None):
             eng.p2p_disable()
-            return False
+            return done(False, "export")
         handles = [None] * world
         dist.all_gather_object(handles, handle, group=self.group)
         try:
             eng.p2p_attach(handles)
             ok = True
-        except Exception:
+        except Exception as e:
             ok = False
+            info["error"] = repr(e)[:200]
+        info["attach"] = ok
         if not self._all_agree(ok):
             eng.p2p_disable()
-            return False
+            return done(False, "attach")
         dist.barrier(group=self.group)                      # every rank has every buffer mapped before anyone stores
         try:
             ok = eng.p2p_selftest(8)
-        except Exception:
+        except Exception as e:
             ok = False
+            info["error"] = repr(e)[:200]
         if self._debug_fail_rank is not None and int(self._debug_fail_rank) == rank:
             ok = False
+            info["error"] = "debug_fail_selftest_rank"
+        info["selftest"] = bool(ok)
         if not self._all_agree(ok):
             dist.barrier(group=self.group)                  # nobody unmaps while a peer's test kernel may still store
             eng.p2p_disable()
-            return False
-        return True
+            return done(False, "selftest")
+        return done(True, None)
 
     def _refresh_gacc(self):
         import torch

@@ -150,12 +150,21 @@ def measure(device=0, with_large=True, with_headline=True):
         for _ in range(reps):
             eng.eval(eh.EH_SPLIT_TRAIN)
         per = (time.perf_counter() - t0) / reps
+        # the kernel alone, by HIP events on the engine's stream around each launch (94 us per call at the driver against a 78 us kernel)
+        eng.profile_enable(1)
+        for _ in range(reps):
+            eng.eval(eh.EH_SPLIT_TRAIN)
+        kern = eng.profile_samples()
+        eng.profile_enable(False)
         eng.close()
         eval_roof = {"kernel": "eh_step_kernel<..., EVAL> over the headline training split (metrics only: no write-back), one eh_eval call = kernel + 8 x T sums to the host",
                      "samples": n, "ms_per_call": 1e3 * per, "bound": "hbm", "algorithmic_bytes_per_sample": 16, "algorithmic_flop_per_sample": 608,
                      "achieved": 16 * n / per / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": 16 * n / per / 1e9 / 8000.0,
                      "algorithmic_TFLOPs": 608 * n / per / 1e12, "frac_f32_peak": 608 * n / per / 1e12 / 157.3,
-                     "timing": "host clock around 20 synchronous eh_eval calls (each ends with the copy of the sums to the host)"}
+                     "kernel_ms_by_events": float(np.median(kern)) if len(kern) else None, "kernel_ms_by_events_min_max": [float(np.min(kern)), float(np.max(kern))] if len(kern) else None,
+                     "call_minus_kernel_us": 1e3 * (1e3 * per - float(np.median(kern))) if len(kern) else None,
+                     "timing": "host clock around 20 synchronous eh_eval calls (each ends with the copy of the sums to the host); kernel_ms_by_events: HIP events on the "
+                               "engine's stream around each of 20 more launches -- the difference is the launch, the synchronisation and the host's reading of the sums"}
     return {"what": "wall-clock of eh.train(...) end to end (median of 3 calls after one warm-up call) and the split of its epoch loop; the same work in PyTorch-CPU eager beside it",
             "host_threads_for_eager": threads, "runs": runs, "eh_eval_roofline": eval_roof}
 

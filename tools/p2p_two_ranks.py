@@ -61,11 +61,11 @@ same = all(bool(torch.equal(tl[0], q)) for q in tl)
 print(f"rank {rank}: p2p={drv.p2p} p2p_mode={drv.p2p_mode} jit_kernels={eng.jit_status()[0]} steps={nsteps} {1e6 * dt / nsteps:.1f} us/step max|theta-ref|={err:.2e} replicas_identical={same}", flush=True)
 ok = err <= 3e-5 and same
 if os.environ.get("EH_TOOL_FORCE_TIMEOUT") == "1":
-    # recovery: rank 0 runs one step more than rank 1, so its exchange never completes and runs into the 2 s deadline; check() must
+    # recovery: one rank (0, or EH_TOOL_TIMEOUT_RANK) runs one step more than the others, so its exchange never completes and runs into the 2 s deadline; check() must
     # notice on every rank, drop to the all-reduce exchange and re-synchronise parameters AND optimiser state from rank 0
     for i in range(3):
         drv.step(i * b, b)
-    if rank == 0:
+    if rank == int(os.environ.get("EH_TOOL_TIMEOUT_RANK", "0")) % world:          # (the rank that runs ahead: any one of them)
         drv.step(3 * b, b)
     healthy = drv.check()
     for i in range(12):
