@@ -217,10 +217,11 @@ class TrainConfig:
     #                partial sums meet through float atomics, reproducible to ~1e-7, not bitwise.  A run with `random_seed` set -- the
     #                default, as in the reference (TrainingConfig.jl:85-86), where a seeded CPU run IS reproducible -- takes that form
     #                only where it is bitwise reproducible: minibatches one workgroup covers (up to 256 samples: several steps per
-    #                launch, sums in one fixed order); larger minibatches run the deterministic step + reduce/optimiser pair (13.9
-    #                against 9.6 us per step at batch 65 536 on the headline model: `random_seed=None` or `fused_update=True` buys
-    #                the difference back).  False: always the deterministic pair.  True: insist on one kernel per step (raises where
-    #                it is not built).
+    #                launch, sums in one fixed order); larger minibatches run the deterministic step + reduce/optimiser pair (14.6
+    #                against 10.2 us per step at batch 65 536 on the headline model, tools/bench_step_modes.py: `random_seed=None` or
+    #                `fused_update=True` buys the difference back).  False: always the deterministic pair.  True: insist on one kernel
+    #                per step (raises where it is not built).  (An ORDERED one-kernel form -- fixed-point sums, integer atomics -- was
+    #                built and measured in round 6: 13.9 us, and 0.6 us on the float form it shared the kernel with; removed.)
     # bench.py measures specialize on and fused_update = True at the engine.
     specialize: Any = "auto"
     fused_update: Any = "auto"
@@ -249,6 +250,8 @@ def _apply_step_mode(eng, tc: "TrainConfig"):
         raise ValueError("specialize / fused_update must be True, False or 'auto'")
     if tc.fused_update is not False:
         try:
+            # "auto" in a seeded run: one kernel per step only where that is bitwise reproducible (engine option value 2: minibatches one
+            # workgroup covers), the deterministic pair elsewhere -- two default train(random_seed = s) calls are the same bits
             # "auto" in a seeded run: one kernel per step only where that is bitwise reproducible (engine option value 2: minibatches one
             # workgroup covers), the deterministic pair elsewhere -- two default train(random_seed = s) calls are the same bits
             eng.set_option("fused_update", 2 if (tc.fused_update == "auto" and tc.random_seed is not None) else 1)
