@@ -1551,9 +1551,37 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
     if (bn_self) { pa.bn_self = 1; pa.bn_update = bn_update ? 1 : 0; }
     const long long tot = (long long)B * net.P;
     const float* theta = TH(h);
+    // Few rows: minibatch matrix + BatchNorm + first layer + the SECOND layer's few-rows product as one launch (eh_fewrows_first_kernel) where
+    // the second layer is a hidden layer that would run eh_fewrows_gemm_kernel anyway
+    bool fused01 = false;
+    {
+        static const bool nofirst = getenv("EH_LFORM_NOFIRST") != nullptr;
+        static const bool nofew = getenv("EH_GEMM_NOFEWROWS") != nullptr;
+        static const int first_maxb = getenv("EH_LFORM_FIRST_MAXB") ? atoi(getenv("EH_LFORM_FIRST_MAXB")) : 64;   // every workgroup takes the statistics itself: a loss from ~128 rows up
+        const eh_handle_s::LNet& L0 = h->l_net[0];
+        const int stop = lstop >= 0 ? lstop : L0.nl;
+        auto al16 = [](const void* p) { return (reinterpret_cast<unsigned long long>(p) & 15ull) == 0; };
+        if (!nofirst && !nofuse && !nofew && !g_gemm_novec && L0.nl >= 3 && stop >= 2 && L0.in[0] <= 4 && B >= 1 && B <= first_maxb &&
+            L0.out[0] >= 64 && (L0.out[0] % 16) == 0 && (L0.out[1] % 4) == 0 &&
+            al16(theta + L0.woff[0]) && al16(theta + L0.boff[0]) && al16(theta + L0.woff[1])) {
+            EhGemmArgs f{};
+            f.lda = net.P; f.B = theta + L0.woff[0]; f.ldb = L0.out[0]; f.M = B; f.N = L0.out[0]; f.K = L0.in[0]; f.kchunk = f.K;
+            f.bias = theta + L0.boff[0]; f.act = L0.lact[0]; f.C = W.H[0][0]; f.ldc = L0.out[0]; f.Z = W.Z[0][0];
+            EhGemmArgs g{};
+            g.A = nullptr; g.lda = L0.in[1]; g.B = theta + L0.woff[1]; g.ldb = L0.out[1];
+            g.M = B; g.N = L0.out[1]; g.K = L0.in[1]; g.c_zstride = 0;
+            g.bias = theta + L0.boff[1]; g.act = L0.lact[1]; g.C = W.H[0][1]; g.ldc = L0.out[1]; g.Z = W.Z[0][1];
+            g.kchunk = std::max(16, ((g.K + 15) / 16 + 15) / 16 * 16);         // <= 16 slices of whole 16-deep groups (lform_gemm's few-rows rule)
+            const int nwv = (g.K + g.kchunk - 1) / g.kchunk;
+            if (f.K <= 2) hipLaunchKernelGGL((eh_fewrows_first_kernel<EH_GEPI_BIAS_ACT, 2>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nwv), 0, h->stream, pa, f, g, L0.c0);
+            else hipLaunchKernelGGL((eh_fewrows_first_kernel<EH_GEPI_BIAS_ACT, 4>), dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16)), dim3(64u * (unsigned)nwv), 0, h->stream, pa, f, g, L0.c0);
+            HIPCHK(h, hipGetLastError());
+            fused01 = true;
+        }
+    }
     // the first network's first layer rides along when it is one of the few-predictor products (K <= 8, hidden layer behind it)
     bool fused0 = false;
-    {
+    if (!fused01) {
         const eh_handle_s::LNet& L0 = h->l_net[0];
         if (!nofuse && !g_gemm_novec && L0.nl >= 2 && L0.in[0] <= 8 && lstop != 0) {
             EhGemmArgs g{};
@@ -1565,12 +1593,13 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
             fused0 = true;
         }
     }
-    if (!fused0) hipLaunchKernelGGL((eh_lform_prep_kernel<false>), dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa, EhGemmArgs{}, 0);
+    if (!fused0 && !fused01) hipLaunchKernelGGL((eh_lform_prep_kernel<false>), dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (tot + 255) / 256))), dim3(256), 0, h->stream, pa, EhGemmArgs{}, 0);
     HIPCHK(h, hipGetLastError());
     for (int k = 0; k < h->l_nnets; ++k) {
         const eh_handle_s::LNet& L = h->l_net[k];
         for (int l = 0; l < (lstop >= 0 ? lstop : L.nl); ++l) {
-            if (fused0 && k == 0 && l == 0) continue;
+            if ((fused0 || fused01) && k == 0 && l == 0) continue;
+            if (fused01 && k == 0 && l == 1) continue;
             EhGemmArgs g{};
             g.A = l == 0 ? W.Xb + L.c0 : W.H[k][l - 1]; g.lda = l == 0 ? net.P : L.in[l];      // (a network's predictors: its columns of the minibatch matrix)
             g.B = theta + L.woff[l]; g.ldb = L.out[l];                   // canonical (out, in) column-major == [in][out] row-major

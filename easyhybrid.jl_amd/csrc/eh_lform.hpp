@@ -822,6 +822,147 @@ __global__ __launch_bounds__(256) void eh_lform_prep_kernel(const EhLPrepArgs a,
     }
 }
 
+// Few rows, few predictors: the minibatch matrix, the input BatchNorm, the FIRST Dense layer (K = P <= 8: a handful of fused multiply-adds
+// per value) and the SECOND layer's few-rows product (eh_fewrows_gemm_kernel: 16 x 16 output tile per workgroup, the k range over its
+// waves) as ONE launch: the second layer's A operand -- 16 rows of the first layer's activations -- is computed where it is needed, from
+// this workgroup's 16 normalised records in LDS, by the expression of eh_lform_prep_kernel<true> (the same fmaf chain: the same bits); the
+// workgroups of the first column block also store it (and the normalised records) for the weight gradients and act' of the backward pass.
+// Every workgroup takes the minibatch's BatchNorm statistics itself (the same sums in the same order); workgroup (0, 0) advances the running
+// ones.  One launch boundary and one round of dependent loads fewer per step: the tutorial net's prep + first-layer launch was 5 us of 56.
+// g: the second layer's product (g.A unused); f: the first layer (B = W_0 [P][out_0], bias, act, C = H_0, Z = its pre-activation for swish).
+// KP: predictors of the first network, rounded up (2 or 4): its weight fragments are held in registers -- 16 waves leave 128 each (a first
+// version sized for eight predictors spilled: 84 against 56 us per step)
+template <int EPI, int KP>
+__global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArgs a, const EhGemmArgs f, const EhGemmArgs g, const int c0) {
+    static_assert(EPI == EH_GEPI_BIAS_ACT && (KP == 2 || KP == 4), "forward product; at most four predictors");
+    __shared__ float red[16][256];
+    __shared__ float mu[32], rs[32], sred[32][64], xs[16][8];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    // ---- the weights of this wave's first k round are asked for before anything else: they arrive behind the statistics ------------------
+    const int kbeg = wave * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int nc = min(n0 + r, g.N - 1);
+    const float* const pb = g.B + (long long)(4 * q) * g.ldb + nc;
+    f32x4_lf b[4], w0[4][KP], bq[4];
+    auto load_round = [&](const int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kb = k0 + 16 * u;
+            const bool ok = kb < kend;
+            const int kk = ok ? kb + 4 * q : 0;
+            bq[u] = *(const f32x4_lf*)(f.bias + kk);
+#pragma unroll
+            for (int pp = 0; pp < KP; ++pp) w0[u][pp] = *(const f32x4_lf*)(f.B + (long long)min(pp, f.K - 1) * f.ldb + kk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[u][i] = ok ? pb[(long long)(kb + i) * g.ldb] : 0.0f;
+        }
+    };
+    load_round(kbeg);
+    // ---- input BatchNorm statistics of the minibatch (train mode, small minibatch) or the image's (eh_lform_prep_kernel) ------------------
+    const int ngrp = nthr >> 5;                      // sample groups of 32 predictors each
+    if (a.bn_self) {
+        const int p = tid & 31, grp = tid >> 5;
+        const long long nf = a.idx ? (long long)a.idx[a.first] : a.first;
+        float s1 = 0.0f, s2 = 0.0f;
+        if (p < a.P) {
+            const float cc = a.recs[nf * a.C + p];
+            for (int i = grp; i < a.count; i += ngrp) {
+                const long long n = a.idx ? (long long)a.idx[a.first + i] : a.first + i;
+                const float d = a.recs[n * a.C + p] - cc;
+                s1 += d; s2 += d * d;
+            }
+        }
+        sred[grp][p] = s1; sred[grp][32 + p] = s2;
+        __syncthreads();
+    }
+    if (tid < 32) {
+        float m = a.meta[EH_IMG_BNM + tid], rr = a.meta[EH_IMG_BNR + tid];
+        if ((a.bn_part || a.bn_self) && tid < a.P) {
+            float s1 = 0.0f, s2 = 0.0f;
+            if (a.bn_self) { for (int b = 0; b < ngrp; ++b) { s1 += sred[b][tid]; s2 += sred[b][32 + tid]; } }
+            else for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
+            const long long nf = a.idx ? (long long)a.idx[a.first] : a.first;
+            const float cnt = a.bn_n ? *a.bn_n : (float)a.count, cc = a.bn_self ? a.recs[nf * a.C + tid] : a.bn_c[tid];
+            const float d = s1 / cnt, var = fmaxf(s2 / cnt - d * d, 0.0f);
+            m = cc + d; rr = 1.0f / sqrtf(var + EH_BN_EPS);
+            if (a.bn_update && blockIdx.x == 0 && blockIdx.y == 0) {
+                const float rm = (1.0f - EH_BN_MOMENTUM) * a.bn_run[tid] + EH_BN_MOMENTUM * m;
+                const float rv = (1.0f - EH_BN_MOMENTUM) * a.bn_run[32 + tid] + EH_BN_MOMENTUM * (cnt > 1.0f ? cnt / (cnt - 1.0f) : 1.0f) * var;
+                a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
+                a.meta[EH_IMG_BNM + tid] = rm;                          // what forward / eval (test mode) will use
+                a.meta[EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
+            }
+        }
+        mu[tid] = m; rs[tid] = rr;
+    }
+    __syncthreads();
+    // ---- this workgroup's 16 rows, normalised: LDS (all predictors of the first network: K = f.K <= 8) and, from the first column block, Xb
+    if (tid < 16 * f.K) {
+        const int rr = tid / f.K, k = tid - rr * f.K, m = min(m0 + rr, g.M - 1), pcol = c0 + k;
+        const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m;
+        const float x = a.recs[ng * a.C + pcol];
+        xs[rr][k] = pcol < 32 ? (x - mu[pcol]) * rs[pcol] : x;
+    }
+    if (blockIdx.x == 0) {                            // the minibatch matrix (every predictor column: networks of a MultiNN model read theirs from it)
+        for (int e = tid; e < 16 * a.P; e += nthr) {
+            const int rr = e / a.P, pc = e - rr * a.P, m = m0 + rr;
+            if (m < g.M) {
+                const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m;
+                const float x = a.recs[ng * a.C + pc];
+                a.Xb[(long long)m * a.P + pc] = pc < 32 ? (x - mu[pc]) * rs[pc] : x;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the second layer's product, its A operand made on the way ---------------------------------------------------------------------
+    float xr[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) xr[k] = k < f.K ? xs[r][k] : 0.0f;
+    const bool keep = blockIdx.x == 0 && m0 + r < g.M;
+    f32x4_lf acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        f32x4_lf av[4];
+        if (k0 != kbeg) load_round(k0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kb = k0 + 16 * u;
+            const bool ok = kb < kend;
+            f32x4_lf z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = 0.0f;
+#pragma unroll
+                for (int pp = 0; pp < KP; ++pp)
+                    if (pp < f.K) v = fmaf(xr[pp], w0[u][pp][i], v);
+                z[i] = v + bq[u][i];
+                av[u][i] = ok ? eh_act_rt(f.act, z[i]) : 0.0f;
+            }
+            if (keep && ok) {
+                *(f32x4_lf*)(f.C + (long long)(m0 + r) * f.ldc + kb + 4 * q) = av[u];
+                if (f.Z) *(f32x4_lf*)(f.Z + (long long)(m0 + r) * f.ldc + kb + 4 * q) = z;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], b[u][i], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][(4 * q + i) * 16 + r] = acc[i];
+    __syncthreads();
+    if (tid < 256) {
+        float v = 0.0f;
+        for (int w = 0; w < nw; ++w) v += red[w][tid];
+        const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+        if (m < g.M && n < g.N) {
+            v += g.bias[n];
+            if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
+            g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
+        }
+    }
+}
+
 // Mechanistic model + masked loss (+ its pullback), one sample per lane, between the forward and the backward GEMMs:
 // O [K][ldo] raw NN outputs in -> (TRAIN) d loss / d O in place, one row of partial sums per workgroup
 // [grad of the raw globals (8) | S | n_t (4) | Sy | Syy]; (eval) predictions / parameters out, metric sums per workgroup.
