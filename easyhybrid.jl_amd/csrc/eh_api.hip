@@ -1758,14 +1758,24 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         t.O = W.O + (long long)L.orow * W.ldo; t.ldo = W.ldo; t.part = W.part;
         const int R = count <= 64 ? 1 : 4;
         const int tgrid = (int)((count + R - 1) / R);
-        const size_t lds = eh_ltail_lds_bytes(R, t.nl, t.wmax, t.any_swish != 0);
+        const size_t lds0 = eh_ltail_lds_bytes(R, t.nl, t.wmax, t.any_swish != 0);
         const bool mp = net.mech == EH_MECH_PROGRAM;
         const void* fn = R == 1 ? (lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, true> : (const void*)&eh_lform_tailchain_kernel<1, false, true>)
                                          : (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, false> : (const void*)&eh_lform_tailchain_kernel<1, false, false>))
                                 : (lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<4, true, true> : (const void*)&eh_lform_tailchain_kernel<4, false, true>)
                                          : (mp ? (const void*)&eh_lform_tailchain_kernel<4, true, false> : (const void*)&eh_lform_tailchain_kernel<4, false, false>));
+        // one or two hidden layers + the output layer whose weights fit the threads' registers: they stay there for the delta products (eh_lform_tailkeep_kernel)
+        static const bool nokeep = getenv("EH_LFORM_NOKEEP") != nullptr;
+        int trf = 0;
+        const bool keep = !nokeep && R == 1 && eh_ltail_keep_ok(t, (int)count, &trf);
+        size_t lds = lds0;
+        if (keep) {
+            lds = lds0 + ((size_t)trf + 8) * sizeof(float);
+            fn = lprog ? (mp ? (const void*)&eh_lform_tailkeep_kernel<true, true> : (const void*)&eh_lform_tailkeep_kernel<false, true>)
+                       : (mp ? (const void*)&eh_lform_tailkeep_kernel<true, false> : (const void*)&eh_lform_tailkeep_kernel<false, false>);
+        }
         if (lds > EH_LDS_LIMIT) return fail(h, EH_EUNSUPPORTED, "layer-wise form: %zu bytes of LDS for the tail chain", lds);
-        bool& prepared = h->l_tail_fn[(R == 4 ? 4 : 0) + (lprog ? 2 : 0) + (mp ? 1 : 0)];      // (per handle = per device)
+        bool& prepared = h->l_tail_fn[(keep ? 8 : (R == 4 ? 4 : 0)) + (lprog ? 2 : 0) + (mp ? 1 : 0)];      // (per handle = per device)
         if (!prepared) { HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EH_LDS_LIMIT)); prepared = true; }
         void* kargs[] = {(void*)&net, (void*)&a, (void*)&t, (void*)&h->image};
         HIPCHK(h, hipLaunchKernel(fn, dim3((unsigned)tgrid), dim3(EH_LTAIL_THREADS), kargs, lds, h->stream));
@@ -1854,6 +1864,18 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         ap.stamps = stamp_dw ? h->stamps : nullptr;
         ap.stamp_wg = stamp_dw ? atoi(getenv("EH_STAMP_DW")) : 0;
         if (ap.stamp_wg < 0) ap.stamp_wg += TG.t0[TG.n] + GG.t0[GG.n] + 1;
+        static const bool noapply64 = getenv("EH_LFORM_NOAPPLY64") != nullptr;
+        if (B <= 64 && ap.tot && !noapply64) {       // everything requested at once, 32 x 32 tiles with the samples split over the waves (eh_dw_apply64_kernel)
+            for (int i = 0; i < GG.n; ++i) {
+                GG.gx[i] = (GG.g[i].N + 31) / 32; GG.gy[i] = (GG.g[i].M + 31) / 32;
+                GG.t0[i + 1] = GG.t0[i] + GG.gx[i] * GG.gy[i];
+            }
+            if (ap.stamp_wg < 0) ap.stamp_wg = TG.t0[TG.n] + GG.t0[GG.n];
+#ifdef EH_STAMPS
+            if (ap.stamps) { hipMemsetAsync(ap.stamps + 28, 0xff, 8, h->stream); hipMemsetAsync(ap.stamps + 30, 0, 8, h->stream); }
+#endif
+            hipLaunchKernelGGL(eh_dw_apply64_kernel, dim3((unsigned)(TG.t0[TG.n] + 8 * ((GG.t0[GG.n] + 7) / 8) + 1)), dim3(256), 0, h->stream, GG, TG, net, ap);
+        } else
         hipLaunchKernelGGL(eh_dw_apply_kernel, dim3((unsigned)(TG.t0[TG.n] + GG.t0[GG.n] + 1)), dim3(256), 0, h->stream, GG, TG, net, ap);
         HIPCHK(h, hipGetLastError());
         h->l_applied = true;

@@ -522,6 +522,29 @@ __global__ __launch_bounds__(256) void eh_thin_gemm_group_kernel(const EhThinGro
     eh_thin_gemm_tile<false>(a, t % gx, t / gx);
 }
 
+// every 64-byte line of a large block of kernel arguments requested at once (eh_kernarg_warm's idea, eh_device.hpp, for blocks beyond
+// its twelve lines): the table of layers is read phase by phase, and every cold line is a memory round trip on the critical path
+template <int LINE0, int BYTES, class KA>
+__device__ __forceinline__ void eh_kernarg_warm4(const KA ka) {
+    if constexpr (64 * LINE0 < BYTES) {
+        unsigned d0, d1 = 0u, d2 = 0u, d3 = 0u;
+        asm volatile("s_load_dword %0, %1, %2" : "=&s"(d0) : "s"(ka), "n"(64 * LINE0));
+        if constexpr (64 * (LINE0 + 1) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d1) : "s"(ka), "n"(64 * (LINE0 + 1)));
+        if constexpr (64 * (LINE0 + 2) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d2) : "s"(ka), "n"(64 * (LINE0 + 2)));
+        if constexpr (64 * (LINE0 + 3) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d3) : "s"(ka), "n"(64 * (LINE0 + 3)));
+        eh_kernarg_warm4<LINE0 + 4, BYTES>(ka);
+        // (the destinations stay allocated up to the wait the outermost call ends with: a register handed out earlier would be overwritten when its load lands)
+        asm volatile("" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+template <int BYTES>
+__device__ __forceinline__ void eh_kernarg_warm_big() {
+    static_assert(BYTES <= 4096, "kernel arguments");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    eh_kernarg_warm4<0, BYTES>(ka);
+}
 // Both groups of a small-batch step's weight gradients -- the tiled ones and the thin ones -- as ONE launch: the first workgroups run
 // the thin products, the others the tiles (one dependent launch fewer; the two bodies' LDS side by side, 44 KB).
 // ... and, as one more workgroup behind them, the sums of the mechanistic stage (rows of partial sums -> the tail columns of the slab:
@@ -1137,29 +1160,6 @@ inline void eh_ltail_geometry(EhLTailLayer& T) {
     T.nloop = (T.out + (CV << lgG) - 1) / (CV << lgG);    // pieces per lane, <= 4
     T.pad0 = T.pad1 = 0;
 }
-// every 64-byte line of a large block of kernel arguments requested at once (eh_kernarg_warm's idea, eh_device.hpp, for blocks beyond
-// its twelve lines): the table of layers is read phase by phase, and every cold line is a memory round trip on the critical path
-template <int LINE0, int BYTES, class KA>
-__device__ __forceinline__ void eh_kernarg_warm4(const KA ka) {
-    if constexpr (64 * LINE0 < BYTES) {
-        unsigned d0, d1 = 0u, d2 = 0u, d3 = 0u;
-        asm volatile("s_load_dword %0, %1, %2" : "=&s"(d0) : "s"(ka), "n"(64 * LINE0));
-        if constexpr (64 * (LINE0 + 1) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d1) : "s"(ka), "n"(64 * (LINE0 + 1)));
-        if constexpr (64 * (LINE0 + 2) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d2) : "s"(ka), "n"(64 * (LINE0 + 2)));
-        if constexpr (64 * (LINE0 + 3) < BYTES) asm volatile("s_load_dword %0, %1, %2" : "=&s"(d3) : "s"(ka), "n"(64 * (LINE0 + 3)));
-        eh_kernarg_warm4<LINE0 + 4, BYTES>(ka);
-        // (the destinations stay allocated up to the wait the outermost call ends with: a register handed out earlier would be overwritten when its load lands)
-        asm volatile("" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3));
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-}
-template <int BYTES>
-__device__ __forceinline__ void eh_kernarg_warm_big() {
-    static_assert(BYTES <= 4096, "kernel arguments");
-    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-    eh_kernarg_warm4<0, BYTES>(ka);
-}
 inline size_t eh_ltail_lds_bytes(int R, int nl, int wmax, bool any_swish) {
     const size_t WP = (size_t)wmax + EH_LTAIL_PAD;
     return sizeof(float) * ((size_t)(nl + 1) * R * WP * (any_swish ? 3 : 2) + (size_t)R * (EH_LTAIL_RED + EH_LTAIL_RED2) + 2 * 16 * 64 +
@@ -1175,6 +1175,9 @@ __device__ __forceinline__ float eh_group_sum(float v, const int lg) {
     if (lg >= 6) v += __shfl_xor(v, 32, 64);
     return v;
 }
+#ifndef EH_STAMP_L
+#define EH_STAMP_L 0      // (diagnostic builds: the layer of the suffix whose phases get the inner stamps 12-14 / 6-7)
+#endif
 template <int R, bool PROG, bool LPROG>
 __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel(const EhNet net, const EhStepArgs a, const EhLTailArgs t, const float* meta_g) {
     extern __shared__ __attribute__((aligned(16))) float eh_lt_smem[];
@@ -1329,7 +1332,7 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel
                     }
             }
         }
-        if (l == 0) EH_STAMP(12);
+        if (l == EH_STAMP_L) EH_STAMP(12);
         if (ks < KS) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -1364,7 +1367,7 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel
             eh_lds_barrier();
             src = red2; nsrc = KS1; sstr = EH_LTAIL_RED2;
         }
-        if (l == 0) EH_STAMP(13);
+        if (l == EH_STAMP_L) EH_STAMP(13);
         const bool last = l + 1 == nl;
         float* const hout = hb + (size_t)(l + 1) * R * WP;
         float* const zout = zb + (size_t)(l + 1) * R * WP;
@@ -1386,7 +1389,7 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel
                 } else hout[r * WP + n] = v;
             }
         }
-        if (l == 0) EH_STAMP(14);
+        if (l == EH_STAMP_L) EH_STAMP(14);
         eh_lds_barrier();
         EH_STAMP(3 + l);
     }
@@ -1526,7 +1529,7 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel
                         }
                     }
                 }
-            if (l == 0) EH_STAMP(6);
+            if (l == EH_STAMP_L) EH_STAMP(6);
 #pragma unroll
             for (int u = 0; u < BU; ++u)
                 if (kb + u * NWV * rpw < in) {
@@ -1538,9 +1541,12 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailchain_kernel
                     }
                 }
         }
-        if (l == 0) EH_STAMP(7);
+        if (l == EH_STAMP_L) EH_STAMP(7);
         // the next delta product's weights while this one's rows go out
         if (l - 1 > 0 || (l - 1 == 0 && t.Dbelow)) bwd_load(t.L[l - 1], wb);
+#ifdef EH_STAMP_BWD
+        if (l == EH_STAMP_L) EH_STAMP(13);
+#endif
         eh_lds_barrier();
         EH_STAMP(9 + (nl - 1 - l));
     }
@@ -1657,4 +1663,535 @@ __global__ __launch_bounds__(256) void eh_dw_apply_kernel(const EhGemmGroup G, c
         eh_gemm_tile<true, false, EH_GEPI_APPLY, true, 64>(g, t % gx, (t / gx) % gy, t / (gx * gy), &S);
         EH_LSTAMP(&S, 5);
     }
+}
+
+// ---- the same launch for minibatches of at most 64 rows (the reference's default batchsize) ------------------------------------------------
+// Stamps of eh_dw_apply_kernel at batch 64 (tools/stamps_lform.py, EH_STAMP_DW): a 64 x 64 tile took 20 k cycles -- 2.5-3.5 k until the
+// step's sums were in, 10.5 k for a product 64 deep (its loads asked for only then; four LDS-staged k steps, each a barrier pair), 5 k for
+// sixteen updates and 32-48 stores per thread -- and a thin product three dependent round trips (thin operand -> LDS, wide loads, parameters).
+// Every memory round trip of data a previous launch wrote is ~3 k cycles, so here everything a workgroup will read is requested in its
+// first instructions -- the step's sums, the beta products, the operands, the parameters and their moments -- and waited for once:
+//   tiled products: 32 x 32 tiles (4 x the workgroups: 698 for the tutorial net, all resident), the <= 64 samples split over the four waves
+//     (<= 16 each: eight 32x32x2 MFMAs whose operands come straight from global memory in the MFMA's own lane layout -- rows of H^T and dZ
+//     are contiguous along m / n, no LDS staging), the four partial tiles folded in LDS in a fixed order; four parameters per thread;
+//   thin products: eh_thin_gemm_tile's arithmetic in its order (the same bits), the wide loads and the parameters requested before the thin
+//     operand is staged.
+__device__ __forceinline__ void eh_lapply64_norm(const EhLApply& ap, const float* totl, float& scale, bool& go) {
+    float loss;
+    eh_loss_finish(ap.loss_kind, totl[8], totl[9], totl[13], totl[14], scale, loss, ap.im.agg_a);
+    go = totl[9] > 0.0f;
+}
+__global__ __launch_bounds__(256) void eh_dw_apply64_kernel(const EhGemmGroup G, const EhThinGroup T, const EhNet net, const EhLApply ap) {
+    __shared__ float totl[EH_LMECH_PART];
+    __shared__ __attribute__((aligned(16))) float red[4][32][40];      // (row stride 40: the two half-waves of an accumulator store land in disjoint banks)
+    __shared__ float csr[8][32];
+    __shared__ float sT[8][64], redq[4][64][10], redt[4][8];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef EH_STAMPS
+#define EH_A64(i) do { __builtin_amdgcn_sched_barrier(0); if (ap.stamps && (int)blockIdx.x == ap.stamp_wg && tid == 0) { ap.stamps[2 * (i)] = __builtin_readcyclecounter(); ap.stamps[2 * (i) + 1] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+    if (ap.stamps && tid == 0) atomicMin(ap.stamps + 28, (unsigned long long)wall_clock64());      // (the launch's span: first start, last end -- the host resets the pair)
+#else
+#define EH_A64(i)
+#endif
+    EH_A64(0);
+    // the tables of products are looked up by a dependent chain of scalar loads (which product? -> its tile counts -> its arguments): ten cold
+    // lines one after the other were 15-26 k cycles before a workgroup's first vector load went out (stamps); all lines at once: one round trip
+    // (asking for every line of the 2.8 KB of arguments at once was no better: 7-8 k cycles for that round alone.)  Two rounds: the tables of
+    // first tiles at fixed offsets -> which product; its arguments -> everything else
+    int gt[EH_GEMM_GROUP + 1], tt[EH_GEMM_GROUP + 1];
+#pragma unroll
+    for (int j = 0; j <= EH_GEMM_GROUP; ++j) { gt[j] = G.t0[j]; tt[j] = T.t0[j]; }
+    const int gn = G.n, tn = T.n;
+    int nthin = 0, ntile = 0;
+#pragma unroll
+    for (int j = 1; j <= EH_GEMM_GROUP; ++j) { if (j == tn) nthin = tt[j]; if (j == gn) ntile = gt[j]; }
+    EH_A64(12);
+    const float tv = tid < EH_LMECH_PART ? ap.tot[tid] : 0.0f;
+    const float bt1 = ap.sc_in[0], bt2 = ap.sc_in[1];
+    const bool use_m = ap.o.rule == EH_OPT_ADAM || ap.o.rule == EH_OPT_ADAMW, use_v = use_m || ap.o.rule == EH_OPT_RMSPROP;
+    eh_gfloat* const tp = (eh_gfloat*)ap.theta; eh_gfloat* const mp = (eh_gfloat*)ap.m; eh_gfloat* const vp = (eh_gfloat*)ap.v;
+    // workgroup -> work: [0, 8 Q) tile slots, then the thin products, then one for the global parameters.  Slot s runs tile (s % 8) Q + s / 8:
+    // consecutive workgroups land on consecutive XCDs, so XCD x works on tiles [x Q, (x + 1) Q) -- a contiguous range of rows of every
+    // product, the same one every step: its L2 fetches an eighth of H^T (and all of dZ) instead of all of both
+    const int Q = (ntile + 7) >> 3, slots = 8 * Q;
+    const int wg = (int)blockIdx.x;
+    if (wg == slots + nthin) {                                           // the global parameters, the loss, the beta products (eh_dw_apply_kernel)
+        if (tid < EH_LMECH_PART) totl[tid] = tv;
+        __syncthreads();
+        float scale, loss;
+        eh_loss_finish(ap.loss_kind, totl[8], totl[9], totl[13], totl[14], scale, loss, ap.im.agg_a);
+        const bool go = totl[9] > 0.0f;
+        const int ng = net.n_theta - net.g_off;
+        if (tid < ng && go) {
+            float gsum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                if (j < net.n_par && ((net.par_kind >> (2 * j)) & 3u) == EH_PAR_GLOBAL && (int)((net.par_idx >> (4 * j)) & 15u) == tid) gsum = totl[j];
+            const int idx = net.g_off + tid;
+            float th = ap.theta[idx], mm = use_m ? ap.m[idx] : 0.0f, vv = use_v ? ap.v[idx] : 0.0f;
+            eh_opt_update(ap.o, gsum * scale, bt1, bt2, th, mm, vv);
+            ap.theta[idx] = th;
+            if (use_m) ap.m[idx] = mm;
+            if (use_v) ap.v[idx] = vv;
+            eh_image_store(ap.im, idx, th);
+        }
+        if (tid == 0) {
+            ap.sc_out[0] = go ? bt1 * ap.o.b1 : bt1;
+            ap.sc_out[1] = go ? bt2 * ap.o.b2 : bt2;
+            ap.gradbuf[net.n_theta] = loss;
+            ap.gradbuf[net.n_theta + 1] = totl[9]; ap.gradbuf[net.n_theta + 2] = totl[13]; ap.gradbuf[net.n_theta + 3] = totl[14];
+            if (ap.loss_slot) *ap.loss_slot = loss;
+        }
+        return;
+    }
+    if (wg >= slots) {
+        const int tb = wg - slots;
+        int i = 0, ti = 0;
+#pragma unroll
+        for (int j = 1; j < EH_GEMM_GROUP; ++j)
+            if (j < tn && tb >= tt[j]) { i = j; ti = tt[j]; }
+        const EhThinArgs a = T.a[i];
+        const int bx = tb - ti;                                          // (one slab row: gx workgroups per product)
+        const int cl = lane, q = wave, col = bx * 64 + cl;
+        const bool live = col < a.ncols;
+        long long ix[9];
+        float th[9], mm[9], vv[9];
+        if (q == 0 && live) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const bool on = j < 8 ? j < a.J : a.cs_wide != nullptr;
+                const float* const slot = j < 8 ? a.C + (long long)col * a.c_col + (long long)min(j, a.J - 1) * a.c_j : (a.cs_wide ? a.cs_wide + col : a.C);
+                ix[j] = slot - ap.slab;
+                th[j] = on ? tp[ix[j]] : 0.0f;
+                mm[j] = (on && use_m) ? mp[ix[j]] : 0.0f;
+                vv[j] = (on && use_v) ? vp[ix[j]] : 0.0f;
+            }
+        }
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int bl = q + 4 * u; w[u] = (live && bl < a.K) ? a.wide[(long long)bl * a.ldw + col] : 0.0f; }
+        for (int e = tid; e < a.J * 64; e += 256) {
+            const int j = a.tsb == 1 ? e / 64 : e % a.J, bl = a.tsb == 1 ? e % 64 : e / a.J;
+            sT[j][bl] = bl < a.K ? a.thin[(long long)bl * a.tsb + (long long)j * a.tsj] : 0.0f;
+        }
+        if (tid < EH_LMECH_PART) totl[tid] = tv;
+        __syncthreads();
+        float acc[8], cst[8], csw = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[j] = 0.0f; cst[j] = 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int bl = q + 4 * u;
+            if (bl < a.K) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < a.J) { const float t = sT[j][bl]; acc[j] = fmaf(t, w[u], acc[j]); cst[j] += t; }
+                csw += w[u];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) redq[q][cl][j] = acc[j];
+        redq[q][cl][8] = csw;
+        if (cl == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) redt[q][j] = cst[j];
+        }
+        __syncthreads();
+        float scale; bool go;
+        eh_lapply64_norm(ap, totl, scale, go);
+        if (!go) return;
+        if (q == 0 && live) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const bool on = j < 8 ? j < a.J : a.cs_wide != nullptr;
+                if (on) eh_opt_update(ap.o, ((redq[0][cl][j] + redq[1][cl][j]) + (redq[2][cl][j] + redq[3][cl][j])) * scale, bt1, bt2, th[j], mm[j], vv[j]);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const bool on = j < 8 ? j < a.J : a.cs_wide != nullptr;
+                if (on) {
+                    tp[ix[j]] = th[j];
+                    if (use_m) mp[ix[j]] = mm[j];
+                    if (use_v) vp[ix[j]] = vv[j];
+                }
+            }
+        }
+        if (a.cs_thin && bx == 0 && tid < a.J) {
+            const long long idx = (a.cs_thin + tid) - ap.slab;
+            float t1 = tp[idx], m1 = use_m ? mp[idx] : 0.0f, v1 = use_v ? vp[idx] : 0.0f;
+            eh_opt_update(ap.o, ((redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid])) * scale, bt1, bt2, t1, m1, v1);
+            tp[idx] = t1;
+            if (use_m) mp[idx] = m1;
+            if (use_v) vp[idx] = v1;
+        }
+        return;
+    }
+    // ---- a 32 x 32 tile of dW_l^T [in x out] = H_{l-1}^T [in x B] * dZ_l [B x out]
+    const int b = (wg & 7) * Q + (wg >> 3);
+    if (b >= ntile) return;
+    int i = 0, gi = 0;
+#pragma unroll
+    for (int j = 1; j < EH_GEMM_GROUP; ++j)
+        if (j < gn && b >= gt[j]) { i = j; gi = gt[j]; }
+    const EhGemmArgs g = G.g[i];
+    const int t = b - gi, gx = (g.N + 31) >> 5;
+    const int bx = t % gx, by = t / gx, m0 = by * 32, n0 = bx * 32;
+    const int l32 = lane & 31, lh = lane >> 5;
+    // this thread's four parameters: column tid & 31, rows (tid >> 5) + 8 j
+    const int pc = n0 + (tid & 31), pr0 = m0 + (tid >> 5);
+    const bool pcol = pc < g.N;
+    long long ix[4];
+    float th[4], mm[4], vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = min(pr0 + 8 * j, g.M - 1);
+        ix[j] = (g.C + (long long)m * g.ldc + min(pc, g.N - 1)) - ap.slab;
+        th[j] = tp[ix[j]];
+        mm[j] = use_m ? mp[ix[j]] : 0.0f;
+        vv[j] = use_v ? vp[ix[j]] : 0.0f;
+    }
+    const bool do_cs = g.colsum != nullptr && by == 0;
+    long long cix = 0; float cth = 0.0f, cm = 0.0f, cv = 0.0f;
+    if (do_cs && tid < 32 && pcol) {
+        cix = (g.colsum + pc) - ap.slab;
+        cth = tp[cix]; cm = use_m ? mp[cix] : 0.0f; cv = use_v ? vp[cix] : 0.0f;
+    }
+    const int kper = (((g.K + 3) >> 2) + 1) & ~1;                          // samples per wave (even, <= 16 for K <= 64)
+    const int k0 = wave * kper, k1 = min(g.K, k0 + kper);
+    const int am = min(m0 + l32, g.M - 1), bn = min(n0 + l32, g.N - 1);     // (rows / columns beyond the matrix: clamped, their outputs are never stored)
+    float av[8], bv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int k = k0 + 2 * s + lh;
+        const bool ok = k < k1;
+        av[s] = ok ? g.A[(long long)k * g.lda + am] : 0.0f;
+        bv[s] = ok ? g.B[(long long)k * g.ldb + bn] : 0.0f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float csum = 0.0f;
+    EH_A64(13);
+#ifdef EH_STAMPS
+    asm volatile("" :: "v"(tv));
+    EH_A64(7);
+    asm volatile("" :: "v"(th[0]), "v"(vv[0]));
+    EH_A64(8);
+    asm volatile("" :: "v"(th[3]), "v"(vv[3]));
+    EH_A64(9);
+    asm volatile("" :: "v"(av[0]), "v"(bv[0]));
+    EH_A64(10);
+    asm volatile("" :: "v"(av[7]), "v"(bv[7]));
+    EH_A64(11);
+#endif
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0); csum += bv[s]; }
+    EH_A64(1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][l32] = acc[r];
+    EH_A64(2);
+    if (do_cs) csr[2 * wave + lh][l32] = csum;
+    if (tid < EH_LMECH_PART) totl[tid] = tv;
+    __syncthreads();
+    EH_A64(3);
+    float scale; bool go;
+    eh_lapply64_norm(ap, totl, scale, go);
+    if (!go) return;
+    float gg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = (tid >> 5) + 8 * j, cc = tid & 31;
+        gg[j] = ((red[0][rr][cc] + red[1][rr][cc]) + (red[2][rr][cc] + red[3][rr][cc])) * scale;
+    }
+    EH_A64(4);
+    eh_opt_update_all<4>(ap.o, gg, bt1, bt2, th, mm, vv);
+    EH_A64(5);
+    if (do_cs && tid < 32 && pcol) {
+        float s = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += csr[p][tid];
+        eh_opt_update(ap.o, s * scale, bt1, bt2, cth, cm, cv);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (pcol && pr0 + 8 * j < g.M) {
+            tp[ix[j]] = th[j];
+            if (use_m) mp[ix[j]] = mm[j];
+            if (use_v) vp[ix[j]] = vv[j];
+        }
+    if (do_cs && tid < 32 && pcol) {
+        tp[cix] = cth;
+        if (use_m) mp[cix] = cm;
+        if (use_v) vp[cix] = cv;
+    }
+    EH_A64(6);
+#ifdef EH_STAMPS
+    if (ap.stamps && tid == 0) atomicMax(ap.stamps + 30, (unsigned long long)wall_clock64());
+#endif
+}
+
+// ---- the chain kernel for a suffix of one or two hidden layers + the output layer whose weights fit the REGISTERS of its 512 threads ---------
+// Stamps of eh_lform_tailchain_kernel on the tutorial net (256 -> 128 -> 64 -> 1, one row per workgroup; tools/stamps_lform.py): 39 k cycles, of
+// which the two delta products took 7.6 k and 4.2 k -- 4.2 k of the first just to ISSUE the sixteen 16-byte loads of the next product's
+// weights: a workgroup streams the suffix's 164 KB twice (forward, delta products) through its CU's 64-byte-per-clock port, and a thread's k
+// slice of more than eight rows fetched its second batch inside the phase.  Here a thread asks for ALL its fragments of both hidden layers
+// (<= 16 + 8 pieces of 16 bytes), the output layer's columns in both layouts, the row and the records in its first instructions and keeps
+// the fragments: the delta product of a layer is taken from the SAME registers -- thread (k slice, column group) has W[k][n0 .. n0 + 3] for
+// its rows k, so it contributes dz[n0 .. n0 + 3] . W[k][n0 .. n0 + 3] to dZ_below[k]; the contributions of the column groups are written to
+// LDS [k][group] and added in group order by the thread of row k.  No global load after the prologue, so the stores of H_l / dZ_l (what the
+// weight-gradient launch needs) go out as the values are produced instead of waiting for the end.  Every sum in a fixed order.
+struct EhLTailKeep { int tr_floats; };
+inline bool eh_ltail_keep_ok(const EhLTailArgs& t, int count, int* tr_floats) {
+    if (count > 64 || t.nl < 2 || t.nl > 3) return false;
+    int tr = 0;
+    for (int j = 0; j + 1 < t.nl; ++j) {
+        const EhLTailLayer& L = t.L[j];
+        if (!L.vec || L.out < 16 || L.kper > (j == 0 ? 16 : 8) || L.in > (int)EH_LTAIL_MAXW) return false;
+        tr = std::max(tr, L.in * ((1 << L.lg_ng) + 4));
+    }
+    if (t.L[t.nl - 1].out > 16 || t.L[t.nl - 1].in > (int)EH_LTAIL_MAXW) return false;
+    *tr_floats = tr;
+    return true;
+}
+template <bool PROG, bool LPROG>
+__global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(const EhNet net, const EhStepArgs a, const EhLTailArgs t, const float* meta_g) {
+    extern __shared__ __attribute__((aligned(16))) float eh_lt_smem[];
+    constexpr int R = 1, NTH = EH_LTAIL_THREADS, NWV = NTH / 64, SR = 64, F0 = 16, F1 = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = t.wmax, WP = W + EH_LTAIL_PAD, nl = t.nl;
+    float* const hb = eh_lt_smem;                                        // (the layout of eh_lform_tailchain_kernel with R = 1, the transposing area behind it)
+    float* const zb = hb + (size_t)(nl + 1) * WP;
+    float* const dd = zb + (t.any_swish ? (size_t)(nl + 1) * WP : 0);
+    float* const red = dd + (size_t)(nl + 1) * WP;
+    float* const red2 = red + EH_LTAIL_RED;
+    float* const OS = red2 + EH_LTAIL_RED2;
+    float* const SG = OS + 16 * SR;
+    float* const RS = SG + 16 * SR;
+    float* const metas = RS + (EH_MAX_FORC + EH_MAX_TARG) * SR;
+    float* const bb = metas + ((EH_IMG_META + 3) & ~3);
+    float* const tr = bb + (((size_t)nl * W + 3) & ~(size_t)3);          // [in][ng + 4] contributions of the column groups to a delta
+    const int count = (int)a.count, row = (int)blockIdx.x;
+    EH_STAMP(0);
+    eh_kernarg_warm_big<(int)(sizeof(EhNet) + sizeof(EhStepArgs) + sizeof(EhLTailArgs) + 8)>();
+    EH_STAMP(1);
+    const bool two = nl == 3;
+    const EhLTailLayer L0 = t.L[0], L1 = t.L[two ? 1 : 0], T = t.L[nl - 1];
+    // ---- everything this workgroup will read from global memory, requested at once ---------------------------------------------------
+    const int g0 = tid & ((1 << L0.lg_ng) - 1), ks0 = tid >> L0.lg_ng, n00 = 4 * g0, k00 = ks0 * L0.kper;
+    const bool on0 = n00 < L0.out && ks0 < L0.KS;
+    const int g1 = tid & ((1 << L1.lg_ng) - 1), ks1 = tid >> L1.lg_ng, n01 = 4 * g1, k01 = ks1 * L1.kper;
+    const bool on1 = two && n01 < L1.out && ks1 < L1.KS;
+    f32x4 w0[F0], w1[F1];
+#pragma unroll
+    for (int u = 0; u < F0; ++u) w0[u] = (on0 && u < L0.kper) ? *(const f32x4*)(L0.W + (long long)min(k00 + u, L0.in - 1) * L0.out + n00) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < F1; ++u) w1[u] = (on1 && u < L1.kper) ? *(const f32x4*)(L1.W + (long long)min(k01 + u, L1.in - 1) * L1.out + n01) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float wof[2][EH_LTAIL_MAXW / 64];                                    // output layer, forward: output n = wave + 8 i, lanes over k
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < EH_LTAIL_MAXW / 64; ++j) { const int n = wave + NWV * i, k = lane + 64 * j; wof[i][j] = (n < T.out && k < T.in) ? T.W[(long long)k * T.out + n] : 0.0f; }
+    float wvo[16];                                                       // ... and for the delta across it: row k = tid, its (<= 16) columns
+#pragma unroll
+    for (int n = 0; n < 16; ++n) wvo[n] = (n < T.out && tid < T.in) ? T.W[(long long)tid * T.out + n] : 0.0f;
+    const bool rok = row < count;
+    const float xin = (tid < L0.in && rok) ? t.Hin[(long long)row * t.ldin + tid] : 0.0f;
+    const float zin = (tid < L0.in && rok && t.Zin) ? t.Zin[(long long)row * L0.in + tid] : 0.0f;
+    for (int e = tid; e < (nl + 1) * WP * (t.any_swish ? 3 : 2); e += NTH) hb[e] = 0.0f;
+    if (wave == 0) {
+        const bool live = lane < R && rok;
+        const long long n_glb = live ? (a.idx ? (long long)a.idx[a.first + row] : a.first + row) : 0;
+        const float* const rec = a.recs + n_glb * a.C;
+#pragma unroll
+        for (int f = 0; f < EH_MAX_FORC; ++f) RS[f * SR + lane] = (f < net.F && live) ? rec[net.P + f] : 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < EH_MAX_TARG; ++tt) RS[(EH_MAX_FORC + tt) * SR + lane] = (tt < net.T && live) ? rec[net.P + net.F + tt] : __builtin_nanf("");
+    } else if (wave == 1) {
+        for (int e = lane; e < EH_IMG_META; e += 64) metas[e] = meta_g[e];
+    }
+    for (int l = wave; l < nl; l += NWV) {
+        const float* const bp = t.L[l].b; const int out = t.L[l].out;
+        for (int n = lane; n < out; n += 64) bb[l * W + n] = bp[n];
+    }
+    eh_lds_barrier();
+    if (tid < L0.in) { hb[tid] = xin; if (t.Zin) zb[tid] = zin; }
+    eh_lds_barrier();
+    EH_STAMP(2);
+    // ---- forward through the hidden layers of the suffix (the sums of eh_lform_tailchain_kernel in its order) -----------------------------
+    auto forward = [&](const int l, const EhLTailLayer& L, const f32x4* w, const int NF, const int ks, const int n0, const int k0, const bool on) {
+        const int out = L.out, KS = L.KS, lg_ostr = L.lg_ostr, ostr = 1 << lg_ostr;
+        const float* const hin = hb + (size_t)l * WP;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < NF && u < L.kper) {
+                    const float hv = hin[k0 + u];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(hv, w[u][c], acc[c]);
+                }
+            *(f32x4*)&red[ks * ostr + n0] = acc;
+        }
+        eh_lds_barrier();
+        const float* src = red;
+        int nsrc = KS;
+        if (KS > 8) {
+            const int KS1 = (KS + 7) >> 3;
+            for (int e = tid; e < (KS1 << lg_ostr); e += NTH) {
+                const int j = e >> lg_ostr, n = e & (ostr - 1);
+                const float* const pp = red + ((8 * j) << lg_ostr) + n;
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = pp[min(i, KS - 1 - 8 * j) << lg_ostr];
+                float v = pv[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) v += 8 * j + i < KS ? pv[i] : 0.0f;
+                red2[e] = v;
+            }
+            eh_lds_barrier();
+            src = red2; nsrc = KS1;
+        }
+        float* const hout = hb + (size_t)(l + 1) * WP;
+        float* const zout = zb + (size_t)(l + 1) * WP;
+        for (int n = tid; n < out; n += NTH) {
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = src[(min(i, nsrc - 1) << lg_ostr) + n];
+            float v = pv[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) v += i < nsrc ? pv[i] : 0.0f;
+            v += bb[l * W + n];
+            const float hv = eh_act_rt(L.act, v);
+            hout[n] = hv;
+            if (L.act == EH_ACT_SWISH) zout[n] = v;
+            if (rok) {                                                    // (what the weight-gradient launch reads)
+                L.H[(long long)row * out + n] = hv;
+                if (L.Z) L.Z[(long long)row * out + n] = v;
+            }
+        }
+        eh_lds_barrier();
+    };
+    forward(0, L0, w0, F0, ks0, n00, k00, on0);
+    EH_STAMP(3);
+    if (two) forward(1, L1, w1, F1, ks1, n01, k01, on1);
+    EH_STAMP(4);
+    // ---- the output layer (<= 16 outputs): an output per wave, lanes over k -----------------------------------------------------------------
+    {
+        const float* const hin = hb + (size_t)(nl - 1) * WP;
+        float* const oraw = hb + (size_t)nl * WP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = wave + NWV * i;
+            if (n < T.out) {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < EH_LTAIL_MAXW / 64; ++j) sacc = fmaf(hin[lane + 64 * j], wof[i][j], sacc);
+                const float sum = eh_wave_sum(sacc);
+                if (lane == 0) oraw[n] = sum + bb[(nl - 1) * W + n];
+            }
+        }
+    }
+    eh_lds_barrier();
+    EH_STAMP(5);
+    // ---- mechanistic model + masked loss + its pullback: wave 0, lane 0 = this workgroup's row (eh_lform_tailchain_kernel) ------------------
+    float* const dcur0 = dd + (size_t)nl * WP;
+    float* const psum = red;
+    if (wave == 0) {
+        auto pkind = [&](int j) { return (int)((net.par_kind >> (2 * j)) & 3u); };
+        auto pidx = [&](int j) { return (int)((net.par_idx >> (4 * j)) & 15u); };
+        const float* const oraw = hb + (size_t)nl * WP;
+        const int K = T.out;
+        const bool live = lane < R && rok;
+        for (int k = 0; k < 16; ++k) { OS[k * SR + lane] = 0.0f; SG[k * SR + lane] = 1.0f; }
+        for (int k = 0; k < K; ++k) {
+            const float ov = live ? oraw[lane * WP + k] : 0.0f;
+            float pv = ov, sv = 1.0f;
+            if (net.scale_nn) {
+                float lo = 0.0f, sc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < EH_MAX_PARAMS; ++j)
+                    if (j < net.n_par && pkind(j) == EH_PAR_NEURAL && pidx(j) == k) { lo = metas[EH_IMG_LO + j]; sc = metas[EH_IMG_SC + j]; }
+                const float sgm = eh_sigmoid(ov);
+                pv = fmaf(sc, sgm, lo);
+                sv = sc * sgm * (1.0f - sgm);
+            }
+            OS[k * SR + lane] = pv; SG[k * SR + lane] = sv;
+        }
+        EhMechAcc MA;
+        MA.clear();
+        eh_mech_stage_lane<true, PROG, LPROG>(net, a, lane, live, row + lane, SR, RS, OS, SG, metas, MA);
+        if (lane < R) {
+            for (int k = 0; k < K; ++k) {
+                const float d = live ? OS[k * SR + lane] : 0.0f;
+                dcur0[lane * WP + k] = d;
+                if (rok) t.O[(long long)k * t.ldo + row] = d;
+            }
+        }
+        float v[EH_LMECH_PART];
+#pragma unroll
+        for (int j = 0; j < EH_MAX_PARAMS; ++j) v[j] = (j < net.n_par && pkind(j) == EH_PAR_GLOBAL) ? MA.gacc[j] * metas[EH_IMG_DPHI + j] : 0.0f;
+        v[8] = MA.lacc;
+#pragma unroll
+        for (int tt = 0; tt < EH_MAX_TARG; ++tt) v[9 + tt] = MA.cacc[tt];
+        v[13] = MA.syacc; v[14] = MA.syyacc; v[15] = 0.0f;
+        float mine = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EH_LMECH_PART; ++k) {
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), 0));
+            mine = lane == k ? s : mine;
+        }
+        if (lane < EH_LMECH_PART) { psum[lane] = mine; t.part[(long long)blockIdx.x * EH_LMECH_PART + lane] = mine; }
+    }
+    eh_lds_barrier();
+    EH_STAMP(8);
+    // ---- deltas back down ---------------------------------------------------------------------------------------------------------------
+    {   // across the output layer: a thread per k
+        const int actp = t.L[nl - 2].act;
+        const float* const hp = (actp == EH_ACT_SWISH ? zb : hb) + (size_t)(nl - 1) * WP;
+        float* const dn = dd + (size_t)(nl - 1) * WP;
+        if (tid < T.in) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) sacc = n < T.out ? fmaf(dcur0[n], wvo[n], sacc) : sacc;
+            const float d = sacc * eh_dact_rt(actp, hp[tid]);
+            dn[tid] = d;
+            if (rok) t.L[nl - 2].D[(long long)row * T.in + tid] = d;
+        }
+        eh_lds_barrier();
+    }
+    EH_STAMP(9);
+    auto backward = [&](const int l, const EhLTailLayer& L, const f32x4* w, const int NF, const int g, const int n0, const int k0, const bool on, float* const dst) {
+        const int in = L.in, ngp = (1 << L.lg_ng) + 4, nga = L.out >> 2;
+        const int actp = l > 0 ? t.L[l - 1].act : t.act_below;
+        const float* const dz = dd + (size_t)(l + 1) * WP;
+        float* const dn = dd + (size_t)l * WP;
+        const float* const hp = (actp == EH_ACT_SWISH ? zb : hb) + (size_t)l * WP;
+        if (on) {
+            const f32x4 d4 = *(const f32x4*)&dz[n0];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < NF && u < L.kper && k0 + u < in)
+                    tr[(k0 + u) * ngp + g] = fmaf(d4[3], w[u][3], fmaf(d4[2], w[u][2], fmaf(d4[1], w[u][1], d4[0] * w[u][0])));
+        }
+        eh_lds_barrier();
+        if (tid < in) {
+            const float* const q = tr + tid * ngp;
+            float s = 0.0f;
+            for (int j = 0; 4 * j < nga; ++j) {
+                const f32x4 v = *(const f32x4*)&q[4 * j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += 4 * j + c < nga ? v[c] : 0.0f;
+            }
+            const float d = s * eh_dact_rt(actp, hp[tid]);
+            dn[tid] = d;
+            if (rok && dst) dst[(long long)row * in + tid] = d;
+        }
+        eh_lds_barrier();
+    };
+    if (two) backward(1, L1, w1, F1, g1, n01, k01, on1, L0.D);
+    EH_STAMP(10);
+    if (t.Dbelow) backward(0, L0, w0, F0, g0, n00, k00, on0, t.Dbelow);
+    EH_STAMP(15);
 }

@@ -25,6 +25,10 @@ for rep in range(3):
     st = np.array(list(buf), dtype=np.int64).reshape(16, 2)
     order = sorted([i for i in range(16) if st[i, 0] > 0], key=lambda i: st[i, 0])
     print("batch %d, run %d: total %d cycles, %.2f us wall" % (B, rep, st[order[-1], 0] - st[order[0], 0], (st[order[-1], 1] - st[order[0], 1]) / 100.0))
+    if os.environ.get("EH_STAMP_DW") and st[14, 0] > 0 and st[15, 0] > 0:
+        order = [i for i in order if i < 14]
+        print("   launch span (first workgroup start -> last workgroup's thread 0 end): %.2f us; this workgroup starts %.2f us after the first, ends %.2f us before the last"
+              % ((st[15, 0] - st[14, 0]) / 100.0, (st[order[0], 1] - st[14, 0]) / 100.0, (st[15, 0] - st[order[-1], 1]) / 100.0))
     prev = None
     for i in order:
         print("   stamp %2d  +%7d cycles" % (i, 0 if prev is None else st[i, 0] - st[prev, 0]))
