@@ -21,6 +21,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EH_GEPI_STORE = 0, EH_GEPI_BIAS_ACT = 1, EH_GEPI_BIAS_T = 2, EH_GEPI_DACT = 3, EH_GEPI_APPLY = 4 };
 
+// A side job of a few-rows launch: pull 128-byte lines that a LATER launch of the step will read into the L2 of the XCD that will read them.
+// An XCD's L2 keeps what its workgroups read across launch boundaries (tools/ubench/l2keep.hip: a 5.6 MB read-modify-write on the same
+// workgroup -> address mapping runs at the launch floor, shifted by one XCD it costs +2.2 us), and the few-rows products are waits for one
+// or two round trips with almost nothing in flight.  Workgroup L of the launch runs on XCD L % 8 (round-robin dispatch; nothing but speed
+// depends on it) and touches its share of XCD x's lines [lo[x], lo[x] + n[x]) of every pointer: one load per thread, looked at when the
+// kernel ends.
+struct EhWarm { const float* p[3]; int np; int lo[8]; int n[8]; };
+__device__ __forceinline__ void eh_warm_touch(const EhWarm& w, float (&v)[3]) {
+    v[0] = v[1] = v[2] = 0.0f;
+    if (w.np > 0) {
+        const int L = (int)(blockIdx.x + gridDim.x * blockIdx.y), nwg = (int)(gridDim.x * gridDim.y), x = L & 7, slot = L >> 3, nslots = (nwg + 7 - x) >> 3;
+        const int n = w.n[x], chunk = (n + nslots - 1) / nslots, i = slot * chunk + (int)threadIdx.x;
+        if ((int)threadIdx.x < chunk && i < n) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < w.np) v[q] = w.p[q][(long long)(w.lo[x] + i) * 32];
+        }
+    }
+}
+__device__ __forceinline__ bool eh_warm_never(const float (&v)[3]) { return v[0] + v[1] + v[2] == -1.2345e-30f; }
 struct EhGemmArgs {
     const float* A; long long lda;       // !ATR: A[m][k] at A + m*lda + k ; ATR: A[k][m] at A + k*lda + m
     const float* B; long long ldb;       // !BTR: B[k][n] at B + k*ldb + n ; BTR: B[n][k] at B + n*ldb + k
@@ -38,6 +58,7 @@ struct EhGemmArgs {
     // kernel) added up in the order of eh_lform_tail_sum -> job_out[16], so that the launch with the optimiser in its epilogues
     // (eh_dw_apply_kernel) finds the step's normalisation ready instead of every workgroup adding the rows up again
     const float* job_part; float* job_out; int job_nblk;
+    EhWarm warm;                         // (eh_fewrows_gemm_kernel only) lines for a later launch, see above
 };
 
 // The optimiser in the epilogue of the weight-gradient products (few rows, ONE slab row: the product IS the gradient, un-normalised):
@@ -658,6 +679,7 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
     const float* const pa = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * q;
     const float* const pb = BTR ? g.B + (long long)nc * g.ldb + 4 * q : g.B + (long long)(4 * q) * g.ldb + nc;
     f32x4_lf acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float warm[3] = {0.0f, 0.0f, 0.0f};
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
         f32x4_lf a[4], b[4];
 #pragma unroll
@@ -671,6 +693,7 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
                 for (int i = 0; i < 4; ++i) b[u][i] = ok ? pb[(long long)(kb + i) * g.ldb] : 0.0f;
             }
         }
+        if (k0 == kbeg) eh_warm_touch(g.warm, warm);      // (behind the product's own requests)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -706,6 +729,7 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
         for (int q = 0; q < 16; ++q) t += red[15][q * 16 + tid];
         g.job_out[tid] = t;
     }
+    if (eh_warm_never(warm)) g.C[0] = 0.0f;      // (keeps the warming loads)
 }
 
 // The same with a 32 x 32 output tile per workgroup (v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[m0 + r][k] and B[k][n0 + r] for
@@ -774,7 +798,13 @@ struct EhLPrepArgs {
     float* meta;              // the handle's EH_IMG_* block (global memory)
     const float* bn_part; int bn_nblk; const float* bn_c; const float* bn_n; int bn_update; float* bn_run;
     int bn_self;              // train-mode statistics of a small minibatch taken here (every workgroup the same sums in the same order) -- no eh_bn_stats_kernel
+    unsigned long long* stamps;     // diagnostic builds (-DEH_STAMPS, EH_STAMP_FIRST): workgroup (0, 0) stamps its phases
 };
+#ifdef EH_STAMPS
+#define EH_FSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.stamps[2 * (i)] = __builtin_readcyclecounter(); a.stamps[2 * (i) + 1] = wall_clock64(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EH_FSTAMP(i)
+#endif
 // FWDK: the first Dense layer of a network with few predictors (eh_thin_fwd_k_kernel's product, K <= 8) in the same launch -- its
 // inputs are the values this kernel writes to Xb, taken from the records by the same expression (other workgroups write the rows this
 // one would need): g.A is not read, the network's predictors are columns c0 .. c0 + K - 1 of the minibatch matrix.
@@ -859,10 +889,11 @@ template <int EPI, int KP>
 __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArgs a, const EhGemmArgs f, const EhGemmArgs g, const int c0) {
     static_assert(EPI == EH_GEPI_BIAS_ACT && (KP == 2 || KP == 4), "forward product; at most four predictors");
     __shared__ float red[16][256];
-    __shared__ float mu[32], rs[32], sred[32][64], xs[16][8];
+    __shared__ float mu[32], rs[32], sred[32][64], xs[16][8], xraw[64][33];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;
     const int r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    EH_FSTAMP(0);
     // ---- the weights of this wave's first k round are asked for before anything else: they arrive behind the statistics ------------------
     const int kbeg = wave * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int nc = min(n0 + r, g.N - 1);
@@ -882,36 +913,49 @@ __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArg
         }
     };
     load_round(kbeg);
+    EH_FSTAMP(1);
     // ---- input BatchNorm statistics of the minibatch (train mode, small minibatch) or the image's (eh_lform_prep_kernel) ------------------
+    // (every barrier of this kernel orders LDS traffic only: eh_lds_barrier does not wait for the stores of the first column block;
+    //  what a later phase needs from global memory again -- the centre, the image's statistics, the running ones -- is asked for here)
     const int ngrp = nthr >> 5;                      // sample groups of 32 predictors each
+    const bool useraw = a.bn_self && a.count <= 64 && a.P <= 32;      // the records the statistics read are kept (LDS) for the normalisation
+    float m_img = 0.0f, r_img = 0.0f, run_m = 0.0f, run_v = 0.0f, cc_self = 0.0f;
+    if (tid < 32) {
+        m_img = a.meta[EH_IMG_BNM + tid]; r_img = a.meta[EH_IMG_BNR + tid];
+        if (a.bn_update && blockIdx.x == 0 && blockIdx.y == 0 && tid < a.P) { run_m = a.bn_run[tid]; run_v = a.bn_run[32 + tid]; }
+    }
     if (a.bn_self) {
         const int p = tid & 31, grp = tid >> 5;
         const long long nf = a.idx ? (long long)a.idx[a.first] : a.first;
         float s1 = 0.0f, s2 = 0.0f;
         if (p < a.P) {
             const float cc = a.recs[nf * a.C + p];
+            cc_self = cc;
             for (int i = grp; i < a.count; i += ngrp) {
                 const long long n = a.idx ? (long long)a.idx[a.first + i] : a.first + i;
-                const float d = a.recs[n * a.C + p] - cc;
+                const float x = a.recs[n * a.C + p];
+                if (useraw) xraw[i][p] = x;
+                const float d = x - cc;
                 s1 += d; s2 += d * d;
             }
         }
+        EH_FSTAMP(2);
         sred[grp][p] = s1; sred[grp][32 + p] = s2;
-        __syncthreads();
+        eh_lds_barrier();
     }
+    EH_FSTAMP(3);
     if (tid < 32) {
-        float m = a.meta[EH_IMG_BNM + tid], rr = a.meta[EH_IMG_BNR + tid];
+        float m = m_img, rr = r_img;
         if ((a.bn_part || a.bn_self) && tid < a.P) {
             float s1 = 0.0f, s2 = 0.0f;
             if (a.bn_self) { for (int b = 0; b < ngrp; ++b) { s1 += sred[b][tid]; s2 += sred[b][32 + tid]; } }
             else for (int b = 0; b < a.bn_nblk; ++b) { s1 += a.bn_part[b * 64 + tid]; s2 += a.bn_part[b * 64 + 32 + tid]; }
-            const long long nf = a.idx ? (long long)a.idx[a.first] : a.first;
-            const float cnt = a.bn_n ? *a.bn_n : (float)a.count, cc = a.bn_self ? a.recs[nf * a.C + tid] : a.bn_c[tid];
+            const float cnt = a.bn_n ? *a.bn_n : (float)a.count, cc = a.bn_self ? cc_self : a.bn_c[tid];      // (tid < 32: group 0, predictor tid -- its own centre)
             const float d = s1 / cnt, var = fmaxf(s2 / cnt - d * d, 0.0f);
             m = cc + d; rr = 1.0f / sqrtf(var + EH_BN_EPS);
             if (a.bn_update && blockIdx.x == 0 && blockIdx.y == 0) {
-                const float rm = (1.0f - EH_BN_MOMENTUM) * a.bn_run[tid] + EH_BN_MOMENTUM * m;
-                const float rv = (1.0f - EH_BN_MOMENTUM) * a.bn_run[32 + tid] + EH_BN_MOMENTUM * (cnt > 1.0f ? cnt / (cnt - 1.0f) : 1.0f) * var;
+                const float rm = (1.0f - EH_BN_MOMENTUM) * run_m + EH_BN_MOMENTUM * m;
+                const float rv = (1.0f - EH_BN_MOMENTUM) * run_v + EH_BN_MOMENTUM * (cnt > 1.0f ? cnt / (cnt - 1.0f) : 1.0f) * var;
                 a.bn_run[tid] = rm; a.bn_run[32 + tid] = rv;
                 a.meta[EH_IMG_BNM + tid] = rm;                          // what forward / eval (test mode) will use
                 a.meta[EH_IMG_BNR + tid] = 1.0f / sqrtf(rv + EH_BN_EPS);
@@ -919,25 +963,29 @@ __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArg
         }
         mu[tid] = m; rs[tid] = rr;
     }
-    __syncthreads();
+    eh_lds_barrier();
+    EH_FSTAMP(4);
     // ---- this workgroup's 16 rows, normalised: LDS (all predictors of the first network: K = f.K <= 8) and, from the first column block, Xb
     if (tid < 16 * f.K) {
         const int rr = tid / f.K, k = tid - rr * f.K, m = min(m0 + rr, g.M - 1), pcol = c0 + k;
-        const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m;
-        const float x = a.recs[ng * a.C + pcol];
+        float x;
+        if (useraw) x = xraw[m][pcol];
+        else { const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m; x = a.recs[ng * a.C + pcol]; }
         xs[rr][k] = pcol < 32 ? (x - mu[pcol]) * rs[pcol] : x;
     }
     if (blockIdx.x == 0) {                            // the minibatch matrix (every predictor column: networks of a MultiNN model read theirs from it)
         for (int e = tid; e < 16 * a.P; e += nthr) {
             const int rr = e / a.P, pc = e - rr * a.P, m = m0 + rr;
             if (m < g.M) {
-                const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m;
-                const float x = a.recs[ng * a.C + pc];
+                float x;
+                if (useraw) x = xraw[m][pc];
+                else { const long long ng = a.idx ? (long long)a.idx[a.first + m] : a.first + m; x = a.recs[ng * a.C + pc]; }
                 a.Xb[(long long)m * a.P + pc] = pc < 32 ? (x - mu[pc]) * rs[pc] : x;
             }
         }
     }
-    __syncthreads();
+    eh_lds_barrier();
+    EH_FSTAMP(5);
     // ---- the second layer's product, its A operand made on the way ---------------------------------------------------------------------
     float xr[KP];
 #pragma unroll
@@ -966,14 +1014,17 @@ __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArg
                 if (f.Z) *(f32x4_lf*)(f.Z + (long long)(m0 + r) * f.ldc + kb + 4 * q) = z;
             }
         }
+        EH_FSTAMP(6);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], b[u][i], acc, 0, 0, 0);
     }
+    EH_FSTAMP(7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[wave][(4 * q + i) * 16 + r] = acc[i];
-    __syncthreads();
+    eh_lds_barrier();
+    EH_FSTAMP(8);
     if (tid < 256) {
         float v = 0.0f;
         for (int w = 0; w < nw; ++w) v += red[w][tid];
@@ -984,6 +1035,7 @@ __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArg
             g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
         }
     }
+    EH_FSTAMP(9);
 }
 
 // Mechanistic model + masked loss (+ its pullback), one sample per lane, between the forward and the backward GEMMs:
@@ -1983,9 +2035,37 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(
     const bool on0 = n00 < L0.out && ks0 < L0.KS;
     const int g1 = tid & ((1 << L1.lg_ng) - 1), ks1 = tid >> L1.lg_ng, n01 = 4 * g1, k01 = ks1 * L1.kper;
     const bool on1 = two && n01 < L1.out && ks1 < L1.KS;
+    // order of the requests = order of their use (a wave's loads come back in order, and a wait for a late one is a wait for all before it):
+    // the sample's index, the row, the small tables -- what the first barrier needs -- then the fragments layer by layer
+    const bool rok = row < count;
+    long long n_glb = 0;
+    if (wave == 0) n_glb = rok ? (a.idx ? (long long)a.idx[a.first + row] : a.first + row) : 0;
+    const float xin = (tid < L0.in && rok) ? t.Hin[(long long)row * t.ldin + tid] : 0.0f;
+    const float zin = (tid < L0.in && rok && t.Zin) ? t.Zin[(long long)row * L0.in + tid] : 0.0f;
+    float mt[(EH_IMG_META + 63) / 64], bv[EH_LTAIL_MAXL][EH_LTAIL_MAXW / 64];
+    if (wave == 1) {
+#pragma unroll
+        for (int j = 0; j < (EH_IMG_META + 63) / 64; ++j) { const int e = lane + 64 * j; mt[j] = e < EH_IMG_META ? meta_g[e] : 0.0f; }
+    }
+#pragma unroll
+    for (int i = 0; i < (EH_LTAIL_MAXL + NWV - 1) / NWV; ++i) {
+        const int l = wave + NWV * i;
+#pragma unroll
+        for (int j = 0; j < EH_LTAIL_MAXW / 64; ++j) { const int n = lane + 64 * j; bv[i][j] = (l < nl && n < t.L[min(l, nl - 1)].out) ? t.L[min(l, nl - 1)].b[n] : 0.0f; }
+    }
     f32x4 w0[F0], w1[F1];
 #pragma unroll
     for (int u = 0; u < F0; ++u) w0[u] = (on0 && u < L0.kper) ? *(const f32x4*)(L0.W + (long long)min(k00 + u, L0.in - 1) * L0.out + n00) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // (wave 0: the sample's record, kept in registers until the mechanistic stage -- its address is the first request's answer)
+    float rf[EH_MAX_FORC], rt[EH_MAX_TARG];
+    if (wave == 0) {
+        const bool live = lane < R && rok;
+        const float* const rec = a.recs + n_glb * a.C;
+#pragma unroll
+        for (int f = 0; f < EH_MAX_FORC; ++f) rf[f] = (f < net.F && live) ? rec[net.P + f] : 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < EH_MAX_TARG; ++tt) rt[tt] = (tt < net.T && live) ? rec[net.P + net.F + tt] : __builtin_nanf("");
+    }
 #pragma unroll
     for (int u = 0; u < F1; ++u) w1[u] = (on1 && u < L1.kper) ? *(const f32x4*)(L1.W + (long long)min(k01 + u, L1.in - 1) * L1.out + n01) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float wof[2][EH_LTAIL_MAXW / 64];                                    // output layer, forward: output n = wave + 8 i, lanes over k
@@ -1996,24 +2076,16 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(
     float wvo[16];                                                       // ... and for the delta across it: row k = tid, its (<= 16) columns
 #pragma unroll
     for (int n = 0; n < 16; ++n) wvo[n] = (n < T.out && tid < T.in) ? T.W[(long long)tid * T.out + n] : 0.0f;
-    const bool rok = row < count;
-    const float xin = (tid < L0.in && rok) ? t.Hin[(long long)row * t.ldin + tid] : 0.0f;
-    const float zin = (tid < L0.in && rok && t.Zin) ? t.Zin[(long long)row * L0.in + tid] : 0.0f;
     for (int e = tid; e < (nl + 1) * WP * (t.any_swish ? 3 : 2); e += NTH) hb[e] = 0.0f;
-    if (wave == 0) {
-        const bool live = lane < R && rok;
-        const long long n_glb = live ? (a.idx ? (long long)a.idx[a.first + row] : a.first + row) : 0;
-        const float* const rec = a.recs + n_glb * a.C;
+    if (wave == 1) {
 #pragma unroll
-        for (int f = 0; f < EH_MAX_FORC; ++f) RS[f * SR + lane] = (f < net.F && live) ? rec[net.P + f] : 0.0f;
-#pragma unroll
-        for (int tt = 0; tt < EH_MAX_TARG; ++tt) RS[(EH_MAX_FORC + tt) * SR + lane] = (tt < net.T && live) ? rec[net.P + net.F + tt] : __builtin_nanf("");
-    } else if (wave == 1) {
-        for (int e = lane; e < EH_IMG_META; e += 64) metas[e] = meta_g[e];
+        for (int j = 0; j < (EH_IMG_META + 63) / 64; ++j) { const int e = lane + 64 * j; if (e < EH_IMG_META) metas[e] = mt[j]; }
     }
-    for (int l = wave; l < nl; l += NWV) {
-        const float* const bp = t.L[l].b; const int out = t.L[l].out;
-        for (int n = lane; n < out; n += 64) bb[l * W + n] = bp[n];
+#pragma unroll
+    for (int i = 0; i < (EH_LTAIL_MAXL + NWV - 1) / NWV; ++i) {
+        const int l = wave + NWV * i;
+#pragma unroll
+        for (int j = 0; j < EH_LTAIL_MAXW / 64; ++j) { const int n = lane + 64 * j; if (l < nl && n < t.L[min(l, nl - 1)].out) bb[l * W + n] = bv[i][j]; }
     }
     eh_lds_barrier();
     if (tid < L0.in) { hb[tid] = xin; if (t.Zin) zb[tid] = zin; }
@@ -2034,7 +2106,9 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(
                 }
             *(f32x4*)&red[ks * ostr + n0] = acc;
         }
+        if (l == EH_STAMP_L) EH_STAMP(12);
         eh_lds_barrier();
+        if (l == EH_STAMP_L) EH_STAMP(13);
         const float* src = red;
         int nsrc = KS;
         if (KS > 8) {
@@ -2053,6 +2127,7 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(
             eh_lds_barrier();
             src = red2; nsrc = KS1;
         }
+        if (l == EH_STAMP_L) EH_STAMP(14);
         float* const hout = hb + (size_t)(l + 1) * WP;
         float* const zout = zb + (size_t)(l + 1) * WP;
         for (int n = tid; n < out; n += NTH) {
@@ -2071,6 +2146,7 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(
                 if (L.Z) L.Z[(long long)row * out + n] = v;
             }
         }
+        if (l == EH_STAMP_L) EH_STAMP(6);
         eh_lds_barrier();
     };
     forward(0, L0, w0, F0, ks0, n00, k00, on0);
@@ -2104,6 +2180,10 @@ __global__ __launch_bounds__(EH_LTAIL_THREADS, 1) void eh_lform_tailkeep_kernel(
         const float* const oraw = hb + (size_t)nl * WP;
         const int K = T.out;
         const bool live = lane < R && rok;
+#pragma unroll
+        for (int f = 0; f < EH_MAX_FORC; ++f) RS[f * SR + lane] = rf[f];
+#pragma unroll
+        for (int tt = 0; tt < EH_MAX_TARG; ++tt) RS[(EH_MAX_FORC + tt) * SR + lane] = rt[tt];
         for (int k = 0; k < 16; ++k) { OS[k * SR + lane] = 0.0f; SG[k * SR + lane] = 1.0f; }
         for (int k = 0; k < K; ++k) {
             const float ov = live ? oraw[lane * WP + k] : 0.0f;
