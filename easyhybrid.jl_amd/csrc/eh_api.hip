@@ -1607,7 +1607,6 @@ static int lform_forward(eh_handle* h, const EhSplit& sp, const int* idx, long l
             g.B = theta + L.woff[l]; g.ldb = L.out[l];                   // canonical (out, in) column-major == [in][out] row-major
             g.M = B; g.N = L.out[l]; g.K = L.in[l]; g.kchunk = g.K; g.c_zstride = 0;
             g.bias = theta + L.boff[l]; g.act = L.lact[l];
-            if (h->l_warm_fwd && lstop >= 0 && l == lstop - 1 && k == 0) g.warm = *h->l_warm_fwd;
             if (l + 1 < L.nl) { g.C = W.H[k][l]; g.ldc = L.out[l]; g.Z = W.Z[k][l]; lform_gemm<false, false, EH_GEPI_BIAS_ACT>(h, g, 1); }
             else { g.C = W.O + (long long)L.orow * W.ldo; g.ldc = W.ldo; lform_gemm<false, false, EH_GEPI_BIAS_T>(h, g, 1); }
             HIPCHK(h, hipGetLastError());
@@ -1681,20 +1680,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
             tail_s = l;
         }
     }
-    // the suffix's weights (rewritten by the previous step's optimiser launch, on other XCDs) into every XCD's L2 one launch ahead of the chain kernel
-    EhWarm warm_fwd{};
-    static const bool nowarm = getenv("EH_LFORM_NOWARM") != nullptr;
-    if (tail_s > 0 && count <= 64 && !nowarm) {
-        const eh_handle_s::LNet& L = h->l_net[0];
-        const unsigned long long b0 = reinterpret_cast<unsigned long long>(TH(h) + L.woff[tail_s]) & ~127ull;
-        const unsigned long long e0 = reinterpret_cast<unsigned long long>(TH(h) + L.boff[L.nl - 1] + L.out[L.nl - 1]);
-        warm_fwd.p[0] = reinterpret_cast<const float*>(b0); warm_fwd.np = 1;
-        for (int x = 0; x < 8; ++x) { warm_fwd.lo[x] = 0; warm_fwd.n[x] = (int)((e0 - b0 + 127) / 128); }
-        h->l_warm_fwd = &warm_fwd;
-    }
-    const int rc_fwd = lform_forward(h, sp, idx, first, count, true, bn_update, W, tail_s);
-    h->l_warm_fwd = nullptr;
-    if (rc_fwd) return rc_fwd;
+    if (int rc = lform_forward(h, sp, idx, first, count, true, bn_update, W, tail_s)) return rc;
     EhStepArgs a{};
     a.prog = h->prog; a.recs = sp.recs; a.C = h->C; a.idx = idx; a.first = first; a.count = count; a.stamps = (getenv("EH_STAMP_DW") || getenv("EH_STAMP_FIRST")) ? nullptr : h->stamps;
     for (int t = 0; t < EH_MAX_TARG; ++t) a.shift[t] = sp.shift[t];

@@ -131,7 +131,6 @@ struct eh_handle_s {
     bool l_job_done = false;                              // lform_gemm -> lform_train: a few-rows product took the side job of summing the chain's partial rows
     struct EhLApply* l_apply = nullptr; bool l_applied = false;   // do_step -> lform_train: the optimiser may run in the epilogue of the grouped weight gradients / it did
     bool l_tail_fn[12] = {false};
-    struct EhWarm* l_warm_fwd = nullptr;                  // lform_train -> lform_forward: lines the LAST forward launch in front of the chain kernel pulls into every L2 (EhWarm)                          // eh_lform_tailchain_kernel: instantiations whose dynamic-LDS limit is raised on this handle's device
     float* l_ws = nullptr;                               // [Xb | H_0 .. H_{NL-1} | D0 | D1 | O | mech partial rows]
     long long l_cap = 0;                                 // samples the workspace holds
     unsigned char* wflag = nullptr;

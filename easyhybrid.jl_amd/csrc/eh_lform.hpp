@@ -21,26 +21,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EH_GEPI_STORE = 0, EH_GEPI_BIAS_ACT = 1, EH_GEPI_BIAS_T = 2, EH_GEPI_DACT = 3, EH_GEPI_APPLY = 4 };
 
-// A side job of a few-rows launch: pull 128-byte lines that a LATER launch of the step will read into the L2 of the XCD that will read them.
-// An XCD's L2 keeps what its workgroups read across launch boundaries (tools/ubench/l2keep.hip: a 5.6 MB read-modify-write on the same
-// workgroup -> address mapping runs at the launch floor, shifted by one XCD it costs +2.2 us), and the few-rows products are waits for one
-// or two round trips with almost nothing in flight.  Workgroup L of the launch runs on XCD L % 8 (round-robin dispatch; nothing but speed
-// depends on it) and touches its share of XCD x's lines [lo[x], lo[x] + n[x]) of every pointer: one load per thread, looked at when the
-// kernel ends.
-struct EhWarm { const float* p[3]; int np; int lo[8]; int n[8]; };
-__device__ __forceinline__ void eh_warm_touch(const EhWarm& w, float (&v)[3]) {
-    v[0] = v[1] = v[2] = 0.0f;
-    if (w.np > 0) {
-        const int L = (int)(blockIdx.x + gridDim.x * blockIdx.y), nwg = (int)(gridDim.x * gridDim.y), x = L & 7, slot = L >> 3, nslots = (nwg + 7 - x) >> 3;
-        const int n = w.n[x], chunk = (n + nslots - 1) / nslots, i = slot * chunk + (int)threadIdx.x;
-        if ((int)threadIdx.x < chunk && i < n) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (q < w.np) v[q] = w.p[q][(long long)(w.lo[x] + i) * 32];
-        }
-    }
-}
-__device__ __forceinline__ bool eh_warm_never(const float (&v)[3]) { return v[0] + v[1] + v[2] == -1.2345e-30f; }
 struct EhGemmArgs {
     const float* A; long long lda;       // !ATR: A[m][k] at A + m*lda + k ; ATR: A[k][m] at A + k*lda + m
     const float* B; long long ldb;       // !BTR: B[k][n] at B + k*ldb + n ; BTR: B[n][k] at B + n*ldb + k
@@ -58,7 +38,6 @@ struct EhGemmArgs {
     // kernel) added up in the order of eh_lform_tail_sum -> job_out[16], so that the launch with the optimiser in its epilogues
     // (eh_dw_apply_kernel) finds the step's normalisation ready instead of every workgroup adding the rows up again
     const float* job_part; float* job_out; int job_nblk;
-    EhWarm warm;                         // (eh_fewrows_gemm_kernel only) lines for a later launch, see above
 };
 
 // The optimiser in the epilogue of the weight-gradient products (few rows, ONE slab row: the product IS the gradient, un-normalised):
@@ -679,7 +658,6 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
     const float* const pa = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * q;
     const float* const pb = BTR ? g.B + (long long)nc * g.ldb + 4 * q : g.B + (long long)(4 * q) * g.ldb + nc;
     f32x4_lf acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    float warm[3] = {0.0f, 0.0f, 0.0f};
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
         f32x4_lf a[4], b[4];
 #pragma unroll
@@ -693,7 +671,6 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
                 for (int i = 0; i < 4; ++i) b[u][i] = ok ? pb[(long long)(kb + i) * g.ldb] : 0.0f;
             }
         }
-        if (k0 == kbeg) eh_warm_touch(g.warm, warm);      // (behind the product's own requests)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -729,7 +706,6 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
         for (int q = 0; q < 16; ++q) t += red[15][q * 16 + tid];
         g.job_out[tid] = t;
     }
-    if (eh_warm_never(warm)) g.C[0] = 0.0f;      // (keeps the warming loads)
 }
 
 // The same with a 32 x 32 output tile per workgroup (v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[m0 + r][k] and B[k][n0 + r] for
@@ -1764,7 +1740,10 @@ __global__ __launch_bounds__(256) void eh_dw_apply64_kernel(const EhGemmGroup G,
     eh_gfloat* const tp = (eh_gfloat*)ap.theta; eh_gfloat* const mp = (eh_gfloat*)ap.m; eh_gfloat* const vp = (eh_gfloat*)ap.v;
     // workgroup -> work: [0, 8 Q) tile slots, then the thin products, then one for the global parameters.  Slot s runs tile (s % 8) Q + s / 8:
     // consecutive workgroups land on consecutive XCDs, so XCD x works on tiles [x Q, (x + 1) Q) -- a contiguous range of rows of every
-    // product, the same one every step: its L2 fetches an eighth of H^T (and all of dZ) instead of all of both
+    // product, the same one every step: its L2 fetches an eighth of H^T (and all of dZ) instead of all of both (TCC_EA0_RDREQ 101 k -> 62 k
+    // lines per launch).  What is left are the parameters and moments themselves: an XCD's L2 does not keep lines across a launch boundary
+    // -- pulling them in from the delta products one and two launches earlier (a side job per workgroup, the consumer's own XCD ranges)
+    // added 49 k lines to those launches and took none off this one (48.2 -> 48.9 us per step; the same for the chain kernel's weights)
     const int Q = (ntile + 7) >> 3, slots = 8 * Q;
     const int wg = (int)blockIdx.x;
     if (wg == slots + nthin) {                                           // the global parameters, the loss, the beta products (eh_dw_apply_kernel)
