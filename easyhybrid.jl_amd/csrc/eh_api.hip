@@ -449,6 +449,8 @@ const char* eh_last_error(const eh_handle* h) { return h ? h->err.c_str() : g_cr
 static std::mutex g_stage_mu;                 // eh_set_data's pinned staging pair (host memory: any device)
 static float* g_stage[2] = {nullptr, nullptr};
 static size_t g_stage_bytes = 0;
+static int copy_out(eh_handle* h, float* dst, const float* src_dev, size_t n);
+static int copy_in(eh_handle* h, float* dst_dev, const float* src, size_t n);
 static std::mutex g_stream_pool_mu;
 static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
 static hipStream_t stream_pool_take(int device) {
@@ -1332,7 +1334,7 @@ int32_t eh_set_params(eh_handle* h, const float* theta, int64_t n) {
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(TH(h), theta, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (int rc = copy_in(h, TH(h), theta, (size_t)n)) return rc;
     hipLaunchKernelGGL(eh_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, TH(h), (int)n, h->img);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1345,8 +1347,7 @@ int32_t eh_get_params(eh_handle* h, float* theta, int64_t n) {
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(theta, TH(h), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    return EH_OK;
+    return copy_out(h, theta, TH(h), (size_t)n);
 }
 
 }   // extern "C"
@@ -2190,7 +2191,7 @@ static int eval_host_acquire(eh_handle* h, size_t need) {
 static int copy_out(eh_handle* h, float* dst, const float* src_dev, size_t n) {
     const size_t bytes = n * sizeof(float);
     std::unique_lock<std::mutex> lk(g_stage_mu, std::try_to_lock);
-    if (bytes < ((size_t)1 << 20) || !lk.owns_lock()) { HIPCHK(h, hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost)); return EH_OK; }
+    if (bytes < ((size_t)256 << 10) || !lk.owns_lock()) { HIPCHK(h, hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost)); return EH_OK; }
     const size_t want = (size_t)8 << 20;                     // 8 MB chunks
     if (g_stage_bytes < want) {
         for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; }
@@ -2219,6 +2220,33 @@ static int copy_out(eh_handle* h, float* dst, const float* src_dev, size_t n) {
     }
     { const hipError_t es = hipStreamSynchronize(h->stream); if (err == hipSuccess) err = es; }      // (the pair is not handed on with a copy in flight)
     (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    HIPCHK(h, err);
+    return EH_OK;
+}
+// ... and the other way (the parameter vector of a wide model, eh_set_params: 2.8 MB for the tutorial's large net -- a plain hipMemcpy from
+// pageable memory was 3 ms of every train() call and 33 ms of one call in eight, tools/e2e_spikes.py)
+static int copy_in(eh_handle* h, float* dst_dev, const float* src, size_t n) {
+    const size_t bytes = n * sizeof(float);
+    std::unique_lock<std::mutex> lk(g_stage_mu, std::try_to_lock);
+    const size_t want = (size_t)8 << 20;
+    if (bytes < ((size_t)256 << 10) || !lk.owns_lock()) { HIPCHK(h, hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice)); return EH_OK; }
+    if (g_stage_bytes < want) {
+        for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; }
+        g_stage_bytes = 0;
+        if (hipHostMalloc((void**)&g_stage[0], want, hipHostMallocPortable) == hipSuccess && hipHostMalloc((void**)&g_stage[1], want, hipHostMallocPortable) == hipSuccess) g_stage_bytes = want;
+        else { (void)hipGetLastError(); for (int k = 0; k < 2; ++k) { if (g_stage[k]) (void)hipHostFree(g_stage[k]); g_stage[k] = nullptr; } }
+    }
+    if (g_stage_bytes < want) { HIPCHK(h, hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice)); return EH_OK; }
+    const size_t CH = want / sizeof(float);
+    hipError_t err = hipSuccess;
+    for (size_t off = 0, k = 0; off < n && err == hipSuccess; off += CH, ++k) {
+        const size_t cnt = std::min(CH, n - off);
+        if (k >= 2) err = hipStreamSynchronize(h->stream);          // (the buffer about to be refilled has been read)
+        if (err != hipSuccess) break;
+        memcpy(g_stage[k & 1], src + off, cnt * sizeof(float));
+        err = hipMemcpyAsync(dst_dev + off, g_stage[k & 1], cnt * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    }
+    { const hipError_t es = hipStreamSynchronize(h->stream); if (err == hipSuccess) err = es; }
     HIPCHK(h, err);
     return EH_OK;
 }
@@ -2514,8 +2542,8 @@ int32_t eh_get_opt_state(eh_handle* h, float* m, float* v, int64_t n, float* bet
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (m) HIPCHK(h, hipMemcpy(m, MM(h), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    if (v) HIPCHK(h, hipMemcpy(v, VV(h), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (m) { if (int rc = copy_out(h, m, MM(h), (size_t)n)) return rc; }
+    if (v) { if (int rc = copy_out(h, v, VV(h), (size_t)n)) return rc; }
     if (beta_t) HIPCHK(h, hipMemcpy(beta_t, h->sc + 2 * h->sc_sel, 2 * sizeof(float), hipMemcpyDeviceToHost));
     return EH_OK;
 }
@@ -2527,8 +2555,8 @@ int32_t eh_set_opt_state(eh_handle* h, const float* m, const float* v, int64_t n
     HIPCHK(h, hipSetDevice(h->device));
     FLUSH(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (m) HIPCHK(h, hipMemcpy(MM(h), m, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    if (v) HIPCHK(h, hipMemcpy(VV(h), v, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (m) { if (int rc = copy_in(h, MM(h), m, (size_t)n)) return rc; }
+    if (v) { if (int rc = copy_in(h, VV(h), v, (size_t)n)) return rc; }
     if (beta_t) HIPCHK(h, hipMemcpy(h->sc + 2 * h->sc_sel, beta_t, 2 * sizeof(float), hipMemcpyHostToDevice));
     return EH_OK;
 }

@@ -655,7 +655,7 @@ def _train_distributed(model, tc: TrainConfig, rng, train_split, val_split) -> T
 _GC_FROZEN = 0
 
 
-def _freeze_gc_once():
+def _freeze_gc_once(at_end=False):
     """The first train() call of a process runs ONE full garbage collection and freezes what survives it (gc.freeze: the interpreter's,
     NumPy's and -- if it is loaded -- torch's module-level objects, about a million of them).  Without this the cyclic collector's first
     full pass lands in the middle of the second to fourth call and walks all of them: 40-100 ms of a 17 ms call (tools/e2e_breakdown2.py:
@@ -664,7 +664,10 @@ def _freeze_gc_once():
     collector alone."""
     global _GC_FROZEN
     import sys
-    state = 2 if "torch" in sys.modules else 1          # (torch imported since the last freeze: its objects are new to the collector -- once more)
+    # (torch imported since the last freeze: its objects are new to the collector -- once more; and once more when the first call of the
+    #  process ENDS -- what it imported and built on the way, the engine library's bindings and the run-time compiler among it, was a 45 ms
+    #  full pass at the end of the second call, tools/e2e_spikes.py)
+    state = (4 if "torch" in sys.modules else 2) + (1 if at_end else 0)
     if _GC_FROZEN >= state or os.environ.get("EH_NO_GC_FREEZE"):
         return
     _GC_FROZEN = state
@@ -801,3 +804,4 @@ def train(model: SingleNNHybridModel, data, save_ps=(), *, train_cfg: Optional[T
     finally:
         if own and not keep_engine:
             eng.close()
+        _freeze_gc_once(at_end=True)
