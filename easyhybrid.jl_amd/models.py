@@ -39,6 +39,7 @@ class MechSpec:
     forcings: Tuple[str, ...]
     outputs: Tuple[str, ...]
     program: Optional[object] = None     # program.Program for a traced closure (id 6)
+    fn: Optional[object] = None          # ... and the closure itself (an extra loss over several of its outputs traces it again, program.trace_extra_loss_mixed)
 
 
 MECH_REGISTRY: Dict[str, MechSpec] = {
@@ -117,7 +118,7 @@ def resolve_mech(m, params=None, forcing=None, targets=None) -> MechSpec:
             raise NotImplementedError(f"mechanistic model {m!r}: pass a registry name {sorted(MECH_REGISTRY)} or a callable")
         from .program import trace
         prog = trace(m, params, forcing, targets)      # GenericHybridModel.jl:420-425: f(; forcing..., params...)
-        spec = MechSpec(L.EH_MECH_PROGRAM, getattr(m, "__name__", "closure"), prog.params, prog.forcings, prog.outputs, prog)
+        spec = MechSpec(L.EH_MECH_PROGRAM, getattr(m, "__name__", "closure"), prog.params, prog.forcings, prog.outputs, prog, m)
     return spec
 
 
@@ -360,8 +361,8 @@ class SingleNNHybridModel:
         return ((nets[0] if nets else []) if self.NNs is None else dict(zip(self.neural_param_names, nets))), glob
 
     # -- C descriptor ----------------------------------------------------------------------------
-    def to_desc(self, device: int = 0, extra_outputs=()) -> L.ModelDesc:
-        ms = self.mechanistic_model
+    def to_desc(self, device: int = 0, extra_outputs=(), mech: Optional[MechSpec] = None) -> L.ModelDesc:
+        ms = mech if mech is not None else self.mechanistic_model      # (mech: the model's closure with the extra loss's entries as outputs of their own)
         d = L.ModelDesc()
         d.struct_size = __import__("ctypes").sizeof(L.ModelDesc)
         d.device = device
@@ -433,11 +434,23 @@ class SingleNNHybridModel:
         "bf16_fwd" = Dense products of the forward pass on bf16 operands with fp32 accumulation, fp32-exact backward;
         "bf16" = bf16 operands in both passes (every backward delta rounded to bf16 once), fp32 accumulation."""
         from .engine import HybridEngine
-        entries = []
+        entries, mech = [], None
         if extra_fn is not None:                      # extra_loss(yhat[, ps]) of the predictions: recorded, one more target per entry
-            from .program import trace_extra_loss
-            entries = trace_extra_loss(extra_fn, list(self.targets))
-        eng = HybridEngine(self.to_desc(device, [e[1] for e in entries]), len(self.mechanistic_model.params), self.targets,
+            from .program import trace_extra_loss, trace_extra_loss_mixed
+            ms = self.mechanistic_model
+            try:
+                entries = trace_extra_loss(extra_fn, list(self.targets))
+            except (NotImplementedError, KeyError, TypeError) as e:
+                # an entry over several predictions, over outputs that are no targets, or over predictions and global parameters
+                # (compute_loss.jl:31-34): possible where the mechanistic model is a recorded closure -- its per-sample expression
+                # becomes one more output of the model's program
+                if ms.fn is None:
+                    raise NotImplementedError(f"extra_loss: {e} -- entries that mix predictions (or read global parameters) need the mechanistic model "
+                                              f"as a Python closure (the recorder adds them to its program); {ms.name!r} is a built-in of the device registry") from e
+                bounds = {p: (float(self.parameters.lower(p)), float(self.parameters.upper(p))) for p in self.global_param_names}
+                prog, entries = trace_extra_loss_mixed(ms.fn, extra_fn, list(ms.params), list(self.forcing), list(self.targets), list(self.global_param_names), bounds)
+                mech = MechSpec(ms.id, ms.name, prog.params, prog.forcings, prog.outputs, prog, ms.fn)
+        eng = HybridEngine(self.to_desc(device, [e[1] for e in entries], mech), len(self.mechanistic_model.params), self.targets,
                            list(self.mechanistic_model.params), n_pseudo=len(entries))
         if entries:
             eng.set_extra_entries(entries)

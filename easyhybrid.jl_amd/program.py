@@ -100,8 +100,12 @@ class Sym:
     def __radd__(self, o): return self._lift(o)._op("add", o, self)
     def __sub__(self, o): return self._op("sub", self, o)
     def __rsub__(self, o): return self._lift(o)._op("sub", o, self)
-    def __mul__(self, o): return self._op("mul", self, o)
+    def __mul__(self, o): return o.__rmul__(self) if isinstance(o, MeanOf) else self._op("mul", self, o)
     def __rmul__(self, o): return self._lift(o)._op("mul", o, self)
+    def __getitem__(self, i):                                       # (`ps.Q10[1]`: a global parameter is a one-element vector in the reference)
+        if _is_uniform(self) and i in (0, 1, -1, Ellipsis):
+            return self
+        raise NotImplementedError("indexing a traced per-sample value")
     def __truediv__(self, o): return self._op("div", self, o)
     def __rtruediv__(self, o): return self._lift(o)._op("div", o, self)
     def __neg__(self): return self._op("neg", self)
@@ -196,6 +200,28 @@ _UFUNCS = {
     "greater_equal": lambda a, b: _sym_of(a, b)._lift(a) >= b, "less_equal": lambda a, b: _sym_of(a, b)._lift(a) <= b,
 }
 
+def _is_uniform(x) -> bool:
+    """a traced value that is the same for every sample of a batch: built from constants and the parameters the trace marked as global
+    (`_Graph.uniform_pars`, trace_extra_loss_mixed) -- what a sum / mean over the samples may be scaled by"""
+    if not isinstance(x, Sym):
+        return False
+    up = getattr(x.g, "uniform_pars", None)
+    if up is None:
+        return False
+    seen, stack = set(), [x.nid]
+    while stack:
+        nid = stack.pop()
+        if nid in seen:
+            continue
+        seen.add(nid)
+        n = x.g.nodes[nid]
+        if n[0] == "frc" or (n[0] == "par" and n[1] not in up):
+            return False
+        if n[0] not in ("par", "const"):
+            stack.extend(n[1:])
+    return True
+
+
 class MeanOf:
     """np.mean(<traced per-sample value>): the only reduction a recorded training loss may end in.  What is linear in the mean stays
     a mean -- `w * mean(l)`, `mean(l) / c`, `mean(l) + c`, `mean(a) + mean(b)` (the reference's own test scales one:
@@ -211,9 +237,10 @@ class MeanOf:
     def _num(x):
         return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
 
-    def __mul__(self, c): return type(self)(self.sym * float(c)) if self._num(c) else self._no()
+    # (a traced value that is the same for every sample -- a global parameter of the model, trace_extra_loss_mixed -- scales a sum / mean like a constant)
+    def __mul__(self, c): return type(self)(self.sym * float(c)) if self._num(c) else (type(self)(self.sym * c) if _is_uniform(c) else self._no())
     __rmul__ = __mul__
-    def __truediv__(self, c): return type(self)(self.sym / float(c)) if self._num(c) else self._no()
+    def __truediv__(self, c): return type(self)(self.sym / float(c)) if self._num(c) else (type(self)(self.sym / c) if _is_uniform(c) else self._no())
     def __neg__(self): return type(self)(-self.sym)
     def __add__(self, o): return type(self)(self.sym + (o.sym if isinstance(o, MeanOf) else float(o))) if (self._num(o) or type(o) is type(self)) else self._no()
     __radd__ = __add__
@@ -244,7 +271,7 @@ class SumOf(MeanOf):
 
 _ARRAY_FUNCS = {
     "mean": lambda x, **kw: MeanOf(x),
-    "sum": lambda x, **kw: SumOf(x),
+    "sum": lambda x, **kw: MeanOf(x) if _is_uniform(x) else SumOf(x),      # (sum over a global parameter's one-element vector: the value itself)
     "where": lambda cond, a, b: where(cond, a, b),
     "clip": lambda x, lo=None, hi=None, **kw: (x if lo is None else maximum(x, lo)) if hi is None else minimum(x if lo is None else maximum(x, lo), hi),
 }
@@ -470,3 +497,110 @@ def trace_extra_loss(fn: Callable, outputs: Sequence[str]):
             raise NotImplementedError(f"extra_loss entry {name!r} has {len(code)} operations / {len(consts)} constants (device limits {MAX_PROG} / {MAX_CONST})")
         out.append((str(name), outputs[k], "sum" if isinstance(v, SumOf) else "mean", Program(("yhat", "y"), (), ("loss",), tuple(consts), tuple(code), (o_,))))
     return out
+
+
+def _identity_entry_program() -> Program:
+    """the per-sample function of an entry that IS an output of the model: l(yhat, y) = yhat + 0"""
+    return Program(("yhat", "y"), (), ("loss",), (0.0,), ((OPS["add"], SLOT_PAR, SLOT_CONST, 0),), (SLOT_INSTR,))
+
+
+def trace_extra_loss_mixed(model_fn: Callable, extra_fn: Callable, params: Sequence[str], forcings: Sequence[str], targets: Sequence[str],
+                           global_params: Sequence[str], bounds: Dict[str, Tuple[float, float]]):
+    """`extra_loss(yhat, ps)` whose entries read SEVERAL predictions, or predictions and global parameters (src/losses/compute_loss.jl:
+    31-34: any function of the model's outputs and its parameter NamedTuple), for a mechanistic model that is itself a recorded closure:
+    the model is traced again, `extra_fn` is called on its traced outputs, and the per-sample expression of every entry becomes one more
+    OUTPUT of the mechanistic program -- the entry then is the sum / mean of that output over the batch and rides on a target of its own
+    like the one-prediction entries of trace_extra_loss; its derivative reaches every prediction and parameter it reads through the
+    program's reverse sweep.  `ps.<g>` / `ps["g"]` of a global parameter g is its RAW value, as in the reference (the model sees
+    lower + (upper - lower) * sigmoid(raw), GenericHybridModel.jl:348-352): recovered inside the program as logit((value - lower) /
+    (upper - lower)).  The network's weights are not reachable here (penalties on them are WeightL2 terms).  What stays linear in the
+    reduction is allowed: `np.sum(a * b)`, `np.mean((a - b) ** 2) * 0.1`, `np.mean(a) * ps.Q10`, `np.sum(ps.Q10 ** 2)`; a product of
+    two reductions is refused.  Returns (Program with the extra outputs, [(entry name, output name, "sum" | "mean", Program)])."""
+    import inspect
+    params, forcings, targets, global_params = list(params), list(forcings), list(targets), list(global_params)
+    g = _Graph()
+    g.uniform_pars = {params.index(p) for p in global_params if p in params}
+    kw = {f: Sym(g, g.node("frc", f)) for f in forcings}
+    for j, p in enumerate(params):
+        kw[p] = Sym(g, g.node("par", j))
+    res = model_fn(**kw)
+    if hasattr(res, "_asdict"):
+        res = res._asdict()
+    some = next(iter(kw.values()))
+    yh = {o: some._lift(v) for o, v in res.items() if not isinstance(v, MeanOf)}
+
+    class _Ps:
+        def __getattr__(self, k):
+            if k in global_params and k in params:
+                lo, hi = bounds[k]
+                u = (kw[k] - float(lo)) / (float(hi) - float(lo))
+                return log(u / (1.0 - u))
+            raise NotImplementedError(f"extra_loss: ps.{k} -- only the global parameters {tuple(global_params)} are reachable in the recorded form "
+                                      "(penalties on the network's weights are WeightL2 terms)")
+        __getitem__ = __getattr__
+    try:
+        npar = len([p for p in inspect.signature(extra_fn).parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.default is p.empty])
+    except (TypeError, ValueError):
+        npar = 1
+    out = extra_fn(yh, _Ps()) if npar >= 2 else extra_fn(yh)
+    if hasattr(out, "_asdict"):
+        out = out._asdict()
+    items = list(out.items()) if isinstance(out, dict) else [(f"extra_{i + 1}", v) for i, v in enumerate(out if isinstance(out, (list, tuple)) else [out])]
+    outs: List[str] = []
+    for t in targets:
+        if t not in res:
+            raise ValueError(f"target {t!r} is not an output of the mechanistic model {tuple(res)}")
+        if t not in outs:
+            outs.append(t)
+    memo: Dict[int, int] = {}
+    roots = [_fold(g, yh[t].nid, memo) for t in outs]
+    entries = []
+    for i, (name, v) in enumerate(items):
+        if _is_uniform(v):
+            v = MeanOf(v)                                  # a function of the global parameters alone: the same for every sample
+        if not isinstance(v, MeanOf):
+            raise NotImplementedError(f"extra_loss entry {name!r}: np.sum(...) / np.mean(...) of a per-sample expression, possibly scaled by constants "
+                                      f"or global parameters (got {type(v).__name__})")
+        oname = f"_xl{i + 1}"
+        outs.append(oname)
+        roots.append(_fold(g, v.sym.nid, memo))
+        entries.append((str(name), oname, "sum" if isinstance(v, SumOf) else "mean", _identity_entry_program()))
+    if len(outs) > MAX_OUT:
+        raise NotImplementedError(f"{len(outs)} outputs (the model's targets + one per extra-loss entry): device limit {MAX_OUT}")
+    used_f: List[str] = []
+    consts: List[float] = []
+    code: List[Tuple[int, int, int, int]] = []
+    slot: Dict[int, int] = {}
+
+    def emit(nid: int) -> int:
+        if nid in slot:
+            return slot[nid]
+        n = g.nodes[nid]
+        if n[0] == "par":
+            s_ = SLOT_PAR + n[1]
+        elif n[0] == "frc":
+            if n[1] not in used_f:
+                used_f.append(n[1])
+            s_ = SLOT_FORC + used_f.index(n[1])
+        elif n[0] == "const":
+            if n[1] not in consts:
+                consts.append(n[1])
+            s_ = SLOT_CONST + consts.index(n[1])
+        else:
+            ops = [emit(a) for a in n[1:]] + [0, 0]
+            code.append((OPS[n[0]], ops[0], ops[1], ops[2]))
+            s_ = SLOT_INSTR + len(code) - 1
+        slot[nid] = s_
+        return s_
+    out_slots = []
+    for r in roots:
+        s_ = emit(r)
+        if s_ < SLOT_INSTR or s_ in out_slots:             # a bare input / constant, or the same value twice: an instruction of its own
+            zero = emit(g.const(0.0))
+            code.append((OPS["add"], s_, zero, 0))
+            s_ = SLOT_INSTR + len(code) - 1
+        out_slots.append(s_)
+    if len(used_f) > L.EH_MAX_FORC or len(consts) > MAX_CONST or len(code) > MAX_PROG:
+        raise NotImplementedError(f"model + extra-loss entries: {len(code)} operations / {len(consts)} constants / {len(used_f)} forcings "
+                                  f"(device limits {MAX_PROG} / {MAX_CONST} / {L.EH_MAX_FORC})")
+    return Program(tuple(params), tuple(used_f), tuple(outs), tuple(consts), tuple(code), tuple(out_slots)), entries

@@ -171,7 +171,14 @@ def _extra_loss_values(model, theta, terms: List[WeightL2], agg: str = "sum", fn
             two = len([p for p in inspect.signature(fn).parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.default is p.empty]) >= 2
         except (TypeError, ValueError):
             two = False
-        res = fn(preds, None) if two else fn(preds)
+        class _Ps:                                    # `ps` as the function sees it in the reference: the global parameters' raw one-element vectors
+            def __init__(self, glob): self._g = glob
+            def __getattr__(self, k):
+                if k.startswith("_") or k not in self._g:
+                    raise AttributeError(k)
+                return np.asarray(self._g[k], np.float64)
+            def __getitem__(self, k): return np.asarray(self._g[k], np.float64)
+        res = fn(preds, _Ps(model.unpack(np.asarray(theta, np.float32))[1])) if two else fn(preds)
         if hasattr(res, "_asdict"):
             res = res._asdict()
         items = res.items() if isinstance(res, dict) else [(f"extra_{i + 1}", v) for i, v in enumerate(res if isinstance(res, (list, tuple)) else [res])]

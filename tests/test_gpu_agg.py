@@ -309,3 +309,123 @@ def test_target_without_a_valid_sample_under_the_data_parallel_seam():
     assert util.relerr(step, g0) <= 3e-5 and np.array_equal(engs[0].get_params(), engs[1].get_params())
     for e in engs:
         e.close()
+
+
+# ---- entries of the extra loss over SEVERAL predictions and over predictions x global parameters (compute_loss.jl:31-34) -------------------
+def _mixed_case(targets, fn, hidden, seed=3, B=1300):
+    """the three-output flux closure as the model; `fn(yhat, ps)` recorded into its program (program.trace_extra_loss_mixed).  The oracle gets
+    the extended program as plain data + a closure that computes the model's outputs AND the entries' per-sample expressions by running
+    `fn`'s pieces on NumPy arrays (independent forward values), and identity entries on the new outputs."""
+    from easyhybrid_jl_amd.program import trace_extra_loss_mixed, _identity_entry_program
+    from tests import closures as cl
+    util.register_closure("flux_closure", cl.flux_closure, list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], targets)
+    spec = ho.HybridSpec(5, list(hidden), "flux_closure", dict(cl.FLUX_TABLE), ["alpha", "rref", "gmax"], ["e0", "k"], list(targets), "tanh", True)
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (5, B)).astype(np.float32)
+    f = {"sw": rng.uniform(0, 800, B).astype(np.float32), "ta": rng.uniform(-5, 30, B).astype(np.float32), "vpd": rng.uniform(0, 30, B).astype(np.float32)}
+    theta = ho.init_theta(spec, seed + 1, np.float32)
+    truth = ho.forward(spec, ho.init_theta(spec, seed + 2, np.float32).astype(np.float64), X, f)
+    y = {}
+    for t in targets:
+        v = truth[t] * (1.0 + 0.05 * rng.normal(size=B)); v[rng.uniform(size=B) < 0.1] = np.nan
+        y[t] = v.astype(np.float32)
+    bounds = {g: (cl.FLUX_TABLE[g][1], cl.FLUX_TABLE[g][2]) for g in ("e0", "k")}
+    prog, entries = trace_extra_loss_mixed(cl.flux_closure, fn, list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], list(targets), ["e0", "k"], bounds)
+    name_x = f"flux_closure_x{id(fn)}"
+    ho.program_mech(name_x, prog.as_dict(), None)
+    spec_x = ho.HybridSpec(5, list(hidden), name_x, dict(cl.FLUX_TABLE), ["alpha", "rref", "gmax"], ["e0", "k"], list(targets), "tanh", True)
+    extra = []
+    for i, (nm, out, red, pg) in enumerate(entries):
+        kname = f"xlm_{id(fn)}_{i}"
+        ho.loss_program(kname, _identity_entry_program().as_dict(), None)
+        extra.append((out, kname, red))
+    return spec, spec_x, extra, theta, X, f, y
+
+
+def _raw_globals(spec, theta):
+    """ps.<global> as the reference's extra_loss sees it: the raw one-element vectors"""
+    _, raw = ho.unpack(spec, np.asarray(theta, np.float64))
+    class Ps:
+        pass
+    ps = Ps()
+    for j, g in enumerate(spec.glob):
+        setattr(ps, g, np.asarray(raw[j], np.float64).reshape(1))
+    ps.__class__.__getitem__ = lambda self, k: getattr(self, k)
+    return ps
+
+
+@pytest.mark.parametrize("hidden", [(16, 8), (100, 40), (160, 48, 24)])          # per-wave kernel, row-split kernel, layer-wise form
+@pytest.mark.parametrize("agg", ["sum", "mean"])
+def test_extra_loss_entries_over_two_predictions_and_global_parameters(hidden, agg):
+    """`extra_loss(yhat, ps) = (; balance = 0.02 mean((yhat.gpp - yhat.reco)^2 + yhat.nee yhat.gpp), scaled = mean(yhat.gpp) ps.k[1] + sum(abs2, ps.e0) 1e-4)`:
+    an entry over three outputs of the model (two of them no targets) and one over a prediction and the RAW global parameters -- the
+    loss against the value computed from the closure's own outputs on NumPy arrays, loss and gradient against the oracle (reverse sweep over
+    the recorded program), the oracle's gradient against central differences in fp64."""
+    fn = lambda yhat, ps: {"balance": 0.02 * np.mean((yhat["gpp"] - yhat["reco"]) ** 2 + yhat["nee"] * yhat["gpp"]),
+                           "scaled": np.mean(yhat["gpp"]) * ps.k[0] + 1e-4 * np.sum(ps.e0 ** 2)}
+    spec, spec_x, extra, theta, X, f, y = _mixed_case(["nee"], fn, hidden)
+    assert [e[2] for e in extra] == ["mean", "mean"]
+    model = util.model_from_spec(spec)
+    eng = model.engine(0, extra_fn=fn)
+    assert eng.n_pseudo == 2
+    eng.set_option("aot_spec", 0)
+    eng.set_data(eh.EH_SPLIT_TRAIN, X, [f[k] for k in model.forcing], [y["nee"]])      # (the model's forcings: the order the recorder met them in)
+    eng.set_params(theta)
+    eng.set_agg(agg, eng.n_pseudo)
+    loss, grad, nv = eng.loss_and_grad()
+    th64 = theta.astype(np.float64)
+    l0, g0, nv0 = ho.loss_and_grad(spec_x, th64, X, f, y, agg=agg, extra=extra)
+    # the value, from the closure's own outputs
+    lm, _, _ = ho.loss_and_grad(spec, th64, X, f, y)
+    res = ho.forward(spec, th64, X, f)
+    ent = fn({k: np.asarray(v, np.float64) for k, v in _all_outputs(spec, th64, X, f).items()}, _raw_globals(spec, th64))
+    want = lm + sum(float(v) for v in ent.values()) if agg == "sum" else (lm + sum(float(v) for v in ent.values())) / 3
+    assert l0 == pytest.approx(want, rel=2e-6), (l0, want)          # (the recorded program holds its constants -- 0.02, the bounds -- in fp32)
+    assert loss == pytest.approx(l0, rel=TOL) and util.relerr(grad, g0) <= TOL, (loss, l0, util.relerr(grad, g0))
+    # the oracle's gradient against central differences (fp64): the last NN bias, both global parameters, two weights
+    for j in (0, 7, theta.size - 3, theta.size - 2, theta.size - 1):
+        h = 1e-6 * max(1.0, abs(th64[j]))
+        tp, tm = th64.copy(), th64.copy(); tp[j] += h; tm[j] -= h
+        fd = (ho.loss_and_grad(spec_x, tp, X, f, y, agg=agg, extra=extra)[0] - ho.loss_and_grad(spec_x, tm, X, f, y, agg=agg, extra=extra)[0]) / (2 * h)
+        assert fd == pytest.approx(g0[j], rel=2e-5, abs=1e-9), (j, fd, g0[j])
+    lm_, gm_, _ = ho.loss_and_grad(spec, th64, X, f, y, agg=agg)
+    assert util.relerr(g0, gm_) > 1e-3                                # the entries are not negligible here
+    m, yh = eng.eval(eh.EH_SPLIT_TRAIN, predictions=True)             # the caller sees the data target only
+    assert len(m) == 1 and set(yh) == {"nee"}
+    eng.close()
+
+
+def _all_outputs(spec, th64, X, f):
+    """every output of the flux closure at the oracle's parameters (the reference's yhat holds all of them)"""
+    from tests import closures as cl
+    res = ho.forward(spec, th64, X, f, keep=True)
+    par = res["_tape"]["par"] if "par" in res["_tape"] else None
+    if par is None:
+        par = {p: res["parameters"][p] for p in cl.FLUX_TABLE}
+    return cl.flux_closure(**{k: np.asarray(v, np.float64) for k, v in f.items()}, **{p: np.asarray(par[p], np.float64) for p in cl.FLUX_TABLE})
+
+
+def test_train_front_door_with_an_entry_over_two_targets_and_a_global_parameter():
+    """TrainConfig.extra_loss = f(yhat, ps) mixing both targets and ps.k: the model's closure is recorded again with the entry as an output;
+    the history carries the entry (host side, from the predictions and the raw parameter), training moves it"""
+    from tests import closures as cl
+    cols_rng = np.random.default_rng(5)
+    n = 3000
+    cols = {f"x{i}": cols_rng.uniform(-1, 1, n).astype(np.float32) for i in range(5)}
+    cols.update(sw=cols_rng.uniform(0, 800, n).astype(np.float32), ta=cols_rng.uniform(-5, 30, n).astype(np.float32), vpd=cols_rng.uniform(0, 30, n).astype(np.float32))
+    out = cl.flux_closure(sw=cols["sw"], ta=cols["ta"], vpd=cols["vpd"], alpha=0.05, gmax=20.0, rref=3.0, e0=150.0, k=0.05)
+    cols["nee"] = (out["nee"] + 0.1 * cols_rng.normal(size=n)).astype(np.float32); cols["gpp"] = (out["gpp"] + 0.1 * cols_rng.normal(size=n)).astype(np.float32)
+    model = eh.constructHybridModel([f"x{i}" for i in range(5)], ["sw", "ta", "vpd"], ["nee", "gpp"], cl.flux_closure, dict(cl.FLUX_TABLE), ["alpha", "rref", "gmax"], ["e0", "k"],
+                                    hidden_layers=[16, 16], activation="tanh", scale_nn_outputs=True)
+    kw = dict(nepochs=3, batchsize=512, opt=eh.Adam(0.01), loss_types=["mse"], random_seed=3)
+    fn = lambda yhat, ps: {"coupling": 0.05 * np.mean(yhat["nee"] * yhat["gpp"]) * ps.k[0] + 0.5 * np.mean((yhat["nee"] + yhat["gpp"]) ** 2)}
+    plain = eh.train(model, cols, **kw)
+    pen = eh.train(model, cols, extra_loss=fn, **kw)
+    last = pen.val_history[-1]["extra_loss"]
+    assert set(last) == {"coupling", "sum"} and np.isfinite(last["coupling"]) and last["coupling"] == pytest.approx(last["sum"])
+    assert not np.allclose(pen.ps, plain.ps)
+    first = pen.val_history[0]["extra_loss"]["coupling"]
+    assert last["coupling"] < first                                   # the penalised quantity went down
+    with pytest.raises(NotImplementedError, match="closure"):
+        m2 = eh.constructHybridModel(["sw_pot", "dsw_pot"], ["ta"], ["reco"], eh.RbQ10, {"rb": (3.0, 0.0, 13.0), "Q10": (2.0, 1.0, 4.0)}, ["rb"], ["Q10"], hidden_layers=[8])
+        m2.engine(0, extra_fn=lambda yhat, ps: np.mean(yhat["reco"]) * ps.Q10[0])

@@ -187,3 +187,36 @@ def test_oracle_custom_loss_equals_builtin_mse_and_mae():
         l0, g0, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=builtin)
         l1, g1, _ = ho.loss_and_grad(spec, theta.astype(np.float64), X, f, y, kind=mine)
         assert l1 == pytest.approx(l0, rel=1e-12) and util.relerr(g1, g0) <= 1e-12
+
+
+# ---- entries of extra_loss(yhat, ps) that mix predictions / read global parameters: outputs of the model's program -------------------------
+def test_mixed_extra_loss_entries_become_outputs_of_the_models_program():
+    """program.trace_extra_loss_mixed (src/losses/compute_loss.jl:31-34): the per-sample expression of an entry over several outputs and the
+    RAW global parameters, recorded behind the model's own outputs; its values equal the expression on NumPy arrays"""
+    fn = lambda yhat, ps: {"balance": 0.25 * np.mean((yhat["gpp"] - yhat["reco"]) ** 2 + yhat["nee"] * yhat["gpp"]),
+                           "scaled": np.sum(yhat["gpp"]) * ps.k[0] * 0.5}
+    bounds = {g: (cl.FLUX_TABLE[g][1], cl.FLUX_TABLE[g][2]) for g in ("e0", "k")}
+    prog, entries = P.trace_extra_loss_mixed(cl.flux_closure, fn, list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee"], ["e0", "k"], bounds)
+    assert prog.outputs == ("nee", "_xl1", "_xl2") and [(e[0], e[1], e[2]) for e in entries] == [("balance", "_xl1", "mean"), ("scaled", "_xl2", "sum")]
+    B = 300
+    rng = np.random.default_rng(2)
+    par = {n: rng.uniform(lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo), B) for n, (_, lo, hi) in cl.FLUX_TABLE.items()}
+    par["e0"] = np.full(B, 171.0); par["k"] = np.full(B, 0.11)          # global parameters: the same for every sample
+    frc = _inputs(["sw", "ta", "vpd"], B, 6, 0.0, 30.0)
+    val = ho.program_values(prog.as_dict(), par, frc, np.dtype(np.float64))
+    out = cl.flux_closure(**frc, **par)
+    raw_k = np.log(((0.11 - 0.0) / 0.5) / (1.0 - (0.11 - 0.0) / 0.5))
+    assert util.relerr(val[prog.out[1]], 0.25 * ((out["gpp"] - out["reco"]) ** 2 + out["nee"] * out["gpp"])) <= 1e-6
+    assert util.relerr(val[prog.out[2]], out["gpp"] * raw_k * 0.5) <= 1e-6
+    # a function of the global parameters alone: one value for the batch, whatever reduction is written
+    prog2, ent2 = P.trace_extra_loss_mixed(cl.flux_closure, lambda yhat, ps: [np.sum(ps.e0 ** 2) * 1e-4], list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee", "gpp"], ["e0", "k"], bounds)
+    assert ent2[0][2] == "mean" and prog2.outputs == ("nee", "gpp", "_xl1")
+    # what is not linear in the reduction, the network's weights, too many outputs: refused
+    with pytest.raises(NotImplementedError):
+        P.trace_extra_loss_mixed(cl.flux_closure, lambda yhat, ps: [np.mean(yhat["gpp"]) * np.mean(yhat["nee"])], list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee"], ["e0", "k"], bounds)
+    with pytest.raises(NotImplementedError, match="global parameters"):
+        P.trace_extra_loss_mixed(cl.flux_closure, lambda yhat, ps: [np.mean(yhat["gpp"]) * ps.alpha], list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee"], ["e0", "k"], bounds)
+    with pytest.raises(NotImplementedError, match="device limit"):
+        P.trace_extra_loss_mixed(cl.flux_closure, lambda yhat, ps: [np.mean(yhat["gpp"] * yhat["nee"]), np.mean(yhat["reco"] * yhat["nee"])], list(cl.FLUX_TABLE), ["sw", "ta", "vpd"], ["nee", "gpp"], ["e0", "k"], bounds)
+    # entries of one prediction still take the old route (a target of their own with their own per-sample program)
+    assert len(P.trace_extra_loss(lambda yhat: [np.sum(np.abs(yhat["nee"]))], ["nee"])) == 1
