@@ -64,8 +64,20 @@ timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 $B > $OUT/bench_driver_
   timeout -k 10 300 python3 tools/bench_config.py c1 --steps 2000
 } > $OUT/bench_config_all.jsonl 2> $OUT/bench_config_all.err; echo "progress: configs"
 timeout -k 10 300 python3 tools/multistep_probe.py > $OUT/multistep_probe.txt 2>&1
-{ timeout -k 10 200 python3 tools/bench_lform.py 64 256 300 1024; echo "== EH_LFORM_NOAPPLY=1 (optimiser as a launch of its own)"; EH_LFORM_NOAPPLY=1 timeout -k 10 200 python3 tools/bench_lform.py 64 256; echo "== EH_LFORM_NOTAIL=1 (round 5: every product a launch)"; EH_LFORM_NOTAIL=1 timeout -k 10 200 python3 tools/bench_lform.py 64 256; } > $OUT/lform_few_rows_ab.txt 2>&1
-{ echo "== chain kernel (workgroup 0)"; EASYHYBRID_HIP_LIB=easyhybrid.jl_amd/libeasyhybrid_hip_stamps.so timeout -k 10 200 python3 tools/stamps_lform.py 64 | tail -17; for w in 0 17 100; do echo "== weight gradients + optimiser, workgroup $w"; EH_STAMP_DW=$w EASYHYBRID_HIP_LIB=easyhybrid.jl_amd/libeasyhybrid_hip_stamps.so timeout -k 10 200 python3 tools/stamps_lform.py 64 | tail -6; done; } > $OUT/stamps_lform.txt 2>&1
+{ timeout -k 10 200 python3 tools/bench_lform.py 16 64 128 256 300 1024
+  for v in EH_LFORM_NOFIRST EH_LFORM_NOKEEP EH_LFORM_NOAPPLY64 EH_LFORM_NOAPPLY EH_LFORM_NOTAIL; do
+    echo "== $v=1 (first launch = prep + first layer + second layer | chain kernel with the weights in registers | 64-row weight-gradient + optimiser launch | optimiser in the weight-gradient launch at all | chain kernel at all: round 5)"
+    env $v=1 timeout -k 10 200 python3 tools/bench_lform.py 64 256
+  done; } > $OUT/lform_few_rows_ab.txt 2>&1
+bash tools/lform_trace_few.sh 64 gpurun_out/prof_r06/lform_few > $OUT/lform_few_timeline_B64.txt 2>&1
+bash tools/lform_pmc_few.sh gpurun_out/prof_r06/lform_pmc > $OUT/lform_few_counters_B64.txt 2>&1
+{ S=easyhybrid.jl_amd/libeasyhybrid_hip_stamps.so
+  echo "== first launch (workgroup (0, 0)): 0 entry | 1 weights requested | 2 statistics read | 3 barrier | 4 statistics done | 5 rows normalised | 6 first layer on the fly (sigmoid) | 7 MFMAs | 8 barrier | 9 end"
+  EH_STAMP_FIRST=1 EASYHYBRID_HIP_LIB=$S timeout -k 10 200 python3 tools/stamps_lform.py 64 | tail -11
+  echo "== chain kernel (workgroup 0): 0 entry | 1 arguments | 2 row in LDS | 12-14, 6 inside the first forward layer | 3 4 forward layers | 5 output layer | 8 mechanistic stage | 9 delta across the output layer | 10 15 delta products"
+  EASYHYBRID_HIP_LIB=$S timeout -k 10 200 python3 tools/stamps_lform.py 64 | tail -15
+  for w in 8 100 400 680; do echo "== weight gradients + optimiser, workgroup $w: 12 tables | 13 everything requested | 7-11 arrivals | 1 MFMAs | 2 3 fold | 4 5 update | 6 stores"; EH_STAMP_DW=$w EASYHYBRID_HIP_LIB=$S timeout -k 10 200 python3 tools/stamps_lform.py 64 | tail -16; done; } > $OUT/stamps_lform.txt 2>&1
+timeout -k 10 300 python3 tools/e2e_spikes.py 2>&1 | grep -v amdgpu.ids > $OUT/train_e2e_calls.txt
 timeout -k 10 300 python3 tools/e2e_breakdown.py > $OUT/train_e2e_breakdown.txt 2>&1
 timeout -k 10 300 python3 tools/bench_step_modes.py > $OUT/headline_step_modes.json 2>/dev/null
 echo "progress: round-6 probes"
