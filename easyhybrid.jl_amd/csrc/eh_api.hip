@@ -1672,7 +1672,10 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     // down to layer tail_s - 1 -- is ONE launch with a workgroup per row (eh_lform_tailchain_kernel, eh_lform.hpp)
     static const bool notail = getenv("EH_LFORM_NOTAIL") != nullptr;
     int tail_s = -1;
-    if (!notail && grouped && h->l_nnets == 1 && count <= 256 && !tpm && !g_gemm_novec) {
+    // (up to 64 rows, a workgroup per row.  With four rows per workgroup it ran up to 256 rows through round 6's first half: slower than the
+    //  products launched one by one at every size measured -- 75.5 / 78.6 / 90.2 / 96.7 against 70.9 / 74.2 / 80.1 / 86.6 us at 96 / 128 / 192 / 256 rows
+    //  -- the four-row instantiations are gone)
+    if (!notail && grouped && h->l_nnets == 1 && count <= 64 && !tpm && !g_gemm_novec) {
         const eh_handle_s::LNet& L = h->l_net[0];
         long long wsum = 0;
         for (int l = L.nl - 1; l >= 0; --l) {
@@ -1759,14 +1762,12 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
         if (t.Zin) t.any_swish = 1;
         t.Dbelow = tail_s > 0 ? dptr[tail_s - 1] : nullptr;
         t.O = W.O + (long long)L.orow * W.ldo; t.ldo = W.ldo; t.part = W.part;
-        const int R = count <= 64 ? 1 : 4;
+        const int R = 1;
         const int tgrid = (int)((count + R - 1) / R);
         const size_t lds0 = eh_ltail_lds_bytes(R, t.nl, t.wmax, t.any_swish != 0);
         const bool mp = net.mech == EH_MECH_PROGRAM;
-        const void* fn = R == 1 ? (lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, true> : (const void*)&eh_lform_tailchain_kernel<1, false, true>)
-                                         : (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, false> : (const void*)&eh_lform_tailchain_kernel<1, false, false>))
-                                : (lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<4, true, true> : (const void*)&eh_lform_tailchain_kernel<4, false, true>)
-                                         : (mp ? (const void*)&eh_lform_tailchain_kernel<4, true, false> : (const void*)&eh_lform_tailchain_kernel<4, false, false>));
+        const void* fn = lprog ? (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, true> : (const void*)&eh_lform_tailchain_kernel<1, false, true>)
+                               : (mp ? (const void*)&eh_lform_tailchain_kernel<1, true, false> : (const void*)&eh_lform_tailchain_kernel<1, false, false>);
         // one or two hidden layers + the output layer whose weights fit the threads' registers: they stay there for the delta products (eh_lform_tailkeep_kernel)
         static const bool nokeep = getenv("EH_LFORM_NOKEEP") != nullptr;
         int trf = 0;
@@ -1778,7 +1779,7 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
                        : (mp ? (const void*)&eh_lform_tailkeep_kernel<true, false> : (const void*)&eh_lform_tailkeep_kernel<false, false>);
         }
         if (lds > EH_LDS_LIMIT) return fail(h, EH_EUNSUPPORTED, "layer-wise form: %zu bytes of LDS for the tail chain", lds);
-        bool& prepared = h->l_tail_fn[(keep ? 8 : (R == 4 ? 4 : 0)) + (lprog ? 2 : 0) + (mp ? 1 : 0)];      // (per handle = per device)
+        bool& prepared = h->l_tail_fn[(keep ? 8 : 0) + (lprog ? 2 : 0) + (mp ? 1 : 0)];      // (per handle = per device)
         if (!prepared) { HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EH_LDS_LIMIT)); prepared = true; }
         void* kargs[] = {(void*)&net, (void*)&a, (void*)&t, (void*)&h->image};
         HIPCHK(h, hipLaunchKernel(fn, dim3((unsigned)tgrid), dim3(EH_LTAIL_THREADS), kargs, lds, h->stream));
