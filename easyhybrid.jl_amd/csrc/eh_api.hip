@@ -1672,10 +1672,11 @@ static int lform_train(eh_handle* h, const EhSplit& sp, const int* idx, long lon
     // down to layer tail_s - 1 -- is ONE launch with a workgroup per row (eh_lform_tailchain_kernel, eh_lform.hpp)
     static const bool notail = getenv("EH_LFORM_NOTAIL") != nullptr;
     int tail_s = -1;
-    // (up to 64 rows, a workgroup per row.  With four rows per workgroup it ran up to 256 rows through round 6's first half: slower than the
-    //  products launched one by one at every size measured -- 75.5 / 78.6 / 90.2 / 96.7 against 70.9 / 74.2 / 80.1 / 86.6 us at 96 / 128 / 192 / 256 rows
-    //  -- the four-row instantiations are gone)
-    if (!notail && grouped && h->l_nnets == 1 && count <= 64 && !tpm && !g_gemm_novec) {
+    // (a workgroup per ROW up to 256 rows: every CU streams the suffix's weights once whatever the number of rows -- 57.5 / 61.3 / 70.1 / 77.5 us
+    //  per step at 96 / 128 / 192 / 256 rows against 70.9 / 74.2 / 80.1 / 86.6 with the products launched one by one.  With FOUR rows per
+    //  workgroup, the form of the round's first half for more than 64 rows, it was slower than either: 75.5 / 78.6 / 90.2 / 96.7; those
+    //  instantiations are gone.)
+    if (!notail && grouped && h->l_nnets == 1 && count <= 256 && !tpm && !g_gemm_novec) {
         const eh_handle_s::LNet& L = h->l_net[0];
         long long wsum = 0;
         for (int l = L.nl - 1; l >= 0; --l) {

@@ -1704,6 +1704,9 @@ __global__ __launch_bounds__(256) void eh_dw_apply_kernel(const EhGemmGroup G, c
 //     are contiguous along m / n, no LDS staging), the four partial tiles folded in LDS in a fixed order; four parameters per thread;
 //   thin products: eh_thin_gemm_tile's arithmetic in its order (the same bits), the wide loads and the parameters requested before the thin
 //     operand is staged.
+// (The same kernel sized for 256 rows -- 64 + 64 operand registers per lane in flight -- was built and is not kept: 19.8 / 28.3 us per launch at
+//  128 / 256 rows, no better than the staged 64 x 64 tiles (20.0) or the two-chunk products + reduction (17.2 + 8.4): 59.7 / 61.3 / 73.2 /
+//  82.3 us per step at 96 / 128 / 192 / 256 rows against 57.5 / 61.3 / 70.1 / 77.5 without it.)
 __device__ __forceinline__ void eh_lapply64_norm(const EhLApply& ap, const float* totl, float& scale, bool& go) {
     float loss;
     eh_loss_finish(ap.loss_kind, totl[8], totl[9], totl[13], totl[14], scale, loss, ap.im.agg_a);
@@ -1973,9 +1976,8 @@ __global__ __launch_bounds__(256) void eh_dw_apply64_kernel(const EhGemmGroup G,
 // its rows k, so it contributes dz[n0 .. n0 + 3] . W[k][n0 .. n0 + 3] to dZ_below[k]; the contributions of the column groups are written to
 // LDS [k][group] and added in group order by the thread of row k.  No global load after the prologue, so the stores of H_l / dZ_l (what the
 // weight-gradient launch needs) go out as the values are produced instead of waiting for the end.  Every sum in a fixed order.
-struct EhLTailKeep { int tr_floats; };
 inline bool eh_ltail_keep_ok(const EhLTailArgs& t, int count, int* tr_floats) {
-    if (count > 64 || t.nl < 2 || t.nl > 3) return false;
+    if (count > 256 || t.nl < 2 || t.nl > 3) return false;
     int tr = 0;
     for (int j = 0; j + 1 < t.nl; ++j) {
         const EhLTailLayer& L = t.L[j];
