@@ -3,11 +3,12 @@
 # usage (GPU box, repo root): bash tools/lform_trace_few.sh [batch] [out_dir]
 B=${1:-64}
 OUT=${2:-gpurun_out/lform_few}
+PROG=${3:-tools/bench_lform.py}      # (tools/bench_lform_epoch.py: the same through the epoch driver)
 mkdir -p $OUT
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr_few
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_few -- python3 $root/tools/bench_lform.py $B > $root/$OUT/bench_B$B.json 2> $root/$OUT/bench_B$B.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_few -- python3 $root/$PROG $B > $root/$OUT/bench_B$B.json 2> $root/$OUT/bench_B$B.err
 f=$(find /tmp/tr_few -name "*kernel_stats.csv" | head -1)
 cp $f $root/$OUT/kernel_stats_B$B.csv
 t=$(find /tmp/tr_few -name "*kernel_trace.csv" | head -1)
