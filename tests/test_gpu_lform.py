@@ -468,3 +468,28 @@ def test_few_rows_recorded_closure_and_recorded_loss():
     y = {t: (truth[t] * (1.0 + 0.05 * rng.normal(size=B))).astype(np.float32) for t in spec.targets}
     y["nee"][rng.uniform(size=B) < 0.1] = np.nan
     _check(spec, ho.init_theta(spec, 32, np.float32), X, f, y)
+
+
+@pytest.mark.parametrize("rule", ["AdamW", "Descent", "Adam"])
+@pytest.mark.parametrize("B", [64, 40])
+def test_few_rows_step_with_every_optimiser_rule_in_the_weight_gradient_launch(rule, B):
+    """the optimiser in the epilogues of the weight-gradient launch (eh_dw_apply64_kernel: tiles, thin products, bias sums, global parameters)
+    for the rules the tutorial does not use: four steps at the tutorial's batch size (and a smaller one: partial tiles) against the oracle's
+    fp32 trajectory, Optimisers.jl's rules op for op"""
+    spec, theta, X, f, y = util.rbq10_case(4 * B, "tanh", True, 0.1, hidden=TUTORIAL)
+    eng = util.load_engine(spec, theta, X, f, y)
+    lr, wd = (0.003, 0.05) if rule == "AdamW" else ((0.05, 0.0) if rule == "Descent" else (0.003, 0.0))
+    eng.opt_init(rule, lr, weight_decay=wd)
+    batches = [(i * B, B) for i in range(4)]
+    losses = [eng.train_step(a, n) for a, n in batches]
+    th = theta.copy(); st = ho.adam_init(theta.size, np.float32); l_ref = []
+    for a, n in batches:
+        sl = slice(a, a + n)
+        l_, g_, _ = ho.loss_and_grad(spec, th, X[:, sl], {k: v[sl] for k, v in f.items()}, {k: v[sl] for k, v in y.items()}, dtype=np.float32)
+        l_ref.append(float(l_))
+        g = g_.astype(np.float32)
+        th = (th - np.float32(lr) * g).astype(np.float32) if rule == "Descent" else ho.adam_step(th, g, st, lr, weight_decay=wd)
+    assert np.allclose(losses, l_ref, rtol=5e-5), (losses, l_ref)
+    d = np.abs(eng.get_params() - th)
+    assert np.mean(d <= 2e-5) >= 0.999 and d.max() <= 4 * lr * 1.01 + 1e-4, (np.mean(d <= 2e-5), d.max())
+    eng.close()
