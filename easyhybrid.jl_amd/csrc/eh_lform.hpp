@@ -657,6 +657,13 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
     const int nc = min(n0 + r, g.N - 1);
     const float* const pa = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + 4 * q;
     const float* const pb = BTR ? g.B + (long long)nc * g.ldb + 4 * q : g.B + (long long)(4 * q) * g.ldb + nc;
+    // what the epilogue needs from global memory -- the bias, or the stored activation act' is taken from -- is asked for NOW: read where it
+    // is used, behind the fold, it was one more cold round trip at the end of a launch that is little more than two of them
+    float epi_in = 0.0f;
+    if (tid < 256) {
+        const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+        if (m < g.M && n < g.N) epi_in = EPI == EH_GEPI_BIAS_ACT ? g.bias[n] : g.H[(long long)m * g.ldh + n];
+    }
     f32x4_lf acc = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
         f32x4_lf a[4], b[4];
@@ -686,11 +693,11 @@ __global__ __launch_bounds__(1024) void eh_fewrows_gemm_kernel(const EhGemmArgs 
         const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
         if (m < g.M && n < g.N) {
             if (EPI == EH_GEPI_BIAS_ACT) {
-                v += g.bias[n];
+                v += epi_in;
                 if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
                 g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
             } else {
-                g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, g.H[(long long)m * g.ldh + n]);
+                g.C[(long long)m * g.ldc + n] = v * eh_dact_rt(g.act, epi_in);
             }
         }
     }
@@ -889,6 +896,8 @@ __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArg
         }
     };
     load_round(kbeg);
+    float bias2 = 0.0f;                                  // (the epilogue's bias: asked for now, not behind the fold)
+    if (tid < 256 && n0 + (tid & 15) < g.N) bias2 = g.bias[n0 + (tid & 15)];
     EH_FSTAMP(1);
     // ---- input BatchNorm statistics of the minibatch (train mode, small minibatch) or the image's (eh_lform_prep_kernel) ------------------
     // (every barrier of this kernel orders LDS traffic only: eh_lds_barrier does not wait for the stores of the first column block;
@@ -1006,7 +1015,7 @@ __global__ __launch_bounds__(1024) void eh_fewrows_first_kernel(const EhLPrepArg
         for (int w = 0; w < nw; ++w) v += red[w][tid];
         const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
         if (m < g.M && n < g.N) {
-            v += g.bias[n];
+            v += bias2;
             if (g.Z) g.Z[(long long)m * g.ldc + n] = v;
             g.C[(long long)m * g.ldc + n] = eh_act_rt(g.act, v);
         }
