@@ -1285,7 +1285,8 @@ int32_t eh_set_data(eh_handle* h, int32_t split, int64_t n, const float* x, cons
             const auto tq1 = std::chrono::steady_clock::now();
             if (cnt >= 65536) {          // a chunk is interleaved by up to eight threads, each on its own run of samples
                 const unsigned hw = std::thread::hardware_concurrency();
-                const int nthr = (int)std::max<int64_t>(2, std::min<int64_t>({(int64_t)8, (int64_t)(hw ? hw / 2 : 2), cnt / 32768}));
+                static const int pack_max = getenv("EH_PACK_THREADS") ? std::max(1, atoi(getenv("EH_PACK_THREADS"))) : 8;
+                const int nthr = (int)std::max<int64_t>(2, std::min<int64_t>({(int64_t)pack_max, (int64_t)(hw ? hw / 2 : 2), cnt / 32768}));
                 const int64_t per = (cnt + nthr - 1) / nthr;
                 std::vector<std::thread> others;
                 int64_t mine_end = std::min(s0 + cnt, s0 + per);
