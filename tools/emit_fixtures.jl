@@ -96,6 +96,10 @@ function run_ext_case(dir)
         yhat, st2 = HM(x, p, st)                            # train mode: with input BatchNorm the batch statistics normalise, st2 carries the running ones
         per = [EasyHybrid.loss_fn(getproperty(yhat, t), ys[t], masks[t], Val(kind)) for t in targets]
         l = agg(per)
+        if get(spec, "extra", "") == "two_outputs"          # an entry over two outputs of the model and the RAW global parameter (compute_loss.jl:31-34)
+            c = 0.05f0 * mean(yhat.reco .* yhat.half) * p.Q10[1] + 0.5f0 * mean((yhat.reco .- yhat.half) .^ 2)
+            return agg([l, c])
+        end
         lam > 0 ? agg([l, lam * EasyHybrid.weight_l2(p)]) : l      # compute_loss.jl:31-34: agg([loss, extra...])
     end
     loss, back = Zygote.pullback(objective, ps)

@@ -9,6 +9,8 @@ cases do not touch -- as plain CSV under tests/golden/csv_for_emit_fixtures/ext_
   ext_weight_l2         extra_loss = (yhat, ps) -> (; l2 = 0.01 * weight_l2(ps)) (extract_weights.jl:69-91, compute_loss.jl:31-34)
   ext_multinn           MultiNNHybridModel: rb and Q10 from a network each, on predictor sets of their own (GenericHybridModel.jl:142-206)
   ext_chain_acts        hidden_layers = Chain(Dense(8, 6, relu)) under activation = tanh (NNModels.jl:145-219)
+  ext_extra_two_outputs extra_loss = (yhat, ps) -> (; c = 0.05 * mean(yhat.reco .* yhat.half) * ps.Q10[1] + 0.5 * mean((yhat.reco .- yhat.half) .^ 2)): an entry
+                        over two outputs of the model and a RAW global parameter (compute_loss.jl:31-34), one target, agg = sum
 Never part of the build or the tests; regenerate when the oracle changes."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -104,3 +106,14 @@ sc = ho.rbq10_spec((8, 6), "tanh", True); sc.layer_activations = ["tanh", "relu"
 tc = ho.init_theta(sc, 15, np.float32)
 lc, gc, _ = ho.loss_and_grad(sc, tc.astype(np.float64), X, f, y)
 write("chain_acts", ["model=rbq10", "hidden=8,6", "activation=tanh", "chain=Dense(8,6,relu)", "scale_nn_outputs=true"], tc, X, f, y, dict(loss=[lc], grad=gc, yhat=ho.forward(sc, tc.astype(np.float64), X, f)["reco"]))
+
+# extra_loss over two outputs of the two-output closure and the raw global parameter: the entry rides as one more output of the model's program
+from easyhybrid_jl_amd.program import trace_extra_loss_mixed, _identity_entry_program
+xfn = lambda yhat, ps: {"c": 0.05 * np.mean(yhat["reco"] * yhat["half"]) * ps.Q10[0] + 0.5 * np.mean((yhat["reco"] - yhat["half"]) ** 2)}
+bounds = {"Q10": (ho.RBQ10_PARAMS["Q10"][1], ho.RBQ10_PARAMS["Q10"][2])}
+progx, entx = trace_extra_loss_mixed(reco2, xfn, ["rb", "Q10"], ["ta"], ["reco"], ["Q10"], bounds)
+ho.program_mech("reco2_x", progx.as_dict(), None)
+sx = ho.HybridSpec(2, [8, 8], "reco2_x", dict(ho.RBQ10_PARAMS), ["rb"], ["Q10"], ["reco"], "tanh", True)
+ho.loss_program("xl_ident", _identity_entry_program().as_dict(), None)
+lx, gx, _ = ho.loss_and_grad(sx, t2.astype(np.float64), X, f, {"reco": y["reco"]}, extra=[(entx[0][1], "xl_ident", entx[0][2])])
+write("extra_two_outputs", ["model=reco2", "hidden=8,8", "activation=tanh", "scale_nn_outputs=true", "targets=reco", "extra=two_outputs"], t2, X, f, {"reco": y["reco"]}, dict(loss=[lx], grad=gx))
